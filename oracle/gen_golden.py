@@ -1,0 +1,277 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz by IMPORTING the
+reference (/root/reference/mpqe) in this container and running its own
+RGCNEncoderDecoder / RGCNConv / get_query_graph / DirectEncoder code on seeded
+synthetic inputs. The absent third-party deps are supplied by
+oracle/standins.py. The reference never travels: only inputs and expected
+outputs are written. Run:  python oracle/gen_golden.py   (needs /root/reference)
+
+Each fixture holds: the synthetic schema + grounded queries (JSON), the model
+config, every parameter, all integer tensors of the collation, x0, every layer
+output, the readout, train-form and eval-form scores, the margin loss and the
+gradient of every parameter.
+"""
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get('MPQE_REFERENCE', '/root/reference')
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def _load_reference():
+    if not os.path.isdir(os.path.join(REF, 'mpqe')):
+        raise SystemExit('reference not found at %s -- fixtures can only be '
+                         'regenerated where /root/reference exists' % REF)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, REF)
+    from oracle import standins
+    standins.install()
+    import mpqe.model as rmodel
+    import mpqe.data_utils as rdata
+    import mpqe.graph as rgraph
+    import mpqe.encoders as renc
+    return rmodel, rdata, rgraph, renc
+
+
+def _jsonable(o):
+    if isinstance(o, (tuple, list)):
+        return [_jsonable(x) for x in o]
+    if isinstance(o, (np.integer,)):
+        return int(o)
+    return o
+
+
+def build_reference_model(rmodel, rgraph, renc, schema, adj, D, cfg, seed):
+    """Mirror of the reference's start-up wiring (data_utils.py:18-37 load_graph,
+    utils.py:101-102 get_encoder depth 0, train.py:67-70) on synthetic data."""
+    torch.manual_seed(seed)
+    n_ent = schema.num_entities
+    node_map = torch.full((n_ent + 1,), -1, dtype=torch.long)
+    for m in schema.modes:
+        for i, n in enumerate(schema.ids[m].tolist()):
+            node_map[n] = i
+    feature_modules = {m: torch.nn.Embedding(len(schema.ids[m]) + 1, D) for m in schema.modes}
+    for m in schema.modes:
+        feature_modules[m].weight.data.normal_(0, 1. / D)
+    features = lambda nodes, mode: feature_modules[mode](node_map[nodes])
+    feature_dims = {m: D for m in schema.modes}
+    graph = rgraph.Graph(features, feature_dims, schema.relations, adj)
+    enc = renc.DirectEncoder(graph.features, feature_modules)
+    model = rmodel.RGCNEncoderDecoder(graph, enc, cfg['readout'], cfg['scatter_op'], 0,
+                                      cfg['weight_decay'], cfg['num_layers'],
+                                      cfg['shared_layers'], cfg['adaptive'])
+    if cfg.get('scale', 1.0) != 1.0:
+        # larger weights so that ReLU masks and max-readout ties are exercised
+        with torch.no_grad():
+            for p in model.layers.parameters():
+                p.mul_(cfg['scale'])
+    return model, graph, node_map
+
+
+def run_case(name, query_type, cfg, D=16, B=8, kg=('tiny',), seed=0):
+    rmodel, rdata, rgraph, renc = _load_reference()
+    from mpqe_amd import synthetic
+    n_ent, n_modes, n_rel = synthetic.KG_SHAPES[kg[0]] if isinstance(kg[0], str) else kg
+    schema = synthetic.make_schema(n_ent, n_modes, n_rel, seed=seed)
+    adj = synthetic.make_adjacency(schema, degree=2, seed=seed)
+    model, graph, node_map = build_reference_model(rmodel, rgraph, renc, schema, adj, D, cfg, seed)
+
+    rng = np.random.RandomState(1000 + seed)
+    my_formula = synthetic.sample_formula(schema, query_type, rng)
+    my_queries = synthetic.sample_queries(schema, my_formula, B, rng, n_neg=3, n_hard=2)
+    # the reference's own Query/Formula objects, built from the same tuples
+    queries = [rgraph.Query(q.query_graph, q.neg_samples, q.hard_neg_samples, 100, True)
+               for q in my_queries]
+    formula = queries[0].formula
+    assert all(q.formula == formula for q in queries)
+
+    anchor_ids, var_ids, qg = rdata.RGCNQueryDataset.get_query_graph(
+        formula, queries, model.rel_ids, model.mode_ids)
+
+    # ---- capture intermediates of one train-form forward
+    layer_outs = []
+    hooks = [l.register_forward_hook(lambda m, i, o: layer_outs.append(o.detach().clone()))
+             for l in set(model.layers)]
+    ro = {}
+    if isinstance(model.readout, torch.nn.Module):
+        hooks.append(model.readout.register_forward_hook(
+            lambda m, i, o: ro.__setitem__('out', o.detach().clone())))
+    else:
+        inner = model.readout
+
+        def wrapped(**kw):
+            o = inner(**kw)
+            ro['out'] = o.detach().clone()
+            return o
+        model.readout = wrapped
+    targets = [q.target_node for q in queries]
+    scores_pos = model.forward(formula, queries, targets, anchor_ids, var_ids, qg)
+    x0 = qg.x.detach().clone()
+    fwd_layers = [t.numpy() for t in layer_outs]
+    readout_out = ro['out'].numpy()
+    for h in hooks:
+        h.remove()
+    if not isinstance(model.readout, torch.nn.Module):
+        model.readout = inner
+
+    # ---- eval form: ragged negatives (model.py:454-460)
+    neg_lengths = [len(q.neg_samples) - (i % 2) for i, q in enumerate(queries)]
+    eval_negs = [n for q, l in zip(queries, neg_lengths) for n in q.neg_samples[:l]]
+    with torch.no_grad():
+        eval_scores = model.forward(formula, queries, targets, neg_nodes=eval_negs,
+                                    neg_lengths=neg_lengths)
+
+    # ---- margin loss with replayable negatives (model.py:464-494)
+    hard = bool(cfg.get('hard_negatives', False)) and 'inter' in query_type
+    random.seed(4242 + seed)
+    if hard:
+        neg_nodes = [random.choice(q.hard_neg_samples) for q in queries]
+    elif query_type == '1-chain':
+        neg_nodes = [random.choice(graph.full_lists[formula.target_mode]) for _ in queries]
+    else:
+        neg_nodes = [random.choice(q.neg_samples) for q in queries]
+    random.seed(4242 + seed)
+    model.zero_grad()
+    loss = model.margin_loss(formula, queries, anchor_ids, var_ids, qg, hard_negatives=hard)
+    loss.backward()
+    with torch.no_grad():
+        scores_neg = model.forward(formula, queries, neg_nodes, anchor_ids, var_ids, qg)
+
+    arrays = {}
+    for k, v in model.state_dict().items():
+        arrays['param/' + k] = v.detach().numpy()
+    for k, p in model.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        arrays['grad/' + k] = g.detach().numpy()
+    arrays.update({
+        'node_map': node_map.numpy(),
+        'anchor_ids': anchor_ids.numpy(), 'var_ids': var_ids.numpy(),
+        'edge_index': qg.edge_index.numpy(), 'edge_type': qg.edge_type.numpy(),
+        'batch': qg.batch.numpy(),
+        'x0': x0.numpy(), 'readout': readout_out,
+        'scores_pos': scores_pos.detach().numpy(), 'scores_neg': scores_neg.numpy(),
+        'eval_scores': eval_scores.numpy(),
+        'loss': np.array(loss.item(), dtype=np.float64),
+        'targets': np.array(targets, dtype=np.int64),
+        'neg_nodes': np.array(neg_nodes, dtype=np.int64),
+        'eval_negs': np.array(eval_negs, dtype=np.int64),
+        'neg_lengths': np.array(neg_lengths, dtype=np.int64),
+    })
+    for i, a in enumerate(fwd_layers):
+        arrays['layer_out/%d' % i] = a
+    meta = {
+        'name': name, 'query_type': query_type, 'cfg': cfg, 'D': D, 'B': B, 'seed': seed,
+        'hard_negatives': hard,
+        'schema': {'modes': schema.modes,
+                   'relations': {m: _jsonable(v) for m, v in schema.relations.items()},
+                   'ids': {m: schema.ids[m].tolist() for m in schema.modes},
+                   'num_entities': schema.num_entities},
+        'mode_weights_order': list(graph.mode_weights.keys()),
+        'num_relations': len(graph.rel_edges),
+        'mode_ids': model.mode_ids,
+        'rel_ids': [[list(k), v] for k, v in model.rel_ids.items()],
+        'formula_rels': _jsonable(formula.rels),
+        'queries': [{'graph': _jsonable(q.query_graph), 'neg': _jsonable(q.neg_samples),
+                     'hard': _jsonable(q.hard_neg_samples)} for q in my_queries],
+        'full_list_target_mode': _jsonable(graph.full_lists[formula.target_mode]),
+        'n_layer_calls': len(fwd_layers),
+    }
+    arrays['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **arrays)
+    return loss.item()
+
+
+def run_conv_case(name, n_nodes, n_edges, R, D_in, D_out, seed, isolated=True):
+    """The reference's RGCNConv alone (model.py:206-310) on a random
+    non-template multigraph: duplicate edges, self loops, isolated nodes and
+    unused relations all occur."""
+    rmodel, _, _, _ = _load_reference()
+    torch.manual_seed(seed)
+    conv = rmodel.RGCNConv(D_in, D_out, R, 0)
+    with torch.no_grad():
+        for p in conv.parameters():
+            p.mul_(4.0)
+    g = torch.Generator().manual_seed(seed + 1)
+    hi = n_nodes - (n_nodes // 4 if isolated else 0)   # top quarter of rows: no edges
+    src = torch.randint(0, hi, (n_edges,), generator=g)
+    dst = torch.randint(0, hi, (n_edges,), generator=g)
+    used = max(1, R - 2)                                # last relations unused
+    et = torch.randint(0, used, (n_edges,), generator=g)
+    if n_edges >= 4:
+        src[1], dst[1], et[1] = src[0], dst[0], et[0]   # exact duplicate edge
+        dst[2] = src[2]                                 # self loop
+    x = torch.randn(n_nodes, D_in, generator=g, requires_grad=True)
+    ei = torch.stack([src, dst])
+    out = conv(x, ei, et)
+    gout = torch.randn(out.shape, generator=g)
+    out.backward(gout)
+    arrays = {'x': x.detach().numpy(), 'edge_index': ei.numpy(), 'edge_type': et.numpy(),
+              'out': out.detach().numpy(), 'grad_out': gout.numpy(),
+              'grad_x': x.grad.numpy(),
+              'basis': conv.basis.detach().numpy(), 'root': conv.root.detach().numpy(),
+              'bias': conv.bias.detach().numpy(),
+              'grad_basis': conv.basis.grad.numpy(), 'grad_root': conv.root.grad.numpy(),
+              'grad_bias': conv.bias.grad.numpy()}
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **arrays)
+
+
+QUERY_TYPES = ['1-chain', '2-chain', '3-chain', '2-inter', '3-inter',
+               '3-inter_chain', '3-chain_inter']
+READOUTS = ['sum', 'max', 'mp', 'mlp', 'targetmlp', 'concat']
+
+
+def case_matrix():
+    """7 query types x 6 readouts; the (adaptive / fixed L, shared / unshared,
+    scatter op, hard negatives, scale) variant rotates so that every value is
+    met by every query type and every readout at least once."""
+    variants = [
+        dict(adaptive=True, num_layers=3, shared_layers=True),
+        dict(adaptive=False, num_layers=2, shared_layers=False),
+        dict(adaptive=False, num_layers=3, shared_layers=False),
+        dict(adaptive=True, num_layers=3, shared_layers=False),
+        dict(adaptive=False, num_layers=3, shared_layers=True),
+    ]
+    ops = ['add', 'max', 'mean']
+    cases = []
+    k = 0
+    for qi, qt in enumerate(QUERY_TYPES):
+        for ri, ro in enumerate(READOUTS):
+            v = dict(variants[(qi + ri) % len(variants)])
+            v.update(readout=ro, scatter_op=ops[(qi + 2 * ri) % 3],
+                     weight_decay=1e-3 if ri % 2 == 0 else 0.0,
+                     hard_negatives=(qi + ri) % 2 == 1,
+                     scale=4.0 if (qi + ri) % 3 else 1.0)
+            if ro == 'concat':
+                # the reference's concat MLP is sized for num_layers blocks
+                # (model.py:370-371): with adaptive=True and a diameter below
+                # num_layers its Linear raises a shape error, so concat is
+                # only generated in the fixed-L form.
+                v['adaptive'] = False
+            name = 'enc_%s_%s' % (qt.replace('-', ''), ro)
+            cases.append((name, qt, v, 16 if k % 2 == 0 else 32, k))
+            k += 1
+    return cases
+
+
+def main():
+    for name, qt, cfg, D, k in case_matrix():
+        loss = run_case(name, qt, cfg, D=D, B=8, seed=k)
+        print('%-36s D=%d loss=%.6f' % (name, D, loss))
+    run_conv_case('conv_random_a', n_nodes=40, n_edges=150, R=7, D_in=16, D_out=16, seed=1)
+    run_conv_case('conv_random_b', n_nodes=9, n_edges=3, R=5, D_in=32, D_out=32, seed=2)
+    run_conv_case('conv_random_c', n_nodes=300, n_edges=2000, R=12, D_in=64, D_out=64, seed=3)
+    run_conv_case('conv_noedges', n_nodes=6, n_edges=0, R=3, D_in=16, D_out=16, seed=4,
+                  isolated=False)
+    print('wrote fixtures to', OUT)
+
+
+if __name__ == '__main__':
+    main()

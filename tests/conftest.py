@@ -1,0 +1,89 @@
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+
+
+def _tuplify(o):
+    if isinstance(o, list):
+        return tuple(_tuplify(x) for x in o)
+    return o
+
+
+class GoldenCase(object):
+    """One fixture written by oracle/gen_golden.py, with the formula / queries
+    rebuilt as this package's harness types."""
+
+    def __init__(self, path):
+        from collections import OrderedDict
+        from mpqe_amd.graph import Formula, Query
+        z = np.load(path)
+        self.arrays = {k: z[k] for k in z.files if k != 'meta'}
+        self.meta = json.loads(bytes(z['meta']).decode())
+        m = self.meta
+        self.name = m['name']
+        self.cfg = m['cfg']
+        self.D, self.B = m['D'], m['B']
+        self.query_type = m['query_type']
+        self.relations = OrderedDict(
+            (mode, [tuple(x) for x in m['schema']['relations'][mode]])
+            for mode in m['schema']['modes'])
+        self.modes = m['schema']['modes']
+        self.ids = {k: np.array(v, dtype=np.int64) for k, v in m['schema']['ids'].items()}
+        self.num_entities = m['schema']['num_entities']
+        self.mode_weights_order = m['mode_weights_order']
+        self.mode_ids = m['mode_ids']
+        self.rel_ids = {tuple(k): v for k, v in m['rel_ids']}
+        self.formula = Formula(self.query_type, _tuplify(m['formula_rels']))
+        self.queries = [Query(_tuplify(q['graph']), q['neg'], q['hard'], keep_graph=True)
+                        for q in m['queries']]
+        self.hard_negatives = m['hard_negatives']
+
+    def params(self):
+        import torch
+        return {k[len('param/'):]: torch.from_numpy(v.copy())
+                for k, v in self.arrays.items() if k.startswith('param/')}
+
+    def grads(self):
+        return {k[len('grad/'):]: v for k, v in self.arrays.items() if k.startswith('grad/')}
+
+    def layer_outs(self):
+        return [self.arrays['layer_out/%d' % i] for i in range(self.meta['n_layer_calls'])]
+
+
+def golden_paths(prefix):
+    return sorted(glob.glob(os.path.join(GOLDEN, prefix + '*.npz')))
+
+
+def pytest_generate_tests(metafunc):
+    if 'enc_case' in metafunc.fixturenames:
+        paths = golden_paths('enc_')
+        metafunc.parametrize('enc_case', paths, ids=[os.path.basename(p)[:-4] for p in paths],
+                             indirect=True)
+    if 'conv_case' in metafunc.fixturenames:
+        paths = golden_paths('conv_')
+        metafunc.parametrize('conv_case', paths, ids=[os.path.basename(p)[:-4] for p in paths],
+                             indirect=True)
+
+
+@pytest.fixture
+def enc_case(request):
+    return GoldenCase(request.param)
+
+
+@pytest.fixture
+def conv_case(request):
+    z = np.load(request.param)
+    return {k: z[k] for k in z.files}
