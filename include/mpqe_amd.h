@@ -1,0 +1,202 @@
+/* mpqe_amd.h -- C ABI of the MI355X-native MPQE R-GCN query-graph encoder.
+ *
+ * The reference (dfdazac/mpqe) is pure Python and has no FFI layer: its
+ * boundary for this path is the nn.Module surface of mpqe/model.py plus the
+ * torch_scatter / PyTorch Geometric calls it makes. Each entry point below
+ * names the reference lines whose arithmetic it replaces. The Python mirror
+ * (mpqe_amd/model.py, encoders.py, data_utils.py) binds these with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host;
+ *   - floats are fp32, contiguous row-major; indices are int64 like the
+ *     reference's LongTensors; sizes are int64_t;
+ *   - the caller owns every buffer, including workspaces (query the size
+ *     first); the library never allocates and holds no global mutable state,
+ *     so it is re-entrant per stream;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream);
+ *   - every function returns MPQE_OK or a negative MPQE_ERR_* code and never
+ *     synchronises. Data-dependent faults (an index outside its table) cannot
+ *     be seen from the host without a sync: kernels then skip the access and
+ *     OR a MPQE_FLAG_* bit into the caller's `err` word (int32 in HBM, may be
+ *     NULL); the host mirror raises IndexError from it like the reference's
+ *     index_select would.
+ */
+#ifndef MPQE_AMD_H
+#define MPQE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPQE_OK 0
+#define MPQE_ERR_INVALID_ARG (-1)    /* null pointer, negative size, bad enum          */
+#define MPQE_ERR_UNSUPPORTED (-2)    /* shape outside what the kernels cover           */
+#define MPQE_ERR_WORKSPACE (-3)      /* workspace smaller than the *_workspace_bytes() */
+#define MPQE_ERR_LAUNCH (-4)         /* hipGetLastError() != hipSuccess after launch   */
+
+#define MPQE_FLAG_BAD_NODE_ID 1      /* entity id outside node_map / maps to -1        */
+#define MPQE_FLAG_BAD_EDGE 2         /* edge endpoint outside [0, num_nodes)           */
+#define MPQE_FLAG_BAD_RELATION 4     /* edge type outside [0, num_relations)           */
+#define MPQE_FLAG_BAD_INDEX 8        /* scatter index outside [0, dim_size)            */
+
+/* query templates, reference data_utils.py:325-362 */
+enum {
+    MPQE_Q_1CHAIN = 0, MPQE_Q_2CHAIN = 1, MPQE_Q_3CHAIN = 2, MPQE_Q_2INTER = 3,
+    MPQE_Q_3INTER = 4, MPQE_Q_3INTER_CHAIN = 5, MPQE_Q_3CHAIN_INTER = 6, MPQE_Q_COUNT = 7
+};
+enum { MPQE_READOUT_SUM = 0, MPQE_READOUT_MAX = 1, MPQE_READOUT_TM = 2 };
+enum { MPQE_SCATTER_ADD = 0, MPQE_SCATTER_MAX = 1, MPQE_SCATTER_MEAN = 2 };
+#define MPQE_MAX_TEMPLATE_EDGES 3
+#define MPQE_MAX_TEMPLATE_NODES 4
+
+const char *mpqe_status_string(int status);
+int mpqe_abi_version(void);
+
+/* Static shape of one query template (host side, no GPU needed).
+ * reference: RGCNQueryDataset.query_edge_indices / query_diameters /
+ * query_edge_label_idx / variable_node_idx, data_utils.py:325-362. */
+typedef struct {
+    int32_t num_anchors, num_vars, num_nodes, num_edges, diameter;
+    int32_t src[MPQE_MAX_TEMPLATE_EDGES];      /* edge source row inside a graph     */
+    int32_t dst[MPQE_MAX_TEMPLATE_EDGES];      /* edge destination row               */
+    int32_t rel_label[MPQE_MAX_TEMPLATE_EDGES];/* index into Formula.get_rels()      */
+    int32_t var_node[MPQE_MAX_TEMPLATE_NODES]; /* index into Formula.get_nodes()     */
+} mpqe_template_t;
+int mpqe_template_info(int query_type, mpqe_template_t *out_host);
+
+/* ---- (a1) collation ------------------------------------------------------------------
+ * reference: RGCNQueryDataset.get_query_graph data_utils.py:394-405 and PyG
+ * Batch.from_data_list: B replicas of one template.
+ *   edge_index[0, b*E+e] = src[e] + b*N     edge_index[1, b*E+e] = dst[e] + b*N
+ *   edge_type[b*E+e] = edge_type_host[e]    batch[b*N+n] = b                        */
+int mpqe_collate_template(int query_type, int64_t batch_size,
+                          const int64_t *edge_type_host /*[E]*/,
+                          int64_t *edge_index /*[2, B*E]*/, int64_t *edge_type /*[B*E]*/,
+                          int64_t *batch /*[B*N]*/, void *stream);
+
+/* ---- (a2, a3) entity embedding gather + L2 normalise -------------------------------------
+ * reference: DirectEncoder.forward encoders.py:40-43 with the features closure
+ * data_utils.py:35 (row = node_map[id]; v = table[row]; y = v / ||v||_2, no eps), written
+ * where RGCNEncoderDecoder.forward puts it (model.py:418-420):
+ *   out[i*out_row_stride + 0..dim) = y_i.   inv_norm[i] = 1/||v_i|| (optional, for bwd). */
+int mpqe_embed_l2norm_fwd(const float *table, int64_t table_rows, int64_t dim,
+                          const int64_t *node_map, int64_t node_map_len,
+                          const int64_t *ids, int64_t n,
+                          float *out, int64_t out_row_stride, float *inv_norm /*[n] or NULL*/,
+                          int32_t *err, void *stream);
+/* grad_table[row_i] += (g_i - y_i (y_i . g_i)) / ||v_i||   (fp32 atomics on duplicates) */
+int mpqe_embed_l2norm_bwd(const float *grad_out, int64_t grad_row_stride,
+                          const float *table, int64_t table_rows, int64_t dim,
+                          const int64_t *node_map, int64_t node_map_len,
+                          const int64_t *ids, int64_t n,
+                          float *grad_table /*[table_rows, dim], accumulated into*/,
+                          int32_t *err, void *stream);
+/* variable rows: out[(b*N + A + k)*dim ..] = mode_emb[var_ids[k]] for every b
+ * reference: model.py:421. */
+int mpqe_var_rows_fwd(const float *mode_emb, int64_t num_modes, int64_t dim,
+                      const int64_t *var_ids /*[V]*/, int64_t num_vars,
+                      int64_t batch_size, int64_t num_nodes, int64_t num_anchors,
+                      float *x /*[B*N, dim]*/, int32_t *err, void *stream);
+/* grad_mode_emb[var_ids[k]] += sum_b grad_x[(b*N + A + k)] (deterministic order) */
+int mpqe_var_rows_bwd(const float *grad_x, int64_t num_modes, int64_t dim,
+                      const int64_t *var_ids, int64_t num_vars,
+                      int64_t batch_size, int64_t num_nodes, int64_t num_anchors,
+                      float *grad_mode_emb, int32_t *err, void *stream);
+
+/* ---- (a4) R-GCN layer -------------------------------------------------------------------
+ * reference: RGCNConv.forward/message/update model.py:269-305 with PyG propagate +
+ * torch_scatter.scatter_add ('add' aggregation, edge_norm None):
+ *   out[i] = sum_{e: dst_e = i} x[src_e] . basis[type_e]  +  x[i] . root  +  bias
+ * relu != 0 additionally applies the F.relu the caller puts after all but the last layer
+ * (model.py:437).
+ *
+ * TEMPLATE form: the batch is B replicas of one template (row = b*N + n). The neighbour sum
+ * runs inside the MFMA K loop: for node slot n with in-edges e1..ek the tile computes
+ * [x[:,src_e1] | ... | x[:,n]] . [basis[r_e1]; ...; root], so nothing is scattered and no
+ * [B*E, D, D] weight copy (model.py:292-293) exists.                                        */
+int mpqe_rgcn_template_fwd(int query_type, int64_t batch_size,
+                           const int64_t *edge_type_host /*[E] relation id per template edge*/,
+                           const float *x /*[B*N, dim_in]*/,
+                           const float *basis /*[R, dim_in, dim_out]*/, int64_t num_relations,
+                           const float *root /*[dim_in, dim_out]*/, const float *bias /*[dim_out] or NULL*/,
+                           int64_t dim_in, int64_t dim_out, int relu,
+                           float *out /*[B*N, dim_out]*/, void *stream);
+size_t mpqe_rgcn_template_bwd_workspace_bytes(int query_type, int64_t batch_size,
+                                              int64_t dim_in, int64_t dim_out);
+/* grad_out is d loss / d out (post-ReLU when relu != 0; `out` is then needed for the mask).
+ * grad_x is overwritten; grad_basis / grad_root / grad_bias are ACCUMULATED into (dense, like
+ * the reference's autograd). Any of the three may be NULL to skip it. Deterministic.        */
+int mpqe_rgcn_template_bwd(int query_type, int64_t batch_size, const int64_t *edge_type_host,
+                           const float *x, const float *out, const float *grad_out,
+                           const float *basis, int64_t num_relations, const float *root,
+                           int64_t dim_in, int64_t dim_out, int relu,
+                           float *grad_x, float *grad_basis, float *grad_root, float *grad_bias,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
+/* GENERAL form: arbitrary edge_index / edge_type (duplicates, self loops, isolated nodes,
+ * unused relations). A plan sorts the edges once per graph: by relation for the grouped
+ * MFMA GEMM, by destination (forward) and by source (backward) for the segmented sums.    */
+size_t mpqe_rgcn_plan_bytes(int64_t num_nodes, int64_t num_edges, int64_t num_relations);
+size_t mpqe_rgcn_plan_workspace_bytes(int64_t num_nodes, int64_t num_edges, int64_t num_relations);
+int mpqe_rgcn_plan_build(const int64_t *edge_index /*[2, E]*/, const int64_t *edge_type /*[E]*/,
+                         int64_t num_nodes, int64_t num_edges, int64_t num_relations,
+                         void *plan, size_t plan_bytes, void *workspace, size_t workspace_bytes,
+                         int32_t *err, void *stream);
+size_t mpqe_rgcn_general_workspace_bytes(int64_t num_nodes, int64_t num_edges, int64_t num_relations,
+                                         int64_t dim_in, int64_t dim_out, int backward);
+int mpqe_rgcn_general_fwd(const void *plan, int64_t num_nodes, int64_t num_edges, int64_t num_relations,
+                          const float *x, const float *basis, const float *root, const float *bias,
+                          int64_t dim_in, int64_t dim_out, int relu, float *out,
+                          void *workspace, size_t workspace_bytes, void *stream);
+int mpqe_rgcn_general_bwd(const void *plan, int64_t num_nodes, int64_t num_edges, int64_t num_relations,
+                          const float *x, const float *out, const float *grad_out,
+                          const float *basis, const float *root,
+                          int64_t dim_in, int64_t dim_out, int relu,
+                          float *grad_x, float *grad_basis, float *grad_root, float *grad_bias,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- (a5) readouts ----------------------------------------------------------------------
+ * Regular form for template batches (batch_idx = b repeated N):
+ *   SUM  reference sum_readout model.py:380-381   out[b] = sum_n h[b*N+n]
+ *   MAX  reference max_readout model.py:383-385   out[b] = max_n h[b*N+n]; argmax[b,d] = lowest n
+ *   TM   reference target_message_readout 387-398 out[b] = h[b*N + A]                        */
+int mpqe_readout_fwd(int kind, const float *h, int64_t batch_size, int64_t num_nodes,
+                     int64_t num_anchors, int64_t dim, float *out /*[B, dim]*/,
+                     int32_t *argmax /*[B, dim], MAX only, may be NULL*/, void *stream);
+int mpqe_readout_bwd(int kind, const float *grad_out /*[B, dim]*/, const int32_t *argmax,
+                     int64_t batch_size, int64_t num_nodes, int64_t num_anchors, int64_t dim,
+                     float *grad_h /*[B*N, dim], overwritten*/, void *stream);
+/* torch_scatter.scatter_add / scatter_max / scatter_mean along dim 0 (reference call sites
+ * model.py:351-355, 381, 384, 509, 547). index must be sorted non-decreasing? NO: any order.
+ * out[i] = reduce_{j: index[j] = i} src[j]; empty rows are 0; arg = lowest j on ties, -1 empty. */
+size_t mpqe_scatter_workspace_bytes(int64_t n_src, int64_t dim_size);
+int mpqe_scatter_fwd(int op, const float *src, const int64_t *index, int64_t n_src, int64_t dim,
+                     int64_t dim_size, float *out /*[dim_size, dim]*/, int64_t *arg /*MAX only*/,
+                     void *workspace, size_t workspace_bytes, int32_t *err, void *stream);
+int mpqe_scatter_bwd(int op, const float *grad_out, const int64_t *index, const int64_t *arg,
+                     int64_t n_src, int64_t dim, int64_t dim_size, float *grad_src,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- (a6, a7) scoring and loss ------------------------------------------------------------
+ * reference: F.cosine_similarity(q, t, dim=1) model.py:452, 458 (eps 1e-8 clamps each norm):
+ *   scores[i] = q[qrow(i)] . t[i] / (max(||q||, eps) * max(||t||, eps))
+ * q_row (may be NULL = identity) is the repeat_interleave(out, neg_lengths) map of model.py:456. */
+int mpqe_cosine_fwd(const float *q, const int64_t *q_row, const float *t, int64_t n, int64_t dim,
+                    float eps, float *scores, void *stream);
+/* grad_q is ACCUMULATED into when q_row != NULL (several i share a row; fp32 atomics),
+ * overwritten otherwise; grad_t overwritten. Either may be NULL.                          */
+int mpqe_cosine_bwd(const float *grad_scores, const float *q, const int64_t *q_row, const float *t,
+                    int64_t n, int64_t dim, float eps, float *grad_q, float *grad_t, void *stream);
+/* reference margin_loss model.py:483-485: loss = mean(clamp(margin - (pos - neg), min=0)).
+ * Deterministic single-block reduction. */
+int mpqe_hinge_fwd(const float *pos, const float *neg, int64_t n, float margin, float *loss, void *stream);
+int mpqe_hinge_bwd(const float *pos, const float *neg, int64_t n, float margin, const float *grad_loss /*[1]*/,
+                   float *grad_pos, float *grad_neg, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPQE_AMD_H */

@@ -1,0 +1,46 @@
+// Shared helpers for the gfx950 kernels. Wavefront = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/mpqe_amd.h"
+
+#define MPQE_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int mpqe_launch_status() {
+    return hipGetLastError() == hipSuccess ? MPQE_OK : MPQE_ERR_LAUNCH;
+}
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Host-side copy of the template tables (reference data_utils.py:325-362).
+struct TemplateDesc {
+    int A, V, N, E, diam;
+    int src[3], dst[3], rel_label[3], var_node[4];
+};
+
+static const TemplateDesc kTemplates[MPQE_Q_COUNT] = {
+    /* 1-chain       */ {1, 1, 2, 1, 1, {0, 0, 0}, {1, 0, 0}, {0, 0, 0}, {0, 0, 0, 0}},
+    /* 2-chain       */ {1, 2, 3, 2, 2, {0, 2, 0}, {2, 1, 0}, {1, 0, 0}, {0, 2, 0, 0}},
+    /* 3-chain       */ {1, 3, 4, 3, 3, {0, 3, 2}, {3, 2, 1}, {2, 1, 0}, {0, 2, 4, 0}},
+    /* 2-inter       */ {2, 1, 3, 2, 1, {0, 1, 0}, {2, 2, 0}, {0, 1, 0}, {0, 0, 0, 0}},
+    /* 3-inter       */ {3, 1, 4, 3, 1, {0, 1, 2}, {3, 3, 3}, {0, 1, 2}, {0, 0, 0, 0}},
+    /* 3-inter_chain */ {2, 2, 4, 3, 2, {0, 1, 3}, {2, 3, 2}, {0, 2, 1}, {0, 3, 0, 0}},
+    /* 3-chain_inter */ {2, 2, 4, 3, 2, {0, 1, 3}, {3, 3, 2}, {1, 2, 0}, {0, 2, 0, 0}},
+};
+
+__device__ __forceinline__ void flag_error(int32_t *err, int32_t bit) {
+    if (err) atomicOr(err, bit);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}

@@ -1,0 +1,385 @@
+// R-GCN layer over a batch of B replicas of ONE query template (row = b*N + n).
+// reference: RGCNConv.forward/message/update, mpqe/model.py:269-305, applied to
+// the Batch built by data_utils.py:394-405.
+//
+// Because every graph shares the template, the neighbour aggregation is not a
+// scatter at all: for node slot n with in-edges e1..ek
+//     out[:, n, :] = [x[:, src_e1, :] | ... | x[:, src_ek, :] | x[:, n, :]]
+//                    . [basis[r_e1]; ...; basis[r_ek]; root]  + bias
+// i.e. a GEMM whose K dimension is the concatenation over incoming edges, so the
+// sum over neighbours happens inside the MFMA accumulator. bias and ReLU are
+// fused into the epilogue. Backward-x is the same on the reversed template with
+// W^T; the weight gradient is x_src^T . g_dst with the batch as K, split over
+// workgroups and reduced in a fixed order (no float atomics -> reproducible).
+#include "gemm_core.h"
+
+struct TmplArgs {
+    int N, E;
+    int src[3], dst[3];
+    long long rel[3];
+};
+
+// ------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void rgcn_tmpl_fwd_kernel(
+    TmplArgs tp, long long B, const float *__restrict__ x, const float *__restrict__ basis,
+    const float *__restrict__ root, const float *__restrict__ bias, int Din, int Dout, int relu,
+    float *__restrict__ out, int vec_x, int vec_w) {
+    __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
+    const int n = blockIdx.z;
+    const long long b0 = (long long)blockIdx.x * GT_BM;
+    const int n0 = blockIdx.y * GT_BN;
+    const int nsteps = (Din + GT_BK - 1) / GT_BK;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    for (int kb = 0; kb <= tp.E; ++kb) {
+        int s;
+        const float *W;
+        if (kb < tp.E) {
+            if (tp.dst[kb] != n) continue;
+            s = tp.src[kb];
+            W = basis + tp.rel[kb] * (long long)Din * Dout;
+        } else {
+            s = n;
+            W = root;
+        }
+        auto aload = [&](int r, int c, int step) -> f32x4 {
+            const long long b = b0 + r;
+            if (b >= B) return f32x4{0.f, 0.f, 0.f, 0.f};
+            const float *p = x + (b * tp.N + s) * (long long)Din;
+            return ld4_guard(p, step * GT_BK + c, Din, vec_x);
+        };
+        auto bload = [&](int k, int c, int step) -> f32x4 {
+            const int kk = step * GT_BK + k;
+            if (kk >= Din) return f32x4{0.f, 0.f, 0.f, 0.f};
+            return ld4_guard(W + (long long)kk * Dout, n0 + c, Dout, vec_w);
+        };
+        gemm_block<false, true>(acc, aload, bload, nsteps, smem);
+    }
+    const int col = n0 + acc_col();
+    if (col < Dout) {
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long b = b0 + acc_row(r);
+            if (b < B) {
+                float v = acc[r] + bv;
+                if (relu) v = v > 0.f ? v : 0.f;
+                out[(b * tp.N + n) * (long long)Dout + col] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ backward wrt x
+// grad_x[:, m, :] = sum_{e: src_e = m} gpre[:, dst_e, :] . basis[r_e]^T + gpre[:, m, :] . root^T
+// gpre = grad_out * (out > 0) when the layer applied ReLU.
+__global__ __launch_bounds__(256) void rgcn_tmpl_bwd_x_kernel(
+    TmplArgs tp, long long B, const float *__restrict__ g, const float *__restrict__ out,
+    const float *__restrict__ basis, const float *__restrict__ root, int Din, int Dout, int relu,
+    float *__restrict__ grad_x, int vec_g, int vec_w) {
+    __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
+    const int m = blockIdx.z;
+    const long long b0 = (long long)blockIdx.x * GT_BM;
+    const int n0 = blockIdx.y * GT_BN;               // column tile over Din
+    const int nsteps = (Dout + GT_BK - 1) / GT_BK;   // K runs over Dout
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    for (int kb = 0; kb <= tp.E; ++kb) {
+        int d;
+        const float *W;
+        if (kb < tp.E) {
+            if (tp.src[kb] != m) continue;
+            d = tp.dst[kb];
+            W = basis + tp.rel[kb] * (long long)Din * Dout;
+        } else {
+            d = m;
+            W = root;
+        }
+        auto aload = [&](int r, int c, int step) -> f32x4 {
+            const long long b = b0 + r;
+            if (b >= B) return f32x4{0.f, 0.f, 0.f, 0.f};
+            const long long off = (b * tp.N + d) * (long long)Dout;
+            f32x4 v = ld4_guard(g + off, step * GT_BK + c, Dout, vec_g);
+            if (relu) {
+                f32x4 o = ld4_guard(out + off, step * GT_BK + c, Dout, vec_g);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = o[q] > 0.f ? v[q] : 0.f;
+            }
+            return v;
+        };
+        // B[k][n] = W[n][k]: R-type image, tile row = output column n (over Din), contiguous in k
+        auto bload = [&](int r, int c, int step) -> f32x4 {
+            const int nn = n0 + r;
+            if (nn >= Din) return f32x4{0.f, 0.f, 0.f, 0.f};
+            return ld4_guard(W + (long long)nn * Dout, step * GT_BK + c, Dout, vec_w);
+        };
+        gemm_block<false, false>(acc, aload, bload, nsteps, smem);
+    }
+    const int col = n0 + acc_col();
+    if (col < Din) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long b = b0 + acc_row(r);
+            if (b < B) grad_x[(b * tp.N + m) * (long long)Din + col] = acc[r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ weight gradient
+// slot z < E : slab = sum_{b in chunk} x[b*N+src_z]^T (x) gpre[b*N+dst_z]      (-> basis[rel_z])
+// slot z = E : slab = sum_{q in chunk} x[q]^T (x) gpre[q], q over all B*N rows  (-> root)
+// One workgroup = one 64x64 tile of one K-chunk; slabs go to the workspace and are summed
+// in fixed order by rgcn_tmpl_reduce_w_kernel.
+struct WChunks {
+    int nch_edge, ch_edge;     // chunks per edge slot, rows per chunk
+    int nch_root, ch_root;
+};
+
+__global__ __launch_bounds__(256) void rgcn_tmpl_grad_w_kernel(
+    TmplArgs tp, WChunks wc, long long B, const float *__restrict__ x, const float *__restrict__ g,
+    const float *__restrict__ out, int Din, int Dout, int relu, float *__restrict__ slabs,
+    int vec_x, int vec_g) {
+    __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
+    const int z = blockIdx.z;
+    const int c = blockIdx.x;
+    const bool is_root = (z == tp.E);
+    const int nch = is_root ? wc.nch_root : wc.nch_edge;
+    if (c >= nch) return;
+    const int tiles_j = (Dout + GT_BN - 1) / GT_BN;
+    const int i0 = (blockIdx.y / tiles_j) * GT_BM;
+    const int j0 = (blockIdx.y % tiles_j) * GT_BN;
+    const long long count = is_root ? B * tp.N : B;
+    const long long ch = is_root ? wc.ch_root : wc.ch_edge;
+    const long long q0 = (long long)c * ch;
+    long long q1 = q0 + ch;
+    if (q1 > count) q1 = count;
+    const int nsteps = q1 > q0 ? (int)((q1 - q0 + GT_BK - 1) / GT_BK) : 0;
+    const long long xs = is_root ? 1 : tp.N, xo = is_root ? 0 : tp.src[z];
+    const long long gs = is_root ? 1 : tp.N, go = is_root ? 0 : tp.dst[z];
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    auto aload = [&](int k, int cc, int step) -> f32x4 {
+        const long long q = q0 + (long long)step * GT_BK + k;
+        if (q >= q1) return f32x4{0.f, 0.f, 0.f, 0.f};
+        return ld4_guard(x + (q * xs + xo) * (long long)Din, i0 + cc, Din, vec_x);
+    };
+    auto bload = [&](int k, int cc, int step) -> f32x4 {
+        const long long q = q0 + (long long)step * GT_BK + k;
+        if (q >= q1) return f32x4{0.f, 0.f, 0.f, 0.f};
+        const long long off = (q * gs + go) * (long long)Dout;
+        f32x4 v = ld4_guard(g + off, j0 + cc, Dout, vec_g);
+        if (relu) {
+            f32x4 o = ld4_guard(out + off, j0 + cc, Dout, vec_g);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) v[qq] = o[qq] > 0.f ? v[qq] : 0.f;
+        }
+        return v;
+    };
+    gemm_block<true, true>(acc, aload, bload, nsteps, smem);
+
+    const long long slab = is_root ? (long long)tp.E * wc.nch_edge + c : (long long)z * wc.nch_edge + c;
+    float *dst = slabs + slab * (long long)Din * Dout;
+    const int col = j0 + acc_col();
+    if (col < Dout) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = i0 + acc_row(r);
+            if (row < Din) dst[(long long)row * Dout + col] = acc[r];
+        }
+    }
+}
+
+// grad_basis[rel_z] += sum over (slots sharing rel_z, chunks) in fixed order; grad_root likewise.
+__global__ __launch_bounds__(256) void rgcn_tmpl_reduce_w_kernel(
+    TmplArgs tp, WChunks wc, int Din, int Dout, const float *__restrict__ slabs,
+    float *__restrict__ grad_basis, float *__restrict__ grad_root) {
+    const int z = blockIdx.y;
+    const long long elems = (long long)Din * Dout;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= elems) return;
+    if (z == tp.E) {
+        if (!grad_root) return;
+        float s = 0.f;
+        const float *p = slabs + (long long)tp.E * wc.nch_edge * elems + idx;
+        for (int c = 0; c < wc.nch_root; ++c) s += p[(long long)c * elems];
+        grad_root[idx] += s;
+        return;
+    }
+    if (!grad_basis) return;
+    for (int zz = 0; zz < z; ++zz)
+        if (tp.rel[zz] == tp.rel[z]) return;          // an earlier slot owns this relation
+    float s = 0.f;
+    for (int zz = z; zz < tp.E; ++zz) {
+        if (tp.rel[zz] != tp.rel[z]) continue;
+        const float *p = slabs + (long long)zz * wc.nch_edge * elems + idx;
+        for (int c = 0; c < wc.nch_edge; ++c) s += p[(long long)c * elems];
+    }
+    grad_basis[tp.rel[z] * elems + idx] += s;
+}
+
+// grad_bias[j] += sum_q gpre[q][j]: per-block partial column sums, then one block adds them up.
+#define BIAS_ROWS 64
+__global__ __launch_bounds__(256) void bias_partial_kernel(long long rows, const float *__restrict__ g,
+                                                           const float *__restrict__ out, int Dout, int relu,
+                                                           float *__restrict__ partial) {
+    const long long r0 = (long long)blockIdx.x * BIAS_ROWS;
+    long long r1 = r0 + BIAS_ROWS;
+    if (r1 > rows) r1 = rows;
+    for (int col = threadIdx.x; col < Dout; col += blockDim.x) {
+        float s = 0.f;
+        for (long long r = r0; r < r1; ++r) {
+            float v = g[r * Dout + col];
+            if (relu && !(out[r * Dout + col] > 0.f)) v = 0.f;
+            s += v;
+        }
+        partial[(long long)blockIdx.x * Dout + col] = s;
+    }
+}
+__global__ __launch_bounds__(256) void bias_final_kernel(int nblk, int Dout, const float *__restrict__ partial,
+                                                         float *__restrict__ grad_bias) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= Dout) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(long long)b * Dout + col];
+    grad_bias[col] += s;
+}
+
+// ------------------------------------------------------------------------------------ host side
+static int fill_tmpl(int query_type, const int64_t *edge_type_host, int64_t num_relations, TmplArgs *tp) {
+    if (query_type < 0 || query_type >= MPQE_Q_COUNT || !edge_type_host) return MPQE_ERR_INVALID_ARG;
+    const TemplateDesc &d = kTemplates[query_type];
+    tp->N = d.N;
+    tp->E = d.E;
+    for (int e = 0; e < 3; ++e) {
+        tp->src[e] = e < d.E ? d.src[e] : 0;
+        tp->dst[e] = e < d.E ? d.dst[e] : 0;
+        tp->rel[e] = e < d.E ? edge_type_host[e] : 0;
+        if (e < d.E && (edge_type_host[e] < 0 || edge_type_host[e] >= num_relations))
+            return MPQE_ERR_INVALID_ARG;
+    }
+    return MPQE_OK;
+}
+
+static WChunks plan_chunks(int64_t B, int N) {
+    auto pick = [](int64_t count, int max_chunks, int *nch, int *ch) {
+        int64_t n = (count + 127) / 128;
+        if (n < 1) n = 1;
+        if (n > max_chunks) n = max_chunks;
+        int64_t c = (count + n - 1) / n;
+        c = (c + GT_BK - 1) / GT_BK * GT_BK;
+        if (c < GT_BK) c = GT_BK;
+        n = (count + c - 1) / c;
+        if (n < 1) n = 1;
+        *nch = (int)n;
+        *ch = (int)c;
+    };
+    WChunks w;
+    pick(B, 16, &w.nch_edge, &w.ch_edge);
+    pick(B * N, 32, &w.nch_root, &w.ch_root);
+    return w;
+}
+
+extern "C" int mpqe_template_info(int query_type, mpqe_template_t *o) {
+    if (query_type < 0 || query_type >= MPQE_Q_COUNT || !o) return MPQE_ERR_INVALID_ARG;
+    const TemplateDesc &d = kTemplates[query_type];
+    o->num_anchors = d.A;
+    o->num_vars = d.V;
+    o->num_nodes = d.N;
+    o->num_edges = d.E;
+    o->diameter = d.diam;
+    for (int e = 0; e < 3; ++e) {
+        o->src[e] = d.src[e];
+        o->dst[e] = d.dst[e];
+        o->rel_label[e] = d.rel_label[e];
+    }
+    for (int v = 0; v < 4; ++v) o->var_node[v] = d.var_node[v];
+    return MPQE_OK;
+}
+
+extern "C" int mpqe_rgcn_template_fwd(int query_type, int64_t B, const int64_t *edge_type_host,
+                                      const float *x, const float *basis, int64_t R, const float *root,
+                                      const float *bias, int64_t Din, int64_t Dout, int relu, float *out,
+                                      void *stream) {
+    TmplArgs tp;
+    int st = fill_tmpl(query_type, edge_type_host, R, &tp);
+    if (st) return st;
+    if (!x || !basis || !root || !out || B < 0 || Din <= 0 || Dout <= 0) return MPQE_ERR_INVALID_ARG;
+    if (Din > (1 << 20) || Dout > (1 << 20)) return MPQE_ERR_UNSUPPORTED;
+    if (B == 0) return MPQE_OK;
+    dim3 grid((unsigned)((B + GT_BM - 1) / GT_BM), (unsigned)((Dout + GT_BN - 1) / GT_BN), tp.N);
+    hipLaunchKernelGGL(rgcn_tmpl_fwd_kernel, grid, dim3(256), 0, as_stream(stream), tp, (long long)B, x, basis,
+                       root, bias, (int)Din, (int)Dout, relu, out, (int)ptr_vec_ok(x, Din),
+                       (int)(ptr_vec_ok(basis, Dout) && ptr_vec_ok(root, Dout) && (Din * Dout) % 4 == 0));
+    return mpqe_launch_status();
+}
+
+static size_t tmpl_slab_floats(const TmplArgs &tp, const WChunks &w, int64_t Din, int64_t Dout) {
+    return (size_t)(tp.E * w.nch_edge + w.nch_root) * (size_t)Din * (size_t)Dout;
+}
+
+extern "C" size_t mpqe_rgcn_template_bwd_workspace_bytes(int query_type, int64_t B, int64_t Din, int64_t Dout) {
+    if (query_type < 0 || query_type >= MPQE_Q_COUNT || B < 0) return 0;
+    const TemplateDesc &d = kTemplates[query_type];
+    TmplArgs tp;
+    tp.N = d.N;
+    tp.E = d.E;
+    WChunks w = plan_chunks(B, d.N);
+    size_t rows = (size_t)B * d.N;
+    size_t nblk = (rows + BIAS_ROWS - 1) / BIAS_ROWS;
+    return align_up(tmpl_slab_floats(tp, w, Din, Dout) * 4, 256) + align_up(nblk * Dout * 4, 256) + 256;
+}
+
+extern "C" int mpqe_rgcn_template_bwd(int query_type, int64_t B, const int64_t *edge_type_host, const float *x,
+                                      const float *out, const float *grad_out, const float *basis, int64_t R,
+                                      const float *root, int64_t Din, int64_t Dout, int relu, float *grad_x,
+                                      float *grad_basis, float *grad_root, float *grad_bias, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+    TmplArgs tp;
+    int st = fill_tmpl(query_type, edge_type_host, R, &tp);
+    if (st) return st;
+    if (!x || !grad_out || !basis || !root || B < 0 || Din <= 0 || Dout <= 0) return MPQE_ERR_INVALID_ARG;
+    if (relu && !out) return MPQE_ERR_INVALID_ARG;
+    if (B == 0) return MPQE_OK;
+    hipStream_t s = as_stream(stream);
+    const int vec_w = ptr_vec_ok(basis, Dout) && ptr_vec_ok(root, Dout) && (Din * Dout) % 4 == 0;
+    const int vec_g = ptr_vec_ok(grad_out, Dout) && (!relu || ptr_vec_ok(out, Dout));
+    if (grad_x) {
+        dim3 grid((unsigned)((B + GT_BM - 1) / GT_BM), (unsigned)((Din + GT_BN - 1) / GT_BN), tp.N);
+        hipLaunchKernelGGL(rgcn_tmpl_bwd_x_kernel, grid, dim3(256), 0, s, tp, (long long)B, grad_out, out, basis,
+                           root, (int)Din, (int)Dout, relu, grad_x, vec_g, vec_w);
+    }
+    if (grad_basis || grad_root || grad_bias) {
+        if (workspace_bytes < mpqe_rgcn_template_bwd_workspace_bytes(query_type, B, Din, Dout) || !workspace)
+            return MPQE_ERR_WORKSPACE;
+        WChunks w = plan_chunks(B, tp.N);
+        float *slabs = reinterpret_cast<float *>(workspace);
+        float *bias_part = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) +
+                                                     align_up(tmpl_slab_floats(tp, w, Din, Dout) * 4, 256));
+        if (grad_basis || grad_root) {
+            const int tiles = (int)(((Din + GT_BM - 1) / GT_BM) * ((Dout + GT_BN - 1) / GT_BN));
+            const int maxch = w.nch_root > w.nch_edge ? w.nch_root : w.nch_edge;
+            dim3 grid(maxch, tiles, tp.E + 1);
+            hipLaunchKernelGGL(rgcn_tmpl_grad_w_kernel, grid, dim3(256), 0, s, tp, w, (long long)B, x, grad_out,
+                               out, (int)Din, (int)Dout, relu, slabs, (int)ptr_vec_ok(x, Din), vec_g);
+            const long long elems = (long long)Din * Dout;
+            dim3 rgrid((unsigned)((elems + 255) / 256), tp.E + 1);
+            hipLaunchKernelGGL(rgcn_tmpl_reduce_w_kernel, rgrid, dim3(256), 0, s, tp, w, (int)Din, (int)Dout,
+                               slabs, grad_basis, grad_root);
+        }
+        if (grad_bias) {
+            const long long rows = (long long)B * tp.N;
+            const int nblk = (int)((rows + BIAS_ROWS - 1) / BIAS_ROWS);
+            hipLaunchKernelGGL(bias_partial_kernel, dim3(nblk), dim3(256), 0, s, rows, grad_out, out, (int)Dout,
+                               relu, bias_part);
+            hipLaunchKernelGGL(bias_final_kernel, dim3((unsigned)((Dout + 255) / 256)), dim3(256), 0, s, nblk,
+                               (int)Dout, bias_part, grad_bias);
+        }
+    }
+    return mpqe_launch_status();
+}

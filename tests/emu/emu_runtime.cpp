@@ -1,0 +1,168 @@
+// TEST INFRASTRUCTURE ONLY -- fiber scheduler behind tests/emu/include/hip/hip_runtime.h.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <ucontext.h>
+
+#include <vector>
+
+emu_uint3 threadIdx, blockIdx;
+dim3 blockDim, gridDim;
+
+namespace emu {
+namespace {
+struct Fiber {
+    ucontext_t ctx;
+    char *stack = nullptr;
+    unsigned tid = 0;
+    bool done = false;
+};
+constexpr size_t kStack = 256 * 1024;
+ucontext_t g_main;
+std::vector<Fiber> g_fibers;
+Fiber *g_cur = nullptr;
+const std::function<void()> *g_body = nullptr;
+int g_alive = 0, g_block_gen = 0, g_block_arrived = 0;
+long g_events = 0;
+constexpr int kMaxWaves = 16;
+int g_wave_alive[kMaxWaves], g_wave_gen[kMaxWaves], g_wave_arrived[kMaxWaves];
+float g_xa[kMaxWaves][64], g_xb[kMaxWaves][64];
+
+void set_tid(unsigned tid) {
+    threadIdx.x = tid % blockDim.x;
+    threadIdx.y = (tid / blockDim.x) % blockDim.y;
+    threadIdx.z = tid / (blockDim.x * blockDim.y);
+}
+void yield() { swapcontext(&g_cur->ctx, &g_main); }
+void trampoline() {
+    (*g_body)();
+    g_cur->done = true;
+    yield();
+}
+void wave_barrier() {
+    const int w = g_cur->tid / 64;
+    const int gen = g_wave_gen[w];
+    ++g_events;
+    if (++g_wave_arrived[w] >= g_wave_alive[w]) {
+        g_wave_arrived[w] = 0;
+        g_wave_gen[w]++;
+    } else {
+        while (g_wave_gen[w] == gen) yield();
+    }
+}
+}  // namespace
+
+void block_barrier() {
+    const int gen = g_block_gen;
+    ++g_events;
+    if (++g_block_arrived >= g_alive) {
+        g_block_arrived = 0;
+        g_block_gen++;
+    } else {
+        while (g_block_gen == gen) yield();
+    }
+}
+
+float wave_exchange(float v, int arg, int mode, int width) {
+    const int w = g_cur->tid / 64, lane = g_cur->tid % 64;
+    g_xa[w][lane] = v;
+    wave_barrier();
+    int src;
+    if (mode == 0) src = lane ^ arg;
+    else if (mode == 1) src = lane + arg;
+    else src = (lane / width) * width + (arg % width);
+    if (mode != 2 && (src / width != lane / width || src >= 64 || src < 0)) src = lane;
+    float r = g_xa[w][src];
+    wave_barrier();
+    return r;
+}
+
+void mfma_32x32x2(float a, float b, float *c) {
+    const int w = g_cur->tid / 64, lane = g_cur->tid % 64;
+    g_xa[w][lane] = a;
+    g_xb[w][lane] = b;
+    wave_barrier();
+    const int col = lane & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float d = c[r];
+        d = fmaf(g_xa[w][row], g_xb[w][col], d);            // k = 0
+        d = fmaf(g_xa[w][row + 32], g_xb[w][col + 32], d);  // k = 1
+        c[r] = d;
+    }
+    wave_barrier();
+}
+
+void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
+    const unsigned nthreads = block.x * block.y * block.z;
+    if (nthreads == 0 || nthreads > 1024) {
+        fprintf(stderr, "emu: bad block size %u\n", nthreads);
+        abort();
+    }
+    if (g_fibers.size() < nthreads) {
+        size_t old = g_fibers.size();
+        g_fibers.resize(nthreads);
+        for (size_t i = old; i < nthreads; ++i) g_fibers[i].stack = (char *)malloc(kStack);
+    }
+    blockDim = block;
+    gridDim = grid;
+    g_body = &body;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                blockIdx.x = bx;
+                blockIdx.y = by;
+                blockIdx.z = bz;
+                g_alive = (int)nthreads;
+                g_block_gen = g_block_arrived = 0;
+                for (int w = 0; w < kMaxWaves; ++w) {
+                    int lo = w * 64, hi = lo + 64;
+                    g_wave_alive[w] = (int)nthreads > lo ? ((int)nthreads < hi ? (int)nthreads - lo : 64) : 0;
+                    g_wave_gen[w] = g_wave_arrived[w] = 0;
+                }
+                for (unsigned t = 0; t < nthreads; ++t) {
+                    Fiber &f = g_fibers[t];
+                    f.tid = t;
+                    f.done = false;
+                    getcontext(&f.ctx);
+                    f.ctx.uc_stack.ss_sp = f.stack;
+                    f.ctx.uc_stack.ss_size = kStack;
+                    f.ctx.uc_link = &g_main;
+                    makecontext(&f.ctx, (void (*)())trampoline, 0);
+                }
+                int remaining = (int)nthreads;
+                while (remaining > 0) {
+                    int progressed = 0;
+                    const long ev0 = g_events;
+                    for (unsigned t = 0; t < nthreads; ++t) {
+                        Fiber &f = g_fibers[t];
+                        if (f.done) continue;
+                        g_cur = &f;
+                        set_tid(t);
+                        swapcontext(&g_main, &f.ctx);
+                        if (f.done) {
+                            --remaining;
+                            --g_alive;
+                            --g_wave_alive[t / 64];
+                            ++progressed;
+                            // a finished work-item may have been the last one others wait for
+                            if (g_alive > 0 && g_block_arrived >= g_alive) {
+                                g_block_arrived = 0;
+                                g_block_gen++;
+                            }
+                            int w = t / 64;
+                            if (g_wave_alive[w] > 0 && g_wave_arrived[w] >= g_wave_alive[w]) {
+                                g_wave_arrived[w] = 0;
+                                g_wave_gen[w]++;
+                            }
+                        }
+                    }
+                    if (!progressed && g_events == ev0) {
+                        fprintf(stderr, "emu: deadlock (divergent barrier?) in block (%u,%u,%u)\n", bx, by, bz);
+                        abort();
+                    }
+                }
+            }
+    g_body = nullptr;
+}
+}  // namespace emu
