@@ -1,0 +1,21 @@
+"""Loads the gfx950 C-ABI library. There is no CPU or PyTorch fallback: if the
+library is missing or lacks a symbol the import fails loudly."""
+import ctypes
+import os
+
+from . import _capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libmpqe_amd.so')
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                'mpqe_amd: %s not found. Build it with `python -m mpqe_amd.build` '
+                '(hipcc --offload-arch=gfx950). There is no fallback path.' % LIB_PATH)
+        _lib = _capi.bind(ctypes.CDLL(LIB_PATH))
+    return _lib

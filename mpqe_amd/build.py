@@ -1,0 +1,59 @@
+"""Builds mpqe_amd/lib/libmpqe_amd.so: every .hip source under mpqe_amd/csrc compiled by
+hipcc for gfx950 (MI355X) only and linked into one C-ABI shared library. hipcc
+cross-compiles without a GPU, so this also runs in the authoring container.
+    python -m mpqe_amd.build [--force]
+"""
+import glob
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+SRC = os.path.join(PKG, 'csrc')
+LIB_DIR = os.path.join(PKG, 'lib')
+LIB = os.path.join(LIB_DIR, 'libmpqe_amd.so')
+OBJ_DIR = os.path.join(PKG, 'lib', 'obj')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+ARCH = 'gfx950'
+FLAGS = ['--offload-arch=' + ARCH, '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result',
+         '-I' + os.path.join(ROOT, 'include')]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    srcs = sorted(glob.glob(os.path.join(SRC, '*.hip')))
+    hdrs = glob.glob(os.path.join(SRC, '*.h')) + [os.path.join(ROOT, 'include', 'mpqe_amd.h')]
+    if not srcs:
+        raise RuntimeError('no HIP sources under %s' % SRC)
+    if not os.path.exists(HIPCC):
+        raise RuntimeError('hipcc not found at %s' % HIPCC)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    jobs = []
+    objs = []
+    for s in srcs:
+        o = os.path.join(OBJ_DIR, os.path.basename(s)[:-4] + '.o')
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            jobs.append([HIPCC] + FLAGS + ['-c', s, '-o', o])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(LIB, objs):
+        run([HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC'] + objs + ['-o', LIB])
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,518 @@
+// R-GCN layer on ARBITRARY graphs (the inner boundary RGCNConv.forward(x, edge_index,
+// edge_type), reference mpqe/model.py:269-305): duplicate edges, self loops, isolated
+// nodes, unused relations.
+//
+//   plan     sort edges once per graph (rocPRIM LSD radix sort, stable):
+//              by relation   -> message slots p in [0,E), grouped so that one MFMA tile
+//                               multiplies 64 gathered rows by ONE relation matrix;
+//                               slots [E, E+Nn) are the self/root term of every node
+//              by destination-> CSR of message slots per output row   (forward sum)
+//              by source     -> CSR of message slots per input row    (backward sum)
+//   forward  msg[p] = x[row(p)] . W[rel(p)]      grouped gather-GEMM, fp32 MFMA
+//            out[i] = act(bias + msg[E+i] + sum_{p in CSR_dst(i)} msg[p])
+//                                                destination-sorted segmented sum: every
+//                                                row is read once, coalesced; fixed order
+//                                                (no float atomics -> reproducible)
+//   backward gmsg[p] = gpre[drow(p)] . W[rel(p)]^T ; grad_x[i] = gmsg[E+i] + sum CSR_src(i)
+//            grad W[r] = sum_{p in rel r} x[row(p)]^T (x) gpre[drow(p)]   split over K chunks,
+//            slabs reduced in fixed order.
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "bias_grad.h"
+#include "gemm_core.h"
+
+#define GEN_CHUNK 256   // message slots per weight-gradient K chunk
+
+// ------------------------------------------------------------------------------------ plan layout
+struct PlanLayout {
+    size_t rows_fwd, rows_bwd, rel_ptr, tile_ptr, chunk_ptr, dst_ptr, dst_list, src_ptr, src_list, total;
+};
+static PlanLayout plan_layout(int64_t Nn, int64_t E, int64_t R) {
+    PlanLayout L;
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        size_t o = off;
+        off += align_up(n * 4, 256);
+        return o;
+    };
+    L.rows_fwd = take((size_t)(E + Nn));
+    L.rows_bwd = take((size_t)(E + Nn));
+    L.rel_ptr = take((size_t)R + 2);
+    L.tile_ptr = take((size_t)R + 2);
+    L.chunk_ptr = take((size_t)R + 2);
+    L.dst_ptr = take((size_t)Nn + 1);
+    L.dst_list = take((size_t)E + 1);
+    L.src_ptr = take((size_t)Nn + 1);
+    L.src_list = take((size_t)E + 1);
+    L.total = off;
+    return L;
+}
+struct PlanView {
+    const int *rows_fwd, *rows_bwd, *rel_ptr, *tile_ptr, *chunk_ptr, *dst_ptr, *dst_list, *src_ptr, *src_list;
+};
+static PlanView plan_view(const void *plan, int64_t Nn, int64_t E, int64_t R) {
+    PlanLayout L = plan_layout(Nn, E, R);
+    const char *b = reinterpret_cast<const char *>(plan);
+    PlanView v;
+    v.rows_fwd = (const int *)(b + L.rows_fwd);
+    v.rows_bwd = (const int *)(b + L.rows_bwd);
+    v.rel_ptr = (const int *)(b + L.rel_ptr);
+    v.tile_ptr = (const int *)(b + L.tile_ptr);
+    v.chunk_ptr = (const int *)(b + L.chunk_ptr);
+    v.dst_ptr = (const int *)(b + L.dst_ptr);
+    v.dst_list = (const int *)(b + L.dst_list);
+    v.src_ptr = (const int *)(b + L.src_ptr);
+    v.src_list = (const int *)(b + L.src_list);
+    return v;
+}
+static inline int64_t tile_bound(int64_t Nn, int64_t E, int64_t R) { return (E + Nn) / GT_BM + R + 2; }
+static inline int64_t chunk_bound(int64_t Nn, int64_t E, int64_t R) { return (E + Nn) / GEN_CHUNK + R + 2; }
+
+// ------------------------------------------------------------------------------------ plan kernels
+__global__ void plan_prep_kernel(const long long *__restrict__ edge_index, const long long *__restrict__ edge_type,
+                                 long long Nn, long long E, long long R, int *key_rel, int *key_dst, int *key_src,
+                                 int *iota, int32_t *err) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    long long s = edge_index[e], d = edge_index[E + e], t = edge_type[e];
+    if (s < 0 || s >= Nn || d < 0 || d >= Nn) {
+        flag_error(err, MPQE_FLAG_BAD_EDGE);
+        s = s < 0 || s >= Nn ? 0 : s;
+        d = d < 0 || d >= Nn ? 0 : d;
+    }
+    if (t < 0 || t >= R) {
+        flag_error(err, MPQE_FLAG_BAD_RELATION);
+        t = 0;
+    }
+    key_rel[e] = (int)t;
+    key_dst[e] = (int)d;
+    key_src[e] = (int)s;
+    iota[e] = (int)e;
+}
+
+__global__ void plan_slots_kernel(const int *__restrict__ perm, const int *__restrict__ key_src,
+                                  const int *__restrict__ key_dst, long long Nn, long long E, int *rows_fwd,
+                                  int *rows_bwd, int *pos_of_edge) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < E) {
+        const int e = perm[p];
+        rows_fwd[p] = key_src[e];
+        rows_bwd[p] = key_dst[e];
+        pos_of_edge[e] = (int)p;
+    } else if (p < E + Nn) {
+        rows_fwd[p] = (int)(p - E);
+        rows_bwd[p] = (int)(p - E);
+    }
+}
+
+// ptr[v] = first position in sorted keys[0..n) with key >= v, for v in [0, nvals]
+__global__ void plan_lower_bound_kernel(const int *__restrict__ keys, long long n, long long nvals, int *ptr) {
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v > nvals) return;
+    long long lo = 0, hi = n;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (keys[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    ptr[v] = (int)lo;
+}
+
+// rel_ptr[R+1] = E+Nn (the root pseudo relation R owns slots [E, E+Nn)); exclusive scans of the
+// per-relation tile / chunk counts. One thread: R+1 is a few hundred at most.
+__global__ void plan_scan_kernel(long long Nn, long long E, long long R, int *rel_ptr, int *tile_ptr,
+                                 int *chunk_ptr) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    rel_ptr[R] = (int)E;
+    rel_ptr[R + 1] = (int)(E + Nn);
+    int t = 0, c = 0;
+    for (long long r = 0; r <= R; ++r) {
+        tile_ptr[r] = t;
+        chunk_ptr[r] = c;
+        const int cnt = rel_ptr[r + 1] - rel_ptr[r];
+        t += (cnt + GT_BM - 1) / GT_BM;
+        c += (cnt + GEN_CHUNK - 1) / GEN_CHUNK;
+    }
+    tile_ptr[R + 1] = t;
+    chunk_ptr[R + 1] = c;
+}
+
+static int bits_for(int64_t n) {
+    int b = 1;
+    while (b < 31 && (1ll << b) < n) ++b;
+    return b;
+}
+
+struct PlanWs {
+    size_t key_rel, key_dst, key_src, iota, key_out, perm, pos, sort_tmp, sort_bytes, total;
+};
+static size_t sort_tmp_bytes(int64_t E, int bits) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const int *)nullptr, (int *)nullptr, (const int *)nullptr,
+                              (int *)nullptr, (size_t)E, 0u, (unsigned)bits, (hipStream_t) nullptr);
+    return bytes;
+}
+static PlanWs plan_ws_layout(int64_t Nn, int64_t E, int64_t R) {
+    PlanWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align_up(bytes, 256);
+        return o;
+    };
+    const size_t n = (size_t)(E > 0 ? E : 1);
+    w.key_rel = take(n * 4);
+    w.key_dst = take(n * 4);
+    w.key_src = take(n * 4);
+    w.iota = take(n * 4);
+    w.key_out = take(n * 4);
+    w.perm = take(n * 4);
+    w.pos = take(n * 4);
+    size_t bytes = 0;
+    if (E > 0) {
+        const size_t b1 = sort_tmp_bytes(E, bits_for(R)), b2 = sort_tmp_bytes(E, bits_for(Nn));
+        bytes = b1 > b2 ? b1 : b2;
+    }
+    w.sort_bytes = bytes + 256;
+    w.sort_tmp = take(w.sort_bytes);
+    w.total = off;
+    return w;
+}
+
+extern "C" size_t mpqe_rgcn_plan_bytes(int64_t Nn, int64_t E, int64_t R) {
+    if (Nn < 0 || E < 0 || R < 0) return 0;
+    return plan_layout(Nn, E, R).total;
+}
+extern "C" size_t mpqe_rgcn_plan_workspace_bytes(int64_t Nn, int64_t E, int64_t R) {
+    if (Nn < 0 || E < 0 || R < 0) return 0;
+    return plan_ws_layout(Nn, E, R).total;
+}
+
+extern "C" int mpqe_rgcn_plan_build(const int64_t *edge_index, const int64_t *edge_type, int64_t Nn, int64_t E,
+                                    int64_t R, void *plan, size_t plan_bytes, void *workspace,
+                                    size_t workspace_bytes, int32_t *err, void *stream) {
+    if (Nn < 0 || E < 0 || R < 0 || !plan) return MPQE_ERR_INVALID_ARG;
+    if (E + Nn >= (1ll << 31) || R >= (1ll << 30)) return MPQE_ERR_UNSUPPORTED;
+    if (E > 0 && (!edge_index || !edge_type)) return MPQE_ERR_INVALID_ARG;
+    PlanLayout L = plan_layout(Nn, E, R);
+    PlanWs W = plan_ws_layout(Nn, E, R);
+    if (plan_bytes < L.total) return MPQE_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < W.total) return MPQE_ERR_WORKSPACE;
+    hipStream_t s = as_stream(stream);
+    char *pb = reinterpret_cast<char *>(plan);
+    char *wb = reinterpret_cast<char *>(workspace);
+    int *rows_fwd = (int *)(pb + L.rows_fwd), *rows_bwd = (int *)(pb + L.rows_bwd);
+    int *rel_ptr = (int *)(pb + L.rel_ptr), *tile_ptr = (int *)(pb + L.tile_ptr);
+    int *chunk_ptr = (int *)(pb + L.chunk_ptr);
+    int *dst_ptr = (int *)(pb + L.dst_ptr), *dst_list = (int *)(pb + L.dst_list);
+    int *src_ptr = (int *)(pb + L.src_ptr), *src_list = (int *)(pb + L.src_list);
+    int *key_rel = (int *)(wb + W.key_rel), *key_dst = (int *)(wb + W.key_dst), *key_src = (int *)(wb + W.key_src);
+    int *iota = (int *)(wb + W.iota), *key_out = (int *)(wb + W.key_out), *perm = (int *)(wb + W.perm);
+    int *pos = (int *)(wb + W.pos);
+    void *tmp = wb + W.sort_tmp;
+    size_t tmp_bytes = W.sort_bytes;
+
+    if (E > 0) {
+        hipLaunchKernelGGL(plan_prep_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s,
+                           (const long long *)edge_index, (const long long *)edge_type, (long long)Nn, (long long)E,
+                           (long long)R, key_rel, key_dst, key_src, iota, err);
+        if (rocprim::radix_sort_pairs(tmp, tmp_bytes, (const int *)key_rel, key_out, (const int *)iota, perm,
+                                      (size_t)E, 0u, (unsigned)bits_for(R), s) != hipSuccess)
+            return MPQE_ERR_LAUNCH;
+    }
+    const long long slots = E + Nn;
+    if (slots > 0)
+        hipLaunchKernelGGL(plan_slots_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s,
+                           (const int *)perm, (const int *)key_src, (const int *)key_dst, (long long)Nn,
+                           (long long)E, rows_fwd, rows_bwd, pos);
+    // key_out now holds the relation-sorted keys: rel_ptr[r] = lower_bound(r) for r in [0, R]
+    hipLaunchKernelGGL(plan_lower_bound_kernel, dim3((unsigned)((R + 1 + 255) / 256)), dim3(256), 0, s,
+                       (const int *)key_out, (long long)E, (long long)R, rel_ptr);
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(64), 0, s, (long long)Nn, (long long)E, (long long)R,
+                       rel_ptr, tile_ptr, chunk_ptr);
+    if (E > 0) {
+        tmp_bytes = W.sort_bytes;
+        if (rocprim::radix_sort_pairs(tmp, tmp_bytes, (const int *)key_dst, key_out, (const int *)pos, dst_list,
+                                      (size_t)E, 0u, (unsigned)bits_for(Nn), s) != hipSuccess)
+            return MPQE_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(plan_lower_bound_kernel, dim3((unsigned)((Nn + 1 + 255) / 256)), dim3(256), 0, s,
+                       (const int *)key_out, (long long)E, (long long)Nn, dst_ptr);
+    if (E > 0) {
+        tmp_bytes = W.sort_bytes;
+        if (rocprim::radix_sort_pairs(tmp, tmp_bytes, (const int *)key_src, key_out, (const int *)pos, src_list,
+                                      (size_t)E, 0u, (unsigned)bits_for(Nn), s) != hipSuccess)
+            return MPQE_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(plan_lower_bound_kernel, dim3((unsigned)((Nn + 1 + 255) / 256)), dim3(256), 0, s,
+                       (const int *)key_out, (long long)E, (long long)Nn, src_ptr);
+    return mpqe_launch_status();
+}
+
+// ------------------------------------------------------------------------------------ grouped gather-GEMM
+// first r with ptr[r+1] > t  (ptr non-decreasing, ptr[0] = 0, t < ptr[n])
+__device__ __forceinline__ int find_group(const int *__restrict__ ptr, int n, int t) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (ptr[mid + 1] > t) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
+
+// TRANS = false: msg[p]  = x[rows[p]]    . W[rel]      (K = Din,  cols = Dout)
+// TRANS = true : gmsg[p] = gpre[rows[p]] . W[rel]^T    (K = Dout, cols = Din), gpre masked by out > 0
+template <bool TRANS>
+__global__ __launch_bounds__(256) void rgcn_gen_gemm_kernel(
+    const int *__restrict__ rows, const int *__restrict__ rel_ptr, const int *__restrict__ tile_ptr, int R,
+    const float *__restrict__ a, const float *__restrict__ mask, const float *__restrict__ basis,
+    const float *__restrict__ root, int Din, int Dout, float *__restrict__ msg, int vec_a, int vec_w) {
+    __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
+    const int t = blockIdx.x;
+    if (t >= tile_ptr[R + 1]) return;
+    const int r = find_group(tile_ptr, R + 1, t);
+    const int start = rel_ptr[r] + (t - tile_ptr[r]) * GT_BM;
+    int nrows = rel_ptr[r + 1] - start;
+    if (nrows > GT_BM) nrows = GT_BM;
+    const float *W = r < R ? basis + (long long)r * Din * Dout : root;
+    const int K = TRANS ? Dout : Din;       // length of an A row
+    const int C = TRANS ? Din : Dout;       // output columns
+    const int n0 = blockIdx.y * GT_BN;
+    const int nsteps = (K + GT_BK - 1) / GT_BK;
+
+    // staging rows of this thread in gemm_block's R-type map: (threadIdx.x >> 3) and + 32
+    const int ar0 = threadIdx.x >> 3;
+    const long long off0 = ar0 < nrows ? (long long)rows[start + ar0] * K : -1;
+    const long long off1 = ar0 + 32 < nrows ? (long long)rows[start + ar0 + 32] * K : -1;
+
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    auto aload = [&](int rr, int c, int step) -> f32x4 {
+        const long long off = rr < 32 ? off0 : off1;
+        if (off < 0) return f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 v = ld4_guard(a + off, step * GT_BK + c, K, vec_a);
+        if (TRANS && mask) {
+            f32x4 o = ld4_guard(mask + off, step * GT_BK + c, K, vec_a);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = o[q] > 0.f ? v[q] : 0.f;
+        }
+        return v;
+    };
+    if (!TRANS) {
+        auto bload = [&](int k, int c, int step) -> f32x4 {
+            const int kk = step * GT_BK + k;
+            if (kk >= Din) return f32x4{0.f, 0.f, 0.f, 0.f};
+            return ld4_guard(W + (long long)kk * Dout, n0 + c, Dout, vec_w);
+        };
+        gemm_block<false, true>(acc, aload, bload, nsteps, smem);
+    } else {
+        auto bload = [&](int rr, int c, int step) -> f32x4 {
+            const int nn = n0 + rr;
+            if (nn >= Din) return f32x4{0.f, 0.f, 0.f, 0.f};
+            return ld4_guard(W + (long long)nn * Dout, step * GT_BK + c, Dout, vec_w);
+        };
+        gemm_block<false, false>(acc, aload, bload, nsteps, smem);
+    }
+    const int col = n0 + acc_col();
+    if (col < C) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = acc_row(q);
+            if (row < nrows) msg[(long long)(start + row) * C + col] = acc[q];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ segmented sum
+// out[i] = act(bias + msg[E+i] + sum_{k in [ptr[i], ptr[i+1])} msg[list[k]]): one thread owns 4
+// consecutive columns of one row, so a row is read by D/4 adjacent lanes in 16-byte pieces
+// and no cross-lane step is needed. Message rows are added in CSR order (stable in edge id).
+__global__ __launch_bounds__(256) void segment_sum_kernel(const int *__restrict__ ptr, const int *__restrict__ list,
+                                                          long long Nn, long long E, int D,
+                                                          const float *__restrict__ msg,
+                                                          const float *__restrict__ bias, int relu,
+                                                          float *__restrict__ out, int vec) {
+    const int per_row = vec ? D / 4 : D;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = idx / per_row;
+    if (i >= Nn) return;
+    const int c = (int)(idx - i * per_row) * (vec ? 4 : 1);
+    const int k0 = ptr[i], k1 = ptr[i + 1];
+    if (vec) {
+        f32x4 s = *reinterpret_cast<const f32x4 *>(msg + (E + i) * D + c);
+        if (bias) {
+            f32x4 b = *reinterpret_cast<const f32x4 *>(bias + c);
+            s[0] += b[0]; s[1] += b[1]; s[2] += b[2]; s[3] += b[3];
+        }
+        int k = k0;
+        for (; k + 1 < k1; k += 2) {   // two rows in flight, added in order
+            f32x4 m0 = *reinterpret_cast<const f32x4 *>(msg + (long long)list[k] * D + c);
+            f32x4 m1 = *reinterpret_cast<const f32x4 *>(msg + (long long)list[k + 1] * D + c);
+            s[0] += m0[0]; s[1] += m0[1]; s[2] += m0[2]; s[3] += m0[3];
+            s[0] += m1[0]; s[1] += m1[1]; s[2] += m1[2]; s[3] += m1[3];
+        }
+        if (k < k1) {
+            f32x4 m0 = *reinterpret_cast<const f32x4 *>(msg + (long long)list[k] * D + c);
+            s[0] += m0[0]; s[1] += m0[1]; s[2] += m0[2]; s[3] += m0[3];
+        }
+        if (relu) {
+            s[0] = s[0] > 0.f ? s[0] : 0.f; s[1] = s[1] > 0.f ? s[1] : 0.f;
+            s[2] = s[2] > 0.f ? s[2] : 0.f; s[3] = s[3] > 0.f ? s[3] : 0.f;
+        }
+        *reinterpret_cast<f32x4 *>(out + i * D + c) = s;
+    } else {
+        float s = msg[(E + i) * D + c] + (bias ? bias[c] : 0.f);
+        for (int k = k0; k < k1; ++k) s += msg[(long long)list[k] * D + c];
+        if (relu) s = s > 0.f ? s : 0.f;
+        out[i * D + c] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------ weight gradient
+__global__ __launch_bounds__(256) void rgcn_gen_grad_w_kernel(
+    const int *__restrict__ rows_fwd, const int *__restrict__ rows_bwd, const int *__restrict__ rel_ptr,
+    const int *__restrict__ chunk_ptr, int R, const float *__restrict__ x, const float *__restrict__ g,
+    const float *__restrict__ out, int Din, int Dout, int relu, float *__restrict__ slabs, int vec_x, int vec_g) {
+    __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
+    const int c = blockIdx.x;
+    if (c >= chunk_ptr[R + 1]) return;
+    const int r = find_group(chunk_ptr, R + 1, c);
+    const int q0 = rel_ptr[r] + (c - chunk_ptr[r]) * GEN_CHUNK;
+    int q1 = q0 + GEN_CHUNK;
+    if (q1 > rel_ptr[r + 1]) q1 = rel_ptr[r + 1];
+    const int tiles_j = (Dout + GT_BN - 1) / GT_BN;
+    const int i0 = (blockIdx.y / tiles_j) * GT_BM;
+    const int j0 = (blockIdx.y % tiles_j) * GT_BN;
+    const int nsteps = (q1 - q0 + GT_BK - 1) / GT_BK;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    auto aload = [&](int k, int cc, int step) -> f32x4 {
+        const int q = q0 + step * GT_BK + k;
+        if (q >= q1) return f32x4{0.f, 0.f, 0.f, 0.f};
+        return ld4_guard(x + (long long)rows_fwd[q] * Din, i0 + cc, Din, vec_x);
+    };
+    auto bload = [&](int k, int cc, int step) -> f32x4 {
+        const int q = q0 + step * GT_BK + k;
+        if (q >= q1) return f32x4{0.f, 0.f, 0.f, 0.f};
+        const long long off = (long long)rows_bwd[q] * Dout;
+        f32x4 v = ld4_guard(g + off, j0 + cc, Dout, vec_g);
+        if (relu) {
+            f32x4 o = ld4_guard(out + off, j0 + cc, Dout, vec_g);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) v[qq] = o[qq] > 0.f ? v[qq] : 0.f;
+        }
+        return v;
+    };
+    gemm_block<true, true>(acc, aload, bload, nsteps, smem);
+    float *dst = slabs + (long long)c * Din * Dout;
+    const int col = j0 + acc_col();
+    if (col < Dout) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = i0 + acc_row(q);
+            if (row < Din) dst[(long long)row * Dout + col] = acc[q];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void rgcn_gen_reduce_w_kernel(const int *__restrict__ chunk_ptr, int R, int Din,
+                                                                int Dout, const float *__restrict__ slabs,
+                                                                float *__restrict__ grad_basis,
+                                                                float *__restrict__ grad_root) {
+    const int r = blockIdx.y;
+    const long long elems = (long long)Din * Dout;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= elems) return;
+    const int c0 = chunk_ptr[r], c1 = chunk_ptr[r + 1];
+    if (c0 == c1) return;
+    float *dst = r < R ? grad_basis : grad_root;
+    if (!dst) return;
+    float s = 0.f;
+    for (int c = c0; c < c1; ++c) s += slabs[(long long)c * elems + idx];
+    if (r < R) dst[(long long)r * elems + idx] += s;
+    else dst[idx] += s;
+}
+
+// ------------------------------------------------------------------------------------ host side
+extern "C" size_t mpqe_rgcn_general_workspace_bytes(int64_t Nn, int64_t E, int64_t R, int64_t Din, int64_t Dout,
+                                                    int backward) {
+    if (Nn < 0 || E < 0 || R < 0 || Din <= 0 || Dout <= 0) return 0;
+    const size_t slots = (size_t)(E + Nn);
+    if (!backward) return align_up(slots * (size_t)Dout * 4, 256) + 256;
+    return align_up(slots * (size_t)Din * 4, 256) +
+           align_up((size_t)chunk_bound(Nn, E, R) * (size_t)Din * (size_t)Dout * 4, 256) +
+           bias_partial_bytes(Nn, Dout) + 256;
+}
+
+extern "C" int mpqe_rgcn_general_fwd(const void *plan, int64_t Nn, int64_t E, int64_t R, const float *x,
+                                     const float *basis, const float *root, const float *bias, int64_t Din,
+                                     int64_t Dout, int relu, float *out, void *workspace, size_t workspace_bytes,
+                                     void *stream) {
+    if (!plan || Nn < 0 || E < 0 || R < 0 || Din <= 0 || Dout <= 0) return MPQE_ERR_INVALID_ARG;
+    if (Nn == 0) return MPQE_OK;
+    if (!x || !root || !out || (R > 0 && !basis)) return MPQE_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < mpqe_rgcn_general_workspace_bytes(Nn, E, R, Din, Dout, 0))
+        return MPQE_ERR_WORKSPACE;
+    PlanView P = plan_view(plan, Nn, E, R);
+    hipStream_t s = as_stream(stream);
+    float *msg = reinterpret_cast<float *>(workspace);
+    const int vec_w = (!basis || ptr_vec_ok(basis, Dout)) && ptr_vec_ok(root, Dout) && (Din * Dout) % 4 == 0;
+    dim3 grid((unsigned)tile_bound(Nn, E, R), (unsigned)((Dout + GT_BN - 1) / GT_BN));
+    hipLaunchKernelGGL(rgcn_gen_gemm_kernel<false>, grid, dim3(256), 0, s, P.rows_fwd, P.rel_ptr, P.tile_ptr, (int)R,
+                       x, (const float *)nullptr, basis, root, (int)Din, (int)Dout, msg, (int)ptr_vec_ok(x, Din),
+                       vec_w);
+    const int vec = Dout % 4 == 0 && ptr_vec_ok(out, Dout) && (!bias || (uintptr_t)bias % 16 == 0) &&
+                    (uintptr_t)workspace % 16 == 0;
+    const long long threads = Nn * (vec ? Dout / 4 : Dout);
+    hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, P.dst_ptr,
+                       P.dst_list, (long long)Nn, (long long)E, (int)Dout, (const float *)msg, bias, relu, out, vec);
+    return mpqe_launch_status();
+}
+
+extern "C" int mpqe_rgcn_general_bwd(const void *plan, int64_t Nn, int64_t E, int64_t R, const float *x,
+                                     const float *out, const float *grad_out, const float *basis, const float *root,
+                                     int64_t Din, int64_t Dout, int relu, float *grad_x, float *grad_basis,
+                                     float *grad_root, float *grad_bias, void *workspace, size_t workspace_bytes,
+                                     void *stream) {
+    if (!plan || Nn < 0 || E < 0 || R < 0 || Din <= 0 || Dout <= 0) return MPQE_ERR_INVALID_ARG;
+    if (Nn == 0) return MPQE_OK;
+    if (!x || !grad_out || !root || (R > 0 && !basis) || (relu && !out)) return MPQE_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < mpqe_rgcn_general_workspace_bytes(Nn, E, R, Din, Dout, 1))
+        return MPQE_ERR_WORKSPACE;
+    PlanView P = plan_view(plan, Nn, E, R);
+    hipStream_t s = as_stream(stream);
+    char *wb = reinterpret_cast<char *>(workspace);
+    float *gmsg = reinterpret_cast<float *>(wb);
+    float *slabs = reinterpret_cast<float *>(wb + align_up((size_t)(E + Nn) * (size_t)Din * 4, 256));
+    float *bias_part = reinterpret_cast<float *>(
+        reinterpret_cast<char *>(slabs) + align_up((size_t)chunk_bound(Nn, E, R) * (size_t)Din * (size_t)Dout * 4, 256));
+    const int vec_w = (!basis || ptr_vec_ok(basis, Dout)) && ptr_vec_ok(root, Dout) && (Din * Dout) % 4 == 0;
+    const int vec_g = ptr_vec_ok(grad_out, Dout) && (!relu || ptr_vec_ok(out, Dout));
+    const float *mask = relu ? out : nullptr;
+    if (grad_x) {
+        dim3 grid((unsigned)tile_bound(Nn, E, R), (unsigned)((Din + GT_BN - 1) / GT_BN));
+        hipLaunchKernelGGL(rgcn_gen_gemm_kernel<true>, grid, dim3(256), 0, s, P.rows_bwd, P.rel_ptr, P.tile_ptr,
+                           (int)R, grad_out, mask, basis, root, (int)Din, (int)Dout, gmsg, vec_g, vec_w);
+        const int vec = Din % 4 == 0 && ptr_vec_ok(grad_x, Din) && (uintptr_t)workspace % 16 == 0;
+        const long long threads = Nn * (vec ? Din / 4 : Din);
+        hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, P.src_ptr,
+                           P.src_list, (long long)Nn, (long long)E, (int)Din, (const float *)gmsg,
+                           (const float *)nullptr, 0, grad_x, vec);
+    }
+    if (grad_basis || grad_root) {
+        const int tiles = (int)(((Din + GT_BM - 1) / GT_BM) * ((Dout + GT_BN - 1) / GT_BN));
+        dim3 grid((unsigned)chunk_bound(Nn, E, R), tiles);
+        hipLaunchKernelGGL(rgcn_gen_grad_w_kernel, grid, dim3(256), 0, s, P.rows_fwd, P.rows_bwd, P.rel_ptr,
+                           P.chunk_ptr, (int)R, x, grad_out, mask, (int)Din, (int)Dout, relu, slabs,
+                           (int)ptr_vec_ok(x, Din), vec_g);
+        const long long elems = (long long)Din * Dout;
+        dim3 rgrid((unsigned)((elems + 255) / 256), (unsigned)(R + 1));
+        hipLaunchKernelGGL(rgcn_gen_reduce_w_kernel, rgrid, dim3(256), 0, s, P.chunk_ptr, (int)R, (int)Din,
+                           (int)Dout, (const float *)slabs, grad_basis, grad_root);
+    }
+    if (grad_bias) launch_bias_grad((long long)Nn, grad_out, mask, (int)Dout, relu, bias_part, grad_bias, s);
+    return mpqe_launch_status();
+}

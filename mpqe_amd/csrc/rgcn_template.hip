@@ -11,6 +11,7 @@
 // fused into the epilogue. Backward-x is the same on the reversed template with
 // W^T; the weight gradient is x_src^T . g_dst with the batch as K, split over
 // workgroups and reduced in a fixed order (no float atomics -> reproducible).
+#include "bias_grad.h"
 #include "gemm_core.h"
 
 struct TmplArgs {
@@ -223,33 +224,6 @@ __global__ __launch_bounds__(256) void rgcn_tmpl_reduce_w_kernel(
     grad_basis[tp.rel[z] * elems + idx] += s;
 }
 
-// grad_bias[j] += sum_q gpre[q][j]: per-block partial column sums, then one block adds them up.
-#define BIAS_ROWS 64
-__global__ __launch_bounds__(256) void bias_partial_kernel(long long rows, const float *__restrict__ g,
-                                                           const float *__restrict__ out, int Dout, int relu,
-                                                           float *__restrict__ partial) {
-    const long long r0 = (long long)blockIdx.x * BIAS_ROWS;
-    long long r1 = r0 + BIAS_ROWS;
-    if (r1 > rows) r1 = rows;
-    for (int col = threadIdx.x; col < Dout; col += blockDim.x) {
-        float s = 0.f;
-        for (long long r = r0; r < r1; ++r) {
-            float v = g[r * Dout + col];
-            if (relu && !(out[r * Dout + col] > 0.f)) v = 0.f;
-            s += v;
-        }
-        partial[(long long)blockIdx.x * Dout + col] = s;
-    }
-}
-__global__ __launch_bounds__(256) void bias_final_kernel(int nblk, int Dout, const float *__restrict__ partial,
-                                                         float *__restrict__ grad_bias) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= Dout) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(long long)b * Dout + col];
-    grad_bias[col] += s;
-}
-
 // ------------------------------------------------------------------------------------ host side
 static int fill_tmpl(int query_type, const int64_t *edge_type_host, int64_t num_relations, TmplArgs *tp) {
     if (query_type < 0 || query_type >= MPQE_Q_COUNT || !edge_type_host) return MPQE_ERR_INVALID_ARG;
@@ -330,9 +304,7 @@ extern "C" size_t mpqe_rgcn_template_bwd_workspace_bytes(int query_type, int64_t
     tp.N = d.N;
     tp.E = d.E;
     WChunks w = plan_chunks(B, d.N);
-    size_t rows = (size_t)B * d.N;
-    size_t nblk = (rows + BIAS_ROWS - 1) / BIAS_ROWS;
-    return align_up(tmpl_slab_floats(tp, w, Din, Dout) * 4, 256) + align_up(nblk * Dout * 4, 256) + 256;
+    return align_up(tmpl_slab_floats(tp, w, Din, Dout) * 4, 256) + bias_partial_bytes((long long)B * d.N, Dout) + 256;
 }
 
 extern "C" int mpqe_rgcn_template_bwd(int query_type, int64_t B, const int64_t *edge_type_host, const float *x,
@@ -373,12 +345,7 @@ extern "C" int mpqe_rgcn_template_bwd(int query_type, int64_t B, const int64_t *
                                slabs, grad_basis, grad_root);
         }
         if (grad_bias) {
-            const long long rows = (long long)B * tp.N;
-            const int nblk = (int)((rows + BIAS_ROWS - 1) / BIAS_ROWS);
-            hipLaunchKernelGGL(bias_partial_kernel, dim3(nblk), dim3(256), 0, s, rows, grad_out, out, (int)Dout,
-                               relu, bias_part);
-            hipLaunchKernelGGL(bias_final_kernel, dim3((unsigned)((Dout + 255) / 256)), dim3(256), 0, s, nblk,
-                               (int)Dout, bias_part, grad_bias);
+            launch_bias_grad((long long)B * tp.N, grad_out, out, (int)Dout, relu, bias_part, grad_bias, s);
         }
     }
     return mpqe_launch_status();

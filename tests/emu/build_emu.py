@@ -1,0 +1,36 @@
+"""TEST INFRASTRUCTURE ONLY -- builds tests/emu/_build/libmpqe_emu.so: the kernel sources
+of mpqe_amd/csrc compiled for the HOST against the fiber emulator (tests/emu/include),
+so kernel logic can be checked without a GPU. Never loaded by the product."""
+import glob
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = os.path.join(HERE, '_build', 'libmpqe_emu.so')
+CLANG = '/opt/rocm/lib/llvm/bin/clang++'
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(ROOT, 'mpqe_amd', 'csrc', '*.hip')))
+
+
+def build_emu(force=False):
+    deps = sources() + glob.glob(os.path.join(ROOT, 'mpqe_amd', 'csrc', '*.h')) + \
+        glob.glob(os.path.join(HERE, 'include', '*', '*.h*')) + \
+        glob.glob(os.path.join(HERE, 'include', '*', '*', '*.h*')) + \
+        [os.path.join(HERE, 'emu_runtime.cpp'), os.path.join(ROOT, 'include', 'mpqe_amd.h')]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+        return OUT
+    if not os.path.exists(CLANG):
+        raise RuntimeError('clang++ not found at %s' % CLANG)
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    cmd = [CLANG, '-x', 'c++', '-std=c++17', '-O1', '-g', '-fPIC', '-shared',
+           '-I' + os.path.join(HERE, 'include'), '-I' + os.path.join(ROOT, 'include')] + \
+        sources() + [os.path.join(HERE, 'emu_runtime.cpp'), '-o', OUT]
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build_emu(force=True))

@@ -1,0 +1,429 @@
+"""Parity of every C-ABI kernel with the CPU oracle (oracle/ref_cpu.py, itself pinned to the
+reference by tests/test_oracle_golden.py) and with the golden vectors.
+
+Each test runs twice: on the host fiber emulator (`emu`, kernel LOGIC, runs without a GPU) and
+on the real gfx950 library (`hip`, marked gpu). Integers bit-exact; fp32 forward rtol 1e-5 with an
+absolute floor scaled to the operand magnitude, gradients rtol 1e-4.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from mpqe_amd._capi import (FLAG_BAD_EDGE, FLAG_BAD_INDEX, FLAG_BAD_NODE_ID, FLAG_BAD_RELATION,
+                            QUERY_TYPE_IDS, READOUT_IDS, SCATTER_IDS)
+from oracle import ref_cpu
+
+QTYPES = list(QUERY_TYPE_IDS)
+
+
+@pytest.fixture(scope='module', params=['emu', pytest.param('hip', marks=pytest.mark.gpu)])
+def be(request):
+    from tests import kernel_backend
+    if request.param == 'emu':
+        return kernel_backend.EmuBackend()
+    return kernel_backend.HipBackend()
+
+
+def close(a, b, rtol=1e-5, scale=None, what=''):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    s = max(1.0, float(np.abs(b).max()) if b.size else 1.0) if scale is None else scale
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=2e-6 * s, err_msg=what)
+
+
+def template_graph(qt, B):
+    t = ref_cpu.TEMPLATES[qt]
+    N = 1 + max(max(t['src']), max(t['dst']))
+    offs = (np.arange(B, dtype=np.int64) * N)[:, None]
+    ei = np.stack([(np.array(t['src'], dtype=np.int64)[None] + offs).reshape(-1),
+                   (np.array(t['dst'], dtype=np.int64)[None] + offs).reshape(-1)])
+    return N, len(t['src']), ei
+
+
+def layer_oracle(x, ei, et, basis, root, bias, relu, gout):
+    xt, bt, rt, bi = [torch.from_numpy(a.copy()).requires_grad_(True) for a in (x, basis, root, bias)]
+    out = ref_cpu.rgcn_layer_refseq(xt, torch.from_numpy(ei), torch.from_numpy(et), bt, rt, bi)
+    if relu:
+        out = torch.relu(out)
+    out.backward(torch.from_numpy(gout))
+    z = lambda t, like: np.zeros_like(like) if t.grad is None else t.grad.numpy()
+    return out.detach().numpy(), z(xt, x), z(bt, basis), z(rt, root), z(bi, bias)
+
+
+# ------------------------------------------------------------------------------------------ collation
+def test_collation_bit_exact_vs_reference(be, enc_case):
+    c = enc_case
+    qt = QUERY_TYPE_IDS[c.query_type]
+    B = c.B
+    a = c.arrays
+    E, N = a['edge_type'].shape[0] // B, a['batch'].shape[0] // B
+    et = np.ascontiguousarray(a['edge_type'][:E])
+    ei = be.empty((2, B * E), np.int64)
+    ety = be.empty((B * E,), np.int64)
+    bt = be.empty((B * N,), np.int64)
+    be.check(be.lib.mpqe_collate_template(qt, B, et.ctypes.data, be.ptr(ei), be.ptr(ety), be.ptr(bt), be.stream))
+    np.testing.assert_array_equal(be.get(ei), a['edge_index'])
+    np.testing.assert_array_equal(be.get(ety), a['edge_type'])
+    np.testing.assert_array_equal(be.get(bt), a['batch'])
+
+
+def test_template_info_matches_oracle_tables(be):
+    from mpqe_amd._capi import TemplateInfo
+    for qt, qi in QUERY_TYPE_IDS.items():
+        info = TemplateInfo()
+        be.check(be.lib.mpqe_template_info(qi, ctypes.byref(info)))
+        t = ref_cpu.TEMPLATES[qt]
+        E = len(t['src'])
+        assert info.num_edges == E and info.diameter == t['diam']
+        assert list(info.src)[:E] == t['src'] and list(info.dst)[:E] == t['dst']
+        assert list(info.rel_label)[:E] == t['rel']
+        assert list(info.var_node)[:info.num_vars] == t['var']
+        assert info.num_nodes == info.num_anchors + info.num_vars == 1 + max(t['src'] + t['dst'])
+
+
+# ------------------------------------------------------------------------------------------ template layer
+@pytest.mark.parametrize('qt', QTYPES)
+@pytest.mark.parametrize('shape', [(5, 16, 16, 4), (70, 40, 24, 5), (67, 128, 128, 7), (9, 18, 22, 3)],
+                         ids=lambda s: 'B%d_%dx%d' % s[:3])
+@pytest.mark.parametrize('relu', [0, 1])
+def test_template_layer_fwd_bwd(be, qt, shape, relu):
+    B, Din, Dout, R = shape
+    rng = np.random.RandomState(hash((qt, shape, relu)) % (2 ** 31))
+    N, E, ei = template_graph(qt, B)
+    x = rng.randn(B * N, Din).astype(np.float32)
+    basis = (rng.randn(R, Din, Dout) * 0.3).astype(np.float32)
+    root = (rng.randn(Din, Dout) * 0.3).astype(np.float32)
+    bias = rng.randn(Dout).astype(np.float32)
+    et = rng.randint(0, R, size=E).astype(np.int64)
+    if E == 3 and R > 1:
+        et[2] = et[0]                      # two template edges sharing a relation
+    gout = rng.randn(B * N, Dout).astype(np.float32)
+    ref = layer_oracle(x, ei, np.tile(et, B), basis, root, bias, relu, gout)
+
+    dx, db, dr, dbi, dg = [be.put(a) for a in (x, basis, root, bias, gout)]
+    out = be.empty((B * N, Dout))
+    qi = QUERY_TYPE_IDS[qt]
+    be.check(be.lib.mpqe_rgcn_template_fwd(qi, B, et.ctypes.data, be.ptr(dx), be.ptr(db), R, be.ptr(dr),
+                                           be.ptr(dbi), Din, Dout, relu, be.ptr(out), be.stream), 'fwd')
+    close(be.get(out), ref[0], what='out')
+    wsb = be.lib.mpqe_rgcn_template_bwd_workspace_bytes(qi, B, Din, Dout)
+    ws = be.nbytes(wsb)
+    gx = be.empty((B * N, Din))
+    # gradients accumulate into what is already there
+    gb0, gr0, gbi0 = [rng.randn(*s).astype(np.float32) for s in (basis.shape, root.shape, bias.shape)]
+    gb, gr, gbi = be.put(gb0), be.put(gr0), be.put(gbi0)
+    be.check(be.lib.mpqe_rgcn_template_bwd(qi, B, et.ctypes.data, be.ptr(dx), be.ptr(out), be.ptr(dg), be.ptr(db),
+                                           R, be.ptr(dr), Din, Dout, relu, be.ptr(gx), be.ptr(gb), be.ptr(gr),
+                                           be.ptr(gbi), be.ptr(ws), wsb, be.stream), 'bwd')
+    close(be.get(gx), ref[1], rtol=1e-4, what='grad_x')
+    close(be.get(gb) - gb0, ref[2], rtol=1e-4, scale=max(1.0, np.abs(ref[2]).max() + np.abs(gb0).max()), what='grad_basis')
+    close(be.get(gr) - gr0, ref[3], rtol=1e-4, scale=max(1.0, np.abs(ref[3]).max() + np.abs(gr0).max()), what='grad_root')
+    close(be.get(gbi) - gbi0, ref[4], rtol=1e-4, scale=max(1.0, np.abs(ref[4]).max() + np.abs(gbi0).max()), what='grad_bias')
+
+
+def test_template_layer_rejects_bad_arguments(be):
+    et = np.array([5], dtype=np.int64)
+    x = be.zeros((4, 8))
+    assert be.lib.mpqe_rgcn_template_fwd(0, 2, et.ctypes.data, be.ptr(x), be.ptr(x), 3, be.ptr(x), None, 8, 8, 0,
+                                         be.ptr(x), be.stream) != 0        # relation 5 >= R 3
+    assert be.lib.mpqe_rgcn_template_fwd(9, 2, et.ctypes.data, be.ptr(x), be.ptr(x), 9, be.ptr(x), None, 8, 8, 0,
+                                         be.ptr(x), be.stream) != 0        # unknown template
+    assert be.lib.mpqe_rgcn_template_fwd(0, 0, et.ctypes.data, None, None, 9, None, None, 8, 8, 0, None,
+                                         be.stream) != 0                   # null operands
+
+
+# ------------------------------------------------------------------------------------------ general layer
+def run_general(be, x, ei, et, basis, root, bias, relu, gout, Nn):
+    E, R = ei.shape[1], basis.shape[0]
+    Din, Dout = root.shape
+    err = be.zeros((1,), np.int32)
+    pb = be.lib.mpqe_rgcn_plan_bytes(Nn, E, R)
+    pw = be.lib.mpqe_rgcn_plan_workspace_bytes(Nn, E, R)
+    plan, pws = be.nbytes(pb), be.nbytes(pw)
+    dei, det = be.put(ei), be.put(et)
+    be.check(be.lib.mpqe_rgcn_plan_build(be.ptr(dei), be.ptr(det), Nn, E, R, be.ptr(plan), pb, be.ptr(pws), pw,
+                                         be.ptr(err), be.stream), 'plan')
+    dx, db, dr, dbi, dg = [be.put(a) for a in (x, basis, root, bias, gout)]
+    out = be.empty((Nn, Dout))
+    wf = be.lib.mpqe_rgcn_general_workspace_bytes(Nn, E, R, Din, Dout, 0)
+    ws = be.nbytes(wf)
+    be.check(be.lib.mpqe_rgcn_general_fwd(be.ptr(plan), Nn, E, R, be.ptr(dx), be.ptr(db), be.ptr(dr), be.ptr(dbi),
+                                          Din, Dout, relu, be.ptr(out), be.ptr(ws), wf, be.stream), 'fwd')
+    wb = be.lib.mpqe_rgcn_general_workspace_bytes(Nn, E, R, Din, Dout, 1)
+    ws2 = be.nbytes(wb)
+    gx = be.empty((Nn, Din))
+    gb, gr, gbi = be.zeros(basis.shape), be.zeros(root.shape), be.zeros(bias.shape)
+    be.check(be.lib.mpqe_rgcn_general_bwd(be.ptr(plan), Nn, E, R, be.ptr(dx), be.ptr(out), be.ptr(dg), be.ptr(db),
+                                          be.ptr(dr), Din, Dout, relu, be.ptr(gx), be.ptr(gb), be.ptr(gr),
+                                          be.ptr(gbi), be.ptr(ws2), wb, be.stream), 'bwd')
+    return [be.get(a) for a in (out, gx, gb, gr, gbi)], int(be.get(err)[0])
+
+
+def test_general_layer_vs_reference_conv(be, conv_case):
+    z = conv_case
+    got, err = run_general(be, z['x'], z['edge_index'], z['edge_type'], z['basis'], z['root'], z['bias'], 0,
+                           z['grad_out'], z['x'].shape[0])
+    assert err == 0
+    for g, k, tol in zip(got, ('out', 'grad_x', 'grad_basis', 'grad_root', 'grad_bias'),
+                         (1e-5, 1e-4, 1e-4, 1e-4, 1e-4)):
+        close(g, z[k], rtol=tol, what=k)
+
+
+@pytest.mark.parametrize('qt', ['3-chain', '3-inter', '3-inter_chain'])
+@pytest.mark.parametrize('relu', [0, 1])
+def test_general_layer_on_template_batches(be, qt, relu):
+    rng = np.random.RandomState(7)
+    B, Din, Dout, R = 37, 32, 32, 6
+    N, E, ei = template_graph(qt, B)
+    et = np.tile(rng.randint(0, R, size=E).astype(np.int64), B)
+    x = rng.randn(B * N, Din).astype(np.float32)
+    basis = (rng.randn(R, Din, Dout) * 0.3).astype(np.float32)
+    root = (rng.randn(Din, Dout) * 0.3).astype(np.float32)
+    bias = rng.randn(Dout).astype(np.float32)
+    gout = rng.randn(B * N, Dout).astype(np.float32)
+    ref = layer_oracle(x, ei, et, basis, root, bias, relu, gout)
+    got, err = run_general(be, x, ei, et, basis, root, bias, relu, gout, B * N)
+    assert err == 0
+    for g, r, k in zip(got, ref, ('out', 'grad_x', 'grad_basis', 'grad_root', 'grad_bias')):
+        close(g, r, rtol=1e-4, what=k)
+
+
+def test_general_layer_heavy_relation_and_odd_dims(be):
+    """one relation with > 256 edges (several K chunks), many edges into one node, dims not
+    multiples of 4 (scalar load path)."""
+    rng = np.random.RandomState(11)
+    Nn, E, R, Din, Dout = 50, 700, 3, 10, 6
+    src = rng.randint(0, Nn, size=E)
+    dst = rng.randint(0, Nn, size=E)
+    dst[:200] = 3
+    et = np.zeros(E, dtype=np.int64)
+    et[600:] = 2
+    ei = np.stack([src, dst]).astype(np.int64)
+    x = rng.randn(Nn, Din).astype(np.float32)
+    basis = (rng.randn(R, Din, Dout) * 0.3).astype(np.float32)
+    root = (rng.randn(Din, Dout) * 0.3).astype(np.float32)
+    bias = rng.randn(Dout).astype(np.float32)
+    gout = rng.randn(Nn, Dout).astype(np.float32)
+    ref = layer_oracle(x, ei, et, basis, root, bias, 1, gout)
+    got, err = run_general(be, x, ei, et, basis, root, bias, 1, gout, Nn)
+    assert err == 0
+    for g, r, k in zip(got, ref, ('out', 'grad_x', 'grad_basis', 'grad_root', 'grad_bias')):
+        close(g, r, rtol=1e-4, what=k)
+
+
+def test_general_plan_flags_bad_indices(be):
+    Nn, R = 5, 3
+    ei = np.array([[0, 1, 9], [1, -1, 2]], dtype=np.int64)
+    et = np.array([0, 7, 1], dtype=np.int64)
+    x = np.zeros((Nn, 8), np.float32)
+    basis = np.zeros((R, 8, 8), np.float32)
+    _, err = run_general(be, x, ei, et, basis, basis[0], np.zeros(8, np.float32), 0, x, Nn)
+    assert err & FLAG_BAD_EDGE and err & FLAG_BAD_RELATION
+
+
+# ------------------------------------------------------------------------------------------ embedding
+@pytest.mark.parametrize('D', [16, 128, 10])
+def test_embed_l2norm_fwd_bwd(be, D):
+    rng = np.random.RandomState(3)
+    rows, n_ent, n = 40, 100, 33
+    table = rng.randn(rows, D).astype(np.float32)
+    node_map = np.full(n_ent + 1, -1, dtype=np.int64)
+    ents = rng.permutation(n_ent)[:rows - 1]
+    node_map[ents] = np.arange(rows - 1)
+    ids = rng.choice(ents, size=n).astype(np.int64)
+    ids[1] = ids[0]                                  # duplicate id -> accumulated gradient
+    stride = 3 * D                                   # written into x[b, i, :] of a [B, 3, D] tensor
+    g = rng.randn(n, D).astype(np.float32)
+    tt = torch.from_numpy(table.copy()).requires_grad_(True)
+    ref = ref_cpu.direct_encode(tt, torch.from_numpy(node_map), ids)
+    ref.backward(torch.from_numpy(g))
+
+    dt, dm, di = be.put(table), be.put(node_map), be.put(ids)
+    out = be.empty((n, 3, D))
+    inv = be.empty((n,))
+    err = be.zeros((1,), np.int32)
+    be.check(be.lib.mpqe_embed_l2norm_fwd(be.ptr(dt), rows, D, be.ptr(dm), n_ent + 1, be.ptr(di), n, be.ptr(out),
+                                          stride, be.ptr(inv), be.ptr(err), be.stream))
+    o = be.get(out)
+    close(o[:, 0, :], ref.detach().numpy(), what='y')
+    assert np.isnan(o[:, 1:, :]).all()               # nothing written outside the strided rows
+    close(be.get(inv), 1.0 / np.linalg.norm(table[node_map[ids]], axis=1), rtol=1e-5)
+    gt = be.zeros((rows, D))
+    gfull = np.zeros((n, 3, D), np.float32)
+    gfull[:, 0, :] = g
+    dg = be.put(gfull)
+    be.check(be.lib.mpqe_embed_l2norm_bwd(be.ptr(dg), stride, be.ptr(dt), rows, D, be.ptr(dm), n_ent + 1,
+                                          be.ptr(di), n, be.ptr(gt), be.ptr(err), be.stream))
+    close(be.get(gt), tt.grad.numpy(), rtol=1e-4, what='grad_table')
+    assert int(be.get(err)[0]) == 0
+
+
+def test_embed_flags_foreign_and_out_of_range_ids(be):
+    table = np.ones((4, 8), np.float32)
+    node_map = np.array([0, 1, -1, 2], dtype=np.int64)
+    for bad in (2, 17, -3):
+        ids = np.array([0, bad], dtype=np.int64)
+        out = be.empty((2, 8))
+        err = be.zeros((1,), np.int32)
+        dt, dm, di = be.put(table), be.put(node_map), be.put(ids)
+        be.check(be.lib.mpqe_embed_l2norm_fwd(be.ptr(dt), 4, 8, be.ptr(dm), 4, be.ptr(di), 2, be.ptr(out), 8, None,
+                                              be.ptr(err), be.stream))
+        assert int(be.get(err)[0]) == FLAG_BAD_NODE_ID
+        assert (be.get(out)[1] == 0).all()
+
+
+def test_var_rows_fwd_bwd(be):
+    rng = np.random.RandomState(5)
+    B, N, A, D, M = 19, 4, 1, 24, 5
+    V = N - A
+    mode = rng.randn(M, D).astype(np.float32)
+    var_ids = np.array([3, 1, 3], dtype=np.int64)    # two variables of the same mode
+    x = be.empty((B * N, D))
+    err = be.zeros((1,), np.int32)
+    dm, dv = be.put(mode), be.put(var_ids)
+    be.check(be.lib.mpqe_var_rows_fwd(be.ptr(dm), M, D, be.ptr(dv), V, B, N, A, be.ptr(x), be.ptr(err), be.stream))
+    xo = be.get(x).reshape(B, N, D)
+    assert np.isnan(xo[:, :A]).all()
+    np.testing.assert_array_equal(xo[:, A:], np.broadcast_to(mode[var_ids][None], (B, V, D)))
+    gx = rng.randn(B * N, D).astype(np.float32)
+    g0 = rng.randn(M, D).astype(np.float32)
+    gm = be.put(g0)
+    dgx = be.put(gx)
+    be.check(be.lib.mpqe_var_rows_bwd(be.ptr(dgx), M, D, be.ptr(dv), V, B, N, A, be.ptr(gm), be.ptr(err),
+                                      be.stream))
+    ref = g0.astype(np.float64).copy()
+    g3 = gx.reshape(B, N, D).astype(np.float64)
+    for k in range(V):
+        ref[var_ids[k]] += g3[:, A + k].sum(0)
+    close(be.get(gm), ref, rtol=1e-5, what='grad_mode')
+    assert int(be.get(err)[0]) == 0
+
+
+# ------------------------------------------------------------------------------------------ readouts
+@pytest.mark.parametrize('kind', ['sum', 'max', 'mp'])
+@pytest.mark.parametrize('shape', [(8, 4, 3, 16), (33, 2, 1, 20), (5, 3, 2, 128)])
+def test_readout_fwd_bwd(be, kind, shape):
+    B, N, A, D = shape
+    rng = np.random.RandomState(B + N)
+    h = rng.randn(B * N, D).astype(np.float32)
+    h[0, :] = h[1, :]                                 # ties inside graph 0 -> lowest row wins
+    g = rng.randn(B, D).astype(np.float32)
+    ht = torch.from_numpy(h.copy()).requires_grad_(True)
+    bidx = torch.arange(B).repeat_interleave(N)
+    ref = ref_cpu.readout(kind, 'add', {}, ht, bidx, B, N, A)
+    out = be.empty((B, D))
+    arg = be.empty((B, D), np.int32)
+    dh = be.put(h)
+    be.check(be.lib.mpqe_readout_fwd(READOUT_IDS[kind], be.ptr(dh), B, N, A, D, be.ptr(out), be.ptr(arg), be.stream))
+    np.testing.assert_array_equal(be.get(out), ref.detach().numpy())   # exact: adds in node order
+    gh = be.empty((B * N, D))
+    dg = be.put(g)
+    be.check(be.lib.mpqe_readout_bwd(READOUT_IDS[kind], be.ptr(dg), be.ptr(arg), B, N, A, D, be.ptr(gh),
+                                     be.stream))
+    if kind == 'max':
+        # the build's statement: gradient goes to the LOWEST row attaining the max
+        a = be.get(arg)
+        exp = np.zeros((B, N, D), np.float32)
+        for n in range(N):
+            exp[:, n, :] = np.where(a == n, g, 0)
+        np.testing.assert_array_equal(be.get(gh), exp.reshape(B * N, D))
+        _, oa = ref_cpu.scatter_max(torch.from_numpy(h), bidx, B)
+        np.testing.assert_array_equal(a, (oa.numpy() - (np.arange(B) * N)[:, None]))
+    else:
+        ref.backward(torch.from_numpy(g))
+        np.testing.assert_array_equal(be.get(gh), ht.grad.numpy())
+
+
+@pytest.mark.parametrize('op', ['add', 'max', 'mean'])
+def test_scatter_any_index_order(be, op):
+    rng = np.random.RandomState(9)
+    n, D, size = 57, 12, 9
+    src = rng.randn(n, D).astype(np.float32)
+    index = rng.randint(0, size - 2, size=n).astype(np.int64)      # rows size-2, size-1 stay empty
+    src[5] = src[3]
+    index[5] = index[3]                                             # a tie for max
+    g = rng.randn(size, D).astype(np.float32)
+    st = torch.from_numpy(src.copy()).requires_grad_(True)
+    it = torch.from_numpy(index)
+    if op == 'max':
+        ref, ref_arg = ref_cpu.scatter_max(st, it, size)
+    else:
+        ref = ref_cpu._SCATTER[op](st, it, size)
+    ref.backward(torch.from_numpy(g))
+    wsb = be.lib.mpqe_scatter_workspace_bytes(n, size)
+    ws = be.nbytes(wsb)
+    out = be.empty((size, D))
+    arg = be.empty((size, D), np.int64)
+    err = be.zeros((1,), np.int32)
+    ds, di = be.put(src), be.put(index)
+    be.check(be.lib.mpqe_scatter_fwd(SCATTER_IDS[op], be.ptr(ds), be.ptr(di), n, D, size, be.ptr(out), be.ptr(arg),
+                                     be.ptr(ws), wsb, be.ptr(err), be.stream))
+    close(be.get(out), ref.detach().numpy(), what='out')
+    if op == 'max':
+        np.testing.assert_array_equal(be.get(arg), ref_arg.numpy())
+    gs = be.empty((n, D))
+    dg = be.put(g)
+    be.check(be.lib.mpqe_scatter_bwd(SCATTER_IDS[op], be.ptr(dg), be.ptr(di), be.ptr(arg), n, D, size,
+                                     be.ptr(gs), be.ptr(ws), wsb, be.stream))
+    close(be.get(gs), st.grad.numpy(), what='grad_src')
+    assert int(be.get(err)[0]) == 0
+    # out-of-range index is flagged, not dereferenced
+    index[0] = size + 3
+    di2 = be.put(index)
+    be.check(be.lib.mpqe_scatter_fwd(SCATTER_IDS[op], be.ptr(ds), be.ptr(di2), n, D, size, be.ptr(out),
+                                     be.ptr(arg), be.ptr(ws), wsb, be.ptr(err), be.stream))
+    assert int(be.get(err)[0]) == FLAG_BAD_INDEX
+
+
+# ------------------------------------------------------------------------------------------ scoring / loss
+@pytest.mark.parametrize('ragged', [False, True])
+def test_cosine_fwd_bwd(be, ragged):
+    rng = np.random.RandomState(13)
+    B, D = 21, 48
+    q = rng.randn(B, D).astype(np.float32)
+    q[2] = 0.0                                        # zero query: eps clamp path
+    lengths = rng.randint(0, 4, size=B) if ragged else np.ones(B, dtype=np.int64)
+    qrow = np.repeat(np.arange(B), lengths).astype(np.int64)
+    n = qrow.shape[0]
+    t = rng.randn(n, D).astype(np.float32)
+    gs = rng.randn(n).astype(np.float32)
+    qt, tt = torch.from_numpy(q.copy()).requires_grad_(True), torch.from_numpy(t.copy()).requires_grad_(True)
+    rep = qt.repeat_interleave(torch.from_numpy(np.asarray(lengths)), dim=0)
+    ref = torch.nn.functional.cosine_similarity(rep, tt, dim=1)
+    ref.backward(torch.from_numpy(gs))
+    dq, dt, dr = be.put(q), be.put(t), (be.put(qrow) if ragged else None)
+    sc = be.empty((n,))
+    be.check(be.lib.mpqe_cosine_fwd(be.ptr(dq), be.ptr(dr), be.ptr(dt), n, D, 1e-8, be.ptr(sc), be.stream))
+    close(be.get(sc), ref.detach().numpy(), what='scores')
+    gq = be.zeros((B, D)) if ragged else be.empty((B, D))
+    gt = be.empty((n, D))
+    dgs = be.put(gs)
+    be.check(be.lib.mpqe_cosine_bwd(be.ptr(dgs), be.ptr(dq), be.ptr(dr), be.ptr(dt), n, D, 1e-8,
+                                    be.ptr(gq), be.ptr(gt), be.stream))
+    close(be.get(gt), tt.grad.numpy(), rtol=1e-4, what='grad_t')
+    mine, theirs = be.get(gq), qt.grad.numpy()
+    keep = np.ones(B, bool)
+    keep[2] = False            # d/dq at q = 0 is defined by the eps clamp only; compared separately
+    close(mine[keep], theirs[keep], rtol=1e-4, what='grad_q')
+    assert np.isfinite(mine[2]).all()
+
+
+@pytest.mark.parametrize('n', [1, 7, 512, 1000])
+def test_hinge_fwd_bwd(be, n):
+    rng = np.random.RandomState(n)
+    pos = rng.uniform(-1, 1, size=n).astype(np.float32)
+    neg = rng.uniform(-1, 1, size=n).astype(np.float32)
+    margin = 0.6                                     # about half of the terms are clamped
+    pt, nt = torch.from_numpy(pos.copy()).requires_grad_(True), torch.from_numpy(neg.copy()).requires_grad_(True)
+    ref = torch.clamp(margin - (pt - nt), min=0).mean()
+    (ref * 1.7).backward()
+    loss = be.empty((1,))
+    dp, dn = be.put(pos), be.put(neg)
+    be.check(be.lib.mpqe_hinge_fwd(be.ptr(dp), be.ptr(dn), n, margin, be.ptr(loss), be.stream))
+    close(be.get(loss)[0], ref.item(), rtol=1e-5)
+    gp, gn = be.empty((n,)), be.empty((n,))
+    gl = be.put(np.array([1.7], np.float32))
+    be.check(be.lib.mpqe_hinge_bwd(be.ptr(dp), be.ptr(dn), n, margin, be.ptr(gl), be.ptr(gp), be.ptr(gn), be.stream))
+    close(be.get(gp), pt.grad.numpy(), rtol=1e-5)
+    close(be.get(gn), nt.grad.numpy(), rtol=1e-5)
