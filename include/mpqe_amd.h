@@ -81,7 +81,8 @@ int mpqe_collate_template(int query_type, int64_t batch_size,
  * reference: DirectEncoder.forward encoders.py:40-43 with the features closure
  * data_utils.py:35 (row = node_map[id]; v = table[row]; y = v / ||v||_2, no eps), written
  * where RGCNEncoderDecoder.forward puts it (model.py:418-420):
- *   out[i*out_row_stride + 0..dim) = y_i.   inv_norm[i] = 1/||v_i|| (optional, for bwd). */
+ *   out[i*out_row_stride + 0..dim) = y_i.   inv_norm[i] = 1/||v_i|| (optional, for bwd).
+ * node_map == NULL means ids are table rows already (identity map).                        */
 int mpqe_embed_l2norm_fwd(const float *table, int64_t table_rows, int64_t dim,
                           const int64_t *node_map, int64_t node_map_len,
                           const int64_t *ids, int64_t n,
@@ -170,8 +171,9 @@ int mpqe_readout_bwd(int kind, const float *grad_out /*[B, dim]*/, const int32_t
                      int64_t batch_size, int64_t num_nodes, int64_t num_anchors, int64_t dim,
                      float *grad_h /*[B*N, dim], overwritten*/, void *stream);
 /* torch_scatter.scatter_add / scatter_max / scatter_mean along dim 0 (reference call sites
- * model.py:351-355, 381, 384, 509, 547). index must be sorted non-decreasing? NO: any order.
- * out[i] = reduce_{j: index[j] = i} src[j]; empty rows are 0; arg = lowest j on ties, -1 empty. */
+ * model.py:351-355, 381, 384, 509, 547). index may come in any order.
+ * out[i] = reduce_{j: index[j] = i} src[j]; empty rows are 0; arg = lowest j on ties, -1 empty.
+ * add / mean accumulate with fp32 atomics (order-dependent last bits when rows collide).     */
 size_t mpqe_scatter_workspace_bytes(int64_t n_src, int64_t dim_size);
 int mpqe_scatter_fwd(int op, const float *src, const int64_t *index, int64_t n_src, int64_t dim,
                      int64_t dim_size, float *out /*[dim_size, dim]*/, int64_t *arg /*MAX only*/,

@@ -45,6 +45,13 @@ extern "C" int mpqe_collate_template(int query_type, int64_t B, const int64_t *e
 // ------------------------------------------------------------------------------------ embedding
 __device__ __forceinline__ long long lookup_row(const long long *node_map, long long map_len, long long id,
                                                 long long table_rows, int32_t *err) {
+    if (!node_map) {                       // identity map: ids are table rows
+        if (id < 0 || id >= table_rows) {
+            flag_error(err, MPQE_FLAG_BAD_NODE_ID);
+            return -1;
+        }
+        return id;
+    }
     if (id < 0 || id >= map_len) {
         flag_error(err, MPQE_FLAG_BAD_NODE_ID);
         return -1;
@@ -100,7 +107,7 @@ extern "C" int mpqe_embed_l2norm_fwd(const float *table, int64_t table_rows, int
                                      int64_t out_row_stride, float *inv_norm, int32_t *err, void *stream) {
     if (n < 0 || dim <= 0 || table_rows < 0 || out_row_stride < dim) return MPQE_ERR_INVALID_ARG;
     if (n == 0) return MPQE_OK;
-    if (!table || !node_map || !ids || !out) return MPQE_ERR_INVALID_ARG;
+    if (!table || !ids || !out) return MPQE_ERR_INVALID_ARG;
     const int vec = dim % 4 == 0 && out_row_stride % 4 == 0 && (uintptr_t)table % 16 == 0 && (uintptr_t)out % 16 == 0;
     hipLaunchKernelGGL(embed_l2norm_fwd_kernel, dim3((unsigned)((n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)),
                        dim3(256), 0, as_stream(stream), table, (long long)table_rows, (int)dim,
@@ -143,7 +150,7 @@ extern "C" int mpqe_embed_l2norm_bwd(const float *grad_out, int64_t grad_row_str
                                      const int64_t *ids, int64_t n, float *grad_table, int32_t *err, void *stream) {
     if (n < 0 || dim <= 0 || grad_row_stride < dim) return MPQE_ERR_INVALID_ARG;
     if (n == 0) return MPQE_OK;
-    if (!grad_out || !table || !node_map || !ids || !grad_table) return MPQE_ERR_INVALID_ARG;
+    if (!grad_out || !table || !ids || !grad_table) return MPQE_ERR_INVALID_ARG;
     hipLaunchKernelGGL(embed_l2norm_bwd_kernel, dim3((unsigned)((n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)),
                        dim3(256), 0, as_stream(stream), grad_out, (long long)grad_row_stride, table,
                        (long long)table_rows, (int)dim, (const long long *)node_map, (long long)node_map_len,

@@ -1,0 +1,145 @@
+"""Query-graph collation with the reference's interface (mpqe/data_utils.py:268-426).
+
+get_query_graph returns what the reference returns -- (anchor_ids [B,A] int64, var_ids [V]
+int64, graph) -- but the graph's B-fold replicated tensors (edge_index, edge_type, batch) are
+expanded ON THE DEVICE from the <= 3-edge template by one kernel instead of B-way torch.cat
+on the host (reference: PyG Batch.from_data_list, data_utils.py:402-405).
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+from . import ops
+from .graph import reverse_relation
+
+
+class QueryGraphBatch(object):
+    """Stand-in for the PyG `Batch` the reference passes around: attributes edge_index
+    [2, B*E], edge_type [B*E], batch [B*N], x, num_nodes and .to(device). Holds the template
+    so the encoder can take the scatter-free fused path."""
+
+    def __init__(self, template):
+        self.template = template
+        self.num_nodes = template.B * template.N
+        self.x = None
+        self.device = None
+        self._tensors = None
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise RuntimeError('mpqe_amd: query graphs live on the GPU; .to(%s) is not supported' % device)
+        if device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        if self._tensors is None or self.device != device:
+            ei, et, bt = ops.collate_template(self.template, device)
+            ei._mpqe_graph = self.template          # lets RGCNConv.forward recognise the batch
+            self._tensors = (ei, et, bt)
+            self.device = device
+        return self
+
+    def _get(self, i):
+        if self._tensors is None:
+            raise RuntimeError('mpqe_amd: call .to("cuda") first; graph tensors are built on the device')
+        return self._tensors[i]
+
+    edge_index = property(lambda self: self._get(0))
+    edge_type = property(lambda self: self._get(1))
+    batch = property(lambda self: self._get(2))
+
+
+class QueryDataset(Dataset):
+    """reference: data_utils.py:268-311. One formula per batch, drawn with probability
+    proportional to its number of queries; the index window wraps around the formula's list."""
+
+    def __init__(self, queries, *args, **kwargs):
+        self.queries = queries
+        self.num_formula_queries = OrderedDict((f, len(qs)) for f, qs in queries.items())
+        self.num_queries = sum(self.num_formula_queries.values())
+        self.max_num_queries = max(self.num_formula_queries.values())
+
+    def __len__(self):
+        return self.max_num_queries
+
+    def __getitem__(self, index):
+        return index
+
+    def collate_fn(self, idx_list):
+        counts = np.array(list(self.num_formula_queries.values()))
+        pick = np.argmax(np.random.multinomial(1, counts / float(self.num_queries)))
+        formula = list(self.num_formula_queries.keys())[pick]
+        n = self.num_formula_queries[formula]
+        lo, hi = idx_list[0], idx_list[-1]
+        start = lo % n
+        end = min((hi + 1) % n, n)
+        if end <= start:
+            end = n
+        return formula, self.queries[formula][start:end]
+
+
+class RGCNQueryDataset(QueryDataset):
+    """reference: data_utils.py:314-409."""
+    # kept as class attributes because the reference exposes them (model.py:426)
+    query_diameters = {'1-chain': 1, '2-chain': 2, '3-chain': 3, '2-inter': 1, '3-inter': 1,
+                       '3-inter_chain': 2, '3-chain_inter': 2}
+
+    def __init__(self, queries, enc_dec):
+        super(RGCNQueryDataset, self).__init__(queries)
+        self.mode_ids = enc_dec.mode_ids
+        self.rel_ids = enc_dec.rel_ids
+
+    def collate_fn(self, idx_list):
+        formula, queries = super(RGCNQueryDataset, self).collate_fn(idx_list)
+        anchor_ids, var_ids, graph = RGCNQueryDataset.get_query_graph(formula, queries, self.rel_ids,
+                                                                      self.mode_ids)
+        return formula, queries, anchor_ids, var_ids, graph
+
+    @staticmethod
+    def get_query_graph(formula, queries, rel_ids, mode_ids):
+        info = ops.template_info(formula.query_type)
+        B, A, V, E = len(queries), info.num_anchors, info.num_vars, info.num_edges
+        if A != len(formula.anchor_modes):
+            raise ValueError('formula %s has %d anchor modes, template expects %d'
+                             % (formula, len(formula.anchor_modes), A))
+        anchor_ids = np.empty((B, A), dtype=np.int64)
+        for i in range(A):
+            anchor_ids[:, i] = [q.anchor_nodes[i] for q in queries]
+        nodes = formula.get_nodes()
+        var_ids = np.array([mode_ids[nodes[info.var_node[k]]] for k in range(V)], dtype=np.int64)
+        rels = formula.get_rels()
+        edge_type = [rel_ids[reverse_relation(rels[info.rel_label[e]])] for e in range(E)]
+        graph = QueryGraphBatch(ops.Template(formula.query_type, B, edge_type))
+        return torch.from_numpy(anchor_ids), torch.from_numpy(var_ids), graph
+
+
+def make_data_iterator(data_loader):
+    while True:
+        for item in data_loader:
+            yield item
+
+
+def get_queries_iterator(queries, batch_size, enc_dec=None):
+    """reference: data_utils.py:422-426."""
+    dataset = RGCNQueryDataset(queries, enc_dec)
+    loader = DataLoader(dataset, batch_size, shuffle=False, collate_fn=dataset.collate_fn)
+    return make_data_iterator(loader)
+
+
+def make_feature_modules(node_ids_by_mode, embed_dim, num_entities=None):
+    """The embedding-table layout of load_graph (reference data_utils.py:20-35) from
+    {mode: list of global entity ids}: per mode an nn.Embedding(count + 1, D) initialised
+    N(0, 1/D), and the int64 LUT global id -> row (-1 = not of any mode)."""
+    if num_entities is None:
+        num_entities = sum(len(v) for v in node_ids_by_mode.values())
+    node_maps = torch.full((num_entities + 1,), -1, dtype=torch.long)
+    feature_modules = {}
+    for mode, ids in node_ids_by_mode.items():
+        ids = torch.as_tensor(np.asarray(ids), dtype=torch.long)
+        if (node_maps[ids] != -1).any():
+            raise ValueError('entity id listed under two modes')
+        node_maps[ids] = torch.arange(ids.shape[0])
+        feature_modules[mode] = torch.nn.Embedding(ids.shape[0] + 1, embed_dim)
+        feature_modules[mode].weight.data.normal_(0, 1. / embed_dim)
+    return feature_modules, node_maps

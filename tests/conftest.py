@@ -87,3 +87,37 @@ def enc_case(request):
 def conv_case(request):
     z = np.load(request.param)
     return {k: z[k] for k in z.files}
+
+
+class CaseGraph(object):
+    """The attributes RGCNEncoderDecoder reads from the KG container, rebuilt from a fixture."""
+
+    def __init__(self, case):
+        from collections import OrderedDict
+        self.relations = case.relations
+        self.feature_dims = {m: case.D for m in case.modes}
+        self.rel_edges = OrderedDict()
+        for m in case.relations:
+            for (to, name) in case.relations[m]:
+                self.rel_edges[(m, name, to)] = 1.0
+        self.mode_weights = OrderedDict((m, 1.0) for m in case.mode_weights_order)
+        self.full_lists = {case.formula.target_mode: list(case.meta['full_list_target_mode'])}
+        self.features = None
+        self.adj_lists = None
+
+
+def build_model(case, device):
+    """This package's RGCNEncoderDecoder wired like the reference's start-up code, with the
+    fixture's parameters loaded through load_state_dict (strict: key parity with the reference)."""
+    import torch
+    from mpqe_amd.data_utils import make_feature_modules
+    from mpqe_amd.encoders import DirectEncoder
+    from mpqe_amd.model import RGCNEncoderDecoder
+    feature_modules, node_maps = make_feature_modules(case.ids, case.D, case.num_entities)
+    assert torch.equal(node_maps, torch.from_numpy(case.arrays['node_map']))
+    enc = DirectEncoder(None, feature_modules, node_maps)
+    cfg = case.cfg
+    model = RGCNEncoderDecoder(CaseGraph(case), enc, cfg['readout'], cfg['scatter_op'], 0, cfg['weight_decay'],
+                               cfg['num_layers'], cfg['shared_layers'], cfg['adaptive'])
+    model.load_state_dict(case.params(), strict=True)
+    return model.to(device)
