@@ -1,0 +1,302 @@
+"""Throughput of the MPQE R-GCN query-graph encoder hot path (forward + backward) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): the reference's post-burn-in training step on an
+AIFB-shaped synthetic KG -- 11 batches of B=512 query graphs (1x 1/2/3-chain, 2x each of
+2-inter / 3-inter / 3-inter_chain / 3-chain_inter; reference train_helpers.py:81, 97-112),
+embed_dim 128, readout 'mp' (TM), adaptive, num_layers 3, unshared layers. A step = feature
+assembly -> L layers -> readout -> cosine scores vs positive and negative targets -> hinge,
+forward and backward to every parameter gradient, with all inputs already resident in HBM.
+Collation from python objects and the optimiser are outside the metric.
+Each rank runs the same-sized workload (weak scaling); N > 1 adds one RCCL all-reduce of
+the flattened gradients per step.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PATH_WEIGHT, INTER_WEIGHT = 0.01, 0.005     # reference train_helpers.py:60-61
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3                # MI355X_MICROARCH.md: fp32 MFMA dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--kg', default='aifb')
+    ap.add_argument('--embed-dim', type=int, default=128)
+    ap.add_argument('--batch-size', type=int, default=512)
+    ap.add_argument('--readout', default='mp')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--path', default='auto', choices=['auto', 'modules', 'fused'])
+    return ap.parse_args()
+
+
+class StepData(object):
+    """One training step's 11 batches, pre-collated and resident in HBM."""
+
+    def __init__(self, schema, model, B, rng, device):
+        from mpqe_amd import synthetic
+        from mpqe_amd.data_utils import RGCNQueryDataset
+        self.batches = []
+        for qt, hard in synthetic.FULL_MIX:
+            formula = synthetic.sample_formula(schema, qt, rng)
+            A = len(formula.anchor_modes)
+            anchors = np.stack([synthetic._pick(schema, m, rng, size=B) for m in formula.anchor_modes], axis=1)
+            targets = synthetic._pick(schema, formula.target_mode, rng, size=B)
+            negs = synthetic._pick(schema, formula.target_mode, rng, size=B)
+            # light-weight query records: get_query_graph only reads anchor_nodes
+            queries = [_Q(tuple(int(v) for v in anchors[b])) for b in range(B)]
+            anchor_ids, var_ids, graph = RGCNQueryDataset.get_query_graph(formula, queries, model.rel_ids,
+                                                                          model.mode_ids)
+            weight = 1.0 if qt == '1-chain' else (INTER_WEIGHT if 'inter' in qt else PATH_WEIGHT)
+            self.batches.append(dict(
+                formula=formula, queries=queries, weight=weight, A=A,
+                anchor_ids=anchor_ids.to(device), var_ids=var_ids.to(device), graph=graph.to(device),
+                targets=torch.from_numpy(targets).to(device), negs=torch.from_numpy(negs).to(device),
+                anchor_np=anchors, targets_np=targets, negs_np=negs))
+        self.num_graphs = B * len(self.batches)
+
+
+class _Q(object):
+    __slots__ = ('anchor_nodes',)
+
+    def __init__(self, anchor_nodes):
+        self.anchor_nodes = anchor_nodes
+
+
+def step_modules(model, data):
+    """The step through the drop-in modules (one autograd graph, one backward)."""
+    from mpqe_amd import ops
+    model.zero_grad(set_to_none=True)
+    loss = None
+    for b in data.batches:
+        out = model.encode(b['formula'], b['queries'], b['anchor_ids'], b['var_ids'], b['graph'])
+        pos = model.score(b['formula'], out, b['targets'])
+        neg = model.score(b['formula'], out, b['negs'])
+        l = ops.hinge(pos, neg, 1.0) * b['weight']
+        loss = l if loss is None else loss + l
+    loss.backward()
+    return loss
+
+
+def layer_work(data, model):
+    """Algorithmic work of one step's R-GCN layers: per query graph and executed
+    layer flops fwd = 2 D^2 (E+N), fwd+bwd = 6 D^2 (E+N); scatter-aggregate bytes fwd+bwd =
+    12 D (E+2N)."""
+    from mpqe_amd.data_utils import RGCNQueryDataset
+    D = model.emb_dim
+    flops_fwd = flops_all = bytes_all = 0
+    launches = 0
+    for b in data.batches:
+        t = b['graph'].template
+        L = RGCNQueryDataset.query_diameters[t.query_type] if model.adaptive else model.num_layers
+        flops_fwd += L * t.B * 2 * D * D * (t.E + t.N)
+        flops_all += L * t.B * 6 * D * D * (t.E + t.N)
+        bytes_all += L * t.B * 12 * D * (t.E + 2 * t.N)
+        launches += L
+    return flops_fwd, flops_all, bytes_all, launches
+
+
+def time_layer_forward(model, data, reps=20):
+    """Average duration of the dominant kernel (the fused template layer forward,
+    rgcn_tmpl_fwd_kernel: exactly one launch per mpqe_rgcn_template_fwd call), measured with
+    HIP events on the stream the kernel is launched on, over the layer calls of one step."""
+    from mpqe_amd import ops
+    from mpqe_amd.data_utils import RGCNQueryDataset
+    D = model.emb_dim
+    calls = []
+    for b in data.batches:
+        t = b['graph'].template
+        L = RGCNQueryDataset.query_diameters[t.query_type] if model.adaptive else model.num_layers
+        x = torch.randn(t.B * t.N, D, device='cuda')
+        for i in range(L):
+            layer = model.layers[i] if i < L - 1 else model.layers[-1]
+            calls.append((t, x, layer, i < L - 1))
+    lib = ops.lib()
+    stream = torch.cuda.current_stream()
+    outs = [torch.empty_like(c[1]) for c in calls]
+
+    def launch(c, out):
+        t, x, layer, relu = c
+        st = lib.mpqe_rgcn_template_fwd(t.qid, t.B, t.et_ptr, x.data_ptr(), layer.basis.data_ptr(),
+                                        layer.num_relations, layer.root.data_ptr(), layer.bias.data_ptr(), D, D,
+                                        int(relu), out.data_ptr(), stream.cuda_stream)
+        assert st == 0
+    for c, o in zip(calls, outs):
+        launch(c, o)
+    torch.cuda.synchronize()
+    total_ms, n = 0.0, 0
+    for _ in range(reps):
+        evs = []
+        for c, o in zip(calls, outs):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            launch(c, o)
+            e1.record(stream)
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        for e0, e1 in evs:
+            total_ms += e0.elapsed_time(e1)
+            n += 1
+    return total_ms / n * 1e-3, len(calls)
+
+
+def cpu_baseline(args, schema, model_state, node_maps, rel_ids, mode_ids, cfg, seconds):
+    """The oracle in the reference's op sequence (per-edge weight copy + bmm + index_add, two
+    encoder passes per loss: reference model.py:280-305, 478-482) timed on the host cores for a
+    bounded sample of the same workload."""
+    from mpqe_amd import synthetic
+    from oracle import ref_cpu
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    rng = np.random.RandomState(777)
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model_state.items()}
+    B = args.batch_size
+    done_graphs, t0, steps = 0, time.perf_counter(), 0
+    while True:
+        for p in params.values():
+            p.grad = None
+        loss = 0
+        for qt, hard in synthetic.FULL_MIX:
+            formula = synthetic.sample_formula(schema, qt, rng)
+            queries = synthetic.sample_queries(schema, formula, B, rng)
+            col = ref_cpu.collate(formula, queries, rel_ids, mode_ids)
+            tg = [q.target_node for q in queries]
+            ng = [q.neg_samples[0] for q in queries]
+            t_start = time.perf_counter()
+            w = 1.0 if qt == '1-chain' else (INTER_WEIGHT if 'inter' in qt else PATH_WEIGHT)
+            loss = loss + w * ref_cpu.margin_loss(params, cfg, node_maps, formula, col, tg, ng)
+            done_graphs += B
+        loss.backward()
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or steps >= 20:
+            break
+    el = time.perf_counter() - t0
+    return dict(value=done_graphs / el, unit='query-graphs/s', cores=cores, kind='port',
+                sample='%d full-mix steps (%d query graphs), oracle in reference op sequence, torch %s CPU, '
+                       '%d threads, includes python collation of the sample' % (steps, done_graphs,
+                                                                                torch.__version__, cores))
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    else:
+        torch.cuda.set_device(0)
+    device = torch.device('cuda', torch.cuda.current_device())
+
+    from mpqe_amd import synthetic
+    from mpqe_amd.data_utils import make_feature_modules
+    from mpqe_amd.encoders import DirectEncoder
+    from mpqe_amd.model import RGCNEncoderDecoder
+    torch.manual_seed(0)                                  # identical replicas on every rank
+    D = args.embed_dim
+    schema = synthetic.make_schema(*synthetic.KG_SHAPES[args.kg], seed=0)
+    graph = synthetic.SchemaGraph(schema, D)
+    fm, node_maps = make_feature_modules(schema.ids, D, schema.num_entities)
+    adaptive = args.readout == 'mp'
+    model = RGCNEncoderDecoder(graph, DirectEncoder(None, fm, node_maps), readout=args.readout, num_layers=3,
+                               shared_layers=False, adaptive=adaptive, weight_decay=0)
+    cpu_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(device)
+    model.validate = False                                # no per-call D2H flag read in the timed loop
+    rng = np.random.RandomState(1000 + rank)
+    pool = [StepData(schema, model, args.batch_size, rng, device) for _ in range(4)]
+
+    reducer = None
+    if world > 1:
+        from mpqe_amd.parallel import GradReducer
+        reducer = GradReducer(model)
+
+    def one_step(i):
+        loss = step_modules(model, pool[i % len(pool)])
+        if reducer is not None:
+            reducer.all_reduce()
+        return loss
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    graphs_per_step = pool[0].num_graphs * world
+    value = graphs_per_step * args.steps / elapsed
+    out = {
+        'metric': 'query-graphs/sec (encoder fwd+bwd)', 'value': value, 'unit': 'query-graphs/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'AIFB-shaped full query mix: 11 batches x B=%d per step (1/2/3-chain, 2x each of '
+                               '2-inter, 3-inter, 3-inter_chain, 3-chain_inter), embed_dim=%d, readout=%s, '
+                               'adaptive=%s, num_layers=3 unshared, KG %s (%d entities, %d typed relations)'
+                               % (args.batch_size, D, args.readout, adaptive, args.kg, schema.num_entities,
+                                  len(graph.rel_edges)),
+                   'global_query_graphs_per_step': graphs_per_step,
+                   'parallelism': 'dp%d (graphs sharded by rank, RCCL all-reduce of gradients)' % world
+                                  if world > 1 else 'single GPU',
+                   'host_path': 'drop-in modules (one autograd graph per step)'},
+    }
+    if rank == 0:
+        flops_fwd, flops_all, bytes_all, launches = layer_work(pool[0], model)
+        dur, ncalls = time_layer_forward(model, pool[0])
+        per_launch_flops = flops_fwd / launches
+        achieved = per_launch_flops / dur / 1e12
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'rgcn_tmpl_fwd_kernel', 'achieved': achieved,
+                           'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_F32_PEAK_TFLOPS,
+                           'traffic': None, 'avg_launch_us': dur * 1e6,
+                           'algorithmic_flops_per_launch': per_launch_flops,
+                           'launches_per_step': launches}
+        out['step_work'] = {'layer_flops_fwd_bwd': flops_all, 'scatter_aggregate_bytes_fwd_bwd': bytes_all,
+                            'layer_tflops_over_whole_step': flops_all / (elapsed / args.steps) / 1e12}
+        if world == 1 and not args.no_cpu_baseline:
+            cfg = dict(readout=args.readout, scatter_op='add', num_layers=3, adaptive=adaptive, weight_decay=0)
+            out['cpu_baseline'] = cpu_baseline(args, schema, cpu_state, node_maps, model.rel_ids, model.mode_ids,
+                                               cfg, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

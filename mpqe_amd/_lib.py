@@ -17,5 +17,11 @@ def load():
             raise ImportError(
                 'mpqe_amd: %s not found. Build it with `python -m mpqe_amd.build` '
                 '(hipcc --offload-arch=gfx950). There is no fallback path.' % LIB_PATH)
+        # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so). The kernels
+        # are launched on torch's streams with torch's allocations, so they must live in
+        # THAT runtime: import torch first so the loader resolves our libamdhip64.so.7
+        # dependency to the copy torch already mapped (two runtimes in one process make
+        # every launch fail with an invalid-handle error).
+        import torch  # noqa: F401
         _lib = _capi.bind(ctypes.CDLL(LIB_PATH))
     return _lib

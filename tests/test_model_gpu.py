@@ -109,12 +109,12 @@ def test_bad_entity_id_raises_index_error(enc_case):
     targets[0] = c.num_entities + 50
     with pytest.raises(IndexError):
         model.forward(c.formula, c.queries, targets)
-    # a valid id of another mode maps to -1 in the LUT -> also an IndexError, like nn.Embedding(-1)
-    foreign = [m for m in c.modes if m != c.formula.target_mode]
-    if foreign:
-        targets[0] = int(c.ids[foreign[0]][0])
-        with pytest.raises(IndexError):
-            model.forward(c.formula, c.queries, targets)
+    # an id that belongs to no mode maps to -1 in the LUT -> IndexError, like nn.Embedding(-1).
+    # (An id of ANOTHER mode has a valid row number in its own table, so -- exactly as in the
+    # reference, data_utils.py:23-35 -- it silently reads that row of the wrong table.)
+    targets[0] = c.num_entities
+    with pytest.raises(IndexError):
+        model.forward(c.formula, c.queries, targets)
 
 
 def test_general_path_bad_edge_raises():
