@@ -96,6 +96,55 @@ def step_modules(model, data):
     return loss
 
 
+def pack_for_fused(step, data):
+    return step.pack([dict(formula=b['formula'], anchor_ids=b['anchor_np'], targets=b['targets_np'],
+                           negs=b['negs_np'], weight=b['weight']) for b in data.batches])
+
+
+def time_fused_kernels(step, packed, data, model, reps=20):
+    """Per-launch durations of the three MFMA kernel families of the fused step, from HIP events
+    recorded by the library on the stream it launches on (events bracket single launches)."""
+    from mpqe_amd.data_utils import RGCNQueryDataset
+    D = model.emb_dim
+    Ls = [RGCNQueryDataset.query_diameters[b['graph'].template.query_type] if model.adaptive
+          else model.num_layers for b in data.batches]
+    Lmax = max(Ls)
+    n_ev = 2 * (2 * Lmax + 1)
+    fam = {'step_layer_fwd_kernel': [0.0, 0, 0.0], 'step_layer_bwd_x_kernel': [0.0, 0, 0.0],
+           'step_grad_w_kernel': [0.0, 0, 0.0]}          # ms, launches, flops
+    import ctypes
+    for _ in range(reps):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
+        for e in evs:
+            e.record()                                   # creates the underlying hipEvent_t
+        arr = (ctypes.c_void_p * n_ev)(*[e.cuda_event for e in evs])
+        step.run(packed, events=arr)
+        torch.cuda.synchronize()
+        k = 0
+        for p in range(Lmax):
+            fl = sum(2.0 * b['graph'].template.B * D * D * (b['graph'].template.E + b['graph'].template.N)
+                     for b, L in zip(data.batches, Ls) if L > p)
+            f = fam['step_layer_fwd_kernel']
+            f[0] += evs[k].elapsed_time(evs[k + 1]); f[1] += 1; f[2] += fl
+            k += 2
+        for p in range(Lmax - 1, -1, -1):
+            fl = sum(2.0 * b['graph'].template.B * D * D * (b['graph'].template.E + b['graph'].template.N)
+                     for b, L in zip(data.batches, Ls) if L > p)
+            f = fam['step_layer_bwd_x_kernel']
+            f[0] += evs[k].elapsed_time(evs[k + 1]); f[1] += 1; f[2] += fl
+            k += 2
+        fl = sum(2.0 * L * b['graph'].template.B * D * D * (b['graph'].template.E + b['graph'].template.N)
+                 for b, L in zip(data.batches, Ls))
+        f = fam['step_grad_w_kernel']
+        f[0] += evs[k].elapsed_time(evs[k + 1]); f[1] += 1; f[2] += fl
+    out = []
+    for name, (ms, n, fl) in fam.items():
+        out.append(dict(kernel=name, launches_per_step=n // reps, avg_launch_us=ms / n * 1e3,
+                        algorithmic_flops_per_launch=fl / n, achieved=fl / (ms * 1e-3) / 1e12,
+                        total_us_per_step=ms / reps * 1e3))
+    return out
+
+
 def layer_work(data, model):
     """Algorithmic work of one step's R-GCN layers: per query graph and executed
     layer flops fwd = 2 D^2 (E+N), fwd+bwd = 6 D^2 (E+N); scatter-aggregate bytes fwd+bwd =
@@ -158,42 +207,74 @@ def time_layer_forward(model, data, reps=20):
     return total_ms / n * 1e-3, len(calls)
 
 
+def usable_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(args, schema, model_state, node_maps, rel_ids, mode_ids, cfg, seconds):
     """The oracle in the reference's op sequence (per-edge weight copy + bmm + index_add, two
     encoder passes per loss: reference model.py:280-305, 478-482) timed on the host cores for a
-    bounded sample of the same workload."""
+    bounded sample of the same workload: whole formula batches of the full mix, forward + backward,
+    drawn in mix order until the time budget is spent. The torch thread count is calibrated on one
+    3-chain batch (1, 8, 16, 32, all usable cores) and the fastest is used and reported."""
     from mpqe_amd import synthetic
     from oracle import ref_cpu
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    B = args.batch_size
     rng = np.random.RandomState(777)
     params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model_state.items()}
-    B = args.batch_size
-    done_graphs, t0, steps = 0, time.perf_counter(), 0
-    while True:
+
+    def make(qt):
+        formula = synthetic.sample_formula(schema, qt, rng)
+        anchors = np.stack([synthetic._pick(schema, m, rng, size=B) for m in formula.anchor_modes], axis=1)
+        queries = [_Q(tuple(int(v) for v in anchors[b])) for b in range(B)]
+        col = ref_cpu.collate(formula, queries, rel_ids, mode_ids)
+        return formula, col, synthetic._pick(schema, formula.target_mode, rng, size=B), \
+            synthetic._pick(schema, formula.target_mode, rng, size=B)
+
+    def run(item, w):
+        formula, col, tg, ng = item
         for p in params.values():
             p.grad = None
-        loss = 0
-        for qt, hard in synthetic.FULL_MIX:
-            formula = synthetic.sample_formula(schema, qt, rng)
-            queries = synthetic.sample_queries(schema, formula, B, rng)
-            col = ref_cpu.collate(formula, queries, rel_ids, mode_ids)
-            tg = [q.target_node for q in queries]
-            ng = [q.neg_samples[0] for q in queries]
-            t_start = time.perf_counter()
-            w = 1.0 if qt == '1-chain' else (INTER_WEIGHT if 'inter' in qt else PATH_WEIGHT)
-            loss = loss + w * ref_cpu.margin_loss(params, cfg, node_maps, formula, col, tg, ng)
-            done_graphs += B
+        loss = w * ref_cpu.margin_loss(params, cfg, node_maps, formula, col, tg, ng)
         loss.backward()
-        steps += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or steps >= 20:
+
+    avail = usable_cores()
+    cand = sorted(set(c for c in (1, 8, 16, 32, avail) if c <= avail))
+    probe = make('3-chain')
+    timing = {}
+    for c in cand:
+        torch.set_num_threads(c)
+        run(probe, 1.0)
+        t0 = time.perf_counter()
+        run(probe, 1.0)
+        timing[c] = time.perf_counter() - t0
+        if timing[c] > 20:
+            break
+    best = min(timing, key=timing.get)
+    torch.set_num_threads(best)
+    done, t0, nbatch = 0, time.perf_counter(), 0
+    items = [(make(qt), 1.0 if qt == '1-chain' else (INTER_WEIGHT if 'inter' in qt else PATH_WEIGHT))
+             for qt, _ in synthetic.FULL_MIX]
+    t0 = time.perf_counter()
+    while True:
+        item, w = items[nbatch % len(items)]
+        run(item, w)
+        done += B
+        nbatch += 1
+        if time.perf_counter() - t0 >= seconds and nbatch >= len(items):
+            break
+        if time.perf_counter() - t0 >= 4 * seconds:
             break
     el = time.perf_counter() - t0
-    return dict(value=done_graphs / el, unit='query-graphs/s', cores=cores, kind='port',
-                sample='%d full-mix steps (%d query graphs), oracle in reference op sequence, torch %s CPU, '
-                       '%d threads, includes python collation of the sample' % (steps, done_graphs,
-                                                                                torch.__version__, cores))
+    return dict(value=done / el, unit='query-graphs/s', cores=best, kind='port',
+                sample='%d formula batches of B=%d in full-mix order (%d query graphs, %.1f s), oracle in the '
+                       'reference op sequence (weight copy + bmm + index_add, two encoder passes), torch %s; '
+                       '%d usable host cores; 3-chain batch seconds by thread count: %s'
+                       % (nbatch, B, done, el, torch.__version__, avail,
+                          ', '.join('%d: %.2f' % (c, t) for c, t in sorted(timing.items()))))
 
 
 def main():
@@ -228,12 +309,24 @@ def main():
     rng = np.random.RandomState(1000 + rank)
     pool = [StepData(schema, model, args.batch_size, rng, device) for _ in range(4)]
 
-    reducer = None
-    if world > 1:
+    use_fused = args.path in ('auto', 'fused') and args.readout in ('mp', 'sum', 'max')
+    reducer = fstep = packed = None
+    if use_fused:
+        from mpqe_amd.fused import FusedTrainStep
+        fstep = FusedTrainStep(model)
+        packed = [pack_for_fused(fstep, d) for d in pool]
+    elif world > 1:
         from mpqe_amd.parallel import GradReducer
         reducer = GradReducer(model)
 
     def one_step(i):
+        if use_fused:
+            loss = fstep.run(packed[i % len(pool)])
+            if world > 1:
+                import torch.distributed as dist
+                dist.all_reduce(fstep.flat_grad)          # one bucket: p.grad are views of it
+                fstep.flat_grad.mul_(1.0 / world)
+            return loss
         loss = step_modules(model, pool[i % len(pool)])
         if reducer is not None:
             reducer.all_reduce()
@@ -274,18 +367,30 @@ def main():
                    'global_query_graphs_per_step': graphs_per_step,
                    'parallelism': 'dp%d (graphs sharded by rank, RCCL all-reduce of gradients)' % world
                                   if world > 1 else 'single GPU',
-                   'host_path': 'drop-in modules (one autograd graph per step)'},
+                   'host_path': 'fused step: one C-ABI call, ~20 launches per step' if use_fused
+                                else 'drop-in modules (one autograd graph per step)'},
     }
     if rank == 0:
         flops_fwd, flops_all, bytes_all, launches = layer_work(pool[0], model)
-        dur, ncalls = time_layer_forward(model, pool[0])
-        per_launch_flops = flops_fwd / launches
-        achieved = per_launch_flops / dur / 1e12
-        out['roofline'] = {'bound': 'mfma', 'kernel': 'rgcn_tmpl_fwd_kernel', 'achieved': achieved,
-                           'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_F32_PEAK_TFLOPS,
-                           'traffic': None, 'avg_launch_us': dur * 1e6,
-                           'algorithmic_flops_per_launch': per_launch_flops,
-                           'launches_per_step': launches}
+        if use_fused:
+            fams = time_fused_kernels(fstep, packed[0], pool[0], model)
+            dom = max(fams, key=lambda f: f['total_us_per_step'])
+            out['roofline'] = {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['achieved'],
+                               'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': dom['achieved'] / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
+                               'avg_launch_us': dom['avg_launch_us'],
+                               'algorithmic_flops_per_launch': dom['algorithmic_flops_per_launch'],
+                               'launches_per_step': dom['launches_per_step']}
+            out['kernels'] = fams
+        else:
+            dur, ncalls = time_layer_forward(model, pool[0])
+            per_launch_flops = flops_fwd / launches
+            achieved = per_launch_flops / dur / 1e12
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'rgcn_tmpl_fwd_kernel', 'achieved': achieved,
+                               'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
+                               'avg_launch_us': dur * 1e6, 'algorithmic_flops_per_launch': per_launch_flops,
+                               'launches_per_step': launches}
         out['step_work'] = {'layer_flops_fwd_bwd': flops_all, 'scatter_aggregate_bytes_fwd_bwd': bytes_all,
                             'layer_tflops_over_whole_step': flops_all / (elapsed / args.steps) / 1e12}
         if world == 1 and not args.no_cpu_baseline:

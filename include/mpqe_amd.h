@@ -198,6 +198,67 @@ int mpqe_hinge_fwd(const float *pos, const float *neg, int64_t n, float margin, 
 int mpqe_hinge_bwd(const float *pos, const float *neg, int64_t n, float margin, const float *grad_loss /*[1]*/,
                    float *grad_pos, float *grad_neg, void *stream);
 
+/* ---- fused training step -------------------------------------------------------------------
+ * Forward + backward of RGCNEncoderDecoder.margin_loss (reference model.py:464-494) for ALL the
+ * formula batches of one training step (reference train_helpers.py:76-120 draws 11 after
+ * burn-in), each with explicit positive and negative targets, in ~15 launches:
+ *     loss[0] = sum_b weight_b * mean_i clamp(margin - (pos_bi - neg_bi), 0);  loss[1+b] = that mean
+ * Gradients of every parameter are ACCUMULATED into `grads` (dense, like the reference's
+ * autograd). Readouts: sum / max / mp(TM). The query embedding is computed once per batch and
+ * scored against both targets (the reference encodes twice; same maths).
+ * Descriptors are HOST structs; every pointer inside them is a device pointer.               */
+#define MPQE_STEP_MAX_BATCHES 16
+#define MPQE_STEP_MAX_LAYERS 8
+#define MPQE_STEP_MAX_MODES 16
+
+typedef struct {
+    int32_t query_type;        /* MPQE_Q_*                                                     */
+    int32_t num_passes;        /* message-passing passes: diameter if adaptive else num_layers */
+    int32_t batch_size;        /* B: query graphs of this formula                              */
+    int32_t target_mode;       /* entity-table index of the targets / negatives                */
+    int64_t edge_type[MPQE_MAX_TEMPLATE_EDGES];  /* relation id per template edge              */
+    int64_t var_ids[MPQE_MAX_TEMPLATE_NODES - 1];/* mode id per variable node                  */
+    int32_t anchor_mode[MPQE_MAX_TEMPLATE_EDGES];/* entity-table index per anchor slot         */
+    float weight;              /* weight of this batch's loss in the step loss                 */
+} mpqe_step_batch_t;
+
+typedef struct {
+    int32_t dim, num_layers, num_relations, num_modes;
+    int32_t readout;           /* MPQE_READOUT_*                                               */
+    int32_t reserved;
+    const float *tables[MPQE_STEP_MAX_MODES];    /* per-mode entity table [rows, dim]          */
+    int64_t table_rows[MPQE_STEP_MAX_MODES];
+    const int64_t *node_map;   /* global entity id -> row of its mode's table (-1: none)       */
+    int64_t node_map_len;
+    const float *mode_emb;     /* [num_modes, dim]                                             */
+    const float *basis[MPQE_STEP_MAX_LAYERS];    /* layers[i].basis [R, dim, dim]; shared      */
+    const float *root[MPQE_STEP_MAX_LAYERS];     /* layers repeat the same pointers            */
+    const float *bias[MPQE_STEP_MAX_LAYERS];
+} mpqe_step_params_t;
+
+typedef struct {
+    float *tables[MPQE_STEP_MAX_MODES];          /* NULL = not wanted                          */
+    float *mode_emb;
+    float *basis[MPQE_STEP_MAX_LAYERS];
+    float *root[MPQE_STEP_MAX_LAYERS];
+    float *bias[MPQE_STEP_MAX_LAYERS];
+} mpqe_step_grads_t;
+
+size_t mpqe_step_workspace_bytes(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,
+                                 int num_batches);
+/* anchor_ids: per batch b a block of [A_b, B_b] ids (slot-major), blocks concatenated in batch
+ * order; targets / negs: [sum_b B_b]. backward = 0 stops after the loss (grads may be NULL).
+ * scores_pos / scores_neg: [sum_b B_b] or NULL. workspace must be 256-byte aligned.
+ * events (may be NULL): hipEvent_t handles recorded on `stream` in pairs around single launches, in
+ * this order: layer forward level 0..Lmax-1, backward-x level Lmax-1..0, weight gradient -- i.e.
+ * 2*(2*Lmax + 1) events; fewer are filled as far as they go. For roofline accounting only.     */
+int mpqe_step_forward_backward(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,
+                               int num_batches, const int64_t *anchor_ids, const int64_t *targets,
+                               const int64_t *negs, float margin, const mpqe_step_grads_t *grads_host,
+                               int backward, float *loss /*[1 + num_batches]*/, float *scores_pos,
+                               float *scores_neg, void *workspace, size_t workspace_bytes, int32_t *err,
+                               void *const *events, int num_events, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

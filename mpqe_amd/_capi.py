@@ -22,6 +22,32 @@ class TemplateInfo(ctypes.Structure):
                 ('rel_label', ctypes.c_int32 * 3), ('var_node', ctypes.c_int32 * 4)]
 
 
+STEP_MAX_BATCHES, STEP_MAX_LAYERS, STEP_MAX_MODES = 16, 8, 16
+
+
+class StepBatch(ctypes.Structure):
+    _fields_ = [('query_type', ctypes.c_int32), ('num_passes', ctypes.c_int32),
+                ('batch_size', ctypes.c_int32), ('target_mode', ctypes.c_int32),
+                ('edge_type', ctypes.c_int64 * 3), ('var_ids', ctypes.c_int64 * 3),
+                ('anchor_mode', ctypes.c_int32 * 3), ('weight', ctypes.c_float)]
+
+
+class StepParams(ctypes.Structure):
+    _fields_ = [('dim', ctypes.c_int32), ('num_layers', ctypes.c_int32),
+                ('num_relations', ctypes.c_int32), ('num_modes', ctypes.c_int32),
+                ('readout', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('tables', c_void_p * STEP_MAX_MODES), ('table_rows', ctypes.c_int64 * STEP_MAX_MODES),
+                ('node_map', c_void_p), ('node_map_len', ctypes.c_int64), ('mode_emb', c_void_p),
+                ('basis', c_void_p * STEP_MAX_LAYERS), ('root', c_void_p * STEP_MAX_LAYERS),
+                ('bias', c_void_p * STEP_MAX_LAYERS)]
+
+
+class StepGrads(ctypes.Structure):
+    _fields_ = [('tables', c_void_p * STEP_MAX_MODES), ('mode_emb', c_void_p),
+                ('basis', c_void_p * STEP_MAX_LAYERS), ('root', c_void_p * STEP_MAX_LAYERS),
+                ('bias', c_void_p * STEP_MAX_LAYERS)]
+
+
 # name: (restype, [argtypes])
 PROTOTYPES = {
     'mpqe_status_string': (c_char_p, [I]),
@@ -50,6 +76,9 @@ PROTOTYPES = {
     'mpqe_cosine_bwd': (I, [P, P, P, P, L, L, F, P, P, P]),
     'mpqe_hinge_fwd': (I, [P, P, L, F, P, P]),
     'mpqe_hinge_bwd': (I, [P, P, L, F, P, P, P, P]),
+    'mpqe_step_workspace_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I]),
+    'mpqe_step_forward_backward': (I, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, P, P, P, F,
+                                       ctypes.POINTER(StepGrads), I, P, P, P, P, Z, P, P, I, P]),
 }
 
 QUERY_TYPE_IDS = {'1-chain': 0, '2-chain': 1, '3-chain': 2, '2-inter': 3, '3-inter': 4,
@@ -83,3 +112,40 @@ def check(cdll, status, what):
     if status != 0:
         msg = cdll.mpqe_status_string(status)
         raise MpqeError('%s failed: %s (%d)' % (what, msg.decode() if msg else '?', status))
+
+
+def make_step_params(dim, num_relations, readout, table_ptrs, table_rows, node_map_ptr, node_map_len,
+                     mode_emb_ptr, basis_ptrs, root_ptrs, bias_ptrs):
+    """StepParams from raw addresses (ints); lists are per mode / per layer."""
+    p = StepParams()
+    p.dim, p.num_layers, p.num_relations, p.num_modes = dim, len(basis_ptrs), num_relations, len(table_ptrs)
+    p.readout = READOUT_IDS[readout] if isinstance(readout, str) else readout
+    for m, (ptr, rows) in enumerate(zip(table_ptrs, table_rows)):
+        p.tables[m], p.table_rows[m] = ptr, rows
+    p.node_map, p.node_map_len, p.mode_emb = node_map_ptr, node_map_len, mode_emb_ptr
+    for l, (b, r, bi) in enumerate(zip(basis_ptrs, root_ptrs, bias_ptrs)):
+        p.basis[l], p.root[l], p.bias[l] = b, r, bi
+    return p
+
+
+def make_step_grads(table_ptrs, mode_emb_ptr, basis_ptrs, root_ptrs, bias_ptrs):
+    g = StepGrads()
+    for m, ptr in enumerate(table_ptrs):
+        g.tables[m] = ptr
+    g.mode_emb = mode_emb_ptr
+    for l, (b, r, bi) in enumerate(zip(basis_ptrs, root_ptrs, bias_ptrs)):
+        g.basis[l], g.root[l], g.bias[l] = b, r, bi
+    return g
+
+
+def make_step_batch(query_type, num_passes, batch_size, edge_type, var_ids, anchor_modes, target_mode, weight):
+    b = StepBatch()
+    b.query_type = QUERY_TYPE_IDS[query_type] if isinstance(query_type, str) else query_type
+    b.num_passes, b.batch_size, b.target_mode, b.weight = num_passes, batch_size, target_mode, weight
+    for i, e in enumerate(edge_type):
+        b.edge_type[i] = int(e)
+    for i, v in enumerate(var_ids):
+        b.var_ids[i] = int(v)
+    for i, m in enumerate(anchor_modes):
+        b.anchor_mode[i] = int(m)
+    return b

@@ -12,13 +12,7 @@
 // W^T; the weight gradient is x_src^T . g_dst with the batch as K, split over
 // workgroups and reduced in a fixed order (no float atomics -> reproducible).
 #include "bias_grad.h"
-#include "gemm_core.h"
-
-struct TmplArgs {
-    int N, E;
-    int src[3], dst[3];
-    long long rel[3];
-};
+#include "rgcn_template_body.h"
 
 // ------------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256) void rgcn_tmpl_fwd_kernel(
@@ -26,108 +20,18 @@ __global__ __launch_bounds__(256) void rgcn_tmpl_fwd_kernel(
     const float *__restrict__ root, const float *__restrict__ bias, int Din, int Dout, int relu,
     float *__restrict__ out, int vec_x, int vec_w) {
     __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
-    const int n = blockIdx.z;
-    const long long b0 = (long long)blockIdx.x * GT_BM;
-    const int n0 = blockIdx.y * GT_BN;
-    const int nsteps = (Din + GT_BK - 1) / GT_BK;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-    for (int kb = 0; kb <= tp.E; ++kb) {
-        int s;
-        const float *W;
-        if (kb < tp.E) {
-            if (tp.dst[kb] != n) continue;
-            s = tp.src[kb];
-            W = basis + tp.rel[kb] * (long long)Din * Dout;
-        } else {
-            s = n;
-            W = root;
-        }
-        auto aload = [&](int r, int c, int step) -> f32x4 {
-            const long long b = b0 + r;
-            if (b >= B) return f32x4{0.f, 0.f, 0.f, 0.f};
-            const float *p = x + (b * tp.N + s) * (long long)Din;
-            return ld4_guard(p, step * GT_BK + c, Din, vec_x);
-        };
-        auto bload = [&](int k, int c, int step) -> f32x4 {
-            const int kk = step * GT_BK + k;
-            if (kk >= Din) return f32x4{0.f, 0.f, 0.f, 0.f};
-            return ld4_guard(W + (long long)kk * Dout, n0 + c, Dout, vec_w);
-        };
-        gemm_block<false, true>(acc, aload, bload, nsteps, smem);
-    }
-    const int col = n0 + acc_col();
-    if (col < Dout) {
-        const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long long b = b0 + acc_row(r);
-            if (b < B) {
-                float v = acc[r] + bv;
-                if (relu) v = v > 0.f ? v : 0.f;
-                out[(b * tp.N + n) * (long long)Dout + col] = v;
-            }
-        }
-    }
+    tmpl_fwd_tile(tp, B, x, basis, root, bias, Din, Dout, relu, out, vec_x, vec_w, (int)blockIdx.z,
+                  (long long)blockIdx.x * GT_BM, (int)blockIdx.y * GT_BN, smem);
 }
 
 // ------------------------------------------------------------------------------------ backward wrt x
-// grad_x[:, m, :] = sum_{e: src_e = m} gpre[:, dst_e, :] . basis[r_e]^T + gpre[:, m, :] . root^T
-// gpre = grad_out * (out > 0) when the layer applied ReLU.
 __global__ __launch_bounds__(256) void rgcn_tmpl_bwd_x_kernel(
     TmplArgs tp, long long B, const float *__restrict__ g, const float *__restrict__ out,
     const float *__restrict__ basis, const float *__restrict__ root, int Din, int Dout, int relu,
     float *__restrict__ grad_x, int vec_g, int vec_w) {
     __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
-    const int m = blockIdx.z;
-    const long long b0 = (long long)blockIdx.x * GT_BM;
-    const int n0 = blockIdx.y * GT_BN;               // column tile over Din
-    const int nsteps = (Dout + GT_BK - 1) / GT_BK;   // K runs over Dout
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-    for (int kb = 0; kb <= tp.E; ++kb) {
-        int d;
-        const float *W;
-        if (kb < tp.E) {
-            if (tp.src[kb] != m) continue;
-            d = tp.dst[kb];
-            W = basis + tp.rel[kb] * (long long)Din * Dout;
-        } else {
-            d = m;
-            W = root;
-        }
-        auto aload = [&](int r, int c, int step) -> f32x4 {
-            const long long b = b0 + r;
-            if (b >= B) return f32x4{0.f, 0.f, 0.f, 0.f};
-            const long long off = (b * tp.N + d) * (long long)Dout;
-            f32x4 v = ld4_guard(g + off, step * GT_BK + c, Dout, vec_g);
-            if (relu) {
-                f32x4 o = ld4_guard(out + off, step * GT_BK + c, Dout, vec_g);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = o[q] > 0.f ? v[q] : 0.f;
-            }
-            return v;
-        };
-        // B[k][n] = W[n][k]: R-type image, tile row = output column n (over Din), contiguous in k
-        auto bload = [&](int r, int c, int step) -> f32x4 {
-            const int nn = n0 + r;
-            if (nn >= Din) return f32x4{0.f, 0.f, 0.f, 0.f};
-            return ld4_guard(W + (long long)nn * Dout, step * GT_BK + c, Dout, vec_w);
-        };
-        gemm_block<false, false>(acc, aload, bload, nsteps, smem);
-    }
-    const int col = n0 + acc_col();
-    if (col < Din) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long long b = b0 + acc_row(r);
-            if (b < B) grad_x[(b * tp.N + m) * (long long)Din + col] = acc[r];
-        }
-    }
+    tmpl_bwd_x_tile(tp, B, g, out, basis, root, Din, Dout, relu, grad_x, vec_g, vec_w, (int)blockIdx.z,
+                    (long long)blockIdx.x * GT_BM, (int)blockIdx.y * GT_BN, smem);
 }
 
 // ------------------------------------------------------------------------------------ weight gradient
@@ -158,42 +62,11 @@ __global__ __launch_bounds__(256) void rgcn_tmpl_grad_w_kernel(
     const long long q0 = (long long)c * ch;
     long long q1 = q0 + ch;
     if (q1 > count) q1 = count;
-    const int nsteps = q1 > q0 ? (int)((q1 - q0 + GT_BK - 1) / GT_BK) : 0;
     const long long xs = is_root ? 1 : tp.N, xo = is_root ? 0 : tp.src[z];
     const long long gs = is_root ? 1 : tp.N, go = is_root ? 0 : tp.dst[z];
-
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    auto aload = [&](int k, int cc, int step) -> f32x4 {
-        const long long q = q0 + (long long)step * GT_BK + k;
-        if (q >= q1) return f32x4{0.f, 0.f, 0.f, 0.f};
-        return ld4_guard(x + (q * xs + xo) * (long long)Din, i0 + cc, Din, vec_x);
-    };
-    auto bload = [&](int k, int cc, int step) -> f32x4 {
-        const long long q = q0 + (long long)step * GT_BK + k;
-        if (q >= q1) return f32x4{0.f, 0.f, 0.f, 0.f};
-        const long long off = (q * gs + go) * (long long)Dout;
-        f32x4 v = ld4_guard(g + off, j0 + cc, Dout, vec_g);
-        if (relu) {
-            f32x4 o = ld4_guard(out + off, j0 + cc, Dout, vec_g);
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) v[qq] = o[qq] > 0.f ? v[qq] : 0.f;
-        }
-        return v;
-    };
-    gemm_block<true, true>(acc, aload, bload, nsteps, smem);
-
     const long long slab = is_root ? (long long)tp.E * wc.nch_edge + c : (long long)z * wc.nch_edge + c;
-    float *dst = slabs + slab * (long long)Din * Dout;
-    const int col = j0 + acc_col();
-    if (col < Dout) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = i0 + acc_row(r);
-            if (row < Din) dst[(long long)row * Dout + col] = acc[r];
-        }
-    }
+    tmpl_grad_w_tile(x, g, out, Din, Dout, relu, xs, xo, gs, go, q0, q1, i0, j0,
+                     slabs + slab * (long long)Din * Dout, vec_x, vec_g, smem);
 }
 
 // grad_basis[rel_z] += sum over (slots sharing rel_z, chunks) in fixed order; grad_root likewise.

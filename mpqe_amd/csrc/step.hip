@@ -1,0 +1,889 @@
+// Fused training step: forward + backward of the whole query-graph encoder for ALL batches of
+// one step (the reference's post-burn-in step draws 11 formula batches: train_helpers.py:81,
+// 97-112; each goes through RGCNEncoderDecoder.margin_loss, model.py:464-494) in ~15 kernel
+// launches instead of one launch per op per batch.
+//
+// At the reference's batch size (B = 512, <= 4 nodes per graph, D = 128) every single op is
+// far too small to fill 256 CUs and the path is launch-latency bound. So the unit of a launch
+// here is a LEVEL of the whole step: level p applies message-passing pass p of every batch
+// that still has a pass to run (batches differ in template, relations and number of passes),
+// as one grid of 64x64 MFMA tiles described by a small descriptor table in HBM.
+//
+//   forward   assemble (anchors: gather + L2 normalise; variables: mode rows; +/- targets)
+//             level 0 .. Lmax-1 layer tiles
+//             readout + cosine(+/-) + hinge terms per graph;  loss reduction (one workgroup)
+//   backward  d hinge -> d cosine -> d readout -> rows of gH[L_b]; target/negative table grads
+//             level Lmax-1 .. 0 backward-x tiles
+//             weight-gradient tiles of ALL levels (split over K chunks, slabs)
+//             bias / variable-row partial sums; anchor table grads
+//             one reduction pass: slabs and partials -> gradients, fixed order
+//
+// Arithmetic is identical to the per-op kernels (same tile bodies, rgcn_template_body.h);
+// margin_loss's two encoder passes are one here (the query embedding does not depend on the
+// target).
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "rgcn_template_body.h"
+
+#define STEP_MAX_LEVELS MPQE_STEP_MAX_LAYERS
+#define UPLOAD_BYTES 2048
+
+struct BatchDev {
+    TmplArgs tp;
+    int A, V, L, B;
+    long long var_id[3];
+    int anchor_tab[3];
+    int target_tab;
+    long long row_off, g_off, anchor_off;
+    float weight;
+    int pad;
+};
+
+struct StepDev {
+    int nb, D, num_layers, readout;
+    long long rows_total, graphs_total;
+    int tile_off[STEP_MAX_LEVELS][MPQE_STEP_MAX_BATCHES + 1];
+    BatchDev b[MPQE_STEP_MAX_BATCHES];
+};
+
+struct LayerPtrs {
+    const float *basis[MPQE_STEP_MAX_LAYERS], *root[MPQE_STEP_MAX_LAYERS], *bias[MPQE_STEP_MAX_LAYERS];
+};
+struct TablePtrs {
+    const float *table[MPQE_STEP_MAX_MODES];
+    float *grad[MPQE_STEP_MAX_MODES];
+    long long rows[MPQE_STEP_MAX_MODES];
+};
+
+// one weight-gradient source: (batch, level, slot) -> nch K-chunks, each a slab of D*D floats
+struct WSource {
+    int batch, level, slot, relu;
+    int nch, ch, slab_start, block_start;
+};
+// one partial-vector source: kind 0 = bias colsum of (batch, level), kind 1 = variable row (batch, k)
+struct VSource {
+    int kind, batch, level_or_k, relu;
+    int nblk, part_start, block_start, pad;
+};
+// one reduction group: out[...] += sum of `count` consecutive slabs/partials starting at `start`
+struct RGroup {
+    int kind;          // 0 basis, 1 root, 2 bias, 3 mode row
+    int layer;         // layer index (kinds 0-2)
+    long long row;     // relation id (kind 0) / mode id (kind 3)
+    int start, count;
+};
+
+struct Blob {
+    char bytes[UPLOAD_BYTES];
+};
+__global__ void step_upload_kernel(Blob blob, char *dst, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = blob.bytes[i];
+}
+
+__device__ __forceinline__ int find_le(const int *__restrict__ off, int n, int t) {
+    // largest i in [0, n) with off[i] <= t   (off non-decreasing, off[0] = 0)
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (off[mid] <= t) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ int layer_index(int p, int L, int num_layers) {
+    return p < L - 1 ? p : num_layers - 1;     // reference model.py:435-441
+}
+
+// ------------------------------------------------------------------------------------ assemble
+__device__ __forceinline__ long long table_row(const long long *__restrict__ node_map, long long map_len,
+                                               long long id, long long rows, int32_t *err) {
+    if (id < 0 || id >= map_len) {
+        flag_error(err, MPQE_FLAG_BAD_NODE_ID);
+        return -1;
+    }
+    const long long r = node_map[id];
+    if (r < 0 || r >= rows) {
+        flag_error(err, MPQE_FLAG_BAD_NODE_ID);
+        return -1;
+    }
+    return r;
+}
+
+// wave per row: rows [0, rows_total) are node rows of H0, then G positive and G negative targets
+__global__ __launch_bounds__(256) void step_assemble_kernel(
+    const StepDev *__restrict__ sd, TablePtrs tabs, const long long *__restrict__ node_map, long long map_len,
+    const float *__restrict__ mode_emb, long long num_modes, const long long *__restrict__ anchor_ids,
+    const long long *__restrict__ targets, const long long *__restrict__ negs, float *__restrict__ H0,
+    float *__restrict__ tpos, float *__restrict__ tneg, int32_t *err) {
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int D = sd->D;
+    const long long R = sd->rows_total, G = sd->graphs_total;
+    if (w >= R + 2 * G) return;
+    int32_t *e = lane == 0 ? err : nullptr;
+    const float *src = nullptr;
+    float *dst;
+    bool normalise = true;
+    if (w < R) {
+        int bi = 0;
+        for (int i = 1; i < sd->nb; ++i)
+            if (sd->b[i].row_off <= w) bi = i;
+        const BatchDev &b = sd->b[bi];
+        const long long lr = w - b.row_off;
+        const long long g = lr / b.tp.N;
+        const int n = (int)(lr - g * b.tp.N);
+        dst = H0 + w * D;
+        if (n < b.A) {
+            const int tab = b.anchor_tab[n];
+            const long long id = anchor_ids[b.anchor_off + (long long)n * b.B + g];
+            const long long row = table_row(node_map, map_len, id, tabs.rows[tab], e);
+            if (row >= 0) src = tabs.table[tab] + row * D;
+        } else {
+            const long long m = b.var_id[n - b.A];
+            normalise = false;
+            if (m < 0 || m >= num_modes) flag_error(e, MPQE_FLAG_BAD_NODE_ID);
+            else src = mode_emb + m * D;
+        }
+    } else {
+        const long long gi = (w - R) % G;
+        const bool is_neg = (w - R) >= G;
+        int bi = 0;
+        for (int i = 1; i < sd->nb; ++i)
+            if (sd->b[i].g_off <= gi) bi = i;
+        const int tab = sd->b[bi].target_tab;
+        const long long id = is_neg ? negs[gi] : targets[gi];
+        const long long row = table_row(node_map, map_len, id, tabs.rows[tab], e);
+        if (row >= 0) src = tabs.table[tab] + row * D;
+        dst = (is_neg ? tneg : tpos) + gi * D;
+    }
+    if (!src) {
+        for (int c = lane; c < D; c += 64) dst[c] = 0.f;
+        return;
+    }
+    if (!normalise) {
+        for (int c = lane; c < D; c += 64) dst[c] = src[c];
+        return;
+    }
+    float ss = 0.f;
+    for (int c = lane; c < D; c += 64) ss += src[c] * src[c];
+    ss = wave_sum(ss);
+    const float nrm = sqrtf(ss);
+    for (int c = lane; c < D; c += 64) dst[c] = src[c] / nrm;
+}
+
+// ------------------------------------------------------------------------------------ layer levels
+__global__ __launch_bounds__(256) void step_layer_fwd_kernel(const StepDev *__restrict__ sd, LayerPtrs lp, int p,
+                                                             const float *__restrict__ Hin,
+                                                             float *__restrict__ Hout, int vec) {
+    __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
+    const int t = blockIdx.x;
+    const int bi = find_le(sd->tile_off[p], sd->nb + 1, t);
+    const BatchDev &b = sd->b[bi];
+    const int D = sd->D;
+    const int ct = (D + GT_BN - 1) / GT_BN, rt = (b.B + GT_BM - 1) / GT_BM;
+    const int lt = t - sd->tile_off[p][bi];
+    const int n = lt / (rt * ct), rem = lt - n * rt * ct;
+    const int li = layer_index(p, b.L, sd->num_layers);
+    const TmplArgs tp = b.tp;
+    tmpl_fwd_tile(tp, b.B, Hin + b.row_off * D, lp.basis[li], lp.root[li], lp.bias[li], D, D, p < b.L - 1,
+                  Hout + b.row_off * D, vec, vec, n, (long long)(rem / ct) * GT_BM, (rem % ct) * GT_BN, smem);
+}
+
+__global__ __launch_bounds__(256) void step_layer_bwd_x_kernel(const StepDev *__restrict__ sd, LayerPtrs lp, int p,
+                                                               const float *__restrict__ Gout,
+                                                               const float *__restrict__ Hout,
+                                                               float *__restrict__ Gin, int vec) {
+    __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
+    const int t = blockIdx.x;
+    const int bi = find_le(sd->tile_off[p], sd->nb + 1, t);
+    const BatchDev &b = sd->b[bi];
+    const int D = sd->D;
+    const int ct = (D + GT_BN - 1) / GT_BN, rt = (b.B + GT_BM - 1) / GT_BM;
+    const int lt = t - sd->tile_off[p][bi];
+    const int m = lt / (rt * ct), rem = lt - m * rt * ct;
+    const int li = layer_index(p, b.L, sd->num_layers);
+    const TmplArgs tp = b.tp;
+    tmpl_bwd_x_tile(tp, b.B, Gout + b.row_off * D, Hout + b.row_off * D, lp.basis[li], lp.root[li], D, D,
+                    p < b.L - 1, Gin + b.row_off * D, vec, vec, m, (long long)(rem / ct) * GT_BM,
+                    (rem % ct) * GT_BN, smem);
+}
+
+// ------------------------------------------------------------------------------------ score / loss
+__device__ __forceinline__ float readout_value(int readout, const float *__restrict__ h, int N, int A, int D,
+                                               int c, int *arg) {
+    if (readout == MPQE_READOUT_TM) return h[(long long)A * D + c];
+    if (readout == MPQE_READOUT_SUM) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += h[(long long)n * D + c];
+        return s;
+    }
+    float best = h[c];
+    int a = 0;
+    for (int n = 1; n < N; ++n) {
+        const float v = h[(long long)n * D + c];
+        if (v > best) {
+            best = v;
+            a = n;
+        }
+    }
+    *arg = a;
+    return best;
+}
+
+#define STEP_MAX_COLS_PER_LANE 8     // D <= 512 on the fused path
+
+// wave per graph. BWD = false: scores and hinge terms. BWD = true: gradient rows of gH[L_b] and the
+// positive / negative target-table gradients (through the L2 normalisation).
+template <bool BWD>
+__global__ __launch_bounds__(256) void step_score_kernel(
+    const StepDev *__restrict__ sd, const float *__restrict__ H, long long level_stride,
+    const float *__restrict__ tpos, const float *__restrict__ tneg, float margin, float eps,
+    float *__restrict__ s_pos, float *__restrict__ s_neg, float *__restrict__ terms,
+    float *__restrict__ GH, TablePtrs tabs, const long long *__restrict__ node_map, long long map_len,
+    const long long *__restrict__ targets, const long long *__restrict__ negs) {
+    const long long gi = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (gi >= sd->graphs_total) return;
+    int bi = 0;
+    for (int i = 1; i < sd->nb; ++i)
+        if (sd->b[i].g_off <= gi) bi = i;
+    const BatchDev &b = sd->b[bi];
+    const int D = sd->D, N = b.tp.N, A = b.A;
+    const long long row0 = b.row_off + (gi - b.g_off) * N;
+    const float *h = H + (long long)b.L * level_stride + row0 * D;
+    const float *tp_ = tpos + gi * D, *tn_ = tneg + gi * D;
+    float q[STEP_MAX_COLS_PER_LANE];
+    int arg[STEP_MAX_COLS_PER_LANE];
+    float dp = 0.f, dn = 0.f, qq = 0.f, pp = 0.f, nn = 0.f;
+#pragma unroll
+    for (int j = 0; j < STEP_MAX_COLS_PER_LANE; ++j) {
+        const int c = lane + 64 * j;
+        q[j] = 0.f;
+        arg[j] = 0;
+        if (c < D) {
+            q[j] = readout_value(sd->readout, h, N, A, D, c, &arg[j]);
+            const float a = tp_[c], bb = tn_[c];
+            dp += q[j] * a;
+            dn += q[j] * bb;
+            qq += q[j] * q[j];
+            pp += a * a;
+            nn += bb * bb;
+        }
+    }
+    dp = wave_sum(dp);
+    dn = wave_sum(dn);
+    qq = wave_sum(qq);
+    pp = wave_sum(pp);
+    nn = wave_sum(nn);
+    const float rq = sqrtf(qq), rp = sqrtf(pp), rn = sqrtf(nn);
+    const float nq = fmaxf(rq, eps), np_ = fmaxf(rp, eps), nn_ = fmaxf(rn, eps);
+    const float sp = dp / (nq * np_), sn = dn / (nq * nn_);
+    const float v = margin - (sp - sn);
+    if (!BWD) {
+        if (lane == 0) {
+            s_pos[gi] = sp;
+            s_neg[gi] = sn;
+            terms[gi] = v > 0.f ? v : 0.f;
+        }
+        return;
+    }
+    // d loss / d sp = -w/B on active terms, d/d sn = +w/B   (loss = sum_b w_b mean_b hinge)
+    const float act = v >= 0.f ? b.weight / (float)b.B : 0.f;
+    const float gsp = -act, gsn = act;
+    const float inv_p = 1.f / (nq * np_), inv_n = 1.f / (nq * nn_);
+    const float kq = rq > eps ? (gsp * sp + gsn * sn) / (nq * nq) : 0.f;
+    const float ktp = rp > eps ? sp / (np_ * np_) : 0.f;
+    const float ktn = rn > eps ? sn / (nn_ * nn_) : 0.f;
+    // target rows: y = v/|v| (unit norm), dv = (g - y (y.g)) / |v|; |v| from the table row
+    const int tab = b.target_tab;
+    const long long prow = table_row(node_map, map_len, targets[gi], tabs.rows[tab], nullptr);
+    const long long nrow = table_row(node_map, map_len, negs[gi], tabs.rows[tab], nullptr);
+    float gyp[STEP_MAX_COLS_PER_LANE], gyn[STEP_MAX_COLS_PER_LANE];
+    float yg_p = 0.f, yg_n = 0.f, ssp = 0.f, ssn = 0.f;
+#pragma unroll
+    for (int j = 0; j < STEP_MAX_COLS_PER_LANE; ++j) {
+        const int c = lane + 64 * j;
+        gyp[j] = gyn[j] = 0.f;
+        if (c < D) {
+            const float a = tp_[c], bb = tn_[c];
+            gyp[j] = gsp * (q[j] * inv_p - ktp * a);
+            gyn[j] = gsn * (q[j] * inv_n - ktn * bb);
+            yg_p += a * gyp[j];
+            yg_n += bb * gyn[j];
+            if (prow >= 0) {
+                const float t = tabs.table[tab][prow * D + c];
+                ssp += t * t;
+            }
+            if (nrow >= 0) {
+                const float t = tabs.table[tab][nrow * D + c];
+                ssn += t * t;
+            }
+            const float gq = gsp * tp_[c] * inv_p + gsn * tn_[c] * inv_n - kq * q[j];
+            float *gh = GH + (long long)b.L * level_stride + row0 * D + c;
+            for (int n = 0; n < N; ++n) {
+                float gv;
+                if (sd->readout == MPQE_READOUT_SUM) gv = gq;
+                else if (sd->readout == MPQE_READOUT_TM) gv = n == A ? gq : 0.f;
+                else gv = arg[j] == n ? gq : 0.f;
+                gh[(long long)n * D] = gv;
+            }
+        }
+    }
+    yg_p = wave_sum(yg_p);
+    yg_n = wave_sum(yg_n);
+    ssp = wave_sum(ssp);
+    ssn = wave_sum(ssn);
+    const float ivp = 1.f / sqrtf(ssp), ivn = 1.f / sqrtf(ssn);
+    float *gt = tabs.grad[tab];
+    if (gt) {
+#pragma unroll
+        for (int j = 0; j < STEP_MAX_COLS_PER_LANE; ++j) {
+            const int c = lane + 64 * j;
+            if (c < D) {
+                if (prow >= 0) atomicAdd(gt + prow * D + c, (gyp[j] - tp_[c] * yg_p) * ivp);
+                if (nrow >= 0) atomicAdd(gt + nrow * D + c, (gyn[j] - tn_[c] * yg_n) * ivn);
+            }
+        }
+    }
+}
+
+// loss[0] = sum_b w_b * mean_b(terms), loss[1 + b] = mean_b(terms): one workgroup, fixed order
+__global__ __launch_bounds__(256) void step_loss_kernel(const StepDev *__restrict__ sd,
+                                                        const float *__restrict__ terms,
+                                                        float *__restrict__ loss) {
+    __shared__ float red[256];
+    float total = 0.f;
+    for (int bi = 0; bi < sd->nb; ++bi) {
+        const BatchDev &b = sd->b[bi];
+        float s = 0.f;
+        for (int i = threadIdx.x; i < b.B; i += 256) s += terms[b.g_off + i];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+            __syncthreads();
+        }
+        const float mean = red[0] / (float)b.B;
+        if (threadIdx.x == 0) loss[1 + bi] = mean;
+        total += b.weight * mean;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = total;
+}
+
+// ------------------------------------------------------------------------------------ weight gradients
+__global__ __launch_bounds__(256) void step_grad_w_kernel(const StepDev *__restrict__ sd,
+                                                          const WSource *__restrict__ src, int nsrc,
+                                                          const int *__restrict__ block_start,
+                                                          const float *__restrict__ H, const float *__restrict__ GH,
+                                                          long long level_stride, float *__restrict__ slabs,
+                                                          int vec) {
+    __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
+    const int D = sd->D;
+    const int tiles_j = (D + GT_BN - 1) / GT_BN, tiles = tiles_j * ((D + GT_BM - 1) / GT_BM);
+    const int si = find_le(block_start, nsrc + 1, (int)blockIdx.x);
+    const WSource s = src[si];
+    const int lb = blockIdx.x - s.block_start;
+    const int c = lb / tiles, tile = lb - c * tiles;
+    const BatchDev &b = sd->b[s.batch];
+    const bool is_root = s.slot == b.tp.E;
+    const long long count = is_root ? (long long)b.B * b.tp.N : b.B;
+    const long long q0 = (long long)c * s.ch;
+    long long q1 = q0 + s.ch;
+    if (q1 > count) q1 = count;
+    const long long xs = is_root ? 1 : b.tp.N, xo = is_root ? 0 : b.tp.src[s.slot];
+    const long long gs = is_root ? 1 : b.tp.N, go = is_root ? 0 : b.tp.dst[s.slot];
+    const float *x = H + (long long)s.level * level_stride + b.row_off * D;
+    const float *out = H + (long long)(s.level + 1) * level_stride + b.row_off * D;
+    const float *g = GH + (long long)(s.level + 1) * level_stride + b.row_off * D;
+    tmpl_grad_w_tile(x, g, out, D, D, s.relu, xs, xo, gs, go, q0, q1, (tile / tiles_j) * GT_BM,
+                     (tile % tiles_j) * GT_BN, slabs + (long long)(s.slab_start + c) * D * D, vec, vec, smem);
+}
+
+// partial vectors. kind 0: column sums of gpre over 64-row blocks of (batch, level).
+// kind 1: sum over the batch of gH[0] variable row k, 4 row groups x 64 columns per workgroup.
+__global__ __launch_bounds__(256) void step_vec_partial_kernel(const StepDev *__restrict__ sd,
+                                                               const VSource *__restrict__ src, int nsrc,
+                                                               const int *__restrict__ block_start,
+                                                               const float *__restrict__ H,
+                                                               const float *__restrict__ GH, long long level_stride,
+                                                               float *__restrict__ partial) {
+    __shared__ float part[4][64];
+    const int D = sd->D;
+    const int si = find_le(block_start, nsrc + 1, (int)blockIdx.x);
+    const VSource s = src[si];
+    const int lb = blockIdx.x - s.block_start;
+    const BatchDev &b = sd->b[s.batch];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int cchunks = (D + 63) / 64;
+    const int blk = lb / cchunks, c = (lb % cchunks) * 64 + cl;
+    float acc = 0.f;
+    if (s.kind == 0) {
+        const long long rows = (long long)b.B * b.tp.N;
+        const float *g = GH + (long long)(s.level_or_k + 1) * level_stride + b.row_off * D;
+        const float *o = H + (long long)(s.level_or_k + 1) * level_stride + b.row_off * D;
+        const long long r0 = (long long)blk * 64;
+        if (c < D)
+            for (long long r = r0 + rg; r < r0 + 64 && r < rows; r += 4) {
+                float v = g[r * D + c];
+                if (s.relu && !(o[r * D + c] > 0.f)) v = 0.f;
+                acc += v;
+            }
+    } else {
+        const float *g = GH + b.row_off * D;          // level 0
+        const int k = s.level_or_k;
+        if (c < D)
+            for (long long gi = rg; gi < b.B; gi += 4) acc += g[(gi * b.tp.N + b.A + k) * D + c];
+    }
+    part[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0 && c < D)
+        partial[(long long)(s.part_start + blk) * D + c] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+}
+
+// anchor rows of gH[0] through the L2 normalisation into the entity-table gradients (fp32 atomics:
+// an entity can occur in several graphs)
+__global__ __launch_bounds__(256) void step_anchor_bwd_kernel(const StepDev *__restrict__ sd, TablePtrs tabs,
+                                                              const long long *__restrict__ node_map,
+                                                              long long map_len,
+                                                              const long long *__restrict__ anchor_ids,
+                                                              const float *__restrict__ G0,
+                                                              const int *__restrict__ anchor_row_off, int nb) {
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (w >= anchor_row_off[nb]) return;
+    const int bi = find_le(anchor_row_off, nb + 1, (int)w);
+    const BatchDev &b = sd->b[bi];
+    const long long lr = w - anchor_row_off[bi];
+    const int n = (int)(lr / b.B);
+    const long long g = lr - (long long)n * b.B;
+    const int D = sd->D, tab = b.anchor_tab[n];
+    float *gt = tabs.grad[tab];
+    if (!gt) return;
+    const long long row = table_row(node_map, map_len, anchor_ids[b.anchor_off + lr], tabs.rows[tab], nullptr);
+    if (row < 0) return;
+    const float *v = tabs.table[tab] + row * D;
+    const float *gi = G0 + (b.row_off + g * b.tp.N + n) * D;
+    float ss = 0.f, vg = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        ss += v[c] * v[c];
+        vg += v[c] * gi[c];
+    }
+    ss = wave_sum(ss);
+    vg = wave_sum(vg);
+    const float nrm = sqrtf(ss), inv = 1.f / nrm, ydotg = vg * inv;
+    for (int c = lane; c < D; c += 64) atomicAdd(gt + row * D + c, (gi[c] - (v[c] / nrm) * ydotg) * inv);
+}
+
+struct GradPtrs {
+    float *basis[MPQE_STEP_MAX_LAYERS], *root[MPQE_STEP_MAX_LAYERS], *bias[MPQE_STEP_MAX_LAYERS];
+    float *mode_emb;
+};
+
+__global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restrict__ groups, int D, GradPtrs gp,
+                                                          const float *__restrict__ slabs,
+                                                          const float *__restrict__ partial) {
+    const RGroup g = groups[blockIdx.y];
+    const long long elems = g.kind <= 1 ? (long long)D * D : D;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= elems) return;
+    const float *p = (g.kind <= 1 ? slabs : partial) + (long long)g.start * elems + idx;
+    float s = 0.f;
+    for (int i = 0; i < g.count; ++i) s += p[(long long)i * elems];
+    float *dst;
+    if (g.kind == 0) dst = gp.basis[g.layer] ? gp.basis[g.layer] + g.row * elems : nullptr;
+    else if (g.kind == 1) dst = gp.root[g.layer];
+    else if (g.kind == 2) dst = gp.bias[g.layer];
+    else dst = gp.mode_emb ? gp.mode_emb + g.row * D : nullptr;
+    if (dst) dst[idx] += s;
+}
+
+// ------------------------------------------------------------------------------------ host side
+namespace {
+
+struct HostPlan {
+    StepDev sd;
+    int Lmax;
+    int tiles[STEP_MAX_LEVELS];
+    std::vector<WSource> wsrc;
+    std::vector<int> wblock;          // nsrc + 1
+    std::vector<VSource> vsrc;
+    std::vector<int> vblock;
+    std::vector<RGroup> groups;
+    std::vector<int> anchor_off;      // nb + 1 (rows of the anchor backward)
+    int total_slabs, total_parts;
+    // workspace offsets (bytes)
+    size_t o_sd, o_wsrc, o_wblock, o_vsrc, o_vblock, o_groups, o_anchor, o_H, o_GH, o_tpos, o_tneg, o_spos,
+        o_sneg, o_terms, o_slabs, o_parts, total;
+    long long level_stride;
+};
+
+void pick_chunks(long long count, int max_chunks, int *nch, int *ch) {
+    long long n = (count + 127) / 128;
+    if (n < 1) n = 1;
+    if (n > max_chunks) n = max_chunks;
+    long long c = (count + n - 1) / n;
+    c = (c + GT_BK - 1) / GT_BK * GT_BK;
+    if (c < GT_BK) c = GT_BK;
+    n = (count + c - 1) / c;
+    if (n < 1) n = 1;
+    *nch = (int)n;
+    *ch = (int)c;
+}
+
+int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, HostPlan *hp) {
+    if (!P || !B || nb <= 0 || nb > MPQE_STEP_MAX_BATCHES) return MPQE_ERR_INVALID_ARG;
+    if (P->dim <= 0 || P->dim > 64 * STEP_MAX_COLS_PER_LANE) return MPQE_ERR_UNSUPPORTED;
+    if (P->num_layers <= 0 || P->num_layers > MPQE_STEP_MAX_LAYERS) return MPQE_ERR_UNSUPPORTED;
+    if (P->num_modes <= 0 || P->num_modes > MPQE_STEP_MAX_MODES) return MPQE_ERR_UNSUPPORTED;
+    if (P->readout < 0 || P->readout > 2) return MPQE_ERR_INVALID_ARG;
+    const int D = P->dim;
+    StepDev &sd = hp->sd;
+    memset(&sd, 0, sizeof(sd));
+    sd.nb = nb;
+    sd.D = D;
+    sd.num_layers = P->num_layers;
+    sd.readout = P->readout;
+    long long rows = 0, graphs = 0, anchors = 0;
+    hp->Lmax = 0;
+    hp->anchor_off.assign(nb + 1, 0);
+    for (int i = 0; i < nb; ++i) {
+        const mpqe_step_batch_t &b = B[i];
+        if (b.query_type < 0 || b.query_type >= MPQE_Q_COUNT || b.batch_size <= 0) return MPQE_ERR_INVALID_ARG;
+        if (b.num_passes <= 0 || b.num_passes > P->num_layers) return MPQE_ERR_INVALID_ARG;
+        const TemplateDesc &t = kTemplates[b.query_type];
+        BatchDev &d = sd.b[i];
+        d.tp.N = t.N;
+        d.tp.E = t.E;
+        for (int e = 0; e < 3; ++e) {
+            d.tp.src[e] = e < t.E ? t.src[e] : 0;
+            d.tp.dst[e] = e < t.E ? t.dst[e] : 0;
+            d.tp.rel[e] = e < t.E ? b.edge_type[e] : 0;
+            if (e < t.E && (b.edge_type[e] < 0 || b.edge_type[e] >= P->num_relations)) return MPQE_ERR_INVALID_ARG;
+        }
+        d.A = t.A;
+        d.V = t.V;
+        d.L = b.num_passes;
+        d.B = b.batch_size;
+        for (int k = 0; k < 3; ++k) d.var_id[k] = k < t.V ? b.var_ids[k] : 0;
+        for (int a = 0; a < 3; ++a) {
+            d.anchor_tab[a] = a < t.A ? b.anchor_mode[a] : 0;
+            if (a < t.A && (b.anchor_mode[a] < 0 || b.anchor_mode[a] >= P->num_modes)) return MPQE_ERR_INVALID_ARG;
+        }
+        if (b.target_mode < 0 || b.target_mode >= P->num_modes) return MPQE_ERR_INVALID_ARG;
+        d.target_tab = b.target_mode;
+        d.row_off = rows;
+        d.g_off = graphs;
+        d.anchor_off = anchors;
+        d.weight = b.weight;
+        hp->anchor_off[i] = (int)anchors;
+        rows += (long long)d.B * t.N;
+        graphs += d.B;
+        anchors += (long long)d.B * t.A;
+        if (d.L > hp->Lmax) hp->Lmax = d.L;
+    }
+    if (rows >= (1ll << 30)) return MPQE_ERR_UNSUPPORTED;
+    hp->anchor_off[nb] = (int)anchors;
+    sd.rows_total = rows;
+    sd.graphs_total = graphs;
+    const int ct = (D + GT_BN - 1) / GT_BN;
+    for (int p = 0; p < STEP_MAX_LEVELS; ++p) {
+        int t = 0;
+        for (int i = 0; i < nb; ++i) {
+            sd.tile_off[p][i] = t;
+            if (sd.b[i].L > p) t += sd.b[i].tp.N * ((sd.b[i].B + GT_BM - 1) / GT_BM) * ct;
+        }
+        sd.tile_off[p][nb] = t;
+        for (int i = nb + 1; i <= MPQE_STEP_MAX_BATCHES; ++i) sd.tile_off[p][i] = t;
+        hp->tiles[p] = t;
+    }
+
+    // unique layer buffers (shared layers alias one parameter set -> one gradient buffer)
+    int uid[MPQE_STEP_MAX_LAYERS];
+    for (int l = 0; l < P->num_layers; ++l) {
+        uid[l] = l;
+        for (int m = 0; m < l; ++m)
+            if (P->basis[m] == P->basis[l]) {
+                uid[l] = uid[m];
+                break;
+            }
+    }
+    // weight-gradient sources, ordered by (unique layer, relation | root) so every reduction group
+    // owns a contiguous slab range
+    struct Key {
+        int layer;
+        long long rel;     // relation id, or -1 for root
+        int batch, level, slot;
+    };
+    std::vector<Key> keys;
+    for (int i = 0; i < nb; ++i)
+        for (int p = 0; p < sd.b[i].L; ++p) {
+            const int li = uid[p < sd.b[i].L - 1 ? p : P->num_layers - 1];
+            for (int z = 0; z <= sd.b[i].tp.E; ++z)
+                keys.push_back(Key{li, z < sd.b[i].tp.E ? sd.b[i].tp.rel[z] : -1, i, p, z});
+        }
+    std::stable_sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+        if (a.layer != b.layer) return a.layer < b.layer;
+        return a.rel < b.rel;
+    });
+    const int tiles = ct * ((D + GT_BM - 1) / GT_BM);
+    int slab = 0, block = 0;
+    hp->wsrc.clear();
+    hp->wblock.clear();
+    hp->groups.clear();
+    for (size_t k = 0; k < keys.size(); ++k) {
+        const Key &key = keys[k];
+        const BatchDev &d = sd.b[key.batch];
+        WSource s;
+        s.batch = key.batch;
+        s.level = key.level;
+        s.slot = key.slot;
+        s.relu = key.level < d.L - 1;
+        const bool is_root = key.slot == d.tp.E;
+        pick_chunks(is_root ? (long long)d.B * d.tp.N : d.B, is_root ? 32 : 16, &s.nch, &s.ch);
+        s.slab_start = slab;
+        s.block_start = block;
+        hp->wsrc.push_back(s);
+        hp->wblock.push_back(block);
+        if (k == 0 || keys[k - 1].layer != key.layer || keys[k - 1].rel != key.rel) {
+            RGroup g;
+            g.kind = key.rel < 0 ? 1 : 0;
+            g.layer = key.layer;
+            g.row = key.rel < 0 ? 0 : key.rel;
+            g.start = slab;
+            g.count = 0;
+            hp->groups.push_back(g);
+        }
+        hp->groups.back().count += s.nch;
+        slab += s.nch;
+        block += s.nch * tiles;
+    }
+    hp->wblock.push_back(block);
+    hp->total_slabs = slab;
+
+    // vector partial sources: bias per (unique layer) and variable rows per mode id
+    struct VKey {
+        int kind, layer;
+        long long row;
+        int batch, lk;
+    };
+    std::vector<VKey> vk;
+    for (int i = 0; i < nb; ++i) {
+        for (int p = 0; p < sd.b[i].L; ++p)
+            vk.push_back(VKey{0, uid[p < sd.b[i].L - 1 ? p : P->num_layers - 1], 0, i, p});
+        for (int k = 0; k < sd.b[i].V; ++k) vk.push_back(VKey{1, 0, sd.b[i].var_id[k], i, k});
+    }
+    std::stable_sort(vk.begin(), vk.end(), [](const VKey &a, const VKey &b) {
+        if (a.kind != b.kind) return a.kind < b.kind;
+        if (a.layer != b.layer) return a.layer < b.layer;
+        return a.row < b.row;
+    });
+    const int cchunks = (D + 63) / 64;
+    int part = 0, vblock = 0;
+    hp->vsrc.clear();
+    hp->vblock.clear();
+    for (size_t k = 0; k < vk.size(); ++k) {
+        const VKey &key = vk[k];
+        const BatchDev &d = sd.b[key.batch];
+        VSource s;
+        s.kind = key.kind;
+        s.batch = key.batch;
+        s.level_or_k = key.lk;
+        s.relu = key.kind == 0 ? key.lk < d.L - 1 : 0;
+        s.nblk = key.kind == 0 ? (int)(((long long)d.B * d.tp.N + 63) / 64) : 1;
+        s.part_start = part;
+        s.block_start = vblock;
+        s.pad = 0;
+        hp->vsrc.push_back(s);
+        hp->vblock.push_back(vblock);
+        if (k == 0 || vk[k - 1].kind != key.kind || vk[k - 1].layer != key.layer || vk[k - 1].row != key.row) {
+            RGroup g;
+            g.kind = key.kind == 0 ? 2 : 3;
+            g.layer = key.layer;
+            g.row = key.row;
+            g.start = part;
+            g.count = 0;
+            hp->groups.push_back(g);
+        }
+        hp->groups.back().count += s.nblk;
+        part += s.nblk;
+        vblock += s.nblk * cchunks;
+    }
+    hp->vblock.push_back(vblock);
+    hp->total_parts = part;
+
+    // workspace layout
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align_up(bytes, 256);
+        return o;
+    };
+    hp->level_stride = rows * D;
+    hp->o_sd = take(sizeof(StepDev));
+    hp->o_wsrc = take(hp->wsrc.size() * sizeof(WSource));
+    hp->o_wblock = take(hp->wblock.size() * sizeof(int));
+    hp->o_vsrc = take(hp->vsrc.size() * sizeof(VSource));
+    hp->o_vblock = take(hp->vblock.size() * sizeof(int));
+    hp->o_groups = take(hp->groups.size() * sizeof(RGroup));
+    hp->o_anchor = take(hp->anchor_off.size() * sizeof(int));
+    hp->o_H = take((size_t)(hp->Lmax + 1) * rows * D * 4);
+    hp->o_GH = take((size_t)(hp->Lmax + 1) * rows * D * 4);
+    hp->o_tpos = take((size_t)graphs * D * 4);
+    hp->o_tneg = take((size_t)graphs * D * 4);
+    hp->o_spos = take((size_t)graphs * 4);
+    hp->o_sneg = take((size_t)graphs * 4);
+    hp->o_terms = take((size_t)graphs * 4);
+    hp->o_slabs = take((size_t)hp->total_slabs * D * D * 4);
+    hp->o_parts = take((size_t)hp->total_parts * D * 4);
+    hp->total = off;
+    return MPQE_OK;
+}
+
+void upload(hipStream_t s, char *dst, const void *src, size_t n) {
+    const char *p = reinterpret_cast<const char *>(src);
+    for (size_t o = 0; o < n; o += UPLOAD_BYTES) {
+        Blob b;
+        const size_t m = n - o < UPLOAD_BYTES ? n - o : UPLOAD_BYTES;
+        memcpy(b.bytes, p + o, m);
+        hipLaunchKernelGGL(step_upload_kernel, dim3(1), dim3(256), 0, s, b, dst + o, (int)m);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t mpqe_step_workspace_bytes(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb) {
+    HostPlan hp;
+    if (make_plan(P, B, nb, &hp) != MPQE_OK) return 0;
+    return hp.total;
+}
+
+extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb,
+                                          const int64_t *anchor_ids, const int64_t *targets, const int64_t *negs,
+                                          float margin, const mpqe_step_grads_t *G, int backward,
+                                          float *loss, float *scores_pos, float *scores_neg, void *workspace,
+                                          size_t workspace_bytes, int32_t *err, void *const *events,
+                                          int num_events, void *stream) {
+    HostPlan hp;
+    int st = make_plan(P, B, nb, &hp);
+    if (st) return st;
+    if (!anchor_ids || !targets || !negs || !loss || !workspace) return MPQE_ERR_INVALID_ARG;
+    if (backward && !G) return MPQE_ERR_INVALID_ARG;
+    if (workspace_bytes < hp.total) return MPQE_ERR_WORKSPACE;
+    if ((uintptr_t)workspace % 256 != 0) return MPQE_ERR_INVALID_ARG;
+    if (!P->node_map || !P->mode_emb) return MPQE_ERR_INVALID_ARG;
+    hipStream_t s = as_stream(stream);
+    char *wb = reinterpret_cast<char *>(workspace);
+    const int D = P->dim;
+    const long long rows = hp.sd.rows_total, graphs = hp.sd.graphs_total;
+    // optional timing: event pair k brackets one launch (see mpqe_amd.h for the order)
+    int ev = 0;
+    auto mark = [&]() {
+        if (events && ev < num_events) hipEventRecord(reinterpret_cast<hipEvent_t>(events[ev]), s);
+        ++ev;
+    };
+
+    LayerPtrs lp;
+    GradPtrs gp;
+    TablePtrs tabs;
+    memset(&lp, 0, sizeof(lp));
+    memset(&gp, 0, sizeof(gp));
+    memset(&tabs, 0, sizeof(tabs));
+    int vec = D % 4 == 0;
+    for (int l = 0; l < P->num_layers; ++l) {
+        if (!P->basis[l] || !P->root[l]) return MPQE_ERR_INVALID_ARG;
+        lp.basis[l] = P->basis[l];
+        lp.root[l] = P->root[l];
+        lp.bias[l] = P->bias[l];
+        vec = vec && ptr_vec_ok(P->basis[l], D) && ptr_vec_ok(P->root[l], D);
+        if (backward) {
+            gp.basis[l] = G->basis[l];
+            gp.root[l] = G->root[l];
+            gp.bias[l] = G->bias[l];
+        }
+    }
+    for (int m = 0; m < P->num_modes; ++m) {
+        if (!P->tables[m]) return MPQE_ERR_INVALID_ARG;
+        tabs.table[m] = P->tables[m];
+        tabs.rows[m] = P->table_rows[m];
+        tabs.grad[m] = backward ? G->tables[m] : nullptr;
+    }
+    if (backward) gp.mode_emb = G->mode_emb;
+
+    const StepDev *sd = reinterpret_cast<const StepDev *>(wb + hp.o_sd);
+    upload(s, wb + hp.o_sd, &hp.sd, sizeof(StepDev));
+    float *H = reinterpret_cast<float *>(wb + hp.o_H), *GH = reinterpret_cast<float *>(wb + hp.o_GH);
+    float *tpos = reinterpret_cast<float *>(wb + hp.o_tpos), *tneg = reinterpret_cast<float *>(wb + hp.o_tneg);
+    float *spos = scores_pos ? scores_pos : reinterpret_cast<float *>(wb + hp.o_spos);
+    float *sneg = scores_neg ? scores_neg : reinterpret_cast<float *>(wb + hp.o_sneg);
+    float *terms = reinterpret_cast<float *>(wb + hp.o_terms);
+    const long long *ids = reinterpret_cast<const long long *>(anchor_ids);
+    const long long *tg = reinterpret_cast<const long long *>(targets), *ng = reinterpret_cast<const long long *>(negs);
+    const long long *nm = reinterpret_cast<const long long *>(P->node_map);
+
+    // ---- forward
+    {
+        const long long waves = rows + 2 * graphs;
+        hipLaunchKernelGGL(step_assemble_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, sd, tabs, nm,
+                           (long long)P->node_map_len, P->mode_emb, (long long)P->num_modes, ids, tg, ng, H, tpos,
+                           tneg, err);
+    }
+    for (int p = 0; p < hp.Lmax; ++p) {
+        mark();
+        hipLaunchKernelGGL(step_layer_fwd_kernel, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p,
+                           (const float *)(H + (long long)p * hp.level_stride),
+                           H + (long long)(p + 1) * hp.level_stride, vec);
+        mark();
+    }
+    hipLaunchKernelGGL(step_score_kernel<false>, dim3((unsigned)((graphs + 3) / 4)), dim3(256), 0, s, sd,
+                       (const float *)H, hp.level_stride, (const float *)tpos, (const float *)tneg, margin, 1e-8f,
+                       spos, sneg, terms, (float *)nullptr, tabs, nm, (long long)P->node_map_len, tg, ng);
+    hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(256), 0, s, sd, (const float *)terms, loss);
+    if (!backward) return mpqe_launch_status();
+
+    // ---- backward
+    upload(s, wb + hp.o_wsrc, hp.wsrc.data(), hp.wsrc.size() * sizeof(WSource));
+    upload(s, wb + hp.o_wblock, hp.wblock.data(), hp.wblock.size() * sizeof(int));
+    upload(s, wb + hp.o_vsrc, hp.vsrc.data(), hp.vsrc.size() * sizeof(VSource));
+    upload(s, wb + hp.o_vblock, hp.vblock.data(), hp.vblock.size() * sizeof(int));
+    upload(s, wb + hp.o_groups, hp.groups.data(), hp.groups.size() * sizeof(RGroup));
+    upload(s, wb + hp.o_anchor, hp.anchor_off.data(), hp.anchor_off.size() * sizeof(int));
+    hipLaunchKernelGGL(step_score_kernel<true>, dim3((unsigned)((graphs + 3) / 4)), dim3(256), 0, s, sd,
+                       (const float *)H, hp.level_stride, (const float *)tpos, (const float *)tneg, margin, 1e-8f,
+                       spos, sneg, terms, GH, tabs, nm, (long long)P->node_map_len, tg, ng);
+    for (int p = hp.Lmax - 1; p >= 0; --p) {
+        mark();
+        hipLaunchKernelGGL(step_layer_bwd_x_kernel, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p,
+                           (const float *)(GH + (long long)(p + 1) * hp.level_stride),
+                           (const float *)(H + (long long)(p + 1) * hp.level_stride),
+                           GH + (long long)p * hp.level_stride, vec);
+        mark();
+    }
+    float *slabs = reinterpret_cast<float *>(wb + hp.o_slabs), *parts = reinterpret_cast<float *>(wb + hp.o_parts);
+    mark();
+    hipLaunchKernelGGL(step_grad_w_kernel, dim3(hp.wblock.back()), dim3(256), 0, s, sd,
+                       reinterpret_cast<const WSource *>(wb + hp.o_wsrc), (int)hp.wsrc.size(),
+                       reinterpret_cast<const int *>(wb + hp.o_wblock), (const float *)H, (const float *)GH,
+                       hp.level_stride, slabs, vec);
+    mark();
+    hipLaunchKernelGGL(step_vec_partial_kernel, dim3(hp.vblock.back()), dim3(256), 0, s, sd,
+                       reinterpret_cast<const VSource *>(wb + hp.o_vsrc), (int)hp.vsrc.size(),
+                       reinterpret_cast<const int *>(wb + hp.o_vblock), (const float *)H, (const float *)GH,
+                       hp.level_stride, parts);
+    if (hp.anchor_off[nb] > 0)
+        hipLaunchKernelGGL(step_anchor_bwd_kernel, dim3((unsigned)((hp.anchor_off[nb] + 3) / 4)), dim3(256), 0, s, sd,
+                           tabs, nm, (long long)P->node_map_len, ids, (const float *)GH,
+                           reinterpret_cast<const int *>(wb + hp.o_anchor), nb);
+    {
+        const long long elems = (long long)D * D;
+        dim3 grid((unsigned)((elems + 255) / 256), (unsigned)hp.groups.size());
+        hipLaunchKernelGGL(step_reduce_kernel, grid, dim3(256), 0, s,
+                           reinterpret_cast<const RGroup *>(wb + hp.o_groups), D, gp, (const float *)slabs,
+                           (const float *)parts);
+    }
+    return mpqe_launch_status();
+}

@@ -1,0 +1,148 @@
+"""Whole-step execution of the encoder: every formula batch of one training step (the
+reference's run_train inner loop, train_helpers.py:76-120: `loss = margin_loss(1-chain) +
+path_weight * ... + inter_weight * ...; loss.backward()`) goes through ONE C-ABI call,
+mpqe_step_forward_backward (~15 kernel launches), instead of one launch per op per batch.
+
+    step = FusedTrainStep(model)                 # model: mpqe_amd.model.RGCNEncoderDecoder
+    packed = step.pack(batches)                  # ids -> HBM, descriptors -> host structs
+    loss = step.run(packed)                      # forward + backward; p.grad holds the gradients
+    optimizer.step()
+
+`p.grad` of every parameter is a view into one flat fp32 buffer, so the data-parallel gradient
+exchange is a single all-reduce of that buffer with no packing copies (mpqe_amd/parallel.py).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _capi, ops
+from .data_utils import RGCNQueryDataset
+
+
+class PackedStep(object):
+    __slots__ = ('batches', 'nb', 'anchor_ids', 'targets', 'negs', 'num_graphs', 'ws_bytes', 'sizes')
+
+
+class FusedTrainStep(object):
+    def __init__(self, model, margin=1.0):
+        enc = model.enc
+        if not hasattr(enc, 'table') or getattr(enc, 'node_maps', None) is None:
+            raise ValueError('FusedTrainStep needs a DirectEncoder built with node_maps')
+        if model.readout_str not in _capi.READOUT_IDS:
+            raise NotImplementedError('fused step covers readouts sum / max / mp; %r runs through the '
+                                      'module path' % model.readout_str)
+        self.model = model
+        self.margin = float(margin)
+        self.device = next(model.parameters()).device
+        if self.device.type != 'cuda':
+            raise RuntimeError('mpqe_amd: the model must be on the GPU -- there is no CPU path')
+        self.modes = list(model.mode_ids.keys())          # table index = mode id order
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.err = ops.new_error_word(self.device)
+        self._ws = None
+        self._refresh_pointers()
+
+    def _refresh_pointers(self):
+        m = self.model
+        tabs = [m.enc.table(mode) for mode in self.modes]
+        for t in tabs + [m.mode_embeddings.weight]:
+            if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+                raise RuntimeError('parameters must be contiguous fp32 CUDA tensors')
+        layers = list(m.layers)
+        self.P = _capi.make_step_params(
+            m.emb_dim, layers[0].num_relations, m.readout_str, [t.data_ptr() for t in tabs],
+            [t.shape[0] for t in tabs], m.enc.node_maps.data_ptr(), m.enc.node_maps.shape[0],
+            m.mode_embeddings.weight.data_ptr(), [l.basis.data_ptr() for l in layers],
+            [l.root.data_ptr() for l in layers], [l.bias.data_ptr() for l in layers])
+        self.G = _capi.make_step_grads(
+            [t.grad.data_ptr() for t in tabs], m.mode_embeddings.weight.grad.data_ptr(),
+            [l.basis.grad.data_ptr() for l in layers], [l.root.grad.data_ptr() for l in layers],
+            [l.bias.grad.data_ptr() for l in layers])
+        self._keep = (tabs, layers)
+
+    def pack(self, batches):
+        """batches: list of dicts with keys formula, anchor_ids ([B, A] int64 tensor/array),
+        targets, negs ([B] ids), weight. Returns the HBM-resident packed step."""
+        m = self.model
+        nb = len(batches)
+        if nb == 0 or nb > _capi.STEP_MAX_BATCHES:
+            raise ValueError('a step holds 1..%d batches' % _capi.STEP_MAX_BATCHES)
+        SB = (_capi.StepBatch * nb)()
+        anchors, tg, ng, sizes = [], [], [], []
+        for i, b in enumerate(batches):
+            f = b['formula']
+            info = ops.template_info(f.query_type)
+            a = torch.as_tensor(b['anchor_ids'], dtype=torch.long)
+            B = a.shape[0]
+            if a.shape[1] != info.num_anchors:
+                raise ValueError('anchor_ids must be [B, %d] for %s' % (info.num_anchors, f.query_type))
+            if m.adaptive:
+                passes = RGCNQueryDataset.query_diameters[f.query_type]
+                if passes > len(m.layers):
+                    raise ValueError(f'RGCN is adaptive with {len(m.layers)}'
+                                     f' layers, but query requires {passes}.')
+            else:
+                passes = m.num_layers
+            nodes, rels = f.get_nodes(), f.get_rels()
+            edge_type = [m.rel_ids[(rels[info.rel_label[e]][2], rels[info.rel_label[e]][1],
+                                    rels[info.rel_label[e]][0])] for e in range(info.num_edges)]
+            var_ids = [m.mode_ids[nodes[info.var_node[k]]] for k in range(info.num_vars)]
+            SB[i] = _capi.make_step_batch(f.query_type, passes, B, edge_type, var_ids,
+                                          [m.mode_ids[x] for x in f.anchor_modes], m.mode_ids[f.target_mode],
+                                          float(b.get('weight', 1.0)))
+            anchors.append(a.t().contiguous().reshape(-1))
+            tg.append(torch.as_tensor(b['targets'], dtype=torch.long).reshape(-1))
+            ng.append(torch.as_tensor(b['negs'], dtype=torch.long).reshape(-1))
+            if tg[-1].shape[0] != B or ng[-1].shape[0] != B:
+                raise ValueError('targets / negs must have one id per query')
+            sizes.append(B)
+        ps = PackedStep()
+        ps.batches, ps.nb, ps.sizes = SB, nb, sizes
+        ps.anchor_ids = torch.cat(anchors).to(self.device)
+        ps.targets = torch.cat(tg).to(self.device)
+        ps.negs = torch.cat(ng).to(self.device)
+        ps.num_graphs = int(sum(sizes))
+        ps.ws_bytes = ops.lib().mpqe_step_workspace_bytes(ctypes.byref(self.P), SB, nb)
+        if ps.ws_bytes == 0:
+            raise _capi.MpqeError('mpqe_step_workspace_bytes rejected the step descriptors')
+        return ps
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes + 256:
+            self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        return (self._ws.data_ptr() + 255) // 256 * 256
+
+    def run(self, packed, backward=True, zero_grad=True, scores=False, events=None):
+        """Returns loss [1 + nb] on the device: loss[0] = weighted step loss, loss[1 + b] =
+        batch b's mean hinge. With backward=True every p.grad then holds d loss[0] / d p
+        (accumulated on top of the previous content unless zero_grad)."""
+        if backward and zero_grad:
+            self.flat_grad.zero_()
+        loss = torch.empty(1 + packed.nb, dtype=torch.float32, device=self.device)
+        sp = sn = None
+        if scores:
+            sp = torch.empty(packed.num_graphs, dtype=torch.float32, device=self.device)
+            sn = torch.empty_like(sp)
+        wptr = self._workspace(packed.ws_bytes)
+        with torch.cuda.device(self.device):
+            st = ops.lib().mpqe_step_forward_backward(
+                ctypes.byref(self.P), packed.batches, packed.nb, packed.anchor_ids.data_ptr(),
+                packed.targets.data_ptr(), packed.negs.data_ptr(), self.margin, ctypes.byref(self.G),
+                1 if backward else 0, loss.data_ptr(), None if sp is None else sp.data_ptr(),
+                None if sn is None else sn.data_ptr(), wptr, packed.ws_bytes, self.err.data_ptr(),
+                events, 0 if events is None else len(events), torch.cuda.current_stream().cuda_stream)
+        _capi.check(ops.lib(), st, 'mpqe_step_forward_backward')
+        if scores:
+            return loss, sp, sn
+        return loss
+
+    def check(self):
+        """Raise IndexError if any kernel of a previous run saw an invalid entity id (one D2H read)."""
+        ops.raise_on_flags(self.err)

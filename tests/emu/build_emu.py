@@ -1,6 +1,7 @@
 """TEST INFRASTRUCTURE ONLY -- builds tests/emu/_build/libmpqe_emu.so: the kernel sources
 of mpqe_amd/csrc compiled for the HOST against the fiber emulator (tests/emu/include),
 so kernel logic can be checked without a GPU. Never loaded by the product."""
+import fcntl
 import glob
 import os
 import subprocess
@@ -20,15 +21,22 @@ def build_emu(force=False):
         glob.glob(os.path.join(HERE, 'include', '*', '*.h*')) + \
         glob.glob(os.path.join(HERE, 'include', '*', '*', '*.h*')) + \
         [os.path.join(HERE, 'emu_runtime.cpp'), os.path.join(ROOT, 'include', 'mpqe_amd.h')]
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+    def fresh():
+        return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps)
+    if not force and fresh():
         return OUT
     if not os.path.exists(CLANG):
         raise RuntimeError('clang++ not found at %s' % CLANG)
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [CLANG, '-x', 'c++', '-std=c++17', '-O1', '-g', '-fPIC', '-shared',
-           '-I' + os.path.join(HERE, 'include'), '-I' + os.path.join(ROOT, 'include')] + \
-        sources() + [os.path.join(HERE, 'emu_runtime.cpp'), '-o', OUT]
-    subprocess.check_call(cmd)
+    with open(OUT + '.lock', 'w') as lock:            # pytest-xdist workers build at most once
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or not fresh():
+            tmp = OUT + '.tmp.%d' % os.getpid()
+            cmd = [CLANG, '-x', 'c++', '-std=c++17', '-O1', '-g', '-fPIC', '-shared',
+                   '-I' + os.path.join(HERE, 'include'), '-I' + os.path.join(ROOT, 'include')] + \
+                sources() + [os.path.join(HERE, 'emu_runtime.cpp'), '-o', tmp]
+            subprocess.check_call(cmd)
+            os.replace(tmp, OUT)
     return OUT
 
 

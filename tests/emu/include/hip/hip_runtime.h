@@ -53,6 +53,9 @@ static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMem
     return hipSuccess;
 }
 
+typedef void *hipEvent_t;
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+
 namespace emu {
 void launch(dim3 grid, dim3 block, const std::function<void()> &body);
 void block_barrier();

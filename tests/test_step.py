@@ -1,0 +1,193 @@
+"""The fused training step (mpqe_step_forward_backward) against the CPU oracle: the weighted sum
+of the reference's margin losses over a mix of formula batches, every score, and every parameter
+gradient. Runs on the host emulator and (gpu) on the real library."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from mpqe_amd import _capi, synthetic
+from oracle import ref_cpu
+
+
+@pytest.fixture(scope='module', params=['emu', pytest.param('hip', marks=pytest.mark.gpu)])
+def be(request):
+    from tests import kernel_backend
+    return kernel_backend.EmuBackend() if request.param == 'emu' else kernel_backend.HipBackend()
+
+
+def make_problem(seed, D, num_layers, shared, mix, readout, adaptive, scale=3.0):
+    rng = np.random.RandomState(seed)
+    torch.manual_seed(seed)
+    schema = synthetic.make_schema(*synthetic.KG_SHAPES['tiny'], seed=seed)
+    graph = synthetic.SchemaGraph(schema, D)
+    mode_ids, rel_ids = ref_cpu.build_ids(schema.relations, graph.mode_weights)
+    R = len(rel_ids)
+    params = {}
+    node_map = torch.full((schema.num_entities + 1,), -1, dtype=torch.long)
+    for m in schema.modes:
+        ids = torch.from_numpy(schema.ids[m])
+        node_map[ids] = torch.arange(len(ids))
+        params['enc.feat-%s.weight' % m] = torch.randn(len(ids) + 1, D) / D
+    params['mode_embeddings.weight'] = torch.randn(len(schema.modes), D)
+    bound = scale / np.sqrt(R * D)
+    for l in range(num_layers):
+        if shared and l > 0:
+            for k in ('basis', 'root', 'bias'):
+                params['layers.%d.%s' % (l, k)] = params['layers.0.%s' % k]
+            continue
+        params['layers.%d.basis' % l] = (torch.rand(R, D, D) * 2 - 1) * bound
+        params['layers.%d.root' % l] = (torch.rand(D, D) * 2 - 1) * bound
+        params['layers.%d.bias' % l] = (torch.rand(D) * 2 - 1) * bound
+    for v in params.values():
+        v.requires_grad_(True)
+    cfg = dict(readout=readout, scatter_op='add', num_layers=num_layers, adaptive=adaptive, weight_decay=0)
+    batches = []
+    for qt, B, w in mix:
+        formula = synthetic.sample_formula(schema, qt, rng)
+        queries = synthetic.sample_queries(schema, formula, B, rng)
+        col = ref_cpu.collate(formula, queries, rel_ids, mode_ids)
+        tg = np.array([q.target_node for q in queries], dtype=np.int64)
+        ng = np.array([q.neg_samples[0] for q in queries], dtype=np.int64)
+        batches.append(dict(formula=formula, col=col, targets=tg, negs=ng, weight=w, qt=qt, B=B))
+    return schema, mode_ids, rel_ids, params, node_map, cfg, batches
+
+
+def oracle_step(params, cfg, node_map, batches, margin):
+    total, per, sp, sn = 0, [], [], []
+    for b in batches:
+        q = ref_cpu.encode_queries(params, cfg, node_map, b['formula'], b['col'])
+        pos = ref_cpu.score(params, node_map, b['formula'], q, b['targets'])
+        neg = ref_cpu.score(params, node_map, b['formula'], q, b['negs'])
+        # the reference's own sequence (two encoder passes) gives the same loss; checked below once
+        l = torch.clamp(margin - (pos - neg), min=0).mean()
+        total = total + b['weight'] * l
+        per.append(l.item())
+        sp.append(pos.detach().numpy())
+        sn.append(neg.detach().numpy())
+    total.backward()
+    return total.item(), per, np.concatenate(sp), np.concatenate(sn)
+
+
+def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=1):
+    D = params['mode_embeddings.weight'].shape[1]
+    L = cfg['num_layers']
+    R = params['layers.0.basis'].shape[0]
+    modes = list(schema.modes)
+    dev = {}
+
+    def put(key):
+        if key not in dev:
+            dev[key] = be.put(params[key].detach().numpy())
+        return dev[key]
+    tables = [put('enc.feat-%s.weight' % m) for m in modes]
+    # shared layers must alias ONE buffer, exactly like the reference's ModuleList of one module
+    uniq = {}
+    lay = []
+    for l in range(L):
+        key = id(params['layers.%d.basis' % l])
+        if key not in uniq:
+            uniq[key] = tuple(put('layers.%d.%s' % (l, k)) for k in ('basis', 'root', 'bias'))
+        lay.append(uniq[key])
+    dnm = be.put(node_map.numpy())
+    dmode = put('mode_embeddings.weight')
+    P = _capi.make_step_params(D, R, cfg['readout'], [be.ptr(t) for t in tables],
+                               [params['enc.feat-%s.weight' % m].shape[0] for m in modes], be.ptr(dnm),
+                               node_map.shape[0], be.ptr(dmode), [be.ptr(x[0]) for x in lay],
+                               [be.ptr(x[1]) for x in lay], [be.ptr(x[2]) for x in lay])
+    gtabs = [be.zeros(tuple(params['enc.feat-%s.weight' % m].shape)) for m in modes]
+    gmode = be.zeros(tuple(params['mode_embeddings.weight'].shape))
+    glay_u = {k: (be.zeros((R, D, D)), be.zeros((D, D)), be.zeros((D,))) for k in uniq}
+    glay = [glay_u[id(params['layers.%d.basis' % l])] for l in range(L)]
+    G = _capi.make_step_grads([be.ptr(t) for t in gtabs], be.ptr(gmode), [be.ptr(x[0]) for x in glay],
+                              [be.ptr(x[1]) for x in glay], [be.ptr(x[2]) for x in glay])
+    nb = len(batches)
+    SB = (_capi.StepBatch * nb)()
+    anchors = []
+    for i, b in enumerate(batches):
+        col, f = b['col'], b['formula']
+        passes = ref_cpu.num_passes(cfg, b['qt'])
+        E = col['E']
+        SB[i] = _capi.make_step_batch(b['qt'], passes, b['B'], col['edge_type'][:E], col['var_ids'],
+                                      [modes.index(m) for m in f.anchor_modes], modes.index(f.target_mode),
+                                      b['weight'])
+        anchors.append(np.ascontiguousarray(col['anchor_ids'].T).reshape(-1))
+    d_anchor = be.put(np.concatenate(anchors))
+    d_tg = be.put(np.concatenate([b['targets'] for b in batches]))
+    d_ng = be.put(np.concatenate([b['negs'] for b in batches]))
+    Gtot = sum(b['B'] for b in batches)
+    wsb = be.lib.mpqe_step_workspace_bytes(ctypes.byref(P), SB, nb)
+    assert wsb > 0
+    ws = be.nbytes(wsb + 256)
+    wptr = (be.ptr(ws) + 255) // 256 * 256
+    loss = be.empty((1 + nb,))
+    sp, sn = be.empty((Gtot,)), be.empty((Gtot,))
+    err = be.zeros((1,), np.int32)
+    be.check(be.lib.mpqe_step_forward_backward(ctypes.byref(P), SB, nb, be.ptr(d_anchor), be.ptr(d_tg),
+                                               be.ptr(d_ng), margin, ctypes.byref(G), backward, be.ptr(loss),
+                                               be.ptr(sp), be.ptr(sn), wptr, wsb, be.ptr(err), None, 0, be.stream), 'step')
+    grads = {'mode_embeddings.weight': be.get(gmode)}
+    for m, g in zip(modes, gtabs):
+        grads['enc.feat-%s.weight' % m] = be.get(g)
+    for l in range(L):
+        for k, g in zip(('basis', 'root', 'bias'), glay[l]):
+            grads['layers.%d.%s' % (l, k)] = be.get(g)
+    return be.get(loss), be.get(sp), be.get(sn), grads, int(be.get(err)[0])
+
+
+MIXES = {
+    'all7': [('1-chain', 9, 1.0), ('2-chain', 70, 0.01), ('3-chain', 33, 0.01), ('2-inter', 5, 0.005),
+             ('3-inter', 65, 0.005), ('3-inter_chain', 12, 0.005), ('3-chain_inter', 40, 0.005)],
+    'dup': [('3-inter', 20, 1.0), ('3-inter', 20, 0.5), ('2-chain', 17, 2.0)],
+}
+
+
+@pytest.mark.parametrize('readout,adaptive,shared,L', [('mp', True, False, 3), ('sum', False, False, 2),
+                                                       ('max', False, True, 3), ('mp', True, True, 3)])
+@pytest.mark.parametrize('mix', ['all7', 'dup'])
+def test_fused_step_matches_oracle(be, readout, adaptive, shared, L, mix):
+    D, margin = 32, 1.0
+    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(
+        11, D, L, shared, MIXES[mix], readout, adaptive)
+    ref_loss, ref_per, ref_sp, ref_sn = oracle_step(params, cfg, node_map, batches, margin)
+    loss, sp, sn, grads, err = run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin)
+    assert err == 0
+    np.testing.assert_allclose(sp, ref_sp, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sn, ref_sn, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(loss[1:], ref_per, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(loss[0], ref_loss, rtol=1e-5, atol=1e-6)
+    seen = set()
+    for k, p in params.items():
+        if id(p) in seen:
+            continue                      # shared layers: one buffer, one accumulated gradient
+        seen.add(id(p))
+        ref = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
+        np.testing.assert_allclose(grads[k], ref, rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+def test_fused_step_equals_reference_two_pass_loss(be):
+    """margin_loss as the reference runs it (two full encoder passes, model.py:478-482) gives the
+    loss the fused single-pass step reports."""
+    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(
+        5, 16, 3, False, [('3-chain_inter', 21, 1.0)], 'mp', True)
+    b = batches[0]
+    ref = ref_cpu.margin_loss(params, cfg, node_map, b['formula'], b['col'], b['targets'], b['negs'],
+                              encode_twice=True)
+    loss, _, _, _, _ = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, backward=0)
+    np.testing.assert_allclose(loss[0], ref.item(), rtol=1e-5, atol=1e-6)
+
+
+def test_fused_step_flags_bad_entity(be):
+    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(
+        7, 16, 2, False, [('2-inter', 6, 1.0)], 'sum', False)
+    batches[0]['targets'][2] = schema.num_entities      # maps to -1 in the LUT
+    _, _, _, _, err = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0)
+    assert err & _capi.FLAG_BAD_NODE_ID
+
+
+def test_fused_step_rejects_bad_descriptors(be):
+    P = _capi.StepParams()
+    SB = (_capi.StepBatch * 1)()
+    assert be.lib.mpqe_step_workspace_bytes(ctypes.byref(P), SB, 1) == 0          # dim 0
+    assert be.lib.mpqe_step_workspace_bytes(ctypes.byref(P), SB, 17) == 0         # > MAX_BATCHES
