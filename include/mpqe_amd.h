@@ -246,6 +246,13 @@ typedef struct {
 
 size_t mpqe_step_workspace_bytes(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,
                                  int num_batches);
+/* The kernels read a small descriptor table (templates, relations, offsets, reduction groups). It
+ * lives in a caller-owned device buffer `desc` (256-byte aligned): with upload_desc != 0 the call
+ * first writes it (by kernel arguments, no host memory is read asynchronously); a packed step
+ * that is run again unchanged passes upload_desc = 0 and re-uses it -- building it is part of
+ * collation, like the reference's collate_fn building edge_index / edge_type.                  */
+size_t mpqe_step_desc_bytes(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,
+                            int num_batches);
 /* anchor_ids: per batch b a block of [A_b, B_b] ids (slot-major), blocks concatenated in batch
  * order; targets / negs: [sum_b B_b]. backward = 0 stops after the loss (grads may be NULL).
  * scores_pos / scores_neg: [sum_b B_b] or NULL. workspace must be 256-byte aligned.
@@ -256,7 +263,8 @@ int mpqe_step_forward_backward(const mpqe_step_params_t *params_host, const mpqe
                                int num_batches, const int64_t *anchor_ids, const int64_t *targets,
                                const int64_t *negs, float margin, const mpqe_step_grads_t *grads_host,
                                int backward, float *loss /*[1 + num_batches]*/, float *scores_pos,
-                               float *scores_neg, void *workspace, size_t workspace_bytes, int32_t *err,
+                               float *scores_neg, void *desc, size_t desc_bytes, int upload_desc,
+                               void *workspace, size_t workspace_bytes, int32_t *err,
                                void *const *events, int num_events, void *stream);
 
 #ifdef __cplusplus

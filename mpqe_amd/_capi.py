@@ -77,8 +77,9 @@ PROTOTYPES = {
     'mpqe_hinge_fwd': (I, [P, P, L, F, P, P]),
     'mpqe_hinge_bwd': (I, [P, P, L, F, P, P, P, P]),
     'mpqe_step_workspace_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I]),
+    'mpqe_step_desc_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I]),
     'mpqe_step_forward_backward': (I, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, P, P, P, F,
-                                       ctypes.POINTER(StepGrads), I, P, P, P, P, Z, P, P, I, P]),
+                                       ctypes.POINTER(StepGrads), I, P, P, P, P, Z, I, P, Z, P, P, I, P]),
 }
 
 QUERY_TYPE_IDS = {'1-chain': 0, '2-chain': 1, '3-chain': 2, '2-inter': 3, '3-inter': 4,

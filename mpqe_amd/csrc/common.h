@@ -44,3 +44,31 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+
+// L2 normalisation of one embedding row by one wave: dst = v / ||v||_2 (no eps, reference
+// encoders.py:42-43). ONE definition shared by the per-op kernel and the fused step so that both
+// paths round identically (a last-bit difference in x0 can flip a ReLU downstream).
+__device__ __forceinline__ float row_norm_store(const float *__restrict__ v, float *__restrict__ o, int D,
+                                                int lane, bool vec) {
+    float ss = 0.f;
+    if (vec) {
+        for (int c = lane * 4; c < D; c += 256) {
+            f32x4 q = *reinterpret_cast<const f32x4 *>(v + c);
+            ss += q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+        }
+    } else {
+        for (int c = lane; c < D; c += 64) ss += v[c] * v[c];
+    }
+    ss = wave_sum(ss);
+    const float nrm = sqrtf(ss);
+    if (vec) {
+        for (int c = lane * 4; c < D; c += 256) {
+            f32x4 q = *reinterpret_cast<const f32x4 *>(v + c);
+            q[0] /= nrm; q[1] /= nrm; q[2] /= nrm; q[3] /= nrm;
+            *reinterpret_cast<f32x4 *>(o + c) = q;
+        }
+    } else {
+        for (int c = lane; c < D; c += 64) o[c] = v[c] / nrm;
+    }
+    return nrm;
+}

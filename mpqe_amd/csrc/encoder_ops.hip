@@ -78,27 +78,7 @@ __global__ __launch_bounds__(256) void embed_l2norm_fwd_kernel(
         if (inv_norm && lane == 0) inv_norm[i] = 0.f;
         return;
     }
-    const float *v = table + row * D;
-    float ss = 0.f;
-    if (vec) {
-        for (int c = lane * 4; c < D; c += 256) {
-            f32x4 q = *reinterpret_cast<const f32x4 *>(v + c);
-            ss += q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
-        }
-    } else {
-        for (int c = lane; c < D; c += 64) ss += v[c] * v[c];
-    }
-    ss = wave_sum(ss);
-    const float nrm = sqrtf(ss);
-    if (vec) {
-        for (int c = lane * 4; c < D; c += 256) {
-            f32x4 q = *reinterpret_cast<const f32x4 *>(v + c);
-            q[0] /= nrm; q[1] /= nrm; q[2] /= nrm; q[3] /= nrm;
-            *reinterpret_cast<f32x4 *>(o + c) = q;
-        }
-    } else {
-        for (int c = lane; c < D; c += 64) o[c] = v[c] / nrm;
-    }
+    const float nrm = row_norm_store(table + row * D, o, D, lane, vec);
     if (inv_norm && lane == 0) inv_norm[i] = 1.f / nrm;
 }
 

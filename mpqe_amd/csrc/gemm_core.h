@@ -47,6 +47,12 @@ __device__ __forceinline__ f32x4 ld4_guard(const float *p, int c, int limit, boo
 // (row, col..col+3) of K-step `step`, zero beyond the operand's extent:
 //   R-type: row in [0,64), col in {0,4,..,28} along k
 //   K-type: row in [0,32) along k, col in {0,4,..,60}
+//
+// Pipeline: prefetch distance 2. Two register sets hold the tiles of steps s+1 and s+2 while
+// step s is multiplied out of LDS, so every global load has two MFMA phases (~0.9 us) to land;
+// at this path's problem sizes a tile is a short dependent chain of <= 16 steps and the load
+// latency, not bandwidth or MFMA rate, sets its duration. The loop is unrolled by two so that
+// the register sets are addressed statically (a runtime-indexed set would live in scratch).
 template <bool A_K, bool B_K, class AF, class BF>
 __device__ __forceinline__ void gemm_block(f32x16 &acc, AF aload, BF bload, int nsteps, float *smem) {
     const int t = threadIdx.x;
@@ -67,25 +73,22 @@ __device__ __forceinline__ void gemm_block(f32x16 &acc, AF aload, BF bload, int 
     const int ldb = B_K ? GT_LDK : GT_LDR;
 
     if (nsteps <= 0) return;
-    f32x4 ra0 = aload(ar0, ac, 0), ra1 = aload(ar1, ac, 0);
-    f32x4 rb0 = bload(br0, bc, 0), rb1 = bload(br1, bc, 0);
-    *reinterpret_cast<f32x4 *>(As + ar0 * lda + ac) = ra0;
-    *reinterpret_cast<f32x4 *>(As + ar1 * lda + ac) = ra1;
-    *reinterpret_cast<f32x4 *>(Bs + br0 * ldb + bc) = rb0;
-    *reinterpret_cast<f32x4 *>(Bs + br1 * ldb + bc) = rb1;
-    __syncthreads();
+    f32x4 pa0, pa1, pb0, pb1;      // register set P
+    f32x4 qa0, qa1, qb0, qb1;      // register set Q
+#define GT_LOAD(A0, A1, B0, B1, STEP) \
+    A0 = aload(ar0, ac, (STEP));       \
+    A1 = aload(ar1, ac, (STEP));       \
+    B0 = bload(br0, bc, (STEP));       \
+    B1 = bload(br1, bc, (STEP));
+#define GT_STORE(BUF, A0, A1, B0, B1)                                                   \
+    *reinterpret_cast<f32x4 *>(As + (BUF)*GT_TILE_FLOATS + ar0 * lda + ac) = A0;        \
+    *reinterpret_cast<f32x4 *>(As + (BUF)*GT_TILE_FLOATS + ar1 * lda + ac) = A1;        \
+    *reinterpret_cast<f32x4 *>(Bs + (BUF)*GT_TILE_FLOATS + br0 * ldb + bc) = B0;        \
+    *reinterpret_cast<f32x4 *>(Bs + (BUF)*GT_TILE_FLOATS + br1 * ldb + bc) = B1;
 
-    for (int s = 0; s < nsteps; ++s) {
-        const int cur = s & 1;
-        const bool more = (s + 1) < nsteps;
-        if (more) {
-            ra0 = aload(ar0, ac, s + 1);
-            ra1 = aload(ar1, ac, s + 1);
-            rb0 = bload(br0, bc, s + 1);
-            rb1 = bload(br1, bc, s + 1);
-        }
-        const float *Ac = As + cur * GT_TILE_FLOATS;
-        const float *Bc = Bs + cur * GT_TILE_FLOATS;
+    auto compute = [&](int buf) {
+        const float *Ac = As + buf * GT_TILE_FLOATS;
+        const float *Bc = Bs + buf * GT_TILE_FLOATS;
         float a[16], b[16];
         if (A_K) {
 #pragma unroll
@@ -109,16 +112,31 @@ __device__ __forceinline__ void gemm_block(f32x16 &acc, AF aload, BF bload, int 
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[k], acc, 0, 0, 0);
-        if (more) {
-            float *An = As + (cur ^ 1) * GT_TILE_FLOATS;
-            float *Bn = Bs + (cur ^ 1) * GT_TILE_FLOATS;
-            *reinterpret_cast<f32x4 *>(An + ar0 * lda + ac) = ra0;
-            *reinterpret_cast<f32x4 *>(An + ar1 * lda + ac) = ra1;
-            *reinterpret_cast<f32x4 *>(Bn + br0 * ldb + bc) = rb0;
-            *reinterpret_cast<f32x4 *>(Bn + br1 * ldb + bc) = rb1;
-        }
+    };
+
+    // prologue: tile 0 -> LDS[0]; tiles 1, 2 in flight in Q, P
+    GT_LOAD(pa0, pa1, pb0, pb1, 0)
+    if (nsteps > 1) { GT_LOAD(qa0, qa1, qb0, qb1, 1) }
+    GT_STORE(0, pa0, pa1, pb0, pb1)
+    if (nsteps > 2) { GT_LOAD(pa0, pa1, pb0, pb1, 2) }
+    __syncthreads();
+    int s = 0;
+    while (true) {
+        // even step: tile s in LDS[0]; Q holds tile s+1, P holds tile s+2
+        compute(0);
+        if (s + 1 < nsteps) { GT_STORE(1, qa0, qa1, qb0, qb1) }
+        if (s + 3 < nsteps) { GT_LOAD(qa0, qa1, qb0, qb1, s + 3) }
         __syncthreads();
+        if (++s >= nsteps) break;
+        // odd step: tile s in LDS[1]; P holds tile s+1, Q holds tile s+2
+        compute(1);
+        if (s + 1 < nsteps) { GT_STORE(0, pa0, pa1, pb0, pb1) }
+        if (s + 3 < nsteps) { GT_LOAD(pa0, pa1, pb0, pb1, s + 3) }
+        __syncthreads();
+        if (++s >= nsteps) break;
     }
+#undef GT_LOAD
+#undef GT_STORE
 }
 
 // C/D fragment coordinates of accumulator register `reg` for this lane inside

@@ -16,34 +16,50 @@ __device__ __forceinline__ void tmpl_fwd_tile(const TmplArgs &tp, long long B, c
                                               const float *__restrict__ bias, int Din, int Dout, int relu,
                                               float *__restrict__ out, int vec_x, int vec_w, int n, long long b0,
                                               int n0, float *smem) {
-    const int nsteps = (Din + GT_BK - 1) / GT_BK;
+    // K-blocks of this node slot: one per incoming template edge, then the self/root block.
+    // They are walked as ONE pipelined K loop (block kb = step / spb) so the prefetch never drains
+    // between blocks; the (source slot, weight) of a block is picked with selects, not an array,
+    // to stay in registers.
+    const int spb = (Din + GT_BK - 1) / GT_BK;     // steps per block
+    int nk = 0;
+    int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    const float *W0 = root, *W1 = root, *W2 = root, *W3 = root;
+    for (int e = 0; e <= tp.E; ++e) {
+        int sv;
+        const float *Wv;
+        if (e < tp.E) {
+            if (tp.dst[e] != n) continue;
+            sv = tp.src[e];
+            Wv = basis + tp.rel[e] * (long long)Din * Dout;
+        } else {
+            sv = n;
+            Wv = root;
+        }
+        if (nk == 0) { s0 = sv; W0 = Wv; }
+        else if (nk == 1) { s1 = sv; W1 = Wv; }
+        else if (nk == 2) { s2 = sv; W2 = Wv; }
+        else { s3 = sv; W3 = Wv; }
+        ++nk;
+    }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int kb = 0; kb <= tp.E; ++kb) {
-        int s;
-        const float *W;
-        if (kb < tp.E) {
-            if (tp.dst[kb] != n) continue;
-            s = tp.src[kb];
-            W = basis + tp.rel[kb] * (long long)Din * Dout;
-        } else {
-            s = n;
-            W = root;
-        }
-        auto aload = [&](int r, int c, int step) -> f32x4 {
-            const long long b = b0 + r;
-            if (b >= B) return f32x4{0.f, 0.f, 0.f, 0.f};
-            const float *p = x + (b * tp.N + s) * (long long)Din;
-            return ld4_guard(p, step * GT_BK + c, Din, vec_x);
-        };
-        auto bload = [&](int k, int c, int step) -> f32x4 {
-            const int kk = step * GT_BK + k;
-            if (kk >= Din) return f32x4{0.f, 0.f, 0.f, 0.f};
-            return ld4_guard(W + (long long)kk * Dout, n0 + c, Dout, vec_w);
-        };
-        gemm_block<false, true>(acc, aload, bload, nsteps, smem);
-    }
+    auto aload = [&](int r, int c, int step) -> f32x4 {
+        const long long b = b0 + r;
+        if (b >= B) return f32x4{0.f, 0.f, 0.f, 0.f};
+        const int kb = step / spb, ls = step - kb * spb;
+        const int sv = kb == 0 ? s0 : (kb == 1 ? s1 : (kb == 2 ? s2 : s3));
+        const float *p = x + (b * tp.N + sv) * (long long)Din;
+        return ld4_guard(p, ls * GT_BK + c, Din, vec_x);
+    };
+    auto bload = [&](int k, int c, int step) -> f32x4 {
+        const int kb = step / spb, ls = step - kb * spb;
+        const int kk = ls * GT_BK + k;
+        if (kk >= Din) return f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *Wv = kb == 0 ? W0 : (kb == 1 ? W1 : (kb == 2 ? W2 : W3));
+        return ld4_guard(Wv + (long long)kk * Dout, n0 + c, Dout, vec_w);
+    };
+    gemm_block<false, true>(acc, aload, bload, nk * spb, smem);
     const int col = n0 + acc_col();
     if (col < Dout) {
         const float bv = bias ? bias[col] : 0.f;
@@ -66,41 +82,53 @@ __device__ __forceinline__ void tmpl_bwd_x_tile(const TmplArgs &tp, long long B,
                                                 const float *__restrict__ root, int Din, int Dout, int relu,
                                                 float *__restrict__ grad_x, int vec_g, int vec_w, int m,
                                                 long long b0, int n0, float *smem) {
-    const int nsteps = (Dout + GT_BK - 1) / GT_BK;   // K runs over Dout
+    const int spb = (Dout + GT_BK - 1) / GT_BK;   // K runs over Dout; steps per block
+    int nk = 0;
+    int d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+    const float *W0 = root, *W1 = root, *W2 = root, *W3 = root;
+    for (int e = 0; e <= tp.E; ++e) {
+        int dv;
+        const float *Wv;
+        if (e < tp.E) {
+            if (tp.src[e] != m) continue;
+            dv = tp.dst[e];
+            Wv = basis + tp.rel[e] * (long long)Din * Dout;
+        } else {
+            dv = m;
+            Wv = root;
+        }
+        if (nk == 0) { d0 = dv; W0 = Wv; }
+        else if (nk == 1) { d1 = dv; W1 = Wv; }
+        else if (nk == 2) { d2 = dv; W2 = Wv; }
+        else { d3 = dv; W3 = Wv; }
+        ++nk;
+    }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int kb = 0; kb <= tp.E; ++kb) {
-        int d;
-        const float *W;
-        if (kb < tp.E) {
-            if (tp.src[kb] != m) continue;
-            d = tp.dst[kb];
-            W = basis + tp.rel[kb] * (long long)Din * Dout;
-        } else {
-            d = m;
-            W = root;
-        }
-        auto aload = [&](int r, int c, int step) -> f32x4 {
-            const long long b = b0 + r;
-            if (b >= B) return f32x4{0.f, 0.f, 0.f, 0.f};
-            const long long off = (b * tp.N + d) * (long long)Dout;
-            f32x4 v = ld4_guard(g + off, step * GT_BK + c, Dout, vec_g);
-            if (relu) {
-                f32x4 o = ld4_guard(out + off, step * GT_BK + c, Dout, vec_g);
+    auto aload = [&](int r, int c, int step) -> f32x4 {
+        const long long b = b0 + r;
+        if (b >= B) return f32x4{0.f, 0.f, 0.f, 0.f};
+        const int kb = step / spb, ls = step - kb * spb;
+        const int dv = kb == 0 ? d0 : (kb == 1 ? d1 : (kb == 2 ? d2 : d3));
+        const long long off = (b * tp.N + dv) * (long long)Dout;
+        f32x4 v = ld4_guard(g + off, ls * GT_BK + c, Dout, vec_g);
+        if (relu) {
+            f32x4 o = ld4_guard(out + off, ls * GT_BK + c, Dout, vec_g);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = o[q] > 0.f ? v[q] : 0.f;
-            }
-            return v;
-        };
-        // B[k][n] = W[n][k]: R-type image, tile row = output column n (over Din), contiguous in k
-        auto bload = [&](int r, int c, int step) -> f32x4 {
-            const int nn = n0 + r;
-            if (nn >= Din) return f32x4{0.f, 0.f, 0.f, 0.f};
-            return ld4_guard(W + (long long)nn * Dout, step * GT_BK + c, Dout, vec_w);
-        };
-        gemm_block<false, false>(acc, aload, bload, nsteps, smem);
-    }
+            for (int q = 0; q < 4; ++q) v[q] = o[q] > 0.f ? v[q] : 0.f;
+        }
+        return v;
+    };
+    // B[k][n] = W[n][k]: R-type image, tile row = output column n (over Din), contiguous in k
+    auto bload = [&](int r, int c, int step) -> f32x4 {
+        const int nn = n0 + r;
+        if (nn >= Din) return f32x4{0.f, 0.f, 0.f, 0.f};
+        const int kb = step / spb, ls = step - kb * spb;
+        const float *Wv = kb == 0 ? W0 : (kb == 1 ? W1 : (kb == 2 ? W2 : W3));
+        return ld4_guard(Wv + (long long)nn * Dout, ls * GT_BK + c, Dout, vec_w);
+    };
+    gemm_block<false, false>(acc, aload, bload, nk * spb, smem);
     const int col = n0 + acc_col();
     if (col < Din) {
 #pragma unroll

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(
     const StepDev *__restrict__ sd, TablePtrs tabs, const long long *__restrict__ node_map, long long map_len,
     const float *__restrict__ mode_emb, long long num_modes, const long long *__restrict__ anchor_ids,
     const long long *__restrict__ targets, const long long *__restrict__ negs, float *__restrict__ H0,
-    float *__restrict__ tpos, float *__restrict__ tneg, int32_t *err) {
+    float *__restrict__ tpos, float *__restrict__ tneg, int32_t *err, int vec) {
     const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int D = sd->D;
@@ -168,11 +168,7 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(
         for (int c = lane; c < D; c += 64) dst[c] = src[c];
         return;
     }
-    float ss = 0.f;
-    for (int c = lane; c < D; c += 64) ss += src[c] * src[c];
-    ss = wave_sum(ss);
-    const float nrm = sqrtf(ss);
-    for (int c = lane; c < D; c += 64) dst[c] = src[c] / nrm;
+    row_norm_store(src, dst, D, lane, vec);
 }
 
 // ------------------------------------------------------------------------------------ layer levels
@@ -351,28 +347,29 @@ __global__ __launch_bounds__(256) void step_score_kernel(
     }
 }
 
-// loss[0] = sum_b w_b * mean_b(terms), loss[1 + b] = mean_b(terms): one workgroup, fixed order
-__global__ __launch_bounds__(256) void step_loss_kernel(const StepDev *__restrict__ sd,
-                                                        const float *__restrict__ terms,
-                                                        float *__restrict__ loss) {
-    __shared__ float red[256];
-    float total = 0.f;
-    for (int bi = 0; bi < sd->nb; ++bi) {
-        const BatchDev &b = sd->b[bi];
+// loss[0] = sum_b w_b * mean_b(terms), loss[1 + b] = mean_b(terms): one workgroup of 16 waves, wave b
+// sums batch b (lane-strided, then a butterfly), thread 0 adds the batches in order -> fixed order
+__global__ __launch_bounds__(1024) void step_loss_kernel(const StepDev *__restrict__ sd,
+                                                         const float *__restrict__ terms,
+                                                         float *__restrict__ loss) {
+    __shared__ float mean[MPQE_STEP_MAX_BATCHES];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (w < sd->nb) {
+        const BatchDev &b = sd->b[w];
         float s = 0.f;
-        for (int i = threadIdx.x; i < b.B; i += 256) s += terms[b.g_off + i];
-        red[threadIdx.x] = s;
-        __syncthreads();
-        for (int w = 128; w > 0; w >>= 1) {
-            if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-            __syncthreads();
+        for (int i = lane; i < b.B; i += 64) s += terms[b.g_off + i];
+        s = wave_sum(s);
+        if (lane == 0) {
+            mean[w] = s / (float)b.B;
+            loss[1 + w] = mean[w];
         }
-        const float mean = red[0] / (float)b.B;
-        if (threadIdx.x == 0) loss[1 + bi] = mean;
-        total += b.weight * mean;
-        __syncthreads();
     }
-    if (threadIdx.x == 0) loss[0] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float total = 0.f;
+        for (int bi = 0; bi < sd->nb; ++bi) total += sd->b[bi].weight * mean[bi];
+        loss[0] = total;
+    }
 }
 
 // ------------------------------------------------------------------------------------ weight gradients
@@ -405,7 +402,8 @@ __global__ __launch_bounds__(256) void step_grad_w_kernel(const StepDev *__restr
 }
 
 // partial vectors. kind 0: column sums of gpre over 64-row blocks of (batch, level).
-// kind 1: sum over the batch of gH[0] variable row k, 4 row groups x 64 columns per workgroup.
+// kind 1: sums of gH[0] variable row k over 64-graph blocks of the batch; 4 row groups x 64 columns per
+// workgroup in both kinds.
 __global__ __launch_bounds__(256) void step_vec_partial_kernel(const StepDev *__restrict__ sd,
                                                                const VSource *__restrict__ src, int nsrc,
                                                                const int *__restrict__ block_start,
@@ -436,8 +434,10 @@ __global__ __launch_bounds__(256) void step_vec_partial_kernel(const StepDev *__
     } else {
         const float *g = GH + b.row_off * D;          // level 0
         const int k = s.level_or_k;
+        const long long g0 = (long long)blk * 64;
         if (c < D)
-            for (long long gi = rg; gi < b.B; gi += 4) acc += g[(gi * b.tp.N + b.A + k) * D + c];
+            for (long long gi = g0 + rg; gi < g0 + 64 && gi < b.B; gi += 4)
+                acc += g[(gi * b.tp.N + b.A + k) * D + c];
     }
     part[rg][cl] = acc;
     __syncthreads();
@@ -484,22 +484,31 @@ struct GradPtrs {
     float *mode_emb;
 };
 
+// out += sum of the group's slabs / partial rows. A workgroup owns 64 consecutive elements; its 4
+// waves each add every 4th slab, the four sums are combined as (0+1)+(2+3): a fixed order.
 __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restrict__ groups, int D, GradPtrs gp,
                                                           const float *__restrict__ slabs,
                                                           const float *__restrict__ partial) {
+    __shared__ float part[4][64];
     const RGroup g = groups[blockIdx.y];
     const long long elems = g.kind <= 1 ? (long long)D * D : D;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= elems) return;
-    const float *p = (g.kind <= 1 ? slabs : partial) + (long long)g.start * elems + idx;
+    const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const long long idx = (long long)blockIdx.x * 64 + el;
+    if ((long long)blockIdx.x * 64 >= elems) return;
     float s = 0.f;
-    for (int i = 0; i < g.count; ++i) s += p[(long long)i * elems];
+    if (idx < elems) {
+        const float *p = (g.kind <= 1 ? slabs : partial) + (long long)g.start * elems + idx;
+        for (int i = sg; i < g.count; i += 4) s += p[(long long)i * elems];
+    }
+    part[sg][el] = s;
+    __syncthreads();
+    if (sg != 0 || idx >= elems) return;
     float *dst;
     if (g.kind == 0) dst = gp.basis[g.layer] ? gp.basis[g.layer] + g.row * elems : nullptr;
     else if (g.kind == 1) dst = gp.root[g.layer];
     else if (g.kind == 2) dst = gp.bias[g.layer];
     else dst = gp.mode_emb ? gp.mode_emb + g.row * D : nullptr;
-    if (dst) dst[idx] += s;
+    if (dst) dst[idx] += (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
 }
 
 // ------------------------------------------------------------------------------------ host side
@@ -517,13 +526,15 @@ struct HostPlan {
     std::vector<int> anchor_off;      // nb + 1 (rows of the anchor backward)
     int total_slabs, total_parts;
     // workspace offsets (bytes)
-    size_t o_sd, o_wsrc, o_wblock, o_vsrc, o_vblock, o_groups, o_anchor, o_H, o_GH, o_tpos, o_tneg, o_spos,
-        o_sneg, o_terms, o_slabs, o_parts, total;
+    size_t o_sd, o_wsrc, o_wblock, o_vsrc, o_vblock, o_groups, o_anchor, desc_total;     // descriptor buffer
+    size_t o_H, o_GH, o_tpos, o_tneg, o_spos, o_sneg, o_terms, o_slabs, o_parts, total;  // workspace
     long long level_stride;
 };
 
 void pick_chunks(long long count, int max_chunks, int *nch, int *ch) {
-    long long n = (count + 127) / 128;
+    // ~512 rows (16 K-steps) per workgroup: long enough to amortise the pipeline fill and the
+    // 16 KB slab store, short enough that the AIFB-sized step still yields ~500 workgroups
+    long long n = (count + 511) / 512;
     if (n < 1) n = 1;
     if (n > max_chunks) n = max_chunks;
     long long c = (count + n - 1) / n;
@@ -644,7 +655,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, H
         s.slot = key.slot;
         s.relu = key.level < d.L - 1;
         const bool is_root = key.slot == d.tp.E;
-        pick_chunks(is_root ? (long long)d.B * d.tp.N : d.B, is_root ? 32 : 16, &s.nch, &s.ch);
+        pick_chunks(is_root ? (long long)d.B * d.tp.N : d.B, is_root ? 64 : 32, &s.nch, &s.ch);
         s.slab_start = slab;
         s.block_start = block;
         hp->wsrc.push_back(s);
@@ -694,7 +705,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, H
         s.batch = key.batch;
         s.level_or_k = key.lk;
         s.relu = key.kind == 0 ? key.lk < d.L - 1 : 0;
-        s.nblk = key.kind == 0 ? (int)(((long long)d.B * d.tp.N + 63) / 64) : 1;
+        s.nblk = key.kind == 0 ? (int)(((long long)d.B * d.tp.N + 63) / 64) : (d.B + 63) / 64;
         s.part_start = part;
         s.block_start = vblock;
         s.pad = 0;
@@ -731,6 +742,8 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, H
     hp->o_vblock = take(hp->vblock.size() * sizeof(int));
     hp->o_groups = take(hp->groups.size() * sizeof(RGroup));
     hp->o_anchor = take(hp->anchor_off.size() * sizeof(int));
+    hp->desc_total = off;
+    off = 0;
     hp->o_H = take((size_t)(hp->Lmax + 1) * rows * D * 4);
     hp->o_GH = take((size_t)(hp->Lmax + 1) * rows * D * 4);
     hp->o_tpos = take((size_t)graphs * D * 4);
@@ -761,23 +774,32 @@ extern "C" size_t mpqe_step_workspace_bytes(const mpqe_step_params_t *P, const m
     if (make_plan(P, B, nb, &hp) != MPQE_OK) return 0;
     return hp.total;
 }
+extern "C" size_t mpqe_step_desc_bytes(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb) {
+    HostPlan hp;
+    if (make_plan(P, B, nb, &hp) != MPQE_OK) return 0;
+    return hp.desc_total;
+}
 
 extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb,
                                           const int64_t *anchor_ids, const int64_t *targets, const int64_t *negs,
                                           float margin, const mpqe_step_grads_t *G, int backward,
-                                          float *loss, float *scores_pos, float *scores_neg, void *workspace,
+                                          float *loss, float *scores_pos, float *scores_neg, void *desc,
+                                          size_t desc_bytes, int upload_desc, void *workspace,
                                           size_t workspace_bytes, int32_t *err, void *const *events,
                                           int num_events, void *stream) {
     HostPlan hp;
     int st = make_plan(P, B, nb, &hp);
     if (st) return st;
-    if (!anchor_ids || !targets || !negs || !loss || !workspace) return MPQE_ERR_INVALID_ARG;
+    if (!anchor_ids || !targets || !negs || !loss || !workspace || !desc) return MPQE_ERR_INVALID_ARG;
+    if (desc_bytes < hp.desc_total) return MPQE_ERR_WORKSPACE;
+    if ((uintptr_t)desc % 256 != 0) return MPQE_ERR_INVALID_ARG;
     if (backward && !G) return MPQE_ERR_INVALID_ARG;
     if (workspace_bytes < hp.total) return MPQE_ERR_WORKSPACE;
     if ((uintptr_t)workspace % 256 != 0) return MPQE_ERR_INVALID_ARG;
     if (!P->node_map || !P->mode_emb) return MPQE_ERR_INVALID_ARG;
     hipStream_t s = as_stream(stream);
     char *wb = reinterpret_cast<char *>(workspace);
+    char *db = reinterpret_cast<char *>(desc);
     const int D = P->dim;
     const long long rows = hp.sd.rows_total, graphs = hp.sd.graphs_total;
     // optional timing: event pair k brackets one launch (see mpqe_amd.h for the order)
@@ -806,16 +828,26 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             gp.bias[l] = G->bias[l];
         }
     }
+    int vec_tab = D % 4 == 0;
     for (int m = 0; m < P->num_modes; ++m) {
         if (!P->tables[m]) return MPQE_ERR_INVALID_ARG;
+        vec_tab = vec_tab && (uintptr_t)P->tables[m] % 16 == 0;
         tabs.table[m] = P->tables[m];
         tabs.rows[m] = P->table_rows[m];
         tabs.grad[m] = backward ? G->tables[m] : nullptr;
     }
     if (backward) gp.mode_emb = G->mode_emb;
 
-    const StepDev *sd = reinterpret_cast<const StepDev *>(wb + hp.o_sd);
-    upload(s, wb + hp.o_sd, &hp.sd, sizeof(StepDev));
+    const StepDev *sd = reinterpret_cast<const StepDev *>(db + hp.o_sd);
+    if (upload_desc) {
+        upload(s, db + hp.o_sd, &hp.sd, sizeof(StepDev));
+        upload(s, db + hp.o_wsrc, hp.wsrc.data(), hp.wsrc.size() * sizeof(WSource));
+        upload(s, db + hp.o_wblock, hp.wblock.data(), hp.wblock.size() * sizeof(int));
+        upload(s, db + hp.o_vsrc, hp.vsrc.data(), hp.vsrc.size() * sizeof(VSource));
+        upload(s, db + hp.o_vblock, hp.vblock.data(), hp.vblock.size() * sizeof(int));
+        upload(s, db + hp.o_groups, hp.groups.data(), hp.groups.size() * sizeof(RGroup));
+        upload(s, db + hp.o_anchor, hp.anchor_off.data(), hp.anchor_off.size() * sizeof(int));
+    }
     float *H = reinterpret_cast<float *>(wb + hp.o_H), *GH = reinterpret_cast<float *>(wb + hp.o_GH);
     float *tpos = reinterpret_cast<float *>(wb + hp.o_tpos), *tneg = reinterpret_cast<float *>(wb + hp.o_tneg);
     float *spos = scores_pos ? scores_pos : reinterpret_cast<float *>(wb + hp.o_spos);
@@ -830,7 +862,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         const long long waves = rows + 2 * graphs;
         hipLaunchKernelGGL(step_assemble_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, sd, tabs, nm,
                            (long long)P->node_map_len, P->mode_emb, (long long)P->num_modes, ids, tg, ng, H, tpos,
-                           tneg, err);
+                           tneg, err, vec_tab);
     }
     for (int p = 0; p < hp.Lmax; ++p) {
         mark();
@@ -842,16 +874,10 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     hipLaunchKernelGGL(step_score_kernel<false>, dim3((unsigned)((graphs + 3) / 4)), dim3(256), 0, s, sd,
                        (const float *)H, hp.level_stride, (const float *)tpos, (const float *)tneg, margin, 1e-8f,
                        spos, sneg, terms, (float *)nullptr, tabs, nm, (long long)P->node_map_len, tg, ng);
-    hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(256), 0, s, sd, (const float *)terms, loss);
+    hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss);
     if (!backward) return mpqe_launch_status();
 
     // ---- backward
-    upload(s, wb + hp.o_wsrc, hp.wsrc.data(), hp.wsrc.size() * sizeof(WSource));
-    upload(s, wb + hp.o_wblock, hp.wblock.data(), hp.wblock.size() * sizeof(int));
-    upload(s, wb + hp.o_vsrc, hp.vsrc.data(), hp.vsrc.size() * sizeof(VSource));
-    upload(s, wb + hp.o_vblock, hp.vblock.data(), hp.vblock.size() * sizeof(int));
-    upload(s, wb + hp.o_groups, hp.groups.data(), hp.groups.size() * sizeof(RGroup));
-    upload(s, wb + hp.o_anchor, hp.anchor_off.data(), hp.anchor_off.size() * sizeof(int));
     hipLaunchKernelGGL(step_score_kernel<true>, dim3((unsigned)((graphs + 3) / 4)), dim3(256), 0, s, sd,
                        (const float *)H, hp.level_stride, (const float *)tpos, (const float *)tneg, margin, 1e-8f,
                        spos, sneg, terms, GH, tabs, nm, (long long)P->node_map_len, tg, ng);
@@ -866,23 +892,23 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     float *slabs = reinterpret_cast<float *>(wb + hp.o_slabs), *parts = reinterpret_cast<float *>(wb + hp.o_parts);
     mark();
     hipLaunchKernelGGL(step_grad_w_kernel, dim3(hp.wblock.back()), dim3(256), 0, s, sd,
-                       reinterpret_cast<const WSource *>(wb + hp.o_wsrc), (int)hp.wsrc.size(),
-                       reinterpret_cast<const int *>(wb + hp.o_wblock), (const float *)H, (const float *)GH,
+                       reinterpret_cast<const WSource *>(db + hp.o_wsrc), (int)hp.wsrc.size(),
+                       reinterpret_cast<const int *>(db + hp.o_wblock), (const float *)H, (const float *)GH,
                        hp.level_stride, slabs, vec);
     mark();
     hipLaunchKernelGGL(step_vec_partial_kernel, dim3(hp.vblock.back()), dim3(256), 0, s, sd,
-                       reinterpret_cast<const VSource *>(wb + hp.o_vsrc), (int)hp.vsrc.size(),
-                       reinterpret_cast<const int *>(wb + hp.o_vblock), (const float *)H, (const float *)GH,
+                       reinterpret_cast<const VSource *>(db + hp.o_vsrc), (int)hp.vsrc.size(),
+                       reinterpret_cast<const int *>(db + hp.o_vblock), (const float *)H, (const float *)GH,
                        hp.level_stride, parts);
     if (hp.anchor_off[nb] > 0)
         hipLaunchKernelGGL(step_anchor_bwd_kernel, dim3((unsigned)((hp.anchor_off[nb] + 3) / 4)), dim3(256), 0, s, sd,
                            tabs, nm, (long long)P->node_map_len, ids, (const float *)GH,
-                           reinterpret_cast<const int *>(wb + hp.o_anchor), nb);
+                           reinterpret_cast<const int *>(db + hp.o_anchor), nb);
     {
         const long long elems = (long long)D * D;
-        dim3 grid((unsigned)((elems + 255) / 256), (unsigned)hp.groups.size());
+        dim3 grid((unsigned)((elems + 63) / 64), (unsigned)hp.groups.size());
         hipLaunchKernelGGL(step_reduce_kernel, grid, dim3(256), 0, s,
-                           reinterpret_cast<const RGroup *>(wb + hp.o_groups), D, gp, (const float *)slabs,
+                           reinterpret_cast<const RGroup *>(db + hp.o_groups), D, gp, (const float *)slabs,
                            (const float *)parts);
     }
     return mpqe_launch_status();

@@ -21,7 +21,8 @@ from .data_utils import RGCNQueryDataset
 
 
 class PackedStep(object):
-    __slots__ = ('batches', 'nb', 'anchor_ids', 'targets', 'negs', 'num_graphs', 'ws_bytes', 'sizes')
+    __slots__ = ('batches', 'nb', 'anchor_ids', 'targets', 'negs', 'num_graphs', 'ws_bytes', 'sizes',
+                 'desc', 'desc_bytes', 'desc_ptr', 'desc_resident')
 
 
 class FusedTrainStep(object):
@@ -112,6 +113,11 @@ class FusedTrainStep(object):
         ps.ws_bytes = ops.lib().mpqe_step_workspace_bytes(ctypes.byref(self.P), SB, nb)
         if ps.ws_bytes == 0:
             raise _capi.MpqeError('mpqe_step_workspace_bytes rejected the step descriptors')
+        # descriptor table of this step: written to HBM by the first run, re-used afterwards
+        ps.desc_bytes = ops.lib().mpqe_step_desc_bytes(ctypes.byref(self.P), SB, nb)
+        ps.desc = torch.empty(ps.desc_bytes + 256, dtype=torch.uint8, device=self.device)
+        ps.desc_ptr = (ps.desc.data_ptr() + 255) // 256 * 256
+        ps.desc_resident = False
         return ps
 
     def _workspace(self, nbytes):
@@ -136,9 +142,11 @@ class FusedTrainStep(object):
                 ctypes.byref(self.P), packed.batches, packed.nb, packed.anchor_ids.data_ptr(),
                 packed.targets.data_ptr(), packed.negs.data_ptr(), self.margin, ctypes.byref(self.G),
                 1 if backward else 0, loss.data_ptr(), None if sp is None else sp.data_ptr(),
-                None if sn is None else sn.data_ptr(), wptr, packed.ws_bytes, self.err.data_ptr(),
+                None if sn is None else sn.data_ptr(), packed.desc_ptr, packed.desc_bytes,
+                0 if packed.desc_resident else 1, wptr, packed.ws_bytes, self.err.data_ptr(),
                 events, 0 if events is None else len(events), torch.cuda.current_stream().cuda_stream)
         _capi.check(ops.lib(), st, 'mpqe_step_forward_backward')
+        packed.desc_resident = True
         if scores:
             return loss, sp, sn
         return loss

@@ -121,12 +121,15 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
     assert wsb > 0
     ws = be.nbytes(wsb + 256)
     wptr = (be.ptr(ws) + 255) // 256 * 256
+    dsb = be.lib.mpqe_step_desc_bytes(ctypes.byref(P), SB, nb)
+    dbuf = be.nbytes(dsb + 256)
+    dptr = (be.ptr(dbuf) + 255) // 256 * 256
     loss = be.empty((1 + nb,))
     sp, sn = be.empty((Gtot,)), be.empty((Gtot,))
     err = be.zeros((1,), np.int32)
     be.check(be.lib.mpqe_step_forward_backward(ctypes.byref(P), SB, nb, be.ptr(d_anchor), be.ptr(d_tg),
                                                be.ptr(d_ng), margin, ctypes.byref(G), backward, be.ptr(loss),
-                                               be.ptr(sp), be.ptr(sn), wptr, wsb, be.ptr(err), None, 0, be.stream), 'step')
+                                               be.ptr(sp), be.ptr(sn), dptr, dsb, 1, wptr, wsb, be.ptr(err), None, 0, be.stream), 'step')
     grads = {'mode_embeddings.weight': be.get(gmode)}
     for m, g in zip(modes, gtabs):
         grads['enc.feat-%s.weight' % m] = be.get(g)
