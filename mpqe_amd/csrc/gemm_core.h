@@ -27,13 +27,31 @@
 #define GT_TILE_FLOATS 2304     // max(64*36, 32*68)
 #define GT_SMEM_FLOATS (4 * GT_TILE_FLOATS)   // A,B x 2 buffers = 36,864 B
 
-// Guarded 4-float load: elements at index >= limit read as 0. `vec` says the
-// row base is 16-byte aligned and limit % 4 == 0 (uniform per launch).
-__device__ __forceinline__ f32x4 ld4_guard(const float *p, int c, int limit, bool vec) {
+// Operand load modes (compile-time):
+//   LD_SCALAR  odd dims / unaligned rows: element-wise guarded loads, zeros outside the operand
+//   LD_PRED    16-byte loads; a slot outside the operand reads a safe address and is flagged !ok,
+//              the pipeline stores zeros for it (no branch between a load and its use)
+//   LD_FAST    16-byte loads, nothing to check: the caller guarantees every address it forms is
+//              inside the tensor (dims multiples of the tile, out-of-range rows clamped to a
+//              valid row whose result is discarded). The loop body is then straight-line code and
+//              hipcc keeps two tiles of loads in flight behind counted s_waitcnt.
+enum { LD_SCALAR = 0, LD_PRED = 1, LD_FAST = 2 };
+
+template <int MODE>
+__device__ __forceinline__ f32x4 ld4_pred(const float *__restrict__ safe, const float *__restrict__ p, int c,
+                                          int limit, bool row_ok, bool &ok) {
+    if (MODE == LD_FAST) {
+        ok = true;
+        return *reinterpret_cast<const f32x4 *>(p + c);
+    }
+    if (MODE == LD_PRED) {
+        ok = row_ok && c < limit;
+        const float *q = ok ? p + c : safe;
+        return *reinterpret_cast<const f32x4 *>(q);
+    }
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (vec) {
-        if (c < limit) v = *reinterpret_cast<const f32x4 *>(p + c);
-    } else {
+    ok = true;
+    if (row_ok) {
         if (c + 0 < limit) v[0] = p[c + 0];
         if (c + 1 < limit) v[1] = p[c + 1];
         if (c + 2 < limit) v[2] = p[c + 2];
@@ -43,18 +61,24 @@ __device__ __forceinline__ f32x4 ld4_guard(const float *p, int c, int limit, boo
 }
 
 // A_K / B_K: operand image is K-type (true) or R-type (false).
-// aload(row_or_k, col, step) / bload(...) return the 4 floats at tile-local
-// (row, col..col+3) of K-step `step`, zero beyond the operand's extent:
+// aload(row_or_k, col, ok) / bload(...) return the 4 floats at tile-local (row, col..col+3)
+// of the loader's CURRENT K-step; ok = false marks a slot beyond the operand's extent (stored as
+// zeros). advance() moves the loader state to the next K-step: steps are fetched strictly in
+// order, so a loader tracks its position incrementally (no per-load div/mod or block lookup).
+// Loaders must stay safe when advanced PAST the last step (the pipeline issues up to two such
+// loads and never uses them), e.g. by clamping to valid memory:
 //   R-type: row in [0,64), col in {0,4,..,28} along k
 //   K-type: row in [0,32) along k, col in {0,4,..,60}
 //
 // Pipeline: prefetch distance 2. Two register sets hold the tiles of steps s+1 and s+2 while
 // step s is multiplied out of LDS, so every global load has two MFMA phases (~0.9 us) to land;
 // at this path's problem sizes a tile is a short dependent chain of <= 16 steps and the load
-// latency, not bandwidth or MFMA rate, sets its duration. The loop is unrolled by two so that
-// the register sets are addressed statically (a runtime-indexed set would live in scratch).
-template <bool A_K, bool B_K, class AF, class BF>
-__device__ __forceinline__ void gemm_block(f32x16 &acc, AF aload, BF bload, int nsteps, float *smem) {
+// latency, not bandwidth or MFMA rate, sets its duration. Every iteration stores one set and
+// refills it unconditionally (surplus loads/stores at the tail touch only valid memory and the
+// idle LDS buffer), so the body is branch-free; it is unrolled by two so that the register sets
+// are addressed statically (a runtime-indexed set would live in scratch).
+template <bool A_K, bool B_K, class AF, class BF, class NF>
+__device__ __forceinline__ void gemm_block(f32x16 &acc, AF aload, BF bload, NF advance, int nsteps, float *smem) {
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -75,16 +99,19 @@ __device__ __forceinline__ void gemm_block(f32x16 &acc, AF aload, BF bload, int 
     if (nsteps <= 0) return;
     f32x4 pa0, pa1, pb0, pb1;      // register set P
     f32x4 qa0, qa1, qb0, qb1;      // register set Q
-#define GT_LOAD(A0, A1, B0, B1, STEP) \
-    A0 = aload(ar0, ac, (STEP));       \
-    A1 = aload(ar1, ac, (STEP));       \
-    B0 = bload(br0, bc, (STEP));       \
-    B1 = bload(br1, bc, (STEP));
-#define GT_STORE(BUF, A0, A1, B0, B1)                                                   \
-    *reinterpret_cast<f32x4 *>(As + (BUF)*GT_TILE_FLOATS + ar0 * lda + ac) = A0;        \
-    *reinterpret_cast<f32x4 *>(As + (BUF)*GT_TILE_FLOATS + ar1 * lda + ac) = A1;        \
-    *reinterpret_cast<f32x4 *>(Bs + (BUF)*GT_TILE_FLOATS + br0 * ldb + bc) = B0;        \
-    *reinterpret_cast<f32x4 *>(Bs + (BUF)*GT_TILE_FLOATS + br1 * ldb + bc) = B1;
+    bool pm0 = true, pm1 = true, pm2 = true, pm3 = true, qm0 = true, qm1 = true, qm2 = true, qm3 = true;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#define GT_LOAD(A0, A1, B0, B1, M0, M1, M2, M3) \
+    A0 = aload(ar0, ac, M0);                    \
+    A1 = aload(ar1, ac, M1);                    \
+    B0 = bload(br0, bc, M2);                    \
+    B1 = bload(br1, bc, M3);                    \
+    advance();
+#define GT_STORE(BUF, A0, A1, B0, B1, M0, M1, M2, M3)                                              \
+    *reinterpret_cast<f32x4 *>(As + (BUF)*GT_TILE_FLOATS + ar0 * lda + ac) = M0 ? A0 : zero4;      \
+    *reinterpret_cast<f32x4 *>(As + (BUF)*GT_TILE_FLOATS + ar1 * lda + ac) = M1 ? A1 : zero4;      \
+    *reinterpret_cast<f32x4 *>(Bs + (BUF)*GT_TILE_FLOATS + br0 * ldb + bc) = M2 ? B0 : zero4;      \
+    *reinterpret_cast<f32x4 *>(Bs + (BUF)*GT_TILE_FLOATS + br1 * ldb + bc) = M3 ? B1 : zero4;
 
     auto compute = [&](int buf) {
         const float *Ac = As + buf * GT_TILE_FLOATS;
@@ -115,23 +142,23 @@ __device__ __forceinline__ void gemm_block(f32x16 &acc, AF aload, BF bload, int 
     };
 
     // prologue: tile 0 -> LDS[0]; tiles 1, 2 in flight in Q, P
-    GT_LOAD(pa0, pa1, pb0, pb1, 0)
-    if (nsteps > 1) { GT_LOAD(qa0, qa1, qb0, qb1, 1) }
-    GT_STORE(0, pa0, pa1, pb0, pb1)
-    if (nsteps > 2) { GT_LOAD(pa0, pa1, pb0, pb1, 2) }
+    GT_LOAD(pa0, pa1, pb0, pb1, pm0, pm1, pm2, pm3)
+    GT_LOAD(qa0, qa1, qb0, qb1, qm0, qm1, qm2, qm3)
+    GT_STORE(0, pa0, pa1, pb0, pb1, pm0, pm1, pm2, pm3)
+    GT_LOAD(pa0, pa1, pb0, pb1, pm0, pm1, pm2, pm3)
     __syncthreads();
     int s = 0;
     while (true) {
         // even step: tile s in LDS[0]; Q holds tile s+1, P holds tile s+2
         compute(0);
-        if (s + 1 < nsteps) { GT_STORE(1, qa0, qa1, qb0, qb1) }
-        if (s + 3 < nsteps) { GT_LOAD(qa0, qa1, qb0, qb1, s + 3) }
+        GT_STORE(1, qa0, qa1, qb0, qb1, qm0, qm1, qm2, qm3)
+        GT_LOAD(qa0, qa1, qb0, qb1, qm0, qm1, qm2, qm3)
         __syncthreads();
         if (++s >= nsteps) break;
         // odd step: tile s in LDS[1]; P holds tile s+1, Q holds tile s+2
         compute(1);
-        if (s + 1 < nsteps) { GT_STORE(0, pa0, pa1, pb0, pb1) }
-        if (s + 3 < nsteps) { GT_LOAD(pa0, pa1, pb0, pb1, s + 3) }
+        GT_STORE(0, pa0, pa1, pb0, pb1, pm0, pm1, pm2, pm3)
+        GT_LOAD(pa0, pa1, pb0, pb1, pm0, pm1, pm2, pm3)
         __syncthreads();
         if (++s >= nsteps) break;
     }

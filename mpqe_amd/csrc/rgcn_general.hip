@@ -263,11 +263,11 @@ __device__ __forceinline__ int find_group(const int *__restrict__ ptr, int n, in
 
 // TRANS = false: msg[p]  = x[rows[p]]    . W[rel]      (K = Din,  cols = Dout)
 // TRANS = true : gmsg[p] = gpre[rows[p]] . W[rel]^T    (K = Dout, cols = Din), gpre masked by out > 0
-template <bool TRANS>
+template <bool TRANS, int MODE>
 __global__ __launch_bounds__(256) void rgcn_gen_gemm_kernel(
     const int *__restrict__ rows, const int *__restrict__ rel_ptr, const int *__restrict__ tile_ptr, int R,
     const float *__restrict__ a, const float *__restrict__ mask, const float *__restrict__ basis,
-    const float *__restrict__ root, int Din, int Dout, float *__restrict__ msg, int vec_a, int vec_w) {
+    const float *__restrict__ root, int Din, int Dout, float *__restrict__ msg) {
     __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
     const int t = blockIdx.x;
     if (t >= tile_ptr[R + 1]) return;
@@ -289,31 +289,31 @@ __global__ __launch_bounds__(256) void rgcn_gen_gemm_kernel(
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    auto aload = [&](int rr, int c, int step) -> f32x4 {
+    int ks = 0;       // first k of the loader's current K-step
+    auto advance = [&]() { ks += GT_BK; };
+    auto aload = [&](int rr, int c, bool &ok) -> f32x4 {
         const long long off = rr < 32 ? off0 : off1;
-        if (off < 0) return f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 v = ld4_guard(a + off, step * GT_BK + c, K, vec_a);
+        f32x4 v = ld4_pred<MODE>(a, a + off, ks + c, K, off >= 0, ok);
         if (TRANS && mask) {
-            f32x4 o = ld4_guard(mask + off, step * GT_BK + c, K, vec_a);
+            bool ok2;
+            f32x4 o = ld4_pred<MODE>(mask, mask + off, ks + c, K, off >= 0, ok2);
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = o[q] > 0.f ? v[q] : 0.f;
         }
         return v;
     };
     if (!TRANS) {
-        auto bload = [&](int k, int c, int step) -> f32x4 {
-            const int kk = step * GT_BK + k;
-            if (kk >= Din) return f32x4{0.f, 0.f, 0.f, 0.f};
-            return ld4_guard(W + (long long)kk * Dout, n0 + c, Dout, vec_w);
+        auto bload = [&](int k, int c, bool &ok) -> f32x4 {
+            const int kk = ks + k;
+            return ld4_pred<MODE>(root, W + (long long)kk * Dout, n0 + c, Dout, kk < Din, ok);
         };
-        gemm_block<false, true>(acc, aload, bload, nsteps, smem);
+        gemm_block<false, true>(acc, aload, bload, advance, nsteps, smem);
     } else {
-        auto bload = [&](int rr, int c, int step) -> f32x4 {
+        auto bload = [&](int rr, int c, bool &ok) -> f32x4 {
             const int nn = n0 + rr;
-            if (nn >= Din) return f32x4{0.f, 0.f, 0.f, 0.f};
-            return ld4_guard(W + (long long)nn * Dout, step * GT_BK + c, Dout, vec_w);
+            return ld4_pred<MODE>(root, W + (long long)nn * Dout, ks + c, Dout, nn < Din, ok);
         };
-        gemm_block<false, false>(acc, aload, bload, nsteps, smem);
+        gemm_block<false, false>(acc, aload, bload, advance, nsteps, smem);
     }
     const int col = n0 + acc_col();
     if (col < C) {
@@ -371,10 +371,11 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const int *__restrict_
 }
 
 // ------------------------------------------------------------------------------------ weight gradient
+template <int MODE>
 __global__ __launch_bounds__(256) void rgcn_gen_grad_w_kernel(
     const int *__restrict__ rows_fwd, const int *__restrict__ rows_bwd, const int *__restrict__ rel_ptr,
     const int *__restrict__ chunk_ptr, int R, const float *__restrict__ x, const float *__restrict__ g,
-    const float *__restrict__ out, int Din, int Dout, int relu, float *__restrict__ slabs, int vec_x, int vec_g) {
+    const float *__restrict__ out, int Din, int Dout, int relu, float *__restrict__ slabs) {
     __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
     const int c = blockIdx.x;
     if (c >= chunk_ptr[R + 1]) return;
@@ -389,24 +390,27 @@ __global__ __launch_bounds__(256) void rgcn_gen_grad_w_kernel(
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    auto aload = [&](int k, int cc, int step) -> f32x4 {
-        const int q = q0 + step * GT_BK + k;
-        if (q >= q1) return f32x4{0.f, 0.f, 0.f, 0.f};
-        return ld4_guard(x + (long long)rows_fwd[q] * Din, i0 + cc, Din, vec_x);
+    int qs = q0;      // first slot of the loader's current K-step
+    auto advance = [&]() { qs += GT_BK; };
+    auto aload = [&](int k, int cc, bool &ok) -> f32x4 {
+        const int q = qs + k;
+        const int qc = q < q1 ? q : q0;            // clamped slot: the row-id read stays in range
+        return ld4_pred<MODE>(x, x + (long long)rows_fwd[qc] * Din, i0 + cc, Din, q < q1, ok);
     };
-    auto bload = [&](int k, int cc, int step) -> f32x4 {
-        const int q = q0 + step * GT_BK + k;
-        if (q >= q1) return f32x4{0.f, 0.f, 0.f, 0.f};
-        const long long off = (long long)rows_bwd[q] * Dout;
-        f32x4 v = ld4_guard(g + off, j0 + cc, Dout, vec_g);
+    auto bload = [&](int k, int cc, bool &ok) -> f32x4 {
+        const int q = qs + k;
+        const int qc = q < q1 ? q : q0;
+        const long long off = (long long)rows_bwd[qc] * Dout;
+        f32x4 v = ld4_pred<MODE>(g, g + off, j0 + cc, Dout, q < q1, ok);
         if (relu) {
-            f32x4 o = ld4_guard(out + off, j0 + cc, Dout, vec_g);
+            bool ok2;
+            f32x4 o = ld4_pred<MODE>(out, out + off, j0 + cc, Dout, q < q1, ok2);
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) v[qq] = o[qq] > 0.f ? v[qq] : 0.f;
         }
         return v;
     };
-    gemm_block<true, true>(acc, aload, bload, nsteps, smem);
+    gemm_block<true, true>(acc, aload, bload, advance, nsteps, smem);
     float *dst = slabs + (long long)c * Din * Dout;
     const int col = j0 + acc_col();
     if (col < Dout) {
@@ -459,11 +463,15 @@ extern "C" int mpqe_rgcn_general_fwd(const void *plan, int64_t Nn, int64_t E, in
     PlanView P = plan_view(plan, Nn, E, R);
     hipStream_t s = as_stream(stream);
     float *msg = reinterpret_cast<float *>(workspace);
-    const int vec_w = (!basis || ptr_vec_ok(basis, Dout)) && ptr_vec_ok(root, Dout) && (Din * Dout) % 4 == 0;
+    const bool gvec = (!basis || ptr_vec_ok(basis, Dout)) && ptr_vec_ok(root, Dout) && (Din * Dout) % 4 == 0 &&
+                      ptr_vec_ok(x, Din);
     dim3 grid((unsigned)tile_bound(Nn, E, R), (unsigned)((Dout + GT_BN - 1) / GT_BN));
-    hipLaunchKernelGGL(rgcn_gen_gemm_kernel<false>, grid, dim3(256), 0, s, P.rows_fwd, P.rel_ptr, P.tile_ptr, (int)R,
-                       x, (const float *)nullptr, basis, root, (int)Din, (int)Dout, msg, (int)ptr_vec_ok(x, Din),
-                       vec_w);
+    if (gvec)
+        hipLaunchKernelGGL((rgcn_gen_gemm_kernel<false, LD_PRED>), grid, dim3(256), 0, s, P.rows_fwd, P.rel_ptr,
+                           P.tile_ptr, (int)R, x, (const float *)nullptr, basis, root, (int)Din, (int)Dout, msg);
+    else
+        hipLaunchKernelGGL((rgcn_gen_gemm_kernel<false, LD_SCALAR>), grid, dim3(256), 0, s, P.rows_fwd, P.rel_ptr,
+                           P.tile_ptr, (int)R, x, (const float *)nullptr, basis, root, (int)Din, (int)Dout, msg);
     const int vec = Dout % 4 == 0 && ptr_vec_ok(out, Dout) && (!bias || (uintptr_t)bias % 16 == 0) &&
                     (uintptr_t)workspace % 16 == 0;
     const long long threads = Nn * (vec ? Dout / 4 : Dout);
@@ -489,13 +497,17 @@ extern "C" int mpqe_rgcn_general_bwd(const void *plan, int64_t Nn, int64_t E, in
     float *slabs = reinterpret_cast<float *>(wb + align_up((size_t)(E + Nn) * (size_t)Din * 4, 256));
     float *bias_part = reinterpret_cast<float *>(
         reinterpret_cast<char *>(slabs) + align_up((size_t)chunk_bound(Nn, E, R) * (size_t)Din * (size_t)Dout * 4, 256));
-    const int vec_w = (!basis || ptr_vec_ok(basis, Dout)) && ptr_vec_ok(root, Dout) && (Din * Dout) % 4 == 0;
-    const int vec_g = ptr_vec_ok(grad_out, Dout) && (!relu || ptr_vec_ok(out, Dout));
+    const bool gvec = (!basis || ptr_vec_ok(basis, Dout)) && ptr_vec_ok(root, Dout) && (Din * Dout) % 4 == 0 &&
+                      ptr_vec_ok(grad_out, Dout) && (!relu || ptr_vec_ok(out, Dout)) && ptr_vec_ok(x, Din);
     const float *mask = relu ? out : nullptr;
     if (grad_x) {
         dim3 grid((unsigned)tile_bound(Nn, E, R), (unsigned)((Din + GT_BN - 1) / GT_BN));
-        hipLaunchKernelGGL(rgcn_gen_gemm_kernel<true>, grid, dim3(256), 0, s, P.rows_bwd, P.rel_ptr, P.tile_ptr,
-                           (int)R, grad_out, mask, basis, root, (int)Din, (int)Dout, gmsg, vec_g, vec_w);
+        if (gvec)
+            hipLaunchKernelGGL((rgcn_gen_gemm_kernel<true, LD_PRED>), grid, dim3(256), 0, s, P.rows_bwd, P.rel_ptr,
+                               P.tile_ptr, (int)R, grad_out, mask, basis, root, (int)Din, (int)Dout, gmsg);
+        else
+            hipLaunchKernelGGL((rgcn_gen_gemm_kernel<true, LD_SCALAR>), grid, dim3(256), 0, s, P.rows_bwd, P.rel_ptr,
+                               P.tile_ptr, (int)R, grad_out, mask, basis, root, (int)Din, (int)Dout, gmsg);
         const int vec = Din % 4 == 0 && ptr_vec_ok(grad_x, Din) && (uintptr_t)workspace % 16 == 0;
         const long long threads = Nn * (vec ? Din / 4 : Din);
         hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, P.src_ptr,
@@ -505,9 +517,12 @@ extern "C" int mpqe_rgcn_general_bwd(const void *plan, int64_t Nn, int64_t E, in
     if (grad_basis || grad_root) {
         const int tiles = (int)(((Din + GT_BM - 1) / GT_BM) * ((Dout + GT_BN - 1) / GT_BN));
         dim3 grid((unsigned)chunk_bound(Nn, E, R), tiles);
-        hipLaunchKernelGGL(rgcn_gen_grad_w_kernel, grid, dim3(256), 0, s, P.rows_fwd, P.rows_bwd, P.rel_ptr,
-                           P.chunk_ptr, (int)R, x, grad_out, mask, (int)Din, (int)Dout, relu, slabs,
-                           (int)ptr_vec_ok(x, Din), vec_g);
+        if (gvec)
+            hipLaunchKernelGGL(rgcn_gen_grad_w_kernel<LD_PRED>, grid, dim3(256), 0, s, P.rows_fwd, P.rows_bwd, P.rel_ptr,
+                               P.chunk_ptr, (int)R, x, grad_out, mask, (int)Din, (int)Dout, relu, slabs);
+        else
+            hipLaunchKernelGGL(rgcn_gen_grad_w_kernel<LD_SCALAR>, grid, dim3(256), 0, s, P.rows_fwd, P.rows_bwd,
+                               P.rel_ptr, P.chunk_ptr, (int)R, x, grad_out, mask, (int)Din, (int)Dout, relu, slabs);
         const long long elems = (long long)Din * Dout;
         dim3 rgrid((unsigned)((elems + 255) / 256), (unsigned)(R + 1));
         hipLaunchKernelGGL(rgcn_gen_reduce_w_kernel, rgrid, dim3(256), 0, s, P.chunk_ptr, (int)R, (int)Din,

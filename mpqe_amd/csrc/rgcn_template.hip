@@ -15,23 +15,25 @@
 #include "rgcn_template_body.h"
 
 // ------------------------------------------------------------------------------------ forward
+template <int MODE>
 __global__ __launch_bounds__(256) void rgcn_tmpl_fwd_kernel(
     TmplArgs tp, long long B, const float *__restrict__ x, const float *__restrict__ basis,
     const float *__restrict__ root, const float *__restrict__ bias, int Din, int Dout, int relu,
-    float *__restrict__ out, int vec_x, int vec_w) {
+    float *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
-    tmpl_fwd_tile(tp, B, x, basis, root, bias, Din, Dout, relu, out, vec_x, vec_w, (int)blockIdx.z,
-                  (long long)blockIdx.x * GT_BM, (int)blockIdx.y * GT_BN, smem);
+    tmpl_fwd_tile<MODE>(tp, B, x, basis, root, bias, Din, Dout, relu, out, (int)blockIdx.z,
+                       (long long)blockIdx.x * GT_BM, (int)blockIdx.y * GT_BN, smem);
 }
 
 // ------------------------------------------------------------------------------------ backward wrt x
+template <int MODE>
 __global__ __launch_bounds__(256) void rgcn_tmpl_bwd_x_kernel(
     TmplArgs tp, long long B, const float *__restrict__ g, const float *__restrict__ out,
     const float *__restrict__ basis, const float *__restrict__ root, int Din, int Dout, int relu,
-    float *__restrict__ grad_x, int vec_g, int vec_w) {
+    float *__restrict__ grad_x) {
     __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
-    tmpl_bwd_x_tile(tp, B, g, out, basis, root, Din, Dout, relu, grad_x, vec_g, vec_w, (int)blockIdx.z,
-                    (long long)blockIdx.x * GT_BM, (int)blockIdx.y * GT_BN, smem);
+    tmpl_bwd_x_tile<MODE>(tp, B, g, out, basis, root, Din, Dout, relu, grad_x, (int)blockIdx.z,
+                         (long long)blockIdx.x * GT_BM, (int)blockIdx.y * GT_BN, smem);
 }
 
 // ------------------------------------------------------------------------------------ weight gradient
@@ -44,10 +46,10 @@ struct WChunks {
     int nch_root, ch_root;
 };
 
+template <int MODE>
 __global__ __launch_bounds__(256) void rgcn_tmpl_grad_w_kernel(
     TmplArgs tp, WChunks wc, long long B, const float *__restrict__ x, const float *__restrict__ g,
-    const float *__restrict__ out, int Din, int Dout, int relu, float *__restrict__ slabs,
-    int vec_x, int vec_g) {
+    const float *__restrict__ out, int Din, int Dout, int relu, float *__restrict__ slabs) {
     __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
     const int z = blockIdx.z;
     const int c = blockIdx.x;
@@ -65,8 +67,8 @@ __global__ __launch_bounds__(256) void rgcn_tmpl_grad_w_kernel(
     const long long xs = is_root ? 1 : tp.N, xo = is_root ? 0 : tp.src[z];
     const long long gs = is_root ? 1 : tp.N, go = is_root ? 0 : tp.dst[z];
     const long long slab = is_root ? (long long)tp.E * wc.nch_edge + c : (long long)z * wc.nch_edge + c;
-    tmpl_grad_w_tile(x, g, out, Din, Dout, relu, xs, xo, gs, go, q0, q1, i0, j0,
-                     slabs + slab * (long long)Din * Dout, vec_x, vec_g, smem);
+    tmpl_grad_w_tile<MODE>(x, g, out, Din, Dout, relu, xs, xo, gs, go, q0, q1, count - 1, i0, j0,
+                          slabs + slab * (long long)Din * Dout, smem);
 }
 
 // grad_basis[rel_z] += sum over (slots sharing rel_z, chunks) in fixed order; grad_root likewise.
@@ -160,9 +162,18 @@ extern "C" int mpqe_rgcn_template_fwd(int query_type, int64_t B, const int64_t *
     if (Din > (1 << 20) || Dout > (1 << 20)) return MPQE_ERR_UNSUPPORTED;
     if (B == 0) return MPQE_OK;
     dim3 grid((unsigned)((B + GT_BM - 1) / GT_BM), (unsigned)((Dout + GT_BN - 1) / GT_BN), tp.N);
-    hipLaunchKernelGGL(rgcn_tmpl_fwd_kernel, grid, dim3(256), 0, as_stream(stream), tp, (long long)B, x, basis,
-                       root, bias, (int)Din, (int)Dout, relu, out, (int)ptr_vec_ok(x, Din),
-                       (int)(ptr_vec_ok(basis, Dout) && ptr_vec_ok(root, Dout) && (Din * Dout) % 4 == 0));
+    // one compile-time switch: every operand row is 16-byte aligned (dims % 4 == 0) or none is assumed to be
+    const bool vec = ptr_vec_ok(x, Din) && ptr_vec_ok(basis, Dout) && ptr_vec_ok(root, Dout) && (Din * Dout) % 4 == 0;
+    const bool fast = vec && Din % GT_BK == 0 && Dout % GT_BN == 0;
+    if (fast)
+        hipLaunchKernelGGL(rgcn_tmpl_fwd_kernel<LD_FAST>, grid, dim3(256), 0, as_stream(stream), tp, (long long)B,
+                           x, basis, root, bias, (int)Din, (int)Dout, relu, out);
+    else if (vec)
+        hipLaunchKernelGGL(rgcn_tmpl_fwd_kernel<LD_PRED>, grid, dim3(256), 0, as_stream(stream), tp, (long long)B,
+                           x, basis, root, bias, (int)Din, (int)Dout, relu, out);
+    else
+        hipLaunchKernelGGL(rgcn_tmpl_fwd_kernel<LD_SCALAR>, grid, dim3(256), 0, as_stream(stream), tp,
+                           (long long)B, x, basis, root, bias, (int)Din, (int)Dout, relu, out);
     return mpqe_launch_status();
 }
 
@@ -192,12 +203,19 @@ extern "C" int mpqe_rgcn_template_bwd(int query_type, int64_t B, const int64_t *
     if (relu && !out) return MPQE_ERR_INVALID_ARG;
     if (B == 0) return MPQE_OK;
     hipStream_t s = as_stream(stream);
-    const int vec_w = ptr_vec_ok(basis, Dout) && ptr_vec_ok(root, Dout) && (Din * Dout) % 4 == 0;
-    const int vec_g = ptr_vec_ok(grad_out, Dout) && (!relu || ptr_vec_ok(out, Dout));
+    const bool vec = ptr_vec_ok(basis, Dout) && ptr_vec_ok(root, Dout) && (Din * Dout) % 4 == 0 &&
+                     ptr_vec_ok(grad_out, Dout) && (!relu || ptr_vec_ok(out, Dout)) && ptr_vec_ok(x, Din);
     if (grad_x) {
         dim3 grid((unsigned)((B + GT_BM - 1) / GT_BM), (unsigned)((Din + GT_BN - 1) / GT_BN), tp.N);
-        hipLaunchKernelGGL(rgcn_tmpl_bwd_x_kernel, grid, dim3(256), 0, s, tp, (long long)B, grad_out, out, basis,
-                           root, (int)Din, (int)Dout, relu, grad_x, vec_g, vec_w);
+        if (vec && Dout % GT_BK == 0 && Din % GT_BN == 0)
+            hipLaunchKernelGGL(rgcn_tmpl_bwd_x_kernel<LD_FAST>, grid, dim3(256), 0, s, tp, (long long)B, grad_out,
+                               out, basis, root, (int)Din, (int)Dout, relu, grad_x);
+        else if (vec)
+            hipLaunchKernelGGL(rgcn_tmpl_bwd_x_kernel<LD_PRED>, grid, dim3(256), 0, s, tp, (long long)B, grad_out,
+                               out, basis, root, (int)Din, (int)Dout, relu, grad_x);
+        else
+            hipLaunchKernelGGL(rgcn_tmpl_bwd_x_kernel<LD_SCALAR>, grid, dim3(256), 0, s, tp, (long long)B, grad_out,
+                               out, basis, root, (int)Din, (int)Dout, relu, grad_x);
     }
     if (grad_basis || grad_root || grad_bias) {
         if (workspace_bytes < mpqe_rgcn_template_bwd_workspace_bytes(query_type, B, Din, Dout) || !workspace)
@@ -210,8 +228,16 @@ extern "C" int mpqe_rgcn_template_bwd(int query_type, int64_t B, const int64_t *
             const int tiles = (int)(((Din + GT_BM - 1) / GT_BM) * ((Dout + GT_BN - 1) / GT_BN));
             const int maxch = w.nch_root > w.nch_edge ? w.nch_root : w.nch_edge;
             dim3 grid(maxch, tiles, tp.E + 1);
-            hipLaunchKernelGGL(rgcn_tmpl_grad_w_kernel, grid, dim3(256), 0, s, tp, w, (long long)B, x, grad_out,
-                               out, (int)Din, (int)Dout, relu, slabs, (int)ptr_vec_ok(x, Din), vec_g);
+            // LD_FAST needs whole K-steps in every chunk (the K dimension is the batch here)
+            if (vec && Din % GT_BM == 0 && Dout % GT_BN == 0 && B % GT_BK == 0)
+                hipLaunchKernelGGL(rgcn_tmpl_grad_w_kernel<LD_FAST>, grid, dim3(256), 0, s, tp, w, (long long)B, x,
+                                   grad_out, out, (int)Din, (int)Dout, relu, slabs);
+            else if (vec)
+                hipLaunchKernelGGL(rgcn_tmpl_grad_w_kernel<LD_PRED>, grid, dim3(256), 0, s, tp, w, (long long)B, x,
+                                   grad_out, out, (int)Din, (int)Dout, relu, slabs);
+            else
+                hipLaunchKernelGGL(rgcn_tmpl_grad_w_kernel<LD_SCALAR>, grid, dim3(256), 0, s, tp, w, (long long)B,
+                                   x, grad_out, out, (int)Din, (int)Dout, relu, slabs);
             const long long elems = (long long)Din * Dout;
             dim3 rgrid((unsigned)((elems + 255) / 256), tp.E + 1);
             hipLaunchKernelGGL(rgcn_tmpl_reduce_w_kernel, rgrid, dim3(256), 0, s, tp, w, (int)Din, (int)Dout,

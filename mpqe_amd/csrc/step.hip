@@ -94,6 +94,15 @@ __device__ __forceinline__ int find_le(const int *__restrict__ off, int n, int t
     return lo;
 }
 
+// lp.X[li] with a runtime li would spill the by-value pointer table to scratch; select instead
+__device__ __forceinline__ const float *pick_layer(const float *const *arr, int li) {
+    const float *r = arr[0];
+#pragma unroll
+    for (int l = 1; l < MPQE_STEP_MAX_LAYERS; ++l)
+        if (l == li) r = arr[l];
+    return r;
+}
+
 __device__ __forceinline__ int layer_index(int p, int L, int num_layers) {
     return p < L - 1 ? p : num_layers - 1;     // reference model.py:435-441
 }
@@ -172,9 +181,10 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(
 }
 
 // ------------------------------------------------------------------------------------ layer levels
+template <int MODE>
 __global__ __launch_bounds__(256) void step_layer_fwd_kernel(const StepDev *__restrict__ sd, LayerPtrs lp, int p,
                                                              const float *__restrict__ Hin,
-                                                             float *__restrict__ Hout, int vec) {
+                                                             float *__restrict__ Hout) {
     __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
     const int t = blockIdx.x;
     const int bi = find_le(sd->tile_off[p], sd->nb + 1, t);
@@ -185,14 +195,16 @@ __global__ __launch_bounds__(256) void step_layer_fwd_kernel(const StepDev *__re
     const int n = lt / (rt * ct), rem = lt - n * rt * ct;
     const int li = layer_index(p, b.L, sd->num_layers);
     const TmplArgs tp = b.tp;
-    tmpl_fwd_tile(tp, b.B, Hin + b.row_off * D, lp.basis[li], lp.root[li], lp.bias[li], D, D, p < b.L - 1,
-                  Hout + b.row_off * D, vec, vec, n, (long long)(rem / ct) * GT_BM, (rem % ct) * GT_BN, smem);
+    tmpl_fwd_tile<MODE>(tp, b.B, Hin + b.row_off * D, pick_layer(lp.basis, li), pick_layer(lp.root, li),
+                        pick_layer(lp.bias, li), D, D, p < b.L - 1,
+                       Hout + b.row_off * D, n, (long long)(rem / ct) * GT_BM, (rem % ct) * GT_BN, smem);
 }
 
+template <int MODE>
 __global__ __launch_bounds__(256) void step_layer_bwd_x_kernel(const StepDev *__restrict__ sd, LayerPtrs lp, int p,
                                                                const float *__restrict__ Gout,
-                                                               const float *__restrict__ Hout,
-                                                               float *__restrict__ Gin, int vec) {
+                                                               const float *__restrict__ Hin,
+                                                               float *__restrict__ Gin) {
     __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
     const int t = blockIdx.x;
     const int bi = find_le(sd->tile_off[p], sd->nb + 1, t);
@@ -203,9 +215,12 @@ __global__ __launch_bounds__(256) void step_layer_bwd_x_kernel(const StepDev *__
     const int m = lt / (rt * ct), rem = lt - m * rt * ct;
     const int li = layer_index(p, b.L, sd->num_layers);
     const TmplArgs tp = b.tp;
-    tmpl_bwd_x_tile(tp, b.B, Gout + b.row_off * D, Hout + b.row_off * D, lp.basis[li], lp.root[li], D, D,
-                    p < b.L - 1, Gin + b.row_off * D, vec, vec, m, (long long)(rem / ct) * GT_BM,
-                    (rem % ct) * GT_BN, smem);
+    // Gout is already a pre-activation gradient (masked by whoever wrote it); the gradient written
+    // here belongs to H[p], which for p >= 1 is the ReLU output of pass p-1 -> mask it on the way out
+    tmpl_bwd_x_tile<MODE>(tp, b.B, Gout + b.row_off * D, (const float *)nullptr, pick_layer(lp.basis, li),
+                          pick_layer(lp.root, li), D, D, 0,
+                         Gin + b.row_off * D, m, (long long)(rem / ct) * GT_BM, (rem % ct) * GT_BN, smem,
+                         p >= 1 ? Hin + b.row_off * D : (const float *)nullptr);
 }
 
 // ------------------------------------------------------------------------------------ score / loss
@@ -373,12 +388,12 @@ __global__ __launch_bounds__(1024) void step_loss_kernel(const StepDev *__restri
 }
 
 // ------------------------------------------------------------------------------------ weight gradients
+template <int MODE>
 __global__ __launch_bounds__(256) void step_grad_w_kernel(const StepDev *__restrict__ sd,
                                                           const WSource *__restrict__ src, int nsrc,
                                                           const int *__restrict__ block_start,
                                                           const float *__restrict__ H, const float *__restrict__ GH,
-                                                          long long level_stride, float *__restrict__ slabs,
-                                                          int vec) {
+                                                          long long level_stride, float *__restrict__ slabs) {
     __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
     const int D = sd->D;
     const int tiles_j = (D + GT_BN - 1) / GT_BN, tiles = tiles_j * ((D + GT_BM - 1) / GT_BM);
@@ -397,8 +412,8 @@ __global__ __launch_bounds__(256) void step_grad_w_kernel(const StepDev *__restr
     const float *x = H + (long long)s.level * level_stride + b.row_off * D;
     const float *out = H + (long long)(s.level + 1) * level_stride + b.row_off * D;
     const float *g = GH + (long long)(s.level + 1) * level_stride + b.row_off * D;
-    tmpl_grad_w_tile(x, g, out, D, D, s.relu, xs, xo, gs, go, q0, q1, (tile / tiles_j) * GT_BM,
-                     (tile % tiles_j) * GT_BN, slabs + (long long)(s.slab_start + c) * D * D, vec, vec, smem);
+    tmpl_grad_w_tile<MODE>(x, g, out, D, D, s.relu, xs, xo, gs, go, q0, q1, count - 1, (tile / tiles_j) * GT_BM,
+                          (tile % tiles_j) * GT_BN, slabs + (long long)(s.slab_start + c) * D * D, smem);
 }
 
 // partial vectors. kind 0: column sums of gpre over 64-row blocks of (batch, level).
@@ -525,6 +540,7 @@ struct HostPlan {
     std::vector<RGroup> groups;
     std::vector<int> anchor_off;      // nb + 1 (rows of the anchor backward)
     int total_slabs, total_parts;
+    bool whole_ksteps;                // every batch size is a multiple of the K-step (weight-gradient LD_FAST)
     // workspace offsets (bytes)
     size_t o_sd, o_wsrc, o_wblock, o_vsrc, o_vblock, o_groups, o_anchor, desc_total;     // descriptor buffer
     size_t o_H, o_GH, o_tpos, o_tneg, o_spos, o_sneg, o_terms, o_slabs, o_parts, total;  // workspace
@@ -561,6 +577,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, H
     sd.readout = P->readout;
     long long rows = 0, graphs = 0, anchors = 0;
     hp->Lmax = 0;
+    hp->whole_ksteps = true;
     hp->anchor_off.assign(nb + 1, 0);
     for (int i = 0; i < nb; ++i) {
         const mpqe_step_batch_t &b = B[i];
@@ -596,6 +613,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, H
         graphs += d.B;
         anchors += (long long)d.B * t.A;
         if (d.L > hp->Lmax) hp->Lmax = d.L;
+        if (d.B % GT_BK != 0) hp->whole_ksteps = false;
     }
     if (rows >= (1ll << 30)) return MPQE_ERR_UNSUPPORTED;
     hp->anchor_off[nb] = (int)anchors;
@@ -653,7 +671,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, H
         s.batch = key.batch;
         s.level = key.level;
         s.slot = key.slot;
-        s.relu = key.level < d.L - 1;
+        s.relu = 0;      // gH is stored as a pre-activation gradient (masked by its producer)
         const bool is_root = key.slot == d.tp.E;
         pick_chunks(is_root ? (long long)d.B * d.tp.N : d.B, is_root ? 64 : 32, &s.nch, &s.ch);
         s.slab_start = slab;
@@ -704,7 +722,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, H
         s.kind = key.kind;
         s.batch = key.batch;
         s.level_or_k = key.lk;
-        s.relu = key.kind == 0 ? key.lk < d.L - 1 : 0;
+        s.relu = 0;
         s.nblk = key.kind == 0 ? (int)(((long long)d.B * d.tp.N + 63) / 64) : (d.B + 63) / 64;
         s.part_start = part;
         s.block_start = vblock;
@@ -816,6 +834,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     memset(&gp, 0, sizeof(gp));
     memset(&tabs, 0, sizeof(tabs));
     int vec = D % 4 == 0;
+    const bool fast_dims = D % GT_BN == 0;     // D is both K (multiple of 32) and the tile width (64)
     for (int l = 0; l < P->num_layers; ++l) {
         if (!P->basis[l] || !P->root[l]) return MPQE_ERR_INVALID_ARG;
         lp.basis[l] = P->basis[l];
@@ -838,6 +857,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     }
     if (backward) gp.mode_emb = G->mode_emb;
 
+    const bool fast = vec && fast_dims;
     const StepDev *sd = reinterpret_cast<const StepDev *>(db + hp.o_sd);
     if (upload_desc) {
         upload(s, db + hp.o_sd, &hp.sd, sizeof(StepDev));
@@ -866,9 +886,15 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     }
     for (int p = 0; p < hp.Lmax; ++p) {
         mark();
-        hipLaunchKernelGGL(step_layer_fwd_kernel, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p,
-                           (const float *)(H + (long long)p * hp.level_stride),
-                           H + (long long)(p + 1) * hp.level_stride, vec);
+        const float *hin = H + (long long)p * hp.level_stride;
+        float *hout = H + (long long)(p + 1) * hp.level_stride;
+        if (fast)
+            hipLaunchKernelGGL(step_layer_fwd_kernel<LD_FAST>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, hin, hout);
+        else if (vec)
+            hipLaunchKernelGGL(step_layer_fwd_kernel<LD_PRED>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, hin, hout);
+        else
+            hipLaunchKernelGGL(step_layer_fwd_kernel<LD_SCALAR>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, hin,
+                               hout);
         mark();
     }
     hipLaunchKernelGGL(step_score_kernel<false>, dim3((unsigned)((graphs + 3) / 4)), dim3(256), 0, s, sd,
@@ -883,18 +909,37 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                        spos, sneg, terms, GH, tabs, nm, (long long)P->node_map_len, tg, ng);
     for (int p = hp.Lmax - 1; p >= 0; --p) {
         mark();
-        hipLaunchKernelGGL(step_layer_bwd_x_kernel, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p,
-                           (const float *)(GH + (long long)(p + 1) * hp.level_stride),
-                           (const float *)(H + (long long)(p + 1) * hp.level_stride),
-                           GH + (long long)p * hp.level_stride, vec);
+        const float *gout = GH + (long long)(p + 1) * hp.level_stride;
+        const float *hin = H + (long long)p * hp.level_stride;
+        float *gin = GH + (long long)p * hp.level_stride;
+        if (fast)
+            hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_FAST>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gout,
+                               hin, gin);
+        else if (vec)
+            hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_PRED>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gout,
+                               hin, gin);
+        else
+            hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_SCALAR>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p,
+                               gout, hin, gin);
         mark();
     }
     float *slabs = reinterpret_cast<float *>(wb + hp.o_slabs), *parts = reinterpret_cast<float *>(wb + hp.o_parts);
     mark();
-    hipLaunchKernelGGL(step_grad_w_kernel, dim3(hp.wblock.back()), dim3(256), 0, s, sd,
-                       reinterpret_cast<const WSource *>(db + hp.o_wsrc), (int)hp.wsrc.size(),
-                       reinterpret_cast<const int *>(db + hp.o_wblock), (const float *)H, (const float *)GH,
-                       hp.level_stride, slabs, vec);
+    {
+        const WSource *wsrc = reinterpret_cast<const WSource *>(db + hp.o_wsrc);
+        const int *wblk = reinterpret_cast<const int *>(db + hp.o_wblock);
+        const int nsrc = (int)hp.wsrc.size();
+        dim3 wgrid(hp.wblock.back());
+        if (fast && hp.whole_ksteps)
+            hipLaunchKernelGGL(step_grad_w_kernel<LD_FAST>, wgrid, dim3(256), 0, s, sd, wsrc, nsrc, wblk,
+                               (const float *)H, (const float *)GH, hp.level_stride, slabs);
+        else if (vec)
+            hipLaunchKernelGGL(step_grad_w_kernel<LD_PRED>, wgrid, dim3(256), 0, s, sd, wsrc, nsrc, wblk,
+                               (const float *)H, (const float *)GH, hp.level_stride, slabs);
+        else
+            hipLaunchKernelGGL(step_grad_w_kernel<LD_SCALAR>, wgrid, dim3(256), 0, s, sd, wsrc, nsrc, wblk,
+                               (const float *)H, (const float *)GH, hp.level_stride, slabs);
+    }
     mark();
     hipLaunchKernelGGL(step_vec_partial_kernel, dim3(hp.vblock.back()), dim3(256), 0, s, sd,
                        reinterpret_cast<const VSource *>(db + hp.o_vsrc), (int)hp.vsrc.size(),

@@ -114,6 +114,7 @@ static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, 
     for (int i = 0; i < 16; ++i) c[i] = t[i];
     return c;
 }
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4); return i; }

@@ -143,14 +143,20 @@ MIXES = {
     'all7': [('1-chain', 9, 1.0), ('2-chain', 70, 0.01), ('3-chain', 33, 0.01), ('2-inter', 5, 0.005),
              ('3-inter', 65, 0.005), ('3-inter_chain', 12, 0.005), ('3-chain_inter', 40, 0.005)],
     'dup': [('3-inter', 20, 1.0), ('3-inter', 20, 0.5), ('2-chain', 17, 2.0)],
+    # batch sizes that are whole K-steps with D % 64 == 0: the unpredicated LD_FAST kernels
+    'fast': [('3-chain', 64, 1.0), ('3-inter_chain', 32, 0.5), ('1-chain', 96, 0.25)],
+    # same dims, ragged batch sizes: LD_FAST layer tiles with clamped rows, predicated weight gradient
+    'fastragged': [('3-chain_inter', 70, 1.0), ('2-inter', 33, 0.5)],
 }
 
 
 @pytest.mark.parametrize('readout,adaptive,shared,L', [('mp', True, False, 3), ('sum', False, False, 2),
                                                        ('max', False, True, 3), ('mp', True, True, 3)])
-@pytest.mark.parametrize('mix', ['all7', 'dup'])
+@pytest.mark.parametrize('mix', ['all7', 'dup', 'fast', 'fastragged'])
 def test_fused_step_matches_oracle(be, readout, adaptive, shared, L, mix):
-    D, margin = 32, 1.0
+    D, margin = (64 if mix.startswith('fast') else 32), 1.0
+    if mix.startswith('fast') and readout == 'max':
+        pytest.skip('one fast-path case per readout family is enough for the emulator budget')
     schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(
         11, D, L, shared, MIXES[mix], readout, adaptive)
     ref_loss, ref_per, ref_sp, ref_sn = oracle_step(params, cfg, node_map, batches, margin)
