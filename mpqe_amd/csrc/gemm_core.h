@@ -60,25 +60,37 @@ __device__ __forceinline__ f32x4 ld4_pred(const float *__restrict__ safe, const 
     return v;
 }
 
+// Staging coordinates of this thread in an operand image: it fills two slots (0, 1) of each
+// operand per K-step, 4 consecutive floats each.
+//   R-type [64 rows][32 k]: row = t/8 (+32 for slot 1), col = 4*(t%8)   along k
+//   K-type [32 k][64 cols]: row = t/16 (+16 for slot 1), col = 4*(t%16)
+__device__ __forceinline__ int stage_row(bool ktype, int slot) {
+    const int t = threadIdx.x;
+    return ktype ? (t >> 4) + 16 * slot : (t >> 3) + 32 * slot;
+}
+__device__ __forceinline__ int stage_col(bool ktype) {
+    const int t = threadIdx.x;
+    return ktype ? (t & 15) * 4 : (t & 7) * 4;
+}
+
 // A_K / B_K: operand image is K-type (true) or R-type (false).
-// aload(row_or_k, col, ok) / bload(...) return the 4 floats at tile-local (row, col..col+3)
-// of the loader's CURRENT K-step; ok = false marks a slot beyond the operand's extent (stored as
-// zeros). advance() moves the loader state to the next K-step: steps are fetched strictly in
-// order, so a loader tracks its position incrementally (no per-load div/mod or block lookup).
-// Loaders must stay safe when advanced PAST the last step (the pipeline issues up to two such
-// loads and never uses them), e.g. by clamping to valid memory:
-//   R-type: row in [0,64), col in {0,4,..,28} along k
-//   K-type: row in [0,32) along k, col in {0,4,..,60}
+// The loader L owns all addressing: L.a(slot, ok) / L.b(slot, ok) return this thread's 4 floats of
+// staging slot `slot` for the loader's CURRENT K-step (ok = false: outside the operand, stored as
+// zeros), L.next() moves to the next K-step. Steps are fetched strictly in order, so a loader keeps
+// ready-made pointers and bumps them (a handful of VALU ops per step instead of rebuilding 64-bit
+// addresses for every load -- at fp32 MFMA rates that address arithmetic would cost as much issue
+// time as the MFMAs). The pipeline calls next() up to two steps past the end and never uses those
+// loads; loaders freeze at the last step so they stay inside the tensors.
 //
 // Pipeline: prefetch distance 2. Two register sets hold the tiles of steps s+1 and s+2 while
 // step s is multiplied out of LDS, so every global load has two MFMA phases (~0.9 us) to land;
 // at this path's problem sizes a tile is a short dependent chain of <= 16 steps and the load
 // latency, not bandwidth or MFMA rate, sets its duration. Every iteration stores one set and
-// refills it unconditionally (surplus loads/stores at the tail touch only valid memory and the
-// idle LDS buffer), so the body is branch-free; it is unrolled by two so that the register sets
-// are addressed statically (a runtime-indexed set would live in scratch).
-template <bool A_K, bool B_K, class AF, class BF, class NF>
-__device__ __forceinline__ void gemm_block(f32x16 &acc, AF aload, BF bload, NF advance, int nsteps, float *smem) {
+// refills it unconditionally (surplus work at the tail touches only valid memory and the idle LDS
+// buffer), so the body is branch-free; it is unrolled by two so that the register sets are
+// addressed statically (a runtime-indexed set would live in scratch).
+template <bool A_K, bool B_K, class LD>
+__device__ __forceinline__ void gemm_block(f32x16 &acc, LD &L, int nsteps, float *smem) {
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -86,13 +98,8 @@ __device__ __forceinline__ void gemm_block(f32x16 &acc, AF aload, BF bload, NF a
     float *As = smem;                          // 2 buffers
     float *Bs = smem + 2 * GT_TILE_FLOATS;     // 2 buffers
 
-    // this thread's two staging slots per operand
-    const int ar0 = A_K ? (t >> 4) : (t >> 3);
-    const int ac = A_K ? ((t & 15) * 4) : ((t & 7) * 4);
-    const int ar1 = ar0 + (A_K ? 16 : 32);
-    const int br0 = B_K ? (t >> 4) : (t >> 3);
-    const int bc = B_K ? ((t & 15) * 4) : ((t & 7) * 4);
-    const int br1 = br0 + (B_K ? 16 : 32);
+    const int ar0 = stage_row(A_K, 0), ar1 = stage_row(A_K, 1), ac = stage_col(A_K);
+    const int br0 = stage_row(B_K, 0), br1 = stage_row(B_K, 1), bc = stage_col(B_K);
     const int lda = A_K ? GT_LDK : GT_LDR;
     const int ldb = B_K ? GT_LDK : GT_LDR;
 
@@ -102,11 +109,11 @@ __device__ __forceinline__ void gemm_block(f32x16 &acc, AF aload, BF bload, NF a
     bool pm0 = true, pm1 = true, pm2 = true, pm3 = true, qm0 = true, qm1 = true, qm2 = true, qm3 = true;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #define GT_LOAD(A0, A1, B0, B1, M0, M1, M2, M3) \
-    A0 = aload(ar0, ac, M0);                    \
-    A1 = aload(ar1, ac, M1);                    \
-    B0 = bload(br0, bc, M2);                    \
-    B1 = bload(br1, bc, M3);                    \
-    advance();
+    A0 = L.a(0, M0);                            \
+    A1 = L.a(1, M1);                            \
+    B0 = L.b(0, M2);                            \
+    B1 = L.b(1, M3);                            \
+    L.next();
 #define GT_STORE(BUF, A0, A1, B0, B1, M0, M1, M2, M3)                                              \
     *reinterpret_cast<f32x4 *>(As + (BUF)*GT_TILE_FLOATS + ar0 * lda + ac) = M0 ? A0 : zero4;      \
     *reinterpret_cast<f32x4 *>(As + (BUF)*GT_TILE_FLOATS + ar1 * lda + ac) = M1 ? A1 : zero4;      \

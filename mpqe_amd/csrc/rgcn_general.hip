@@ -261,6 +261,123 @@ __device__ __forceinline__ int find_group(const int *__restrict__ ptr, int n, in
     return lo;
 }
 
+// Loader of the gather-GEMM tile: A rows are gathered through a row-id list (one id per tile row),
+// B is one relation matrix: W[k][n] (K-type) forward, W[n][k] (R-type) for the transposed use.
+template <int MODE, bool TRANS>
+struct GatherLoader {
+    const float *abase, *mask, *wsafe;
+    int K, Din, Dout, left, ks;           // ks = first k of the current step
+    int ac, brow0, brow1, bcol0;
+    bool rok0, rok1;
+    const float *pa0, *pa1, *pm0, *pm1, *pb0, *pb1;
+
+    __device__ __forceinline__ void init(const int *__restrict__ rows, int nrows, const float *a_,
+                                         const float *mask_, const float *W, const float *wsafe_, int K_, int Din_,
+                                         int Dout_, int n0, int nsteps) {
+        abase = a_;
+        mask = mask_;
+        wsafe = wsafe_;
+        K = K_;
+        Din = Din_;
+        Dout = Dout_;
+        left = nsteps;
+        ks = 0;
+        ac = stage_col(false);
+        const int r0 = stage_row(false, 0), r1 = stage_row(false, 1);
+        rok0 = r0 < nrows;
+        rok1 = r1 < nrows;
+        const long long o0 = rok0 ? (long long)rows[r0] * K : 0, o1 = rok1 ? (long long)rows[r1] * K : 0;
+        pa0 = abase + o0;
+        pa1 = abase + o1;
+        pm0 = mask ? mask + o0 : nullptr;
+        pm1 = mask ? mask + o1 : nullptr;
+        if (!TRANS) {
+            brow0 = stage_row(true, 0);
+            brow1 = stage_row(true, 1);
+            bcol0 = n0 + stage_col(true);
+        } else {
+            brow0 = n0 + stage_row(false, 0);
+            brow1 = n0 + stage_row(false, 1);
+            bcol0 = stage_col(false);
+        }
+        pb0 = W + (long long)brow0 * Dout;
+        pb1 = W + (long long)brow1 * Dout;
+    }
+    __device__ __forceinline__ f32x4 a(int slot, bool &ok) {
+        f32x4 v = ld4_pred<MODE>(abase, slot ? pa1 : pa0, ks + ac, K, slot ? rok1 : rok0, ok);
+        if (mask) {
+            bool ok2;
+            f32x4 o = ld4_pred<MODE>(mask, slot ? pm1 : pm0, ks + ac, K, slot ? rok1 : rok0, ok2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = o[q] > 0.f ? v[q] : 0.f;
+        }
+        return v;
+    }
+    __device__ __forceinline__ f32x4 b(int slot, bool &ok) {
+        if (!TRANS) return ld4_pred<MODE>(wsafe, slot ? pb1 : pb0, bcol0, Dout, ks + (slot ? brow1 : brow0) < Din, ok);
+        return ld4_pred<MODE>(wsafe, slot ? pb1 : pb0, ks + bcol0, Dout, (slot ? brow1 : brow0) < Din, ok);
+    }
+    __device__ __forceinline__ void next() {
+        if (left <= 1) return;
+        --left;
+        ks += GT_BK;
+        if (!TRANS) {
+            pb0 += (long long)GT_BK * Dout;
+            pb1 += (long long)GT_BK * Dout;
+        }
+    }
+};
+
+// Loader of the gathered weight gradient: K runs over message slots q; x / gpre rows come through
+// the plan's row-id lists.
+template <int MODE>
+struct GatherGradWLoader {
+    const float *x, *g, *mask;
+    const int *rows_fwd, *rows_bwd;
+    int Din, Dout, left, q, q0, q1, ca, cb;
+
+    __device__ __forceinline__ void init(const int *rf, const int *rb, const float *x_, const float *g_,
+                                         const float *mask_, int Din_, int Dout_, int q0_, int q1_, int i0, int j0,
+                                         int nsteps) {
+        rows_fwd = rf;
+        rows_bwd = rb;
+        x = x_;
+        g = g_;
+        mask = mask_;
+        Din = Din_;
+        Dout = Dout_;
+        left = nsteps;
+        q0 = q0_;
+        q1 = q1_;
+        q = q0 + stage_row(true, 0);
+        ca = i0 + stage_col(true);
+        cb = j0 + stage_col(true);
+    }
+    __device__ __forceinline__ f32x4 a(int slot, bool &ok) {
+        const int qq = q + 16 * slot;
+        const int qc = qq < q1 ? qq : q0;          // clamped slot: the row-id read stays in range
+        return ld4_pred<MODE>(x, x + (long long)rows_fwd[qc] * Din, ca, Din, qq < q1, ok);
+    }
+    __device__ __forceinline__ f32x4 b(int slot, bool &ok) {
+        const int qq = q + 16 * slot;
+        const int qc = qq < q1 ? qq : q0;
+        const long long off = (long long)rows_bwd[qc] * Dout;
+        f32x4 v = ld4_pred<MODE>(g, g + off, cb, Dout, qq < q1, ok);
+        if (mask) {
+            bool ok2;
+            f32x4 o = ld4_pred<MODE>(mask, mask + off, cb, Dout, qq < q1, ok2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = o[k] > 0.f ? v[k] : 0.f;
+        }
+        return v;
+    }
+    __device__ __forceinline__ void next() {
+        if (left <= 1) return;
+        --left;
+        q += GT_BK;
+    }
+};
+
 // TRANS = false: msg[p]  = x[rows[p]]    . W[rel]      (K = Din,  cols = Dout)
 // TRANS = true : gmsg[p] = gpre[rows[p]] . W[rel]^T    (K = Dout, cols = Din), gpre masked by out > 0
 template <bool TRANS, int MODE>
@@ -281,40 +398,12 @@ __global__ __launch_bounds__(256) void rgcn_gen_gemm_kernel(
     const int n0 = blockIdx.y * GT_BN;
     const int nsteps = (K + GT_BK - 1) / GT_BK;
 
-    // staging rows of this thread in gemm_block's R-type map: (threadIdx.x >> 3) and + 32
-    const int ar0 = threadIdx.x >> 3;
-    const long long off0 = ar0 < nrows ? (long long)rows[start + ar0] * K : -1;
-    const long long off1 = ar0 + 32 < nrows ? (long long)rows[start + ar0 + 32] * K : -1;
-
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    int ks = 0;       // first k of the loader's current K-step
-    auto advance = [&]() { ks += GT_BK; };
-    auto aload = [&](int rr, int c, bool &ok) -> f32x4 {
-        const long long off = rr < 32 ? off0 : off1;
-        f32x4 v = ld4_pred<MODE>(a, a + off, ks + c, K, off >= 0, ok);
-        if (TRANS && mask) {
-            bool ok2;
-            f32x4 o = ld4_pred<MODE>(mask, mask + off, ks + c, K, off >= 0, ok2);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = o[q] > 0.f ? v[q] : 0.f;
-        }
-        return v;
-    };
-    if (!TRANS) {
-        auto bload = [&](int k, int c, bool &ok) -> f32x4 {
-            const int kk = ks + k;
-            return ld4_pred<MODE>(root, W + (long long)kk * Dout, n0 + c, Dout, kk < Din, ok);
-        };
-        gemm_block<false, true>(acc, aload, bload, advance, nsteps, smem);
-    } else {
-        auto bload = [&](int rr, int c, bool &ok) -> f32x4 {
-            const int nn = n0 + rr;
-            return ld4_pred<MODE>(root, W + (long long)nn * Dout, ks + c, Dout, nn < Din, ok);
-        };
-        gemm_block<false, false>(acc, aload, bload, advance, nsteps, smem);
-    }
+    GatherLoader<MODE, TRANS> L;
+    L.init(rows + start, nrows, a, TRANS ? mask : nullptr, W, root, K, Din, Dout, n0, nsteps);
+    gemm_block<false, !TRANS>(acc, L, nsteps, smem);
     const int col = n0 + acc_col();
     if (col < C) {
 #pragma unroll
@@ -390,27 +479,11 @@ __global__ __launch_bounds__(256) void rgcn_gen_grad_w_kernel(
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    int qs = q0;      // first slot of the loader's current K-step
-    auto advance = [&]() { qs += GT_BK; };
-    auto aload = [&](int k, int cc, bool &ok) -> f32x4 {
-        const int q = qs + k;
-        const int qc = q < q1 ? q : q0;            // clamped slot: the row-id read stays in range
-        return ld4_pred<MODE>(x, x + (long long)rows_fwd[qc] * Din, i0 + cc, Din, q < q1, ok);
-    };
-    auto bload = [&](int k, int cc, bool &ok) -> f32x4 {
-        const int q = qs + k;
-        const int qc = q < q1 ? q : q0;
-        const long long off = (long long)rows_bwd[qc] * Dout;
-        f32x4 v = ld4_pred<MODE>(g, g + off, j0 + cc, Dout, q < q1, ok);
-        if (relu) {
-            bool ok2;
-            f32x4 o = ld4_pred<MODE>(out, out + off, j0 + cc, Dout, q < q1, ok2);
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) v[qq] = o[qq] > 0.f ? v[qq] : 0.f;
-        }
-        return v;
-    };
-    gemm_block<true, true>(acc, aload, bload, advance, nsteps, smem);
+    if (nsteps > 0) {
+        GatherGradWLoader<MODE> L;
+        L.init(rows_fwd, rows_bwd, x, g, relu ? out : nullptr, Din, Dout, q0, q1, i0, j0, nsteps);
+        gemm_block<true, true>(acc, L, nsteps, smem);
+    }
     float *dst = slabs + (long long)c * Din * Dout;
     const int col = j0 + acc_col();
     if (col < Dout) {

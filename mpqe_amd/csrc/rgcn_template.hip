@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void rgcn_tmpl_grad_w_kernel(
     const long long xs = is_root ? 1 : tp.N, xo = is_root ? 0 : tp.src[z];
     const long long gs = is_root ? 1 : tp.N, go = is_root ? 0 : tp.dst[z];
     const long long slab = is_root ? (long long)tp.E * wc.nch_edge + c : (long long)z * wc.nch_edge + c;
-    tmpl_grad_w_tile<MODE>(x, g, out, Din, Dout, relu, xs, xo, gs, go, q0, q1, count - 1, i0, j0,
+    tmpl_grad_w_tile<MODE>(x, g, out, Din, Dout, relu, xs, xo, gs, go, q0, q1, i0, j0,
                           slabs + slab * (long long)Din * Dout, smem);
 }
 

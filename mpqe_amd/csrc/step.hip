@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void step_grad_w_kernel(const StepDev *__restr
     const float *x = H + (long long)s.level * level_stride + b.row_off * D;
     const float *out = H + (long long)(s.level + 1) * level_stride + b.row_off * D;
     const float *g = GH + (long long)(s.level + 1) * level_stride + b.row_off * D;
-    tmpl_grad_w_tile<MODE>(x, g, out, D, D, s.relu, xs, xo, gs, go, q0, q1, count - 1, (tile / tiles_j) * GT_BM,
+    tmpl_grad_w_tile<MODE>(x, g, out, D, D, s.relu, xs, xo, gs, go, q0, q1, (tile / tiles_j) * GT_BM,
                           (tile % tiles_j) * GT_BN, slabs + (long long)(s.slab_start + c) * D * D, smem);
 }
 
