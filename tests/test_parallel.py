@@ -1,0 +1,88 @@
+"""Data-parallel pieces on CPU with the gloo backend, world size 2 (the GPU path uses the same code
+over RCCL): the gradient bucket all-reduce equals the single-process gradient of the whole batch,
+ranks that touched different parameters still agree on the bucket layout, and graph sharding covers
+every query exactly once."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mpqe_amd.parallel import GradReducer, shard_slice
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class _Toy(torch.nn.Module):
+    """Stands in for the encoder's parameter set: two 'relation' matrices of which a rank may use
+    only one (different formulas touch different relations), plus a shared table."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.w = torch.nn.Parameter(torch.randn(2, 4, 4))
+        self.table = torch.nn.Parameter(torch.randn(6, 4))
+
+    def loss(self, ids, rel):
+        return (self.table[ids] @ self.w[rel]).pow(2).mean()
+
+
+def _worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        model = _Toy()
+        ids = torch.arange(6)
+        lo, hi = shard_slice(6, rank, world)
+        red = GradReducer(model)
+        # rank 0 only uses relation 0, rank 1 only relation 1 -> w.grad rows differ in support
+        model.loss(ids[lo:hi], rank).backward()
+        red.all_reduce()
+        out[rank] = {k: p.grad.clone() for k, p in model.named_parameters()}
+        # second step without the table: its grad must come back as exact zeros on both ranks
+        model.zero_grad(set_to_none=True)
+        (model.w[rank].sum() * 2.0).backward()
+        red.all_reduce()
+        out[rank + world] = {k: p.grad.clone() for k, p in model.named_parameters()}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_bucket_allreduce_world2():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    # single-process reference: mean over ranks of each rank's loss
+    model = _Toy()
+    ids = torch.arange(6)
+    total = 0
+    for r in range(world):
+        lo, hi = shard_slice(6, r, world)
+        total = total + model.loss(ids[lo:hi], r) / world
+    total.backward()
+    for k, p in model.named_parameters():
+        np.testing.assert_allclose(out[0][k].numpy(), p.grad.numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_array_equal(out[0][k].numpy(), out[1][k].numpy())
+    assert float(out[2]['table'].abs().max()) == 0.0 and float(out[3]['table'].abs().max()) == 0.0
+    np.testing.assert_allclose(out[2]['w'].numpy(), np.ones((2, 4, 4), np.float32))   # 2.0 * (1/2) each
+
+
+@pytest.mark.parametrize('n,world', [(512, 8), (513, 8), (5, 8), (0, 2), (7, 3)])
+def test_shard_slice_partitions_exactly(n, world):
+    covered = []
+    for r in range(world):
+        lo, hi = shard_slice(n, r, world)
+        assert 0 <= lo <= hi <= n
+        covered.extend(range(lo, hi))
+    assert covered == list(range(n))
