@@ -111,7 +111,7 @@ def time_fused_kernels(step, packed, data, model, reps=20):
     Lmax = max(Ls)
     n_ev = 2 * (2 * Lmax + 1)
     fam = {'step_layer_fwd_kernel': [0.0, 0, 0.0], 'step_layer_bwd_x_kernel': [0.0, 0, 0.0],
-           'step_grad_w_kernel': [0.0, 0, 0.0]}          # ms, launches, flops
+           'step_tail_kernel': [0.0, 0, 0.0]}          # ms, launches, flops
     import ctypes
     for _ in range(reps):
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
@@ -135,7 +135,7 @@ def time_fused_kernels(step, packed, data, model, reps=20):
             k += 2
         fl = sum(2.0 * L * b['graph'].template.B * D * D * (b['graph'].template.E + b['graph'].template.N)
                  for b, L in zip(data.batches, Ls))
-        f = fam['step_grad_w_kernel']
+        f = fam['step_tail_kernel']
         f[0] += evs[k].elapsed_time(evs[k + 1]); f[1] += 1; f[2] += fl
     out = []
     for name, (ms, n, fl) in fam.items():

@@ -247,9 +247,10 @@ __device__ __forceinline__ float readout_value(int readout, const float *__restr
 
 #define STEP_MAX_COLS_PER_LANE 8     // D <= 512 on the fused path
 
-// wave per graph. BWD = false: scores and hinge terms. BWD = true: gradient rows of gH[L_b] and the
+// wave per graph, NJ = ceil(D / 64) columns per lane (compile-time: keeps the per-lane arrays in
+// registers). BWD = false: scores and hinge terms. BWD = true: gradient rows of gH[L_b] and the
 // positive / negative target-table gradients (through the L2 normalisation).
-template <bool BWD>
+template <bool BWD, int NJ>
 __global__ __launch_bounds__(256) void step_score_kernel(
     const StepDev *__restrict__ sd, const float *__restrict__ H, long long level_stride,
     const float *__restrict__ tpos, const float *__restrict__ tneg, float margin, float eps,
@@ -267,11 +268,11 @@ __global__ __launch_bounds__(256) void step_score_kernel(
     const long long row0 = b.row_off + (gi - b.g_off) * N;
     const float *h = H + (long long)b.L * level_stride + row0 * D;
     const float *tp_ = tpos + gi * D, *tn_ = tneg + gi * D;
-    float q[STEP_MAX_COLS_PER_LANE];
-    int arg[STEP_MAX_COLS_PER_LANE];
+    float q[NJ];
+    int arg[NJ];
     float dp = 0.f, dn = 0.f, qq = 0.f, pp = 0.f, nn = 0.f;
 #pragma unroll
-    for (int j = 0; j < STEP_MAX_COLS_PER_LANE; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int c = lane + 64 * j;
         q[j] = 0.f;
         arg[j] = 0;
@@ -313,10 +314,10 @@ __global__ __launch_bounds__(256) void step_score_kernel(
     const int tab = b.target_tab;
     const long long prow = table_row(node_map, map_len, targets[gi], tabs.rows[tab], nullptr);
     const long long nrow = table_row(node_map, map_len, negs[gi], tabs.rows[tab], nullptr);
-    float gyp[STEP_MAX_COLS_PER_LANE], gyn[STEP_MAX_COLS_PER_LANE];
+    float gyp[NJ], gyn[NJ];
     float yg_p = 0.f, yg_n = 0.f, ssp = 0.f, ssn = 0.f;
 #pragma unroll
-    for (int j = 0; j < STEP_MAX_COLS_PER_LANE; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int c = lane + 64 * j;
         gyp[j] = gyn[j] = 0.f;
         if (c < D) {
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(256) void step_score_kernel(
     float *gt = tabs.grad[tab];
     if (gt) {
 #pragma unroll
-        for (int j = 0; j < STEP_MAX_COLS_PER_LANE; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int c = lane + 64 * j;
             if (c < D) {
                 if (prow >= 0) atomicAdd(gt + prow * D + c, (gyp[j] - tp_[c] * yg_p) * ivp);
@@ -389,17 +390,16 @@ __global__ __launch_bounds__(1024) void step_loss_kernel(const StepDev *__restri
 
 // ------------------------------------------------------------------------------------ weight gradients
 template <int MODE>
-__global__ __launch_bounds__(256) void step_grad_w_kernel(const StepDev *__restrict__ sd,
-                                                          const WSource *__restrict__ src, int nsrc,
-                                                          const int *__restrict__ block_start,
-                                                          const float *__restrict__ H, const float *__restrict__ GH,
-                                                          long long level_stride, float *__restrict__ slabs) {
-    __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
+__device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, const WSource *__restrict__ src,
+                                             int nsrc, const int *__restrict__ block_start,
+                                             const float *__restrict__ H, const float *__restrict__ GH,
+                                             long long level_stride, float *__restrict__ slabs, int bid,
+                                             float *smem) {
     const int D = sd->D;
     const int tiles_j = (D + GT_BN - 1) / GT_BN, tiles = tiles_j * ((D + GT_BM - 1) / GT_BM);
-    const int si = find_le(block_start, nsrc + 1, (int)blockIdx.x);
+    const int si = find_le(block_start, nsrc + 1, bid);
     const WSource s = src[si];
-    const int lb = blockIdx.x - s.block_start;
+    const int lb = bid - s.block_start;
     const int c = lb / tiles, tile = lb - c * tiles;
     const BatchDev &b = sd->b[s.batch];
     const bool is_root = s.slot == b.tp.E;
@@ -419,17 +419,16 @@ __global__ __launch_bounds__(256) void step_grad_w_kernel(const StepDev *__restr
 // partial vectors. kind 0: column sums of gpre over 64-row blocks of (batch, level).
 // kind 1: sums of gH[0] variable row k over 64-graph blocks of the batch; 4 row groups x 64 columns per
 // workgroup in both kinds.
-__global__ __launch_bounds__(256) void step_vec_partial_kernel(const StepDev *__restrict__ sd,
-                                                               const VSource *__restrict__ src, int nsrc,
-                                                               const int *__restrict__ block_start,
-                                                               const float *__restrict__ H,
-                                                               const float *__restrict__ GH, long long level_stride,
-                                                               float *__restrict__ partial) {
-    __shared__ float part[4][64];
+__device__ __forceinline__ void vec_partial_block(const StepDev *__restrict__ sd, const VSource *__restrict__ src,
+                                                  int nsrc, const int *__restrict__ block_start,
+                                                  const float *__restrict__ H, const float *__restrict__ GH,
+                                                  long long level_stride, float *__restrict__ partial, int bid,
+                                                  float *smem) {
+    float(*part)[64] = reinterpret_cast<float(*)[64]>(smem);
     const int D = sd->D;
-    const int si = find_le(block_start, nsrc + 1, (int)blockIdx.x);
+    const int si = find_le(block_start, nsrc + 1, bid);
     const VSource s = src[si];
-    const int lb = blockIdx.x - s.block_start;
+    const int lb = bid - s.block_start;
     const BatchDev &b = sd->b[s.batch];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int cchunks = (D + 63) / 64;
@@ -462,13 +461,12 @@ __global__ __launch_bounds__(256) void step_vec_partial_kernel(const StepDev *__
 
 // anchor rows of gH[0] through the L2 normalisation into the entity-table gradients (fp32 atomics:
 // an entity can occur in several graphs)
-__global__ __launch_bounds__(256) void step_anchor_bwd_kernel(const StepDev *__restrict__ sd, TablePtrs tabs,
-                                                              const long long *__restrict__ node_map,
-                                                              long long map_len,
-                                                              const long long *__restrict__ anchor_ids,
-                                                              const float *__restrict__ G0,
-                                                              const int *__restrict__ anchor_row_off, int nb) {
-    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void anchor_bwd_block(const StepDev *__restrict__ sd, const TablePtrs &tabs,
+                                                 const long long *__restrict__ node_map, long long map_len,
+                                                 const long long *__restrict__ anchor_ids,
+                                                 const float *__restrict__ G0,
+                                                 const int *__restrict__ anchor_row_off, int nb, int bid) {
+    const long long w = (long long)bid * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (w >= anchor_row_off[nb]) return;
     const int bi = find_le(anchor_row_off, nb + 1, (int)w);
@@ -494,36 +492,81 @@ __global__ __launch_bounds__(256) void step_anchor_bwd_kernel(const StepDev *__r
     for (int c = lane; c < D; c += 64) atomicAdd(gt + row * D + c, (gi[c] - (v[c] / nrm) * ydotg) * inv);
 }
 
+// Backward tail: weight-gradient tiles, bias / variable-row partial sums and anchor-table gradients
+// all depend only on H and gH and write disjoint outputs, so they share ONE launch (a role per block
+// range, heavy MFMA tiles first) instead of three half-empty ones.
+struct TailArgs {
+    const WSource *wsrc;
+    const int *wblock;
+    int nwsrc, wblocks;
+    const VSource *vsrc;
+    const int *vblock;
+    int nvsrc, vblocks;
+    const int *anchor_off;
+    int nb;
+    const long long *node_map;
+    long long map_len;
+    const long long *anchor_ids;
+    float *slabs, *parts;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restrict__ sd, TailArgs ta, TablePtrs tabs,
+                                                        const float *__restrict__ H, const float *__restrict__ GH,
+                                                        long long level_stride) {
+    __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
+    const int bid = blockIdx.x;
+    if (bid < ta.wblocks)
+        grad_w_block<MODE>(sd, ta.wsrc, ta.nwsrc, ta.wblock, H, GH, level_stride, ta.slabs, bid, smem);
+    else if (bid < ta.wblocks + ta.vblocks)
+        vec_partial_block(sd, ta.vsrc, ta.nvsrc, ta.vblock, H, GH, level_stride, ta.parts, bid - ta.wblocks, smem);
+    else
+        anchor_bwd_block(sd, tabs, ta.node_map, ta.map_len, ta.anchor_ids, GH, ta.anchor_off, ta.nb,
+                         bid - ta.wblocks - ta.vblocks);
+}
+
 struct GradPtrs {
     float *basis[MPQE_STEP_MAX_LAYERS], *root[MPQE_STEP_MAX_LAYERS], *bias[MPQE_STEP_MAX_LAYERS];
     float *mode_emb;
 };
 
-// out += sum of the group's slabs / partial rows. A workgroup owns 64 consecutive elements; its 4
-// waves each add every 4th slab, the four sums are combined as (0+1)+(2+3): a fixed order.
+// out += sum of the group's slabs / partial rows. A workgroup owns 256 consecutive elements (4 per
+// lane, 16-byte loads); its 4 waves each add every 4th slab, the four sums are combined as
+// (0+1)+(2+3): a fixed order.
 __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restrict__ groups, int D, GradPtrs gp,
                                                           const float *__restrict__ slabs,
-                                                          const float *__restrict__ partial) {
-    __shared__ float part[4][64];
+                                                          const float *__restrict__ partial, int vec) {
+    __shared__ f32x4 part[4][64];
     const RGroup g = groups[blockIdx.y];
     const long long elems = g.kind <= 1 ? (long long)D * D : D;
     const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
-    const long long idx = (long long)blockIdx.x * 64 + el;
-    if ((long long)blockIdx.x * 64 >= elems) return;
-    float s = 0.f;
-    if (idx < elems) {
-        const float *p = (g.kind <= 1 ? slabs : partial) + (long long)g.start * elems + idx;
-        for (int i = sg; i < g.count; i += 4) s += p[(long long)i * elems];
+    const long long idx = ((long long)blockIdx.x * 64 + el) * 4;
+    if ((long long)blockIdx.x * 256 >= elems) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const float *p = (g.kind <= 1 ? slabs : partial) + (long long)g.start * elems + idx;
+    if (vec) {
+        if (idx < elems)
+            for (int i = sg; i < g.count; i += 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(p + (long long)i * elems);
+                s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+            }
+    } else {
+        for (int i = sg; i < g.count; i += 4)
+            for (int k = 0; k < 4; ++k)
+                if (idx + k < elems) s[k] += p[(long long)i * elems + k];
     }
     part[sg][el] = s;
     __syncthreads();
-    if (sg != 0 || idx >= elems) return;
+    if (sg != 0) return;
     float *dst;
     if (g.kind == 0) dst = gp.basis[g.layer] ? gp.basis[g.layer] + g.row * elems : nullptr;
     else if (g.kind == 1) dst = gp.root[g.layer];
     else if (g.kind == 2) dst = gp.bias[g.layer];
     else dst = gp.mode_emb ? gp.mode_emb + g.row * D : nullptr;
-    if (dst) dst[idx] += (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+    if (!dst) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (idx + k < elems) dst[idx + k] += (part[0][el][k] + part[1][el][k]) + (part[2][el][k] + part[3][el][k]);
 }
 
 // ------------------------------------------------------------------------------------ host side
@@ -897,16 +940,23 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                                hout);
         mark();
     }
-    hipLaunchKernelGGL(step_score_kernel<false>, dim3((unsigned)((graphs + 3) / 4)), dim3(256), 0, s, sd,
-                       (const float *)H, hp.level_stride, (const float *)tpos, (const float *)tneg, margin, 1e-8f,
-                       spos, sneg, terms, (float *)nullptr, tabs, nm, (long long)P->node_map_len, tg, ng);
+#define LAUNCH_SCORE(BWD, NJ, GHP)                                                                                 \
+    hipLaunchKernelGGL((step_score_kernel<BWD, NJ>), dim3((unsigned)((graphs + 3) / 4)), dim3(256), 0, s, sd,    \
+                       (const float *)H, hp.level_stride, (const float *)tpos, (const float *)tneg, margin, 1e-8f, \
+                       spos, sneg, terms, GHP, tabs, nm, (long long)P->node_map_len, tg, ng)
+#define LAUNCH_SCORE_D(BWD, GHP)                  \
+    if (D <= 64) LAUNCH_SCORE(BWD, 1, GHP);       \
+    else if (D <= 128) LAUNCH_SCORE(BWD, 2, GHP); \
+    else if (D <= 256) LAUNCH_SCORE(BWD, 4, GHP); \
+    else LAUNCH_SCORE(BWD, 8, GHP)
+    LAUNCH_SCORE_D(false, (float *)nullptr);
     hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss);
     if (!backward) return mpqe_launch_status();
 
     // ---- backward
-    hipLaunchKernelGGL(step_score_kernel<true>, dim3((unsigned)((graphs + 3) / 4)), dim3(256), 0, s, sd,
-                       (const float *)H, hp.level_stride, (const float *)tpos, (const float *)tneg, margin, 1e-8f,
-                       spos, sneg, terms, GH, tabs, nm, (long long)P->node_map_len, tg, ng);
+    LAUNCH_SCORE_D(true, GH);
+#undef LAUNCH_SCORE_D
+#undef LAUNCH_SCORE
     for (int p = hp.Lmax - 1; p >= 0; --p) {
         mark();
         const float *gout = GH + (long long)(p + 1) * hp.level_stride;
@@ -924,37 +974,42 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         mark();
     }
     float *slabs = reinterpret_cast<float *>(wb + hp.o_slabs), *parts = reinterpret_cast<float *>(wb + hp.o_parts);
-    mark();
     {
-        const WSource *wsrc = reinterpret_cast<const WSource *>(db + hp.o_wsrc);
-        const int *wblk = reinterpret_cast<const int *>(db + hp.o_wblock);
-        const int nsrc = (int)hp.wsrc.size();
-        dim3 wgrid(hp.wblock.back());
+        TailArgs ta;
+        ta.wsrc = reinterpret_cast<const WSource *>(db + hp.o_wsrc);
+        ta.wblock = reinterpret_cast<const int *>(db + hp.o_wblock);
+        ta.nwsrc = (int)hp.wsrc.size();
+        ta.wblocks = hp.wblock.back();
+        ta.vsrc = reinterpret_cast<const VSource *>(db + hp.o_vsrc);
+        ta.vblock = reinterpret_cast<const int *>(db + hp.o_vblock);
+        ta.nvsrc = (int)hp.vsrc.size();
+        ta.vblocks = hp.vblock.back();
+        ta.anchor_off = reinterpret_cast<const int *>(db + hp.o_anchor);
+        ta.nb = nb;
+        ta.node_map = nm;
+        ta.map_len = (long long)P->node_map_len;
+        ta.anchor_ids = ids;
+        ta.slabs = slabs;
+        ta.parts = parts;
+        dim3 tgrid((unsigned)(ta.wblocks + ta.vblocks + (hp.anchor_off[nb] + 3) / 4));
+        mark();
         if (fast && hp.whole_ksteps)
-            hipLaunchKernelGGL(step_grad_w_kernel<LD_FAST>, wgrid, dim3(256), 0, s, sd, wsrc, nsrc, wblk,
-                               (const float *)H, (const float *)GH, hp.level_stride, slabs);
+            hipLaunchKernelGGL(step_tail_kernel<LD_FAST>, tgrid, dim3(256), 0, s, sd, ta, tabs, (const float *)H,
+                               (const float *)GH, hp.level_stride);
         else if (vec)
-            hipLaunchKernelGGL(step_grad_w_kernel<LD_PRED>, wgrid, dim3(256), 0, s, sd, wsrc, nsrc, wblk,
-                               (const float *)H, (const float *)GH, hp.level_stride, slabs);
+            hipLaunchKernelGGL(step_tail_kernel<LD_PRED>, tgrid, dim3(256), 0, s, sd, ta, tabs, (const float *)H,
+                               (const float *)GH, hp.level_stride);
         else
-            hipLaunchKernelGGL(step_grad_w_kernel<LD_SCALAR>, wgrid, dim3(256), 0, s, sd, wsrc, nsrc, wblk,
-                               (const float *)H, (const float *)GH, hp.level_stride, slabs);
+            hipLaunchKernelGGL(step_tail_kernel<LD_SCALAR>, tgrid, dim3(256), 0, s, sd, ta, tabs, (const float *)H,
+                               (const float *)GH, hp.level_stride);
+        mark();
     }
-    mark();
-    hipLaunchKernelGGL(step_vec_partial_kernel, dim3(hp.vblock.back()), dim3(256), 0, s, sd,
-                       reinterpret_cast<const VSource *>(db + hp.o_vsrc), (int)hp.vsrc.size(),
-                       reinterpret_cast<const int *>(db + hp.o_vblock), (const float *)H, (const float *)GH,
-                       hp.level_stride, parts);
-    if (hp.anchor_off[nb] > 0)
-        hipLaunchKernelGGL(step_anchor_bwd_kernel, dim3((unsigned)((hp.anchor_off[nb] + 3) / 4)), dim3(256), 0, s, sd,
-                           tabs, nm, (long long)P->node_map_len, ids, (const float *)GH,
-                           reinterpret_cast<const int *>(db + hp.o_anchor), nb);
     {
         const long long elems = (long long)D * D;
-        dim3 grid((unsigned)((elems + 63) / 64), (unsigned)hp.groups.size());
+        dim3 grid((unsigned)((elems + 255) / 256), (unsigned)hp.groups.size());
         hipLaunchKernelGGL(step_reduce_kernel, grid, dim3(256), 0, s,
                            reinterpret_cast<const RGroup *>(db + hp.o_groups), D, gp, (const float *)slabs,
-                           (const float *)parts);
+                           (const float *)parts, (int)(D % 4 == 0));
     }
     return mpqe_launch_status();
 }
