@@ -37,25 +37,34 @@
 //              hipcc keeps two tiles of loads in flight behind counted s_waitcnt.
 enum { LD_SCALAR = 0, LD_PRED = 1, LD_FAST = 2 };
 
+// Every operand lives in HBM. Pointers that reach a kernel inside a by-value struct or through a
+// select lose their address space and hipcc would emit FLAT loads for them (slower, and they tie
+// up both the vm and the lgkm counters); loading through an explicit global-address-space pointer
+// keeps them global_load_dwordx4.
+typedef const f32x4 __attribute__((address_space(1))) * gvec4_ptr;
+typedef const float __attribute__((address_space(1))) * gfloat_ptr;
+__device__ __forceinline__ f32x4 gload4(const float *p) { return *(gvec4_ptr)(p); }
+__device__ __forceinline__ float gload1(const float *p) { return *(gfloat_ptr)(p); }
+
 template <int MODE>
 __device__ __forceinline__ f32x4 ld4_pred(const float *__restrict__ safe, const float *__restrict__ p, int c,
                                           int limit, bool row_ok, bool &ok) {
     if (MODE == LD_FAST) {
         ok = true;
-        return *reinterpret_cast<const f32x4 *>(p + c);
+        return gload4(p + c);
     }
     if (MODE == LD_PRED) {
         ok = row_ok && c < limit;
         const float *q = ok ? p + c : safe;
-        return *reinterpret_cast<const f32x4 *>(q);
+        return gload4(q);
     }
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     ok = true;
     if (row_ok) {
-        if (c + 0 < limit) v[0] = p[c + 0];
-        if (c + 1 < limit) v[1] = p[c + 1];
-        if (c + 2 < limit) v[2] = p[c + 2];
-        if (c + 3 < limit) v[3] = p[c + 3];
+        if (c + 0 < limit) v[0] = gload1(p + c + 0);
+        if (c + 1 < limit) v[1] = gload1(p + c + 1);
+        if (c + 2 < limit) v[2] = gload1(p + c + 2);
+        if (c + 3 < limit) v[3] = gload1(p + c + 3);
     }
     return v;
 }

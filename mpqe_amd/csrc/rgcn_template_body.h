@@ -23,9 +23,16 @@ struct KBlocks {
         else { s3 = sv; W3 = Wv; }
         ++nk;
     }
-    __device__ __forceinline__ int slot(int kb) const { return kb == 0 ? s0 : (kb == 1 ? s1 : (kb == 2 ? s2 : s3)); }
-    __device__ __forceinline__ const float *weight(int kb) const {
-        return kb == 0 ? W0 : (kb == 1 ? W1 : (kb == 2 ? W2 : W3));
+    // The current block is always entry 0; moving to the next block shifts the table down. Plain
+    // selects on wave-uniform values (s_cselect) -- indexing the table by a runtime block number
+    // compiles to a nest of scalar branches in the middle of the MFMA loop.
+    __device__ __forceinline__ void shift_if(bool wrap) {
+        s0 = wrap ? s1 : s0;
+        s1 = wrap ? s2 : s1;
+        s2 = wrap ? s3 : s2;
+        W0 = wrap ? W1 : W0;
+        W1 = wrap ? W2 : W1;
+        W2 = wrap ? W3 : W2;
     }
 };
 
@@ -41,7 +48,7 @@ struct LayerLoader {
     KBlocks kb;
     const float *abase, *mask, *wsafe;
     int K, ldw, wrows;          // A row length; W leading dim (= Dout); rows of W the B tile may touch
-    int spb, cur, ls, left;
+    int spb, ls, left;
     int ca;                     // column of this thread's A slots in the current step: ls*32 + ac
     int bcol0;                  // K-type: n0 + bc (fixed); R-type: bc (column inside the step)
     bool rok0, rok1;            // A rows inside the batch
@@ -50,14 +57,14 @@ struct LayerLoader {
     const float *pa0, *pa1, *pm0, *pm1, *pb0, *pb1;
 
     __device__ __forceinline__ void set_block() {
-        const long long so = (long long)kb.slot(cur) * K;
+        const long long so = (long long)kb.s0 * K;
         pa0 = abase + arow0 + so;
         pa1 = abase + arow1 + so;
         if (mask) {
             pm0 = mask + arow0 + so;
             pm1 = mask + arow1 + so;
         }
-        const float *W = kb.weight(cur);
+        const float *W = kb.W0;
         pb0 = W + (long long)brow0 * ldw;       // forward: row k = brow of step 0; backward: row n = brow
         pb1 = W + (long long)brow1 * ldw;
     }
@@ -73,7 +80,6 @@ struct LayerLoader {
         ldw = ldw_;
         wrows = wrows_;
         spb = (K + GT_BK - 1) / GT_BK;
-        cur = 0;
         ls = 0;
         left = kb.nk * spb;
         ca = stage_col(false);
@@ -117,21 +123,28 @@ struct LayerLoader {
         return ld4_pred<MODE>(wsafe, slot ? pb1 : pb0, ls * GT_BK + bcol0, ldw, nn < wrows, ok);
     }
 
+    // Written with selects only (the conditions are wave-uniform, so they become s_cselect): a
+    // taken scalar branch per condition per step would cost about as much issue time as the MFMAs
+    // it sits between.
     __device__ __forceinline__ void next() {
-        if (left <= 1) return;              // freeze on the last step (surplus pipeline loads)
-        --left;
-        if (++ls == spb) {
-            ls = 0;
-            ++cur;
-            ca = stage_col(false);
-            set_block();
-        } else {
-            ca += GT_BK;
-            if (!TRANS) {
-                pb0 += (long long)GT_BK * ldw;
-                pb1 += (long long)GT_BK * ldw;
-            }
+        const bool go = left > 1;            // freeze on the last step (surplus pipeline loads)
+        left -= go ? 1 : 0;
+        const bool wrap = go && (ls + 1 == spb);
+        ls = wrap ? 0 : (go ? ls + 1 : ls);
+        kb.shift_if(wrap);
+        ca = wrap ? stage_col(false) : (go ? ca + GT_BK : ca);
+        const long long so = (long long)kb.s0 * K;
+        const float *W = kb.W0;
+        const float *nb0 = W + (long long)brow0 * ldw, *nb1 = W + (long long)brow1 * ldw;
+        const long long bump = (!TRANS && go) ? (long long)GT_BK * ldw : 0;
+        pa0 = wrap ? abase + arow0 + so : pa0;
+        pa1 = wrap ? abase + arow1 + so : pa1;
+        if (mask) {
+            pm0 = wrap ? mask + arow0 + so : pm0;
+            pm1 = wrap ? mask + arow1 + so : pm1;
         }
+        pb0 = wrap ? nb0 : pb0 + bump;
+        pb1 = wrap ? nb1 : pb1 + bump;
     }
 };
 
@@ -264,12 +277,12 @@ struct GradWLoader {
         return v;
     }
     __device__ __forceinline__ void next() {
-        if (left <= 1) return;       // freeze on the last step: LD_FAST never runs past the tensors
-        --left;
-        q += GT_BK;
-        px += stepx;
-        pg += stepg;
-        if (mask) pm += stepg;
+        const bool go = left > 1;    // freeze on the last step: LD_FAST never runs past the tensors
+        left -= go ? 1 : 0;
+        q += go ? GT_BK : 0;
+        px += go ? stepx : 0;
+        pg += go ? stepg : 0;
+        if (mask) pm += go ? stepg : 0;
     }
 };
 
