@@ -45,7 +45,6 @@ struct BatchDev {
 struct StepDev {
     int nb, D, num_layers, readout;
     long long rows_total, graphs_total;
-    int tile_off[STEP_MAX_LEVELS][MPQE_STEP_MAX_BATCHES + 1];
     BatchDev b[MPQE_STEP_MAX_BATCHES];
 };
 
@@ -56,6 +55,15 @@ struct TablePtrs {
     const float *table[MPQE_STEP_MAX_MODES];
     float *grad[MPQE_STEP_MAX_MODES];
     long long rows[MPQE_STEP_MAX_MODES];
+};
+
+// Tiles of one (batch, node slot) at one level: rt*ct tiles of equal K length. Groups are sorted by
+// DEscending length: all workgroups of a level are resident at once and are dealt round-robin over
+// the 256 CUs, so block i shares its CU with blocks i+256, i+512; longest-first pairs every long
+// tile with shorter ones instead of stacking three 16-step tiles on one CU (per-CU MFMA time is
+// what bounds a level).
+struct TileGroup {
+    int batch, node, tile_off, steps;
 };
 
 // one weight-gradient source: (batch, level, slot) -> nch K-chunks, each a slab of D*D floats
@@ -101,6 +109,16 @@ __device__ __forceinline__ const float *pick_layer(const float *const *arr, int 
     for (int l = 1; l < MPQE_STEP_MAX_LAYERS; ++l)
         if (l == li) r = arr[l];
     return r;
+}
+
+__device__ __forceinline__ int find_group_le(const TileGroup *__restrict__ g, int n, int t) {
+    int lo = 0, hi = n - 1;     // largest i in [0, n) with g[i].tile_off <= t
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (g[mid].tile_off <= t) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
 }
 
 __device__ __forceinline__ int layer_index(int p, int L, int num_layers) {
@@ -183,16 +201,16 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(
 // ------------------------------------------------------------------------------------ layer levels
 template <int MODE>
 __global__ __launch_bounds__(256) void step_layer_fwd_kernel(const StepDev *__restrict__ sd, LayerPtrs lp, int p,
+                                                             const TileGroup *__restrict__ groups, int ngroups,
                                                              const float *__restrict__ Hin,
                                                              float *__restrict__ Hout) {
     __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
     const int t = blockIdx.x;
-    const int bi = find_le(sd->tile_off[p], sd->nb + 1, t);
-    const BatchDev &b = sd->b[bi];
+    const TileGroup tg = groups[find_group_le(groups, ngroups, t)];
+    const BatchDev &b = sd->b[tg.batch];
     const int D = sd->D;
-    const int ct = (D + GT_BN - 1) / GT_BN, rt = (b.B + GT_BM - 1) / GT_BM;
-    const int lt = t - sd->tile_off[p][bi];
-    const int n = lt / (rt * ct), rem = lt - n * rt * ct;
+    const int ct = (D + GT_BN - 1) / GT_BN;
+    const int n = tg.node, rem = t - tg.tile_off;
     const int li = layer_index(p, b.L, sd->num_layers);
     const TmplArgs tp = b.tp;
     tmpl_fwd_tile<MODE>(tp, b.B, Hin + b.row_off * D, pick_layer(lp.basis, li), pick_layer(lp.root, li),
@@ -202,17 +220,17 @@ __global__ __launch_bounds__(256) void step_layer_fwd_kernel(const StepDev *__re
 
 template <int MODE>
 __global__ __launch_bounds__(256) void step_layer_bwd_x_kernel(const StepDev *__restrict__ sd, LayerPtrs lp, int p,
+                                                               const TileGroup *__restrict__ groups, int ngroups,
                                                                const float *__restrict__ Gout,
                                                                const float *__restrict__ Hin,
                                                                float *__restrict__ Gin) {
     __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
     const int t = blockIdx.x;
-    const int bi = find_le(sd->tile_off[p], sd->nb + 1, t);
-    const BatchDev &b = sd->b[bi];
+    const TileGroup tg = groups[find_group_le(groups, ngroups, t)];
+    const BatchDev &b = sd->b[tg.batch];
     const int D = sd->D;
-    const int ct = (D + GT_BN - 1) / GT_BN, rt = (b.B + GT_BM - 1) / GT_BM;
-    const int lt = t - sd->tile_off[p][bi];
-    const int m = lt / (rt * ct), rem = lt - m * rt * ct;
+    const int ct = (D + GT_BN - 1) / GT_BN;
+    const int m = tg.node, rem = t - tg.tile_off;
     const int li = layer_index(p, b.L, sd->num_layers);
     const TmplArgs tp = b.tp;
     // Gout is already a pre-activation gradient (masked by whoever wrote it); the gradient written
@@ -576,6 +594,8 @@ struct HostPlan {
     StepDev sd;
     int Lmax;
     int tiles[STEP_MAX_LEVELS];
+    std::vector<TileGroup> gfwd[STEP_MAX_LEVELS], gbwd[STEP_MAX_LEVELS];
+    size_t o_gfwd[STEP_MAX_LEVELS], o_gbwd[STEP_MAX_LEVELS];
     std::vector<WSource> wsrc;
     std::vector<int> wblock;          // nsrc + 1
     std::vector<VSource> vsrc;
@@ -663,15 +683,29 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, H
     sd.rows_total = rows;
     sd.graphs_total = graphs;
     const int ct = (D + GT_BN - 1) / GT_BN;
+    const int spb = (D + GT_BK - 1) / GT_BK;
     for (int p = 0; p < STEP_MAX_LEVELS; ++p) {
-        int t = 0;
-        for (int i = 0; i < nb; ++i) {
-            sd.tile_off[p][i] = t;
-            if (sd.b[i].L > p) t += sd.b[i].tp.N * ((sd.b[i].B + GT_BM - 1) / GT_BM) * ct;
+        for (int dir = 0; dir < 2; ++dir) {
+            std::vector<TileGroup> &g = dir ? hp->gbwd[p] : hp->gfwd[p];
+            g.clear();
+            for (int i = 0; i < nb; ++i) {
+                if (sd.b[i].L <= p) continue;
+                const TmplArgs &tp = sd.b[i].tp;
+                for (int n = 0; n < tp.N; ++n) {
+                    int deg = 0;      // forward: edges INTO n; backward-x: edges OUT of n
+                    for (int e = 0; e < tp.E; ++e) deg += (dir ? tp.src[e] : tp.dst[e]) == n;
+                    g.push_back(TileGroup{i, n, 0, (deg + 1) * spb});
+                }
+            }
+            std::stable_sort(g.begin(), g.end(), [](const TileGroup &a, const TileGroup &b) { return a.steps > b.steps; });
+            int t = 0;
+            for (size_t k = 0; k < g.size(); ++k) {
+                g[k].tile_off = t;
+                t += ((sd.b[g[k].batch].B + GT_BM - 1) / GT_BM) * ct;
+            }
+            g.push_back(TileGroup{0, 0, t, 0});      // sentinel: total tile count
+            hp->tiles[p] = t;
         }
-        sd.tile_off[p][nb] = t;
-        for (int i = nb + 1; i <= MPQE_STEP_MAX_BATCHES; ++i) sd.tile_off[p][i] = t;
-        hp->tiles[p] = t;
     }
 
     // unique layer buffers (shared layers alias one parameter set -> one gradient buffer)
@@ -803,6 +837,10 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, H
     hp->o_vblock = take(hp->vblock.size() * sizeof(int));
     hp->o_groups = take(hp->groups.size() * sizeof(RGroup));
     hp->o_anchor = take(hp->anchor_off.size() * sizeof(int));
+    for (int p = 0; p < hp->Lmax; ++p) {
+        hp->o_gfwd[p] = take(hp->gfwd[p].size() * sizeof(TileGroup));
+        hp->o_gbwd[p] = take(hp->gbwd[p].size() * sizeof(TileGroup));
+    }
     hp->desc_total = off;
     off = 0;
     hp->o_H = take((size_t)(hp->Lmax + 1) * rows * D * 4);
@@ -910,6 +948,10 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         upload(s, db + hp.o_vblock, hp.vblock.data(), hp.vblock.size() * sizeof(int));
         upload(s, db + hp.o_groups, hp.groups.data(), hp.groups.size() * sizeof(RGroup));
         upload(s, db + hp.o_anchor, hp.anchor_off.data(), hp.anchor_off.size() * sizeof(int));
+        for (int p = 0; p < hp.Lmax; ++p) {
+            upload(s, db + hp.o_gfwd[p], hp.gfwd[p].data(), hp.gfwd[p].size() * sizeof(TileGroup));
+            upload(s, db + hp.o_gbwd[p], hp.gbwd[p].data(), hp.gbwd[p].size() * sizeof(TileGroup));
+        }
     }
     float *H = reinterpret_cast<float *>(wb + hp.o_H), *GH = reinterpret_cast<float *>(wb + hp.o_GH);
     float *tpos = reinterpret_cast<float *>(wb + hp.o_tpos), *tneg = reinterpret_cast<float *>(wb + hp.o_tneg);
@@ -931,13 +973,15 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         mark();
         const float *hin = H + (long long)p * hp.level_stride;
         float *hout = H + (long long)(p + 1) * hp.level_stride;
+        const TileGroup *gf = reinterpret_cast<const TileGroup *>(db + hp.o_gfwd[p]);
+        const int ngf = (int)hp.gfwd[p].size();
         if (fast)
-            hipLaunchKernelGGL(step_layer_fwd_kernel<LD_FAST>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, hin, hout);
+            hipLaunchKernelGGL(step_layer_fwd_kernel<LD_FAST>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gf, ngf, hin, hout);
         else if (vec)
-            hipLaunchKernelGGL(step_layer_fwd_kernel<LD_PRED>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, hin, hout);
+            hipLaunchKernelGGL(step_layer_fwd_kernel<LD_PRED>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gf, ngf, hin, hout);
         else
-            hipLaunchKernelGGL(step_layer_fwd_kernel<LD_SCALAR>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, hin,
-                               hout);
+            hipLaunchKernelGGL(step_layer_fwd_kernel<LD_SCALAR>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gf, ngf,
+                               hin, hout);
         mark();
     }
 #define LAUNCH_SCORE(BWD, NJ, GHP)                                                                                 \
@@ -962,15 +1006,17 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         const float *gout = GH + (long long)(p + 1) * hp.level_stride;
         const float *hin = H + (long long)p * hp.level_stride;
         float *gin = GH + (long long)p * hp.level_stride;
+        const TileGroup *gb = reinterpret_cast<const TileGroup *>(db + hp.o_gbwd[p]);
+        const int ngb = (int)hp.gbwd[p].size();
         if (fast)
-            hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_FAST>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gout,
-                               hin, gin);
+            hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_FAST>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gb, ngb,
+                               gout, hin, gin);
         else if (vec)
-            hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_PRED>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gout,
-                               hin, gin);
+            hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_PRED>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gb, ngb,
+                               gout, hin, gin);
         else
             hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_SCALAR>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p,
-                               gout, hin, gin);
+                               gb, ngb, gout, hin, gin);
         mark();
     }
     float *slabs = reinterpret_cast<float *>(wb + hp.o_slabs), *parts = reinterpret_cast<float *>(wb + hp.o_parts);
