@@ -412,12 +412,22 @@ __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, con
                                              int nsrc, const int *__restrict__ block_start,
                                              const float *__restrict__ H, const float *__restrict__ GH,
                                              long long level_stride, float *__restrict__ slabs, int bid,
-                                             float *smem) {
+                                             int wblocks_total, float *smem) {
     const int D = sd->D;
     const int tiles_j = (D + GT_BN - 1) / GT_BN, tiles = tiles_j * ((D + GT_BM - 1) / GT_BM);
-    const int si = find_le(block_start, nsrc + 1, bid);
+    // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2: blocks b and b+8 share
+    // one. The `tiles` output tiles of a K-chunk read the SAME rows of H and gH (different column
+    // halves), so they are mapped to blocks 8 apart -> one XCD, one L2 fetch of the rows instead of
+    // `tiles`. Pure placement: correctness never depends on it.
+    const int span = 8 * tiles;
+    int vb = bid;
+    if (bid < (wblocks_total / span) * span) {
+        const int grp = bid / span, r = bid - grp * span;
+        vb = grp * span + (r & 7) * tiles + (r >> 3);
+    }
+    const int si = find_le(block_start, nsrc + 1, vb);
     const WSource s = src[si];
-    const int lb = bid - s.block_start;
+    const int lb = vb - s.block_start;
     const int c = lb / tiles, tile = lb - c * tiles;
     const BatchDev &b = sd->b[s.batch];
     const bool is_root = s.slot == b.tp.E;
@@ -535,7 +545,7 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
     __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
     const int bid = blockIdx.x;
     if (bid < ta.wblocks)
-        grad_w_block<MODE>(sd, ta.wsrc, ta.nwsrc, ta.wblock, H, GH, level_stride, ta.slabs, bid, smem);
+        grad_w_block<MODE>(sd, ta.wsrc, ta.nwsrc, ta.wblock, H, GH, level_stride, ta.slabs, bid, ta.wblocks, smem);
     else if (bid < ta.wblocks + ta.vblocks)
         vec_partial_block(sd, ta.vsrc, ta.nvsrc, ta.vblock, H, GH, level_stride, ta.parts, bid - ta.wblocks, smem);
     else
@@ -548,43 +558,41 @@ struct GradPtrs {
     float *mode_emb;
 };
 
-// out += sum of the group's slabs / partial rows. A workgroup owns 256 consecutive elements (4 per
-// lane, 16-byte loads); its 4 waves each add every 4th slab, the four sums are combined as
-// (0+1)+(2+3): a fixed order.
+// out += sum of the group's slabs / partial rows, slabs added in index order (fixed order ->
+// reproducible). One thread owns 16 consecutive elements (4 x 16-byte loads per slab, all
+// independent, so a slab's loads pipeline): few fat waves instead of thousands of one-load waves,
+// which is what bounded the first version of this pass.
+#define RED_ELEMS_PER_THREAD 16
 __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restrict__ groups, int D, GradPtrs gp,
                                                           const float *__restrict__ slabs,
                                                           const float *__restrict__ partial, int vec) {
-    __shared__ f32x4 part[4][64];
     const RGroup g = groups[blockIdx.y];
     const long long elems = g.kind <= 1 ? (long long)D * D : D;
-    const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
-    const long long idx = ((long long)blockIdx.x * 64 + el) * 4;
-    if ((long long)blockIdx.x * 256 >= elems) return;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    const float *p = (g.kind <= 1 ? slabs : partial) + (long long)g.start * elems + idx;
-    if (vec) {
-        if (idx < elems)
-            for (int i = sg; i < g.count; i += 4) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(p + (long long)i * elems);
-                s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
-            }
-    } else {
-        for (int i = sg; i < g.count; i += 4)
-            for (int k = 0; k < 4; ++k)
-                if (idx + k < elems) s[k] += p[(long long)i * elems + k];
-    }
-    part[sg][el] = s;
-    __syncthreads();
-    if (sg != 0) return;
+    const long long idx = ((long long)blockIdx.x * 256 + threadIdx.x) * RED_ELEMS_PER_THREAD;
+    if (idx >= elems) return;
     float *dst;
     if (g.kind == 0) dst = gp.basis[g.layer] ? gp.basis[g.layer] + g.row * elems : nullptr;
     else if (g.kind == 1) dst = gp.root[g.layer];
     else if (g.kind == 2) dst = gp.bias[g.layer];
     else dst = gp.mode_emb ? gp.mode_emb + g.row * D : nullptr;
     if (!dst) return;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (idx + k < elems) dst[idx + k] += (part[0][el][k] + part[1][el][k]) + (part[2][el][k] + part[3][el][k]);
+    const float *p = (g.kind <= 1 ? slabs : partial) + (long long)g.start * elems + idx;
+    if (vec && idx + RED_ELEMS_PER_THREAD <= elems) {
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+        for (int i = 0; i < g.count; ++i) {
+            const float *q = p + (long long)i * elems;
+            const f32x4 v0 = gload4(q), v1 = gload4(q + 4), v2 = gload4(q + 8), v3 = gload4(q + 12);
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+        }
+        f32x4 *d4 = reinterpret_cast<f32x4 *>(dst + idx);
+        d4[0] += s0; d4[1] += s1; d4[2] += s2; d4[3] += s3;
+    } else {
+        for (int k = 0; k < RED_ELEMS_PER_THREAD && idx + k < elems; ++k) {
+            float s = 0.f;
+            for (int i = 0; i < g.count; ++i) s += p[(long long)i * elems + k];
+            dst[idx + k] += s;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------ host side
@@ -1052,10 +1060,15 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     }
     {
         const long long elems = (long long)D * D;
-        dim3 grid((unsigned)((elems + 255) / 256), (unsigned)hp.groups.size());
+        const long long per_block = 256 * RED_ELEMS_PER_THREAD;
+        dim3 grid((unsigned)((elems + per_block - 1) / per_block), (unsigned)hp.groups.size());
+        int rvec = D % 16 == 0;      // 16-element runs stay inside a row and 16-byte aligned
+        for (int l = 0; l < P->num_layers && rvec; ++l)
+            rvec = (uintptr_t)gp.basis[l] % 16 == 0 && (uintptr_t)gp.root[l] % 16 == 0 && (uintptr_t)gp.bias[l] % 16 == 0;
+        rvec = rvec && (uintptr_t)gp.mode_emb % 16 == 0;
         hipLaunchKernelGGL(step_reduce_kernel, grid, dim3(256), 0, s,
                            reinterpret_cast<const RGroup *>(db + hp.o_groups), D, gp, (const float *)slabs,
-                           (const float *)parts, (int)(D % 4 == 0));
+                           (const float *)parts, rvec);
     }
     return mpqe_launch_status();
 }
