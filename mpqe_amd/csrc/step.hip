@@ -558,41 +558,48 @@ struct GradPtrs {
     float *mode_emb;
 };
 
-// out += sum of the group's slabs / partial rows, slabs added in index order (fixed order ->
-// reproducible). One thread owns 16 consecutive elements (4 x 16-byte loads per slab, all
-// independent, so a slab's loads pipeline): few fat waves instead of thousands of one-load waves,
-// which is what bounded the first version of this pass.
-#define RED_ELEMS_PER_THREAD 16
+// out += sum of the group's slabs / partial rows. A workgroup owns 256 consecutive elements (4 per
+// lane, 16-byte loads); its 4 waves each add every 4th slab (two loads in flight), the four sums
+// are combined as (0+1)+(2+3): a fixed order. (A one-thread-per-16-elements variant that walked all
+// slabs serially measured 2.5x slower: the 40-slab root group became the long pole.)
 __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restrict__ groups, int D, GradPtrs gp,
                                                           const float *__restrict__ slabs,
                                                           const float *__restrict__ partial, int vec) {
+    __shared__ f32x4 part[4][64];
     const RGroup g = groups[blockIdx.y];
     const long long elems = g.kind <= 1 ? (long long)D * D : D;
-    const long long idx = ((long long)blockIdx.x * 256 + threadIdx.x) * RED_ELEMS_PER_THREAD;
-    if (idx >= elems) return;
+    const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const long long idx = ((long long)blockIdx.x * 64 + el) * 4;
+    if ((long long)blockIdx.x * 256 >= elems) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const float *p = (g.kind <= 1 ? slabs : partial) + (long long)g.start * elems + idx;
+    if (vec) {
+        if (idx < elems) {
+            int i = sg;
+            for (; i + 4 < g.count; i += 8) {
+                const f32x4 v0 = gload4(p + (long long)i * elems), v1 = gload4(p + (long long)(i + 4) * elems);
+                s += v0;
+                s += v1;
+            }
+            if (i < g.count) s += gload4(p + (long long)i * elems);
+        }
+    } else {
+        for (int i = sg; i < g.count; i += 4)
+            for (int k = 0; k < 4; ++k)
+                if (idx + k < elems) s[k] += p[(long long)i * elems + k];
+    }
+    part[sg][el] = s;
+    __syncthreads();
+    if (sg != 0) return;
     float *dst;
     if (g.kind == 0) dst = gp.basis[g.layer] ? gp.basis[g.layer] + g.row * elems : nullptr;
     else if (g.kind == 1) dst = gp.root[g.layer];
     else if (g.kind == 2) dst = gp.bias[g.layer];
     else dst = gp.mode_emb ? gp.mode_emb + g.row * D : nullptr;
     if (!dst) return;
-    const float *p = (g.kind <= 1 ? slabs : partial) + (long long)g.start * elems + idx;
-    if (vec && idx + RED_ELEMS_PER_THREAD <= elems) {
-        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-        for (int i = 0; i < g.count; ++i) {
-            const float *q = p + (long long)i * elems;
-            const f32x4 v0 = gload4(q), v1 = gload4(q + 4), v2 = gload4(q + 8), v3 = gload4(q + 12);
-            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
-        }
-        f32x4 *d4 = reinterpret_cast<f32x4 *>(dst + idx);
-        d4[0] += s0; d4[1] += s1; d4[2] += s2; d4[3] += s3;
-    } else {
-        for (int k = 0; k < RED_ELEMS_PER_THREAD && idx + k < elems; ++k) {
-            float s = 0.f;
-            for (int i = 0; i < g.count; ++i) s += p[(long long)i * elems + k];
-            dst[idx + k] += s;
-        }
-    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (idx + k < elems) dst[idx + k] += (part[0][el][k] + part[1][el][k]) + (part[2][el][k] + part[3][el][k]);
 }
 
 // ------------------------------------------------------------------------------------ host side
@@ -1060,15 +1067,10 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     }
     {
         const long long elems = (long long)D * D;
-        const long long per_block = 256 * RED_ELEMS_PER_THREAD;
-        dim3 grid((unsigned)((elems + per_block - 1) / per_block), (unsigned)hp.groups.size());
-        int rvec = D % 16 == 0;      // 16-element runs stay inside a row and 16-byte aligned
-        for (int l = 0; l < P->num_layers && rvec; ++l)
-            rvec = (uintptr_t)gp.basis[l] % 16 == 0 && (uintptr_t)gp.root[l] % 16 == 0 && (uintptr_t)gp.bias[l] % 16 == 0;
-        rvec = rvec && (uintptr_t)gp.mode_emb % 16 == 0;
+        dim3 grid((unsigned)((elems + 255) / 256), (unsigned)hp.groups.size());
         hipLaunchKernelGGL(step_reduce_kernel, grid, dim3(256), 0, s,
                            reinterpret_cast<const RGroup *>(db + hp.o_groups), D, gp, (const float *)slabs,
-                           (const float *)parts, rvec);
+                           (const float *)parts, (int)(D % 4 == 0));
     }
     return mpqe_launch_status();
 }
