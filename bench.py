@@ -145,6 +145,22 @@ def time_fused_kernels(step, packed, data, model, reps=20):
     return out
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summary
+    (profiles/r01_c_fused_pmc.json: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled as
+    the MI355X guide prescribes for gfx950). PMC counters need the rocprofv3 wrapper, so they are
+    not collected inside this process; None when no summary is committed for the kernel."""
+    path = os.path.join(ROOT, 'profiles', 'r01_c_fused_pmc.json')
+    try:
+        table = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    for name, rec in table.items():
+        if name.split('<')[0] == kernel and isinstance(rec, dict):
+            return rec.get('hbm_bytes')
+    return None
+
+
 def layer_work(data, model):
     """Algorithmic work of one step's R-GCN layers: per query graph and executed
     layer flops fwd = 2 D^2 (E+N), fwd+bwd = 6 D^2 (E+N); scatter-aggregate bytes fwd+bwd =
@@ -377,7 +393,8 @@ def main():
             dom = max(fams, key=lambda f: f['total_us_per_step'])
             out['roofline'] = {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['achieved'],
                                'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': dom['achieved'] / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
+                               'frac': dom['achieved'] / MFMA_F32_PEAK_TFLOPS,
+                               'traffic': pmc_traffic(dom['kernel']),
                                'avg_launch_us': dom['avg_launch_us'],
                                'algorithmic_flops_per_launch': dom['algorithmic_flops_per_launch'],
                                'launches_per_step': dom['launches_per_step']}

@@ -42,13 +42,24 @@ class FusedTrainStep(object):
         self.params = [p for p in model.parameters() if p.requires_grad]
         total = sum(p.numel() for p in self.params)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self._views = []
         off = 0
         for p in self.params:
-            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            self._views.append(self.flat_grad[off:off + p.numel()].view_as(p))
             off += p.numel()
+        self.bind_grads()
         self.err = ops.new_error_word(self.device)
         self._ws = None
         self._refresh_pointers()
+
+    def bind_grads(self):
+        """Make every p.grad the parameter's view of the flat gradient buffer (again). Anything that
+        replaced p.grad in between -- autograd after zero_grad(set_to_none=True), an optimizer that
+        sets grads to None -- is undone here; run() calls it, so the kernels always write where
+        p.grad reads."""
+        for p, v in zip(self.params, self._views):
+            if p.grad is not v:
+                p.grad = v
 
     def _refresh_pointers(self):
         m = self.model
@@ -129,8 +140,10 @@ class FusedTrainStep(object):
         """Returns loss [1 + nb] on the device: loss[0] = weighted step loss, loss[1 + b] =
         batch b's mean hinge. With backward=True every p.grad then holds d loss[0] / d p
         (accumulated on top of the previous content unless zero_grad)."""
-        if backward and zero_grad:
-            self.flat_grad.zero_()
+        if backward:
+            self.bind_grads()
+            if zero_grad:
+                self.flat_grad.zero_()
         loss = torch.empty(1 + packed.nb, dtype=torch.float32, device=self.device)
         sp = sn = None
         if scores:

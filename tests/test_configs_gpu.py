@@ -1,0 +1,134 @@
+"""The other BASELINE.json configurations at their full shapes on one GPU. Where the CPU oracle would
+take minutes, parity is established through size-independent properties of the path (plus the oracle
+on a sub-batch at full embedding width and full KG size):
+  * splitting: scores of a batch of B graphs == scores of its sub-batches, bit for bit (query graphs
+    never interact; reference data_utils.py:405 builds a block-diagonal batch)
+  * permutation equivariance over the graphs of a batch
+  * gradient additivity: d(sum of sub-batch losses) == d(whole-batch loss) for every parameter
+  * the fused step == the module path
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def build(kg, D, readout, adaptive, seed=0):
+    from mpqe_amd import synthetic
+    from mpqe_amd.data_utils import make_feature_modules
+    from mpqe_amd.encoders import DirectEncoder
+    from mpqe_amd.model import RGCNEncoderDecoder
+    torch.manual_seed(seed)
+    schema = synthetic.make_schema(*synthetic.KG_SHAPES[kg], seed=seed)
+    graph = synthetic.SchemaGraph(schema, D)
+    fm, node_maps = make_feature_modules(schema.ids, D, schema.num_entities)
+    model = RGCNEncoderDecoder(graph, DirectEncoder(None, fm, node_maps), readout=readout, num_layers=3,
+                               shared_layers=False, adaptive=adaptive, weight_decay=0)
+    with torch.no_grad():
+        for p in model.layers.parameters():
+            p.mul_(4.0)
+    return schema, node_maps, model
+
+
+def draw(schema, qt, B, rng):
+    from mpqe_amd import synthetic
+    f = synthetic.sample_formula(schema, qt, rng)
+    anchors = np.stack([synthetic._pick(schema, m, rng, size=B) for m in f.anchor_modes], axis=1)
+    tg = synthetic._pick(schema, f.target_mode, rng, size=B)
+    ng = synthetic._pick(schema, f.target_mode, rng, size=B)
+    return dict(formula=f, anchor_ids=anchors, targets=tg, negs=ng, weight=1.0)
+
+
+def sub(b, idx):
+    return dict(formula=b['formula'], anchor_ids=b['anchor_ids'][idx], targets=b['targets'][idx],
+                negs=b['negs'][idx], weight=b['weight'])
+
+
+def grads(model):
+    return {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize('kg,D,readout,adaptive', [('mutag', 256, 'sum', False),      # configs[2]
+                                                   ('am', 128, 'max', False)])        # configs[3]
+def test_full_mix_fused_equals_modules_and_oracle(kg, D, readout, adaptive):
+    from mpqe_amd import ops, synthetic
+    from mpqe_amd.fused import FusedTrainStep
+    from oracle import ref_cpu
+    schema, node_maps, model = build(kg, D, readout, adaptive)
+    cpu_params = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    model = model.to('cuda:0')
+    rng = np.random.RandomState(3)
+    batches = [draw(schema, qt, 512, rng) for qt, _ in synthetic.FULL_MIX]
+    step = FusedTrainStep(model)
+    loss, sp, sn = step.run(step.pack(batches), scores=True)
+    step.check()
+    g_fused = grads(model)
+    # module path on the same batches
+    for p in model.parameters():
+        p.grad = None
+    total, off = None, 0
+    for b in batches:
+        queries = [type('Q', (), {'anchor_nodes': tuple(int(v) for v in row)})() for row in b['anchor_ids']]
+        out = model.encode(b['formula'], queries)
+        pos = model.score(b['formula'], out, torch.from_numpy(b['targets']).cuda())
+        neg = model.score(b['formula'], out, torch.from_numpy(b['negs']).cuda())
+        np.testing.assert_allclose(sp[off:off + 512].cpu().numpy(), pos.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(sn[off:off + 512].cpu().numpy(), neg.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+        off += 512
+        l = ops.hinge(pos, neg, 1.0)
+        total = l if total is None else total + l
+    total.backward()
+    np.testing.assert_allclose(loss[0].item(), total.item(), rtol=1e-5, atol=1e-6)
+    for k, p in model.named_parameters():
+        ref = torch.zeros_like(p) if p.grad is None else p.grad
+        np.testing.assert_allclose(g_fused[k].cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+    # the oracle (reference op sequence) on a sub-batch of one formula, full width, full KG
+    b = sub(batches[5], np.arange(96))
+    cfg = dict(readout=readout, scatter_op='add', num_layers=3, adaptive=adaptive, weight_decay=0)
+    queries = [type('Q', (), {'anchor_nodes': tuple(int(v) for v in row)})() for row in b['anchor_ids']]
+    col = ref_cpu.collate(b['formula'], queries, model.rel_ids, model.mode_ids)
+    ref_loss = ref_cpu.margin_loss(cpu_params, cfg, node_maps, b['formula'], col, b['targets'], b['negs'])
+    l2 = step.run(step.pack([b]))
+    np.testing.assert_allclose(l2[0].item(), ref_loss.item(), rtol=1e-5, atol=1e-6)
+    ref_loss.backward()
+    for k, p in model.named_parameters():
+        ref = cpu_params[k].grad
+        ref = torch.zeros_like(cpu_params[k]) if ref is None else ref
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+def test_stress_shape_properties():
+    """configs[4]: 1M entities / 8 modes / 64 relation names, D = 256, B = 8192, 3-chain + 3-inter."""
+    from mpqe_amd.fused import FusedTrainStep
+    schema, node_maps, model = build('stress', 256, 'sum', False)
+    model = model.to('cuda:0')
+    rng = np.random.RandomState(11)
+    B = 8192
+    big = [draw(schema, '3-chain', B, rng), draw(schema, '3-inter', B, rng)]
+    step = FusedTrainStep(model)
+    loss, sp, sn = step.run(step.pack(big), scores=True)
+    step.check()
+    g_big = grads(model)
+    assert torch.isfinite(sp).all() and torch.isfinite(sn).all() and sp.abs().max() <= 1.0001
+    # splitting: four quarter batches give the same scores bit for bit, and their summed gradient
+    # (each loss is a mean over its own B/4 graphs -> weight 1/4) is the whole batch's gradient
+    acc = None
+    for q in range(4):
+        idx = np.arange(q * B // 4, (q + 1) * B // 4)
+        parts = [dict(sub(b, idx), weight=0.25) for b in big]
+        l, p1, n1 = step.run(step.pack(parts), scores=True)
+        for j in range(2):
+            lo = j * B + q * B // 4
+            assert torch.equal(p1[j * B // 4:(j + 1) * B // 4], sp[lo:lo + B // 4])
+            assert torch.equal(n1[j * B // 4:(j + 1) * B // 4], sn[lo:lo + B // 4])
+        g = grads(model)
+        acc = g if acc is None else {k: acc[k] + g[k] for k in g}
+    for k in g_big:
+        np.testing.assert_allclose(acc[k].cpu().numpy(), g_big[k].cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+    # permutation equivariance
+    perm = rng.permutation(B)
+    shuffled = [sub(b, perm) for b in big]
+    _, p2, n2 = step.run(step.pack(shuffled), scores=True)
+    for j in range(2):
+        assert torch.equal(p2[j * B:(j + 1) * B], sp[j * B:(j + 1) * B][torch.from_numpy(perm).cuda()])
