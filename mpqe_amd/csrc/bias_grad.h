@@ -1,44 +1,63 @@
-// grad_bias[j] += sum_q gpre[q][j] in a fixed order: per-block partial column sums over
-// BIAS_ROWS rows, then one pass over the partials (no atomics -> reproducible).
+// grad_bias[j] += sum_q gpre[q][j] in a fixed order: per-block partial column sums over `rpb` rows
+// (4 row groups x 64 columns per workgroup, combined as (0+1)+(2+3)), then one pass over the <= 256
+// partial rows with the same shape (no atomics -> reproducible).
 #pragma once
 #include "common.h"
 
-#define BIAS_ROWS 64
+static inline int bias_rows_per_block(long long rows) {
+    long long r = (rows + 255) / 256;        // at most 256 partial rows
+    if (r < 64) r = 64;
+    return (int)r;
+}
+static inline int bias_num_blocks(long long rows) {
+    const int rpb = bias_rows_per_block(rows);
+    return (int)((rows + rpb - 1) / rpb);
+}
 
-static __global__ __launch_bounds__(256) void bias_partial_kernel(long long rows, const float *__restrict__ g,
+static __global__ __launch_bounds__(256) void bias_partial_kernel(long long rows, int rpb, const float *__restrict__ g,
                                                                   const float *__restrict__ out, int Dout, int relu,
                                                                   float *__restrict__ partial) {
-    const long long r0 = (long long)blockIdx.x * BIAS_ROWS;
-    long long r1 = r0 + BIAS_ROWS;
+    __shared__ float part[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.y * 64 + cl;
+    const long long r0 = (long long)blockIdx.x * rpb;
+    long long r1 = r0 + rpb;
     if (r1 > rows) r1 = rows;
-    for (int col = threadIdx.x; col < Dout; col += blockDim.x) {
-        float s = 0.f;
-        for (long long r = r0; r < r1; ++r) {
+    float s = 0.f;
+    if (col < Dout)
+        for (long long r = r0 + rg; r < r1; r += 4) {
             float v = g[r * Dout + col];
             if (relu && !(out[r * Dout + col] > 0.f)) v = 0.f;
             s += v;
         }
-        partial[(long long)blockIdx.x * Dout + col] = s;
-    }
+    part[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && col < Dout)
+        partial[(long long)blockIdx.x * Dout + col] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
 }
 
 static __global__ __launch_bounds__(256) void bias_final_kernel(int nblk, int Dout, const float *__restrict__ partial,
                                                                 float *__restrict__ grad_bias) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= Dout) return;
+    __shared__ float part[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(long long)b * Dout + col];
-    grad_bias[col] += s;
+    if (col < Dout)
+        for (int b = rg; b < nblk; b += 4) s += partial[(long long)b * Dout + col];
+    part[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && col < Dout) grad_bias[col] += (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
 }
 
 static inline size_t bias_partial_bytes(long long rows, long long Dout) {
-    return align_up((size_t)((rows + BIAS_ROWS - 1) / BIAS_ROWS) * (size_t)Dout * 4, 256);
+    return align_up((size_t)bias_num_blocks(rows) * (size_t)Dout * 4, 256);
 }
 
 static inline void launch_bias_grad(long long rows, const float *g, const float *out, int Dout, int relu,
                                     float *partial, float *grad_bias, hipStream_t s) {
-    const int nblk = (int)((rows + BIAS_ROWS - 1) / BIAS_ROWS);
-    hipLaunchKernelGGL(bias_partial_kernel, dim3(nblk), dim3(256), 0, s, rows, g, out, Dout, relu, partial);
-    hipLaunchKernelGGL(bias_final_kernel, dim3((unsigned)((Dout + 255) / 256)), dim3(256), 0, s, nblk, Dout, partial,
+    const int rpb = bias_rows_per_block(rows), nblk = bias_num_blocks(rows);
+    hipLaunchKernelGGL(bias_partial_kernel, dim3(nblk, (unsigned)((Dout + 63) / 64)), dim3(256), 0, s, rows, rpb, g,
+                       out, Dout, relu, partial);
+    hipLaunchKernelGGL(bias_final_kernel, dim3((unsigned)((Dout + 63) / 64)), dim3(256), 0, s, nblk, Dout, partial,
                        grad_bias);
 }
