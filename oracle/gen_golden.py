@@ -223,6 +223,61 @@ def run_conv_case(name, n_nodes, n_edges, R, D_in, D_out, seed, isolated=True):
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **arrays)
 
 
+def run_sage_case(name, D, layer_norm, seed):
+    """The reference's depth-1 Encoder + MeanAggregator (encoders.py:47-129, aggregators.py:17-68,
+    wired as utils.py:104-111) on the tiny synthetic KG, called the GQE way (python list of ids)."""
+    rmodel, rdata, rgraph, renc = _load_reference()
+    import mpqe.aggregators as ragg
+    from mpqe_amd import synthetic
+    n_ent, n_modes, n_rel = synthetic.KG_SHAPES['tiny']
+    schema = synthetic.make_schema(n_ent, n_modes, n_rel, seed=seed)
+    adj = synthetic.make_adjacency(schema, degree=3, seed=seed)
+    # the reference's Encoder gives a node without neighbours the null neighbour -1, which its own
+    # features closure cannot look up (IndexError): make every node have at least one neighbour
+    fix = np.random.RandomState(seed + 101)
+    for rel in list(adj):
+        inv = (rel[2], rel[1], rel[0])
+        for n, nb in adj[rel].items():
+            if len(nb) == 0:
+                d = int(fix.choice(schema.ids[rel[2]]))
+                nb.add(d)
+                adj[inv][d].add(n)
+    torch.manual_seed(seed)
+    node_map = torch.full((n_ent + 1,), -1, dtype=torch.long)
+    for m in schema.modes:
+        for i, n in enumerate(schema.ids[m].tolist()):
+            node_map[n] = i
+    fm = {m: torch.nn.Embedding(len(schema.ids[m]) + 1, D) for m in schema.modes}
+    for m in schema.modes:
+        fm[m].weight.data.normal_(0, 1. / D)
+    features = lambda nodes, mode: fm[mode](node_map[nodes])
+    dims = {m: D for m in schema.modes}
+    agg = ragg.MeanAggregator(features)
+    enc = renc.Encoder(features, dims, dims, schema.relations, adj, feature_modules=fm, cuda=False,
+                       aggregator=agg, layer_norm=layer_norm)
+    mode = schema.modes[seed % len(schema.modes)]
+    rng = np.random.RandomState(seed)
+    nodes = [int(x) for x in rng.choice(schema.ids[mode], size=12, replace=True)]
+    random.seed(99 + seed)
+    out = enc.forward(nodes, mode, keep_prob=0.7, max_keep=2)
+    gout = torch.randn(out.shape, generator=torch.Generator().manual_seed(seed))
+    out.backward(gout)
+    arrays = {'out': out.detach().numpy(), 'grad_out': gout.numpy(), 'node_map': node_map.numpy(),
+              'nodes': np.array(nodes, dtype=np.int64)}
+    for k, v in enc.state_dict().items():
+        arrays['param/' + k] = v.detach().numpy()
+    for k, p in enc.named_parameters():
+        arrays['grad/' + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().numpy()
+    meta = {'name': name, 'D': D, 'layer_norm': layer_norm, 'seed': seed, 'mode': mode, 'random_seed': 99 + seed,
+            'keep_prob': 0.7, 'max_keep': 2,
+            'schema': {'modes': schema.modes, 'relations': {m: _jsonable(v) for m, v in schema.relations.items()},
+                       'ids': {m: schema.ids[m].tolist() for m in schema.modes}, 'num_entities': n_ent},
+            # neighbour collections in the iteration order python gives the reference's sets
+            'adj': [[list(rel), [[int(n), [int(x) for x in nb]] for n, nb in adj[rel].items()]] for rel in adj]}
+    arrays['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **arrays)
+
+
 QUERY_TYPES = ['1-chain', '2-chain', '3-chain', '2-inter', '3-inter',
                '3-inter_chain', '3-chain_inter']
 READOUTS = ['sum', 'max', 'mp', 'mlp', 'targetmlp', 'concat']
@@ -270,6 +325,8 @@ def main():
     run_conv_case('conv_random_c', n_nodes=300, n_edges=2000, R=12, D_in=64, D_out=64, seed=3)
     run_conv_case('conv_noedges', n_nodes=6, n_edges=0, R=3, D_in=16, D_out=16, seed=4,
                   isolated=False)
+    run_sage_case('sage_depth1_plain', D=16, layer_norm=False, seed=5)
+    run_sage_case('sage_depth1_ln', D=16, layer_norm=True, seed=6)
     print('wrote fixtures to', OUT)
 
 

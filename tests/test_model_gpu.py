@@ -169,3 +169,39 @@ def test_baseline_shape_against_oracle(qt, readout):
         ref = torch.zeros_like(params[k]) if ref is None else ref
         mine = torch.zeros_like(p) if p.grad is None else p.grad
         np.testing.assert_allclose(_np(mine), ref.numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.parametrize('name', ['sage_depth1_plain', 'sage_depth1_ln'])
+def test_sampled_neighbour_encoder_matches_reference(name):
+    """the reference's depth-1 Encoder + MeanAggregator (sampled-neighbour mean per
+    relation -> concat -> compress -> [LayerNorm] -> ReLU), same python `random` draws."""
+    import json
+    import os
+    from collections import OrderedDict
+    from mpqe_amd.aggregators import MeanAggregator
+    from mpqe_amd.encoders import Encoder
+    from tests.conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    meta = json.loads(bytes(z['meta']).decode())
+    dev = torch.device('cuda:0')
+    D = meta['D']
+    modes = meta['schema']['modes']
+    relations = OrderedDict((m, [tuple(x) for x in meta['schema']['relations'][m]]) for m in modes)
+    adj = {tuple(rel): {int(n): list(nb) for n, nb in items} for rel, items in meta['adj']}
+    node_map = torch.from_numpy(z['node_map']).to(dev)
+    fm = {m: torch.nn.Embedding(len(meta['schema']['ids'][m]) + 1, D) for m in modes}
+    features = lambda nodes, mode: fm[mode](node_map[torch.as_tensor(nodes, dtype=torch.long, device=dev)])
+    dims = {m: D for m in modes}
+    enc = Encoder(features, dims, dims, relations, adj, feature_modules=fm, cuda=True,
+                  aggregator=MeanAggregator(features), layer_norm=meta['layer_norm'])
+    state = {k[len('param/'):]: torch.from_numpy(z[k]) for k in z.files if k.startswith('param/')}
+    enc.load_state_dict(state, strict=True)          # same keys as the reference
+    enc = enc.to(dev)
+    random.seed(meta['random_seed'])
+    out = enc.forward(z['nodes'].tolist(), meta['mode'], keep_prob=meta['keep_prob'], max_keep=meta['max_keep'])
+    np.testing.assert_allclose(_np(out), z['out'], **FWD)
+    out.backward(torch.from_numpy(z['grad_out']).to(dev))
+    for k, p in enc.named_parameters():
+        g = z['grad/' + k]
+        mine = np.zeros_like(g) if p.grad is None else _np(p.grad)
+        np.testing.assert_allclose(mine, g, err_msg=k, **BWD)
