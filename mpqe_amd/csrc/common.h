@@ -72,3 +72,36 @@ __device__ __forceinline__ float row_norm_store(const float *__restrict__ v, flo
     }
     return nrm;
 }
+
+// The same for a SUB-wave: `lpr` (a power of two <= 64) adjacent lanes own one row, so a wave
+// normalises 64/lpr rows at once. Bit-identical to row_norm_store: there the lanes beyond D/4
+// contribute exact zeros to the first butterfly steps, which is all that differs.
+__device__ __forceinline__ int lanes_per_row(int D, bool vec) {
+    if (!vec) return 64;
+    int l = 1;
+    while (l < 64 && l * 4 < D) l <<= 1;
+    return l;
+}
+__device__ __forceinline__ void row_norm_store_sub(const float *__restrict__ v, float *__restrict__ o, int D,
+                                                   int sub, int lpr, bool vec) {
+    float ss = 0.f;
+    if (vec) {
+        for (int c = sub * 4; c < D; c += 4 * lpr) {
+            f32x4 q = *reinterpret_cast<const f32x4 *>(v + c);
+            ss += q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+        }
+    } else {
+        for (int c = sub; c < D; c += lpr) ss += v[c] * v[c];
+    }
+    for (int off = lpr >> 1; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    const float nrm = sqrtf(ss);
+    if (vec) {
+        for (int c = sub * 4; c < D; c += 4 * lpr) {
+            f32x4 q = *reinterpret_cast<const f32x4 *>(v + c);
+            q[0] /= nrm; q[1] /= nrm; q[2] /= nrm; q[3] /= nrm;
+            *reinterpret_cast<f32x4 *>(o + c) = q;
+        }
+    } else {
+        for (int c = sub; c < D; c += lpr) o[c] = v[c] / nrm;
+    }
+}

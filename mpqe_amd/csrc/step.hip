@@ -140,22 +140,26 @@ __device__ __forceinline__ long long table_row(const long long *__restrict__ nod
     return r;
 }
 
-// wave per row: rows [0, rows_total) are node rows of H0, then G positive and G negative targets
+// rows [0, rows_total) are node rows of H0, then G positive and G negative targets. D/4 adjacent lanes
+// own a row (two rows per wave at D = 128): the kernel is a chain of dependent gathers (id -> LUT ->
+// table row), so more rows in flight per wave is what shortens it.
 __global__ __launch_bounds__(256) void step_assemble_kernel(
     const StepDev *__restrict__ sd, TablePtrs tabs, const long long *__restrict__ node_map, long long map_len,
     const float *__restrict__ mode_emb, long long num_modes, const long long *__restrict__ anchor_ids,
     const long long *__restrict__ targets, const long long *__restrict__ negs, float *__restrict__ H0,
     float *__restrict__ tpos, float *__restrict__ tneg, int32_t *err, int vec) {
-    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
     const int D = sd->D;
+    const int lpr = lanes_per_row(D, vec), rpw = 64 / lpr;
+    const int lane = threadIdx.x & 63, sub = lane & (lpr - 1);
+    const long long w = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + lane / lpr;
     const long long R = sd->rows_total, G = sd->graphs_total;
-    if (w >= R + 2 * G) return;
-    int32_t *e = lane == 0 ? err : nullptr;
+    // no early return: every lane takes part in the sub-wave shuffles; out-of-range groups idle
+    const bool live = w < R + 2 * G;
+    int32_t *e = sub == 0 ? err : nullptr;
     const float *src = nullptr;
-    float *dst;
+    float *dst = nullptr;
     bool normalise = true;
-    if (w < R) {
+    if (live && w < R) {
         int bi = 0;
         for (int i = 1; i < sd->nb; ++i)
             if (sd->b[i].row_off <= w) bi = i;
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(
             if (m < 0 || m >= num_modes) flag_error(e, MPQE_FLAG_BAD_NODE_ID);
             else src = mode_emb + m * D;
         }
-    } else {
+    } else if (live) {
         const long long gi = (w - R) % G;
         const bool is_neg = (w - R) >= G;
         int bi = 0;
@@ -187,15 +191,24 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(
         if (row >= 0) src = tabs.table[tab] + row * D;
         dst = (is_neg ? tneg : tpos) + gi * D;
     }
-    if (!src) {
-        for (int c = lane; c < D; c += 64) dst[c] = 0.f;
-        return;
+    if (live && (!src || !normalise)) {
+        if (vec) {
+            for (int c = sub * 4; c < D; c += 4 * lpr)
+                *reinterpret_cast<f32x4 *>(dst + c) = src ? *reinterpret_cast<const f32x4 *>(src + c)
+                                                          : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            for (int c = sub; c < D; c += lpr) dst[c] = src ? src[c] : 0.f;
+        }
     }
-    if (!normalise) {
-        for (int c = lane; c < D; c += 64) dst[c] = src[c];
-        return;
+    // the normalising groups run the shuffles; the others feed them a dummy (valid) row and discard
+    const bool norm = live && src && normalise;
+    const float *vs = norm ? src : mode_emb;
+    if (norm) row_norm_store_sub(vs, dst, D, sub, lpr, vec);
+    else {
+        float dummy = 0.f;
+        for (int off = lpr >> 1; off > 0; off >>= 1) dummy += __shfl_xor(dummy, off, 64);   // keep lanes converged
+        (void)dummy;
     }
-    row_norm_store(src, dst, D, lane, vec);
 }
 
 // ------------------------------------------------------------------------------------ layer levels
@@ -313,14 +326,12 @@ __global__ __launch_bounds__(256) void step_score_kernel(
     const float nq = fmaxf(rq, eps), np_ = fmaxf(rp, eps), nn_ = fmaxf(rn, eps);
     const float sp = dp / (nq * np_), sn = dn / (nq * nn_);
     const float v = margin - (sp - sn);
-    if (!BWD) {
-        if (lane == 0) {
-            s_pos[gi] = sp;
-            s_neg[gi] = sn;
-            terms[gi] = v > 0.f ? v : 0.f;
-        }
-        return;
+    if (lane == 0) {        // the backward instance also emits the scores: no separate forward launch then
+        s_pos[gi] = sp;
+        s_neg[gi] = sn;
+        terms[gi] = v > 0.f ? v : 0.f;
     }
+    if (!BWD) return;
     // d loss / d sp = -w/B on active terms, d/d sn = +w/B   (loss = sum_b w_b mean_b hinge)
     const float act = v >= 0.f ? b.weight / (float)b.B : 0.f;
     const float gsp = -act, gsn = act;
@@ -980,7 +991,9 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     // ---- forward
     {
         const long long waves = rows + 2 * graphs;
-        hipLaunchKernelGGL(step_assemble_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, sd, tabs, nm,
+        const int lpr_h = [&] { if (!vec_tab) return 64; int l = 1; while (l < 64 && l * 4 < D) l <<= 1; return l; }();
+        const long long per_block = 4 * (64 / lpr_h);
+        hipLaunchKernelGGL(step_assemble_kernel, dim3((unsigned)((waves + per_block - 1) / per_block)), dim3(256), 0, s, sd, tabs, nm,
                            (long long)P->node_map_len, P->mode_emb, (long long)P->num_modes, ids, tg, ng, H, tpos,
                            tneg, err, vec_tab);
     }
@@ -1008,12 +1021,15 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     else if (D <= 128) LAUNCH_SCORE(BWD, 2, GHP); \
     else if (D <= 256) LAUNCH_SCORE(BWD, 4, GHP); \
     else LAUNCH_SCORE(BWD, 8, GHP)
-    LAUNCH_SCORE_D(false, (float *)nullptr);
-    hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss);
-    if (!backward) return mpqe_launch_status();
+    if (!backward) {
+        LAUNCH_SCORE_D(false, (float *)nullptr);
+        hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss);
+        return mpqe_launch_status();
+    }
 
-    // ---- backward
+    // ---- backward (the score kernel's backward instance writes scores and hinge terms too)
     LAUNCH_SCORE_D(true, GH);
+    hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss);
 #undef LAUNCH_SCORE_D
 #undef LAUNCH_SCORE
     for (int p = hp.Lmax - 1; p >= 0; --p) {
