@@ -45,6 +45,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--path', default='auto', choices=['auto', 'modules', 'fused'])
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='nccl = RCCL over xGMI (the real path); gloo only to exercise the multi-rank code on one GPU')
     return ap.parse_args()
 
 
@@ -301,8 +303,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        ndev = torch.cuda.device_count()
+        if args.backend == 'nccl' and local >= ndev:
+            raise SystemExit('rank %d has no GPU (%d visible): one process per GPU' % (local, ndev))
+        torch.cuda.set_device(local % ndev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local % ndev))
+        else:
+            dist.init_process_group('gloo')
     else:
         torch.cuda.set_device(0)
     device = torch.device('cuda', torch.cuda.current_device())
@@ -364,7 +372,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=device if args.backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
