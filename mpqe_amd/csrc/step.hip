@@ -65,6 +65,13 @@ struct TablePtrs {
 struct TileGroup {
     int batch, node, tile_off, steps;
 };
+// One entry per workgroup of a level launch: a workgroup finds its work with ONE 8-byte load instead
+// of a binary search over the groups (each probe is a dependent ~0.5 us scalar round trip that sits in
+// front of the first MFMA; with launches this short that start-up cost is a visible share).
+struct TileRef {
+    short batch, node;
+    int rem;            // tile index inside the (batch, node) group: row tile * ct + column tile
+};
 
 // one weight-gradient source: (batch, level, slot) -> nch K-chunks, each a slab of D*D floats
 struct WSource {
@@ -214,16 +221,15 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(
 // ------------------------------------------------------------------------------------ layer levels
 template <int MODE>
 __global__ __launch_bounds__(256) void step_layer_fwd_kernel(const StepDev *__restrict__ sd, LayerPtrs lp, int p,
-                                                             const TileGroup *__restrict__ groups, int ngroups,
+                                                             const TileRef *__restrict__ tiles,
                                                              const float *__restrict__ Hin,
                                                              float *__restrict__ Hout) {
     __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
-    const int t = blockIdx.x;
-    const TileGroup tg = groups[find_group_le(groups, ngroups, t)];
-    const BatchDev &b = sd->b[tg.batch];
+    const TileRef tr = tiles[blockIdx.x];
+    const BatchDev &b = sd->b[tr.batch];
     const int D = sd->D;
     const int ct = (D + GT_BN - 1) / GT_BN;
-    const int n = tg.node, rem = t - tg.tile_off;
+    const int n = tr.node, rem = tr.rem;
     const int li = layer_index(p, b.L, sd->num_layers);
     const TmplArgs tp = b.tp;
     tmpl_fwd_tile<MODE>(tp, b.B, Hin + b.row_off * D, pick_layer(lp.basis, li), pick_layer(lp.root, li),
@@ -233,17 +239,16 @@ __global__ __launch_bounds__(256) void step_layer_fwd_kernel(const StepDev *__re
 
 template <int MODE>
 __global__ __launch_bounds__(256) void step_layer_bwd_x_kernel(const StepDev *__restrict__ sd, LayerPtrs lp, int p,
-                                                               const TileGroup *__restrict__ groups, int ngroups,
+                                                               const TileRef *__restrict__ tiles,
                                                                const float *__restrict__ Gout,
                                                                const float *__restrict__ Hin,
                                                                float *__restrict__ Gin) {
     __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
-    const int t = blockIdx.x;
-    const TileGroup tg = groups[find_group_le(groups, ngroups, t)];
-    const BatchDev &b = sd->b[tg.batch];
+    const TileRef tr = tiles[blockIdx.x];
+    const BatchDev &b = sd->b[tr.batch];
     const int D = sd->D;
     const int ct = (D + GT_BN - 1) / GT_BN;
-    const int m = tg.node, rem = t - tg.tile_off;
+    const int m = tr.node, rem = tr.rem;
     const int li = layer_index(p, b.L, sd->num_layers);
     const TmplArgs tp = b.tp;
     // Gout is already a pre-activation gradient (masked by whoever wrote it); the gradient written
@@ -436,7 +441,7 @@ __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, con
         const int grp = bid / span, r = bid - grp * span;
         vb = grp * span + (r & 7) * tiles + (r >> 3);
     }
-    const int si = find_le(block_start, nsrc + 1, vb);
+    const int si = block_start[vb];          // per-workgroup source index (one load, no search)
     const WSource s = src[si];
     const int lb = vb - s.block_start;
     const int c = lb / tiles, tile = lb - c * tiles;
@@ -465,7 +470,7 @@ __device__ __forceinline__ void vec_partial_block(const StepDev *__restrict__ sd
                                                   float *smem) {
     float(*part)[64] = reinterpret_cast<float(*)[64]>(smem);
     const int D = sd->D;
-    const int si = find_le(block_start, nsrc + 1, bid);
+    const int si = block_start[bid];
     const VSource s = src[si];
     const int lb = bid - s.block_start;
     const BatchDev &b = sd->b[s.batch];
@@ -621,9 +626,12 @@ struct HostPlan {
     int Lmax;
     int tiles[STEP_MAX_LEVELS];
     std::vector<TileGroup> gfwd[STEP_MAX_LEVELS], gbwd[STEP_MAX_LEVELS];
+    std::vector<TileRef> tfwd[STEP_MAX_LEVELS], tbwd[STEP_MAX_LEVELS];
+    std::vector<int> wref;            // per weight-gradient workgroup: source index
     size_t o_gfwd[STEP_MAX_LEVELS], o_gbwd[STEP_MAX_LEVELS];
     std::vector<WSource> wsrc;
-    std::vector<int> wblock;          // nsrc + 1
+    std::vector<int> wblock;          // per weight-gradient workgroup: its source index
+    int wblocks_total, vblocks_total;
     std::vector<VSource> vsrc;
     std::vector<int> vblock;
     std::vector<RGroup> groups;
@@ -729,7 +737,12 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, H
                 g[k].tile_off = t;
                 t += ((sd.b[g[k].batch].B + GT_BM - 1) / GT_BM) * ct;
             }
-            g.push_back(TileGroup{0, 0, t, 0});      // sentinel: total tile count
+            std::vector<TileRef> &tr = dir ? hp->tbwd[p] : hp->tfwd[p];
+            tr.clear();
+            for (size_t k = 0; k < g.size(); ++k) {
+                const int cnt = ((sd.b[g[k].batch].B + GT_BM - 1) / GT_BM) * ct;
+                for (int r = 0; r < cnt; ++r) tr.push_back(TileRef{(short)g[k].batch, (short)g[k].node, r});
+            }
             hp->tiles[p] = t;
         }
     }
@@ -780,7 +793,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, H
         s.slab_start = slab;
         s.block_start = block;
         hp->wsrc.push_back(s);
-        hp->wblock.push_back(block);
+        for (int q = 0; q < s.nch * tiles; ++q) hp->wblock.push_back((int)hp->wsrc.size() - 1);
         if (k == 0 || keys[k - 1].layer != key.layer || keys[k - 1].rel != key.rel) {
             RGroup g;
             g.kind = key.rel < 0 ? 1 : 0;
@@ -794,7 +807,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, H
         slab += s.nch;
         block += s.nch * tiles;
     }
-    hp->wblock.push_back(block);
+    hp->wblocks_total = block;
     hp->total_slabs = slab;
 
     // vector partial sources: bias per (unique layer) and variable rows per mode id
@@ -831,7 +844,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, H
         s.block_start = vblock;
         s.pad = 0;
         hp->vsrc.push_back(s);
-        hp->vblock.push_back(vblock);
+        for (int q = 0; q < s.nblk * cchunks; ++q) hp->vblock.push_back((int)hp->vsrc.size() - 1);
         if (k == 0 || vk[k - 1].kind != key.kind || vk[k - 1].layer != key.layer || vk[k - 1].row != key.row) {
             RGroup g;
             g.kind = key.kind == 0 ? 2 : 3;
@@ -845,7 +858,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, H
         part += s.nblk;
         vblock += s.nblk * cchunks;
     }
-    hp->vblock.push_back(vblock);
+    hp->vblocks_total = vblock;
     hp->total_parts = part;
 
     // workspace layout
@@ -864,8 +877,8 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, H
     hp->o_groups = take(hp->groups.size() * sizeof(RGroup));
     hp->o_anchor = take(hp->anchor_off.size() * sizeof(int));
     for (int p = 0; p < hp->Lmax; ++p) {
-        hp->o_gfwd[p] = take(hp->gfwd[p].size() * sizeof(TileGroup));
-        hp->o_gbwd[p] = take(hp->gbwd[p].size() * sizeof(TileGroup));
+        hp->o_gfwd[p] = take(hp->tfwd[p].size() * sizeof(TileRef));
+        hp->o_gbwd[p] = take(hp->tbwd[p].size() * sizeof(TileRef));
     }
     hp->desc_total = off;
     off = 0;
@@ -975,8 +988,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         upload(s, db + hp.o_groups, hp.groups.data(), hp.groups.size() * sizeof(RGroup));
         upload(s, db + hp.o_anchor, hp.anchor_off.data(), hp.anchor_off.size() * sizeof(int));
         for (int p = 0; p < hp.Lmax; ++p) {
-            upload(s, db + hp.o_gfwd[p], hp.gfwd[p].data(), hp.gfwd[p].size() * sizeof(TileGroup));
-            upload(s, db + hp.o_gbwd[p], hp.gbwd[p].data(), hp.gbwd[p].size() * sizeof(TileGroup));
+            upload(s, db + hp.o_gfwd[p], hp.tfwd[p].data(), hp.tfwd[p].size() * sizeof(TileRef));
+            upload(s, db + hp.o_gbwd[p], hp.tbwd[p].data(), hp.tbwd[p].size() * sizeof(TileRef));
         }
     }
     float *H = reinterpret_cast<float *>(wb + hp.o_H), *GH = reinterpret_cast<float *>(wb + hp.o_GH);
@@ -1001,14 +1014,13 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         mark();
         const float *hin = H + (long long)p * hp.level_stride;
         float *hout = H + (long long)(p + 1) * hp.level_stride;
-        const TileGroup *gf = reinterpret_cast<const TileGroup *>(db + hp.o_gfwd[p]);
-        const int ngf = (int)hp.gfwd[p].size();
+        const TileRef *gf = reinterpret_cast<const TileRef *>(db + hp.o_gfwd[p]);
         if (fast)
-            hipLaunchKernelGGL(step_layer_fwd_kernel<LD_FAST>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gf, ngf, hin, hout);
+            hipLaunchKernelGGL(step_layer_fwd_kernel<LD_FAST>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gf, hin, hout);
         else if (vec)
-            hipLaunchKernelGGL(step_layer_fwd_kernel<LD_PRED>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gf, ngf, hin, hout);
+            hipLaunchKernelGGL(step_layer_fwd_kernel<LD_PRED>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gf, hin, hout);
         else
-            hipLaunchKernelGGL(step_layer_fwd_kernel<LD_SCALAR>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gf, ngf,
+            hipLaunchKernelGGL(step_layer_fwd_kernel<LD_SCALAR>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gf,
                                hin, hout);
         mark();
     }
@@ -1037,17 +1049,16 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         const float *gout = GH + (long long)(p + 1) * hp.level_stride;
         const float *hin = H + (long long)p * hp.level_stride;
         float *gin = GH + (long long)p * hp.level_stride;
-        const TileGroup *gb = reinterpret_cast<const TileGroup *>(db + hp.o_gbwd[p]);
-        const int ngb = (int)hp.gbwd[p].size();
+        const TileRef *gb = reinterpret_cast<const TileRef *>(db + hp.o_gbwd[p]);
         if (fast)
-            hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_FAST>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gb, ngb,
+            hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_FAST>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gb,
                                gout, hin, gin);
         else if (vec)
-            hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_PRED>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gb, ngb,
+            hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_PRED>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gb,
                                gout, hin, gin);
         else
             hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_SCALAR>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p,
-                               gb, ngb, gout, hin, gin);
+                               gb, gout, hin, gin);
         mark();
     }
     float *slabs = reinterpret_cast<float *>(wb + hp.o_slabs), *parts = reinterpret_cast<float *>(wb + hp.o_parts);
@@ -1056,11 +1067,11 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         ta.wsrc = reinterpret_cast<const WSource *>(db + hp.o_wsrc);
         ta.wblock = reinterpret_cast<const int *>(db + hp.o_wblock);
         ta.nwsrc = (int)hp.wsrc.size();
-        ta.wblocks = hp.wblock.back();
+        ta.wblocks = hp.wblocks_total;
         ta.vsrc = reinterpret_cast<const VSource *>(db + hp.o_vsrc);
         ta.vblock = reinterpret_cast<const int *>(db + hp.o_vblock);
         ta.nvsrc = (int)hp.vsrc.size();
-        ta.vblocks = hp.vblock.back();
+        ta.vblocks = hp.vblocks_total;
         ta.anchor_off = reinterpret_cast<const int *>(db + hp.o_anchor);
         ta.nb = nb;
         ta.node_map = nm;
