@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "grad_w_dma.h"
 #include "rgcn_template_body.h"
 
 #define STEP_MAX_LEVELS MPQE_STEP_MAX_LAYERS
@@ -456,8 +457,12 @@ __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, con
     const float *x = H + (long long)s.level * level_stride + b.row_off * D;
     const float *out = H + (long long)(s.level + 1) * level_stride + b.row_off * D;
     const float *g = GH + (long long)(s.level + 1) * level_stride + b.row_off * D;
-    tmpl_grad_w_tile<MODE>(x, g, out, D, D, s.relu, xs, xo, gs, go, q0, q1, (tile / tiles_j) * GT_BM,
-                          (tile % tiles_j) * GT_BN, slabs + (long long)(s.slab_start + c) * D * D, smem);
+    if (MODE == LD_FAST)      // whole K-steps, D % 64 == 0: deep LDS-DMA pipeline
+        grad_w_tile_dma(x, g, D, D, xs, xo, gs, go, q0, (int)((q1 - q0) / GT_BK), (tile / tiles_j) * GT_BM,
+                        (tile % tiles_j) * GT_BN, slabs + (long long)(s.slab_start + c) * D * D, smem);
+    else
+        tmpl_grad_w_tile<MODE>(x, g, out, D, D, s.relu, xs, xo, gs, go, q0, q1, (tile / tiles_j) * GT_BM,
+                               (tile % tiles_j) * GT_BN, slabs + (long long)(s.slab_start + c) * D * D, smem);
 }
 
 // partial vectors. kind 0: column sums of gpre over 64-row blocks of (batch, level).
@@ -558,7 +563,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restrict__ sd, TailArgs ta, TablePtrs tabs,
                                                         const float *__restrict__ H, const float *__restrict__ GH,
                                                         long long level_stride) {
-    __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[MODE == LD_FAST ? GWD_SMEM_FLOATS : GT_SMEM_FLOATS];
     const int bid = blockIdx.x;
     if (bid < ta.wblocks)
         grad_w_block<MODE>(sd, ta.wsrc, ta.nwsrc, ta.wblock, H, GH, level_stride, ta.slabs, bid, ta.wblocks, smem);

@@ -115,6 +115,16 @@ static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, 
     return c;
 }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+// LDS-DMA: every lane copies `size` bytes from its own global address to (wave-uniform base + lane*size)
+static inline void __builtin_amdgcn_global_load_lds(const void __attribute__((address_space(1))) * g,
+                                                    void __attribute__((address_space(3))) * l, unsigned size,
+                                                    int offset, unsigned) {
+    const char *src = (const char *)(const void *)g + offset;
+    char *dst = (char *)(void *)l + (threadIdx.x & 63) * size;
+    memcpy(dst, src, size);
+}
+static inline void __builtin_amdgcn_s_waitcnt(int) {}
+static inline void __builtin_amdgcn_s_barrier() { emu::block_barrier(); }
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4); return i; }
