@@ -560,18 +560,28 @@ struct TailArgs {
 };
 
 template <int MODE>
-__global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restrict__ sd, TailArgs ta, TablePtrs tabs,
+__global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restrict__ sd, TailArgs ta,
                                                         const float *__restrict__ H, const float *__restrict__ GH,
                                                         long long level_stride) {
+    // weight-gradient tiles only: the DMA ring takes 64 KB of LDS per workgroup, which would throttle the
+    // thousands of light partial-sum / anchor workgroups to 2 per CU if they shared this kernel
     __shared__ __attribute__((aligned(16))) float smem[MODE == LD_FAST ? GWD_SMEM_FLOATS : GT_SMEM_FLOATS];
+    grad_w_block<MODE>(sd, ta.wsrc, ta.nwsrc, ta.wblock, H, GH, level_stride, ta.slabs, (int)blockIdx.x, ta.wblocks,
+                       smem);
+}
+
+// bias / variable-row partial sums and anchor-table gradients: light, latency-bound roles in one launch
+__global__ __launch_bounds__(256) void step_tail_small_kernel(const StepDev *__restrict__ sd, TailArgs ta,
+                                                              TablePtrs tabs, const float *__restrict__ H,
+                                                              const float *__restrict__ GH,
+                                                              long long level_stride) {
+    __shared__ float smem[4 * 64];
     const int bid = blockIdx.x;
-    if (bid < ta.wblocks)
-        grad_w_block<MODE>(sd, ta.wsrc, ta.nwsrc, ta.wblock, H, GH, level_stride, ta.slabs, bid, ta.wblocks, smem);
-    else if (bid < ta.wblocks + ta.vblocks)
-        vec_partial_block(sd, ta.vsrc, ta.nvsrc, ta.vblock, H, GH, level_stride, ta.parts, bid - ta.wblocks, smem);
+    if (bid < ta.vblocks)
+        vec_partial_block(sd, ta.vsrc, ta.nvsrc, ta.vblock, H, GH, level_stride, ta.parts, bid, smem);
     else
         anchor_bwd_block(sd, tabs, ta.node_map, ta.map_len, ta.anchor_ids, GH, ta.anchor_off, ta.nb,
-                         bid - ta.wblocks - ta.vblocks);
+                         bid - ta.vblocks);
 }
 
 struct GradPtrs {
@@ -1084,18 +1094,20 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         ta.anchor_ids = ids;
         ta.slabs = slabs;
         ta.parts = parts;
-        dim3 tgrid((unsigned)(ta.wblocks + ta.vblocks + (hp.anchor_off[nb] + 3) / 4));
+        dim3 tgrid((unsigned)ta.wblocks);
         mark();
         if (fast && hp.whole_ksteps)
-            hipLaunchKernelGGL(step_tail_kernel<LD_FAST>, tgrid, dim3(256), 0, s, sd, ta, tabs, (const float *)H,
+            hipLaunchKernelGGL(step_tail_kernel<LD_FAST>, tgrid, dim3(256), 0, s, sd, ta, (const float *)H,
                                (const float *)GH, hp.level_stride);
         else if (vec)
-            hipLaunchKernelGGL(step_tail_kernel<LD_PRED>, tgrid, dim3(256), 0, s, sd, ta, tabs, (const float *)H,
+            hipLaunchKernelGGL(step_tail_kernel<LD_PRED>, tgrid, dim3(256), 0, s, sd, ta, (const float *)H,
                                (const float *)GH, hp.level_stride);
         else
-            hipLaunchKernelGGL(step_tail_kernel<LD_SCALAR>, tgrid, dim3(256), 0, s, sd, ta, tabs, (const float *)H,
+            hipLaunchKernelGGL(step_tail_kernel<LD_SCALAR>, tgrid, dim3(256), 0, s, sd, ta, (const float *)H,
                                (const float *)GH, hp.level_stride);
         mark();
+        hipLaunchKernelGGL(step_tail_small_kernel, dim3((unsigned)(ta.vblocks + (hp.anchor_off[nb] + 3) / 4)),
+                           dim3(256), 0, s, sd, ta, tabs, (const float *)H, (const float *)GH, hp.level_stride);
     }
     {
         const long long elems = (long long)D * D;
