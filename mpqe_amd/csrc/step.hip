@@ -400,19 +400,20 @@ __global__ __launch_bounds__(256) void step_score_kernel(
 
 // loss[0] = sum_b w_b * mean_b(terms), loss[1 + b] = mean_b(terms): one workgroup of 16 waves, wave b
 // sums batch b (lane-strided, then a butterfly), thread 0 adds the batches in order -> fixed order
-__global__ __launch_bounds__(1024) void step_loss_kernel(const StepDev *__restrict__ sd,
-                                                         const float *__restrict__ terms,
-                                                         float *__restrict__ loss) {
-    __shared__ float mean[MPQE_STEP_MAX_BATCHES];
+// nwaves waves of the calling workgroup take the batches round-robin (fixed order per batch, and the
+// total is added in batch order by thread 0): reproducible.
+__device__ __forceinline__ void loss_block(const StepDev *__restrict__ sd, const float *__restrict__ terms,
+                                           float *__restrict__ loss, float *mean /*LDS, MAX_BATCHES floats*/,
+                                           int nwaves) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (w < sd->nb) {
-        const BatchDev &b = sd->b[w];
+    for (int bi = w; bi < sd->nb; bi += nwaves) {
+        const BatchDev &b = sd->b[bi];
         float s = 0.f;
         for (int i = lane; i < b.B; i += 64) s += terms[b.g_off + i];
         s = wave_sum(s);
         if (lane == 0) {
-            mean[w] = s / (float)b.B;
-            loss[1 + w] = mean[w];
+            mean[bi] = s / (float)b.B;
+            loss[1 + bi] = mean[bi];
         }
     }
     __syncthreads();
@@ -421,6 +422,13 @@ __global__ __launch_bounds__(1024) void step_loss_kernel(const StepDev *__restri
         for (int bi = 0; bi < sd->nb; ++bi) total += sd->b[bi].weight * mean[bi];
         loss[0] = total;
     }
+}
+
+__global__ __launch_bounds__(1024) void step_loss_kernel(const StepDev *__restrict__ sd,
+                                                         const float *__restrict__ terms,
+                                                         float *__restrict__ loss) {
+    __shared__ float mean[MPQE_STEP_MAX_BATCHES];
+    loss_block(sd, terms, loss, mean, 16);
 }
 
 // ------------------------------------------------------------------------------------ weight gradients
@@ -593,10 +601,17 @@ struct GradPtrs {
 // lane, 16-byte loads); its 4 waves each add every 4th slab (two loads in flight), the four sums
 // are combined as (0+1)+(2+3): a fixed order. (A one-thread-per-16-elements variant that walked all
 // slabs serially measured 2.5x slower: the 40-slab root group became the long pole.)
-__global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restrict__ groups, int D, GradPtrs gp,
-                                                          const float *__restrict__ slabs,
-                                                          const float *__restrict__ partial, int vec) {
+__global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restrict__ groups, int ngroups, int D,
+                                                          GradPtrs gp, const float *__restrict__ slabs,
+                                                          const float *__restrict__ partial, int vec,
+                                                          const StepDev *__restrict__ sd,
+                                                          const float *__restrict__ terms,
+                                                          float *__restrict__ loss) {
     __shared__ f32x4 part[4][64];
+    if ((int)blockIdx.y == ngroups) {       // one extra workgroup row: the loss reduction rides along
+        if (blockIdx.x == 0) loss_block(sd, terms, loss, reinterpret_cast<float *>(part), 4);
+        return;
+    }
     const RGroup g = groups[blockIdx.y];
     const long long elems = g.kind <= 1 ? (long long)D * D : D;
     const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
@@ -1055,8 +1070,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     }
 
     // ---- backward (the score kernel's backward instance writes scores and hinge terms too)
-    LAUNCH_SCORE_D(true, GH);
-    hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss);
+    LAUNCH_SCORE_D(true, GH);       // (the loss itself is reduced by the last launch of the step)
 #undef LAUNCH_SCORE_D
 #undef LAUNCH_SCORE
     for (int p = hp.Lmax - 1; p >= 0; --p) {
@@ -1111,10 +1125,11 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     }
     {
         const long long elems = (long long)D * D;
-        dim3 grid((unsigned)((elems + 255) / 256), (unsigned)hp.groups.size());
+        dim3 grid((unsigned)((elems + 255) / 256), (unsigned)hp.groups.size() + 1);
         hipLaunchKernelGGL(step_reduce_kernel, grid, dim3(256), 0, s,
-                           reinterpret_cast<const RGroup *>(db + hp.o_groups), D, gp, (const float *)slabs,
-                           (const float *)parts, (int)(D % 4 == 0));
+                           reinterpret_cast<const RGroup *>(db + hp.o_groups), (int)hp.groups.size(), D, gp,
+                           (const float *)slabs, (const float *)parts, (int)(D % 4 == 0), sd, (const float *)terms,
+                           loss);
     }
     return mpqe_launch_status();
 }
