@@ -45,6 +45,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--path', default='auto', choices=['auto', 'modules', 'fused'])
+    ap.add_argument('--lanes', type=int, default=2, help='HIP streams one fused step is spread over')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='nccl = RCCL over xGMI (the real path); gloo only to exercise the multi-rank code on one GPU')
     return ap.parse_args()
@@ -104,17 +105,30 @@ def pack_for_fused(step, data):
 
 
 def time_fused_kernels(step, packed, data, model, reps=20):
-    """Per-launch durations of the three MFMA kernel families of the fused step, from HIP events
-    recorded by the library on the stream it launches on (events bracket single launches)."""
+    """Per-launch durations of the three MFMA kernel families of the fused step, from HIP events the
+    library records around single launches on the stream of each launch (order: mpqe_amd.h). With
+    stream lanes a level is one launch PER LANE that has it; the launches of different lanes overlap
+    in time, so a duration here is that launch's own span, as rocprofv3 reports it."""
+    import ctypes
     from mpqe_amd.data_utils import RGCNQueryDataset
     D = model.emb_dim
-    Ls = [RGCNQueryDataset.query_diameters[b['graph'].template.query_type] if model.adaptive
-          else model.num_layers for b in data.batches]
+    # library batch i = bench batch packed.order[i]; lane l owns library batches [lane_begin[l], lane_begin[l+1])
+    tmpl = [data.batches[j]['graph'].template for j in packed.order]
+    Ls = [RGCNQueryDataset.query_diameters[t.query_type] if model.adaptive else model.num_layers for t in tmpl]
+    lanes = [(packed.lane_begin[l], packed.lane_begin[l + 1]) for l in range(len(packed.lane_begin) - 1)]
     Lmax = max(Ls)
-    n_ev = 2 * (2 * Lmax + 1)
+
+    def flops(lo, hi, p):
+        return sum(2.0 * t.B * D * D * (t.E + t.N) for t, L in zip(tmpl[lo:hi], Ls[lo:hi]) if L > p)
+    plan = []                                            # (family, flops) per event pair, in library order
+    for p in range(Lmax):
+        plan += [('step_layer_fwd_kernel', flops(lo, hi, p)) for lo, hi in lanes if max(Ls[lo:hi]) > p]
+    for p in range(Lmax - 1, -1, -1):
+        plan += [('step_layer_bwd_x_kernel', flops(lo, hi, p)) for lo, hi in lanes if max(Ls[lo:hi]) > p]
+    plan.append(('step_tail_kernel', sum(2.0 * L * t.B * D * D * (t.E + t.N) for t, L in zip(tmpl, Ls))))
+    n_ev = 2 * len(plan)
     fam = {'step_layer_fwd_kernel': [0.0, 0, 0.0], 'step_layer_bwd_x_kernel': [0.0, 0, 0.0],
            'step_tail_kernel': [0.0, 0, 0.0]}          # ms, launches, flops
-    import ctypes
     for _ in range(reps):
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
         for e in evs:
@@ -122,23 +136,11 @@ def time_fused_kernels(step, packed, data, model, reps=20):
         arr = (ctypes.c_void_p * n_ev)(*[e.cuda_event for e in evs])
         step.run(packed, events=arr)
         torch.cuda.synchronize()
-        k = 0
-        for p in range(Lmax):
-            fl = sum(2.0 * b['graph'].template.B * D * D * (b['graph'].template.E + b['graph'].template.N)
-                     for b, L in zip(data.batches, Ls) if L > p)
-            f = fam['step_layer_fwd_kernel']
-            f[0] += evs[k].elapsed_time(evs[k + 1]); f[1] += 1; f[2] += fl
-            k += 2
-        for p in range(Lmax - 1, -1, -1):
-            fl = sum(2.0 * b['graph'].template.B * D * D * (b['graph'].template.E + b['graph'].template.N)
-                     for b, L in zip(data.batches, Ls) if L > p)
-            f = fam['step_layer_bwd_x_kernel']
-            f[0] += evs[k].elapsed_time(evs[k + 1]); f[1] += 1; f[2] += fl
-            k += 2
-        fl = sum(2.0 * L * b['graph'].template.B * D * D * (b['graph'].template.E + b['graph'].template.N)
-                 for b, L in zip(data.batches, Ls))
-        f = fam['step_tail_kernel']
-        f[0] += evs[k].elapsed_time(evs[k + 1]); f[1] += 1; f[2] += fl
+        for k, (name, fl) in enumerate(plan):
+            f = fam[name]
+            f[0] += evs[2 * k].elapsed_time(evs[2 * k + 1])
+            f[1] += 1
+            f[2] += fl
     out = []
     for name, (ms, n, fl) in fam.items():
         out.append(dict(kernel=name, launches_per_step=n // reps, avg_launch_us=ms / n * 1e3,
@@ -337,7 +339,7 @@ def main():
     reducer = fstep = packed = None
     if use_fused:
         from mpqe_amd.fused import FusedTrainStep
-        fstep = FusedTrainStep(model)
+        fstep = FusedTrainStep(model, lanes=args.lanes)
         packed = [pack_for_fused(fstep, d) for d in pool]
     elif world > 1:
         from mpqe_amd.parallel import GradReducer
@@ -391,7 +393,7 @@ def main():
                    'global_query_graphs_per_step': graphs_per_step,
                    'parallelism': 'dp%d (graphs sharded by rank, RCCL all-reduce of gradients)' % world
                                   if world > 1 else 'single GPU',
-                   'host_path': 'fused step: one C-ABI call, ~20 launches per step' if use_fused
+                   'host_path': 'fused step: one C-ABI call per step, %d stream lane(s)' % args.lanes if use_fused
                                 else 'drop-in modules (one autograd graph per step)'},
     }
     if rank == 0:

@@ -244,6 +244,21 @@ typedef struct {
     float *bias[MPQE_STEP_MAX_LAYERS];
 } mpqe_step_grads_t;
 
+/* Stream lanes (optional). At the reference's batch size every launch of the step is short enough that
+ * its fixed cost (~8 us: dispatch, descriptor + first-tile latency, drain) dominates, and one step is a
+ * chain of ~13 dependent launches. With lanes, lane l runs the whole chain (assemble -> message-passing
+ * levels -> score -> levels back) of batches [batch_begin[l], batch_begin[l+1]) on its own stream; lane 0
+ * is `stream`. The lanes fork after the descriptor upload and join before the weight-gradient launch.
+ * The caller owns the streams and events (no allocation, no synchronisation in the library).          */
+#define MPQE_STEP_MAX_LANES 4
+typedef struct {
+    int32_t num_lanes;                              /* 1 .. MPQE_STEP_MAX_LANES                      */
+    int32_t batch_begin[MPQE_STEP_MAX_LANES + 1];   /* ascending, [0] = 0, [num_lanes] = num_batches */
+    void *aux_stream[MPQE_STEP_MAX_LANES];          /* hipStream_t of lanes 1.. ([0] unused)         */
+    void *fork_event;                               /* hipEvent_t                                    */
+    void *join_event[MPQE_STEP_MAX_LANES];          /* hipEvent_t of lanes 1.. ([0] unused)          */
+} mpqe_step_lanes_t;
+
 size_t mpqe_step_workspace_bytes(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,
                                  int num_batches);
 /* The kernels read a small descriptor table (templates, relations, offsets, reduction groups). It
@@ -256,16 +271,19 @@ size_t mpqe_step_desc_bytes(const mpqe_step_params_t *params_host, const mpqe_st
 /* anchor_ids: per batch b a block of [A_b, B_b] ids (slot-major), blocks concatenated in batch
  * order; targets / negs: [sum_b B_b]. backward = 0 stops after the loss (grads may be NULL).
  * scores_pos / scores_neg: [sum_b B_b] or NULL. workspace must be 256-byte aligned.
- * events (may be NULL): hipEvent_t handles recorded on `stream` in pairs around single launches, in
- * this order: layer forward level 0..Lmax-1, backward-x level Lmax-1..0, weight gradient -- i.e.
- * 2*(2*Lmax + 1) events; fewer are filled as far as they go. For roofline accounting only.     */
+ * lanes (may be NULL = one lane): see mpqe_step_lanes_t.
+ * events (may be NULL): hipEvent_t handles recorded in pairs around single launches on the stream of the
+ * launch, in this order: for level 0..Lmax-1, for each lane that has the level: layer forward; for level
+ * Lmax-1..0, for each such lane: backward-x; then the weight-gradient launch. Fewer are filled as far as
+ * they go. For roofline accounting only.                                                          */
 int mpqe_step_forward_backward(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,
                                int num_batches, const int64_t *anchor_ids, const int64_t *targets,
                                const int64_t *negs, float margin, const mpqe_step_grads_t *grads_host,
                                int backward, float *loss /*[1 + num_batches]*/, float *scores_pos,
                                float *scores_neg, void *desc, size_t desc_bytes, int upload_desc,
                                void *workspace, size_t workspace_bytes, int32_t *err,
-                               void *const *events, int num_events, void *stream);
+                               const mpqe_step_lanes_t *lanes, void *const *events, int num_events,
+                               void *stream);
 
 #ifdef __cplusplus
 }

@@ -48,6 +48,15 @@ class StepGrads(ctypes.Structure):
                 ('bias', c_void_p * STEP_MAX_LAYERS)]
 
 
+STEP_MAX_LANES = 4
+
+
+class StepLanes(ctypes.Structure):
+    _fields_ = [('num_lanes', ctypes.c_int32), ('batch_begin', ctypes.c_int32 * (STEP_MAX_LANES + 1)),
+                ('aux_stream', c_void_p * STEP_MAX_LANES), ('fork_event', c_void_p),
+                ('join_event', c_void_p * STEP_MAX_LANES)]
+
+
 # name: (restype, [argtypes])
 PROTOTYPES = {
     'mpqe_status_string': (c_char_p, [I]),
@@ -79,7 +88,8 @@ PROTOTYPES = {
     'mpqe_step_workspace_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I]),
     'mpqe_step_desc_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I]),
     'mpqe_step_forward_backward': (I, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, P, P, P, F,
-                                       ctypes.POINTER(StepGrads), I, P, P, P, P, Z, I, P, Z, P, P, I, P]),
+                                       ctypes.POINTER(StepGrads), I, P, P, P, P, Z, I, P, Z, P, ctypes.POINTER(StepLanes),
+                                       P, I, P]),
 }
 
 QUERY_TYPE_IDS = {'1-chain': 0, '2-chain': 1, '3-chain': 2, '2-inter': 3, '3-inter': 4,

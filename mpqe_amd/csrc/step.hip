@@ -155,19 +155,21 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(
     const StepDev *__restrict__ sd, TablePtrs tabs, const long long *__restrict__ node_map, long long map_len,
     const float *__restrict__ mode_emb, long long num_modes, const long long *__restrict__ anchor_ids,
     const long long *__restrict__ targets, const long long *__restrict__ negs, float *__restrict__ H0,
-    float *__restrict__ tpos, float *__restrict__ tneg, int32_t *err, int vec) {
+    float *__restrict__ tpos, float *__restrict__ tneg, int32_t *err, int vec, long long row0, long long R,
+    long long g0, long long G) {
+    // this launch covers node rows [row0, row0 + R) and graphs [g0, g0 + G) (one stream lane of the step)
     const int D = sd->D;
     const int lpr = lanes_per_row(D, vec), rpw = 64 / lpr;
     const int lane = threadIdx.x & 63, sub = lane & (lpr - 1);
-    const long long w = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + lane / lpr;
-    const long long R = sd->rows_total, G = sd->graphs_total;
+    const long long wl = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + lane / lpr;
     // no early return: every lane takes part in the sub-wave shuffles; out-of-range groups idle
-    const bool live = w < R + 2 * G;
+    const bool live = wl < R + 2 * G;
+    const long long w = row0 + wl;        // global node row when wl < R
     int32_t *e = sub == 0 ? err : nullptr;
     const float *src = nullptr;
     float *dst = nullptr;
     bool normalise = true;
-    if (live && w < R) {
+    if (live && wl < R) {
         int bi = 0;
         for (int i = 1; i < sd->nb; ++i)
             if (sd->b[i].row_off <= w) bi = i;
@@ -188,8 +190,8 @@ __global__ __launch_bounds__(256) void step_assemble_kernel(
             else src = mode_emb + m * D;
         }
     } else if (live) {
-        const long long gi = (w - R) % G;
-        const bool is_neg = (w - R) >= G;
+        const long long gi = g0 + (wl - R) % G;
+        const bool is_neg = (wl - R) >= G;
         int bi = 0;
         for (int i = 1; i < sd->nb; ++i)
             if (sd->b[i].g_off <= gi) bi = i;
@@ -293,10 +295,11 @@ __global__ __launch_bounds__(256) void step_score_kernel(
     const float *__restrict__ tpos, const float *__restrict__ tneg, float margin, float eps,
     float *__restrict__ s_pos, float *__restrict__ s_neg, float *__restrict__ terms,
     float *__restrict__ GH, TablePtrs tabs, const long long *__restrict__ node_map, long long map_len,
-    const long long *__restrict__ targets, const long long *__restrict__ negs) {
-    const long long gi = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long *__restrict__ targets, const long long *__restrict__ negs, long long g0, long long ng) {
+    const long long gl = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (gi >= sd->graphs_total) return;
+    if (gl >= ng) return;
+    const long long gi = g0 + gl;          // graphs [g0, g0 + ng): one stream lane of the step
     int bi = 0;
     for (int i = 1; i < sd->nb; ++i)
         if (sd->b[i].g_off <= gi) bi = i;
@@ -654,11 +657,11 @@ namespace {
 struct HostPlan {
     StepDev sd;
     int Lmax;
-    int tiles[STEP_MAX_LEVELS];
-    std::vector<TileGroup> gfwd[STEP_MAX_LEVELS], gbwd[STEP_MAX_LEVELS];
-    std::vector<TileRef> tfwd[STEP_MAX_LEVELS], tbwd[STEP_MAX_LEVELS];
+    // per (lane, level): tile tables of the forward / backward-x launches
+    int nlanes, lane_begin[MPQE_STEP_MAX_LANES + 1], lane_Lmax[MPQE_STEP_MAX_LANES];
+    std::vector<TileRef> tfwd[MPQE_STEP_MAX_LANES][STEP_MAX_LEVELS], tbwd[MPQE_STEP_MAX_LANES][STEP_MAX_LEVELS];
+    size_t o_tf[MPQE_STEP_MAX_LANES][STEP_MAX_LEVELS], o_tb[MPQE_STEP_MAX_LANES][STEP_MAX_LEVELS];
     std::vector<int> wref;            // per weight-gradient workgroup: source index
-    size_t o_gfwd[STEP_MAX_LEVELS], o_gbwd[STEP_MAX_LEVELS];
     std::vector<WSource> wsrc;
     std::vector<int> wblock;          // per weight-gradient workgroup: its source index
     int wblocks_total, vblocks_total;
@@ -689,8 +692,23 @@ void pick_chunks(long long count, int max_chunks, int *nch, int *ch) {
     *ch = (int)c;
 }
 
-int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, HostPlan *hp) {
+int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, const mpqe_step_lanes_t *lanes,
+              HostPlan *hp) {
     if (!P || !B || nb <= 0 || nb > MPQE_STEP_MAX_BATCHES) return MPQE_ERR_INVALID_ARG;
+    hp->nlanes = 1;
+    hp->lane_begin[0] = 0;
+    hp->lane_begin[1] = nb;
+    if (lanes && lanes->num_lanes > 1) {
+        if (lanes->num_lanes > MPQE_STEP_MAX_LANES) return MPQE_ERR_INVALID_ARG;
+        hp->nlanes = lanes->num_lanes;
+        for (int l = 0; l <= hp->nlanes; ++l) hp->lane_begin[l] = lanes->batch_begin[l];
+        if (hp->lane_begin[0] != 0 || hp->lane_begin[hp->nlanes] != nb) return MPQE_ERR_INVALID_ARG;
+        for (int l = 0; l < hp->nlanes; ++l)
+            if (hp->lane_begin[l + 1] <= hp->lane_begin[l]) return MPQE_ERR_INVALID_ARG;     // no empty lane
+        if (!lanes->fork_event) return MPQE_ERR_INVALID_ARG;
+        for (int l = 1; l < hp->nlanes; ++l)
+            if (!lanes->aux_stream[l] || !lanes->join_event[l]) return MPQE_ERR_INVALID_ARG;
+    }
     if (P->dim <= 0 || P->dim > 64 * STEP_MAX_COLS_PER_LANE) return MPQE_ERR_UNSUPPORTED;
     if (P->num_layers <= 0 || P->num_layers > MPQE_STEP_MAX_LAYERS) return MPQE_ERR_UNSUPPORTED;
     if (P->num_modes <= 0 || P->num_modes > MPQE_STEP_MAX_MODES) return MPQE_ERR_UNSUPPORTED;
@@ -748,33 +766,31 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, H
     sd.graphs_total = graphs;
     const int ct = (D + GT_BN - 1) / GT_BN;
     const int spb = (D + GT_BK - 1) / GT_BK;
-    for (int p = 0; p < STEP_MAX_LEVELS; ++p) {
-        for (int dir = 0; dir < 2; ++dir) {
-            std::vector<TileGroup> &g = dir ? hp->gbwd[p] : hp->gfwd[p];
-            g.clear();
-            for (int i = 0; i < nb; ++i) {
-                if (sd.b[i].L <= p) continue;
-                const TmplArgs &tp = sd.b[i].tp;
-                for (int n = 0; n < tp.N; ++n) {
-                    int deg = 0;      // forward: edges INTO n; backward-x: edges OUT of n
-                    for (int e = 0; e < tp.E; ++e) deg += (dir ? tp.src[e] : tp.dst[e]) == n;
-                    g.push_back(TileGroup{i, n, 0, (deg + 1) * spb});
+    for (int l = 0; l < hp->nlanes; ++l) {
+        hp->lane_Lmax[l] = 0;
+        for (int i = hp->lane_begin[l]; i < hp->lane_begin[l + 1]; ++i)
+            if (sd.b[i].L > hp->lane_Lmax[l]) hp->lane_Lmax[l] = sd.b[i].L;
+        for (int p = 0; p < STEP_MAX_LEVELS; ++p)
+            for (int dir = 0; dir < 2; ++dir) {
+                std::vector<TileGroup> g;
+                for (int i = hp->lane_begin[l]; i < hp->lane_begin[l + 1]; ++i) {
+                    if (sd.b[i].L <= p) continue;
+                    const TmplArgs &tp = sd.b[i].tp;
+                    for (int n = 0; n < tp.N; ++n) {
+                        int deg = 0;      // forward: edges INTO n; backward-x: edges OUT of n
+                        for (int e = 0; e < tp.E; ++e) deg += (dir ? tp.src[e] : tp.dst[e]) == n;
+                        g.push_back(TileGroup{i, n, 0, (deg + 1) * spb});
+                    }
+                }
+                std::stable_sort(g.begin(), g.end(),
+                                 [](const TileGroup &a, const TileGroup &b) { return a.steps > b.steps; });
+                std::vector<TileRef> &tr = dir ? hp->tbwd[l][p] : hp->tfwd[l][p];
+                tr.clear();
+                for (size_t k = 0; k < g.size(); ++k) {
+                    const int cnt = ((sd.b[g[k].batch].B + GT_BM - 1) / GT_BM) * ct;
+                    for (int r = 0; r < cnt; ++r) tr.push_back(TileRef{(short)g[k].batch, (short)g[k].node, r});
                 }
             }
-            std::stable_sort(g.begin(), g.end(), [](const TileGroup &a, const TileGroup &b) { return a.steps > b.steps; });
-            int t = 0;
-            for (size_t k = 0; k < g.size(); ++k) {
-                g[k].tile_off = t;
-                t += ((sd.b[g[k].batch].B + GT_BM - 1) / GT_BM) * ct;
-            }
-            std::vector<TileRef> &tr = dir ? hp->tbwd[p] : hp->tfwd[p];
-            tr.clear();
-            for (size_t k = 0; k < g.size(); ++k) {
-                const int cnt = ((sd.b[g[k].batch].B + GT_BM - 1) / GT_BM) * ct;
-                for (int r = 0; r < cnt; ++r) tr.push_back(TileRef{(short)g[k].batch, (short)g[k].node, r});
-            }
-            hp->tiles[p] = t;
-        }
     }
 
     // unique layer buffers (shared layers alias one parameter set -> one gradient buffer)
@@ -906,10 +922,11 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, H
     hp->o_vblock = take(hp->vblock.size() * sizeof(int));
     hp->o_groups = take(hp->groups.size() * sizeof(RGroup));
     hp->o_anchor = take(hp->anchor_off.size() * sizeof(int));
-    for (int p = 0; p < hp->Lmax; ++p) {
-        hp->o_gfwd[p] = take(hp->tfwd[p].size() * sizeof(TileRef));
-        hp->o_gbwd[p] = take(hp->tbwd[p].size() * sizeof(TileRef));
-    }
+    for (int l = 0; l < hp->nlanes; ++l)
+        for (int p = 0; p < hp->lane_Lmax[l]; ++p) {
+            hp->o_tf[l][p] = take(hp->tfwd[l][p].size() * sizeof(TileRef));
+            hp->o_tb[l][p] = take(hp->tbwd[l][p].size() * sizeof(TileRef));
+        }
     hp->desc_total = off;
     off = 0;
     hp->o_H = take((size_t)(hp->Lmax + 1) * rows * D * 4);
@@ -939,13 +956,14 @@ void upload(hipStream_t s, char *dst, const void *src, size_t n) {
 
 extern "C" size_t mpqe_step_workspace_bytes(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb) {
     HostPlan hp;
-    if (make_plan(P, B, nb, &hp) != MPQE_OK) return 0;
+    if (make_plan(P, B, nb, nullptr, &hp) != MPQE_OK) return 0;
     return hp.total;
 }
 extern "C" size_t mpqe_step_desc_bytes(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb) {
+    // lanes only split the tile tables between streams; their total size does not depend on the split
     HostPlan hp;
-    if (make_plan(P, B, nb, &hp) != MPQE_OK) return 0;
-    return hp.desc_total;
+    if (make_plan(P, B, nb, nullptr, &hp) != MPQE_OK) return 0;
+    return hp.desc_total + 256 * 2 * MPQE_STEP_MAX_LANES * STEP_MAX_LEVELS;
 }
 
 extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb,
@@ -953,10 +971,10 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                                           float margin, const mpqe_step_grads_t *G, int backward,
                                           float *loss, float *scores_pos, float *scores_neg, void *desc,
                                           size_t desc_bytes, int upload_desc, void *workspace,
-                                          size_t workspace_bytes, int32_t *err, void *const *events,
-                                          int num_events, void *stream) {
+                                          size_t workspace_bytes, int32_t *err, const mpqe_step_lanes_t *lanes,
+                                          void *const *events, int num_events, void *stream) {
     HostPlan hp;
-    int st = make_plan(P, B, nb, &hp);
+    int st = make_plan(P, B, nb, lanes, &hp);
     if (st) return st;
     if (!anchor_ids || !targets || !negs || !loss || !workspace || !desc) return MPQE_ERR_INVALID_ARG;
     if (desc_bytes < hp.desc_total) return MPQE_ERR_WORKSPACE;
@@ -969,11 +987,15 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     char *wb = reinterpret_cast<char *>(workspace);
     char *db = reinterpret_cast<char *>(desc);
     const int D = P->dim;
-    const long long rows = hp.sd.rows_total, graphs = hp.sd.graphs_total;
-    // optional timing: event pair k brackets one launch (see mpqe_amd.h for the order)
+    const int NL = hp.nlanes;
+    hipStream_t ls[MPQE_STEP_MAX_LANES];
+    ls[0] = s;
+    for (int l = 1; l < NL; ++l) ls[l] = as_stream(lanes->aux_stream[l]);
+    // optional timing: event pair k brackets one launch, recorded on the stream of that launch
+    // (see mpqe_amd.h for the order)
     int ev = 0;
-    auto mark = [&]() {
-        if (events && ev < num_events) hipEventRecord(reinterpret_cast<hipEvent_t>(events[ev]), s);
+    auto mark = [&](hipStream_t on) {
+        if (events && ev < num_events) hipEventRecord(reinterpret_cast<hipEvent_t>(events[ev]), on);
         ++ev;
     };
 
@@ -1017,10 +1039,11 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         upload(s, db + hp.o_vblock, hp.vblock.data(), hp.vblock.size() * sizeof(int));
         upload(s, db + hp.o_groups, hp.groups.data(), hp.groups.size() * sizeof(RGroup));
         upload(s, db + hp.o_anchor, hp.anchor_off.data(), hp.anchor_off.size() * sizeof(int));
-        for (int p = 0; p < hp.Lmax; ++p) {
-            upload(s, db + hp.o_gfwd[p], hp.tfwd[p].data(), hp.tfwd[p].size() * sizeof(TileRef));
-            upload(s, db + hp.o_gbwd[p], hp.tbwd[p].data(), hp.tbwd[p].size() * sizeof(TileRef));
-        }
+        for (int l = 0; l < NL; ++l)
+            for (int p = 0; p < hp.lane_Lmax[l]; ++p) {
+                upload(s, db + hp.o_tf[l][p], hp.tfwd[l][p].data(), hp.tfwd[l][p].size() * sizeof(TileRef));
+                upload(s, db + hp.o_tb[l][p], hp.tbwd[l][p].data(), hp.tbwd[l][p].size() * sizeof(TileRef));
+            }
     }
     float *H = reinterpret_cast<float *>(wb + hp.o_H), *GH = reinterpret_cast<float *>(wb + hp.o_GH);
     float *tpos = reinterpret_cast<float *>(wb + hp.o_tpos), *tneg = reinterpret_cast<float *>(wb + hp.o_tneg);
@@ -1031,65 +1054,96 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     const long long *tg = reinterpret_cast<const long long *>(targets), *ng = reinterpret_cast<const long long *>(negs);
     const long long *nm = reinterpret_cast<const long long *>(P->node_map);
 
+    // Stream lanes: lane l runs the whole dependent chain (assemble -> levels -> score -> levels back)
+    // of ITS batches on its own stream, so the ~8 us a short launch costs regardless of its size
+    // overlaps with the other lanes' work; the lanes meet again before the weight gradients.
+    long long row0[MPQE_STEP_MAX_LANES + 1], gr0[MPQE_STEP_MAX_LANES + 1];
+    for (int l = 0; l <= NL; ++l) {
+        const int b = hp.lane_begin[l];
+        row0[l] = b < nb ? hp.sd.b[b].row_off : hp.sd.rows_total;
+        gr0[l] = b < nb ? hp.sd.b[b].g_off : hp.sd.graphs_total;
+    }
+    if (NL > 1) {
+        hipEventRecord(reinterpret_cast<hipEvent_t>(lanes->fork_event), s);
+        for (int l = 1; l < NL; ++l) hipStreamWaitEvent(ls[l], reinterpret_cast<hipEvent_t>(lanes->fork_event), 0);
+    }
+
     // ---- forward
-    {
-        const long long waves = rows + 2 * graphs;
-        const int lpr_h = [&] { if (!vec_tab) return 64; int l = 1; while (l < 64 && l * 4 < D) l <<= 1; return l; }();
+    for (int l = 0; l < NL; ++l) {
+        const long long nr = row0[l + 1] - row0[l], ngr = gr0[l + 1] - gr0[l];
+        const long long waves = nr + 2 * ngr;
+        const int lpr_h = [&] { if (!vec_tab) return 64; int q = 1; while (q < 64 && q * 4 < D) q <<= 1; return q; }();
         const long long per_block = 4 * (64 / lpr_h);
-        hipLaunchKernelGGL(step_assemble_kernel, dim3((unsigned)((waves + per_block - 1) / per_block)), dim3(256), 0, s, sd, tabs, nm,
-                           (long long)P->node_map_len, P->mode_emb, (long long)P->num_modes, ids, tg, ng, H, tpos,
-                           tneg, err, vec_tab);
+        hipLaunchKernelGGL(step_assemble_kernel, dim3((unsigned)((waves + per_block - 1) / per_block)), dim3(256), 0,
+                           ls[l], sd, tabs, nm, (long long)P->node_map_len, P->mode_emb, (long long)P->num_modes, ids,
+                           tg, ng, H, tpos, tneg, err, vec_tab, row0[l], nr, gr0[l], ngr);
     }
-    for (int p = 0; p < hp.Lmax; ++p) {
-        mark();
-        const float *hin = H + (long long)p * hp.level_stride;
-        float *hout = H + (long long)(p + 1) * hp.level_stride;
-        const TileRef *gf = reinterpret_cast<const TileRef *>(db + hp.o_gfwd[p]);
-        if (fast)
-            hipLaunchKernelGGL(step_layer_fwd_kernel<LD_FAST>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gf, hin, hout);
-        else if (vec)
-            hipLaunchKernelGGL(step_layer_fwd_kernel<LD_PRED>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gf, hin, hout);
-        else
-            hipLaunchKernelGGL(step_layer_fwd_kernel<LD_SCALAR>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gf,
-                               hin, hout);
-        mark();
-    }
-#define LAUNCH_SCORE(BWD, NJ, GHP)                                                                                 \
-    hipLaunchKernelGGL((step_score_kernel<BWD, NJ>), dim3((unsigned)((graphs + 3) / 4)), dim3(256), 0, s, sd,    \
-                       (const float *)H, hp.level_stride, (const float *)tpos, (const float *)tneg, margin, 1e-8f, \
-                       spos, sneg, terms, GHP, tabs, nm, (long long)P->node_map_len, tg, ng)
-#define LAUNCH_SCORE_D(BWD, GHP)                  \
-    if (D <= 64) LAUNCH_SCORE(BWD, 1, GHP);       \
-    else if (D <= 128) LAUNCH_SCORE(BWD, 2, GHP); \
-    else if (D <= 256) LAUNCH_SCORE(BWD, 4, GHP); \
-    else LAUNCH_SCORE(BWD, 8, GHP)
+    for (int p = 0; p < hp.Lmax; ++p)
+        for (int l = 0; l < NL; ++l) {
+            if (p >= hp.lane_Lmax[l]) continue;
+            const float *hin = H + (long long)p * hp.level_stride;
+            float *hout = H + (long long)(p + 1) * hp.level_stride;
+            const TileRef *gf = reinterpret_cast<const TileRef *>(db + hp.o_tf[l][p]);
+            dim3 grid((unsigned)hp.tfwd[l][p].size());
+            mark(ls[l]);
+            if (fast)
+                hipLaunchKernelGGL(step_layer_fwd_kernel<LD_FAST>, grid, dim3(256), 0, ls[l], sd, lp, p, gf, hin, hout);
+            else if (vec)
+                hipLaunchKernelGGL(step_layer_fwd_kernel<LD_PRED>, grid, dim3(256), 0, ls[l], sd, lp, p, gf, hin, hout);
+            else
+                hipLaunchKernelGGL(step_layer_fwd_kernel<LD_SCALAR>, grid, dim3(256), 0, ls[l], sd, lp, p, gf, hin,
+                                   hout);
+            mark(ls[l]);
+        }
+#define LAUNCH_SCORE(BWD, NJ, GHP, L)                                                                               \
+    hipLaunchKernelGGL((step_score_kernel<BWD, NJ>), dim3((unsigned)((gr0[L + 1] - gr0[L] + 3) / 4)), dim3(256), 0, \
+                       ls[L], sd, (const float *)H, hp.level_stride, (const float *)tpos, (const float *)tneg,     \
+                       margin, 1e-8f, spos, sneg, terms, GHP, tabs, nm, (long long)P->node_map_len, tg, ng, gr0[L], \
+                       gr0[L + 1] - gr0[L])
+#define LAUNCH_SCORE_D(BWD, GHP, L)                  \
+    if (D <= 64) LAUNCH_SCORE(BWD, 1, GHP, L);       \
+    else if (D <= 128) LAUNCH_SCORE(BWD, 2, GHP, L); \
+    else if (D <= 256) LAUNCH_SCORE(BWD, 4, GHP, L); \
+    else LAUNCH_SCORE(BWD, 8, GHP, L)
+    auto join = [&]() {
+        for (int l = 1; l < NL; ++l) {
+            hipEventRecord(reinterpret_cast<hipEvent_t>(lanes->join_event[l]), ls[l]);
+            hipStreamWaitEvent(s, reinterpret_cast<hipEvent_t>(lanes->join_event[l]), 0);
+        }
+    };
     if (!backward) {
-        LAUNCH_SCORE_D(false, (float *)nullptr);
+        for (int l = 0; l < NL; ++l) { LAUNCH_SCORE_D(false, (float *)nullptr, l); }
+        join();
         hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss);
         return mpqe_launch_status();
     }
 
-    // ---- backward (the score kernel's backward instance writes scores and hinge terms too)
-    LAUNCH_SCORE_D(true, GH);       // (the loss itself is reduced by the last launch of the step)
+    // ---- backward (the score kernel's backward instance writes scores and hinge terms too; the loss
+    // itself is reduced by the last launch of the step)
+    for (int l = 0; l < NL; ++l) { LAUNCH_SCORE_D(true, GH, l); }
 #undef LAUNCH_SCORE_D
 #undef LAUNCH_SCORE
-    for (int p = hp.Lmax - 1; p >= 0; --p) {
-        mark();
-        const float *gout = GH + (long long)(p + 1) * hp.level_stride;
-        const float *hin = H + (long long)p * hp.level_stride;
-        float *gin = GH + (long long)p * hp.level_stride;
-        const TileRef *gb = reinterpret_cast<const TileRef *>(db + hp.o_gbwd[p]);
-        if (fast)
-            hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_FAST>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gb,
-                               gout, hin, gin);
-        else if (vec)
-            hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_PRED>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p, gb,
-                               gout, hin, gin);
-        else
-            hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_SCALAR>, dim3(hp.tiles[p]), dim3(256), 0, s, sd, lp, p,
-                               gb, gout, hin, gin);
-        mark();
-    }
+    for (int p = hp.Lmax - 1; p >= 0; --p)
+        for (int l = 0; l < NL; ++l) {
+            if (p >= hp.lane_Lmax[l]) continue;
+            const float *gout = GH + (long long)(p + 1) * hp.level_stride;
+            const float *hin = H + (long long)p * hp.level_stride;
+            float *gin = GH + (long long)p * hp.level_stride;
+            const TileRef *gb = reinterpret_cast<const TileRef *>(db + hp.o_tb[l][p]);
+            dim3 grid((unsigned)hp.tbwd[l][p].size());
+            mark(ls[l]);
+            if (fast)
+                hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_FAST>, grid, dim3(256), 0, ls[l], sd, lp, p, gb, gout,
+                                   hin, gin);
+            else if (vec)
+                hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_PRED>, grid, dim3(256), 0, ls[l], sd, lp, p, gb, gout,
+                                   hin, gin);
+            else
+                hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_SCALAR>, grid, dim3(256), 0, ls[l], sd, lp, p, gb,
+                                   gout, hin, gin);
+            mark(ls[l]);
+        }
+    join();
     float *slabs = reinterpret_cast<float *>(wb + hp.o_slabs), *parts = reinterpret_cast<float *>(wb + hp.o_parts);
     {
         TailArgs ta;
@@ -1109,7 +1163,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         ta.slabs = slabs;
         ta.parts = parts;
         dim3 tgrid((unsigned)ta.wblocks);
-        mark();
+        mark(s);
         if (fast && hp.whole_ksteps)
             hipLaunchKernelGGL(step_tail_kernel<LD_FAST>, tgrid, dim3(256), 0, s, sd, ta, (const float *)H,
                                (const float *)GH, hp.level_stride);
@@ -1119,7 +1173,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         else
             hipLaunchKernelGGL(step_tail_kernel<LD_SCALAR>, tgrid, dim3(256), 0, s, sd, ta, (const float *)H,
                                (const float *)GH, hp.level_stride);
-        mark();
+        mark(s);
         hipLaunchKernelGGL(step_tail_small_kernel, dim3((unsigned)(ta.vblocks + (hp.anchor_off[nb] + 3) / 4)),
                            dim3(256), 0, s, sd, ta, tabs, (const float *)H, (const float *)GH, hp.level_stride);
     }

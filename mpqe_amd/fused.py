@@ -22,11 +22,24 @@ from .data_utils import RGCNQueryDataset
 
 class PackedStep(object):
     __slots__ = ('batches', 'nb', 'anchor_ids', 'targets', 'negs', 'num_graphs', 'ws_bytes', 'sizes',
-                 'desc', 'desc_bytes', 'desc_ptr', 'desc_resident')
+                 'desc', 'desc_bytes', 'desc_ptr', 'desc_resident', 'lanes', 'order', 'lane_begin')
+
+
+def _batch_work(query_type, passes):
+    """Relative MFMA work of one batch per graph: passes * (edges + nodes) K-blocks."""
+    e_n = {'1-chain': 3, '2-chain': 5, '3-chain': 7, '2-inter': 5, '3-inter': 7, '3-inter_chain': 7,
+           '3-chain_inter': 7}[query_type]
+    return passes * e_n
 
 
 class FusedTrainStep(object):
-    def __init__(self, model, margin=1.0):
+    """lanes: number of HIP streams a step is spread over (1 = everything on the current stream).
+    A step is a chain of ~13 dependent, very short launches; with lanes > 1 the batches are split
+    into groups whose chains run concurrently on their own streams and meet before the weight
+    gradients (include/mpqe_amd.h, mpqe_step_lanes_t). The split balances MFMA work and keeps
+    batches of equal depth together (longest chains first)."""
+
+    def __init__(self, model, margin=1.0, lanes=1):
         enc = model.enc
         if not hasattr(enc, 'table') or getattr(enc, 'node_maps', None) is None:
             raise ValueError('FusedTrainStep needs a DirectEncoder built with node_maps')
@@ -50,6 +63,14 @@ class FusedTrainStep(object):
         self.bind_grads()
         self.err = ops.new_error_word(self.device)
         self._ws = None
+        self.num_lanes = max(1, min(int(lanes), _capi.STEP_MAX_LANES))
+        self._streams = [None] + [torch.cuda.Stream(device=self.device) for _ in range(self.num_lanes - 1)]
+        self._fork = torch.cuda.Event()
+        self._joins = [None] + [torch.cuda.Event() for _ in range(self.num_lanes - 1)]
+        with torch.cuda.device(self.device):
+            self._fork.record()            # creates the underlying hipEvent_t handles
+            for e in self._joins[1:]:
+                e.record()
         self._refresh_pointers()
 
     def bind_grads(self):
@@ -86,6 +107,27 @@ class FusedTrainStep(object):
         nb = len(batches)
         if nb == 0 or nb > _capi.STEP_MAX_BATCHES:
             raise ValueError('a step holds 1..%d batches' % _capi.STEP_MAX_BATCHES)
+        # lane assignment: deepest chains first, each batch to the lane with the least work so far;
+        # the library wants every lane to own a contiguous range of batches, so the batches are
+        # re-ordered (packed.order[i] = caller's index of library batch i)
+        passes_of = []
+        for b in batches:
+            qt = b['formula'].query_type
+            passes_of.append(RGCNQueryDataset.query_diameters[qt] if m.adaptive else m.num_layers)
+        nl = min(self.num_lanes, nb)
+        load = [0.0] * nl
+        members = [[] for _ in range(nl)]
+        for i in sorted(range(nb), key=lambda i: (-passes_of[i], -_batch_work(batches[i]['formula'].query_type,
+                                                                                passes_of[i]))):
+            l = min(range(nl), key=lambda l: load[l])
+            members[l].append(i)
+            load[l] += _batch_work(batches[i]['formula'].query_type, passes_of[i]) * len(batches[i]['targets'])
+        members = [sorted(mm) for mm in members if mm]
+        order = [i for mm in members for i in mm]
+        lane_begin = [0]
+        for mm in members:
+            lane_begin.append(lane_begin[-1] + len(mm))
+        batches = [batches[i] for i in order]
         SB = (_capi.StepBatch * nb)()
         anchors, tg, ng, sizes = [], [], [], []
         for i, b in enumerate(batches):
@@ -117,6 +159,18 @@ class FusedTrainStep(object):
             sizes.append(B)
         ps = PackedStep()
         ps.batches, ps.nb, ps.sizes = SB, nb, sizes
+        ps.order, ps.lane_begin = order, lane_begin
+        ps.lanes = None
+        if len(members) > 1:
+            L = _capi.StepLanes()
+            L.num_lanes = len(members)
+            for i, v in enumerate(lane_begin):
+                L.batch_begin[i] = v
+            L.fork_event = self._fork.cuda_event
+            for l in range(1, len(members)):
+                L.aux_stream[l] = self._streams[l].cuda_stream
+                L.join_event[l] = self._joins[l].cuda_event
+            ps.lanes = ctypes.pointer(L)
         ps.anchor_ids = torch.cat(anchors).to(self.device)
         ps.targets = torch.cat(tg).to(self.device)
         ps.negs = torch.cat(ng).to(self.device)
@@ -137,8 +191,9 @@ class FusedTrainStep(object):
         return (self._ws.data_ptr() + 255) // 256 * 256
 
     def run(self, packed, backward=True, zero_grad=True, scores=False, events=None):
-        """Returns loss [1 + nb] on the device: loss[0] = weighted step loss, loss[1 + b] =
-        batch b's mean hinge. With backward=True every p.grad then holds d loss[0] / d p
+        """Returns loss [1 + nb] on the device: loss[0] = weighted step loss, loss[1 + i] = mean hinge
+        of library batch i = the caller's batch packed.order[i] (identity with one lane); scores come
+        back in the same library order. With backward=True every p.grad then holds d loss[0] / d p
         (accumulated on top of the previous content unless zero_grad)."""
         if backward:
             self.bind_grads()
@@ -156,7 +211,7 @@ class FusedTrainStep(object):
                 packed.targets.data_ptr(), packed.negs.data_ptr(), self.margin, ctypes.byref(self.G),
                 1 if backward else 0, loss.data_ptr(), None if sp is None else sp.data_ptr(),
                 None if sn is None else sn.data_ptr(), packed.desc_ptr, packed.desc_bytes,
-                0 if packed.desc_resident else 1, wptr, packed.ws_bytes, self.err.data_ptr(),
+                0 if packed.desc_resident else 1, wptr, packed.ws_bytes, self.err.data_ptr(), packed.lanes,
                 events, 0 if events is None else len(events), torch.cuda.current_stream().cuda_stream)
         _capi.check(ops.lib(), st, 'mpqe_step_forward_backward')
         packed.desc_resident = True

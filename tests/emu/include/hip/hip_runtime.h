@@ -55,6 +55,7 @@ static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMem
 
 typedef void *hipEvent_t;
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 
 namespace emu {
 void launch(dim3 grid, dim3 block, const std::function<void()> &body);

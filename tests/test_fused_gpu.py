@@ -33,9 +33,10 @@ def _setup(readout, adaptive, shared, D=64, B=96, seed=0):
     return model, batches
 
 
+@pytest.mark.parametrize('lanes', [1, 2, 3])
 @pytest.mark.parametrize('readout,adaptive,shared', [('mp', True, False), ('sum', False, False),
                                                      ('max', False, True)])
-def test_fused_step_equals_module_path(readout, adaptive, shared):
+def test_fused_step_equals_module_path(readout, adaptive, shared, lanes):
     from mpqe_amd import ops
     from mpqe_amd.fused import FusedTrainStep
     model, batches = _setup(readout, adaptive, shared)
@@ -53,13 +54,18 @@ def test_fused_step_equals_module_path(readout, adaptive, shared):
     total.backward()
     ref = {k: (torch.zeros_like(p) if p.grad is None else p.grad.clone()) for k, p in model.named_parameters()}
     # fused path
-    step = FusedTrainStep(model)
+    step = FusedTrainStep(model, lanes=lanes)
     packed = step.pack(batches)
+    assert sorted(packed.order) == list(range(len(batches)))
+    assert (packed.lanes is None) == (lanes == 1)
     loss, sp, sn = step.run(packed, scores=True)
     step.check()
     np.testing.assert_allclose(loss[0].item(), total.item(), rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(sp.cpu().numpy(), torch.cat(sp_ref).cpu().numpy(), rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(sn.cpu().numpy(), torch.cat(sn_ref).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # scores come back in library batch order: packed.order maps to the caller's batches
+    np.testing.assert_allclose(sp.cpu().numpy(), torch.cat([sp_ref[i] for i in packed.order]).cpu().numpy(),
+                               rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sn.cpu().numpy(), torch.cat([sn_ref[i] for i in packed.order]).cpu().numpy(),
+                               rtol=1e-5, atol=1e-6)
     for k, p in model.named_parameters():
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref[k].cpu().numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
     # running it again gives bit-identical gradients for the layer weights (fixed reduction order)

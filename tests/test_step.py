@@ -70,7 +70,7 @@ def oracle_step(params, cfg, node_map, batches, margin):
     return total.item(), per, np.concatenate(sp), np.concatenate(sn)
 
 
-def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=1):
+def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=1, lanes=None):
     D = params['mode_embeddings.weight'].shape[1]
     L = cfg['num_layers']
     R = params['layers.0.basis'].shape[0]
@@ -126,10 +126,33 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
     dptr = (be.ptr(dbuf) + 255) // 256 * 256
     loss = be.empty((1 + nb,))
     sp, sn = be.empty((Gtot,)), be.empty((Gtot,))
+    keep = []
+    if lanes is not None:
+        splits = lanes
+        lanes = _capi.StepLanes()
+        lanes.num_lanes = len(splits) - 1
+        for i, v in enumerate(splits):
+            lanes.batch_begin[i] = v
+        if be.name == 'hip':
+            ev = be.torch.cuda.Event()
+            ev.record()
+            keep.append(ev)
+            lanes.fork_event = ev.cuda_event
+            for l in range(1, lanes.num_lanes):
+                st, je = be.torch.cuda.Stream(), be.torch.cuda.Event()
+                je.record()
+                keep.extend([st, je])
+                lanes.aux_stream[l], lanes.join_event[l] = st.cuda_stream, je.cuda_event
+        else:       # the emulator runs launches in program order; handles only need to be non-null
+            lanes.fork_event = 1
+            for l in range(1, lanes.num_lanes):
+                lanes.aux_stream[l], lanes.join_event[l] = 1, 1
+        lanes = ctypes.byref(lanes)
     err = be.zeros((1,), np.int32)
     be.check(be.lib.mpqe_step_forward_backward(ctypes.byref(P), SB, nb, be.ptr(d_anchor), be.ptr(d_tg),
                                                be.ptr(d_ng), margin, ctypes.byref(G), backward, be.ptr(loss),
-                                               be.ptr(sp), be.ptr(sn), dptr, dsb, 1, wptr, wsb, be.ptr(err), None, 0, be.stream), 'step')
+                                               be.ptr(sp), be.ptr(sn), dptr, dsb, 1, wptr, wsb, be.ptr(err), lanes, None, 0,
+                                               be.stream), 'step')
     grads = {'mode_embeddings.weight': be.get(gmode)}
     for m, g in zip(modes, gtabs):
         grads['enc.feat-%s.weight' % m] = be.get(g)
@@ -173,6 +196,36 @@ def test_fused_step_matches_oracle(be, readout, adaptive, shared, L, mix):
         seen.add(id(p))
         ref = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
         np.testing.assert_allclose(grads[k], ref, rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.parametrize('splits', [[0, 3, 7], [0, 1, 2, 4, 7], [0, 6, 7]])
+def test_fused_step_stream_lanes(be, splits):
+    """Lanes (batches split over streams) change scheduling only: same loss, scores and gradients."""
+    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(
+        11, 32, 3, False, MIXES['all7'], 'mp', True)
+    ref = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0)
+    got = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, lanes=splits)
+    np.testing.assert_array_equal(got[0], ref[0])
+    np.testing.assert_array_equal(got[1], ref[1])
+    np.testing.assert_array_equal(got[2], ref[2])
+    for k in ref[3]:
+        if k.startswith('layers') or k.startswith('mode'):
+            np.testing.assert_array_equal(got[3][k], ref[3][k], err_msg=k)      # fixed-order reductions
+        else:
+            np.testing.assert_allclose(got[3][k], ref[3][k], rtol=1e-5, atol=1e-7, err_msg=k)   # atomics
+    assert got[4] == 0
+    # forward-only with lanes
+    fwd = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, backward=0, lanes=splits)
+    np.testing.assert_array_equal(fwd[0], ref[0])
+
+
+def test_fused_step_rejects_bad_lanes(be):
+    P = _capi.StepParams()
+    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(
+        7, 16, 2, False, [('2-inter', 6, 1.0), ('1-chain', 6, 1.0)], 'sum', False)
+    for bad in ([0, 0, 2], [0, 2, 2], [1, 1, 2], [0, 1, 3]):
+        with pytest.raises(_capi.MpqeError):
+            run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, lanes=bad)
 
 
 def test_fused_step_equals_reference_two_pass_loss(be):
