@@ -45,7 +45,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--path', default='auto', choices=['auto', 'modules', 'fused'])
-    ap.add_argument('--lanes', type=int, default=2, help='HIP streams one fused step is spread over')
+    ap.add_argument('--lanes', type=int, default=1, help='HIP streams one fused step is spread over')
+    ap.add_argument('--graph', type=int, default=0, help='1: replay each step from a captured hipGraph')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='nccl = RCCL over xGMI (the real path); gloo only to exercise the multi-rank code on one GPU')
     return ap.parse_args()
@@ -336,18 +337,23 @@ def main():
     pool = [StepData(schema, model, args.batch_size, rng, device) for _ in range(4)]
 
     use_fused = args.path in ('auto', 'fused') and args.readout in ('mp', 'sum', 'max')
-    reducer = fstep = packed = None
+    reducer = fstep = packed = captured = None
     if use_fused:
         from mpqe_amd.fused import FusedTrainStep
         fstep = FusedTrainStep(model, lanes=args.lanes)
         packed = [pack_for_fused(fstep, d) for d in pool]
+        captured = [fstep.capture(p) for p in packed] if args.graph else None
     elif world > 1:
         from mpqe_amd.parallel import GradReducer
         reducer = GradReducer(model)
 
     def one_step(i):
         if use_fused:
-            loss = fstep.run(packed[i % len(pool)])
+            if captured is not None:
+                captured[i % len(pool)][0].replay()
+                loss = captured[i % len(pool)][1]
+            else:
+                loss = fstep.run(packed[i % len(pool)])
             if world > 1:
                 import torch.distributed as dist
                 dist.all_reduce(fstep.flat_grad)          # one bucket: p.grad are views of it
@@ -393,7 +399,8 @@ def main():
                    'global_query_graphs_per_step': graphs_per_step,
                    'parallelism': 'dp%d (graphs sharded by rank, RCCL all-reduce of gradients)' % world
                                   if world > 1 else 'single GPU',
-                   'host_path': 'fused step: one C-ABI call per step, %d stream lane(s)' % args.lanes if use_fused
+                   'host_path': 'fused step: one C-ABI call per step, %d stream lane(s)%s'
+                                % (args.lanes, ', replayed from a hipGraph' if args.graph else '') if use_fused
                                 else 'drop-in modules (one autograd graph per step)'},
     }
     if rank == 0:

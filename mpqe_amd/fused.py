@@ -219,6 +219,18 @@ class FusedTrainStep(object):
             return loss, sp, sn
         return loss
 
+    def capture(self, packed, backward=True, zero_grad=True):
+        """Record one step on `packed` into a hipGraph. Returns (graph, loss): graph.replay() re-runs
+        the step on the buffers of `packed` (refill them in place for a new set of queries of the same
+        formulas) and leaves the losses in `loss`. The library call is capturable because it neither
+        allocates nor synchronises once the descriptor table is resident, which the warm run ensures."""
+        self.run(packed, backward, zero_grad)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = self.run(packed, backward, zero_grad)
+        return graph, loss
+
     def check(self):
         """Raise IndexError if any kernel of a previous run saw an invalid entity id (one D2H read)."""
         ops.raise_on_flags(self.err)
