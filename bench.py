@@ -130,6 +130,7 @@ def time_fused_kernels(step, packed, data, model, reps=20):
     n_ev = 2 * len(plan)
     fam = {'step_layer_fwd_kernel': [0.0, 0, 0.0], 'step_layer_bwd_x_kernel': [0.0, 0, 0.0],
            'step_tail_kernel': [0.0, 0, 0.0]}          # ms, launches, flops
+    per_launch = [0.0] * len(plan)
     for _ in range(reps):
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
         for e in evs:
@@ -140,13 +141,16 @@ def time_fused_kernels(step, packed, data, model, reps=20):
         for k, (name, fl) in enumerate(plan):
             f = fam[name]
             f[0] += evs[2 * k].elapsed_time(evs[2 * k + 1])
+            per_launch[k] += evs[2 * k].elapsed_time(evs[2 * k + 1])
             f[1] += 1
             f[2] += fl
     out = []
     for name, (ms, n, fl) in fam.items():
         out.append(dict(kernel=name, launches_per_step=n // reps, avg_launch_us=ms / n * 1e3,
                         algorithmic_flops_per_launch=fl / n, achieved=fl / (ms * 1e-3) / 1e12,
-                        total_us_per_step=ms / reps * 1e3))
+                        total_us_per_step=ms / reps * 1e3,
+                        launches=[dict(us=per_launch[k] / reps * 1e3, gflop=fl / 1e9)
+                                  for k, (nm, fl) in enumerate(plan) if nm == name]))
     return out
 
 

@@ -24,6 +24,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <memory>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "grad_w_dma.h"
@@ -58,11 +61,11 @@ struct TablePtrs {
     long long rows[MPQE_STEP_MAX_MODES];
 };
 
-// Tiles of one (batch, node slot) at one level: rt*ct tiles of equal K length. Groups are sorted by
-// DEscending length: all workgroups of a level are resident at once and are dealt round-robin over
-// the 256 CUs, so block i shares its CU with blocks i+256, i+512; longest-first pairs every long
-// tile with shorter ones instead of stacking three 16-step tiles on one CU (per-CU MFMA time is
-// what bounds a level).
+// Tiles of one (batch, node slot) at one level: rt*ct tiles of equal K length. Per-CU MFMA time is
+// what bounds a level, and a level's workgroups are (almost always) all resident at once, dealt
+// round-robin over the 256 CUs: block i shares its CU with blocks i+256, i+512, i+768 (measured,
+// scratch/placement.hip; a speed assumption only, results do not depend on it). place_tiles() orders
+// the table so that those per-CU sums are balanced (longest-processing-time-first bin packing).
 struct TileGroup {
     int batch, node, tile_off, steps;
 };
@@ -692,6 +695,27 @@ void pick_chunks(long long count, int max_chunks, int *nch, int *ch) {
     *ch = (int)c;
 }
 
+// `in` is sorted by descending K length. The first STEP_CUS * STEP_RESIDENT tiles start at once, block
+// b on CU b % STEP_CUS: give each to the least-loaded CU that still has a free position; the rest
+// follow in descending order and are picked up by whichever CU drains first.
+#define STEP_CUS 256
+#define STEP_RESIDENT 4
+void place_tiles(const std::vector<TileRef> &in, const std::vector<int> &steps, std::vector<TileRef> &out) {
+    const size_t n = in.size();
+    const size_t first = n < (size_t)STEP_CUS * STEP_RESIDENT ? n : (size_t)STEP_CUS * STEP_RESIDENT;
+    out.assign(in.begin(), in.end());
+    int load[STEP_CUS] = {0}, used[STEP_CUS] = {0}, cap[STEP_CUS];
+    for (int c = 0; c < STEP_CUS; ++c) cap[c] = (int)(first / STEP_CUS) + ((size_t)c < first % STEP_CUS);
+    for (size_t t = 0; t < first; ++t) {
+        int best = -1;
+        for (int c = 0; c < STEP_CUS; ++c)
+            if (used[c] < cap[c] && (best < 0 || load[c] < load[best])) best = c;
+        out[(size_t)used[best] * STEP_CUS + best] = in[t];
+        used[best]++;
+        load[best] += steps[t];
+    }
+}
+
 int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, const mpqe_step_lanes_t *lanes,
               HostPlan *hp) {
     if (!P || !B || nb <= 0 || nb > MPQE_STEP_MAX_BATCHES) return MPQE_ERR_INVALID_ARG;
@@ -784,12 +808,16 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                 }
                 std::stable_sort(g.begin(), g.end(),
                                  [](const TileGroup &a, const TileGroup &b) { return a.steps > b.steps; });
-                std::vector<TileRef> &tr = dir ? hp->tbwd[l][p] : hp->tfwd[l][p];
-                tr.clear();
+                std::vector<TileRef> sorted;
+                std::vector<int> steps;
                 for (size_t k = 0; k < g.size(); ++k) {
                     const int cnt = ((sd.b[g[k].batch].B + GT_BM - 1) / GT_BM) * ct;
-                    for (int r = 0; r < cnt; ++r) tr.push_back(TileRef{(short)g[k].batch, (short)g[k].node, r});
+                    for (int r = 0; r < cnt; ++r) {
+                        sorted.push_back(TileRef{(short)g[k].batch, (short)g[k].node, r});
+                        steps.push_back(g[k].steps);
+                    }
                 }
+                place_tiles(sorted, steps, dir ? hp->tbwd[l][p] : hp->tfwd[l][p]);
             }
     }
 
@@ -952,6 +980,45 @@ void upload(hipStream_t s, char *dst, const void *src, size_t n) {
     }
 }
 
+// Everything make_plan() reads, field by field (struct padding never takes part in the comparison).
+struct PlanKey {
+    int dim, num_layers, num_relations, num_modes, readout, nb, nlanes;
+    int lane_begin[MPQE_STEP_MAX_LANES + 1];
+    int alias[MPQE_STEP_MAX_LAYERS];          // first layer with the same parameter buffers
+    mpqe_step_batch_t b[MPQE_STEP_MAX_BATCHES];
+};
+struct CachedPlan {
+    PlanKey key;
+    HostPlan hp;
+};
+std::mutex g_plan_mu;
+std::unordered_map<void *, std::shared_ptr<CachedPlan>> g_plans;
+
+void make_key(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, const mpqe_step_lanes_t *lanes,
+              PlanKey *k) {
+    memset(k, 0, sizeof(*k));
+    k->dim = P->dim; k->num_layers = P->num_layers; k->num_relations = P->num_relations;
+    k->num_modes = P->num_modes; k->readout = P->readout; k->nb = nb;
+    k->nlanes = lanes ? lanes->num_lanes : 1;
+    if (lanes)
+        for (int l = 0; l <= MPQE_STEP_MAX_LANES; ++l) k->lane_begin[l] = lanes->batch_begin[l];
+    for (int l = 0; l < P->num_layers && l < MPQE_STEP_MAX_LAYERS; ++l) {
+        k->alias[l] = l;
+        for (int m = 0; m < l; ++m)
+            if (P->basis[m] == P->basis[l]) {
+                k->alias[l] = k->alias[m];
+                break;
+            }
+    }
+    for (int i = 0; i < nb; ++i) {
+        mpqe_step_batch_t &d = k->b[i];
+        d.query_type = B[i].query_type; d.num_passes = B[i].num_passes; d.batch_size = B[i].batch_size;
+        d.target_mode = B[i].target_mode; d.weight = B[i].weight;
+        for (int e = 0; e < MPQE_MAX_TEMPLATE_EDGES; ++e) { d.edge_type[e] = B[i].edge_type[e]; d.anchor_mode[e] = B[i].anchor_mode[e]; }
+        for (int v = 0; v < MPQE_MAX_TEMPLATE_NODES - 1; ++v) d.var_ids[v] = B[i].var_ids[v];
+    }
+}
+
 }  // namespace
 
 extern "C" size_t mpqe_step_workspace_bytes(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb) {
@@ -973,10 +1040,31 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                                           size_t desc_bytes, int upload_desc, void *workspace,
                                           size_t workspace_bytes, int32_t *err, const mpqe_step_lanes_t *lanes,
                                           void *const *events, int num_events, void *stream) {
-    HostPlan hp;
-    int st = make_plan(P, B, nb, lanes, &hp);
-    if (st) return st;
-    if (!anchor_ids || !targets || !negs || !loss || !workspace || !desc) return MPQE_ERR_INVALID_ARG;
+    if (!P || !B || nb < 1 || nb > MPQE_STEP_MAX_BATCHES || !desc) return MPQE_ERR_INVALID_ARG;
+    // The launch plan is a pure function of the descriptors; it is kept on the host next to the device
+    // table it describes (same key: the caller's desc buffer), so a steady-state call costs one lookup.
+    std::shared_ptr<const CachedPlan> cached;
+    {
+        PlanKey key;
+        make_key(P, B, nb, lanes, &key);
+        std::lock_guard<std::mutex> lock(g_plan_mu);
+        auto it = g_plans.find(desc);
+        if (it != g_plans.end() && memcmp(&it->second->key, &key, sizeof(key)) == 0) cached = it->second;
+        else if (it != g_plans.end() && !upload_desc) return MPQE_ERR_INVALID_ARG;   // desc holds another step's table
+        if (!cached) {
+            std::shared_ptr<CachedPlan> fresh = std::make_shared<CachedPlan>();
+            fresh->key = key;
+            int st = make_plan(P, B, nb, lanes, &fresh->hp);
+            if (st) return st;
+            if (g_plans.size() >= 1024) g_plans.clear();      // plans in use stay alive through their shared_ptr
+            g_plans[desc] = fresh;
+            cached = fresh;
+        }
+    }
+    const HostPlan &hp = cached->hp;
+    for (int l = 1; l < hp.nlanes; ++l)           // handles are per call, not part of the cached plan
+        if (!lanes->fork_event || !lanes->aux_stream[l] || !lanes->join_event[l]) return MPQE_ERR_INVALID_ARG;
+    if (!anchor_ids || !targets || !negs || !loss || !workspace) return MPQE_ERR_INVALID_ARG;
     if (desc_bytes < hp.desc_total) return MPQE_ERR_WORKSPACE;
     if ((uintptr_t)desc % 256 != 0) return MPQE_ERR_INVALID_ARG;
     if (backward && !G) return MPQE_ERR_INVALID_ARG;
@@ -995,7 +1083,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     // (see mpqe_amd.h for the order)
     int ev = 0;
     auto mark = [&](hipStream_t on) {
-        if (events && ev < num_events) hipEventRecord(reinterpret_cast<hipEvent_t>(events[ev]), on);
+        if (events && ev < num_events) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(events[ev]), on);
         ++ev;
     };
 
@@ -1064,8 +1152,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         gr0[l] = b < nb ? hp.sd.b[b].g_off : hp.sd.graphs_total;
     }
     if (NL > 1) {
-        hipEventRecord(reinterpret_cast<hipEvent_t>(lanes->fork_event), s);
-        for (int l = 1; l < NL; ++l) hipStreamWaitEvent(ls[l], reinterpret_cast<hipEvent_t>(lanes->fork_event), 0);
+        (void)hipEventRecord(reinterpret_cast<hipEvent_t>(lanes->fork_event), s);
+        for (int l = 1; l < NL; ++l) (void)hipStreamWaitEvent(ls[l], reinterpret_cast<hipEvent_t>(lanes->fork_event), 0);
     }
 
     // ---- forward
@@ -1107,8 +1195,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     else LAUNCH_SCORE(BWD, 8, GHP, L)
     auto join = [&]() {
         for (int l = 1; l < NL; ++l) {
-            hipEventRecord(reinterpret_cast<hipEvent_t>(lanes->join_event[l]), ls[l]);
-            hipStreamWaitEvent(s, reinterpret_cast<hipEvent_t>(lanes->join_event[l]), 0);
+            (void)hipEventRecord(reinterpret_cast<hipEvent_t>(lanes->join_event[l]), ls[l]);
+            (void)hipStreamWaitEvent(s, reinterpret_cast<hipEvent_t>(lanes->join_event[l]), 0);
         }
     };
     if (!backward) {
