@@ -210,6 +210,13 @@ int mpqe_hinge_bwd(const float *pos, const float *neg, int64_t n, float margin, 
 #define MPQE_STEP_MAX_BATCHES 16
 #define MPQE_STEP_MAX_LAYERS 8
 #define MPQE_STEP_MAX_MODES 16
+/* flags of mpqe_step_params_t (speed switches; loss, scores and gradients are the same either way):
+ * NO_PRUNE  also compute node states that cannot reach the readout (the reference computes all of them;
+ *           with the TM readout only the target row is read, model.py:391-398, so e.g. 9 of the 21
+ *           node updates of a 3-chain feed nothing and get an exactly-zero gradient). Default: skip them.
+ * NO_CHAIN  one launch per message-passing level instead of the graph-block chain kernels.      */
+#define MPQE_STEP_NO_PRUNE 1
+#define MPQE_STEP_NO_CHAIN 2
 
 typedef struct {
     int32_t query_type;        /* MPQE_Q_*                                                     */
@@ -225,7 +232,7 @@ typedef struct {
 typedef struct {
     int32_t dim, num_layers, num_relations, num_modes;
     int32_t readout;           /* MPQE_READOUT_*                                               */
-    int32_t reserved;
+    int32_t flags;             /* MPQE_STEP_* bits below; 0 = everything on                    */
     const float *tables[MPQE_STEP_MAX_MODES];    /* per-mode entity table [rows, dim]          */
     int64_t table_rows[MPQE_STEP_MAX_MODES];
     const int64_t *node_map;   /* global entity id -> row of its mode's table (-1: none)       */

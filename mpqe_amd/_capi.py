@@ -35,7 +35,7 @@ class StepBatch(ctypes.Structure):
 class StepParams(ctypes.Structure):
     _fields_ = [('dim', ctypes.c_int32), ('num_layers', ctypes.c_int32),
                 ('num_relations', ctypes.c_int32), ('num_modes', ctypes.c_int32),
-                ('readout', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('readout', ctypes.c_int32), ('flags', ctypes.c_int32),
                 ('tables', c_void_p * STEP_MAX_MODES), ('table_rows', ctypes.c_int64 * STEP_MAX_MODES),
                 ('node_map', c_void_p), ('node_map_len', ctypes.c_int64), ('mode_emb', c_void_p),
                 ('basis', c_void_p * STEP_MAX_LAYERS), ('root', c_void_p * STEP_MAX_LAYERS),
@@ -125,10 +125,14 @@ def check(cdll, status, what):
         raise MpqeError('%s failed: %s (%d)' % (what, msg.decode() if msg else '?', status))
 
 
+STEP_NO_PRUNE, STEP_NO_CHAIN = 1, 2
+
+
 def make_step_params(dim, num_relations, readout, table_ptrs, table_rows, node_map_ptr, node_map_len,
-                     mode_emb_ptr, basis_ptrs, root_ptrs, bias_ptrs):
+                     mode_emb_ptr, basis_ptrs, root_ptrs, bias_ptrs, flags=0):
     """StepParams from raw addresses (ints); lists are per mode / per layer."""
     p = StepParams()
+    p.flags = flags
     p.dim, p.num_layers, p.num_relations, p.num_modes = dim, len(basis_ptrs), num_relations, len(table_ptrs)
     p.readout = READOUT_IDS[readout] if isinstance(readout, str) else readout
     for m, (ptr, rows) in enumerate(zip(table_ptrs, table_rows)):

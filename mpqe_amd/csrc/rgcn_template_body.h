@@ -203,13 +203,20 @@ __device__ __forceinline__ void tmpl_bwd_x_tile(const TmplArgs &tp, long long B,
                                                 const float *__restrict__ root, int Din, int Dout, int relu,
                                                 float *__restrict__ grad_x, int m,
                                                 long long b0, int n0, float *smem,
-                                                const float *__restrict__ mask_x = nullptr) {
+                                                const float *__restrict__ mask_x = nullptr,
+                                                unsigned live_out = 0xFu) {
+    // live_out (fused step): node slots whose output gradient can be non-zero; the K-blocks of the
+    // others would multiply exact zeros (rows the step never writes) and are left out. The caller
+    // guarantees that at least one block remains.
     KBlocks kb;
     kblocks_init(kb, root);
-    if (tp.E > 0 && tp.src[0] == m) kb.add(tp.dst[0], basis + tp.rel[0] * (long long)Din * Dout);
-    if (tp.E > 1 && tp.src[1] == m) kb.add(tp.dst[1], basis + tp.rel[1] * (long long)Din * Dout);
-    if (tp.E > 2 && tp.src[2] == m) kb.add(tp.dst[2], basis + tp.rel[2] * (long long)Din * Dout);
-    kb.add(m, root);
+    if (tp.E > 0 && tp.src[0] == m && ((live_out >> tp.dst[0]) & 1u))
+        kb.add(tp.dst[0], basis + tp.rel[0] * (long long)Din * Dout);
+    if (tp.E > 1 && tp.src[1] == m && ((live_out >> tp.dst[1]) & 1u))
+        kb.add(tp.dst[1], basis + tp.rel[1] * (long long)Din * Dout);
+    if (tp.E > 2 && tp.src[2] == m && ((live_out >> tp.dst[2]) & 1u))
+        kb.add(tp.dst[2], basis + tp.rel[2] * (long long)Din * Dout);
+    if ((live_out >> m) & 1u) kb.add(m, root);
     kb.nk = __builtin_amdgcn_readfirstlane(kb.nk);
     f32x16 acc;
 #pragma unroll

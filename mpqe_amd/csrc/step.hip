@@ -44,6 +44,10 @@ struct BatchDev {
     long long row_off, g_off, anchor_off;
     float weight;
     int pad;
+    // live[p]: node slots whose state H[p] can reach the readout (bit n). Everything else is neither
+    // computed nor read: its gradient is exactly zero (MPQE_STEP_NO_PRUNE: all slots at every level).
+    unsigned live[MPQE_STEP_MAX_LAYERS + 1];
+    int pad2;
 };
 
 struct StepDev {
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(256) void step_layer_bwd_x_kernel(const StepDev *__
     tmpl_bwd_x_tile<MODE>(tp, b.B, Gout + b.row_off * D, (const float *)nullptr, pick_layer(lp.basis, li),
                           pick_layer(lp.root, li), D, D, 0,
                          Gin + b.row_off * D, m, (long long)(rem / ct) * GT_BM, (rem % ct) * GT_BN, smem,
-                         p >= 1 ? Hin + b.row_off * D : (const float *)nullptr);
+                         p >= 1 ? Hin + b.row_off * D : (const float *)nullptr, b.live[p + 1]);
 }
 
 // ------------------------------------------------------------------------------------ score / loss
@@ -461,13 +465,15 @@ __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, con
     const int lb = vb - s.block_start;
     const int c = lb / tiles, tile = lb - c * tiles;
     const BatchDev &b = sd->b[s.batch];
-    const bool is_root = s.slot == b.tp.E;
-    const long long count = is_root ? (long long)b.B * b.tp.N : b.B;
+    // slot < E: template edge (x = source slot, g = destination slot); slot = E + n: the self/root term
+    // of node slot n. K runs over the batch's graphs in both cases.
+    const bool is_root = s.slot >= b.tp.E;
+    const long long count = b.B;
     const long long q0 = (long long)c * s.ch;
     long long q1 = q0 + s.ch;
     if (q1 > count) q1 = count;
-    const long long xs = is_root ? 1 : b.tp.N, xo = is_root ? 0 : b.tp.src[s.slot];
-    const long long gs = is_root ? 1 : b.tp.N, go = is_root ? 0 : b.tp.dst[s.slot];
+    const long long xs = b.tp.N, xo = is_root ? s.slot - b.tp.E : b.tp.src[s.slot < 3 ? s.slot : 0];
+    const long long gs = b.tp.N, go = is_root ? s.slot - b.tp.E : b.tp.dst[s.slot < 3 ? s.slot : 0];
     const float *x = H + (long long)s.level * level_stride + b.row_off * D;
     const float *out = H + (long long)(s.level + 1) * level_stride + b.row_off * D;
     const float *g = GH + (long long)(s.level + 1) * level_stride + b.row_off * D;
@@ -502,8 +508,11 @@ __device__ __forceinline__ void vec_partial_block(const StepDev *__restrict__ sd
         const float *g = GH + (long long)(s.level_or_k + 1) * level_stride + b.row_off * D;
         const float *o = H + (long long)(s.level_or_k + 1) * level_stride + b.row_off * D;
         const long long r0 = (long long)blk * 64;
+        const unsigned live = b.live[s.level_or_k + 1];
+        const int N = b.tp.N;
         if (c < D)
             for (long long r = r0 + rg; r < r0 + 64 && r < rows; r += 4) {
+                if (!((live >> (int)(r % N)) & 1u)) continue;      // rows the step never wrote: zero gradient
                 float v = g[r * D + c];
                 if (s.relu && !(o[r * D + c] > 0.f)) v = 0.f;
                 acc += v;
@@ -539,7 +548,7 @@ __device__ __forceinline__ void anchor_bwd_block(const StepDev *__restrict__ sd,
     const long long g = lr - (long long)n * b.B;
     const int D = sd->D, tab = b.anchor_tab[n];
     float *gt = tabs.grad[tab];
-    if (!gt) return;
+    if (!gt || !((b.live[0] >> n) & 1u)) return;
     const long long row = table_row(node_map, map_len, anchor_ids[b.anchor_off + lr], tabs.rows[tab], nullptr);
     if (row < 0) return;
     const float *v = tabs.table[tab] + row * D;
@@ -783,6 +792,17 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         anchors += (long long)d.B * t.A;
         if (d.L > hp->Lmax) hp->Lmax = d.L;
         if (d.B % GT_BK != 0) hp->whole_ksteps = false;
+        // liveness, from the readout backwards: H[p][n] matters iff n itself or a destination of one
+        // of its out-edges matters at p+1 (reference RGCNConv: out_i = sum_j x_j W_r + x_i root)
+        const unsigned all = (1u << t.N) - 1u;
+        const bool prune = !(P->flags & MPQE_STEP_NO_PRUNE);
+        d.live[d.L] = (prune && P->readout == MPQE_READOUT_TM) ? (1u << t.A) : all;
+        for (int p = d.L - 1; p >= 0; --p) {
+            unsigned m = d.live[p + 1];
+            for (int e = 0; e < t.E; ++e)
+                if ((d.live[p + 1] >> t.dst[e]) & 1u) m |= 1u << t.src[e];
+            d.live[p] = prune ? m : all;
+        }
     }
     if (rows >= (1ll << 30)) return MPQE_ERR_UNSUPPORTED;
     hp->anchor_off[nb] = (int)anchors;
@@ -800,10 +820,17 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                 for (int i = hp->lane_begin[l]; i < hp->lane_begin[l + 1]; ++i) {
                     if (sd.b[i].L <= p) continue;
                     const TmplArgs &tp = sd.b[i].tp;
+                    const unsigned lin = sd.b[i].live[p], lout = sd.b[i].live[p + 1];
                     for (int n = 0; n < tp.N; ++n) {
-                        int deg = 0;      // forward: edges INTO n; backward-x: edges OUT of n
-                        for (int e = 0; e < tp.E; ++e) deg += (dir ? tp.src[e] : tp.dst[e]) == n;
-                        g.push_back(TileGroup{i, n, 0, (deg + 1) * spb});
+                        // forward: H[p+1][n] from the edges INTO n (+ self); backward-x: gH[p][n] from the
+                        // live destinations of the edges OUT of n (+ self if live)
+                        if (!(((dir ? lin : lout) >> n) & 1u)) continue;
+                        int blocks = dir ? (int)((lout >> n) & 1u) : 1;
+                        for (int e = 0; e < tp.E; ++e) {
+                            if (!dir) blocks += tp.dst[e] == n;
+                            else blocks += tp.src[e] == n && ((lout >> tp.dst[e]) & 1u);
+                        }
+                        g.push_back(TileGroup{i, n, 0, blocks * spb});
                     }
                 }
                 std::stable_sort(g.begin(), g.end(),
@@ -842,8 +869,12 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     for (int i = 0; i < nb; ++i)
         for (int p = 0; p < sd.b[i].L; ++p) {
             const int li = uid[p < sd.b[i].L - 1 ? p : P->num_layers - 1];
-            for (int z = 0; z <= sd.b[i].tp.E; ++z)
-                keys.push_back(Key{li, z < sd.b[i].tp.E ? sd.b[i].tp.rel[z] : -1, i, p, z});
+            const unsigned lout = sd.b[i].live[p + 1];
+            const TmplArgs &tp = sd.b[i].tp;
+            for (int z = 0; z < tp.E; ++z)
+                if ((lout >> tp.dst[z]) & 1u) keys.push_back(Key{li, tp.rel[z], i, p, z});
+            for (int n = 0; n < tp.N; ++n)          // root term: one source per live node slot
+                if ((lout >> n) & 1u) keys.push_back(Key{li, -1, i, p, tp.E + n});
         }
     std::stable_sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
         if (a.layer != b.layer) return a.layer < b.layer;
@@ -862,8 +893,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         s.level = key.level;
         s.slot = key.slot;
         s.relu = 0;      // gH is stored as a pre-activation gradient (masked by its producer)
-        const bool is_root = key.slot == d.tp.E;
-        pick_chunks(is_root ? (long long)d.B * d.tp.N : d.B, is_root ? 64 : 32, &s.nch, &s.ch);
+        pick_chunks(d.B, 32, &s.nch, &s.ch);
         s.slab_start = slab;
         s.block_start = block;
         hp->wsrc.push_back(s);
@@ -894,7 +924,8 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     for (int i = 0; i < nb; ++i) {
         for (int p = 0; p < sd.b[i].L; ++p)
             vk.push_back(VKey{0, uid[p < sd.b[i].L - 1 ? p : P->num_layers - 1], 0, i, p});
-        for (int k = 0; k < sd.b[i].V; ++k) vk.push_back(VKey{1, 0, sd.b[i].var_id[k], i, k});
+        for (int k = 0; k < sd.b[i].V; ++k)
+            if ((sd.b[i].live[0] >> (sd.b[i].A + k)) & 1u) vk.push_back(VKey{1, 0, sd.b[i].var_id[k], i, k});
     }
     std::stable_sort(vk.begin(), vk.end(), [](const VKey &a, const VKey &b) {
         if (a.kind != b.kind) return a.kind < b.kind;
@@ -982,7 +1013,7 @@ void upload(hipStream_t s, char *dst, const void *src, size_t n) {
 
 // Everything make_plan() reads, field by field (struct padding never takes part in the comparison).
 struct PlanKey {
-    int dim, num_layers, num_relations, num_modes, readout, nb, nlanes;
+    int dim, num_layers, num_relations, num_modes, readout, flags, nb, nlanes;
     int lane_begin[MPQE_STEP_MAX_LANES + 1];
     int alias[MPQE_STEP_MAX_LAYERS];          // first layer with the same parameter buffers
     mpqe_step_batch_t b[MPQE_STEP_MAX_BATCHES];
@@ -998,7 +1029,7 @@ void make_key(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
               PlanKey *k) {
     memset(k, 0, sizeof(*k));
     k->dim = P->dim; k->num_layers = P->num_layers; k->num_relations = P->num_relations;
-    k->num_modes = P->num_modes; k->readout = P->readout; k->nb = nb;
+    k->num_modes = P->num_modes; k->readout = P->readout; k->flags = P->flags; k->nb = nb;
     k->nlanes = lanes ? lanes->num_lanes : 1;
     if (lanes)
         for (int l = 0; l <= MPQE_STEP_MAX_LANES; ++l) k->lane_begin[l] = lanes->batch_begin[l];

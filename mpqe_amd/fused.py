@@ -39,7 +39,7 @@ class FusedTrainStep(object):
     gradients (include/mpqe_amd.h, mpqe_step_lanes_t). The split balances MFMA work and keeps
     batches of equal depth together (longest chains first)."""
 
-    def __init__(self, model, margin=1.0, lanes=1):
+    def __init__(self, model, margin=1.0, lanes=1, prune=True, chain=True):
         enc = model.enc
         if not hasattr(enc, 'table') or getattr(enc, 'node_maps', None) is None:
             raise ValueError('FusedTrainStep needs a DirectEncoder built with node_maps')
@@ -48,6 +48,8 @@ class FusedTrainStep(object):
                                       'module path' % model.readout_str)
         self.model = model
         self.margin = float(margin)
+        # speed switches of the library call (include/mpqe_amd.h): identical loss / scores / gradients
+        self.flags = (0 if prune else _capi.STEP_NO_PRUNE) | (0 if chain else _capi.STEP_NO_CHAIN)
         self.device = next(model.parameters()).device
         if self.device.type != 'cuda':
             raise RuntimeError('mpqe_amd: the model must be on the GPU -- there is no CPU path')
@@ -93,7 +95,7 @@ class FusedTrainStep(object):
             m.emb_dim, layers[0].num_relations, m.readout_str, [t.data_ptr() for t in tabs],
             [t.shape[0] for t in tabs], m.enc.node_maps.data_ptr(), m.enc.node_maps.shape[0],
             m.mode_embeddings.weight.data_ptr(), [l.basis.data_ptr() for l in layers],
-            [l.root.data_ptr() for l in layers], [l.bias.data_ptr() for l in layers])
+            [l.root.data_ptr() for l in layers], [l.bias.data_ptr() for l in layers], flags=self.flags)
         self.G = _capi.make_step_grads(
             [t.grad.data_ptr() for t in tabs], m.mode_embeddings.weight.grad.data_ptr(),
             [l.basis.grad.data_ptr() for l in layers], [l.root.grad.data_ptr() for l in layers],

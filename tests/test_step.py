@@ -70,7 +70,7 @@ def oracle_step(params, cfg, node_map, batches, margin):
     return total.item(), per, np.concatenate(sp), np.concatenate(sn)
 
 
-def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=1, lanes=None):
+def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=1, lanes=None, flags=0):
     D = params['mode_embeddings.weight'].shape[1]
     L = cfg['num_layers']
     R = params['layers.0.basis'].shape[0]
@@ -95,7 +95,7 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
     P = _capi.make_step_params(D, R, cfg['readout'], [be.ptr(t) for t in tables],
                                [params['enc.feat-%s.weight' % m].shape[0] for m in modes], be.ptr(dnm),
                                node_map.shape[0], be.ptr(dmode), [be.ptr(x[0]) for x in lay],
-                               [be.ptr(x[1]) for x in lay], [be.ptr(x[2]) for x in lay])
+                               [be.ptr(x[1]) for x in lay], [be.ptr(x[2]) for x in lay], flags=flags)
     gtabs = [be.zeros(tuple(params['enc.feat-%s.weight' % m].shape)) for m in modes]
     gmode = be.zeros(tuple(params['mode_embeddings.weight'].shape))
     glay_u = {k: (be.zeros((R, D, D)), be.zeros((D, D)), be.zeros((D,))) for k in uniq}
@@ -120,6 +120,10 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
     wsb = be.lib.mpqe_step_workspace_bytes(ctypes.byref(P), SB, nb)
     assert wsb > 0
     ws = be.nbytes(wsb + 256)
+    if be.name == 'emu':          # node states the step skips must never be read: poison the arena
+        ws.fill(np.nan)
+    else:
+        ws.fill_(float('nan'))
     wptr = (be.ptr(ws) + 255) // 256 * 256
     dsb = be.lib.mpqe_step_desc_bytes(ctypes.byref(P), SB, nb)
     dbuf = be.nbytes(dsb + 256)
@@ -196,6 +200,26 @@ def test_fused_step_matches_oracle(be, readout, adaptive, shared, L, mix):
         seen.add(id(p))
         ref = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
         np.testing.assert_allclose(grads[k], ref, rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.parametrize('readout,adaptive,L', [('mp', True, 3), ('mp', False, 2), ('max', False, 3)])
+def test_fused_step_pruning_changes_nothing(be, readout, adaptive, L):
+    """Node states that cannot reach the readout are skipped by default (MPQE_STEP_NO_PRUNE computes them
+    all, as the reference does): same scores bit for bit, same gradients (the skipped terms are exact
+    zeros; only the weight-gradient chunking differs)."""
+    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(
+        13, 32, L, False, MIXES['all7'], readout, adaptive)
+    ref_loss, ref_per, ref_sp, ref_sn = oracle_step(params, cfg, node_map, batches, 1.0)
+    full = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_NO_PRUNE)
+    got = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0)
+    np.testing.assert_array_equal(got[0], full[0])
+    np.testing.assert_array_equal(got[1], full[1])
+    np.testing.assert_array_equal(got[2], full[2])
+    for k in full[3]:
+        np.testing.assert_allclose(got[3][k], full[3][k], rtol=1e-5, atol=1e-7, err_msg=k)
+        ref = np.zeros_like(got[3][k]) if params[k].grad is None else params[k].grad.numpy()
+        np.testing.assert_allclose(got[3][k], ref, rtol=1e-4, atol=2e-6, err_msg=k)
+    assert got[4] == 0 and full[4] == 0
 
 
 @pytest.mark.parametrize('splits', [[0, 3, 7], [0, 1, 2, 4, 7], [0, 6, 7]])
