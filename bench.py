@@ -47,6 +47,8 @@ def parse():
     ap.add_argument('--path', default='auto', choices=['auto', 'modules', 'fused'])
     ap.add_argument('--lanes', type=int, default=1, help='HIP streams one fused step is spread over')
     ap.add_argument('--graph', type=int, default=0, help='1: replay each step from a captured hipGraph')
+    ap.add_argument('--no-prune', action='store_true', help='compute node states that cannot reach the readout too')
+    ap.add_argument('--no-chain', action='store_true', help='one launch per message-passing level')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='nccl = RCCL over xGMI (the real path); gloo only to exercise the multi-rank code on one GPU')
     return ap.parse_args()
@@ -105,31 +107,39 @@ def pack_for_fused(step, data):
                            negs=b['negs_np'], weight=b['weight']) for b in data.batches])
 
 
-def time_fused_kernels(step, packed, data, model, reps=20):
-    """Per-launch durations of the three MFMA kernel families of the fused step, from HIP events the
-    library records around single launches on the stream of each launch (order: mpqe_amd.h). With
-    stream lanes a level is one launch PER LANE that has it; the launches of different lanes overlap
-    in time, so a duration here is that launch's own span, as rocprofv3 reports it."""
+def time_fused_kernels(step, packed, data, model, readout, reps=20):
+    """Per-launch durations of the MFMA kernels of the fused step, from HIP events the library records
+    around single launches on the stream of each launch (order: mpqe_amd.h). Flops are the EXECUTED
+    ones: with the TM readout node states that cannot reach the target row are skipped
+    (mpqe_amd.fused.live_units), so they are fewer than SURVEY 8d's 2 D^2 (E + N) per graph and pass."""
     import ctypes
     from mpqe_amd.data_utils import RGCNQueryDataset
+    from mpqe_amd.fused import live_units
     D = model.emb_dim
+    prune = not (step.flags & 1)
     # library batch i = bench batch packed.order[i]; lane l owns library batches [lane_begin[l], lane_begin[l+1])
     tmpl = [data.batches[j]['graph'].template for j in packed.order]
     Ls = [RGCNQueryDataset.query_diameters[t.query_type] if model.adaptive else model.num_layers for t in tmpl]
-    lanes = [(packed.lane_begin[l], packed.lane_begin[l + 1]) for l in range(len(packed.lane_begin) - 1)]
+    units = [live_units(t.query_type, L, readout, prune) for t, L in zip(tmpl, Ls)]
     Lmax = max(Ls)
 
     def flops(lo, hi, p):
-        return sum(2.0 * t.B * D * D * (t.E + t.N) for t, L in zip(tmpl[lo:hi], Ls[lo:hi]) if L > p)
-    plan = []                                            # (family, flops) per event pair, in library order
-    for p in range(Lmax):
-        plan += [('step_layer_fwd_kernel', flops(lo, hi, p)) for lo, hi in lanes if max(Ls[lo:hi]) > p]
-    for p in range(Lmax - 1, -1, -1):
-        plan += [('step_layer_bwd_x_kernel', flops(lo, hi, p)) for lo, hi in lanes if max(Ls[lo:hi]) > p]
-    plan.append(('step_tail_kernel', sum(2.0 * L * t.B * D * D * (t.E + t.N) for t, L in zip(tmpl, Ls))))
+        return sum(2.0 * t.B * D * D * u[p] for t, L, u in zip(tmpl[lo:hi], Ls[lo:hi], units[lo:hi]) if L > p)
+    total = sum(flops(0, len(tmpl), p) for p in range(Lmax))
+    plan = []                                            # (kernel, flops) per event pair, in library order
+    if step.uses_chain(packed):
+        plan += [('step_chain_kernel<fwd>', total), ('step_chain_kernel<bwd>', total)]
+    else:
+        lanes = [(packed.lane_begin[l], packed.lane_begin[l + 1]) for l in range(len(packed.lane_begin) - 1)]
+        for p in range(Lmax):
+            plan += [('step_layer_fwd_kernel', flops(lo, hi, p)) for lo, hi in lanes if max(Ls[lo:hi]) > p]
+        for p in range(Lmax - 1, -1, -1):
+            plan += [('step_layer_bwd_x_kernel', flops(lo, hi, p)) for lo, hi in lanes if max(Ls[lo:hi]) > p]
+    plan.append(('step_tail_kernel', total))
     n_ev = 2 * len(plan)
-    fam = {'step_layer_fwd_kernel': [0.0, 0, 0.0], 'step_layer_bwd_x_kernel': [0.0, 0, 0.0],
-           'step_tail_kernel': [0.0, 0, 0.0]}          # ms, launches, flops
+    fam = {}
+    for name, _ in plan:
+        fam.setdefault(name, [0.0, 0, 0.0])             # ms, launches, flops
     per_launch = [0.0] * len(plan)
     for _ in range(reps):
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
@@ -151,7 +161,7 @@ def time_fused_kernels(step, packed, data, model, reps=20):
                         total_us_per_step=ms / reps * 1e3,
                         launches=[dict(us=per_launch[k] / reps * 1e3, gflop=fl / 1e9)
                                   for k, (nm, fl) in enumerate(plan) if nm == name]))
-    return out
+    return out, 3.0 * total
 
 
 def pmc_traffic(kernel):
@@ -344,7 +354,7 @@ def main():
     reducer = fstep = packed = captured = None
     if use_fused:
         from mpqe_amd.fused import FusedTrainStep
-        fstep = FusedTrainStep(model, lanes=args.lanes)
+        fstep = FusedTrainStep(model, lanes=args.lanes, prune=not args.no_prune, chain=not args.no_chain)
         packed = [pack_for_fused(fstep, d) for d in pool]
         captured = [fstep.capture(p) for p in packed] if args.graph else None
     elif world > 1:
@@ -410,7 +420,7 @@ def main():
     if rank == 0:
         flops_fwd, flops_all, bytes_all, launches = layer_work(pool[0], model)
         if use_fused:
-            fams = time_fused_kernels(fstep, packed[0], pool[0], model)
+            fams, executed = time_fused_kernels(fstep, packed[0], pool[0], model, args.readout)
             dom = max(fams, key=lambda f: f['total_us_per_step'])
             out['roofline'] = {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['achieved'],
                                'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -431,6 +441,9 @@ def main():
                                'launches_per_step': launches}
         out['step_work'] = {'layer_flops_fwd_bwd': flops_all, 'scatter_aggregate_bytes_fwd_bwd': bytes_all,
                             'layer_tflops_over_whole_step': flops_all / (elapsed / args.steps) / 1e12}
+        if use_fused:       # flops_all is SURVEY 8d's count (every node state); executed = after pruning
+            out['step_work']['layer_flops_executed'] = executed
+            out['step_work']['executed_tflops_over_whole_step'] = executed / (elapsed / args.steps) / 1e12
         if world == 1 and not args.no_cpu_baseline:
             cfg = dict(readout=args.readout, scatter_op='add', num_layers=3, adaptive=adaptive, weight_decay=0)
             out['cpu_baseline'] = cpu_baseline(args, schema, cpu_state, node_maps, model.rel_ids, model.mode_ids,

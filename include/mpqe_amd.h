@@ -281,8 +281,10 @@ size_t mpqe_step_desc_bytes(const mpqe_step_params_t *params_host, const mpqe_st
  * lanes (may be NULL = one lane): see mpqe_step_lanes_t.
  * events (may be NULL): hipEvent_t handles recorded in pairs around single launches on the stream of the
  * launch, in this order: for level 0..Lmax-1, for each lane that has the level: layer forward; for level
- * Lmax-1..0, for each such lane: backward-x; then the weight-gradient launch. Fewer are filled as far as
- * they go. For roofline accounting only.                                                          */
+ * Lmax-1..0, for each such lane: backward-x; then the weight-gradient launch. When the graph-block chain
+ * kernels run (dim 64 / 128 / 256, at most 32768 query graphs in the step, MPQE_STEP_NO_CHAIN clear; lanes
+ * are then ignored) the order is: forward chain, backward chain, weight-gradient launch. Fewer are filled
+ * as far as they go. For roofline accounting only.                                                 */
 int mpqe_step_forward_backward(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,
                                int num_batches, const int64_t *anchor_ids, const int64_t *targets,
                                const int64_t *negs, float margin, const mpqe_step_grads_t *grads_host,

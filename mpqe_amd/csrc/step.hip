@@ -33,6 +33,7 @@
 #include "rgcn_template_body.h"
 
 #define STEP_MAX_LEVELS MPQE_STEP_MAX_LAYERS
+#define CHAIN_MAX_GRAPHS 32768
 #define UPLOAD_BYTES 2048
 
 struct BatchDev {
@@ -124,6 +125,18 @@ __device__ __forceinline__ const float *pick_layer(const float *const *arr, int 
     for (int l = 1; l < MPQE_STEP_MAX_LAYERS; ++l)
         if (l == li) r = arr[l];
     return r;
+}
+
+#include "step_chain.h"
+
+template <int NCB, bool BWD>
+__global__ __launch_bounds__(256) void step_chain_kernel(const StepDev *__restrict__ sd, LayerPtrs lp,
+                                                         const ChainRef *__restrict__ refs,
+                                                         const ChainBatch *__restrict__ cbs,
+                                                         const ChainOp *__restrict__ ops, float *__restrict__ X,
+                                                         const float *__restrict__ Hmask, long long level_stride) {
+    __shared__ __attribute__((aligned(16))) float xs[2 * 4 * CH_GB * (64 * NCB + 4)];
+    chain_block<NCB, BWD>(sd, lp, refs, cbs, ops, X, Hmask, level_stride, xs);
 }
 
 __device__ __forceinline__ int find_group_le(const TileGroup *__restrict__ g, int n, int t) {
@@ -683,6 +696,11 @@ struct HostPlan {
     std::vector<int> anchor_off;      // nb + 1 (rows of the anchor backward)
     int total_slabs, total_parts;
     bool whole_ksteps;                // every batch size is a multiple of the K-step (weight-gradient LD_FAST)
+    // graph-block chain kernels (step_chain.h): one entry per workgroup, heaviest blocks first
+    std::vector<ChainRef> crefs;
+    std::vector<ChainOp> cops;
+    ChainBatch cbatch[MPQE_STEP_MAX_BATCHES];
+    size_t o_cref, o_cops, o_cbatch;
     // workspace offsets (bytes)
     size_t o_sd, o_wsrc, o_wblock, o_vsrc, o_vblock, o_groups, o_anchor, desc_total;     // descriptor buffer
     size_t o_H, o_GH, o_tpos, o_tneg, o_spos, o_sneg, o_terms, o_slabs, o_parts, total;  // workspace
@@ -966,6 +984,43 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->vblocks_total = vblock;
     hp->total_parts = part;
 
+    // chain programmes: per batch and level the K-blocks (source slot, matrix) of every live node update
+    hp->cops.clear();
+    hp->crefs.clear();
+    {
+        std::vector<std::pair<int, int> > work;      // (ops of the whole chain, batch)
+        for (int i = 0; i < nb; ++i) {
+            const BatchDev &d = sd.b[i];
+            const TmplArgs &tp = d.tp;
+            ChainBatch &cbt = hp->cbatch[i];
+            memset(&cbt, 0, sizeof(cbt));
+            const int first_op = (int)hp->cops.size();
+            for (int dir = 0; dir < 2; ++dir)
+                for (int p = 0; p < d.L; ++p) {
+                    (dir ? cbt.bwd_off : cbt.fwd_off)[p] = (int)hp->cops.size();
+                    const unsigned lin = d.live[p], lout = d.live[p + 1];
+                    for (int n = 0; n < tp.N; ++n) {
+                        if (!(((dir ? lin : lout) >> n) & 1u)) continue;
+                        const size_t begin = hp->cops.size();
+                        for (int e = 0; e < tp.E; ++e) {
+                            if (!dir && tp.dst[e] == n) hp->cops.push_back(ChainOp{tp.src[e], n, (int)tp.rel[e], 0});
+                            if (dir && tp.src[e] == n && ((lout >> tp.dst[e]) & 1u))
+                                hp->cops.push_back(ChainOp{tp.dst[e], n, (int)tp.rel[e], 0});
+                        }
+                        if (!dir || ((lout >> n) & 1u)) hp->cops.push_back(ChainOp{n, n, -1, 0});
+                        hp->cops[begin].flags |= CH_FIRST;
+                        hp->cops.back().flags |= CH_LAST;
+                    }
+                    (dir ? cbt.bwd_off : cbt.fwd_off)[p + 1] = (int)hp->cops.size();
+                }
+            work.push_back(std::make_pair((int)hp->cops.size() - first_op, i));
+        }
+        std::stable_sort(work.begin(), work.end(),
+                         [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first > b.first; });
+        for (size_t k = 0; k < work.size(); ++k)
+            for (int g0 = 0; g0 < sd.b[work[k].second].B; g0 += CH_GB) hp->crefs.push_back(ChainRef{work[k].second, g0});
+    }
+
     // workspace layout
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -986,6 +1041,9 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
             hp->o_tf[l][p] = take(hp->tfwd[l][p].size() * sizeof(TileRef));
             hp->o_tb[l][p] = take(hp->tbwd[l][p].size() * sizeof(TileRef));
         }
+    hp->o_cref = take(hp->crefs.size() * sizeof(ChainRef));
+    hp->o_cops = take(hp->cops.size() * sizeof(ChainOp));
+    hp->o_cbatch = take(sizeof(hp->cbatch));
     hp->desc_total = off;
     off = 0;
     hp->o_H = take((size_t)(hp->Lmax + 1) * rows * D * 4);
@@ -1072,6 +1130,19 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                                           size_t workspace_bytes, int32_t *err, const mpqe_step_lanes_t *lanes,
                                           void *const *events, int num_events, void *stream) {
     if (!P || !B || nb < 1 || nb > MPQE_STEP_MAX_BATCHES || !desc) return MPQE_ERR_INVALID_ARG;
+    // Chain kernels (step_chain.h): D = 64 / 128 / 256 with 16-byte aligned weights, and a step small
+    // enough that per-level launches cannot fill the chip (above CHAIN_MAX_GRAPHS the 64x64-tile level
+    // kernels re-use each weight tile 4x more often and win). The chain runs all batches in one launch,
+    // so stream lanes do not apply to it.
+    bool use_chain = !(P->flags & MPQE_STEP_NO_CHAIN) && (P->dim == 64 || P->dim == 128 || P->dim == 256);
+    if (use_chain) {
+        long long graphs = 0;
+        for (int i = 0; i < nb; ++i) graphs += B[i].batch_size;
+        use_chain = graphs <= CHAIN_MAX_GRAPHS;
+        for (int l = 0; use_chain && l < P->num_layers && l < MPQE_STEP_MAX_LAYERS; ++l)
+            use_chain = P->basis[l] && P->root[l] && ptr_vec_ok(P->basis[l], P->dim) && ptr_vec_ok(P->root[l], P->dim);
+    }
+    if (use_chain) lanes = nullptr;
     // The launch plan is a pure function of the descriptors; it is kept on the host next to the device
     // table it describes (same key: the caller's desc buffer), so a steady-state call costs one lookup.
     std::shared_ptr<const CachedPlan> cached;
@@ -1163,7 +1234,26 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                 upload(s, db + hp.o_tf[l][p], hp.tfwd[l][p].data(), hp.tfwd[l][p].size() * sizeof(TileRef));
                 upload(s, db + hp.o_tb[l][p], hp.tbwd[l][p].data(), hp.tbwd[l][p].size() * sizeof(TileRef));
             }
+        upload(s, db + hp.o_cref, hp.crefs.data(), hp.crefs.size() * sizeof(ChainRef));
+        upload(s, db + hp.o_cops, hp.cops.data(), hp.cops.size() * sizeof(ChainOp));
+        upload(s, db + hp.o_cbatch, hp.cbatch, sizeof(hp.cbatch));
     }
+    const ChainRef *crefs = reinterpret_cast<const ChainRef *>(db + hp.o_cref);
+    const ChainOp *cops = reinterpret_cast<const ChainOp *>(db + hp.o_cops);
+    const ChainBatch *cbatch = reinterpret_cast<const ChainBatch *>(db + hp.o_cbatch);
+#define LAUNCH_CHAIN(BWD, XP, MASKP)                                                                                  \
+    do {                                                                                                              \
+        dim3 cgrid((unsigned)hp.crefs.size());                                                                        \
+        if (D == 64)                                                                                                  \
+            hipLaunchKernelGGL((step_chain_kernel<1, BWD>), cgrid, dim3(256), 0, s, sd, lp, crefs, cbatch, cops, XP,  \
+                               MASKP, hp.level_stride);                                                               \
+        else if (D == 128)                                                                                            \
+            hipLaunchKernelGGL((step_chain_kernel<2, BWD>), cgrid, dim3(256), 0, s, sd, lp, crefs, cbatch, cops, XP,  \
+                               MASKP, hp.level_stride);                                                               \
+        else                                                                                                          \
+            hipLaunchKernelGGL((step_chain_kernel<4, BWD>), cgrid, dim3(256), 0, s, sd, lp, crefs, cbatch, cops, XP,  \
+                               MASKP, hp.level_stride);                                                               \
+    } while (0)
     float *H = reinterpret_cast<float *>(wb + hp.o_H), *GH = reinterpret_cast<float *>(wb + hp.o_GH);
     float *tpos = reinterpret_cast<float *>(wb + hp.o_tpos), *tneg = reinterpret_cast<float *>(wb + hp.o_tneg);
     float *spos = scores_pos ? scores_pos : reinterpret_cast<float *>(wb + hp.o_spos);
@@ -1197,7 +1287,12 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                            ls[l], sd, tabs, nm, (long long)P->node_map_len, P->mode_emb, (long long)P->num_modes, ids,
                            tg, ng, H, tpos, tneg, err, vec_tab, row0[l], nr, gr0[l], ngr);
     }
-    for (int p = 0; p < hp.Lmax; ++p)
+    if (use_chain) {
+        mark(s);
+        LAUNCH_CHAIN(false, H, (const float *)nullptr);
+        mark(s);
+    }
+    for (int p = 0; !use_chain && p < hp.Lmax; ++p)
         for (int l = 0; l < NL; ++l) {
             if (p >= hp.lane_Lmax[l]) continue;
             const float *hin = H + (long long)p * hp.level_stride;
@@ -1242,7 +1337,13 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     for (int l = 0; l < NL; ++l) { LAUNCH_SCORE_D(true, GH, l); }
 #undef LAUNCH_SCORE_D
 #undef LAUNCH_SCORE
-    for (int p = hp.Lmax - 1; p >= 0; --p)
+    if (use_chain) {
+        mark(s);
+        LAUNCH_CHAIN(true, GH, (const float *)H);
+        mark(s);
+    }
+#undef LAUNCH_CHAIN
+    for (int p = hp.Lmax - 1; !use_chain && p >= 0; --p)
         for (int l = 0; l < NL; ++l) {
             if (p >= hp.lane_Lmax[l]) continue;
             const float *gout = GH + (long long)(p + 1) * hp.level_stride;

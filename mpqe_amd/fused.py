@@ -32,6 +32,33 @@ def _batch_work(query_type, passes):
     return passes * e_n
 
 
+_TEMPLATES = {   # query type -> (num anchors, num nodes, [(src, dst)]) : reference data_utils.py:325-362
+    '1-chain': (1, 2, [(0, 1)]), '2-chain': (1, 3, [(0, 2), (2, 1)]), '3-chain': (1, 4, [(0, 3), (3, 2), (2, 1)]),
+    '2-inter': (2, 3, [(0, 2), (1, 2)]), '3-inter': (3, 4, [(0, 3), (1, 3), (2, 3)]),
+    '3-inter_chain': (2, 4, [(0, 2), (1, 3), (3, 2)]), '3-chain_inter': (2, 4, [(0, 3), (1, 3), (3, 2)])}
+CHAIN_MAX_GRAPHS = 32768          # csrc/step.hip
+
+
+def live_units(query_type, passes, readout, prune=True):
+    """GEMM units ([B, D] x [D, D] products) the fused step executes per pass for one formula batch:
+    units[p] = edges whose destination state is live after pass p + live node slots (self terms). A
+    state is live when it can reach the readout (host mirror of the liveness masks in csrc/step.hip);
+    without pruning every pass has E + N units. Forward, backward-x and the weight
+    gradient each execute exactly these units."""
+    A, N, edges = _TEMPLATES[query_type]
+    full = (1 << N) - 1
+    live = (1 << A) if (prune and readout == 'mp') else full
+    units = [0] * passes
+    for p in range(passes - 1, -1, -1):
+        units[p] = sum(1 for s, d in edges if (live >> d) & 1) + bin(live).count('1')
+        nxt = live
+        for s, d in edges:
+            if (live >> d) & 1:
+                nxt |= 1 << s
+        live = nxt if prune else full
+    return units
+
+
 class FusedTrainStep(object):
     """lanes: number of HIP streams a step is spread over (1 = everything on the current stream).
     A step is a chain of ~13 dependent, very short launches; with lanes > 1 the batches are split
@@ -186,6 +213,11 @@ class FusedTrainStep(object):
         ps.desc_ptr = (ps.desc.data_ptr() + 255) // 256 * 256
         ps.desc_resident = False
         return ps
+
+    def uses_chain(self, packed):
+        """True when the library runs the graph-block chain kernels for this step (csrc/step.hip)."""
+        return (not (self.flags & _capi.STEP_NO_CHAIN) and self.model.emb_dim in (64, 128, 256)
+                and packed.num_graphs <= CHAIN_MAX_GRAPHS)
 
     def _workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes + 256:

@@ -93,6 +93,21 @@ void mfma_32x32x2(float a, float b, float *c) {
     wave_barrier();
 }
 
+void mfma_16x16x4(float a, float b, float *c) {
+    const int w = g_cur->tid / 64, lane = g_cur->tid % 64;
+    g_xa[w][lane] = a;
+    g_xb[w][lane] = b;
+    wave_barrier();
+    const int col = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (lane >> 4) + r;
+        float d = c[r];
+        for (int k = 0; k < 4; ++k) d = fmaf(g_xa[w][row + 16 * k], g_xb[w][col + 16 * k], d);
+        c[r] = d;
+    }
+    wave_barrier();
+}
+
 void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
     const unsigned nthreads = block.x * block.y * block.z;
     if (nthreads == 0 || nthreads > 1024) {

@@ -11,6 +11,7 @@
 // MI355X guide: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], D col=l&31 row=(r&3)+8(r>>2)+4(l>>5),
 // evaluated as a k-ordered fmaf chain), hipLaunchKernelGGL, hipMemsetAsync/hipMemcpyAsync.
 #pragma once
+#define MPQE_EMU 1
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -62,6 +63,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body);
 void block_barrier();
 float wave_exchange(float v, int src_lane_xor, int mode, int arg);
 void mfma_32x32x2(float a, float b, float *c16);
+void mfma_16x16x4(float a, float b, float *c4);
 }  // namespace emu
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
@@ -115,6 +117,15 @@ static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, 
     for (int i = 0; i < 16; ++i) c[i] = t[i];
     return c;
 }
+// v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D col=l&15 row=4(l>>4)+r, k-ordered fmaf chain
+typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
+static inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c, int, int, int) {
+    float t[4];
+    for (int i = 0; i < 4; ++i) t[i] = c[i];
+    emu::mfma_16x16x4(a, b, t);
+    for (int i = 0; i < 4; ++i) c[i] = t[i];
+    return c;
+}
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 // LDS-DMA: every lane copies `size` bytes from its own global address to (wave-uniform base + lane*size)
 static inline void __builtin_amdgcn_global_load_lds(const void __attribute__((address_space(1))) * g,
@@ -125,6 +136,7 @@ static inline void __builtin_amdgcn_global_load_lds(const void __attribute__((ad
     memcpy(dst, src, size);
 }
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
+static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_s_barrier() { emu::block_barrier(); }
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }

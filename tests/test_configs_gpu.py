@@ -45,6 +45,18 @@ def sub(b, idx):
                 negs=b['negs'][idx], weight=b['weight'])
 
 
+def close_enough(got, ref, readout, name):
+    """rtol 1e-4 / atol 2e-6; with the max readout the two paths sum K in different orders, so a near-tie
+    between two node states can pick the other node in one of them (a discrete, equally valid argmax): up
+    to 0.01 % of a tensor's elements may then differ, by at most 1e-3."""
+    if readout != 'max':
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-6, err_msg=name)
+        return
+    bad = np.abs(got - ref) > 2e-6 + 1e-4 * np.abs(ref)
+    assert bad.mean() <= 1e-4, (name, bad.sum())
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-3, err_msg=name)
+
+
 def grads(model):
     return {k: p.grad.detach().clone() for k, p in model.named_parameters()}
 
@@ -82,7 +94,7 @@ def test_full_mix_fused_equals_modules_and_oracle(kg, D, readout, adaptive):
     np.testing.assert_allclose(loss[0].item(), total.item(), rtol=1e-5, atol=1e-6)
     for k, p in model.named_parameters():
         ref = torch.zeros_like(p) if p.grad is None else p.grad
-        np.testing.assert_allclose(g_fused[k].cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+        close_enough(g_fused[k].cpu().numpy(), ref.cpu().numpy(), readout, k)
     # the oracle (reference op sequence) on a sub-batch of one formula, full width, full KG
     b = sub(batches[5], np.arange(96))
     cfg = dict(readout=readout, scatter_op='add', num_layers=3, adaptive=adaptive, weight_decay=0)

@@ -222,6 +222,42 @@ def test_fused_step_pruning_changes_nothing(be, readout, adaptive, L):
     assert got[4] == 0 and full[4] == 0
 
 
+CHAIN_MIX = [('3-chain', 21, 1.0), ('3-inter_chain', 16, 0.5), ('1-chain', 35, 0.25), ('3-chain_inter', 7, 2.0),
+             ('2-inter', 48, 0.1)]
+
+
+@pytest.mark.parametrize('D,readout,adaptive,shared,L', [(64, 'mp', True, False, 3), (64, 'sum', False, True, 2),
+                                                         (128, 'mp', True, False, 3), (128, 'max', False, False, 3),
+                                                         (256, 'mp', True, True, 3)])
+def test_fused_step_chain_kernels(be, D, readout, adaptive, shared, L):
+    """The graph-block chain kernels (all levels of 16 graphs in one workgroup; D = 64 / 128 / 256) against
+    the oracle and against the one-launch-per-level form (MPQE_STEP_NO_CHAIN): ragged batch sizes, every
+    readout family, pruned and unpruned."""
+    mix = CHAIN_MIX if D < 256 else CHAIN_MIX[:2]
+    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(17, D, L, shared, mix, readout, adaptive)
+    ref_loss, ref_per, ref_sp, ref_sn = oracle_step(params, cfg, node_map, batches, 1.0)
+    got = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0)
+    lev = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_NO_CHAIN)
+    runs = [got, lev]
+    if D == 64:
+        runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_NO_PRUNE))
+    for r in runs:
+        assert r[4] == 0
+        np.testing.assert_allclose(r[1], ref_sp, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(r[2], ref_sn, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(r[0][0], ref_loss, rtol=1e-5, atol=1e-6)
+        seen = set()
+        for k, p in params.items():
+            if id(p) in seen:
+                continue
+            seen.add(id(p))
+            ref = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
+            np.testing.assert_allclose(r[3][k], ref, rtol=1e-4, atol=2e-6, err_msg=k)
+    # forward only
+    fwd = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, backward=0)
+    np.testing.assert_array_equal(fwd[0], got[0])
+
+
 @pytest.mark.parametrize('splits', [[0, 3, 7], [0, 1, 2, 4, 7], [0, 6, 7]])
 def test_fused_step_stream_lanes(be, splits):
     """Lanes (batches split over streams) change scheduling only: same loss, scores and gradients."""
