@@ -128,7 +128,7 @@ def time_fused_kernels(step, packed, data, model, readout, reps=20):
     total = sum(flops(0, len(tmpl), p) for p in range(Lmax))
     plan = []                                            # (kernel, flops) per event pair, in library order
     if step.uses_chain(packed):
-        plan += [('step_chain_kernel<fwd>', total), ('step_chain_kernel<bwd>', total)]
+        plan += [('step_chain_kernel', 2.0 * total)]      # forward + backward-x levels (+ gather, scores) in one launch
     else:
         lanes = [(packed.lane_begin[l], packed.lane_begin[l + 1]) for l in range(len(packed.lane_begin) - 1)]
         for p in range(Lmax):

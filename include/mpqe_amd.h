@@ -217,6 +217,9 @@ int mpqe_hinge_bwd(const float *pos, const float *neg, int64_t n, float margin, 
  * NO_CHAIN  one launch per message-passing level instead of the graph-block chain kernels.      */
 #define MPQE_STEP_NO_PRUNE 1
 #define MPQE_STEP_NO_CHAIN 2
+/* ZERO_GRADS  the call zero-fills every buffer of `grads` before accumulating into it (one launch shared
+ *             with the step's other prologue work, instead of a memset per buffer by the caller).    */
+#define MPQE_STEP_ZERO_GRADS 4
 
 typedef struct {
     int32_t query_type;        /* MPQE_Q_*                                                     */
@@ -283,8 +286,9 @@ size_t mpqe_step_desc_bytes(const mpqe_step_params_t *params_host, const mpqe_st
  * launch, in this order: for level 0..Lmax-1, for each lane that has the level: layer forward; for level
  * Lmax-1..0, for each such lane: backward-x; then the weight-gradient launch. When the graph-block chain
  * kernels run (dim 64 / 128 / 256, at most 32768 query graphs in the step, MPQE_STEP_NO_CHAIN clear; lanes
- * are then ignored) the order is: forward chain, backward chain, weight-gradient launch. Fewer are filled
- * as far as they go. For roofline accounting only.                                                 */
+ * are then ignored; every batch has at most 5 passes) the order is: the chain launch (assemble, levels
+ * forward, scores, levels backward), then the weight-gradient launch. Fewer are filled as far as they go.
+ * For roofline accounting only.                                                                     */
 int mpqe_step_forward_backward(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,
                                int num_batches, const int64_t *anchor_ids, const int64_t *targets,
                                const int64_t *negs, float margin, const mpqe_step_grads_t *grads_host,
@@ -293,6 +297,12 @@ int mpqe_step_forward_backward(const mpqe_step_params_t *params_host, const mpqe
                                void *workspace, size_t workspace_bytes, int32_t *err,
                                const mpqe_step_lanes_t *lanes, void *const *events, int num_events,
                                void *stream);
+
+/* Diagnostics, not part of the data path: while `device_buffer` (8 int64 per workgroup, num_blocks
+ * workgroups) is set, every chain-kernel launch with at most num_blocks workgroups writes per workgroup the
+ * device wall clock (100 MHz) at its phase boundaries [0..6] and HW_ID | XCC_ID << 32 in [7]. NULL turns it
+ * off. Process-global; used by tools/chain_timeline.py only.                                        */
+void mpqe_debug_chain_stamps(void *device_buffer, size_t num_blocks);
 
 #ifdef __cplusplus
 }

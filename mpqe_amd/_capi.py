@@ -85,6 +85,7 @@ PROTOTYPES = {
     'mpqe_cosine_bwd': (I, [P, P, P, P, L, L, F, P, P, P]),
     'mpqe_hinge_fwd': (I, [P, P, L, F, P, P]),
     'mpqe_hinge_bwd': (I, [P, P, L, F, P, P, P, P]),
+    'mpqe_debug_chain_stamps': (None, [P, Z]),
     'mpqe_step_workspace_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I]),
     'mpqe_step_desc_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I]),
     'mpqe_step_forward_backward': (I, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, P, P, P, F,
@@ -125,7 +126,7 @@ def check(cdll, status, what):
         raise MpqeError('%s failed: %s (%d)' % (what, msg.decode() if msg else '?', status))
 
 
-STEP_NO_PRUNE, STEP_NO_CHAIN = 1, 2
+STEP_NO_PRUNE, STEP_NO_CHAIN, STEP_ZERO_GRADS = 1, 2, 4
 
 
 def make_step_params(dim, num_relations, readout, table_ptrs, table_rows, node_map_ptr, node_map_len,

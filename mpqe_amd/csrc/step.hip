@@ -127,18 +127,6 @@ __device__ __forceinline__ const float *pick_layer(const float *const *arr, int 
     return r;
 }
 
-#include "step_chain.h"
-
-template <int NCB, bool BWD>
-__global__ __launch_bounds__(256) void step_chain_kernel(const StepDev *__restrict__ sd, LayerPtrs lp,
-                                                         const ChainRef *__restrict__ refs,
-                                                         const ChainBatch *__restrict__ cbs,
-                                                         const ChainOp *__restrict__ ops, float *__restrict__ X,
-                                                         const float *__restrict__ Hmask, long long level_stride) {
-    __shared__ __attribute__((aligned(16))) float xs[2 * 4 * CH_GB * (64 * NCB + 4)];
-    chain_block<NCB, BWD>(sd, lp, refs, cbs, ops, X, Hmask, level_stride, xs);
-}
-
 __device__ __forceinline__ int find_group_le(const TileGroup *__restrict__ g, int n, int t) {
     int lo = 0, hi = n - 1;     // largest i in [0, n) with g[i].tile_off <= t
     while (lo < hi) {
@@ -166,6 +154,72 @@ __device__ __forceinline__ long long table_row(const long long *__restrict__ nod
         return -1;
     }
     return r;
+}
+
+#include "step_chain.h"
+
+template <int NCB>
+__global__ __launch_bounds__(256) void step_chain_kernel(const StepDev *__restrict__ sd, LayerPtrs lp, TablePtrs tabs,
+                                                         ChainArgs ca) {
+    __shared__ __attribute__((aligned(16))) ChainLds<NCB> S;
+    chain_block<NCB>(sd, lp, tabs, ca, S);
+}
+
+// Step prologue, one launch: (a) transposed copies of the matrices the backward chains multiply by (32x32
+// tiles through LDS; ~35 matrices of 64 KB in the AIFB step), (b) with MPQE_STEP_ZERO_GRADS, zero fill of
+// every gradient buffer (what the caller's memset would do).
+struct WtSlot {
+    int layer, mat;       // mat < 0: root
+};
+#define PREP_MAX_SEGS 48
+struct ZeroSegs {
+    float *p[PREP_MAX_SEGS];
+    long long n[PREP_MAX_SEGS];       // floats
+    long long block0[PREP_MAX_SEGS + 1];   // first zero-fill workgroup of each segment
+    int count;
+};
+#define PREP_ZERO_FLOATS_PER_BLOCK 8192      // 256 threads x 8 x float4
+__global__ __launch_bounds__(256) void step_prep_kernel(LayerPtrs lp, const WtSlot *__restrict__ slots, int nslots, int D,
+                                                        float *__restrict__ WT, int tblocks, ZeroSegs zs) {
+    __shared__ float tile[32][33];
+    const int bid = blockIdx.x;
+    if (bid < tblocks) {
+        const int tpd = (D + 31) / 32, per = tpd * tpd;
+        const int si = bid / per, tr = (bid % per) / tpd, tc = bid % tpd;
+        const WtSlot sl = slots[si];
+        const float *W = sl.mat >= 0 ? pick_layer(lp.basis, sl.layer) + (long long)sl.mat * D * D
+                                     : pick_layer(lp.root, sl.layer);
+        float *T = WT + (long long)si * D * D;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+        for (int r = ty; r < 32; r += 8) {
+            const int row = tr * 32 + r, col = tc * 32 + tx;
+            tile[r][tx] = row < D && col < D ? W[(long long)row * D + col] : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int row = tc * 32 + r, col = tr * 32 + tx;               // T[col of W][row of W]
+            if (row < D && col < D) T[(long long)row * D + col] = tile[tx][r];
+        }
+        return;
+    }
+    const long long zb = bid - tblocks;
+    int sg = 0;
+    for (int i = 1; i < zs.count; ++i)
+        if (zs.block0[i] <= zb) sg = i;
+    const long long base = (zb - zs.block0[sg]) * PREP_ZERO_FLOATS_PER_BLOCK;
+    float *p = zs.p[sg];
+    const long long n = zs.n[sg];
+    if (((uintptr_t)p & 15) == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const long long i = base + (long long)(threadIdx.x + 256 * k) * 4;
+            if (i + 3 < n) *reinterpret_cast<f32x4 *>(p + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+            else
+                for (long long q = i; q < n; ++q) p[q] = 0.f;
+        }
+    } else {
+        for (long long i = base + threadIdx.x; i < base + PREP_ZERO_FLOATS_PER_BLOCK && i < n; i += 256) p[i] = 0.f;
+    }
 }
 
 // rows [0, rows_total) are node rows of H0, then G positive and G negative targets. D/4 adjacent lanes
@@ -699,8 +753,8 @@ struct HostPlan {
     // graph-block chain kernels (step_chain.h): one entry per workgroup, heaviest blocks first
     std::vector<ChainRef> crefs;
     std::vector<ChainOp> cops;
-    ChainBatch cbatch[MPQE_STEP_MAX_BATCHES];
-    size_t o_cref, o_cops, o_cbatch;
+    std::vector<WtSlot> wt_slots;     // matrices with a transposed copy (those of the backward programmes)
+    size_t o_cref, o_cops, o_wtslots, o_WT;
     // workspace offsets (bytes)
     size_t o_sd, o_wsrc, o_wblock, o_vsrc, o_vblock, o_groups, o_anchor, desc_total;     // descriptor buffer
     size_t o_H, o_GH, o_tpos, o_tneg, o_spos, o_sneg, o_terms, o_slabs, o_parts, total;  // workspace
@@ -726,6 +780,7 @@ void pick_chunks(long long count, int max_chunks, int *nch, int *ch) {
 // b on CU b % STEP_CUS: give each to the least-loaded CU that still has a free position; the rest
 // follow in descending order and are picked up by whichever CU drains first.
 #define STEP_CUS 256
+#define STEP_XCDS 8
 #define STEP_RESIDENT 4
 void place_tiles(const std::vector<TileRef> &in, const std::vector<int> &steps, std::vector<TileRef> &out) {
     const size_t n = in.size();
@@ -984,41 +1039,108 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->vblocks_total = vblock;
     hp->total_parts = part;
 
-    // chain programmes: per batch and level the K-blocks (source slot, matrix) of every live node update
+    // chain programmes: per batch the K-blocks (source slot, matrix) of every live node update, forward levels
+    // 0 .. L-1 then backward levels L-1 .. 0, in execution order
     hp->cops.clear();
     hp->crefs.clear();
+    hp->wt_slots.clear();
     {
-        std::vector<std::pair<int, int> > work;      // (ops of the whole chain, batch)
+        struct Prog {
+            int work, batch, fb, fc, bb, bc;
+        };
+        std::vector<Prog> progs;
         for (int i = 0; i < nb; ++i) {
             const BatchDev &d = sd.b[i];
             const TmplArgs &tp = d.tp;
-            ChainBatch &cbt = hp->cbatch[i];
-            memset(&cbt, 0, sizeof(cbt));
-            const int first_op = (int)hp->cops.size();
-            for (int dir = 0; dir < 2; ++dir)
-                for (int p = 0; p < d.L; ++p) {
-                    (dir ? cbt.bwd_off : cbt.fwd_off)[p] = (int)hp->cops.size();
+            Prog pr;
+            pr.batch = i;
+            for (int dir = 0; dir < 2; ++dir) {
+                const int begin = (int)hp->cops.size();
+                for (int q = 0; q < d.L; ++q) {
+                    const int p = dir ? d.L - 1 - q : q;
+                    const int li = p < d.L - 1 ? p : P->num_layers - 1;
                     const unsigned lin = d.live[p], lout = d.live[p + 1];
+                    int lvl_flags = 0;
+                    if (!dir && p < d.L - 1) lvl_flags |= CH_RELU;
+                    if (dir && p >= 1) lvl_flags |= CH_MASK;
                     for (int n = 0; n < tp.N; ++n) {
                         if (!(((dir ? lin : lout) >> n) & 1u)) continue;
-                        const size_t begin = hp->cops.size();
+                        const size_t first = hp->cops.size();
+                        auto push = [&](int src, int mat) {
+                            ChainOp op;
+                            op.src = (unsigned char)src;
+                            op.node = (unsigned char)n;
+                            op.layer = (unsigned char)li;
+                            op.level = (unsigned char)(dir ? p : p + 1);
+                            op.mat = mat;
+                            op.flags = lvl_flags;
+                            op.wt_slot = 0;
+                            if (dir) {      // shared layers alias one parameter set: one copy per unique (layer, matrix)
+                                size_t k = 0;
+                                for (; k < hp->wt_slots.size(); ++k)
+                                    if (hp->wt_slots[k].layer == uid[li] && hp->wt_slots[k].mat == mat) break;
+                                if (k == hp->wt_slots.size()) hp->wt_slots.push_back(WtSlot{uid[li], mat});
+                                op.wt_slot = (int)k;
+                            }
+                            hp->cops.push_back(op);
+                        };
                         for (int e = 0; e < tp.E; ++e) {
-                            if (!dir && tp.dst[e] == n) hp->cops.push_back(ChainOp{tp.src[e], n, (int)tp.rel[e], 0});
-                            if (dir && tp.src[e] == n && ((lout >> tp.dst[e]) & 1u))
-                                hp->cops.push_back(ChainOp{tp.dst[e], n, (int)tp.rel[e], 0});
+                            if (!dir && tp.dst[e] == n) push(tp.src[e], (int)tp.rel[e]);
+                            if (dir && tp.src[e] == n && ((lout >> tp.dst[e]) & 1u)) push(tp.dst[e], (int)tp.rel[e]);
                         }
-                        if (!dir || ((lout >> n) & 1u)) hp->cops.push_back(ChainOp{n, n, -1, 0});
-                        hp->cops[begin].flags |= CH_FIRST;
+                        if (!dir || ((lout >> n) & 1u)) push(n, -1);
+                        hp->cops[first].flags |= CH_FIRST;
                         hp->cops.back().flags |= CH_LAST;
                     }
-                    (dir ? cbt.bwd_off : cbt.fwd_off)[p + 1] = (int)hp->cops.size();
+                    hp->cops.back().flags |= CH_LEVEL_END;
                 }
-            work.push_back(std::make_pair((int)hp->cops.size() - first_op, i));
+                (dir ? pr.bb : pr.fb) = begin;
+                (dir ? pr.bc : pr.fc) = (int)hp->cops.size() - begin;
+            }
+            pr.work = pr.fc + pr.bc;
+            progs.push_back(pr);
         }
-        std::stable_sort(work.begin(), work.end(),
-                         [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first > b.first; });
-        for (size_t k = 0; k < work.size(); ++k)
-            for (int g0 = 0; g0 < sd.b[work[k].second].B; g0 += CH_GB) hp->crefs.push_back(ChainRef{work[k].second, g0});
+        // Placement (speed only, results never depend on it). Workgroups are dealt round-robin over the 8 XCDs
+        // (block i -> XCD i % 8, measured) and each XCD has its own 4 MB L2, which cannot hold the weight
+        // matrices of all batches plus their transposed copies: so every batch is given to ONE XCD (all its
+        // blocks multiply by the same few matrices: one fetch per XCD, L2 hits for the other blocks), batches
+        // dealt to XCDs heaviest first onto the least loaded. Inside an XCD (32 CUs; block k of the XCD shares
+        // its CU with block k + 32, measured) the heaviest blocks run alone and the lightest pair up.
+        // Grid = 8 x (largest XCD list); the holes are refs with batch = -1 (the workgroup exits at once).
+        std::stable_sort(progs.begin(), progs.end(), [](const Prog &a, const Prog &b) { return a.work > b.work; });
+        std::vector<ChainRef> bins[STEP_XCDS];
+        long long load[STEP_XCDS] = {0};
+        const size_t cus = STEP_CUS / STEP_XCDS;
+        for (size_t k = 0; k < progs.size(); ++k) {          // a big batch goes out in chunks of one block per CU
+            const int Bk = sd.b[progs[k].batch].B;
+            for (int c0 = 0; c0 < Bk; c0 += (int)cus * CH_GB) {
+                int best = 0;
+                for (int x = 1; x < STEP_XCDS; ++x)
+                    if (load[x] < load[best]) best = x;
+                for (int g0 = c0; g0 < Bk && g0 < c0 + (int)cus * CH_GB; g0 += CH_GB) {   // progs is sorted: bins stay sorted
+                    bins[best].push_back(
+                        ChainRef{progs[k].batch, g0, progs[k].fb, progs[k].fc, progs[k].bb, progs[k].bc, 0, 0});
+                    load[best] += progs[k].work;
+                }
+            }
+        }
+        size_t longest = 0;
+        for (int x = 0; x < STEP_XCDS; ++x) {
+            std::vector<ChainRef> &v = bins[x];
+            const size_t n = v.size();
+            if (n > cus && n <= 2 * cus) {
+                std::vector<ChainRef> o;
+                const size_t R = n - cus;                   // CUs that take two blocks
+                for (size_t k = 0; k < R; ++k) o.push_back(v[n - 2 * R + k]);           // heavier of a pair
+                for (size_t k = 0; k < n - 2 * R; ++k) o.push_back(v[k]);               // alone
+                for (size_t k = 0; k < R; ++k) o.push_back(v[n - 1 - k]);               // its light partner
+                v.swap(o);
+            }
+            if (n > longest) longest = n;
+        }
+        for (size_t k = 0; k < longest; ++k)
+            for (int x = 0; x < STEP_XCDS; ++x)
+                hp->crefs.push_back(k < bins[x].size() ? bins[x][k] : ChainRef{-1, 0, 0, 0, 0, 0, 0, 0});
     }
 
     // workspace layout
@@ -1043,7 +1165,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         }
     hp->o_cref = take(hp->crefs.size() * sizeof(ChainRef));
     hp->o_cops = take(hp->cops.size() * sizeof(ChainOp));
-    hp->o_cbatch = take(sizeof(hp->cbatch));
+    hp->o_wtslots = take(hp->wt_slots.size() * sizeof(WtSlot));
     hp->desc_total = off;
     off = 0;
     hp->o_H = take((size_t)(hp->Lmax + 1) * rows * D * 4);
@@ -1055,6 +1177,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->o_terms = take((size_t)graphs * 4);
     hp->o_slabs = take((size_t)hp->total_slabs * D * D * 4);
     hp->o_parts = take((size_t)hp->total_parts * D * 4);
+    hp->o_WT = take(hp->wt_slots.size() * (size_t)D * D * 4);
     hp->total = off;
     return MPQE_OK;
 }
@@ -1087,7 +1210,7 @@ void make_key(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
               PlanKey *k) {
     memset(k, 0, sizeof(*k));
     k->dim = P->dim; k->num_layers = P->num_layers; k->num_relations = P->num_relations;
-    k->num_modes = P->num_modes; k->readout = P->readout; k->flags = P->flags; k->nb = nb;
+    k->num_modes = P->num_modes; k->readout = P->readout; k->flags = P->flags & ~MPQE_STEP_ZERO_GRADS; k->nb = nb;
     k->nlanes = lanes ? lanes->num_lanes : 1;
     if (lanes)
         for (int l = 0; l <= MPQE_STEP_MAX_LANES; ++l) k->lane_begin[l] = lanes->batch_begin[l];
@@ -1109,6 +1232,14 @@ void make_key(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
 }
 
 }  // namespace
+
+// diagnostics: phase time stamps of the chain kernel's workgroups (tools/chain_timeline.py)
+static long long *g_chain_stamps = nullptr;
+static size_t g_chain_stamp_blocks = 0;
+extern "C" void mpqe_debug_chain_stamps(void *device_buffer, size_t num_blocks) {
+    g_chain_stamps = reinterpret_cast<long long *>(device_buffer);
+    g_chain_stamp_blocks = num_blocks;
+}
 
 extern "C" size_t mpqe_step_workspace_bytes(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb) {
     HostPlan hp;
@@ -1138,9 +1269,14 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     if (use_chain) {
         long long graphs = 0;
         for (int i = 0; i < nb; ++i) graphs += B[i].batch_size;
-        use_chain = graphs <= CHAIN_MAX_GRAPHS;
-        for (int l = 0; use_chain && l < P->num_layers && l < MPQE_STEP_MAX_LAYERS; ++l)
+        use_chain = graphs <= CHAIN_MAX_GRAPHS && P->num_layers <= MPQE_STEP_MAX_LAYERS;
+        // (5 passes x (3 edges + 4 nodes) x 2 directions = 70 ops <= CH_MAX_OPS)
+        for (int i = 0; i < nb; ++i) use_chain = use_chain && B[i].num_passes <= CH_MASK_LEVELS + 1;
+        for (int l = 0; use_chain && l < P->num_layers; ++l)
             use_chain = P->basis[l] && P->root[l] && ptr_vec_ok(P->basis[l], P->dim) && ptr_vec_ok(P->root[l], P->dim);
+        for (int m = 0; use_chain && m < P->num_modes && m < MPQE_STEP_MAX_MODES; ++m)
+            use_chain = P->tables[m] && (uintptr_t)P->tables[m] % 16 == 0;
+        use_chain = use_chain && P->mode_emb && (uintptr_t)P->mode_emb % 16 == 0;
     }
     if (use_chain) lanes = nullptr;
     // The launch plan is a pure function of the descriptors; it is kept on the host next to the device
@@ -1236,24 +1372,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             }
         upload(s, db + hp.o_cref, hp.crefs.data(), hp.crefs.size() * sizeof(ChainRef));
         upload(s, db + hp.o_cops, hp.cops.data(), hp.cops.size() * sizeof(ChainOp));
-        upload(s, db + hp.o_cbatch, hp.cbatch, sizeof(hp.cbatch));
+        upload(s, db + hp.o_wtslots, hp.wt_slots.data(), hp.wt_slots.size() * sizeof(WtSlot));
     }
-    const ChainRef *crefs = reinterpret_cast<const ChainRef *>(db + hp.o_cref);
-    const ChainOp *cops = reinterpret_cast<const ChainOp *>(db + hp.o_cops);
-    const ChainBatch *cbatch = reinterpret_cast<const ChainBatch *>(db + hp.o_cbatch);
-#define LAUNCH_CHAIN(BWD, XP, MASKP)                                                                                  \
-    do {                                                                                                              \
-        dim3 cgrid((unsigned)hp.crefs.size());                                                                        \
-        if (D == 64)                                                                                                  \
-            hipLaunchKernelGGL((step_chain_kernel<1, BWD>), cgrid, dim3(256), 0, s, sd, lp, crefs, cbatch, cops, XP,  \
-                               MASKP, hp.level_stride);                                                               \
-        else if (D == 128)                                                                                            \
-            hipLaunchKernelGGL((step_chain_kernel<2, BWD>), cgrid, dim3(256), 0, s, sd, lp, crefs, cbatch, cops, XP,  \
-                               MASKP, hp.level_stride);                                                               \
-        else                                                                                                          \
-            hipLaunchKernelGGL((step_chain_kernel<4, BWD>), cgrid, dim3(256), 0, s, sd, lp, crefs, cbatch, cops, XP,  \
-                               MASKP, hp.level_stride);                                                               \
-    } while (0)
     float *H = reinterpret_cast<float *>(wb + hp.o_H), *GH = reinterpret_cast<float *>(wb + hp.o_GH);
     float *tpos = reinterpret_cast<float *>(wb + hp.o_tpos), *tneg = reinterpret_cast<float *>(wb + hp.o_tneg);
     float *spos = scores_pos ? scores_pos : reinterpret_cast<float *>(wb + hp.o_spos);
@@ -1277,8 +1397,77 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         for (int l = 1; l < NL; ++l) (void)hipStreamWaitEvent(ls[l], reinterpret_cast<hipEvent_t>(lanes->fork_event), 0);
     }
 
+    float *WT = reinterpret_cast<float *>(wb + hp.o_WT);
+    if (backward) {
+        // prologue launch: transposed weight copies for the backward chains; zero fill of the gradients
+        ZeroSegs zs;
+        memset(&zs, 0, sizeof(zs));
+        long long zblocks = 0;
+        if (P->flags & MPQE_STEP_ZERO_GRADS) {
+            auto seg = [&](float *ptr, long long n) {
+                if (!ptr || n <= 0) return;
+                for (int k = 0; k < zs.count; ++k)
+                    if (zs.p[k] == ptr) return;                  // shared layers repeat their buffers
+                if (zs.count >= PREP_MAX_SEGS) return;
+                zs.p[zs.count] = ptr;
+                zs.n[zs.count] = n;
+                zs.block0[zs.count] = zblocks;
+                zblocks += (n + PREP_ZERO_FLOATS_PER_BLOCK - 1) / PREP_ZERO_FLOATS_PER_BLOCK;
+                zs.count++;
+            };
+            for (int l = 0; l < P->num_layers; ++l) {
+                seg(G->basis[l], (long long)P->num_relations * D * D);
+                seg(G->root[l], (long long)D * D);
+                seg(G->bias[l], D);
+            }
+            seg(G->mode_emb, (long long)P->num_modes * D);
+            for (int m = 0; m < P->num_modes; ++m) seg(G->tables[m], (long long)P->table_rows[m] * D);
+            zs.block0[zs.count] = zblocks;
+        }
+        const int tpd = (D + 31) / 32;
+        const int tblocks = use_chain ? (int)hp.wt_slots.size() * tpd * tpd : 0;
+        if (tblocks + zblocks > 0)
+            hipLaunchKernelGGL(step_prep_kernel, dim3((unsigned)(tblocks + zblocks)), dim3(256), 0, s, lp,
+                               reinterpret_cast<const WtSlot *>(db + hp.o_wtslots), (int)hp.wt_slots.size(), D, WT,
+                               tblocks, zs);
+    }
+    if (use_chain) {
+        // assemble -> levels -> scores (-> levels back -> anchor-table gradients): one launch
+        ChainArgs ca;
+        ca.refs = reinterpret_cast<const ChainRef *>(db + hp.o_cref);
+        ca.ops = reinterpret_cast<const ChainOp *>(db + hp.o_cops);
+        ca.node_map = nm;
+        ca.map_len = (long long)P->node_map_len;
+        ca.mode_emb = P->mode_emb;
+        ca.num_modes = (long long)P->num_modes;
+        ca.anchor_ids = ids;
+        ca.targets = tg;
+        ca.negs = ng;
+        ca.H = H;
+        ca.GH = GH;
+        ca.WT = WT;
+        ca.level_stride = hp.level_stride;
+        ca.margin = margin;
+        ca.eps = 1e-8f;
+        ca.s_pos = spos;
+        ca.s_neg = sneg;
+        ca.terms = terms;
+        ca.err = err;
+        ca.backward = backward ? 1 : 0;
+        ca.stamps = g_chain_stamps && hp.crefs.size() <= g_chain_stamp_blocks ? g_chain_stamps : nullptr;
+        dim3 cgrid((unsigned)hp.crefs.size());
+        mark(s);
+        if (D == 64) hipLaunchKernelGGL(step_chain_kernel<1>, cgrid, dim3(256), 0, s, sd, lp, tabs, ca);
+        else if (D == 128) hipLaunchKernelGGL(step_chain_kernel<2>, cgrid, dim3(256), 0, s, sd, lp, tabs, ca);
+        else hipLaunchKernelGGL(step_chain_kernel<4>, cgrid, dim3(256), 0, s, sd, lp, tabs, ca);
+        mark(s);
+        if (!backward) {
+            hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss);
+            return mpqe_launch_status();
+        }
+    }
     // ---- forward
-    for (int l = 0; l < NL; ++l) {
+    for (int l = 0; !use_chain && l < NL; ++l) {
         const long long nr = row0[l + 1] - row0[l], ngr = gr0[l + 1] - gr0[l];
         const long long waves = nr + 2 * ngr;
         const int lpr_h = [&] { if (!vec_tab) return 64; int q = 1; while (q < 64 && q * 4 < D) q <<= 1; return q; }();
@@ -1286,11 +1475,6 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         hipLaunchKernelGGL(step_assemble_kernel, dim3((unsigned)((waves + per_block - 1) / per_block)), dim3(256), 0,
                            ls[l], sd, tabs, nm, (long long)P->node_map_len, P->mode_emb, (long long)P->num_modes, ids,
                            tg, ng, H, tpos, tneg, err, vec_tab, row0[l], nr, gr0[l], ngr);
-    }
-    if (use_chain) {
-        mark(s);
-        LAUNCH_CHAIN(false, H, (const float *)nullptr);
-        mark(s);
     }
     for (int p = 0; !use_chain && p < hp.Lmax; ++p)
         for (int l = 0; l < NL; ++l) {
@@ -1325,7 +1509,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             (void)hipStreamWaitEvent(s, reinterpret_cast<hipEvent_t>(lanes->join_event[l]), 0);
         }
     };
-    if (!backward) {
+    if (!backward) {      // (not reached with the chain kernel)
         for (int l = 0; l < NL; ++l) { LAUNCH_SCORE_D(false, (float *)nullptr, l); }
         join();
         hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss);
@@ -1334,15 +1518,9 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
 
     // ---- backward (the score kernel's backward instance writes scores and hinge terms too; the loss
     // itself is reduced by the last launch of the step)
-    for (int l = 0; l < NL; ++l) { LAUNCH_SCORE_D(true, GH, l); }
+    for (int l = 0; !use_chain && l < NL; ++l) { LAUNCH_SCORE_D(true, GH, l); }
 #undef LAUNCH_SCORE_D
 #undef LAUNCH_SCORE
-    if (use_chain) {
-        mark(s);
-        LAUNCH_CHAIN(true, GH, (const float *)H);
-        mark(s);
-    }
-#undef LAUNCH_CHAIN
     for (int p = hp.Lmax - 1; !use_chain && p >= 0; --p)
         for (int l = 0; l < NL; ++l) {
             if (p >= hp.lane_Lmax[l]) continue;
@@ -1394,8 +1572,11 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             hipLaunchKernelGGL(step_tail_kernel<LD_SCALAR>, tgrid, dim3(256), 0, s, sd, ta, (const float *)H,
                                (const float *)GH, hp.level_stride);
         mark(s);
-        hipLaunchKernelGGL(step_tail_small_kernel, dim3((unsigned)(ta.vblocks + (hp.anchor_off[nb] + 3) / 4)),
-                           dim3(256), 0, s, sd, ta, tabs, (const float *)H, (const float *)GH, hp.level_stride);
+        // bias / variable-row partials, and (unless the chain kernel already did them) anchor-table gradients
+        const unsigned small_blocks = (unsigned)(ta.vblocks + (use_chain ? 0 : (hp.anchor_off[nb] + 3) / 4));
+        if (small_blocks)
+            hipLaunchKernelGGL(step_tail_small_kernel, dim3(small_blocks), dim3(256), 0, s, sd, ta, tabs,
+                               (const float *)H, (const float *)GH, hp.level_stride);
     }
     {
         const long long elems = (long long)D * D;

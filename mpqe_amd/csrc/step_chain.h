@@ -1,12 +1,13 @@
-// Graph-block chain kernels of the fused step.
+// Graph-block chain kernel of the fused step.
 //
-// Query graphs never interact (reference data_utils.py:405: the batch is block-diagonal), so the
-// whole message-passing chain of a block of graphs -- every level forward, or every level backward --
-// depends on nothing outside the block. One workgroup therefore takes CH_GB = 16 graphs of one batch
-// through ALL its levels: node states stay in LDS between levels (ping-pong), the only barrier is the
-// workgroup's own, and nothing waits for the slowest tile of a level as the one-launch-per-level form
-// does. HBM sees each state once, on the way out (the weight-gradient kernel and the ReLU masks of the
-// backward chain read it from there).
+// Query graphs never interact (reference data_utils.py:405: the batch is block-diagonal), so everything
+// the step does to a block of graphs before the weight gradients -- feature assembly, every message-passing
+// level forward, readout + scores + hinge terms, and every level backward -- depends on nothing outside the
+// block. One workgroup takes CH_GB = 16 graphs of one batch through that whole chain: node states stay in
+// LDS between levels (ping-pong), the only barrier is the workgroup's own, nothing waits for the slowest
+// tile of a level or for a launch, and the latency chains of the gather / score phases overlap with the
+// MFMA phases of the other workgroup on the CU. HBM sees each state once, on the way out (H and gH of
+// every level: the weight-gradient kernel reads them from there).
 //
 // GEMM shape per (node slot, level): [16 graphs] x [K = (in-edges + 1) * D] x [D columns]. A wave owns
 // 16 * NCB columns (NCB column blocks, column = n0 + NCB * j + c, so a lane's NCB columns are adjacent
@@ -15,99 +16,47 @@
 // four MFMAs (u = 0..3), MFMA u multiplying k = 16 t + 4 (l >> 4) + u -- the sum over k is re-ordered,
 // in a fixed order. The weights never pass through LDS: every W element is used by exactly one wave,
 // which loads its slice straight into registers one half-block (64 k) ahead of the MFMAs that use it.
-// Included by step.hip after StepDev / BatchDev / LayerPtrs / pick_layer.
+// Included by step.hip after StepDev / BatchDev / LayerPtrs / TablePtrs / pick_layer / table_row.
 #pragma once
 #include "gemm_core.h"
 
-#ifdef MPQE_EMU
-#define CHAIN_PIN(x) (void)(x)
-#else
-#define CHAIN_PIN(x) asm volatile("" : "+v"(x))
-#endif
 #define CH_GB 16
-#define CH_FIRST 1
-#define CH_LAST 2
+#define CH_FIRST 1        // first K-block of a node update: clear the accumulator
+#define CH_LAST 2         // last K-block: epilogue
+#define CH_LEVEL_END 4    // last K-block of a level: workgroup barrier, swap the LDS buffers
+#define CH_RELU 8         // forward epilogue applies ReLU (and records the mask bits)
+#define CH_MASK 16        // backward epilogue masks with the bits recorded for this (level, node)
+#define CH_MASK_LEVELS 4  // ReLU outputs live at levels 1 .. L-1: chains up to L = 5 passes
+#define CH_MAX_OPS 96     // forward + backward K-blocks of one batch (5 passes x 7 x 2 = 70 at most)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef const f32x2 __attribute__((address_space(1))) * gvec2_ptr;
 __device__ __forceinline__ f32x2 gload2(const float *p) { return *(gvec2_ptr)(p); }
 
-// one K-block of a node update: multiply the LDS rows of node slot `src` by matrix `mat`
-// (relation id, or -1 = the layer's root) into the accumulator of node slot `node`
+// one K-block of a node update: multiply the LDS rows of node slot `src` by matrix `mat` (relation id, or
+// -1 = root) of layer `layer` into the accumulator of node slot `node`; the result is level `level`'s row
+// block of H (forward) / gH (backward)
 struct ChainOp {
-    int src, node, mat, flags;
+    unsigned char src, node, layer, level;
+    int mat, flags;
+    int wt_slot;          // backward ops: slot of the matrix's transposed copy in the step workspace
 };
+// one workgroup: graphs [g0, g0 + 16) of `batch`; its forward / backward programmes in the op table
 struct ChainRef {
-    int batch, g0;
-};
-// ops of batch b: forward level p = [fwd_off[p], fwd_off[p+1]), backward level p = [bwd_off[p], bwd_off[p+1])
-struct ChainBatch {
-    int fwd_off[MPQE_STEP_MAX_LAYERS + 1], bwd_off[MPQE_STEP_MAX_LAYERS + 1];
+    int batch, g0, fwd_begin, fwd_count, bwd_begin, bwd_count, pad0, pad1;
 };
 
 template <int NCB>
 struct WHalf {
     float v[4][4][NCB];      // [t][u][c]: k = 16 t + 4 kq + u of the half-block, column block c
 };
-
-// forward: B[k][n] = W[k][n]; wp = W + (64 h + 4 kq) * D + n0 + NCB * j
-template <int NCB>
-__device__ __forceinline__ void chain_load_w(WHalf<NCB> &f, const float *wp, int D) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float *p = wp + (long long)(16 * t + u) * D;
-            if constexpr (NCB == 1) f.v[t][u][0] = gload1(p);
-            else if constexpr (NCB == 2) {
-                const f32x2 q = gload2(p);
-                f.v[t][u][0] = q[0];
-                f.v[t][u][1] = q[1];
-            } else {
-                const f32x4 q = gload4(p);
-#pragma unroll
-                for (int c = 0; c < NCB; ++c) f.v[t][u][c] = q[c & 3];
-            }
-        }
-}
-// backward-x: B[k][n] = W[n][k]; wp = W + (n0 + NCB * j) * D + 64 h + 4 kq
-template <int NCB>
-__device__ __forceinline__ void chain_load_wt(WHalf<NCB> &f, const float *wp, int D) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int c = 0; c < NCB; ++c) {
-            const f32x4 q = gload4(wp + (long long)c * D + 16 * t);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) f.v[t][u][c] = q[u];
-        }
-}
-
-template <int NCB>
-__device__ __forceinline__ void chain_mma(f32x4 (&acc)[NCB], const WHalf<NCB> &f, const float *xp) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(xp + 16 * t);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int c = 0; c < NCB; ++c)
-                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], f.v[t][u][c], acc[c], 0, 0, 0);
-    }
-}
-
-// BWD = false: X = H. Reads H[0] of the block, writes H[1 .. L].
-// BWD = true:  X = gH (pre-activation gradients). Reads gH[L] (written by the score kernel), writes
-//              gH[L-1 .. 0], each masked by the ReLU output it belongs to (Hmask = H) for levels >= 1.
-//
-// The K loop is straight-line code on purpose: every load of the pipeline is unconditional (indices are
-// clamped to the level's last half-block, surplus loads touch valid memory and are dropped), because a
-// load issued inside a branch makes hipcc's s_waitcnt bookkeeping fall back to vmcnt(0) at the join, which
-// would serialise every half-block behind the prefetch that was just issued for the next one.
 template <int NCB> struct chain_vec;
 template <> struct chain_vec<1> { typedef float type; };
 template <> struct chain_vec<2> { typedef f32x2 type; };
 template <> struct chain_vec<4> { typedef f32x4 type; };
+template <int NCB> struct chain_bits { typedef unsigned char type; };      // 4 * NCB mask bits per lane
+template <> struct chain_bits<4> { typedef unsigned short type; };
+
 template <int NCB>
 __device__ __forceinline__ void chain_gload(float (&d)[NCB], const float *p) {
     if constexpr (NCB == 1) d[0] = gload1(p);
@@ -132,142 +81,498 @@ __device__ __forceinline__ void chain_store(float *p, const float (&v)[NCB]) {
     *reinterpret_cast<typename chain_vec<NCB>::type *>(p) = q;
 }
 
-template <int NCB, bool BWD>
-__device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, const LayerPtrs &lp,
-                                            const ChainRef *__restrict__ refs, const ChainBatch *__restrict__ cbs,
-                                            const ChainOp *__restrict__ ops, float *__restrict__ X,
-                                            const float *__restrict__ Hmask, long long level_stride, float *xs) {
-    constexpr int D = 64 * NCB, LDX = D + 4, BUF = 4 * CH_GB * LDX;
-    const ChainRef ref = refs[blockIdx.x];
-    const BatchDev &b = sd->b[ref.batch];
-    const ChainBatch &cb = cbs[ref.batch];
-    const int N = b.tp.N, L = b.L, g0 = ref.g0;
-    const int ng = b.B - g0 < CH_GB ? b.B - g0 : CH_GB;
-    const long long row0 = b.row_off + (long long)g0 * N;
-    {   // stage the block's rows of the entry level: (graph, node)-major and contiguous in HBM. Thread t
-        // moves float4 number t + 256 k, k < N * NCB; all loads are issued before the first LDS write.
-        const float *src = X + (long long)(BWD ? L : 0) * level_stride + row0 * D;
-        const int nrows = ng * N, nk = N * NCB;
-        f32x4 v[4 * NCB];
+// B[k][n] = M[k][n] with M row-major: forward M = W, backward-x M = W^T (a transposed copy made by
+// step_prep_kernel, so both directions read whole 128-byte row pieces: 16 lanes x NCB adjacent floats).
+// wp = M + (64 h + 4 kq) * D + n0 + NCB * j; one t-step = 16 k.
+#ifndef CHAIN_DBG
+#define CHAIN_DBG 0     // experiments only: 1 = no weight loads in the K loop, 2 = no MFMAs
+#endif
+template <int NCB>
+__device__ __forceinline__ void chain_load_t(WHalf<NCB> &f, const float *wp, int D, int t) {
+    if (CHAIN_DBG == 1) return;
 #pragma unroll
-        for (int k = 0; k < 4 * NCB; ++k) {
-            const int f = threadIdx.x + 256 * (k < nk ? k : 0);
-            const int r = f / (D / 4), c4 = f - r * (D / 4);
-            v[k] = gload4(src + (long long)(r < nrows ? r : nrows - 1) * D + 4 * c4);
-        }
+    for (int u = 0; u < 4; ++u) chain_gload<NCB>(f.v[t][u], wp + (long long)(16 * t + u) * D);
+}
+
+template <int NCB>
+__device__ __forceinline__ void chain_mma(f32x4 (&acc)[NCB], const WHalf<NCB> &f, const float *xp) {
 #pragma unroll
-        for (int k = 0; k < 4 * NCB; ++k) {
-            const int f = threadIdx.x + 256 * k;
-            const int r = f / (D / 4), c4 = f - r * (D / 4);
-            const int i = r / N, n = r - i * N;
-            if (k < nk)
-                *reinterpret_cast<f32x4 *>(xs + (n * CH_GB + i) * LDX + 4 * c4) =
-                    r < nrows ? v[k] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+    for (int t = 0; t < 4; ++t) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(xp + 16 * t);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], f.v[t][u][c], acc[c], 0, 0, 0);
     }
-    __syncthreads();
+}
+
+// LDS of one workgroup (D = 128: 77 KB -> two workgroups per CU; D = 256: 151 KB)
+template <int NCB>
+struct ChainLds {
+    static constexpr int D = 64 * NCB, LDX = D + 4, BUF = 4 * CH_GB * LDX;
+    float xs[2 * BUF];                                   // node states, ping-pong: [node][graph][LDX]
+    float bias[MPQE_STEP_MAX_LAYERS * D];                // every layer's bias
+    typename chain_bits<NCB>::type mbits[CH_MASK_LEVELS * 4 * 256];   // ReLU bits per (level, node, thread)
+    const float *rowp[4 * CH_GB + 2 * CH_GB];            // source row of every node row, then +/- targets
+    float *gradp[4 * CH_GB];                             // entity-table gradient row of every anchor row
+    float nrm[4 * CH_GB];                                // |v| of the anchor rows
+    const float *wp[CH_MAX_OPS];                         // weight matrix of every op of the block's programme
+    int opw[CH_MAX_OPS][2];                              // its (src | node << 8 | layer << 16 | level << 24, flags)
+};
+// an op as the K loop sees it: wave-uniform, read from LDS (a vector load from HBM here would sit in vmcnt
+// behind the weight prefetch and drain it)
+struct ChainStep {
+    int src, node, layer, level, flags;
+};
+
+// The K loop of one direction: the block's programme (T half-blocks) as ONE software pipeline across node
+// updates and levels. Straight-line on purpose: every load of the pipeline is unconditional (indices are
+// clamped to the last half-block, surplus loads touch valid memory and are dropped), because a load issued
+// inside a branch makes hipcc's s_waitcnt bookkeeping fall back to vmcnt(0) at the join, which would
+// serialise every half-block behind the prefetch just issued for the next one; sched_barriers keep hipcc's
+// scheduler from sinking the prefetch loads down to the MFMAs that use them.
+template <int NCB, bool BWD>
+__device__ __forceinline__ void chain_run(ChainLds<NCB> &S, const int first_op, int T /* half-blocks */, int N, int ng,
+                                          float *__restrict__ Xrows, long long level_stride, int &cur) {
+    constexpr int D = 64 * NCB, LDX = D + 4, BUF = 4 * CH_GB * LDX;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kq = lane >> 4;
-    const int n0 = wave * 16 * NCB;
-    const int colb = n0 + NCB * j;               // this lane's NCB adjacent columns
-    int cur = 0;
-    for (int stepi = 0; stepi < L; ++stepi) {
-        const int p = BWD ? L - 1 - stepi : stepi;
-        const int li = p < L - 1 ? p : sd->num_layers - 1;        // reference model.py:435-441
-        const float *basis = pick_layer(lp.basis, li), *root = pick_layer(lp.root, li);
-        const float *bias = pick_layer(lp.bias, li);
-        const int o0 = BWD ? cb.bwd_off[p] : cb.fwd_off[p];
-        const int T = ((BWD ? cb.bwd_off[p + 1] : cb.fwd_off[p + 1]) - o0) * NCB;     // half-blocks of this level
-        const float *Xc = xs + cur * BUF;
-        float *Xn = xs + (cur ^ 1) * BUF;
-        float *Xout = X + (long long)(BWD ? p : p + 1) * level_stride + row0 * D;
-        // ReLU outputs the gradients of this level belong to (levels >= 1; level 0 reads valid rows of
-        // H[0] and ignores them)
-        const float *Mk = BWD ? Hmask + (long long)p * level_stride + row0 * D : nullptr;
-        const bool relu = !BWD && p < L - 1;
-        const bool masked = BWD && p >= 1;
-        float bv[NCB];
+    const int colb = wave * 16 * NCB + NCB * j;          // this lane's NCB adjacent columns
+    auto get_op = [&](int it) -> ChainStep {
+        const int k = first_op + (it < T ? it : T - 1) / NCB;
+        const int w = __builtin_amdgcn_readfirstlane(S.opw[k][0]);
+        ChainStep o;
+        o.src = w & 0xff;
+        o.node = (w >> 8) & 0xff;
+        o.layer = (w >> 16) & 0xff;
+        o.level = (w >> 24) & 0xff;
+        o.flags = __builtin_amdgcn_readfirstlane(S.opw[k][1]);
+        return o;
+    };
+    // matrix pointers come from LDS (filled in phase A1): no scalar memory round trip, no branch, per item
+    auto wptr = [&](int it) -> const float * {
+        const int itc = it < T ? it : T - 1;
+        const int h = itc % NCB;
+        const float *W = S.wp[first_op + itc / NCB];
+        return W + (long long)(64 * h + 4 * kq) * D + colb;
+    };
+    f32x4 acc[NCB];
+    // one half-block: its 4 t-steps of MFMAs, each preceded by the loads of the same t-step of the half-block
+    // two items ahead (`fn` <- `wn`): the load issue is spread between the MFMAs instead of stalling them
+    auto item = [&](const ChainStep &op, int it, const WHalf<NCB> &f, WHalf<NCB> &fn, const float *wn) {
+        const int h = it % NCB;
+        const float *xp = S.xs + cur * BUF + (op.src * CH_GB + j) * LDX + 64 * h + 4 * kq;
+        // all four A fragments of the item up front: one exposed LDS round trip per item instead of four
+        f32x4 av[4];
 #pragma unroll
-        for (int c = 0; c < NCB; ++c) bv[c] = 0.f;
-        if (!BWD && bias) chain_gload<NCB>(bv, bias + colb);
-
-        auto get_op = [&](int it) -> ChainOp { return ops[o0 + (it < T ? it : T - 1) / NCB]; };
-        auto wptr = [&](const ChainOp &op, int it) -> const float * {
-            const int h = (it < T ? it : T - 1) % NCB;
-            const float *W = op.mat >= 0 ? basis + (long long)op.mat * D * D : root;
-            return BWD ? W + (long long)colb * D + 64 * h + 4 * kq : W + (long long)(64 * h + 4 * kq) * D + colb;
-        };
-        f32x4 acc[NCB];
-        // ReLU masks of a node (backward): loaded BEFORE the weight prefetch that precedes the item, so they
-        // are the older loads (vmcnt counts in order: waiting for them never drains the prefetch), and
-        // unconditionally; only the masks of a node's last item are used.
-        auto load_mask = [&](float (&mk)[4][NCB], const ChainOp &op) {
+        for (int t = 0; t < 4; ++t) av[t] = *reinterpret_cast<const f32x4 *>(xp + 16 * t);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            chain_load_t<NCB>(fn, wn, D, t);
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 a = av[t];
+#if CHAIN_DBG == 2
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) asm volatile("" ::"v"(f.v[t][u][c]), "v"(a[u]));
+#else
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int c = 0; c < NCB; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], f.v[t][u][c], acc[c], 0, 0, 0);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (h != NCB - 1) return;
+        if (op.flags & CH_LAST) {
+            float *Xn = S.xs + (cur ^ 1) * BUF;
+            float *Xout = Xrows + (long long)op.level * level_stride;
+            const int mslot = ((op.level - 1) * 4 + op.node) * 256 + threadIdx.x;   // levels 1 .. L-1
+            unsigned bits = 0;
+            if (BWD && (op.flags & CH_MASK)) bits = S.mbits[mslot];
+            float bv[NCB];
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) bv[c] = BWD ? 0.f : S.bias[op.layer * D + colb + c];
+            unsigned out_bits = 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * kq + r;
-                chain_gload<NCB>(mk[r], Mk + ((long long)(row < ng ? row : 0) * N + op.node) * D + colb);
-            }
-        };
-        auto item = [&](const ChainOp &op, int it, const WHalf<NCB> &f, float (&mk)[4][NCB]) {
-            const int h = it % NCB;
-            if (h == 0 && (op.flags & CH_FIRST)) {
+                float v[NCB];
 #pragma unroll
-                for (int c = 0; c < NCB; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            chain_mma<NCB>(acc, f, Xc + (op.src * CH_GB + j) * LDX + 64 * h + 4 * kq);
-            if (BWD) {      // an opaque use after the MFMAs: the mask loads cannot sink into the epilogue branch
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int c = 0; c < NCB; ++c) CHAIN_PIN(mk[r][c]);
-            }
-            if (h == NCB - 1 && (op.flags & CH_LAST)) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * kq + r;
-                    float v[NCB];
-#pragma unroll
-                    for (int c = 0; c < NCB; ++c) {
-                        v[c] = acc[c][r];
-                        if (!BWD) {
-                            v[c] += bv[c];
-                            if (relu) v[c] = v[c] > 0.f ? v[c] : 0.f;
-                        } else if (masked) {
-                            v[c] = mk[r][c] > 0.f ? v[c] : 0.f;
+                for (int c = 0; c < NCB; ++c) {
+                    v[c] = acc[c][r];
+                    if (!BWD) {
+                        v[c] += bv[c];
+                        if (op.flags & CH_RELU) {
+                            v[c] = v[c] > 0.f ? v[c] : 0.f;
+                            out_bits |= (v[c] > 0.f ? 1u : 0u) << (r * NCB + c);
                         }
+                    } else if (op.flags & CH_MASK) {
+                        v[c] = (bits >> (r * NCB + c)) & 1u ? v[c] : 0.f;
                     }
-                    chain_store<NCB>(Xn + (op.node * CH_GB + row) * LDX + colb, v);
-                    if (row < ng) chain_store<NCB>(Xout + ((long long)row * N + op.node) * D + colb, v);
+                }
+                chain_store<NCB>(Xn + (op.node * CH_GB + row) * LDX + colb, v);
+                if (row < ng) chain_store<NCB>(Xout + ((long long)row * N + op.node) * D + colb, v);
+            }
+            if (!BWD && (op.flags & CH_RELU)) S.mbits[mslot] = (typename chain_bits<NCB>::type)out_bits;
+            // the next node update starts from zero (cleared here, inside the uniform branch, rather than by a
+            // select at the top of every item: that select made hipcc park the accumulators in registers of
+            // a load buffer whose loads were still in flight, and wait for them)
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (op.flags & CH_LEVEL_END) {       // uniform over the workgroup: every wave runs the same programme
+            __syncthreads();
+            cur ^= 1;
+        }
+    };
+    if (T <= 0) return;
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // three register buffers, prefetch distance two half-blocks (~2 x 1024 MFMA cycles for a load to land)
+    WHalf<NCB> f0, f1, f2;
+    ChainStep o0 = get_op(0), o1 = get_op(1), o2 = get_op(2);     // ops of items it, it + 1, it + 2
+#pragma unroll
+    for (int t = 0; t < 4; ++t) chain_load_t<NCB>(f0, wptr(0), D, t);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) chain_load_t<NCB>(f1, wptr(1), D, t);
+    __builtin_amdgcn_sched_barrier(0);
+    int it = 0;
+    while (true) {
+        ChainStep o3 = get_op(it + 3);
+        item(o0, it, f0, f2, wptr(it + 2));
+        if (++it >= T) break;
+        o0 = get_op(it + 3);
+        item(o1, it, f1, f0, wptr(it + 2));
+        if (++it >= T) break;
+        o1 = get_op(it + 3);
+        item(o2, it, f2, f1, wptr(it + 2));
+        if (++it >= T) break;
+        o2 = o1;      // rotate: ops of items it, it + 1, it + 2 are (o3, o0, o1)
+        o1 = o0;
+        o0 = o3;
+    }
+}
+
+struct ChainArgs {
+    const ChainRef *refs;
+    const ChainOp *ops;
+    const long long *node_map;
+    long long map_len;
+    const float *mode_emb;
+    long long num_modes;
+    const long long *anchor_ids, *targets, *negs;
+    float *H, *GH;
+    const float *WT;        // transposed copies of the matrices the backward chains multiply by
+    long long level_stride;
+    float margin, eps;
+    float *s_pos, *s_neg, *terms;
+    int32_t *err;
+    int backward;
+    long long *stamps;      // diagnostics (mpqe_debug_chain_stamps): 8 words per workgroup, or NULL
+};
+
+// phase time stamps of a workgroup: the 100 MHz wall clock is one time base for the whole device, so the
+// stamps of different workgroups line up into a timeline (tools/chain_timeline.py)
+__device__ __forceinline__ void chain_stamp(const ChainArgs &ca, int slot) {
+#ifndef MPQE_EMU
+    if (ca.stamps && threadIdx.x == 0) ca.stamps[(long long)blockIdx.x * 8 + slot] = (long long)wall_clock64();
+#endif
+}
+__device__ __forceinline__ void chain_stamp_where(const ChainArgs &ca) {
+#ifndef MPQE_EMU
+    if (ca.stamps && threadIdx.x == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_ID
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);         // XCC_ID[3:0]
+        ca.stamps[(long long)blockIdx.x * 8 + 7] = (long long)hw | ((long long)xcc << 32);
+    }
+#endif
+}
+
+template <int NCB>
+__device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, const LayerPtrs &lp, const TablePtrs &tabs,
+                                            const ChainArgs &ca, ChainLds<NCB> &S) {
+    constexpr int D = 64 * NCB, LDX = D + 4, BUF = 4 * CH_GB * LDX;
+    constexpr int LPR = 16 * NCB;                         // lanes that share one row in the row-major phases
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const ChainRef ref = ca.refs[blockIdx.x];
+    if (ref.batch < 0) return;                            // a hole of the placement grid (uniform)
+    const BatchDev &b = sd->b[ref.batch];
+    const int N = b.tp.N, A = b.A, L = b.L, g0 = ref.g0;
+    const int ng = b.B - g0 < CH_GB ? b.B - g0 : CH_GB;
+    const int nrows = ng * N;
+    const long long row0 = b.row_off + (long long)g0 * N;
+    const long long gi0 = b.g_off + g0;
+
+    chain_stamp(ca, 0);
+    chain_stamp_where(ca);
+    // ---- phase A1: where every row comes from (threads 0 .. 95: node rows, + targets, - targets)
+    if (tid < 4 * CH_GB + 2 * CH_GB) {
+        const float *src = nullptr;
+        float *gdst = nullptr;
+        if (tid < 4 * CH_GB) {
+            const int i = tid / N, n = tid - i * N;       // row r = i * N + n, as in HBM
+            if (tid < nrows) {
+                if (n < A) {
+                    const int tab = b.anchor_tab[n];
+                    const long long id = ca.anchor_ids[b.anchor_off + (long long)n * b.B + g0 + i];
+                    const long long row = table_row(ca.node_map, ca.map_len, id, tabs.rows[tab], ca.err);
+                    if (row >= 0) {
+                        src = tabs.table[tab] + row * D;
+                        if (tabs.grad[tab]) gdst = tabs.grad[tab] + row * D;
+                    }
+                } else {
+                    const long long m = b.var_id[n - A];
+                    if (m < 0 || m >= ca.num_modes) flag_error(ca.err, MPQE_FLAG_BAD_NODE_ID);
+                    else src = ca.mode_emb + m * D;
                 }
             }
-        };
-        auto load = [&](WHalf<NCB> &f, const ChainOp &op, int it) {
-            if (BWD) chain_load_wt<NCB>(f, wptr(op, it), D);
-            else chain_load_w<NCB>(f, wptr(op, it), D);
-        };
-        WHalf<NCB> fa, fb;
-        float mka[4][NCB], mkb[4][NCB];
-        ChainOp opa = get_op(0), opb = get_op(1), opc = get_op(2);     // ops of items it, it + 1, it + 2
-        load(fa, opa, 0);
-        for (int it = 0; it < T; it += 2) {
-            const ChainOp opd = get_op(it + 3), ope = get_op(it + 4);   // next iteration's opb, opc
-            // sched_barrier: hipcc's scheduler otherwise sinks every prefetch load down to the MFMA that
-            // uses it (one exposed L2 round trip per pair of MFMAs)
-            if (BWD) load_mask(mka, opa);
-            load(fb, opb, it + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            item(opa, it, fa, mka);
-            __builtin_amdgcn_sched_barrier(0);
-            if (BWD) load_mask(mkb, opb);
-            load(fa, opc, it + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            if (NCB >= 2 || it + 1 < T) item(opb, it + 1, fb, mkb);     // T = ops * NCB is even for NCB >= 2
-            __builtin_amdgcn_sched_barrier(0);
-            opa = opc;
-            opb = opd;
-            opc = ope;
+            S.gradp[tid] = gdst;
+        } else {
+            const int i = (tid - 4 * CH_GB) & (CH_GB - 1);
+            const bool is_neg = tid >= 5 * CH_GB;
+            if (i < ng) {
+                const int tab = b.target_tab;
+                const long long id = is_neg ? ca.negs[gi0 + i] : ca.targets[gi0 + i];
+                const long long row = table_row(ca.node_map, ca.map_len, id, tabs.rows[tab], ca.err);
+                if (row >= 0) src = tabs.table[tab] + row * D;
+            }
         }
-        __syncthreads();
-        cur ^= 1;
+        S.rowp[tid] = src;
     }
+    for (int f = tid; f < sd->num_layers * D; f += 256) {
+        const float *bp = pick_layer(lp.bias, f / D);
+        S.bias[f] = bp ? bp[f % D] : 0.f;
+    }
+    {   // forward ops then backward ops of this block's programme (the host keeps them adjacent)
+        const int nops = ref.fwd_count + ref.bwd_count;
+        if (tid < nops) {
+            const ChainOp op = ca.ops[ref.fwd_begin + tid];
+            if (tid < ref.fwd_count || CHAIN_DBG == 3)      // (3: timing experiment, wrong results)
+                S.wp[tid] = op.mat >= 0 ? pick_layer(lp.basis, op.layer) + (long long)op.mat * D * D
+                                        : pick_layer(lp.root, op.layer);
+            else
+                S.wp[tid] = ca.WT + (long long)op.wt_slot * D * D;
+            S.opw[tid][0] = op.src | (op.node << 8) | (op.layer << 16) | (op.level << 24);
+            S.opw[tid][1] = op.flags;
+        }
+    }
+    __syncthreads();
+    chain_stamp(ca, 1);
+
+    // ---- phase A2: gather the rows, L2-normalise the anchors (reference encoders.py:41-43, no eps), write
+    // LDS buffer 0 and H[0]. Thread t moves float4 number t + 256 k, k < N * NCB; LPR adjacent lanes share a
+    // row. All loads are issued before the first use.
+    {
+        const int nk = N * NCB;
+        f32x4 v[4 * NCB];
+#pragma unroll
+        for (int k = 0; k < 4 * NCB; ++k) {
+            const int f = tid + 256 * (k < nk ? k : 0);
+            const int r = f / (D / 4), c4 = f - r * (D / 4);
+            const float *src = S.rowp[r];
+            v[k] = src ? gload4(src + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float *H0 = ca.H + row0 * D;
+#pragma unroll
+        for (int k = 0; k < 4 * NCB; ++k) {
+            const int f = tid + 256 * k;
+            const int r = f / (D / 4), c4 = f - r * (D / 4);
+            const int i = r / N, n = r - i * N;
+            f32x4 q = v[k];
+            float ss = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+#pragma unroll
+            for (int off = LPR >> 1; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+            if (k < nk) {
+                const bool anchor = n < A && S.rowp[r] != nullptr;
+                const float nrm = sqrtf(ss);
+                if (anchor) {
+                    q[0] /= nrm; q[1] /= nrm; q[2] /= nrm; q[3] /= nrm;
+                    if ((f & (D / 4 - 1)) == 0) S.nrm[r] = nrm;
+                }
+                *reinterpret_cast<f32x4 *>(S.xs + (n * CH_GB + i) * LDX + 4 * c4) = q;
+                if (r < nrows) *reinterpret_cast<f32x4 *>(H0 + (long long)r * D + 4 * c4) = q;
+            }
+        }
+    }
+    __syncthreads();
+
+    chain_stamp(ca, 2);
+    // ---- forward levels
+    int cur = 0;
+    chain_run<NCB, false>(S, 0, ref.fwd_count * NCB, N, ng, ca.H + row0 * D, ca.level_stride, cur);
+
+    chain_stamp(ca, 3);
+    // ---- readout, cosine scores against the + and - target, hinge terms (reference model.py:447-462,
+    // 483-485); backward: d hinge -> d cosine -> d readout written over H[L] in LDS (a lane group owns whole
+    // graphs) and to gH[L]; target-table gradients through the normalisation. 16 lanes per graph: lane group
+    // g of wave w takes graph 4 w + g, lane s of the group the columns s + 16 cc.
+    {
+        constexpr int CC = D / 16;
+        float *Xc = S.xs + cur * BUF;
+        float *GL = ca.GH + (long long)L * ca.level_stride + row0 * D;
+        const int i = 4 * wave + (lane >> 4), sl = lane & 15;
+        const bool on = i < ng;
+        const float *pp_ = S.rowp[4 * CH_GB + i], *pn_ = S.rowp[5 * CH_GB + i];
+        const int readout = sd->readout;
+        auto gsum = [](float v) {
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            return v;
+        };
+        float tp[CC], tn[CC];
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc) {                 // both target rows of the group's graph in flight at once
+            tp[cc] = pp_ ? gload1(pp_ + sl + 16 * cc) : 0.f;
+            tn[cc] = pn_ ? gload1(pn_ + sl + 16 * cc) : 0.f;
+        }
+        const float *h = Xc + i * LDX;                    // node n at h + n * CH_GB * LDX
+        float q[CC];
+        int arg[CC];
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc) {                 // branch-free: N <= 4 slots, predicated
+            const int col = sl + 16 * cc;
+            float hn[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) hn[n] = h[(n < N ? n : 0) * CH_GB * LDX + col];
+            float sum = hn[0], best = hn[0];
+            int am = 0;
+#pragma unroll
+            for (int n = 1; n < 4; ++n) {
+                sum += n < N ? hn[n] : 0.f;
+                const bool gt = n < N && hn[n] > best;
+                best = gt ? hn[n] : best;
+                am = gt ? n : am;
+            }
+            float tm = hn[0];
+#pragma unroll
+            for (int n = 1; n < 4; ++n) tm = n == A ? hn[n] : tm;
+            q[cc] = readout == MPQE_READOUT_TM ? tm : (readout == MPQE_READOUT_SUM ? sum : best);
+            arg[cc] = am;
+        }
+        float ssp = 0.f, ssn = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc) {
+            ssp += tp[cc] * tp[cc];
+            ssn += tn[cc] * tn[cc];
+        }
+        ssp = gsum(ssp);
+        ssn = gsum(ssn);
+        const float ip0 = 1.f / sqrtf(ssp), in0 = 1.f / sqrtf(ssn);
+        float dp = 0.f, dn = 0.f, qq = 0.f, pp = 0.f, nn = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc) {
+            // the normalised target embeddings (DirectEncoder); an invalid id (flagged) scores as a zero row
+            tp[cc] = pp_ ? tp[cc] * ip0 : 0.f;
+            tn[cc] = pn_ ? tn[cc] * in0 : 0.f;
+            dp += q[cc] * tp[cc];
+            dn += q[cc] * tn[cc];
+            qq += q[cc] * q[cc];
+            pp += tp[cc] * tp[cc];
+            nn += tn[cc] * tn[cc];
+        }
+        dp = gsum(dp);
+        dn = gsum(dn);
+        qq = gsum(qq);
+        pp = gsum(pp);
+        nn = gsum(nn);
+        const float eps = ca.eps;
+        const float rq = sqrtf(qq), rp = sqrtf(pp), rn = sqrtf(nn);
+        const float nq = fmaxf(rq, eps), np_ = fmaxf(rp, eps), nn_ = fmaxf(rn, eps);
+        const float sp = dp / (nq * np_), sn = dn / (nq * nn_);
+        const float hv = ca.margin - (sp - sn);
+        const long long gi = gi0 + i;
+        if (on && sl == 0) {
+            ca.s_pos[gi] = sp;
+            ca.s_neg[gi] = sn;
+            ca.terms[gi] = hv > 0.f ? hv : 0.f;
+        }
+        if (ca.backward) {
+            // d loss / d sp = -w/B on active terms, d/d sn = +w/B   (loss = sum_b w_b mean_b hinge)
+            const float act = hv >= 0.f ? b.weight / (float)b.B : 0.f;
+            const float gsp = -act, gsn = act;
+            const float inv_p = 1.f / (nq * np_), inv_n = 1.f / (nq * nn_);
+            const float kq_ = rq > eps ? (gsp * sp + gsn * sn) / (nq * nq) : 0.f;
+            const float ktp = rp > eps ? sp / (np_ * np_) : 0.f;
+            const float ktn = rn > eps ? sn / (nn_ * nn_) : 0.f;
+            const unsigned tmask = readout == MPQE_READOUT_SUM ? 0xFu : 1u << A;
+            float yg_p = 0.f, yg_n = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc) {
+                const int col = sl + 16 * cc;
+                const float gyp = gsp * (q[cc] * inv_p - ktp * tp[cc]);
+                const float gyn = gsn * (q[cc] * inv_n - ktn * tn[cc]);
+                yg_p += tp[cc] * gyp;
+                yg_n += tn[cc] * gyn;
+                const float gq = gsp * tp[cc] * inv_p + gsn * tn[cc] * inv_n - kq_ * q[cc];
+                const unsigned takes = readout == MPQE_READOUT_MAX ? 1u << arg[cc] : tmask;   // slots that get gq
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const float gv = (takes >> n) & 1u ? gq : 0.f;
+                    if (n < N) {
+                        Xc[(n * CH_GB + i) * LDX + col] = gv;
+                        if (on) GL[((long long)i * N + n) * D + col] = gv;
+                    }
+                }
+            }
+            yg_p = gsum(yg_p);
+            yg_n = gsum(yg_n);
+            float *gt = tabs.grad[b.target_tab];
+            if (gt && on) {       // y = v / |v|:  dv = (g - y (y . g)) / |v|
+                const float *tb = tabs.table[b.target_tab];
+#pragma unroll
+                for (int cc = 0; cc < CC; ++cc) {
+                    const int col = sl + 16 * cc;
+                    const float gyp = gsp * (q[cc] * inv_p - ktp * tp[cc]);
+                    const float gyn = gsn * (q[cc] * inv_n - ktn * tn[cc]);
+                    if (pp_) atomicAdd(gt + (pp_ - tb) + col, (gyp - tp[cc] * yg_p) * ip0);
+                    if (pn_) atomicAdd(gt + (pn_ - tb) + col, (gyn - tn[cc] * yg_n) * in0);
+                }
+            }
+        }
+    }
+    if (!ca.backward) return;
+    __syncthreads();
+    chain_stamp(ca, 4);
+
+    // ---- backward levels
+    chain_run<NCB, true>(S, ref.fwd_count, ref.bwd_count * NCB, N, ng, ca.GH + row0 * D, ca.level_stride, cur);
+
+    chain_stamp(ca, 5);
+    // ---- anchor rows of gH[0] through the L2 normalisation into the entity-table gradients (fp32 atomics:
+    // an entity can occur in several graphs). y comes back from H[0] (this workgroup wrote it; L2).
+    {
+        const float *Xc = S.xs + cur * BUF;
+        const float *H0 = ca.H + row0 * D;
+        const int nk = N * NCB;
+        const unsigned live0 = b.live[0];
+        f32x4 y[4 * NCB];
+#pragma unroll
+        for (int k = 0; k < 4 * NCB; ++k) {
+            const int f = tid + 256 * (k < nk ? k : 0);
+            const int r = f / (D / 4), c4 = f - r * (D / 4);
+            y[k] = gload4(H0 + (long long)(r < nrows ? r : 0) * D + 4 * c4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4 * NCB; ++k) {
+            const int f = tid + 256 * (k < nk ? k : 0);
+            const int r = f / (D / 4), c4 = f - r * (D / 4);
+            const int i = r / N, n = r - i * N;
+            const bool on = k < nk && r < nrows && n < A && ((live0 >> n) & 1u);
+            const f32x4 g = *reinterpret_cast<const f32x4 *>(Xc + (n * CH_GB + i) * LDX + 4 * c4);
+            float yg = y[k][0] * g[0] + y[k][1] * g[1] + y[k][2] * g[2] + y[k][3] * g[3];
+#pragma unroll
+            for (int off = LPR >> 1; off > 0; off >>= 1) yg += __shfl_xor(yg, off, 64);
+            float *gd = on ? S.gradp[r] : nullptr;
+            if (gd) {
+                const float inv = 1.f / S.nrm[r];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(gd + 4 * c4 + e, (g[e] - y[k][e] * yg) * inv);
+            }
+        }
+    }
+    chain_stamp(ca, 6);
 }

@@ -216,8 +216,9 @@ class FusedTrainStep(object):
 
     def uses_chain(self, packed):
         """True when the library runs the graph-block chain kernels for this step (csrc/step.hip)."""
+        passes = max(int(packed.batches[i].num_passes) for i in range(packed.nb))
         return (not (self.flags & _capi.STEP_NO_CHAIN) and self.model.emb_dim in (64, 128, 256)
-                and packed.num_graphs <= CHAIN_MAX_GRAPHS)
+                and packed.num_graphs <= CHAIN_MAX_GRAPHS and passes <= 5)
 
     def _workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes + 256:
@@ -231,8 +232,8 @@ class FusedTrainStep(object):
         (accumulated on top of the previous content unless zero_grad)."""
         if backward:
             self.bind_grads()
-            if zero_grad:
-                self.flat_grad.zero_()
+        # the library zero-fills the gradient buffers itself (one launch with its other prologue work)
+        self.P.flags = self.flags | (_capi.STEP_ZERO_GRADS if (backward and zero_grad) else 0)
         loss = torch.empty(1 + packed.nb, dtype=torch.float32, device=self.device)
         sp = sn = None
         if scores:

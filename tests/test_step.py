@@ -100,6 +100,12 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
     gmode = be.zeros(tuple(params['mode_embeddings.weight'].shape))
     glay_u = {k: (be.zeros((R, D, D)), be.zeros((D, D)), be.zeros((D,))) for k in uniq}
     glay = [glay_u[id(params['layers.%d.basis' % l])] for l in range(L)]
+    if flags & _capi.STEP_ZERO_GRADS:     # the library must clear whatever is in the gradient buffers
+        for t in gtabs + [gmode] + [x for u in glay_u.values() for x in u]:
+            if be.name == 'emu':
+                t.fill(7.5)
+            else:
+                t.fill_(7.5)
     G = _capi.make_step_grads([be.ptr(t) for t in gtabs], be.ptr(gmode), [be.ptr(x[0]) for x in glay],
                               [be.ptr(x[1]) for x in glay], [be.ptr(x[2]) for x in glay])
     nb = len(batches)
@@ -256,6 +262,20 @@ def test_fused_step_chain_kernels(be, D, readout, adaptive, shared, L):
     # forward only
     fwd = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, backward=0)
     np.testing.assert_array_equal(fwd[0], got[0])
+
+
+@pytest.mark.parametrize('D,shared', [(32, False), (64, True)])
+def test_fused_step_zero_grads_flag(be, D, shared):
+    """MPQE_STEP_ZERO_GRADS: the call clears the gradient buffers itself (level path and chain path)."""
+    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(19, D, 3, shared, MIXES['dup'], 'mp', True)
+    ref = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0)
+    got = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_ZERO_GRADS)
+    np.testing.assert_array_equal(got[0], ref[0])
+    for k in ref[3]:
+        if k.startswith('enc.'):
+            np.testing.assert_allclose(got[3][k], ref[3][k], rtol=1e-5, atol=1e-7, err_msg=k)    # atomics
+        else:
+            np.testing.assert_array_equal(got[3][k], ref[3][k], err_msg=k)
 
 
 @pytest.mark.parametrize('splits', [[0, 3, 7], [0, 1, 2, 4, 7], [0, 6, 7]])

@@ -1,0 +1,94 @@
+"""Timeline of the chain kernel's workgroups for one bench step (diagnostics).
+
+    python tools/chain_timeline.py [--batch-size 512] [--embed-dim 128] [--readout mp] [--kg aifb]
+
+Uses mpqe_debug_chain_stamps: every workgroup records the device wall clock (100 MHz) at its phase
+boundaries and where it ran (XCC, SE, CU). Prints, per query type, the mean duration of each phase, and
+the placement (workgroups per CU, busiest CUs)."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import bench
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--kg', default='aifb')
+    ap.add_argument('--embed-dim', type=int, default=128)
+    ap.add_argument('--batch-size', type=int, default=512)
+    ap.add_argument('--readout', default='mp')
+    ap.add_argument('--no-prune', action='store_true')
+    ap.add_argument('--out', default='')
+    args = ap.parse_args()
+    from mpqe_amd import ops, synthetic
+    from mpqe_amd.data_utils import make_feature_modules
+    from mpqe_amd.encoders import DirectEncoder
+    from mpqe_amd.fused import FusedTrainStep
+    from mpqe_amd.model import RGCNEncoderDecoder
+    torch.manual_seed(0)
+    dev = torch.device('cuda:0')
+    D = args.embed_dim
+    schema = synthetic.make_schema(*synthetic.KG_SHAPES[args.kg], seed=0)
+    graph = synthetic.SchemaGraph(schema, D)
+    fm, node_maps = make_feature_modules(schema.ids, D, schema.num_entities)
+    adaptive = args.readout == 'mp'
+    model = RGCNEncoderDecoder(graph, DirectEncoder(None, fm, node_maps), readout=args.readout, num_layers=3,
+                               shared_layers=False, adaptive=adaptive, weight_decay=0).to(dev)
+    model.validate = False
+    data = bench.StepData(schema, model, args.batch_size, np.random.RandomState(1000), dev)
+    step = FusedTrainStep(model, prune=not args.no_prune)
+    packed = bench.pack_for_fused(step, data)
+    assert step.uses_chain(packed), 'this step does not take the chain kernel'
+    for _ in range(5):
+        step.run(packed)
+    torch.cuda.synchronize()
+    cap = 8 * sum((b + 15) // 16 for b in packed.sizes)      # the launch grid has holes (placement by XCD)
+    stamps = torch.zeros(cap * 8, dtype=torch.int64, device=dev)
+    ops.lib().mpqe_debug_chain_stamps(stamps.data_ptr(), cap)
+    step.run(packed)
+    torch.cuda.synchronize()
+    ops.lib().mpqe_debug_chain_stamps(None, 0)
+    st = stamps.cpu().numpy().reshape(cap, 8)
+    st = st[st[:, 6] != 0]
+    nblk = st.shape[0]
+    t = (st[:, :7] - st[:, 0].min()) * 0.01              # us
+    hw = st[:, 7] & 0xffffffff
+    xcc = (st[:, 7] >> 32) & 0xf
+    cu = (hw >> 8) & 0xf
+    sh = (hw >> 12) & 0x1
+    se = (hw >> 13) & 0x7
+    place = xcc * 1000 + se * 100 + sh * 16 + cu
+    names = ['A1 ids', 'A2 gather', 'forward', 'score', 'backward', 'anchors']
+    print('workgroups %d, makespan %.1f us (first start %.1f, last start %.1f)'
+          % (nblk, t[:, 6].max(), t[:, 0].min(), t[:, 0].max()))
+    uniq, cnt = np.unique(place, return_counts=True)
+    print('distinct CUs used %d; workgroups per CU: %s' % (len(uniq), dict(zip(*np.unique(cnt, return_counts=True)))))
+    # which batch a block belongs to cannot be read back from the library; durations by total time instead
+    dur = t[:, 6] - t[:, 0]
+    order = np.argsort(-dur)
+    print('phase means over all workgroups (us): ' + ', '.join(
+        '%s %.1f' % (n, (t[:, k + 1] - t[:, k]).mean()) for k, n in enumerate(names)))
+    print('10 longest workgroups: [block, start, A1, A2, fwd, score, bwd, anchors, total, cu-mates]')
+    for bidx in order[:10]:
+        mates = int((place == place[bidx]).sum())
+        print('  %4d  start %5.1f  ' % (bidx, t[bidx, 0]) + ' '.join('%5.1f' % (t[bidx, k + 1] - t[bidx, k]) for k in range(6))
+              + '  total %5.1f  mates %d' % (dur[bidx], mates))
+    print('10 shortest:')
+    for bidx in order[-10:]:
+        mates = int((place == place[bidx]).sum())
+        print('  %4d  start %5.1f  ' % (bidx, t[bidx, 0]) + ' '.join('%5.1f' % (t[bidx, k + 1] - t[bidx, k]) for k in range(6))
+              + '  total %5.1f  mates %d' % (dur[bidx], mates))
+    print('workgroups per XCD: %s' % dict(zip(*np.unique(xcc, return_counts=True))))
+    if args.out:
+        json.dump(dict(t=t.tolist(), place=place.tolist()), open(args.out, 'w'))
+
+
+if __name__ == '__main__':
+    main()
