@@ -210,7 +210,7 @@ int mpqe_hinge_bwd(const float *pos, const float *neg, int64_t n, float margin, 
 #define MPQE_STEP_MAX_BATCHES 16
 #define MPQE_STEP_MAX_LAYERS 8
 #define MPQE_STEP_MAX_MODES 16
-/* flags of mpqe_step_params_t (speed switches; loss, scores and gradients are the same either way):
+/* mpqe_step_params_t.flags -- speed switches; loss, scores and gradients are the same either way:
  * NO_PRUNE  also compute node states that cannot reach the readout (the reference computes all of them;
  *           with the TM readout only the target row is read, model.py:391-398, so e.g. 9 of the 21
  *           node updates of a 3-chain feed nothing and get an exactly-zero gradient). Default: skip them.

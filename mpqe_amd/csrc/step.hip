@@ -574,11 +574,12 @@ __device__ __forceinline__ void vec_partial_block(const StepDev *__restrict__ sd
         const long long rows = (long long)b.B * b.tp.N;
         const float *g = GH + (long long)(s.level_or_k + 1) * level_stride + b.row_off * D;
         const float *o = H + (long long)(s.level_or_k + 1) * level_stride + b.row_off * D;
-        const long long r0 = (long long)blk * 64;
+        const long long r0 = (long long)blk * CH_GB * b.tp.N;      // one partial row per 16 graphs (a chain block)
+        const long long r1 = r0 + (long long)CH_GB * b.tp.N;
         const unsigned live = b.live[s.level_or_k + 1];
         const int N = b.tp.N;
         if (c < D)
-            for (long long r = r0 + rg; r < r0 + 64 && r < rows; r += 4) {
+            for (long long r = r0 + rg; r < r1 && r < rows; r += 4) {
                 if (!((live >> (int)(r % N)) & 1u)) continue;      // rows the step never wrote: zero gradient
                 float v = g[r * D + c];
                 if (s.relu && !(o[r * D + c] > 0.f)) v = 0.f;
@@ -587,9 +588,9 @@ __device__ __forceinline__ void vec_partial_block(const StepDev *__restrict__ sd
     } else {
         const float *g = GH + b.row_off * D;          // level 0
         const int k = s.level_or_k;
-        const long long g0 = (long long)blk * 64;
+        const long long g0 = (long long)blk * CH_GB;
         if (c < D)
-            for (long long gi = g0 + rg; gi < g0 + 64 && gi < b.B; gi += 4)
+            for (long long gi = g0 + rg; gi < g0 + CH_GB && gi < b.B; gi += 4)
                 acc += g[(gi * b.tp.N + b.A + k) * D + c];
     }
     part[rg][cl] = acc;
@@ -754,7 +755,8 @@ struct HostPlan {
     std::vector<ChainRef> crefs;
     std::vector<ChainOp> cops;
     std::vector<WtSlot> wt_slots;     // matrices with a transposed copy (those of the backward programmes)
-    size_t o_cref, o_cops, o_wtslots, o_WT;
+    ChainParts cparts[MPQE_STEP_MAX_BATCHES];
+    size_t o_cref, o_cops, o_wtslots, o_cparts, o_WT;
     // workspace offsets (bytes)
     size_t o_sd, o_wsrc, o_wblock, o_vsrc, o_vblock, o_groups, o_anchor, desc_total;     // descriptor buffer
     size_t o_H, o_GH, o_tpos, o_tneg, o_spos, o_sneg, o_terms, o_slabs, o_parts, total;  // workspace
@@ -1009,6 +1011,10 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     int part = 0, vblock = 0;
     hp->vsrc.clear();
     hp->vblock.clear();
+    for (int i = 0; i < MPQE_STEP_MAX_BATCHES; ++i) {
+        for (int q = 0; q < MPQE_STEP_MAX_LAYERS; ++q) hp->cparts[i].bias_part[q] = -1;
+        for (int k = 0; k < 3; ++k) hp->cparts[i].var_part[k] = -1;
+    }
     for (size_t k = 0; k < vk.size(); ++k) {
         const VKey &key = vk[k];
         const BatchDev &d = sd.b[key.batch];
@@ -1017,7 +1023,10 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         s.batch = key.batch;
         s.level_or_k = key.lk;
         s.relu = 0;
-        s.nblk = key.kind == 0 ? (int)(((long long)d.B * d.tp.N + 63) / 64) : (d.B + 63) / 64;
+        s.nblk = (d.B + CH_GB - 1) / CH_GB;
+        // where the chain kernel's block `blk` of this batch writes its partial row: part_start + blk
+        if (key.kind == 0) hp->cparts[key.batch].bias_part[key.lk] = part;
+        else hp->cparts[key.batch].var_part[key.lk] = part;
         s.part_start = part;
         s.block_start = vblock;
         s.pad = 0;
@@ -1166,6 +1175,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->o_cref = take(hp->crefs.size() * sizeof(ChainRef));
     hp->o_cops = take(hp->cops.size() * sizeof(ChainOp));
     hp->o_wtslots = take(hp->wt_slots.size() * sizeof(WtSlot));
+    hp->o_cparts = take(sizeof(hp->cparts));
     hp->desc_total = off;
     off = 0;
     hp->o_H = take((size_t)(hp->Lmax + 1) * rows * D * 4);
@@ -1373,6 +1383,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         upload(s, db + hp.o_cref, hp.crefs.data(), hp.crefs.size() * sizeof(ChainRef));
         upload(s, db + hp.o_cops, hp.cops.data(), hp.cops.size() * sizeof(ChainOp));
         upload(s, db + hp.o_wtslots, hp.wt_slots.data(), hp.wt_slots.size() * sizeof(WtSlot));
+        upload(s, db + hp.o_cparts, hp.cparts, sizeof(hp.cparts));
     }
     float *H = reinterpret_cast<float *>(wb + hp.o_H), *GH = reinterpret_cast<float *>(wb + hp.o_GH);
     float *tpos = reinterpret_cast<float *>(wb + hp.o_tpos), *tneg = reinterpret_cast<float *>(wb + hp.o_tneg);
@@ -1446,6 +1457,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         ca.H = H;
         ca.GH = GH;
         ca.WT = WT;
+        ca.cparts = reinterpret_cast<const ChainParts *>(db + hp.o_cparts);
+        ca.parts = reinterpret_cast<float *>(wb + hp.o_parts);
         ca.level_stride = hp.level_stride;
         ca.margin = margin;
         ca.eps = 1e-8f;
@@ -1572,8 +1585,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             hipLaunchKernelGGL(step_tail_kernel<LD_SCALAR>, tgrid, dim3(256), 0, s, sd, ta, (const float *)H,
                                (const float *)GH, hp.level_stride);
         mark(s);
-        // bias / variable-row partials, and (unless the chain kernel already did them) anchor-table gradients
-        const unsigned small_blocks = (unsigned)(ta.vblocks + (use_chain ? 0 : (hp.anchor_off[nb] + 3) / 4));
+        // bias / variable-row partials and anchor-table gradients (the chain kernel does them itself)
+        const unsigned small_blocks = use_chain ? 0u : (unsigned)(ta.vblocks + (hp.anchor_off[nb] + 3) / 4);
         if (small_blocks)
             hipLaunchKernelGGL(step_tail_small_kernel, dim3(small_blocks), dim3(256), 0, s, sd, ta, tabs,
                                (const float *)H, (const float *)GH, hp.level_stride);

@@ -119,7 +119,30 @@ struct ChainLds {
     float nrm[4 * CH_GB];                                // |v| of the anchor rows
     const float *wp[CH_MAX_OPS];                         // weight matrix of every op of the block's programme
     int opw[CH_MAX_OPS][2];                              // its (src | node << 8 | layer << 16 | level << 24, flags)
+    float red[256];                                      // column-sum scratch
 };
+
+// parts[row][:] = sum over the block's graphs i < ng and the node slots in `mask` of the LDS rows of buffer
+// `X` (fixed order). Called by the whole workgroup, between barriers of its own.
+template <int NCB>
+__device__ __forceinline__ void chain_colsum(ChainLds<NCB> &S, const float *X, unsigned mask, int ng,
+                                             float *__restrict__ dst) {
+    constexpr int D = 64 * NCB, LDX = D + 4, NP = 256 / D;
+    const int col = threadIdx.x % D, part = threadIdx.x / D;
+    float s = 0.f;
+    for (int n = 0; n < 4; ++n) {
+        if (!((mask >> n) & 1u)) continue;
+        for (int i = part; i < ng; i += NP) s += X[(n * CH_GB + i) * LDX + col];
+    }
+    S.red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < D && dst) {
+        float t = S.red[threadIdx.x];
+        for (int q = 1; q < NP; ++q) t += S.red[threadIdx.x + q * D];
+        dst[threadIdx.x] = t;
+    }
+    __syncthreads();
+}
 // an op as the K loop sees it: wave-uniform, read from LDS (a vector load from HBM here would sit in vmcnt
 // behind the weight prefetch and drain it)
 struct ChainStep {
@@ -134,7 +157,9 @@ struct ChainStep {
 // scheduler from sinking the prefetch loads down to the MFMAs that use them.
 template <int NCB, bool BWD>
 __device__ __forceinline__ void chain_run(ChainLds<NCB> &S, const int first_op, int T /* half-blocks */, int N, int ng,
-                                          float *__restrict__ Xrows, long long level_stride, int &cur) {
+                                          float *__restrict__ Xrows, long long level_stride, int &cur,
+                                          const unsigned *live = nullptr, const int *bias_part = nullptr,
+                                          float *parts = nullptr, int blk = 0) {
     constexpr int D = 64 * NCB, LDX = D + 4, BUF = 4 * CH_GB * LDX;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kq = lane >> 4;
@@ -227,6 +252,11 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB> &S, const int first_op, 
         if (op.flags & CH_LEVEL_END) {       // uniform over the workgroup: every wave runs the same programme
             __syncthreads();
             cur ^= 1;
+            if (BWD && op.level >= 1) {      // gH[level] is complete: its column sums are pass level-1's bias gradient
+                const int pr = bias_part[op.level - 1];
+                chain_colsum<NCB>(S, S.xs + cur * BUF, live[op.level], ng,
+                                  pr >= 0 ? parts + (long long)(pr + blk) * D : nullptr);
+            }
         }
     };
     if (T <= 0) return;
@@ -257,6 +287,13 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB> &S, const int first_op, 
     }
 }
 
+// where a block's partial column sums go (row of the step's `parts` array; -1 = none): bias gradient of
+// pass q = column sums of gH[q + 1] over the block's live rows; variable row k = sums of gH[0] rows of
+// node slot A + k. Row = entry + (block index inside the batch).
+struct ChainParts {
+    int bias_part[MPQE_STEP_MAX_LAYERS], var_part[3], pad;
+};
+
 struct ChainArgs {
     const ChainRef *refs;
     const ChainOp *ops;
@@ -267,6 +304,8 @@ struct ChainArgs {
     const long long *anchor_ids, *targets, *negs;
     float *H, *GH;
     const float *WT;        // transposed copies of the matrices the backward chains multiply by
+    const ChainParts *cparts;
+    float *parts;
     long long level_stride;
     float margin, eps;
     float *s_pos, *s_neg, *terms;
@@ -537,9 +576,19 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     if (!ca.backward) return;
     __syncthreads();
     chain_stamp(ca, 4);
+    const ChainParts &cp = ca.cparts[ref.batch];
+    const int blk = g0 / CH_GB;
+    {   // bias gradient of the last pass: column sums of gH[L]
+        const int pr = cp.bias_part[L - 1];
+        chain_colsum<NCB>(S, S.xs + cur * BUF, b.live[L], ng, pr >= 0 ? ca.parts + (long long)(pr + blk) * D : nullptr);
+    }
 
     // ---- backward levels
-    chain_run<NCB, true>(S, ref.fwd_count, ref.bwd_count * NCB, N, ng, ca.GH + row0 * D, ca.level_stride, cur);
+    chain_run<NCB, true>(S, ref.fwd_count, ref.bwd_count * NCB, N, ng, ca.GH + row0 * D, ca.level_stride, cur, b.live,
+                         cp.bias_part, ca.parts, blk);
+    for (int k = 0; k < b.V; ++k)        // variable rows of gH[0] -> mode-embedding gradient partials
+        if (cp.var_part[k] >= 0)
+            chain_colsum<NCB>(S, S.xs + cur * BUF, 1u << (A + k), ng, ca.parts + (long long)(cp.var_part[k] + blk) * D);
 
     chain_stamp(ca, 5);
     // ---- anchor rows of gH[0] through the L2 normalisation into the entity-table gradients (fp32 atomics:
