@@ -300,8 +300,9 @@ int mpqe_step_forward_backward(const mpqe_step_params_t *params_host, const mpqe
 
 /* Diagnostics, not part of the data path: while `device_buffer` (8 int64 per workgroup, num_blocks
  * workgroups) is set, every chain-kernel launch with at most num_blocks workgroups writes per workgroup the
- * device wall clock (100 MHz) at its phase boundaries [0..6] and HW_ID | XCC_ID << 32 in [7]. NULL turns it
- * off. Process-global; used by tools/chain_timeline.py only.                                        */
+ * device wall clock (100 MHz) at its phase boundaries [0..6] and HW_ID | XCC_ID << 32 in [7]; workgroup g of a
+ * launch of G workgroups also writes its shader-clock ticks at the first / last stamp to words 0 / 1 of entry
+ * G + g, so 2 G <= num_blocks is required. NULL turns it off. Process-global; tools/chain_timeline.py only. */
 void mpqe_debug_chain_stamps(void *device_buffer, size_t num_blocks);
 
 #ifdef __cplusplus

@@ -1467,7 +1467,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         ca.terms = terms;
         ca.err = err;
         ca.backward = backward ? 1 : 0;
-        ca.stamps = g_chain_stamps && hp.crefs.size() <= g_chain_stamp_blocks ? g_chain_stamps : nullptr;
+        ca.stamps = g_chain_stamps && 2 * hp.crefs.size() <= g_chain_stamp_blocks ? g_chain_stamps : nullptr;
         dim3 cgrid((unsigned)hp.crefs.size());
         mark(s);
         if (D == 64) hipLaunchKernelGGL(step_chain_kernel<1>, cgrid, dim3(256), 0, s, sd, lp, tabs, ca);

@@ -157,8 +157,8 @@ struct ChainStep {
 // scheduler from sinking the prefetch loads down to the MFMAs that use them.
 template <int NCB, bool BWD>
 __device__ __forceinline__ void chain_run(ChainLds<NCB> &S, const int first_op, int T /* half-blocks */, int N, int ng,
-                                          float *__restrict__ Xrows, long long level_stride, int &cur,
-                                          const unsigned *live = nullptr, const int *bias_part = nullptr,
+                                          float *__restrict__ Xrows, long long level_stride, int &cur, int A = 0,
+                                          const int *bias_part = nullptr, const int *var_part = nullptr,
                                           float *parts = nullptr, int blk = 0) {
     constexpr int D = 64 * NCB, LDX = D + 4, BUF = 4 * CH_GB * LDX;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -183,33 +183,38 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB> &S, const int first_op, 
         return W + (long long)(64 * h + 4 * kq) * D + colb;
     };
     f32x4 acc[NCB];
-    // one half-block: its 4 t-steps of MFMAs, each preceded by the loads of the same t-step of the half-block
-    // two items ahead (`fn` <- `wn`): the load issue is spread between the MFMAs instead of stalling them
+    // one half-block: 4 t-steps of NCB x 4 MFMAs; the weights of the half-block two items ahead are loaded
+    // into `fn` (from `wn`) on the way
+    float bs[NCB];          // backward: column sums of this level's gradient rows (bias gradient of the pass below)
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) bs[c] = 0.f;
     auto item = [&](const ChainStep &op, int it, const WHalf<NCB> &f, WHalf<NCB> &fn, const float *wn) {
         const int h = it % NCB;
+        // all four A fragments of the item up front: one exposed LDS round trip per item
         const float *xp = S.xs + cur * BUF + (op.src * CH_GB + j) * LDX + 64 * h + 4 * kq;
-        // all four A fragments of the item up front: one exposed LDS round trip per item instead of four
         f32x4 av[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) av[t] = *reinterpret_cast<const f32x4 *>(xp + 16 * t);
+        // ONE weight load (and its address arithmetic) between every NCB MFMAs: an MFMA occupies the matrix pipe
+        // for 32 cycles but the issue port only for 8, so what follows it issues in its shadow -- a burst of
+        // loads between groups of 8 MFMAs instead leaves the pipe idle for the length of the burst
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            chain_load_t<NCB>(fn, wn, D, t);
-            __builtin_amdgcn_sched_barrier(0);
             const f32x4 a = av[t];
-#if CHAIN_DBG == 2
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 4; ++u) {
+                if (CHAIN_DBG != 1) chain_gload<NCB>(fn.v[t][u], wn + (long long)(16 * t + u) * D);
+                __builtin_amdgcn_sched_barrier(0);
+#if CHAIN_DBG == 2
 #pragma unroll
                 for (int c = 0; c < NCB; ++c) asm volatile("" ::"v"(f.v[t][u][c]), "v"(a[u]));
 #else
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
                 for (int c = 0; c < NCB; ++c)
                     acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], f.v[t][u][c], acc[c], 0, 0, 0);
 #endif
-            __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (h != NCB - 1) return;
         if (op.flags & CH_LAST) {
@@ -222,6 +227,9 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB> &S, const int first_op, 
 #pragma unroll
             for (int c = 0; c < NCB; ++c) bv[c] = BWD ? 0.f : S.bias[op.layer * D + colb + c];
             unsigned out_bits = 0;
+            float ns[NCB];          // this node's column sums over the block's graphs (backward)
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) ns[c] = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * kq + r;
@@ -240,7 +248,26 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB> &S, const int first_op, 
                     }
                 }
                 chain_store<NCB>(Xn + (op.node * CH_GB + row) * LDX + colb, v);
-                if (row < ng) chain_store<NCB>(Xout + ((long long)row * N + op.node) * D + colb, v);
+                if (row < ng) {
+                    chain_store<NCB>(Xout + ((long long)row * N + op.node) * D + colb, v);
+                    if (BWD) {
+#pragma unroll
+                        for (int c = 0; c < NCB; ++c) {
+                            bs[c] += v[c];
+                            ns[c] += v[c];
+                        }
+                    }
+                }
+            }
+            if (BWD && op.level == 0 && op.node >= A && var_part[op.node - A] >= 0) {
+                // a variable row of gH[0]: its sum over the block's graphs is a mode-embedding gradient partial
+                float t[NCB];
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) {
+                    t[c] = ns[c] + __shfl_xor(ns[c], 16, 64);
+                    t[c] += __shfl_xor(t[c], 32, 64);
+                }
+                if (kq == 0) chain_store<NCB>(parts + (long long)(var_part[op.node - A] + blk) * D + colb, t);
             }
             if (!BWD && (op.flags & CH_RELU)) S.mbits[mslot] = (typename chain_bits<NCB>::type)out_bits;
             // the next node update starts from zero (cleared here, inside the uniform branch, rather than by a
@@ -250,13 +277,20 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB> &S, const int first_op, 
             for (int c = 0; c < NCB; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (op.flags & CH_LEVEL_END) {       // uniform over the workgroup: every wave runs the same programme
+            if (BWD) {      // gH[level] is complete: its column sums (rows 4 kq + r live in lane group kq; the wave
+                            // owns its columns) are pass level-1's bias gradient. Fixed order, no barrier.
+                float t[NCB];
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) {
+                    t[c] = bs[c] + __shfl_xor(bs[c], 16, 64);
+                    t[c] += __shfl_xor(t[c], 32, 64);
+                    bs[c] = 0.f;
+                }
+                if (op.level >= 1 && bias_part[op.level - 1] >= 0 && kq == 0)
+                    chain_store<NCB>(parts + (long long)(bias_part[op.level - 1] + blk) * D + colb, t);
+            }
             __syncthreads();
             cur ^= 1;
-            if (BWD && op.level >= 1) {      // gH[level] is complete: its column sums are pass level-1's bias gradient
-                const int pr = bias_part[op.level - 1];
-                chain_colsum<NCB>(S, S.xs + cur * BUF, live[op.level], ng,
-                                  pr >= 0 ? parts + (long long)(pr + blk) * D : nullptr);
-            }
         }
     };
     if (T <= 0) return;
@@ -318,7 +352,16 @@ struct ChainArgs {
 // stamps of different workgroups line up into a timeline (tools/chain_timeline.py)
 __device__ __forceinline__ void chain_stamp(const ChainArgs &ca, int slot) {
 #ifndef MPQE_EMU
-    if (ca.stamps && threadIdx.x == 0) ca.stamps[(long long)blockIdx.x * 8 + slot] = (long long)wall_clock64();
+    if (ca.stamps && threadIdx.x == 0) {
+        ca.stamps[(long long)blockIdx.x * 8 + slot] = (long long)wall_clock64();
+        // shader-clock ticks at the first and the last stamp (beyond the 8 words of every block: second half
+        // of the buffer): ticks / wall time = the clock the CU really ran at
+        if (slot == 0 || slot == 6) {
+            const long long t = (long long)__builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            ca.stamps[((long long)gridDim.x + blockIdx.x) * 8 + (slot == 0 ? 0 : 1)] = t;
+        }
+    }
 #endif
 }
 __device__ __forceinline__ void chain_stamp_where(const ChainArgs &ca) {
@@ -584,11 +627,8 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     }
 
     // ---- backward levels
-    chain_run<NCB, true>(S, ref.fwd_count, ref.bwd_count * NCB, N, ng, ca.GH + row0 * D, ca.level_stride, cur, b.live,
-                         cp.bias_part, ca.parts, blk);
-    for (int k = 0; k < b.V; ++k)        // variable rows of gH[0] -> mode-embedding gradient partials
-        if (cp.var_part[k] >= 0)
-            chain_colsum<NCB>(S, S.xs + cur * BUF, 1u << (A + k), ng, ca.parts + (long long)(cp.var_part[k] + blk) * D);
+    chain_run<NCB, true>(S, ref.fwd_count, ref.bwd_count * NCB, N, ng, ca.GH + row0 * D, ca.level_stride, cur, A,
+                         cp.bias_part, cp.var_part, ca.parts, blk);
 
     chain_stamp(ca, 5);
     // ---- anchor rows of gH[0] through the L2 normalisation into the entity-table gradients (fp32 atomics:

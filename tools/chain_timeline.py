@@ -49,14 +49,21 @@ def main():
     for _ in range(5):
         step.run(packed)
     torch.cuda.synchronize()
-    cap = 8 * sum((b + 15) // 16 for b in packed.sizes)      # the launch grid has holes (placement by XCD)
+    cap = 16 * sum((b + 15) // 16 for b in packed.sizes)     # the launch grid has holes (placement by XCD)
     stamps = torch.zeros(cap * 8, dtype=torch.int64, device=dev)
     ops.lib().mpqe_debug_chain_stamps(stamps.data_ptr(), cap)
     step.run(packed)
     torch.cuda.synchronize()
     ops.lib().mpqe_debug_chain_stamps(None, 0)
     st = stamps.cpu().numpy().reshape(cap, 8)
-    st = st[st[:, 6] != 0]
+    used = np.nonzero(st[:, 6] != 0)[0]
+    grid = int(used.max()) + 1                               # (holes only inside the grid; the last block is real)
+    grid = (grid + 7) // 8 * 8
+    ticks = st[grid:2 * grid]
+    sel = used[used < grid]
+    mhz = (ticks[sel, 1] - ticks[sel, 0]) / ((st[sel, 6] - st[sel, 0]) * 0.01)
+    print('shader clock while the workgroups ran: mean %.0f MHz (min %.0f, max %.0f)' % (mhz.mean(), mhz.min(), mhz.max()))
+    st = st[sel]
     nblk = st.shape[0]
     t = (st[:, :7] - st[:, 0].min()) * 0.01              # us
     hw = st[:, 7] & 0xffffffff
