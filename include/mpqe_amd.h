@@ -298,6 +298,17 @@ int mpqe_step_forward_backward(const mpqe_step_params_t *params_host, const mpqe
                                const mpqe_step_lanes_t *lanes, void *const *events, int num_events,
                                void *stream);
 
+/* ---- optimiser step ---------------------------------------------------------
+ * reference train.py:83-88: optim.Adam(params, lr) / optim.SGD(params, lr, momentum=0) over every
+ * parameter, dense entity tables included. One launch over flat fp32 buffers (the fused step keeps the
+ * gradients flat already). Same update rule as torch.optim.Adam (amsgrad off) / torch.optim.SGD:
+ *   g += wd p;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * step = t >= 1 (the caller counts). All four arrays [n], updated in place. Hyper-parameters are doubles,
+ * as torch holds them: 1 - beta and the bias corrections are formed in double and rounded once.       */
+int mpqe_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, double lr,
+                   double beta1, double beta2, double eps, double weight_decay, int64_t step, void *stream);
+int mpqe_sgd_step(float *param, const float *grad, int64_t n, double lr, double weight_decay, void *stream);
+
 /* Diagnostics, not part of the data path: while `device_buffer` (8 int64 per workgroup, num_blocks
  * workgroups) is set, every chain-kernel launch with at most num_blocks workgroups writes per workgroup the
  * device wall clock (100 MHz) at its phase boundaries [0..6] and HW_ID | XCC_ID << 32 in [7]; workgroup g of a

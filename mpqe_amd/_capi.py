@@ -12,6 +12,7 @@ I = c_int
 L = c_int64
 Z = c_size_t
 F = c_float
+DBL = ctypes.c_double
 
 
 class TemplateInfo(ctypes.Structure):
@@ -86,6 +87,8 @@ PROTOTYPES = {
     'mpqe_hinge_fwd': (I, [P, P, L, F, P, P]),
     'mpqe_hinge_bwd': (I, [P, P, L, F, P, P, P, P]),
     'mpqe_debug_chain_stamps': (None, [P, Z]),
+    'mpqe_adam_step': (I, [P, P, P, P, L, DBL, DBL, DBL, DBL, DBL, L, P]),
+    'mpqe_sgd_step': (I, [P, P, L, DBL, DBL, P]),
     'mpqe_step_workspace_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I]),
     'mpqe_step_desc_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I]),
     'mpqe_step_forward_backward': (I, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, P, P, P, F,

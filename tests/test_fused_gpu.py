@@ -84,3 +84,40 @@ def test_fused_step_bad_id_is_reported():
     step.run(step.pack(batches))
     with pytest.raises(IndexError):
         step.check()
+
+
+@pytest.mark.parametrize('opt', ['adam', 'sgd'])
+def test_training_loop_fused_step_plus_flat_optimizer(opt):
+    """Three training steps: FusedTrainStep + FlatOptimizer (one launch over the flat parameter buffer)
+    against the module path + torch.optim (the reference's loop, train_helpers.py:76-120, train.py:83-88)."""
+    import copy
+    from mpqe_amd import ops
+    from mpqe_amd.fused import FusedTrainStep
+    from mpqe_amd.optim import FlatOptimizer
+    model, batches = _setup('mp', True, False)
+    ref_model = copy.deepcopy(model)
+    ref_opt = (torch.optim.Adam(ref_model.parameters(), lr=0.01) if opt == 'adam'
+               else torch.optim.SGD(ref_model.parameters(), lr=0.01, momentum=0))
+    step = FusedTrainStep(model)
+    fopt = FlatOptimizer(step, lr=0.01, opt=opt)
+    keys = list(model.state_dict().keys())
+    packed = step.pack(batches)
+    for it in range(3):
+        ref_opt.zero_grad()
+        total = None
+        for b in batches:
+            out = ref_model.encode(b['formula'], b['queries'])
+            l = ops.hinge(ref_model.score(b['formula'], out, b['targets'].tolist()),
+                          ref_model.score(b['formula'], out, b['negs'].tolist()), 1.0) * b['weight']
+            total = l if total is None else total + l
+        total.backward()
+        ref_opt.step()
+        loss = step.run(packed)
+        fopt.step()
+        np.testing.assert_allclose(loss[0].item(), total.item(), rtol=2e-5, atol=1e-6)
+    assert list(model.state_dict().keys()) == keys            # re-homing the parameters changes no name
+    for (k, p), (_, q) in zip(model.named_parameters(), ref_model.named_parameters()):
+        # Adam divides by sqrt(v): where a gradient is ~1e-8 the two paths' last bits decide the step's sign
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=1e-3,
+                                   atol=2e-3 if opt == 'adam' else 1e-6, err_msg=k)
+    assert model.layers[0].basis.data_ptr() >= fopt.flat_param.data_ptr()

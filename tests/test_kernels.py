@@ -427,3 +427,40 @@ def test_hinge_fwd_bwd(be, n):
     be.check(be.lib.mpqe_hinge_bwd(be.ptr(dp), be.ptr(dn), n, margin, be.ptr(gl), be.ptr(gp), be.ptr(gn), be.stream))
     close(be.get(gp), pt.grad.numpy(), rtol=1e-5)
     close(be.get(gn), nt.grad.numpy(), rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------ optimiser step
+@pytest.mark.parametrize('n,wd', [(1000, 0.0), (4099, 1e-3), (3, 0.0)])
+def test_adam_step_matches_torch(be, n, wd):
+    """mpqe_adam_step vs torch.optim.Adam (the reference's optimiser, train.py:87) over several steps."""
+    rng = np.random.RandomState(n)
+    p0 = rng.randn(n).astype(np.float32)
+    ref = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.Adam([ref], lr=0.01, weight_decay=wd)
+    p, m, v = be.put(p0), be.zeros((n,)), be.zeros((n,))
+    for t in range(1, 6):
+        g = (rng.randn(n) * (0.1 if t % 2 else 3.0)).astype(np.float32)
+        ref.grad = torch.from_numpy(g.copy())
+        opt.step()
+        dg = be.put(g)
+        be.check(be.lib.mpqe_adam_step(be.ptr(p), be.ptr(dg), be.ptr(m), be.ptr(v), n, 0.01, 0.9, 0.999, 1e-8, wd, t,
+                                       be.stream), 'adam')
+        np.testing.assert_allclose(be.get(p), ref.detach().numpy(), rtol=2e-6, atol=3e-7)     # p ~ 1: a few ulps
+    state = opt.state[ref]
+    # gradients are O(3): one rounding of an O(3) intermediate is ~2.4e-7 absolute
+    np.testing.assert_allclose(be.get(m), state['exp_avg'].numpy(), rtol=1e-6, atol=3e-7)
+    np.testing.assert_allclose(be.get(v), state['exp_avg_sq'].numpy(), rtol=2e-6, atol=1e-9)
+
+
+def test_sgd_step_matches_torch(be):
+    rng = np.random.RandomState(5)
+    p0, g = rng.randn(777).astype(np.float32), rng.randn(777).astype(np.float32)
+    ref = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    ref.grad = torch.from_numpy(g.copy())
+    torch.optim.SGD([ref], lr=0.05, momentum=0, weight_decay=1e-2).step()
+    p, dg = be.put(p0), be.put(g)
+    be.check(be.lib.mpqe_sgd_step(be.ptr(p), be.ptr(dg), 777, 0.05, 1e-2, be.stream), 'sgd')
+    np.testing.assert_allclose(be.get(p), ref.detach().numpy(), rtol=1e-6, atol=1e-7)
+    assert be.lib.mpqe_adam_step(None, None, None, None, 4, 0.01, 0.9, 0.999, 1e-8, 0.0, 1, be.stream) == -1
+    assert be.lib.mpqe_adam_step(be.ptr(p), be.ptr(dg), be.ptr(p), be.ptr(p), 4, 0.01, 0.9, 0.999, 1e-8, 0.0, 0,
+                                 be.stream) == -1
