@@ -309,6 +309,18 @@ int mpqe_adam_step(float *param, const float *grad, float *exp_avg, float *exp_a
                    double beta1, double beta2, double eps, double weight_decay, int64_t step, void *stream);
 int mpqe_sgd_step(float *param, const float *grad, int64_t n, double lr, double weight_decay, void *stream);
 
+/* ---- negative sampling on the device -------------------------------------------
+ * reference model.py:466-476: one negative per query, random.choice over query.neg_samples /
+ * query.hard_neg_samples (ragged per query) or graph.full_lists[target_mode] (1-chain: one list for all).
+ * cand [n_cand]: candidate entity ids. offsets [n_lists + 1] (CSR over cand) or NULL = every query draws
+ * from the whole of cand. qidx [nq] (or NULL = identity): list of batch position i. out[i] = a uniform
+ * draw from the list, chosen by a counter-based hash of (seed, i) -- stateless, reproduced on the CPU by
+ * oracle/ref_cpu.py; NOT python's random stream (same distribution, other numbers). An empty or invalid
+ * list ORs MPQE_FLAG_BAD_INDEX into err and writes -1 (the reference raises IndexError).             */
+int mpqe_sample_negatives(const int64_t *cand, int64_t n_cand, const int64_t *offsets, int64_t n_lists,
+                          const int64_t *qidx, int64_t nq, uint64_t seed, int64_t *out, int32_t *err,
+                          void *stream);
+
 /* Diagnostics, not part of the data path: while `device_buffer` (8 int64 per workgroup, num_blocks
  * workgroups) is set, every chain-kernel launch with at most num_blocks workgroups writes per workgroup the
  * device wall clock (100 MHz) at its phase boundaries [0..6] and HW_ID | XCC_ID << 32 in [7]; workgroup g of a

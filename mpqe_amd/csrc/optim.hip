@@ -86,3 +86,57 @@ extern "C" int mpqe_sgd_step(float *param, const float *grad, int64_t n, double 
                        (float)lr, (float)weight_decay);
     return mpqe_launch_status();
 }
+
+// ------------------------------------------------------------------------------------ negative sampling
+// SURVEY.md 8f-2. reference model.py:466-476 draws ONE negative per query with python's random.choice
+// from query.neg_samples / query.hard_neg_samples (ragged, per query) or, for 1-chain queries, from
+// graph.full_lists[target_mode] (one list for every query). Here the candidate lists sit in HBM as CSR and
+// the draw is a counter-based hash of (seed, position in the batch): no state, reproducible on the CPU
+// (oracle/ref_cpu.py: sample_negatives). It is NOT python's Mersenne-Twister stream: same distribution
+// (uniform over the candidates), different numbers.
+__host__ __device__ __forceinline__ unsigned long long mpqe_mix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;            // splitmix64
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(256) void sample_negatives_kernel(const long long *__restrict__ cand,
+                                                               const long long *__restrict__ offsets,
+                                                               const long long *__restrict__ qidx, long long n_cand,
+                                                               long long n_lists, long long nq, unsigned long long seed,
+                                                               long long *__restrict__ out, int32_t *err) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq) return;
+    long long lo = 0, hi = n_cand;
+    if (offsets) {
+        const long long q = qidx ? qidx[i] : i;
+        if (q < 0 || q >= n_lists) {
+            flag_error(err, MPQE_FLAG_BAD_INDEX);
+            out[i] = -1;
+            return;
+        }
+        lo = offsets[q];
+        hi = offsets[q + 1];
+    }
+    if (hi <= lo || lo < 0 || hi > n_cand) {      // random.choice([]) raises IndexError in the reference
+        flag_error(err, MPQE_FLAG_BAD_INDEX);
+        out[i] = -1;
+        return;
+    }
+    const unsigned long long r = mpqe_mix64(seed ^ mpqe_mix64((unsigned long long)i));
+    out[i] = cand[lo + (long long)(r % (unsigned long long)(hi - lo))];
+}
+
+extern "C" int mpqe_sample_negatives(const int64_t *cand, int64_t n_cand, const int64_t *offsets, int64_t n_lists,
+                                     const int64_t *qidx, int64_t nq, uint64_t seed, int64_t *out, int32_t *err,
+                                     void *stream) {
+    if (!cand || !out || n_cand < 0 || nq <= 0) return MPQE_ERR_INVALID_ARG;
+    if (!offsets && qidx) return MPQE_ERR_INVALID_ARG;
+    if (offsets && n_lists <= 0) return MPQE_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(sample_negatives_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const long long *>(cand), reinterpret_cast<const long long *>(offsets),
+                       reinterpret_cast<const long long *>(qidx), (long long)n_cand, (long long)n_lists, (long long)nq,
+                       (unsigned long long)seed, reinterpret_cast<long long *>(out), err);
+    return mpqe_launch_status();
+}

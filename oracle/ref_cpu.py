@@ -262,3 +262,38 @@ def margin_loss(params, cfg, node_map, formula, col, target_nodes, neg_nodes, ma
             reg = reg + torch.norm(params[k])
         loss = loss + cfg['weight_decay'] * reg
     return loss
+
+
+# --------------------------------------------------------------------------- negative sampling
+_M64 = (1 << 64) - 1
+
+
+def _mix64(x):
+    """splitmix64 finaliser, python ints (mpqe_amd/csrc/optim.hip: mpqe_mix64)."""
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+def sample_negatives(cand, offsets, qidx, nq, seed):
+    """One uniform draw per batch position from its candidate list (reference model.py:466-476 draws with
+    python's random.choice; the device path uses this counter-based stream instead -- same distribution).
+    cand: int64 array; offsets: CSR over cand or None (every query draws from all of cand); qidx: list index
+    per position or None. Returns (int64 [nq], bad) with -1 / bad=True for empty lists."""
+    out = np.empty(nq, dtype=np.int64)
+    bad = False
+    for i in range(nq):
+        lo, hi = 0, len(cand)
+        if offsets is not None:
+            q = int(qidx[i]) if qidx is not None else i
+            if q < 0 or q >= len(offsets) - 1:
+                out[i], bad = -1, True
+                continue
+            lo, hi = int(offsets[q]), int(offsets[q + 1])
+        if hi <= lo or lo < 0 or hi > len(cand):
+            out[i], bad = -1, True
+            continue
+        r = _mix64((seed & _M64) ^ _mix64(i))
+        out[i] = cand[lo + r % (hi - lo)]
+    return out, bad

@@ -121,3 +121,73 @@ def test_training_loop_fused_step_plus_flat_optimizer(opt):
         np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=1e-3,
                                    atol=2e-3 if opt == 'adam' else 1e-6, err_msg=k)
     assert model.layers[0].basis.data_ptr() >= fopt.flat_param.data_ptr()
+
+
+def test_negative_sampler_on_device():
+    """NegativeSampler: draws come from each query's own list, match the CPU stream, and can be written
+    straight into a packed step's id buffer."""
+    from mpqe_amd import synthetic
+    from mpqe_amd.sampling import NegativeSampler
+    from oracle import ref_cpu
+    schema = synthetic.make_schema(*synthetic.KG_SHAPES['tiny'], seed=0)
+    rng = np.random.RandomState(2)
+    f = synthetic.sample_formula(schema, '3-inter', rng)
+    qs = synthetic.sample_queries(schema, f, 200, rng)
+    for q in qs:
+        q.neg_samples = [int(v) for v in rng.randint(1, 50, size=rng.randint(1, 6))]
+        q.hard_neg_samples = [int(v) for v in rng.randint(50, 90, size=rng.randint(1, 4))]
+    s = NegativeSampler(qs, 'cuda:0')
+    idx = rng.permutation(200)[:128]
+    got = s.sample(idx, seed=42).cpu().numpy()
+    off = np.concatenate([[0], np.cumsum([len(q.neg_samples) for q in qs])])
+    cand = np.array([v for q in qs for v in q.neg_samples], dtype=np.int64)
+    np.testing.assert_array_equal(got, ref_cpu.sample_negatives(cand, off, idx, 128, 42)[0])
+    assert all(got[i] in qs[idx[i]].neg_samples for i in range(128))
+    hard = s.sample(idx, seed=43, hard_negatives=True).cpu().numpy()
+    assert all(hard[i] in qs[idx[i]].hard_neg_samples for i in range(128))
+    buf = torch.zeros(256, dtype=torch.long, device='cuda:0')
+    s.sample(idx, seed=42, out=buf[64:192])
+    assert torch.equal(buf[64:192].cpu(), torch.from_numpy(got)) and int(buf[:64].abs().sum()) == 0
+    s.check()
+    shared = NegativeSampler(qs, 'cuda:0', full_list=range(1000, 1010))
+    d = shared.sample(np.arange(64), seed=1).cpu().numpy()
+    assert d.min() >= 1000 and d.max() < 1010
+    qs[3].neg_samples = []
+    with pytest.raises(IndexError):
+        bad = NegativeSampler(qs, 'cuda:0')
+        bad.sample(np.array([3, 4]), seed=0)
+        bad.check()
+
+
+def test_evaluation_loop_on_gpu_matches_oracle():
+    """eval_auc_queries / eval_perc_queries (reference utils.py:34-95) through the GPU modules against the same
+    loops through the CPU oracle: ragged negatives per query (the `neg_lengths` scoring form)."""
+    from mpqe_amd import evaluation, synthetic
+    from oracle import ref_cpu
+    model, _ = _setup('sum', False, False, D=32)
+    schema = synthetic.make_schema(*synthetic.KG_SHAPES['tiny'], seed=0)
+    rng = np.random.RandomState(9)
+    test_queries = {}
+    for qt in ('2-chain', '3-inter_chain'):
+        f = synthetic.sample_formula(schema, qt, rng)
+        qs = []
+        for _ in range(150):
+            q = synthetic.sample_queries(schema, f, 1, rng, n_neg=int(rng.randint(1, 12)), n_hard=3)[0]
+            qs.append(q)
+        test_queries[f] = qs
+    params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cfg = dict(readout='sum', scatter_op='add', num_layers=3, adaptive=False, weight_decay=0)
+    node_map = model.enc.node_maps.cpu()
+
+    class Oracle(object):
+        def forward(self, formula, queries, targets, neg_nodes=None, neg_lengths=None):
+            col = ref_cpu.collate(formula, queries, model.rel_ids, model.mode_ids)
+            return ref_cpu.forward(params, cfg, node_map, formula, col, targets, neg_nodes, neg_lengths)
+    with torch.no_grad():
+        auc, per = evaluation.eval_auc_queries(test_queries, model, batch_size=64, seed=1)
+        perc = evaluation.eval_perc_queries(test_queries, model, batch_size=64)
+        auc_ref, per_ref = evaluation.eval_auc_queries(test_queries, Oracle(), batch_size=64, seed=1)
+        perc_ref = evaluation.eval_perc_queries(test_queries, Oracle(), batch_size=64)
+    assert abs(auc - auc_ref) < 1e-3 and abs(perc - perc_ref) < 0.2     # a near-tie may swap one pair
+    for f in per:
+        assert abs(per[f] - per_ref[f]) < 2e-3

@@ -464,3 +464,50 @@ def test_sgd_step_matches_torch(be):
     assert be.lib.mpqe_adam_step(None, None, None, None, 4, 0.01, 0.9, 0.999, 1e-8, 0.0, 1, be.stream) == -1
     assert be.lib.mpqe_adam_step(be.ptr(p), be.ptr(dg), be.ptr(p), be.ptr(p), 4, 0.01, 0.9, 0.999, 1e-8, 0.0, 0,
                                  be.stream) == -1
+
+
+# ------------------------------------------------------------------------------------ negative sampling
+def test_sample_negatives_matches_oracle(be):
+    """mpqe_sample_negatives: bit-exact against the CPU stream; ragged lists, shared list, indirection,
+    empty lists flagged."""
+    rng = np.random.RandomState(3)
+    lens = rng.randint(1, 9, size=40)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    cand = rng.randint(0, 10 ** 6, size=int(offsets[-1])).astype(np.int64)
+    qidx = rng.randint(0, 40, size=300).astype(np.int64)
+    d_c, d_o, d_q = be.put(cand), be.put(offsets), be.put(qidx)
+    for seed in (0, 12345, 2 ** 63 + 17):
+        out, err = be.empty((300,), np.int64), be.zeros((1,), np.int32)
+        be.check(be.lib.mpqe_sample_negatives(be.ptr(d_c), len(cand), be.ptr(d_o), 40, be.ptr(d_q), 300, seed,
+                                              be.ptr(out), be.ptr(err), be.stream), 'sample')
+        ref, bad = ref_cpu.sample_negatives(cand, offsets, qidx, 300, seed)
+        np.testing.assert_array_equal(be.get(out), ref)
+        assert not bad and int(be.get(err)[0]) == 0
+        # every draw comes from its own list
+        for i in range(300):
+            assert ref[i] in cand[offsets[qidx[i]]:offsets[qidx[i] + 1]]
+    # one shared list (the 1-chain case), identity map
+    out = be.empty((64,), np.int64)
+    be.check(be.lib.mpqe_sample_negatives(be.ptr(d_c), len(cand), None, 0, None, 64, 7, be.ptr(out), None, be.stream), 's')
+    np.testing.assert_array_equal(be.get(out), ref_cpu.sample_negatives(cand, None, None, 64, 7)[0])
+    # an empty list is flagged, like random.choice([]) raising in the reference
+    offsets2 = offsets.copy()
+    offsets2[6:] -= lens[5]
+    offsets2[6] = offsets2[5]
+    d_o2 = be.put(offsets2)
+    out, err = be.empty((300,), np.int64), be.zeros((1,), np.int32)
+    be.check(be.lib.mpqe_sample_negatives(be.ptr(d_c), len(cand), be.ptr(d_o2), 40, be.ptr(d_q), 300, 1, be.ptr(out),
+                                          be.ptr(err), be.stream), 'sample')
+    ref, bad = ref_cpu.sample_negatives(cand, offsets2, qidx, 300, 1)
+    np.testing.assert_array_equal(be.get(out), ref)
+    assert bad and (int(be.get(err)[0]) & FLAG_BAD_INDEX) and (ref == -1).sum() == (qidx == 5).sum()
+    assert be.lib.mpqe_sample_negatives(None, 0, None, 0, None, 4, 1, be.ptr(out), None, be.stream) == -1
+
+
+def test_sample_negatives_is_uniform(be):
+    cand = np.arange(10, dtype=np.int64)
+    out = be.empty((20000,), np.int64)
+    be.check(be.lib.mpqe_sample_negatives(be.ptr(be.put(cand)), 10, None, 0, None, 20000, 99, be.ptr(out), None,
+                                          be.stream), 'sample')
+    counts = np.bincount(be.get(out), minlength=10)
+    assert counts.min() > 1800 and counts.max() < 2200
