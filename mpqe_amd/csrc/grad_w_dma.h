@@ -37,7 +37,7 @@ typedef void __attribute__((address_space(3))) * gwd_lptr;
 __device__ __forceinline__ void grad_w_tile_dma(const float *__restrict__ x, const float *__restrict__ g, int Din,
                                                 int Dout, long long xs, long long xo, long long gs, long long go,
                                                 long long q0, int nsteps, int i0, int j0,
-                                                float *__restrict__ slab, float *smem) {
+                                                float *__restrict__ slab, float *smem, bool accumulate = false) {
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -96,6 +96,7 @@ __device__ __forceinline__ void grad_w_tile_dma(const float *__restrict__ x, con
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = i0 + acc_row(r);
-        slab[(long long)row * Dout + col] = acc[r];
+        float *o = slab + (long long)row * Dout + col;      // accumulate: the tile IS the gradient (one source)
+        *o = accumulate ? *o + acc[r] : acc[r];
     }
 }

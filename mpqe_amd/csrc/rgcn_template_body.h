@@ -301,7 +301,7 @@ __device__ __forceinline__ void tmpl_grad_w_tile(const float *__restrict__ x, co
                                                  const float *__restrict__ out, int Din, int Dout, int relu,
                                                  long long xs, long long xo, long long gs, long long go,
                                                  long long q0, long long q1, int i0, int j0,
-                                                 float *__restrict__ slab, float *smem) {
+                                                 float *__restrict__ slab, float *smem, bool accumulate = false) {
     const int nsteps = q1 > q0 ? (int)((q1 - q0 + GT_BK - 1) / GT_BK) : 0;
     f32x16 acc;
 #pragma unroll
@@ -316,7 +316,10 @@ __device__ __forceinline__ void tmpl_grad_w_tile(const float *__restrict__ x, co
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = i0 + acc_row(r);
-            if (row < Din) slab[(long long)row * Dout + col] = acc[r];
+            if (row < Din) {
+                float *o = slab + (long long)row * Dout + col;
+                *o = accumulate ? *o + acc[r] : acc[r];
+            }
         }
     }
 }

@@ -86,6 +86,10 @@ struct TileRef {
 struct WSource {
     int batch, level, slot, relu;
     int nch, ch, slab_start, block_start;
+    // direct >= 0: this source is the ONLY contribution to its gradient matrix and one K-chunk: the tile adds
+    // straight into the gradient (layer `direct`, relation `rel`, -1 = root), no slab, no reduction group
+    int direct, pad;
+    long long rel;
 };
 // one partial-vector source: kind 0 = bias colsum of (batch, level), kind 1 = variable row (batch, k)
 struct VSource {
@@ -508,13 +512,25 @@ __global__ __launch_bounds__(1024) void step_loss_kernel(const StepDev *__restri
     loss_block(sd, terms, loss, mean, 16);
 }
 
+struct GradPtrs {
+    float *basis[MPQE_STEP_MAX_LAYERS], *root[MPQE_STEP_MAX_LAYERS], *bias[MPQE_STEP_MAX_LAYERS];
+    float *mode_emb;
+};
+__device__ __forceinline__ float *pick_grad(float *const *arr, int li) {
+    float *r = arr[0];
+#pragma unroll
+    for (int l = 1; l < MPQE_STEP_MAX_LAYERS; ++l)
+        if (l == li) r = arr[l];
+    return r;
+}
+
 // ------------------------------------------------------------------------------------ weight gradients
 template <int MODE>
 __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, const WSource *__restrict__ src,
                                              int nsrc, const int *__restrict__ block_start,
                                              const float *__restrict__ H, const float *__restrict__ GH,
                                              long long level_stride, float *__restrict__ slabs, int bid,
-                                             int wblocks_total, float *smem) {
+                                             int wblocks_total, float *smem, const GradPtrs &gp, bool zeroed) {
     const int D = sd->D;
     const int tiles_j = (D + GT_BN - 1) / GT_BN, tiles = tiles_j * ((D + GT_BM - 1) / GT_BM);
     // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2: blocks b and b+8 share
@@ -544,12 +560,21 @@ __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, con
     const float *x = H + (long long)s.level * level_stride + b.row_off * D;
     const float *out = H + (long long)(s.level + 1) * level_stride + b.row_off * D;
     const float *g = GH + (long long)(s.level + 1) * level_stride + b.row_off * D;
+    float *dst = slabs + (long long)(s.slab_start + c) * D * D;
+    bool direct = false;
+    if (s.direct >= 0) {
+        float *gm = s.rel >= 0 ? pick_grad(gp.basis, s.direct) : pick_grad(gp.root, s.direct);
+        if (gm) {
+            dst = gm + (s.rel >= 0 ? s.rel * (long long)D * D : 0);
+            direct = true;
+        }
+    }
     if (MODE == LD_FAST)      // whole K-steps, D % 64 == 0: deep LDS-DMA pipeline
         grad_w_tile_dma(x, g, D, D, xs, xo, gs, go, q0, (int)((q1 - q0) / GT_BK), (tile / tiles_j) * GT_BM,
-                        (tile % tiles_j) * GT_BN, slabs + (long long)(s.slab_start + c) * D * D, smem);
+                        (tile % tiles_j) * GT_BN, dst, smem, direct && !zeroed);
     else
         tmpl_grad_w_tile<MODE>(x, g, out, D, D, s.relu, xs, xo, gs, go, q0, q1, (tile / tiles_j) * GT_BM,
-                               (tile % tiles_j) * GT_BN, slabs + (long long)(s.slab_start + c) * D * D, smem);
+                               (tile % tiles_j) * GT_BN, dst, smem, direct && !zeroed);
 }
 
 // partial vectors. kind 0: column sums of gpre over 64-row blocks of (batch, level).
@@ -653,12 +678,12 @@ struct TailArgs {
 template <int MODE>
 __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restrict__ sd, TailArgs ta,
                                                         const float *__restrict__ H, const float *__restrict__ GH,
-                                                        long long level_stride) {
+                                                        long long level_stride, GradPtrs gp, int zeroed) {
     // weight-gradient tiles only: the DMA ring takes 64 KB of LDS per workgroup, which would throttle the
     // thousands of light partial-sum / anchor workgroups to 2 per CU if they shared this kernel
     __shared__ __attribute__((aligned(16))) float smem[MODE == LD_FAST ? GWD_SMEM_FLOATS : GT_SMEM_FLOATS];
     grad_w_block<MODE>(sd, ta.wsrc, ta.nwsrc, ta.wblock, H, GH, level_stride, ta.slabs, (int)blockIdx.x, ta.wblocks,
-                       smem);
+                       smem, gp, zeroed != 0);      // zeroed: this call zero-filled the gradients, a store suffices
 }
 
 // bias / variable-row partial sums and anchor-table gradients: light, latency-bound roles in one launch
@@ -675,10 +700,6 @@ __global__ __launch_bounds__(256) void step_tail_small_kernel(const StepDev *__r
                          bid - ta.vblocks);
 }
 
-struct GradPtrs {
-    float *basis[MPQE_STEP_MAX_LAYERS], *root[MPQE_STEP_MAX_LAYERS], *bias[MPQE_STEP_MAX_LAYERS];
-    float *mode_emb;
-};
 
 // out += sum of the group's slabs / partial rows. A workgroup owns 256 consecutive elements (4 per
 // lane, 16-byte loads); its 4 waves each add every 4th slab (two loads in flight), the four sums
@@ -704,13 +725,18 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restri
     const float *p = (g.kind <= 1 ? slabs : partial) + (long long)g.start * elems + idx;
     if (vec) {
         if (idx < elems) {
-            int i = sg;
-            for (; i + 4 < g.count; i += 8) {
-                const f32x4 v0 = gload4(p + (long long)i * elems), v1 = gload4(p + (long long)(i + 4) * elems);
-                s += v0;
-                s += v1;
+            // four slabs of this wave in flight at a time (slab i, i+4, i+8, i+12; clamped loads, masked adds)
+            for (int i = sg; i < g.count; i += 16) {
+                f32x4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = i + 4 * q;
+                    v[q] = gload4(p + (long long)(k < g.count ? k : i) * elems);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (i + 4 * q < g.count) s += v[q];
             }
-            if (i < g.count) s += gload4(p + (long long)i * elems);
         }
     } else {
         for (int i = sg; i < g.count; i += 4)
@@ -960,6 +986,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->wsrc.clear();
     hp->wblock.clear();
     hp->groups.clear();
+    std::vector<int> group_first_src;
     for (size_t k = 0; k < keys.size(); ++k) {
         const Key &key = keys[k];
         const BatchDev &d = sd.b[key.batch];
@@ -971,6 +998,9 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         pick_chunks(d.B, 32, &s.nch, &s.ch);
         s.slab_start = slab;
         s.block_start = block;
+        s.direct = -1;
+        s.pad = 0;
+        s.rel = key.rel;
         hp->wsrc.push_back(s);
         for (int q = 0; q < s.nch * tiles; ++q) hp->wblock.push_back((int)hp->wsrc.size() - 1);
         if (k == 0 || keys[k - 1].layer != key.layer || keys[k - 1].rel != key.rel) {
@@ -981,6 +1011,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
             g.start = slab;
             g.count = 0;
             hp->groups.push_back(g);
+            group_first_src.push_back((int)hp->wsrc.size() - 1);
         }
         hp->groups.back().count += s.nch;
         slab += s.nch;
@@ -988,6 +1019,17 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     }
     hp->wblocks_total = block;
     hp->total_slabs = slab;
+    // a gradient matrix with ONE contribution (one source, one K-chunk: most relation matrices, a relation
+    // rarely occurs in two batches of a step) needs no slab and no reduction: its tiles add straight into the
+    // gradient (deterministic: one writer per element)
+    {
+        std::vector<RGroup> kept;
+        for (size_t gi = 0; gi < hp->groups.size(); ++gi) {
+            if (hp->groups[gi].count == 1) hp->wsrc[group_first_src[gi]].direct = hp->groups[gi].layer;
+            else kept.push_back(hp->groups[gi]);
+        }
+        hp->groups.swap(kept);
+    }
 
     // vector partial sources: bias per (unique layer) and variable rows per mode id
     struct VKey {
@@ -1577,13 +1619,16 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         mark(s);
         if (fast && hp.whole_ksteps)
             hipLaunchKernelGGL(step_tail_kernel<LD_FAST>, tgrid, dim3(256), 0, s, sd, ta, (const float *)H,
-                               (const float *)GH, hp.level_stride);
+                               (const float *)GH, hp.level_stride, gp,
+                               (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0);
         else if (vec)
             hipLaunchKernelGGL(step_tail_kernel<LD_PRED>, tgrid, dim3(256), 0, s, sd, ta, (const float *)H,
-                               (const float *)GH, hp.level_stride);
+                               (const float *)GH, hp.level_stride, gp,
+                               (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0);
         else
             hipLaunchKernelGGL(step_tail_kernel<LD_SCALAR>, tgrid, dim3(256), 0, s, sd, ta, (const float *)H,
-                               (const float *)GH, hp.level_stride);
+                               (const float *)GH, hp.level_stride, gp,
+                               (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0);
         mark(s);
         // bias / variable-row partials and anchor-table gradients (the chain kernel does them itself)
         const unsigned small_blocks = use_chain ? 0u : (unsigned)(ta.vblocks + (hp.anchor_off[nb] + 3) / 4);
