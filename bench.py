@@ -127,15 +127,18 @@ def time_fused_kernels(step, packed, data, model, readout, reps=20):
         return sum(2.0 * t.B * D * D * u[p] for t, L, u in zip(tmpl[lo:hi], Ls[lo:hi], units[lo:hi]) if L > p)
     total = sum(flops(0, len(tmpl), p) for p in range(Lmax))
     plan = []                                            # (kernel, flops) per event pair, in library order
+    lanes = [(packed.lane_begin[l], packed.lane_begin[l + 1]) for l in range(len(packed.lane_begin) - 1)]
+    lane_total = [sum(flops(lo, hi, p) for p in range(Lmax)) for lo, hi in lanes]
     if step.uses_chain(packed):
-        plan += [('step_chain_kernel', 2.0 * total)]      # forward + backward-x levels (+ gather, scores) in one launch
+        # per lane: forward + backward-x levels (+ gather, scores) in one launch; then per lane its weight gradients
+        plan += [('step_chain_kernel', 2.0 * t) for t in lane_total]
+        plan += [('step_tail_kernel', t) for t in lane_total]
     else:
-        lanes = [(packed.lane_begin[l], packed.lane_begin[l + 1]) for l in range(len(packed.lane_begin) - 1)]
         for p in range(Lmax):
             plan += [('step_layer_fwd_kernel', flops(lo, hi, p)) for lo, hi in lanes if max(Ls[lo:hi]) > p]
         for p in range(Lmax - 1, -1, -1):
             plan += [('step_layer_bwd_x_kernel', flops(lo, hi, p)) for lo, hi in lanes if max(Ls[lo:hi]) > p]
-    plan.append(('step_tail_kernel', total))
+        plan.append(('step_tail_kernel', total))
     n_ev = 2 * len(plan)
     fam = {}
     for name, _ in plan:

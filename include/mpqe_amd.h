@@ -258,7 +258,8 @@ typedef struct {
  * its fixed cost (~8 us: dispatch, descriptor + first-tile latency, drain) dominates, and one step is a
  * chain of ~13 dependent launches. With lanes, lane l runs the whole chain (assemble -> message-passing
  * levels -> score -> levels back) of batches [batch_begin[l], batch_begin[l+1]) on its own stream; lane 0
- * is `stream`. The lanes fork after the descriptor upload and join before the weight-gradient launch.
+ * is `stream`. The lanes fork after the descriptor upload and join before the weight-gradient launch (chain
+ * form: every lane also launches the weight gradients of its own batches, the lanes join before the reduction).
  * The caller owns the streams and events (no allocation, no synchronisation in the library).          */
 #define MPQE_STEP_MAX_LANES 4
 typedef struct {
@@ -285,9 +286,9 @@ size_t mpqe_step_desc_bytes(const mpqe_step_params_t *params_host, const mpqe_st
  * events (may be NULL): hipEvent_t handles recorded in pairs around single launches on the stream of the
  * launch, in this order: for level 0..Lmax-1, for each lane that has the level: layer forward; for level
  * Lmax-1..0, for each such lane: backward-x; then the weight-gradient launch. When the graph-block chain
- * kernels run (dim 64 / 128 / 256, at most 32768 query graphs in the step, MPQE_STEP_NO_CHAIN clear; lanes
- * are then ignored; every batch has at most 5 passes) the order is: the chain launch (assemble, levels
- * forward, scores, levels backward), then the weight-gradient launch. Fewer are filled as far as they go.
+ * kernel runs (dim 64 / 128 / 256, at most 32768 query graphs in the step, MPQE_STEP_NO_CHAIN clear, every
+ * batch at most 5 passes) the order is: for each lane its chain launch (assemble, levels forward, scores,
+ * levels backward), then for each lane its weight-gradient launch. Fewer are filled as far as they go.
  * For roofline accounting only.                                                                     */
 int mpqe_step_forward_backward(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,
                                int num_batches, const int64_t *anchor_ids, const int64_t *targets,

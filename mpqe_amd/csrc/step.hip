@@ -83,6 +83,10 @@ struct TileRef {
 };
 
 // one weight-gradient source: (batch, level, slot) -> nch K-chunks, each a slab of D*D floats
+// one weight-gradient workgroup: tile / K-chunk number `lb` of source `src`
+struct WBlock {
+    int src, lb;
+};
 struct WSource {
     int batch, level, slot, relu;
     int nch, ch, slab_start, block_start;
@@ -527,7 +531,7 @@ __device__ __forceinline__ float *pick_grad(float *const *arr, int li) {
 // ------------------------------------------------------------------------------------ weight gradients
 template <int MODE>
 __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, const WSource *__restrict__ src,
-                                             int nsrc, const int *__restrict__ block_start,
+                                             int nsrc, const WBlock *__restrict__ block_start,
                                              const float *__restrict__ H, const float *__restrict__ GH,
                                              long long level_stride, float *__restrict__ slabs, int bid,
                                              int wblocks_total, float *smem, const GradPtrs &gp, bool zeroed) {
@@ -543,9 +547,9 @@ __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, con
         const int grp = bid / span, r = bid - grp * span;
         vb = grp * span + (r & 7) * tiles + (r >> 3);
     }
-    const int si = block_start[vb];          // per-workgroup source index (one load, no search)
-    const WSource s = src[si];
-    const int lb = vb - s.block_start;
+    const WBlock wk = block_start[vb];       // per-workgroup (source, block inside the source): one load, no search
+    const WSource s = src[wk.src];
+    const int lb = wk.lb;
     const int c = lb / tiles, tile = lb - c * tiles;
     const BatchDev &b = sd->b[s.batch];
     // slot < E: template edge (x = source slot, g = destination slot); slot = E + n: the self/root term
@@ -662,7 +666,7 @@ __device__ __forceinline__ void anchor_bwd_block(const StepDev *__restrict__ sd,
 // range, heavy MFMA tiles first) instead of three half-empty ones.
 struct TailArgs {
     const WSource *wsrc;
-    const int *wblock;
+    const WBlock *wblock;
     int nwsrc, wblocks;
     const VSource *vsrc;
     const int *vblock;
@@ -769,7 +773,8 @@ struct HostPlan {
     size_t o_tf[MPQE_STEP_MAX_LANES][STEP_MAX_LEVELS], o_tb[MPQE_STEP_MAX_LANES][STEP_MAX_LEVELS];
     std::vector<int> wref;            // per weight-gradient workgroup: source index
     std::vector<WSource> wsrc;
-    std::vector<int> wblock;          // per weight-gradient workgroup: its source index
+    std::vector<WBlock> wblock;       // per weight-gradient workgroup: (source, block), the lanes' blocks in lane order
+    int wblock_begin[MPQE_STEP_MAX_LANES + 1];     // lane l: wblock[wblock_begin[l] .. wblock_begin[l+1])
     int wblocks_total, vblocks_total;
     std::vector<VSource> vsrc;
     std::vector<int> vblock;
@@ -778,7 +783,8 @@ struct HostPlan {
     int total_slabs, total_parts;
     bool whole_ksteps;                // every batch size is a multiple of the K-step (weight-gradient LD_FAST)
     // graph-block chain kernels (step_chain.h): one entry per workgroup, heaviest blocks first
-    std::vector<ChainRef> crefs;
+    std::vector<ChainRef> crefs;      // the lanes' grids one after the other
+    int cref_begin[MPQE_STEP_MAX_LANES + 1];
     std::vector<ChainOp> cops;
     std::vector<WtSlot> wt_slots;     // matrices with a transposed copy (those of the backward programmes)
     ChainParts cparts[MPQE_STEP_MAX_BATCHES];
@@ -1002,7 +1008,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         s.pad = 0;
         s.rel = key.rel;
         hp->wsrc.push_back(s);
-        for (int q = 0; q < s.nch * tiles; ++q) hp->wblock.push_back((int)hp->wsrc.size() - 1);
+
         if (k == 0 || keys[k - 1].layer != key.layer || keys[k - 1].rel != key.rel) {
             RGroup g;
             g.kind = key.rel < 0 ? 1 : 0;
@@ -1019,6 +1025,15 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     }
     hp->wblocks_total = block;
     hp->total_slabs = slab;
+    for (int l = 0; l < hp->nlanes; ++l) {          // block table, grouped by stream lane (a lane launches its own)
+        hp->wblock_begin[l] = (int)hp->wblock.size();
+        for (size_t k = 0; k < hp->wsrc.size(); ++k) {
+            const WSource &ws = hp->wsrc[k];
+            if (ws.batch < hp->lane_begin[l] || ws.batch >= hp->lane_begin[l + 1]) continue;
+            for (int q = 0; q < ws.nch * tiles; ++q) hp->wblock.push_back(WBlock{(int)k, q});
+        }
+    }
+    hp->wblock_begin[hp->nlanes] = (int)hp->wblock.size();
     // a gradient matrix with ONE contribution (one source, one K-chunk: most relation matrices, a relation
     // rarely occurs in two batches of a step) needs no slab and no reduction: its tiles add straight into the
     // gradient (deterministic: one writer per element)
@@ -1159,39 +1174,44 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         // its CU with block k + 32, measured) the heaviest blocks run alone and the lightest pair up.
         // Grid = 8 x (largest XCD list); the holes are refs with batch = -1 (the workgroup exits at once).
         std::stable_sort(progs.begin(), progs.end(), [](const Prog &a, const Prog &b) { return a.work > b.work; });
-        std::vector<ChainRef> bins[STEP_XCDS];
-        long long load[STEP_XCDS] = {0};
         const size_t cus = STEP_CUS / STEP_XCDS;
-        for (size_t k = 0; k < progs.size(); ++k) {          // a big batch goes out in chunks of one block per CU
-            const int Bk = sd.b[progs[k].batch].B;
-            for (int c0 = 0; c0 < Bk; c0 += (int)cus * CH_GB) {
-                int best = 0;
-                for (int x = 1; x < STEP_XCDS; ++x)
-                    if (load[x] < load[best]) best = x;
-                for (int g0 = c0; g0 < Bk && g0 < c0 + (int)cus * CH_GB; g0 += CH_GB) {   // progs is sorted: bins stay sorted
-                    bins[best].push_back(
-                        ChainRef{progs[k].batch, g0, progs[k].fb, progs[k].fc, progs[k].bb, progs[k].bc, 0, 0});
-                    load[best] += progs[k].work;
+        for (int l = 0; l < hp->nlanes; ++l) {             // one grid per stream lane
+            hp->cref_begin[l] = (int)hp->crefs.size();
+            std::vector<ChainRef> bins[STEP_XCDS];
+            long long load[STEP_XCDS] = {0};
+            for (size_t k = 0; k < progs.size(); ++k) {    // a big batch goes out in chunks of one block per CU
+                if (progs[k].batch < hp->lane_begin[l] || progs[k].batch >= hp->lane_begin[l + 1]) continue;
+                const int Bk = sd.b[progs[k].batch].B;
+                for (int c0 = 0; c0 < Bk; c0 += (int)cus * CH_GB) {
+                    int best = 0;
+                    for (int x = 1; x < STEP_XCDS; ++x)
+                        if (load[x] < load[best]) best = x;
+                    for (int g0 = c0; g0 < Bk && g0 < c0 + (int)cus * CH_GB; g0 += CH_GB) {   // progs is sorted: bins stay sorted
+                        bins[best].push_back(
+                            ChainRef{progs[k].batch, g0, progs[k].fb, progs[k].fc, progs[k].bb, progs[k].bc, 0, 0});
+                        load[best] += progs[k].work;
+                    }
                 }
             }
-        }
-        size_t longest = 0;
-        for (int x = 0; x < STEP_XCDS; ++x) {
-            std::vector<ChainRef> &v = bins[x];
-            const size_t n = v.size();
-            if (n > cus && n <= 2 * cus) {
-                std::vector<ChainRef> o;
-                const size_t R = n - cus;                   // CUs that take two blocks
-                for (size_t k = 0; k < R; ++k) o.push_back(v[n - 2 * R + k]);           // heavier of a pair
-                for (size_t k = 0; k < n - 2 * R; ++k) o.push_back(v[k]);               // alone
-                for (size_t k = 0; k < R; ++k) o.push_back(v[n - 1 - k]);               // its light partner
-                v.swap(o);
+            size_t longest = 0;
+            for (int x = 0; x < STEP_XCDS; ++x) {
+                std::vector<ChainRef> &v = bins[x];
+                const size_t n = v.size();
+                if (n > cus && n <= 2 * cus) {
+                    std::vector<ChainRef> o;
+                    const size_t R = n - cus;                   // CUs that take two blocks
+                    for (size_t k = 0; k < R; ++k) o.push_back(v[n - 2 * R + k]);           // heavier of a pair
+                    for (size_t k = 0; k < n - 2 * R; ++k) o.push_back(v[k]);               // alone
+                    for (size_t k = 0; k < R; ++k) o.push_back(v[n - 1 - k]);               // its light partner
+                    v.swap(o);
+                }
+                if (n > longest) longest = n;
             }
-            if (n > longest) longest = n;
+            for (size_t k = 0; k < longest; ++k)
+                for (int x = 0; x < STEP_XCDS; ++x)
+                    hp->crefs.push_back(k < bins[x].size() ? bins[x][k] : ChainRef{-1, 0, 0, 0, 0, 0, 0, 0});
         }
-        for (size_t k = 0; k < longest; ++k)
-            for (int x = 0; x < STEP_XCDS; ++x)
-                hp->crefs.push_back(k < bins[x].size() ? bins[x][k] : ChainRef{-1, 0, 0, 0, 0, 0, 0, 0});
+        hp->cref_begin[hp->nlanes] = (int)hp->crefs.size();
     }
 
     // workspace layout
@@ -1204,7 +1224,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->level_stride = rows * D;
     hp->o_sd = take(sizeof(StepDev));
     hp->o_wsrc = take(hp->wsrc.size() * sizeof(WSource));
-    hp->o_wblock = take(hp->wblock.size() * sizeof(int));
+    hp->o_wblock = take(hp->wblock.size() * sizeof(WBlock));
     hp->o_vsrc = take(hp->vsrc.size() * sizeof(VSource));
     hp->o_vblock = take(hp->vblock.size() * sizeof(int));
     hp->o_groups = take(hp->groups.size() * sizeof(RGroup));
@@ -1315,8 +1335,9 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     if (!P || !B || nb < 1 || nb > MPQE_STEP_MAX_BATCHES || !desc) return MPQE_ERR_INVALID_ARG;
     // Chain kernels (step_chain.h): D = 64 / 128 / 256 with 16-byte aligned weights, and a step small
     // enough that per-level launches cannot fill the chip (above CHAIN_MAX_GRAPHS the 64x64-tile level
-    // kernels re-use each weight tile 4x more often and win). The chain runs all batches in one launch,
-    // so stream lanes do not apply to it.
+    // kernels re-use each weight tile 4x more often and win). With stream lanes every lane launches the chain
+    // kernel and then the weight-gradient kernel of ITS batches: a lane of light batches finishes early and
+    // its weight gradients run beside the long chains of the heavy lane.
     bool use_chain = !(P->flags & MPQE_STEP_NO_CHAIN) && (P->dim == 64 || P->dim == 128 || P->dim == 256);
     if (use_chain) {
         long long graphs = 0;
@@ -1330,7 +1351,6 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             use_chain = P->tables[m] && (uintptr_t)P->tables[m] % 16 == 0;
         use_chain = use_chain && P->mode_emb && (uintptr_t)P->mode_emb % 16 == 0;
     }
-    if (use_chain) lanes = nullptr;
     // The launch plan is a pure function of the descriptors; it is kept on the host next to the device
     // table it describes (same key: the caller's desc buffer), so a steady-state call costs one lookup.
     std::shared_ptr<const CachedPlan> cached;
@@ -1412,7 +1432,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     if (upload_desc) {
         upload(s, db + hp.o_sd, &hp.sd, sizeof(StepDev));
         upload(s, db + hp.o_wsrc, hp.wsrc.data(), hp.wsrc.size() * sizeof(WSource));
-        upload(s, db + hp.o_wblock, hp.wblock.data(), hp.wblock.size() * sizeof(int));
+        upload(s, db + hp.o_wblock, hp.wblock.data(), hp.wblock.size() * sizeof(WBlock));
         upload(s, db + hp.o_vsrc, hp.vsrc.data(), hp.vsrc.size() * sizeof(VSource));
         upload(s, db + hp.o_vblock, hp.vblock.data(), hp.vblock.size() * sizeof(int));
         upload(s, db + hp.o_groups, hp.groups.data(), hp.groups.size() * sizeof(RGroup));
@@ -1445,11 +1465,6 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         row0[l] = b < nb ? hp.sd.b[b].row_off : hp.sd.rows_total;
         gr0[l] = b < nb ? hp.sd.b[b].g_off : hp.sd.graphs_total;
     }
-    if (NL > 1) {
-        (void)hipEventRecord(reinterpret_cast<hipEvent_t>(lanes->fork_event), s);
-        for (int l = 1; l < NL; ++l) (void)hipStreamWaitEvent(ls[l], reinterpret_cast<hipEvent_t>(lanes->fork_event), 0);
-    }
-
     float *WT = reinterpret_cast<float *>(wb + hp.o_WT);
     if (backward) {
         // prologue launch: transposed weight copies for the backward chains; zero fill of the gradients
@@ -1484,8 +1499,47 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                                reinterpret_cast<const WtSlot *>(db + hp.o_wtslots), (int)hp.wt_slots.size(), D, WT,
                                tblocks, zs);
     }
+    if (NL > 1) {       // fork: the lanes start after the descriptor uploads and the prologue
+        (void)hipEventRecord(reinterpret_cast<hipEvent_t>(lanes->fork_event), s);
+        for (int l = 1; l < NL; ++l) (void)hipStreamWaitEvent(ls[l], reinterpret_cast<hipEvent_t>(lanes->fork_event), 0);
+    }
+    float *slabs = reinterpret_cast<float *>(wb + hp.o_slabs), *parts = reinterpret_cast<float *>(wb + hp.o_parts);
+    TailArgs ta;
+    ta.wsrc = reinterpret_cast<const WSource *>(db + hp.o_wsrc);
+    ta.wblock = reinterpret_cast<const WBlock *>(db + hp.o_wblock);
+    ta.nwsrc = (int)hp.wsrc.size();
+    ta.wblocks = hp.wblocks_total;
+    ta.vsrc = reinterpret_cast<const VSource *>(db + hp.o_vsrc);
+    ta.vblock = reinterpret_cast<const int *>(db + hp.o_vblock);
+    ta.nvsrc = (int)hp.vsrc.size();
+    ta.vblocks = hp.vblocks_total;
+    ta.anchor_off = reinterpret_cast<const int *>(db + hp.o_anchor);
+    ta.nb = nb;
+    ta.node_map = nm;
+    ta.map_len = (long long)P->node_map_len;
+    ta.anchor_ids = ids;
+    ta.slabs = slabs;
+    ta.parts = parts;
+    // weight-gradient launch over the block table entries [first, first + count) on stream `on`
+    auto launch_grad_w = [&](hipStream_t on, int first, int count) {
+        if (count <= 0) return;
+        TailArgs tl = ta;
+        tl.wblock = ta.wblock + first;
+        tl.wblocks = count;
+        dim3 tgrid((unsigned)count);
+        const int zeroed = (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0;
+        if (fast && hp.whole_ksteps)
+            hipLaunchKernelGGL(step_tail_kernel<LD_FAST>, tgrid, dim3(256), 0, on, sd, tl, (const float *)H,
+                               (const float *)GH, hp.level_stride, gp, zeroed);
+        else if (vec)
+            hipLaunchKernelGGL(step_tail_kernel<LD_PRED>, tgrid, dim3(256), 0, on, sd, tl, (const float *)H,
+                               (const float *)GH, hp.level_stride, gp, zeroed);
+        else
+            hipLaunchKernelGGL(step_tail_kernel<LD_SCALAR>, tgrid, dim3(256), 0, on, sd, tl, (const float *)H,
+                               (const float *)GH, hp.level_stride, gp, zeroed);
+    };
     if (use_chain) {
-        // assemble -> levels -> scores (-> levels back -> anchor-table gradients): one launch
+        // assemble -> levels -> scores (-> levels back -> anchor-table gradients): one launch per lane
         ChainArgs ca;
         ca.refs = reinterpret_cast<const ChainRef *>(db + hp.o_cref);
         ca.ops = reinterpret_cast<const ChainOp *>(db + hp.o_cops);
@@ -1509,16 +1563,29 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         ca.terms = terms;
         ca.err = err;
         ca.backward = backward ? 1 : 0;
-        ca.stamps = g_chain_stamps && 2 * hp.crefs.size() <= g_chain_stamp_blocks ? g_chain_stamps : nullptr;
-        dim3 cgrid((unsigned)hp.crefs.size());
-        mark(s);
-        if (D == 64) hipLaunchKernelGGL(step_chain_kernel<1>, cgrid, dim3(256), 0, s, sd, lp, tabs, ca);
-        else if (D == 128) hipLaunchKernelGGL(step_chain_kernel<2>, cgrid, dim3(256), 0, s, sd, lp, tabs, ca);
-        else hipLaunchKernelGGL(step_chain_kernel<4>, cgrid, dim3(256), 0, s, sd, lp, tabs, ca);
-        mark(s);
+        ca.stamps = NL == 1 && g_chain_stamps && 2 * hp.crefs.size() <= g_chain_stamp_blocks ? g_chain_stamps : nullptr;
+        for (int l = 0; l < NL; ++l) {
+            ChainArgs cl = ca;
+            cl.refs = ca.refs + hp.cref_begin[l];
+            dim3 cgrid((unsigned)(hp.cref_begin[l + 1] - hp.cref_begin[l]));
+            mark(ls[l]);
+            if (D == 64) hipLaunchKernelGGL(step_chain_kernel<1>, cgrid, dim3(256), 0, ls[l], sd, lp, tabs, cl);
+            else if (D == 128) hipLaunchKernelGGL(step_chain_kernel<2>, cgrid, dim3(256), 0, ls[l], sd, lp, tabs, cl);
+            else hipLaunchKernelGGL(step_chain_kernel<4>, cgrid, dim3(256), 0, ls[l], sd, lp, tabs, cl);
+            mark(ls[l]);
+        }
         if (!backward) {
+            for (int l = 1; l < NL; ++l) {
+                (void)hipEventRecord(reinterpret_cast<hipEvent_t>(lanes->join_event[l]), ls[l]);
+                (void)hipStreamWaitEvent(s, reinterpret_cast<hipEvent_t>(lanes->join_event[l]), 0);
+            }
             hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss);
             return mpqe_launch_status();
+        }
+        for (int l = 0; l < NL; ++l) {      // each lane's weight gradients follow its own chains
+            mark(ls[l]);
+            launch_grad_w(ls[l], hp.wblock_begin[l], hp.wblock_begin[l + 1] - hp.wblock_begin[l]);
+            mark(ls[l]);
         }
     }
     // ---- forward
@@ -1597,41 +1664,12 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             mark(ls[l]);
         }
     join();
-    float *slabs = reinterpret_cast<float *>(wb + hp.o_slabs), *parts = reinterpret_cast<float *>(wb + hp.o_parts);
-    {
-        TailArgs ta;
-        ta.wsrc = reinterpret_cast<const WSource *>(db + hp.o_wsrc);
-        ta.wblock = reinterpret_cast<const int *>(db + hp.o_wblock);
-        ta.nwsrc = (int)hp.wsrc.size();
-        ta.wblocks = hp.wblocks_total;
-        ta.vsrc = reinterpret_cast<const VSource *>(db + hp.o_vsrc);
-        ta.vblock = reinterpret_cast<const int *>(db + hp.o_vblock);
-        ta.nvsrc = (int)hp.vsrc.size();
-        ta.vblocks = hp.vblocks_total;
-        ta.anchor_off = reinterpret_cast<const int *>(db + hp.o_anchor);
-        ta.nb = nb;
-        ta.node_map = nm;
-        ta.map_len = (long long)P->node_map_len;
-        ta.anchor_ids = ids;
-        ta.slabs = slabs;
-        ta.parts = parts;
-        dim3 tgrid((unsigned)ta.wblocks);
+    if (!use_chain) {
         mark(s);
-        if (fast && hp.whole_ksteps)
-            hipLaunchKernelGGL(step_tail_kernel<LD_FAST>, tgrid, dim3(256), 0, s, sd, ta, (const float *)H,
-                               (const float *)GH, hp.level_stride, gp,
-                               (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0);
-        else if (vec)
-            hipLaunchKernelGGL(step_tail_kernel<LD_PRED>, tgrid, dim3(256), 0, s, sd, ta, (const float *)H,
-                               (const float *)GH, hp.level_stride, gp,
-                               (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0);
-        else
-            hipLaunchKernelGGL(step_tail_kernel<LD_SCALAR>, tgrid, dim3(256), 0, s, sd, ta, (const float *)H,
-                               (const float *)GH, hp.level_stride, gp,
-                               (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0);
+        launch_grad_w(s, 0, hp.wblocks_total);
         mark(s);
         // bias / variable-row partials and anchor-table gradients (the chain kernel does them itself)
-        const unsigned small_blocks = use_chain ? 0u : (unsigned)(ta.vblocks + (hp.anchor_off[nb] + 3) / 4);
+        const unsigned small_blocks = (unsigned)(ta.vblocks + (hp.anchor_off[nb] + 3) / 4);
         if (small_blocks)
             hipLaunchKernelGGL(step_tail_small_kernel, dim3(small_blocks), dim3(256), 0, s, sd, ta, tabs,
                                (const float *)H, (const float *)GH, hp.level_stride);

@@ -296,28 +296,56 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB> &S, const int first_op, 
     if (T <= 0) return;
 #pragma unroll
     for (int c = 0; c < NCB; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // three register buffers, prefetch distance two half-blocks (~2 x 1024 MFMA cycles for a load to land)
-    WHalf<NCB> f0, f1, f2;
-    ChainStep o0 = get_op(0), o1 = get_op(1), o2 = get_op(2);     // ops of items it, it + 1, it + 2
-#pragma unroll
-    for (int t = 0; t < 4; ++t) chain_load_t<NCB>(f0, wptr(0), D, t);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) chain_load_t<NCB>(f1, wptr(1), D, t);
-    __builtin_amdgcn_sched_barrier(0);
+    // Register buffers for the weights: prefetch distance PF half-blocks (PF + 1 buffers). With ~36 loads in
+    // flight per wave (PF = 2) the loads of a lone workgroup on a CU return slower than the MFMAs consume them
+    // (L2 hit rate ~75 %, the rest comes from the Infinity Cache): D <= 128 has the registers for PF = 3.
+    ChainStep oc = get_op(0), on = get_op(1);       // ops of items it, it + 1
     int it = 0;
-    while (true) {
-        ChainStep o3 = get_op(it + 3);
-        item(o0, it, f0, f2, wptr(it + 2));
-        if (++it >= T) break;
-        o0 = get_op(it + 3);
-        item(o1, it, f1, f0, wptr(it + 2));
-        if (++it >= T) break;
-        o1 = get_op(it + 3);
-        item(o2, it, f2, f1, wptr(it + 2));
-        if (++it >= T) break;
-        o2 = o1;      // rotate: ops of items it, it + 1, it + 2 are (o3, o0, o1)
-        o1 = o0;
-        o0 = o3;
+    if constexpr (NCB <= 2) {
+        WHalf<NCB> f0, f1, f2, f3;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) chain_load_t<NCB>(f0, wptr(0), D, t);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) chain_load_t<NCB>(f1, wptr(1), D, t);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) chain_load_t<NCB>(f2, wptr(2), D, t);
+        __builtin_amdgcn_sched_barrier(0);
+#define CHAIN_STEP(F, FN)                       \
+    {                                           \
+        const ChainStep o2_ = get_op(it + 2);   \
+        item(oc, it, F, FN, wptr(it + 3));      \
+        if (++it >= T) break;                   \
+        oc = on;                                \
+        on = o2_;                               \
+    }
+        while (true) {
+            CHAIN_STEP(f0, f3)
+            CHAIN_STEP(f1, f0)
+            CHAIN_STEP(f2, f1)
+            CHAIN_STEP(f3, f2)
+        }
+#undef CHAIN_STEP
+    } else {
+        WHalf<NCB> f0, f1, f2;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) chain_load_t<NCB>(f0, wptr(0), D, t);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) chain_load_t<NCB>(f1, wptr(1), D, t);
+        __builtin_amdgcn_sched_barrier(0);
+#define CHAIN_STEP(F, FN)                       \
+    {                                           \
+        const ChainStep o2_ = get_op(it + 2);   \
+        item(oc, it, F, FN, wptr(it + 2));      \
+        if (++it >= T) break;                   \
+        oc = on;                                \
+        on = o2_;                               \
+    }
+        while (true) {
+            CHAIN_STEP(f0, f2)
+            CHAIN_STEP(f1, f0)
+            CHAIN_STEP(f2, f1)
+        }
+#undef CHAIN_STEP
     }
 }
 

@@ -144,13 +144,27 @@ class FusedTrainStep(object):
             qt = b['formula'].query_type
             passes_of.append(RGCNQueryDataset.query_diameters[qt] if m.adaptive else m.num_layers)
         nl = min(self.num_lanes, nb)
-        load = [0.0] * nl
-        members = [[] for _ in range(nl)]
-        for i in sorted(range(nb), key=lambda i: (-passes_of[i], -_batch_work(batches[i]['formula'].query_type,
-                                                                                passes_of[i]))):
-            l = min(range(nl), key=lambda l: load[l])
-            members[l].append(i)
-            load[l] += _batch_work(batches[i]['formula'].query_type, passes_of[i]) * len(batches[i]['targets'])
+        graphs = sum(len(b['targets']) for b in batches)
+        chain = (not (self.flags & _capi.STEP_NO_CHAIN) and m.emb_dim in (64, 128, 256)
+                 and graphs <= CHAIN_MAX_GRAPHS and max(passes_of) <= 5)
+        if chain and nl >= 2:
+            # chain form: lane 0 = the batches with the longest chains per block (their blocks set the kernel's
+            # length), lane 1 = the rest -- the light lane finishes early and its weight-gradient launch runs
+            # beside the heavy lane's chains
+            prune = not (self.flags & _capi.STEP_NO_PRUNE)
+            work = [sum(live_units(b['formula'].query_type, p, m.readout_str, prune))
+                    for b, p in zip(batches, passes_of)]
+            heavy = [i for i in range(nb) if work[i] >= 0.7 * max(work)]
+            light = [i for i in range(nb) if i not in heavy]
+            members = [heavy, light] if light else [heavy]
+        else:
+            load = [0.0] * nl
+            members = [[] for _ in range(nl)]
+            for i in sorted(range(nb), key=lambda i: (-passes_of[i], -_batch_work(batches[i]['formula'].query_type,
+                                                                                    passes_of[i]))):
+                l = min(range(nl), key=lambda l: load[l])
+                members[l].append(i)
+                load[l] += _batch_work(batches[i]['formula'].query_type, passes_of[i]) * len(batches[i]['targets'])
         members = [sorted(mm) for mm in members if mm]
         order = [i for mm in members for i in mm]
         lane_begin = [0]

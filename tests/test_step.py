@@ -299,6 +299,25 @@ def test_fused_step_stream_lanes(be, splits):
     np.testing.assert_array_equal(fwd[0], ref[0])
 
 
+@pytest.mark.parametrize('splits', [[0, 2, 5], [0, 1, 4, 5]])
+def test_fused_step_chain_with_stream_lanes(be, splits):
+    """Chain form with lanes: every lane launches its own chain kernel and weight-gradient kernel; the result
+    does not depend on the split."""
+    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(17, 64, 3, False, CHAIN_MIX, 'mp', True)
+    ref = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0)
+    got = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, lanes=splits)
+    np.testing.assert_array_equal(got[0], ref[0])
+    np.testing.assert_array_equal(got[1], ref[1])
+    np.testing.assert_array_equal(got[2], ref[2])
+    for k in ref[3]:
+        if k.startswith('layers') or k.startswith('mode'):
+            np.testing.assert_array_equal(got[3][k], ref[3][k], err_msg=k)
+        else:
+            np.testing.assert_allclose(got[3][k], ref[3][k], rtol=1e-5, atol=1e-7, err_msg=k)
+    fwd = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, backward=0, lanes=splits)
+    np.testing.assert_array_equal(fwd[0], ref[0])
+
+
 def test_fused_step_rejects_bad_lanes(be):
     P = _capi.StepParams()
     schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(
