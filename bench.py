@@ -102,9 +102,11 @@ def step_modules(model, data):
     return loss
 
 
-def pack_for_fused(step, data):
+def pack_for_fused(step, data, scale=1.0):
+    """scale: 1 / world_size under data parallelism -- the mean over ranks is folded into the batch weights,
+    so the all-reduce (a sum) leaves the averaged gradient with no extra pass over the bucket."""
     return step.pack([dict(formula=b['formula'], anchor_ids=b['anchor_np'], targets=b['targets_np'],
-                           negs=b['negs_np'], weight=b['weight']) for b in data.batches])
+                           negs=b['negs_np'], weight=b['weight'] * scale) for b in data.batches])
 
 
 def time_fused_kernels(step, packed, data, model, readout, reps=20):
@@ -359,7 +361,7 @@ def main():
     if use_fused:
         from mpqe_amd.fused import FusedTrainStep
         fstep = FusedTrainStep(model, lanes=args.lanes, prune=not args.no_prune, chain=not args.no_chain)
-        packed = [pack_for_fused(fstep, d) for d in pool]
+        packed = [pack_for_fused(fstep, d, 1.0 / world) for d in pool]
         captured = [fstep.capture(p) for p in packed] if args.graph else None
     elif world > 1:
         from mpqe_amd.parallel import GradReducer
@@ -374,8 +376,7 @@ def main():
                 loss = fstep.run(packed[i % len(pool)])
             if world > 1:
                 import torch.distributed as dist
-                dist.all_reduce(fstep.flat_grad)          # one bucket: p.grad are views of it
-                fstep.flat_grad.mul_(1.0 / world)
+                dist.all_reduce(fstep.flat_grad)          # one bucket: p.grad are views of it (1/world is in the weights)
             return loss
         loss = step_modules(model, pool[i % len(pool)])
         if reducer is not None:
