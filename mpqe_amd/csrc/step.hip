@@ -1129,6 +1129,9 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                     int lvl_flags = 0;
                     if (!dir && p < d.L - 1) lvl_flags |= CH_RELU;
                     if (dir && p >= 1) lvl_flags |= CH_MASK;
+                    // the weight gradients read H[0 .. L-1] and gH[1 .. L]; H[L] feeds only the scores and gH[0]
+                    // only the anchor / variable-row gradients, all inside the chain kernel
+                    if ((!dir && p == d.L - 1) || (dir && p == 0)) lvl_flags |= CH_NOSTORE;
                     for (int n = 0; n < tp.N; ++n) {
                         if (!(((dir ? lin : lout) >> n) & 1u)) continue;
                         const size_t first = hp->cops.size();

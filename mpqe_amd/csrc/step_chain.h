@@ -26,6 +26,7 @@
 #define CH_LEVEL_END 4    // last K-block of a level: workgroup barrier, swap the LDS buffers
 #define CH_RELU 8         // forward epilogue applies ReLU (and records the mask bits)
 #define CH_MASK 16        // backward epilogue masks with the bits recorded for this (level, node)
+#define CH_NOSTORE 32     // the result stays in LDS: nothing after the chain kernel reads H[L] or gH[0]
 #define CH_MASK_LEVELS 4  // ReLU outputs live at levels 1 .. L-1: chains up to L = 5 passes
 #define CH_MAX_OPS 96     // forward + backward K-blocks of one batch (5 passes x 7 x 2 = 70 at most)
 
@@ -249,7 +250,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB> &S, const int first_op, 
                 }
                 chain_store<NCB>(Xn + (op.node * CH_GB + row) * LDX + colb, v);
                 if (row < ng) {
-                    chain_store<NCB>(Xout + ((long long)row * N + op.node) * D + colb, v);
+                    if (!(op.flags & CH_NOSTORE)) chain_store<NCB>(Xout + ((long long)row * N + op.node) * D + colb, v);
                     if (BWD) {
 #pragma unroll
                         for (int c = 0; c < NCB; ++c) {
