@@ -36,8 +36,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3                # MI355X_MICROARCH.md: fp32 MFMA den
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--kg', default='aifb')
     ap.add_argument('--embed-dim', type=int, default=128)
     ap.add_argument('--batch-size', type=int, default=512)
@@ -49,6 +49,7 @@ def parse():
     ap.add_argument('--graph', type=int, default=0, help='1: replay each step from a captured hipGraph')
     ap.add_argument('--no-prune', action='store_true', help='compute node states that cannot reach the readout too')
     ap.add_argument('--no-chain', action='store_true', help='one launch per message-passing level')
+    ap.add_argument('--no-ksplit', action='store_true', help='dim 128: chain waves own 32 columns and all of K')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='nccl = RCCL over xGMI (the real path); gloo only to exercise the multi-rank code on one GPU')
     return ap.parse_args()
@@ -360,7 +361,8 @@ def main():
     reducer = fstep = packed = captured = None
     if use_fused:
         from mpqe_amd.fused import FusedTrainStep
-        fstep = FusedTrainStep(model, lanes=args.lanes, prune=not args.no_prune, chain=not args.no_chain)
+        fstep = FusedTrainStep(model, lanes=args.lanes, prune=not args.no_prune, chain=not args.no_chain,
+                               ksplit=not args.no_ksplit)
         packed = [pack_for_fused(fstep, d, 1.0 / world) for d in pool]
         captured = [fstep.capture(p) for p in packed] if args.graph else None
     elif world > 1:

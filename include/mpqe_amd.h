@@ -220,6 +220,9 @@ int mpqe_hinge_bwd(const float *pos, const float *neg, int64_t n, float margin, 
 /* ZERO_GRADS  the call zero-fills every buffer of `grads` before accumulating into it (one launch shared
  *             with the step's other prologue work, instead of a memset per buffer by the caller).    */
 #define MPQE_STEP_ZERO_GRADS 4
+/* NO_KSPLIT   dim 128 only: the chain kernel's waves each own 32 columns and the whole K range (the first form)
+ *             instead of 64 columns and half of K.                                                     */
+#define MPQE_STEP_NO_KSPLIT 8
 
 typedef struct {
     int32_t query_type;        /* MPQE_Q_*                                                     */
@@ -286,8 +289,7 @@ size_t mpqe_step_desc_bytes(const mpqe_step_params_t *params_host, const mpqe_st
  * events (may be NULL): hipEvent_t handles recorded in pairs around single launches on the stream of the
  * launch, in this order: for level 0..Lmax-1, for each lane that has the level: layer forward; for level
  * Lmax-1..0, for each such lane: backward-x; then the weight-gradient launch. When the graph-block chain
- * kernel runs (dim 64 / 128 / 256, at most 32768 query graphs in the step, MPQE_STEP_NO_CHAIN clear, every
- * batch at most 5 passes) the order is: for each lane its chain launch (assemble, levels forward, scores,
+ * kernel runs (dim 64 / 128 / 256, MPQE_STEP_NO_CHAIN clear, every batch at most 5 passes) the order is: for each lane its chain launch (assemble, levels forward, scores,
  * levels backward), then for each lane its weight-gradient launch. Fewer are filled as far as they go.
  * For roofline accounting only.                                                                     */
 int mpqe_step_forward_backward(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,

@@ -109,12 +109,16 @@ __device__ __forceinline__ void chain_mma(f32x4 (&acc)[NCB], const WHalf<NCB> &f
 }
 
 // LDS of one workgroup (D = 128: 77 KB -> two workgroups per CU; D = 256: 151 KB)
-template <int NCB>
+// NCB: column blocks (of 16) a wave owns; KS: ways the K range of a K-block is split between the waves.
+// 4 waves = (D / (16 NCB)) column groups x KS.  D = 64: <1,1>.  D = 128: <4,2> (a wave owns 64 columns and half
+// of K: dwordx4 loads, 64 MFMAs per item; the two K-halves meet in the LDS output tile) -- <2,1> is the form
+// without the split (MPQE_STEP_NO_KSPLIT).  D = 256: <4,1>.
+template <int NCB, int KS>
 struct ChainLds {
-    static constexpr int D = 64 * NCB, LDX = D + 4, BUF = 4 * CH_GB * LDX;
+    static constexpr int D = 64 * NCB / KS, LDX = D + 4, BUF = 4 * CH_GB * LDX, MT = 256 / KS;
     float xs[2 * BUF];                                   // node states, ping-pong: [node][graph][LDX]
     float bias[MPQE_STEP_MAX_LAYERS * D];                // every layer's bias
-    typename chain_bits<NCB>::type mbits[CH_MASK_LEVELS * 4 * 256];   // ReLU bits per (level, node, thread)
+    typename chain_bits<NCB>::type mbits[CH_MASK_LEVELS * 4 * MT];    // ReLU bits per (level, node, finishing thread)
     const float *rowp[4 * CH_GB + 2 * CH_GB];            // source row of every node row, then +/- targets
     float *gradp[4 * CH_GB];                             // entity-table gradient row of every anchor row
     float nrm[4 * CH_GB];                                // |v| of the anchor rows
@@ -125,10 +129,10 @@ struct ChainLds {
 
 // parts[row][:] = sum over the block's graphs i < ng and the node slots in `mask` of the LDS rows of buffer
 // `X` (fixed order). Called by the whole workgroup, between barriers of its own.
-template <int NCB>
-__device__ __forceinline__ void chain_colsum(ChainLds<NCB> &S, const float *X, unsigned mask, int ng,
+template <int NCB, int KS>
+__device__ __forceinline__ void chain_colsum(ChainLds<NCB, KS> &S, const float *X, unsigned mask, int ng,
                                              float *__restrict__ dst) {
-    constexpr int D = 64 * NCB, LDX = D + 4, NP = 256 / D;
+    constexpr int D = 64 * NCB / KS, LDX = D + 4, NP = 256 / D;
     const int col = threadIdx.x % D, part = threadIdx.x / D;
     float s = 0.f;
     for (int n = 0; n < 4; ++n) {
@@ -156,17 +160,23 @@ struct ChainStep {
 // inside a branch makes hipcc's s_waitcnt bookkeeping fall back to vmcnt(0) at the join, which would
 // serialise every half-block behind the prefetch just issued for the next one; sched_barriers keep hipcc's
 // scheduler from sinking the prefetch loads down to the MFMAs that use them.
-template <int NCB, bool BWD>
-__device__ __forceinline__ void chain_run(ChainLds<NCB> &S, const int first_op, int T /* half-blocks */, int N, int ng,
+template <int NCB, int KS, bool BWD>
+__device__ __forceinline__ void chain_run(ChainLds<NCB, KS> &S, const int first_op, int T /* items */, int N, int ng,
                                           float *__restrict__ Xrows, long long level_stride, int &cur, int A = 0,
                                           const int *bias_part = nullptr, const int *var_part = nullptr,
                                           float *parts = nullptr, int blk = 0) {
-    constexpr int D = 64 * NCB, LDX = D + 4, BUF = 4 * CH_GB * LDX;
+    constexpr int D = 64 * NCB / KS, LDX = D + 4, BUF = 4 * CH_GB * LDX;
+    constexpr int CW = 4 / KS;                  // column groups of 16 NCB columns
+    constexpr int IPO = D / KS / 64;            // items (64 k each) per K-block and wave
+    constexpr int MT = 256 / KS;                // threads that finish node updates (the last K part's waves)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kq = lane >> 4;
-    const int colb = wave * 16 * NCB + NCB * j;          // this lane's NCB adjacent columns
+    const int ks = wave / CW;                            // which part of K this wave multiplies
+    const int kbase = ks * (D / KS);
+    const int colb = (wave % CW) * 16 * NCB + NCB * j;   // this lane's NCB adjacent columns
+    const bool finisher = ks == KS - 1;
     auto get_op = [&](int it) -> ChainStep {
-        const int k = first_op + (it < T ? it : T - 1) / NCB;
+        const int k = first_op + (it < T ? it : T - 1) / IPO;
         const int w = __builtin_amdgcn_readfirstlane(S.opw[k][0]);
         ChainStep o;
         o.src = w & 0xff;
@@ -179,9 +189,9 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB> &S, const int first_op, 
     // matrix pointers come from LDS (filled in phase A1): no scalar memory round trip, no branch, per item
     auto wptr = [&](int it) -> const float * {
         const int itc = it < T ? it : T - 1;
-        const int h = itc % NCB;
-        const float *W = S.wp[first_op + itc / NCB];
-        return W + (long long)(64 * h + 4 * kq) * D + colb;
+        const int h = itc % IPO;
+        const float *W = S.wp[first_op + itc / IPO];
+        return W + (long long)(kbase + 64 * h + 4 * kq) * D + colb;
     };
     f32x4 acc[NCB];
     // one half-block: 4 t-steps of NCB x 4 MFMAs; the weights of the half-block two items ahead are loaded
@@ -190,9 +200,9 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB> &S, const int first_op, 
 #pragma unroll
     for (int c = 0; c < NCB; ++c) bs[c] = 0.f;
     auto item = [&](const ChainStep &op, int it, const WHalf<NCB> &f, WHalf<NCB> &fn, const float *wn) {
-        const int h = it % NCB;
+        const int h = it % IPO;
         // all four A fragments of the item up front: one exposed LDS round trip per item
-        const float *xp = S.xs + cur * BUF + (op.src * CH_GB + j) * LDX + 64 * h + 4 * kq;
+        const float *xp = S.xs + cur * BUF + (op.src * CH_GB + j) * LDX + kbase + 64 * h + 4 * kq;
         f32x4 av[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) av[t] = *reinterpret_cast<const f32x4 *>(xp + 16 * t);
@@ -217,11 +227,44 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB> &S, const int first_op, 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (h != NCB - 1) return;
-        if (op.flags & CH_LAST) {
+        if (h != IPO - 1) return;
+        if ((op.flags & CH_LAST) && KS > 1) {
+            // K split: the waves of the other K parts hand their partial sums over through the node's LDS output
+            // tile (nobody reads it before the level ends), one part per barrier; the last part's waves finish
+            float *Xn = S.xs + (cur ^ 1) * BUF;
+#pragma unroll
+            for (int part = 0; part + 1 < KS; ++part) {
+                if (ks == part) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v[NCB];
+#pragma unroll
+                        for (int c = 0; c < NCB; ++c) v[c] = acc[c][r];
+                        float *l = Xn + (op.node * CH_GB + 4 * kq + r) * LDX + colb;
+                        if (part > 0) {
+#pragma unroll
+                            for (int c = 0; c < NCB; ++c) v[c] += l[c];
+                        }
+                        chain_store<NCB>(l, v);
+                    }
+#pragma unroll
+                    for (int c = 0; c < NCB; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                __syncthreads();
+            }
+            if (finisher) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float *l = Xn + (op.node * CH_GB + 4 * kq + r) * LDX + colb;
+#pragma unroll
+                    for (int c = 0; c < NCB; ++c) acc[c][r] += l[c];
+                }
+            }
+        }
+        if ((op.flags & CH_LAST) && finisher) {
             float *Xn = S.xs + (cur ^ 1) * BUF;
             float *Xout = Xrows + (long long)op.level * level_stride;
-            const int mslot = ((op.level - 1) * 4 + op.node) * 256 + threadIdx.x;   // levels 1 .. L-1
+            const int mslot = ((op.level - 1) * 4 + op.node) * MT + (threadIdx.x & (MT - 1));   // levels 1 .. L-1
             unsigned bits = 0;
             if (BWD && (op.flags & CH_MASK)) bits = S.mbits[mslot];
             float bv[NCB];
@@ -268,7 +311,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB> &S, const int first_op, 
                     t[c] = ns[c] + __shfl_xor(ns[c], 16, 64);
                     t[c] += __shfl_xor(t[c], 32, 64);
                 }
-                if (kq == 0) chain_store<NCB>(parts + (long long)(var_part[op.node - A] + blk) * D + colb, t);
+                if (kq == 0) chain_store<NCB>(parts + (long long)(var_part[op.node - A] + blk) * D + colb, t);   // (finisher)
             }
             if (!BWD && (op.flags & CH_RELU)) S.mbits[mslot] = (typename chain_bits<NCB>::type)out_bits;
             // the next node update starts from zero (cleared here, inside the uniform branch, rather than by a
@@ -287,7 +330,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB> &S, const int first_op, 
                     t[c] += __shfl_xor(t[c], 32, 64);
                     bs[c] = 0.f;
                 }
-                if (op.level >= 1 && bias_part[op.level - 1] >= 0 && kq == 0)
+                if (op.level >= 1 && bias_part[op.level - 1] >= 0 && kq == 0 && finisher)
                     chain_store<NCB>(parts + (long long)(bias_part[op.level - 1] + blk) * D + colb, t);
             }
             __syncthreads();
@@ -302,7 +345,27 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB> &S, const int first_op, 
     // (L2 hit rate ~75 %, the rest comes from the Infinity Cache): D <= 128 has the registers for PF = 3.
     ChainStep oc = get_op(0), on = get_op(1);       // ops of items it, it + 1
     int it = 0;
-    if constexpr (NCB <= 2) {
+    if constexpr (NCB == 4 && KS == 2) {
+        // 64 registers per buffer and two workgroups per CU: two buffers; an item is 64 MFMAs (2048 cycles), so one
+        // item of distance covers what two cover in the other forms
+        WHalf<NCB> f0, f1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) chain_load_t<NCB>(f0, wptr(0), D, t);
+        __builtin_amdgcn_sched_barrier(0);
+#define CHAIN_STEP(F, FN)                       \
+    {                                           \
+        const ChainStep o2_ = get_op(it + 2);   \
+        item(oc, it, F, FN, wptr(it + 1));      \
+        if (++it >= T) break;                   \
+        oc = on;                                \
+        on = o2_;                               \
+    }
+        while (true) {
+            CHAIN_STEP(f0, f1)
+            CHAIN_STEP(f1, f0)
+        }
+#undef CHAIN_STEP
+    } else if constexpr (NCB <= 2) {
         WHalf<NCB> f0, f1, f2, f3;
 #pragma unroll
         for (int t = 0; t < 4; ++t) chain_load_t<NCB>(f0, wptr(0), D, t);
@@ -403,11 +466,13 @@ __device__ __forceinline__ void chain_stamp_where(const ChainArgs &ca) {
 #endif
 }
 
-template <int NCB>
+template <int NCB, int KS>
 __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, const LayerPtrs &lp, const TablePtrs &tabs,
-                                            const ChainArgs &ca, ChainLds<NCB> &S) {
-    constexpr int D = 64 * NCB, LDX = D + 4, BUF = 4 * CH_GB * LDX;
-    constexpr int LPR = 16 * NCB;                         // lanes that share one row in the row-major phases
+                                            const ChainArgs &ca, ChainLds<NCB, KS> &S) {
+    constexpr int D = 64 * NCB / KS, LDX = D + 4, BUF = 4 * CH_GB * LDX;
+    constexpr int DB = D / 64;                            // float4 passes of 256 threads over one node's 16 rows
+    constexpr int IPO = D / KS / 64;                      // K-loop items per K-block and wave
+    constexpr int LPR = D / 4;                            // lanes that share one row in the row-major phases
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const ChainRef ref = ca.refs[blockIdx.x];
     if (ref.batch < 0) return;                            // a hole of the placement grid (uniform)
@@ -475,13 +540,13 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     chain_stamp(ca, 1);
 
     // ---- phase A2: gather the rows, L2-normalise the anchors (reference encoders.py:41-43, no eps), write
-    // LDS buffer 0 and H[0]. Thread t moves float4 number t + 256 k, k < N * NCB; LPR adjacent lanes share a
+    // LDS buffer 0 and H[0]. Thread t moves float4 number t + 256 k, k < N * DB; LPR adjacent lanes share a
     // row. All loads are issued before the first use.
     {
-        const int nk = N * NCB;
-        f32x4 v[4 * NCB];
+        const int nk = N * DB;
+        f32x4 v[4 * DB];
 #pragma unroll
-        for (int k = 0; k < 4 * NCB; ++k) {
+        for (int k = 0; k < 4 * DB; ++k) {
             const int f = tid + 256 * (k < nk ? k : 0);
             const int r = f / (D / 4), c4 = f - r * (D / 4);
             const float *src = S.rowp[r];
@@ -489,7 +554,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
         }
         float *H0 = ca.H + row0 * D;
 #pragma unroll
-        for (int k = 0; k < 4 * NCB; ++k) {
+        for (int k = 0; k < 4 * DB; ++k) {
             const int f = tid + 256 * k;
             const int r = f / (D / 4), c4 = f - r * (D / 4);
             const int i = r / N, n = r - i * N;
@@ -514,7 +579,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     chain_stamp(ca, 2);
     // ---- forward levels
     int cur = 0;
-    chain_run<NCB, false>(S, 0, ref.fwd_count * NCB, N, ng, ca.H + row0 * D, ca.level_stride, cur);
+    chain_run<NCB, KS, false>(S, 0, ref.fwd_count * IPO, N, ng, ca.H + row0 * D, ca.level_stride, cur);
 
     chain_stamp(ca, 3);
     // ---- readout, cosine scores against the + and - target, hinge terms (reference model.py:447-462,
@@ -652,11 +717,11 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     const int blk = g0 / CH_GB;
     {   // bias gradient of the last pass: column sums of gH[L]
         const int pr = cp.bias_part[L - 1];
-        chain_colsum<NCB>(S, S.xs + cur * BUF, b.live[L], ng, pr >= 0 ? ca.parts + (long long)(pr + blk) * D : nullptr);
+        chain_colsum<NCB, KS>(S, S.xs + cur * BUF, b.live[L], ng, pr >= 0 ? ca.parts + (long long)(pr + blk) * D : nullptr);
     }
 
     // ---- backward levels
-    chain_run<NCB, true>(S, ref.fwd_count, ref.bwd_count * NCB, N, ng, ca.GH + row0 * D, ca.level_stride, cur, A,
+    chain_run<NCB, KS, true>(S, ref.fwd_count, ref.bwd_count * IPO, N, ng, ca.GH + row0 * D, ca.level_stride, cur, A,
                          cp.bias_part, cp.var_part, ca.parts, blk);
 
     chain_stamp(ca, 5);
@@ -665,17 +730,17 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     {
         const float *Xc = S.xs + cur * BUF;
         const float *H0 = ca.H + row0 * D;
-        const int nk = N * NCB;
+        const int nk = N * DB;
         const unsigned live0 = b.live[0];
-        f32x4 y[4 * NCB];
+        f32x4 y[4 * DB];
 #pragma unroll
-        for (int k = 0; k < 4 * NCB; ++k) {
+        for (int k = 0; k < 4 * DB; ++k) {
             const int f = tid + 256 * (k < nk ? k : 0);
             const int r = f / (D / 4), c4 = f - r * (D / 4);
             y[k] = gload4(H0 + (long long)(r < nrows ? r : 0) * D + 4 * c4);
         }
 #pragma unroll
-        for (int k = 0; k < 4 * NCB; ++k) {
+        for (int k = 0; k < 4 * DB; ++k) {
             const int f = tid + 256 * (k < nk ? k : 0);
             const int r = f / (D / 4), c4 = f - r * (D / 4);
             const int i = r / N, n = r - i * N;

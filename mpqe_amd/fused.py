@@ -36,7 +36,7 @@ _TEMPLATES = {   # query type -> (num anchors, num nodes, [(src, dst)]) : refere
     '1-chain': (1, 2, [(0, 1)]), '2-chain': (1, 3, [(0, 2), (2, 1)]), '3-chain': (1, 4, [(0, 3), (3, 2), (2, 1)]),
     '2-inter': (2, 3, [(0, 2), (1, 2)]), '3-inter': (3, 4, [(0, 3), (1, 3), (2, 3)]),
     '3-inter_chain': (2, 4, [(0, 2), (1, 3), (3, 2)]), '3-chain_inter': (2, 4, [(0, 3), (1, 3), (3, 2)])}
-CHAIN_MAX_GRAPHS = 32768          # csrc/step.hip
+CHAIN_MAX_GRAPHS = 1 << 20          # csrc/step.hip
 
 
 def live_units(query_type, passes, readout, prune=True):
@@ -66,7 +66,7 @@ class FusedTrainStep(object):
     gradients (include/mpqe_amd.h, mpqe_step_lanes_t). The split balances MFMA work and keeps
     batches of equal depth together (longest chains first)."""
 
-    def __init__(self, model, margin=1.0, lanes=1, prune=True, chain=True):
+    def __init__(self, model, margin=1.0, lanes=1, prune=True, chain=True, ksplit=True):
         enc = model.enc
         if not hasattr(enc, 'table') or getattr(enc, 'node_maps', None) is None:
             raise ValueError('FusedTrainStep needs a DirectEncoder built with node_maps')
@@ -76,7 +76,8 @@ class FusedTrainStep(object):
         self.model = model
         self.margin = float(margin)
         # speed switches of the library call (include/mpqe_amd.h): identical loss / scores / gradients
-        self.flags = (0 if prune else _capi.STEP_NO_PRUNE) | (0 if chain else _capi.STEP_NO_CHAIN)
+        self.flags = ((0 if prune else _capi.STEP_NO_PRUNE) | (0 if chain else _capi.STEP_NO_CHAIN) |
+                      (0 if ksplit else _capi.STEP_NO_KSPLIT))
         self.device = next(model.parameters()).device
         if self.device.type != 'cuda':
             raise RuntimeError('mpqe_amd: the model must be on the GPU -- there is no CPU path')

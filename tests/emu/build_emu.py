@@ -17,6 +17,9 @@ def sources():
 
 
 def build_emu(force=False):
+    # a prebuilt variant (e.g. an AddressSanitizer build: DESIGN.md, Oracle and parity) can be injected
+    if os.environ.get('MPQE_EMU_LIB'):
+        return os.environ['MPQE_EMU_LIB']
     deps = sources() + glob.glob(os.path.join(ROOT, 'mpqe_amd', 'csrc', '*.h')) + \
         glob.glob(os.path.join(HERE, 'include', '*', '*.h*')) + \
         glob.glob(os.path.join(HERE, 'include', '*', '*', '*.h*')) + \

@@ -46,14 +46,15 @@ def sub(b, idx):
 
 
 def close_enough(got, ref, readout, name):
-    """rtol 1e-4 / atol 2e-6; with the max readout the two paths sum K in different orders, so a near-tie
-    between two node states can pick the other node in one of them (a discrete, equally valid argmax): up
-    to 0.01 % of a tensor's elements (or a few rows of a small one) may then differ, by at most 1e-3."""
+    """rtol 1e-4 / atol 2e-6. With the max readout the two paths sum K in different orders, so a near-tie
+    between two node states can pick the other node in one of them (a discrete, equally valid argmax): the
+    gradient of those few (graph, column) entries is routed to another node slot, which moves every weight
+    gradient a little. Then: norm-wise error below 5e-3 and no element off by more than 1e-3."""
     if readout != 'max':
         np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-6, err_msg=name)
         return
-    bad = np.abs(got - ref) > 2e-6 + 1e-4 * np.abs(ref)
-    assert bad.sum() <= max(1e-4 * bad.size, 1024), (name, bad.sum())     # a flip touches whole rows / columns
+    denom = max(float(np.linalg.norm(ref)), 1e-12)
+    assert float(np.linalg.norm(got - ref)) / denom < 5e-3, (name, float(np.linalg.norm(got - ref)) / denom)
     np.testing.assert_allclose(got, ref, rtol=0, atol=1e-3, err_msg=name)
 
 

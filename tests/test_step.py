@@ -247,6 +247,8 @@ def test_fused_step_chain_kernels(be, D, readout, adaptive, shared, L):
     runs = [got, lev]
     if D == 64:
         runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_NO_PRUNE))
+    if D == 128:      # the form whose waves own 32 columns and all of K (the default splits K between wave pairs)
+        runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_NO_KSPLIT))
     for r in runs:
         assert r[4] == 0
         np.testing.assert_allclose(r[1], ref_sp, rtol=1e-5, atol=1e-6)
