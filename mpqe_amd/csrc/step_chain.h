@@ -125,6 +125,10 @@ struct ChainLds {
     const float *wp[CH_MAX_OPS];                         // weight matrix of every op of the block's programme
     int opw[CH_MAX_OPS][2];                              // its (src | node << 8 | layer << 16 | level << 24, flags)
     float red[256];                                      // column-sum scratch
+#if CHAIN_DBG == 6
+    long long *trace;                                    // diagnostic build: per-item cycle stamps of one wave
+    int trace_n;
+#endif
 };
 
 // parts[row][:] = sum over the block's graphs i < ng and the node slots in `mask` of the LDS rows of buffer
@@ -194,6 +198,9 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS> &S, const int first_
         return W + (long long)(kbase + 64 * h + 4 * kq) * D + colb;
     };
     f32x4 acc[NCB];
+#if CHAIN_DBG == 6
+    int trace_i = BWD ? 2048 : 0;
+#endif
     // one half-block: 4 t-steps of NCB x 4 MFMAs; the weights of the half-block two items ahead are loaded
     // into `fn` (from `wn`) on the way
     float bs[NCB];          // backward: column sums of this level's gradient rows (bias gradient of the pass below)
@@ -201,6 +208,18 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS> &S, const int first_
     for (int c = 0; c < NCB; ++c) bs[c] = 0.f;
     auto item = [&](const ChainStep &op, int it, const WHalf<NCB> &f, WHalf<NCB> &fn, const float *wn) {
         const int h = it % IPO;
+#if CHAIN_DBG == 6
+#define CHAIN_TRACE(tag)                                                                        \
+    if (S.trace && (threadIdx.x & 127) == 0 && S.trace_n < 4000) {                              \
+        const long long tt_ = (long long)__builtin_amdgcn_s_memtime();                          \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                     \
+        S.trace[(threadIdx.x >> 7) * 4096 + S.trace_n * 0 + trace_i] = tt_ * 8 + (tag);         \
+        ++trace_i;                                                                              \
+    }
+        CHAIN_TRACE(0)
+#else
+#define CHAIN_TRACE(tag)
+#endif
         // all four A fragments of the item up front: one exposed LDS round trip per item
         const float *xp = S.xs + cur * BUF + (op.src * CH_GB + j) * LDX + kbase + 64 * h + 4 * kq;
         f32x4 av[4];
@@ -227,6 +246,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS> &S, const int first_
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        CHAIN_TRACE(1)
         if (h != IPO - 1) return;
         if ((op.flags & CH_LAST) && KS > 1) {
             // K split: the waves of the other K parts hand their partial sums over through the node's LDS output
@@ -261,6 +281,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS> &S, const int first_
                 }
             }
         }
+        CHAIN_TRACE(2)
         if ((op.flags & CH_LAST) && finisher) {
             float *Xn = S.xs + (cur ^ 1) * BUF;
             float *Xout = Xrows + (long long)op.level * level_stride;
@@ -320,6 +341,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS> &S, const int first_
 #pragma unroll
             for (int c = 0; c < NCB; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        CHAIN_TRACE(3)
         if (op.flags & CH_LEVEL_END) {       // uniform over the workgroup: every wave runs the same programme
             if (BWD) {      // gH[level] is complete: its column sums (rows 4 kq + r live in lane group kq; the wave
                             // owns its columns) are pass level-1's bias gradient. Fixed order, no barrier.
@@ -340,12 +362,13 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS> &S, const int first_
     if (T <= 0) return;
 #pragma unroll
     for (int c = 0; c < NCB; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
     // Register buffers for the weights: prefetch distance PF half-blocks (PF + 1 buffers). With ~36 loads in
     // flight per wave (PF = 2) the loads of a lone workgroup on a CU return slower than the MFMAs consume them
     // (L2 hit rate ~75 %, the rest comes from the Infinity Cache): D <= 128 has the registers for PF = 3.
     ChainStep oc = get_op(0), on = get_op(1);       // ops of items it, it + 1
     int it = 0;
-    if constexpr (NCB == 4 && KS == 2) {
+    if constexpr (NCB == 4 && KS == 2 && CHAIN_DBG != 5) {
         // 64 registers per buffer and two workgroups per CU: two buffers; an item is 64 MFMAs (2048 cycles), so one
         // item of distance covers what two cover in the other forms
         WHalf<NCB> f0, f1;
@@ -485,6 +508,15 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
 
     chain_stamp(ca, 0);
     chain_stamp_where(ca);
+#if CHAIN_DBG == 6
+    if (threadIdx.x == 0) {      // trace block 0 only: words [2 G * 8 ...) of the stamp buffer
+        S.trace = (ca.stamps && blockIdx.x == 0) ? ca.stamps + (long long)gridDim.x * 16 : nullptr;
+        S.trace_n = 0;
+    }
+#endif
+#if CHAIN_DBG == 4      // experiment: de-synchronise the blocks of an XCD (they read the same matrices in lockstep)
+    for (int q = 0; q < (int)((blockIdx.x / 8) % 4) * 6; ++q) __builtin_amdgcn_s_sleep(127);
+#endif
     // ---- phase A1: where every row comes from (threads 0 .. 95: node rows, + targets, - targets)
     if (tid < 4 * CH_GB + 2 * CH_GB) {
         const float *src = nullptr;

@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--readout', default='mp')
     ap.add_argument('--no-prune', action='store_true')
     ap.add_argument('--out', default='')
+    ap.add_argument('--trace', action='store_true', help='CHAIN_DBG=6 builds: per-item cycle stamps of block 0')
     args = ap.parse_args()
     from mpqe_amd import ops, synthetic
     from mpqe_amd.data_utils import make_feature_modules
@@ -55,10 +56,34 @@ def main():
     step.run(packed)
     torch.cuda.synchronize()
     ops.lib().mpqe_debug_chain_stamps(None, 0)
-    st = stamps.cpu().numpy().reshape(cap, 8)
+    raw = stamps.cpu().numpy()
+    st = raw.reshape(cap, 8)
+    nreal = sum((b + 15) // 16 for b in packed.sizes)
+    grid = (nreal + 7) // 8 * 8                     # the launch grid: 8 x (longest XCD list), holes included
+    while int((st[:grid, 6] != 0).sum()) < nreal or bool((st[grid:2 * grid, 6] != 0).any()):
+        grid += 8
+    trace_words = raw[grid * 16: grid * 16 + 8192].copy()
+    st[2 * grid:] = 0                               # (a CHAIN_DBG=6 build keeps its trace behind the stamps)
     used = np.nonzero(st[:, 6] != 0)[0]
-    grid = int(used.max()) + 1                               # (holes only inside the grid; the last block is real)
-    grid = (grid + 7) // 8 * 8
+    if args.trace:
+        tr = trace_words.reshape(2, 2, 2048)                                 # [tracing wave][fwd / bwd][entry]
+        names = {0: 'item start', 1: 'mfma done', 2: 'handoff done', 3: 'epilogue done'}
+        for w in range(2):
+            for d, dn in enumerate(('fwd', 'bwd')):
+                v = tr[w, d]
+                v = v[v != 0]
+                if not len(v):
+                    continue
+                t, tag = v >> 3, v & 7
+                print('wave %d (%s K part) %s: %d stamps, %d cycles total' % (2 * w, 'first' if w == 0 else 'last', dn,
+                                                                              len(v), t[-1] - t[0]))
+                seg = {}
+                for k in range(1, len(v)):
+                    key = '%s -> %s' % (names[int(tag[k - 1])], names[int(tag[k])])
+                    seg.setdefault(key, []).append(int(t[k] - t[k - 1]))
+                for key, vals in seg.items():
+                    print('    %-32s n=%3d  mean %6.0f  min %5d  max %5d  sum %7d' % (key, len(vals), np.mean(vals),
+                                                                                  min(vals), max(vals), sum(vals)))
     ticks = st[grid:2 * grid]
     sel = used[used < grid]
     mhz = (ticks[sel, 1] - ticks[sel, 0]) / ((st[sel, 6] - st[sel, 0]) * 0.01)
