@@ -509,11 +509,40 @@ __device__ __forceinline__ void loss_block(const StepDev *__restrict__ sd, const
     }
 }
 
+// Chain form: every chain block left the sum of its (<= 16) hinge terms in block_terms, and everything the
+// reduction needs to know about the batches comes by value -- no dependent loads in front of the sums.
+struct LossMeta {
+    int nb, chain;
+    int B[MPQE_STEP_MAX_BATCHES], blk_off[MPQE_STEP_MAX_BATCHES + 1];
+    float weight[MPQE_STEP_MAX_BATCHES];
+};
+__device__ __forceinline__ void loss_block_chain(const LossMeta &lm, const float *__restrict__ bterms,
+                                                 float *__restrict__ loss, float *mean, int nwaves) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int bi = w; bi < lm.nb; bi += nwaves) {
+        float s = 0.f;
+        for (int i = lm.blk_off[bi] + lane; i < lm.blk_off[bi + 1]; i += 64) s += bterms[i];
+        s = wave_sum(s);
+        if (lane == 0) {
+            mean[bi] = s / (float)lm.B[bi];
+            loss[1 + bi] = mean[bi];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float total = 0.f;
+        for (int bi = 0; bi < lm.nb; ++bi) total += lm.weight[bi] * mean[bi];
+        loss[0] = total;
+    }
+}
+
 __global__ __launch_bounds__(1024) void step_loss_kernel(const StepDev *__restrict__ sd,
                                                          const float *__restrict__ terms,
-                                                         float *__restrict__ loss) {
+                                                         float *__restrict__ loss, LossMeta lm,
+                                                         const float *__restrict__ bterms) {
     __shared__ float mean[MPQE_STEP_MAX_BATCHES];
-    loss_block(sd, terms, loss, mean, 16);
+    if (lm.chain) loss_block_chain(lm, bterms, loss, mean, 16);
+    else loss_block(sd, terms, loss, mean, 16);
 }
 
 struct GradPtrs {
@@ -714,19 +743,64 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restri
                                                           const float *__restrict__ partial, int vec,
                                                           const StepDev *__restrict__ sd,
                                                           const float *__restrict__ terms,
-                                                          float *__restrict__ loss) {
+                                                          float *__restrict__ loss, int zeroed, LossMeta lm,
+                                                          const float *__restrict__ bterms) {
+    // zeroed: this call zero-filled the gradients, so `out` is known to be 0 -- a store replaces the
+    // read-modify-write (whose read would be one more dependent round trip at the end of the chain)
     __shared__ f32x4 part[4][64];
     if ((int)blockIdx.y == ngroups) {       // one extra workgroup row: the loss reduction rides along
-        if (blockIdx.x == 0) loss_block(sd, terms, loss, reinterpret_cast<float *>(part), 4);
+        if (blockIdx.x == 0) {
+            if (lm.chain) loss_block_chain(lm, bterms, loss, reinterpret_cast<float *>(part), 4);
+            else loss_block(sd, terms, loss, reinterpret_cast<float *>(part), 4);
+        }
         return;
     }
     const RGroup g = groups[blockIdx.y];
     const long long elems = g.kind <= 1 ? (long long)D * D : D;
+    if (g.kind >= 2 && vec && (256 % (D / 4)) == 0) {
+        // a vector group (bias / mode row): hundreds of partial rows of D floats (one per chain block), ONE
+        // workgroup: D/4 lanes cover a row, the 256 / (D/4) row groups each walk every RG-th row with 8 loads
+        // in flight, then the row groups' sums are added in order (fixed order: reproducible)
+        if (blockIdx.x != 0) return;
+        const int LQ = D / 4, RG = 256 / LQ;
+        const int c4 = threadIdx.x % LQ, rg = threadIdx.x / LQ;
+        const float *pv = partial + (long long)g.start * D + 4 * c4;
+        f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+        for (int i = rg; i < g.count; i += RG * 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = i + RG * q;
+                v[q] = gload4(pv + (long long)(k < g.count ? k : i) * D);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (i + RG * q < g.count) acc4 += v[q];
+        }
+        f32x4 *flat = &part[0][0];
+        flat[threadIdx.x] = acc4;
+        __syncthreads();
+        if (rg != 0) return;
+        float *dstv = g.kind == 2 ? gp.bias[g.layer] : (gp.mode_emb ? gp.mode_emb + g.row * D : nullptr);
+        if (!dstv) return;
+        f32x4 t = flat[c4];
+        for (int q = 1; q < RG; ++q) t += flat[q * LQ + c4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dstv[4 * c4 + k] = zeroed ? t[k] : dstv[4 * c4 + k] + t[k];
+        return;
+    }
     const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const long long idx = ((long long)blockIdx.x * 64 + el) * 4;
     if ((long long)blockIdx.x * 256 >= elems) return;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     const float *p = (g.kind <= 1 ? slabs : partial) + (long long)g.start * elems + idx;
+    float *dst;
+    if (g.kind == 0) dst = gp.basis[g.layer] ? gp.basis[g.layer] + g.row * elems : nullptr;
+    else if (g.kind == 1) dst = gp.root[g.layer];
+    else if (g.kind == 2) dst = gp.bias[g.layer];
+    else dst = gp.mode_emb ? gp.mode_emb + g.row * D : nullptr;
+    f32x4 old4 = {0.f, 0.f, 0.f, 0.f};       // accumulate mode: the old value travels with the slab loads, not after them
+    if (vec && dst && !zeroed && sg == 0 && idx + 3 < elems) old4 = gload4(dst + idx);
     if (vec) {
         if (idx < elems) {
             // four slabs of this wave in flight at a time (slab i, i+4, i+8, i+12; clamped loads, masked adds)
@@ -749,16 +823,14 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restri
     }
     part[sg][el] = s;
     __syncthreads();
-    if (sg != 0) return;
-    float *dst;
-    if (g.kind == 0) dst = gp.basis[g.layer] ? gp.basis[g.layer] + g.row * elems : nullptr;
-    else if (g.kind == 1) dst = gp.root[g.layer];
-    else if (g.kind == 2) dst = gp.bias[g.layer];
-    else dst = gp.mode_emb ? gp.mode_emb + g.row * D : nullptr;
-    if (!dst) return;
+    if (sg != 0 || !dst) return;
+    const bool have_old = vec && !zeroed && idx + 3 < elems;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        if (idx + k < elems) dst[idx + k] += (part[0][el][k] + part[1][el][k]) + (part[2][el][k] + part[3][el][k]);
+        if (idx + k < elems) {
+            const float sum = (part[0][el][k] + part[1][el][k]) + (part[2][el][k] + part[3][el][k]);
+            dst[idx + k] = zeroed ? sum : (have_old ? old4[k] : dst[idx + k]) + sum;
+        }
 }
 
 // ------------------------------------------------------------------------------------ host side
@@ -788,6 +860,8 @@ struct HostPlan {
     std::vector<ChainOp> cops;
     std::vector<WtSlot> wt_slots;     // matrices with a transposed copy (those of the backward programmes)
     ChainParts cparts[MPQE_STEP_MAX_BATCHES];
+    int blk_off[MPQE_STEP_MAX_BATCHES + 1];        // chain blocks before batch i (slots of block_terms)
+    size_t o_bterms;
     size_t o_cref, o_cops, o_wtslots, o_cparts, o_WT;
     // workspace offsets (bytes)
     size_t o_sd, o_wsrc, o_wblock, o_vsrc, o_vblock, o_groups, o_anchor, desc_total;     // descriptor buffer
@@ -1105,6 +1179,8 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->vblocks_total = vblock;
     hp->total_parts = part;
 
+    hp->blk_off[0] = 0;
+    for (int i = 0; i < nb; ++i) hp->blk_off[i + 1] = hp->blk_off[i] + (sd.b[i].B + CH_GB - 1) / CH_GB;
     // chain programmes: per batch the K-blocks (source slot, matrix) of every live node update, forward levels
     // 0 .. L-1 then backward levels L-1 .. 0, in execution order
     hp->cops.clear();
@@ -1190,8 +1266,8 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                     for (int x = 1; x < STEP_XCDS; ++x)
                         if (load[x] < load[best]) best = x;
                     for (int g0 = c0; g0 < Bk && g0 < c0 + (int)cus * CH_GB; g0 += CH_GB) {   // progs is sorted: bins stay sorted
-                        bins[best].push_back(
-                            ChainRef{progs[k].batch, g0, progs[k].fb, progs[k].fc, progs[k].bb, progs[k].bc, 0, 0});
+                        bins[best].push_back(ChainRef{progs[k].batch, g0, progs[k].fb, progs[k].fc, progs[k].bb,
+                                                      progs[k].bc, hp->blk_off[progs[k].batch] + g0 / CH_GB, 0});
                         load[best] += progs[k].work;
                     }
                 }
@@ -1253,6 +1329,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->o_slabs = take((size_t)hp->total_slabs * D * D * 4);
     hp->o_parts = take((size_t)hp->total_parts * D * 4);
     hp->o_WT = take(hp->wt_slots.size() * (size_t)D * D * 4);
+    hp->o_bterms = take((size_t)hp->blk_off[nb] * 4);
     hp->total = off;
     return MPQE_OK;
 }
@@ -1502,6 +1579,17 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                                reinterpret_cast<const WtSlot *>(db + hp.o_wtslots), (int)hp.wt_slots.size(), D, WT,
                                tblocks, zs);
     }
+    LossMeta lm;
+    memset(&lm, 0, sizeof(lm));
+    lm.nb = nb;
+    lm.chain = use_chain ? 1 : 0;
+    for (int i = 0; i < nb; ++i) {
+        lm.B[i] = hp.sd.b[i].B;
+        lm.weight[i] = hp.sd.b[i].weight;
+        lm.blk_off[i] = hp.blk_off[i];
+    }
+    lm.blk_off[nb] = hp.blk_off[nb];
+    const float *bterms = reinterpret_cast<const float *>(wb + hp.o_bterms);
     if (NL > 1) {       // fork: the lanes start after the descriptor uploads and the prologue
         (void)hipEventRecord(reinterpret_cast<hipEvent_t>(lanes->fork_event), s);
         for (int l = 1; l < NL; ++l) (void)hipStreamWaitEvent(ls[l], reinterpret_cast<hipEvent_t>(lanes->fork_event), 0);
@@ -1558,6 +1646,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         ca.WT = WT;
         ca.cparts = reinterpret_cast<const ChainParts *>(db + hp.o_cparts);
         ca.parts = reinterpret_cast<float *>(wb + hp.o_parts);
+        ca.block_terms = reinterpret_cast<float *>(wb + hp.o_bterms);
         ca.level_stride = hp.level_stride;
         ca.margin = margin;
         ca.eps = 1e-8f;
@@ -1584,7 +1673,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                 (void)hipEventRecord(reinterpret_cast<hipEvent_t>(lanes->join_event[l]), ls[l]);
                 (void)hipStreamWaitEvent(s, reinterpret_cast<hipEvent_t>(lanes->join_event[l]), 0);
             }
-            hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss);
+            hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss, lm, bterms);
             return mpqe_launch_status();
         }
         for (int l = 0; l < NL; ++l) {      // each lane's weight gradients follow its own chains
@@ -1639,7 +1728,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     if (!backward) {      // (not reached with the chain kernel)
         for (int l = 0; l < NL; ++l) { LAUNCH_SCORE_D(false, (float *)nullptr, l); }
         join();
-        hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss);
+        hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss, lm, bterms);
         return mpqe_launch_status();
     }
 
@@ -1685,7 +1774,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         hipLaunchKernelGGL(step_reduce_kernel, grid, dim3(256), 0, s,
                            reinterpret_cast<const RGroup *>(db + hp.o_groups), (int)hp.groups.size(), D, gp,
                            (const float *)slabs, (const float *)parts, (int)(D % 4 == 0), sd, (const float *)terms,
-                           loss);
+                           loss, (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0, lm, bterms);
     }
     return mpqe_launch_status();
 }

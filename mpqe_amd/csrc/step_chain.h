@@ -44,7 +44,9 @@ struct ChainOp {
 };
 // one workgroup: graphs [g0, g0 + 16) of `batch`; its forward / backward programmes in the op table
 struct ChainRef {
-    int batch, g0, fwd_begin, fwd_count, bwd_begin, bwd_count, pad0, pad1;
+    int batch, g0, fwd_begin, fwd_count, bwd_begin, bwd_count;
+    int tb;               // number of this block among all blocks of the step (batch order): its slot in block_terms
+    int pad1;
 };
 
 template <int NCB>
@@ -455,6 +457,7 @@ struct ChainArgs {
     const float *WT;        // transposed copies of the matrices the backward chains multiply by
     const ChainParts *cparts;
     float *parts;
+    float *block_terms;     // [blocks of the step]: sum of the block's hinge terms (the loss reduction reads these)
     long long level_stride;
     float margin, eps;
     float *s_pos, *s_neg, *terms;
@@ -693,10 +696,16 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
         const float sp = dp / (nq * np_), sn = dn / (nq * nn_);
         const float hv = ca.margin - (sp - sn);
         const long long gi = gi0 + i;
+        const float term = on && hv > 0.f ? hv : 0.f;
         if (on && sl == 0) {
             ca.s_pos[gi] = sp;
             ca.s_neg[gi] = sn;
-            ca.terms[gi] = hv > 0.f ? hv : 0.f;
+            ca.terms[gi] = term;
+        }
+        {   // the wave's four graphs (every lane of a group holds its graph's term), then the four waves, in order
+            float t4 = term + __shfl_xor(term, 16, 64);
+            t4 += __shfl_xor(t4, 32, 64);
+            if (lane == 0) S.red[wave] = t4;
         }
         if (ca.backward) {
             // d loss / d sp = -w/B on active terms, d/d sn = +w/B   (loss = sum_b w_b mean_b hinge)
@@ -742,8 +751,9 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
             }
         }
     }
-    if (!ca.backward) return;
     __syncthreads();
+    if (tid == 0) ca.block_terms[ref.tb] = (S.red[0] + S.red[1]) + (S.red[2] + S.red[3]);
+    if (!ca.backward) return;
     chain_stamp(ca, 4);
     const ChainParts &cp = ca.cparts[ref.batch];
     const int blk = g0 / CH_GB;
