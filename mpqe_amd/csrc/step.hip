@@ -21,6 +21,7 @@
 // Arithmetic is identical to the per-op kernels (same tile bodies, rgcn_template_body.h);
 // margin_loss's two encoder passes are one here (the query embedding does not depend on the
 // target).
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -872,7 +873,7 @@ struct HostPlan {
 void pick_chunks(long long count, int max_chunks, int *nch, int *ch) {
     // ~512 rows (16 K-steps) per workgroup: long enough to amortise the pipeline fill and the
     // 16 KB slab store, short enough that the AIFB-sized step still yields ~500 workgroups
-    long long n = (count + 511) / 512;
+    long long n = (count + 511) / 512;      // (256- and 128-row chunks measured slower: 0.102 vs 0.097 ms per step)
     if (n < 1) n = 1;
     if (n > max_chunks) n = max_chunks;
     long long c = (count + n - 1) / n;
@@ -1062,6 +1063,29 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         return a.rel < b.rel;
     });
     const int tiles = ct * ((D + GT_BM - 1) / GT_BM);
+    // Balance: with one K-chunk per source the step has (sources x tiles) workgroups; a few more than there are
+    // CUs (264 for the AIFB mix) means a handful of CUs run two whole tiles and the launch lasts twice a tile.
+    // Then the surplus is taken out of a few ROOT sources (they go through the reduction anyway), cut into
+    // four K-chunks: their short workgroups ride along on CUs that also hold one whole tile.
+    std::vector<char> split4(keys.size(), 0);
+    {
+        long long blocks1 = 0;
+        for (size_t k = 0; k < keys.size(); ++k) {
+            int nch1, ch1;
+            pick_chunks(sd.b[keys[k].batch].B, 32, &nch1, &ch1);
+            blocks1 += (long long)nch1 * tiles;
+        }
+        long long excess = blocks1 - STEP_CUS;
+        if (excess > 0 && excess <= STEP_CUS / 4)
+            for (size_t k = keys.size(); k-- > 0 && excess > 0;) {
+                const int Bk = sd.b[keys[k].batch].B;
+                int nch1, ch1;
+                pick_chunks(Bk, 32, &nch1, &ch1);
+                if (keys[k].rel >= 0 || nch1 != 1 || Bk < 4 * 4 * GT_BK || Bk % (4 * GT_BK) != 0) continue;
+                split4[k] = 1;
+                excess -= tiles;
+            }
+    }
     int slab = 0, block = 0;
     hp->wsrc.clear();
     hp->wblock.clear();
@@ -1076,6 +1100,10 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         s.slot = key.slot;
         s.relu = 0;      // gH is stored as a pre-activation gradient (masked by its producer)
         pick_chunks(d.B, 32, &s.nch, &s.ch);
+        if (split4[k]) {
+            s.nch = 4;
+            s.ch = d.B / 4;
+        }
         s.slab_start = slab;
         s.block_start = block;
         s.direct = -1;
@@ -1101,11 +1129,14 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->total_slabs = slab;
     for (int l = 0; l < hp->nlanes; ++l) {          // block table, grouped by stream lane (a lane launches its own)
         hp->wblock_begin[l] = (int)hp->wblock.size();
-        for (size_t k = 0; k < hp->wsrc.size(); ++k) {
-            const WSource &ws = hp->wsrc[k];
-            if (ws.batch < hp->lane_begin[l] || ws.batch >= hp->lane_begin[l + 1]) continue;
-            for (int q = 0; q < ws.nch * tiles; ++q) hp->wblock.push_back(WBlock{(int)k, q});
-        }
+        for (int pass = 0; pass < 2; ++pass)        // whole-batch chunks first, the short ride-along chunks last
+            for (size_t k = 0; k < hp->wsrc.size(); ++k) {
+                const WSource &ws = hp->wsrc[k];
+                if (ws.batch < hp->lane_begin[l] || ws.batch >= hp->lane_begin[l + 1]) continue;
+                const bool is_short = ws.nch > 1 && ws.ch < sd.b[ws.batch].B && ws.ch <= 4 * 4 * GT_BK;
+                if ((int)is_short != pass) continue;
+                for (int q = 0; q < ws.nch * tiles; ++q) hp->wblock.push_back(WBlock{(int)k, q});
+            }
     }
     hp->wblock_begin[hp->nlanes] = (int)hp->wblock.size();
     // a gradient matrix with ONE contribution (one source, one K-chunk: most relation matrices, a relation
