@@ -84,9 +84,16 @@ struct TileRef {
 };
 
 // one weight-gradient source: (batch, level, slot) -> nch K-chunks, each a slab of D*D floats
-// one weight-gradient workgroup: tile / K-chunk number `lb` of source `src`
+// one weight-gradient workgroup, everything it needs in one 64-byte record (the host resolved source, batch
+// and template: three dependent loads in front of the first DMA otherwise)
 struct WBlock {
-    int src, lb;
+    long long x_off, g_off;     // float offsets into H / gH: level base + the batch's first row
+    long long slab_off;         // float offset of the chunk's slab
+    long long rel;              // direct: relation id (-1 = root)
+    int xs, xo, go;             // rows of graph q: x at (q * xs + xo), g at (q * xs + go)
+    int q0, q1;                 // the K-chunk: graphs [q0, q1)
+    int i0, j0;                 // the output tile
+    int direct;                 // >= 0: layer whose gradient matrix the tile writes itself; -1: slab
 };
 struct WSource {
     int batch, level, slot, relu;
@@ -577,38 +584,26 @@ __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, con
         const int grp = bid / span, r = bid - grp * span;
         vb = grp * span + (r & 7) * tiles + (r >> 3);
     }
-    const WBlock wk = block_start[vb];       // per-workgroup (source, block inside the source): one load, no search
-    const WSource s = src[wk.src];
-    const int lb = wk.lb;
-    const int c = lb / tiles, tile = lb - c * tiles;
-    const BatchDev &b = sd->b[s.batch];
-    // slot < E: template edge (x = source slot, g = destination slot); slot = E + n: the self/root term
-    // of node slot n. K runs over the batch's graphs in both cases.
-    const bool is_root = s.slot >= b.tp.E;
-    const long long count = b.B;
-    const long long q0 = (long long)c * s.ch;
-    long long q1 = q0 + s.ch;
-    if (q1 > count) q1 = count;
-    const long long xs = b.tp.N, xo = is_root ? s.slot - b.tp.E : b.tp.src[s.slot < 3 ? s.slot : 0];
-    const long long gs = b.tp.N, go = is_root ? s.slot - b.tp.E : b.tp.dst[s.slot < 3 ? s.slot : 0];
-    const float *x = H + (long long)s.level * level_stride + b.row_off * D;
-    const float *out = H + (long long)(s.level + 1) * level_stride + b.row_off * D;
-    const float *g = GH + (long long)(s.level + 1) * level_stride + b.row_off * D;
-    float *dst = slabs + (long long)(s.slab_start + c) * D * D;
+    const WBlock wk = block_start[vb];       // one record, no search, no second hop
+    const long long xs = wk.xs, xo = wk.xo, gs = wk.xs, go = wk.go;
+    const long long q0 = wk.q0, q1 = wk.q1;
+    const float *x = H + wk.x_off;
+    const float *out = nullptr;              // (masks are applied by the producers: relu = 0 everywhere)
+    const float *g = GH + wk.g_off;
+    float *dst = slabs + wk.slab_off;
     bool direct = false;
-    if (s.direct >= 0) {
-        float *gm = s.rel >= 0 ? pick_grad(gp.basis, s.direct) : pick_grad(gp.root, s.direct);
+    if (wk.direct >= 0) {
+        float *gm = wk.rel >= 0 ? pick_grad(gp.basis, wk.direct) : pick_grad(gp.root, wk.direct);
         if (gm) {
-            dst = gm + (s.rel >= 0 ? s.rel * (long long)D * D : 0);
+            dst = gm + (wk.rel >= 0 ? wk.rel * (long long)D * D : 0);
             direct = true;
         }
     }
     if (MODE == LD_FAST)      // whole K-steps, D % 64 == 0: deep LDS-DMA pipeline
-        grad_w_tile_dma(x, g, D, D, xs, xo, gs, go, q0, (int)((q1 - q0) / GT_BK), (tile / tiles_j) * GT_BM,
-                        (tile % tiles_j) * GT_BN, dst, smem, direct && !zeroed);
+        grad_w_tile_dma(x, g, D, D, xs, xo, gs, go, q0, (int)((q1 - q0) / GT_BK), wk.i0, wk.j0, dst, smem,
+                        direct && !zeroed);
     else
-        tmpl_grad_w_tile<MODE>(x, g, out, D, D, s.relu, xs, xo, gs, go, q0, q1, (tile / tiles_j) * GT_BM,
-                               (tile % tiles_j) * GT_BN, dst, smem, direct && !zeroed);
+        tmpl_grad_w_tile<MODE>(x, g, out, D, D, 0, xs, xo, gs, go, q0, q1, wk.i0, wk.j0, dst, smem, direct && !zeroed);
 }
 
 // partial vectors. kind 0: column sums of gpre over 64-row blocks of (batch, level).
@@ -691,6 +686,14 @@ __device__ __forceinline__ void anchor_bwd_block(const StepDev *__restrict__ sd,
     for (int c = lane; c < D; c += 64) atomicAdd(gt + row * D + c, (gi[c] - (v[c] / nrm) * ydotg) * inv);
 }
 
+// A relation matrix of the gradient that nothing writes this step (with MPQE_STEP_ZERO_GRADS it must read zero
+// afterwards): zero-filled by spare workgroups of the weight-gradient launch instead of the step's prologue.
+struct ZMat {
+    int layer, pad;
+    long long rel;
+};
+#define ZMAT_FLOATS_PER_BLOCK 8192
+
 // Backward tail: weight-gradient tiles, bias / variable-row partial sums and anchor-table gradients
 // all depend only on H and gH and write disjoint outputs, so they share ONE launch (a role per block
 // range, heavy MFMA tiles first) instead of three half-empty ones.
@@ -703,6 +706,8 @@ struct TailArgs {
     int nvsrc, vblocks;
     const int *anchor_off;
     int nb;
+    const ZMat *zmats;       // untouched gradient matrices, zero-filled by workgroups [wblocks, wblocks + zblocks)
+    int zblocks, zper;       // zper = workgroups per matrix
     const long long *node_map;
     long long map_len;
     const long long *anchor_ids;
@@ -716,6 +721,21 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
     // weight-gradient tiles only: the DMA ring takes 64 KB of LDS per workgroup, which would throttle the
     // thousands of light partial-sum / anchor workgroups to 2 per CU if they shared this kernel
     __shared__ __attribute__((aligned(16))) float smem[MODE == LD_FAST ? GWD_SMEM_FLOATS : GT_SMEM_FLOATS];
+    if ((int)blockIdx.x >= ta.wblocks) {        // zero fill of a gradient matrix nobody writes (uniform branch)
+        const int zb = (int)blockIdx.x - ta.wblocks;
+        const ZMat zm = ta.zmats[zb / ta.zper];
+        float *base = pick_grad(gp.basis, zm.layer);
+        if (!base) return;
+        const long long elems = (long long)sd->D * sd->D;
+        float *p = base + zm.rel * elems;
+        const long long lo = (long long)(zb % ta.zper) * ZMAT_FLOATS_PER_BLOCK;
+        for (long long i = lo + threadIdx.x * 4; i < lo + ZMAT_FLOATS_PER_BLOCK && i < elems; i += 1024) {
+            if (i + 3 < elems && ((uintptr_t)(p + i) & 15) == 0) *reinterpret_cast<f32x4 *>(p + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+            else
+                for (long long q = i; q < i + 4 && q < elems; ++q) p[q] = 0.f;
+        }
+        return;
+    }
     grad_w_block<MODE>(sd, ta.wsrc, ta.nwsrc, ta.wblock, H, GH, level_stride, ta.slabs, (int)blockIdx.x, ta.wblocks,
                        smem, gp, zeroed != 0);      // zeroed: this call zero-filled the gradients, a store suffices
 }
@@ -862,6 +882,8 @@ struct HostPlan {
     std::vector<WtSlot> wt_slots;     // matrices with a transposed copy (those of the backward programmes)
     ChainParts cparts[MPQE_STEP_MAX_BATCHES];
     int blk_off[MPQE_STEP_MAX_BATCHES + 1];        // chain blocks before batch i (slots of block_terms)
+    std::vector<ZMat> zmats;                       // relation matrices of the gradient that no source touches
+    size_t o_zmats;
     size_t o_bterms;
     size_t o_cref, o_cops, o_wtslots, o_cparts, o_WT;
     // workspace offsets (bytes)
@@ -989,6 +1011,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     if (rows >= (1ll << 30)) return MPQE_ERR_UNSUPPORTED;
     hp->anchor_off[nb] = (int)anchors;
     sd.rows_total = rows;
+    hp->level_stride = rows * D;
     sd.graphs_total = graphs;
     const int ct = (D + GT_BN - 1) / GT_BN;
     const int spb = (D + GT_BK - 1) / GT_BK;
@@ -1127,18 +1150,6 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     }
     hp->wblocks_total = block;
     hp->total_slabs = slab;
-    for (int l = 0; l < hp->nlanes; ++l) {          // block table, grouped by stream lane (a lane launches its own)
-        hp->wblock_begin[l] = (int)hp->wblock.size();
-        for (int pass = 0; pass < 2; ++pass)        // whole-batch chunks first, the short ride-along chunks last
-            for (size_t k = 0; k < hp->wsrc.size(); ++k) {
-                const WSource &ws = hp->wsrc[k];
-                if (ws.batch < hp->lane_begin[l] || ws.batch >= hp->lane_begin[l + 1]) continue;
-                const bool is_short = ws.nch > 1 && ws.ch < sd.b[ws.batch].B && ws.ch <= 4 * 4 * GT_BK;
-                if ((int)is_short != pass) continue;
-                for (int q = 0; q < ws.nch * tiles; ++q) hp->wblock.push_back(WBlock{(int)k, q});
-            }
-    }
-    hp->wblock_begin[hp->nlanes] = (int)hp->wblock.size();
     // a gradient matrix with ONE contribution (one source, one K-chunk: most relation matrices, a relation
     // rarely occurs in two batches of a step) needs no slab and no reduction: its tiles add straight into the
     // gradient (deterministic: one writer per element)
@@ -1149,7 +1160,50 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
             else kept.push_back(hp->groups[gi]);
         }
         hp->groups.swap(kept);
+        // every other relation matrix of every (unique) layer is untouched
+        std::vector<char> written((size_t)P->num_layers * (size_t)P->num_relations, 0);
+        for (size_t k = 0; k < hp->wsrc.size(); ++k)
+            if (hp->wsrc[k].direct >= 0 && hp->wsrc[k].rel >= 0)
+                written[(size_t)hp->wsrc[k].direct * P->num_relations + hp->wsrc[k].rel] = 1;
+        for (size_t gi = 0; gi < hp->groups.size(); ++gi)
+            if (hp->groups[gi].kind == 0) written[(size_t)hp->groups[gi].layer * P->num_relations + hp->groups[gi].row] = 1;
+        hp->zmats.clear();
+        for (int l = 0; l < P->num_layers; ++l) {
+            if (uid[l] != l) continue;
+            for (long long r = 0; r < P->num_relations; ++r)
+                if (!written[(size_t)l * P->num_relations + r]) hp->zmats.push_back(ZMat{l, 0, r});
+        }
     }
+    for (int l = 0; l < hp->nlanes; ++l) {          // block table, grouped by stream lane (a lane launches its own)
+        hp->wblock_begin[l] = (int)hp->wblock.size();
+        for (int pass = 0; pass < 2; ++pass)        // whole-batch chunks first, the short ride-along chunks last
+            for (size_t k = 0; k < hp->wsrc.size(); ++k) {
+                const WSource &ws = hp->wsrc[k];
+                if (ws.batch < hp->lane_begin[l] || ws.batch >= hp->lane_begin[l + 1]) continue;
+                const bool is_short = ws.nch > 1 && ws.ch < sd.b[ws.batch].B && ws.ch <= 4 * 4 * GT_BK;
+                if ((int)is_short != pass) continue;
+                const BatchDev &bd = sd.b[ws.batch];
+                const bool is_root = ws.slot >= bd.tp.E;
+                for (int q = 0; q < ws.nch * tiles; ++q) {
+                    const int c = q / tiles, tile = q - c * tiles;
+                    WBlock wkb;
+                    wkb.x_off = (long long)ws.level * hp->level_stride + bd.row_off * D;
+                    wkb.g_off = (long long)(ws.level + 1) * hp->level_stride + bd.row_off * D;
+                    wkb.slab_off = (long long)(ws.slab_start + c) * D * D;
+                    wkb.rel = ws.rel;
+                    wkb.xs = bd.tp.N;
+                    wkb.xo = is_root ? ws.slot - bd.tp.E : bd.tp.src[ws.slot];
+                    wkb.go = is_root ? ws.slot - bd.tp.E : bd.tp.dst[ws.slot];
+                    wkb.q0 = c * ws.ch;
+                    wkb.q1 = wkb.q0 + ws.ch < bd.B ? wkb.q0 + ws.ch : bd.B;
+                    wkb.i0 = (tile / ct) * GT_BM;
+                    wkb.j0 = (tile % ct) * GT_BN;
+                    wkb.direct = ws.direct;
+                    hp->wblock.push_back(wkb);
+                }
+            }
+    }
+    hp->wblock_begin[hp->nlanes] = (int)hp->wblock.size();
 
     // vector partial sources: bias per (unique layer) and variable rows per mode id
     struct VKey {
@@ -1347,6 +1401,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->o_cref = take(hp->crefs.size() * sizeof(ChainRef));
     hp->o_cops = take(hp->cops.size() * sizeof(ChainOp));
     hp->o_wtslots = take(hp->wt_slots.size() * sizeof(WtSlot));
+    hp->o_zmats = take(hp->zmats.size() * sizeof(ZMat));
     hp->o_cparts = take(sizeof(hp->cparts));
     hp->desc_total = off;
     off = 0;
@@ -1556,6 +1611,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         upload(s, db + hp.o_cref, hp.crefs.data(), hp.crefs.size() * sizeof(ChainRef));
         upload(s, db + hp.o_cops, hp.cops.data(), hp.cops.size() * sizeof(ChainOp));
         upload(s, db + hp.o_wtslots, hp.wt_slots.data(), hp.wt_slots.size() * sizeof(WtSlot));
+        upload(s, db + hp.o_zmats, hp.zmats.data(), hp.zmats.size() * sizeof(ZMat));
         upload(s, db + hp.o_cparts, hp.cparts, sizeof(hp.cparts));
     }
     float *H = reinterpret_cast<float *>(wb + hp.o_H), *GH = reinterpret_cast<float *>(wb + hp.o_GH);
@@ -1595,7 +1651,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                 zs.count++;
             };
             for (int l = 0; l < P->num_layers; ++l) {
-                seg(G->basis[l], (long long)P->num_relations * D * D);
+                // (relation matrices: the written ones are stored by their writers, the untouched ones are zero-filled
+                // by spare workgroups of the weight-gradient launch, off the critical path: ZMat)
                 seg(G->root[l], (long long)D * D);
                 seg(G->bias[l], D);
             }
@@ -1643,12 +1700,16 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     ta.slabs = slabs;
     ta.parts = parts;
     // weight-gradient launch over the block table entries [first, first + count) on stream `on`
+    ta.zmats = reinterpret_cast<const ZMat *>(db + hp.o_zmats);
+    ta.zper = (int)(((long long)D * D + ZMAT_FLOATS_PER_BLOCK - 1) / ZMAT_FLOATS_PER_BLOCK);
+    ta.zblocks = 0;
     auto launch_grad_w = [&](hipStream_t on, int first, int count) {
-        if (count <= 0) return;
         TailArgs tl = ta;
         tl.wblock = ta.wblock + first;
         tl.wblocks = count;
-        dim3 tgrid((unsigned)count);
+        if (first == 0 && (P->flags & MPQE_STEP_ZERO_GRADS)) tl.zblocks = (int)hp.zmats.size() * ta.zper;
+        if (count + tl.zblocks <= 0) return;
+        dim3 tgrid((unsigned)(count + tl.zblocks));
         const int zeroed = (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0;
         if (fast && hp.whole_ksteps)
             hipLaunchKernelGGL(step_tail_kernel<LD_FAST>, tgrid, dim3(256), 0, on, sd, tl, (const float *)H,
