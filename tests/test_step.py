@@ -301,6 +301,36 @@ def test_fused_step_stream_lanes(be, splits):
     np.testing.assert_array_equal(fwd[0], ref[0])
 
 
+EDGE_MIXES = {
+    'tiny': [('3-chain', 1, 1.0), ('2-inter', 3, 0.5)],                       # one partial block per batch
+    'one': [('3-inter_chain', 15, 1.0)],                                      # a single batch, 15 of 16 rows
+    'many': [(qt, 17 + i, 0.1 * (i + 1)) for i, qt in enumerate(
+        ['1-chain', '2-chain', '3-chain', '2-inter', '3-inter', '3-inter_chain', '3-chain_inter'] * 2)],   # 14 batches
+}
+
+
+@pytest.mark.parametrize('mix,D,readout,adaptive,L', [('tiny', 128, 'mp', True, 3), ('one', 64, 'max', False, 3),
+                                                      ('many', 64, 'mp', True, 3), ('tiny', 64, 'mp', False, 2),
+                                                      ('many', 128, 'mp', False, 2)])
+def test_fused_step_chain_edge_shapes(be, mix, D, readout, adaptive, L):
+    """Chain form at the edges: partial blocks (B < 16), one batch, 14 batches that share relation matrices
+    (reduction groups next to directly written matrices), and TM with fewer passes than the diameter (anchors
+    that cannot reach the target: dead at level 0, zero table gradient). The gradient buffers start as garbage
+    (MPQE_STEP_ZERO_GRADS), so every untouched matrix must come back zero."""
+    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(23, D, L, False, EDGE_MIXES[mix], readout,
+                                                                             adaptive)
+    ref_loss, ref_per, ref_sp, ref_sn = oracle_step(params, cfg, node_map, batches, 1.0)
+    got = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_ZERO_GRADS)
+    assert got[4] == 0
+    np.testing.assert_allclose(got[1], ref_sp, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got[2], ref_sn, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got[0][0], ref_loss, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got[0][1:], ref_per, rtol=1e-5, atol=1e-6)
+    for k, p in params.items():
+        ref = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
+        np.testing.assert_allclose(got[3][k], ref, rtol=1e-4, atol=2e-6, err_msg=k)
+
+
 @pytest.mark.parametrize('splits', [[0, 2, 5], [0, 1, 4, 5]])
 def test_fused_step_chain_with_stream_lanes(be, splits):
     """Chain form with lanes: every lane launches its own chain kernel and weight-gradient kernel; the result
