@@ -87,6 +87,7 @@ PROTOTYPES = {
     'mpqe_hinge_fwd': (I, [P, P, L, F, P, P]),
     'mpqe_hinge_bwd': (I, [P, P, L, F, P, P, P, P]),
     'mpqe_debug_chain_stamps': (None, [P, Z]),
+    'mpqe_debug_tail_stamps': (None, [P, Z]),
     'mpqe_sample_negatives': (I, [P, L, P, L, P, L, ctypes.c_uint64, P, P, P]),
     'mpqe_adam_step': (I, [P, P, P, P, L, DBL, DBL, DBL, DBL, DBL, L, P]),
     'mpqe_sgd_step': (I, [P, P, L, DBL, DBL, P]),

@@ -100,3 +100,4 @@ __device__ __forceinline__ void grad_w_tile_dma(const float *__restrict__ x, con
         *o = accumulate ? *o + acc[r] : acc[r];
     }
 }
+

@@ -600,6 +600,9 @@ __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, con
         }
     }
     if (MODE == LD_FAST)      // whole K-steps, D % 64 == 0: deep LDS-DMA pipeline
+        // (a form with NO LDS -- every MFMA operand one coalesced global_load_dword into its register, four
+        // register buffers -- measured slower: 32 dword loads per 16 MFMAs cost more issue time than the ring's
+        // four DMA pieces, a whole tile took 16.5 us against 14.5)
         grad_w_tile_dma(x, g, D, D, xs, xo, gs, go, q0, (int)((q1 - q0) / GT_BK), wk.i0, wk.j0, dst, smem,
                         direct && !zeroed);
     else
@@ -706,6 +709,7 @@ struct TailArgs {
     int nvsrc, vblocks;
     const int *anchor_off;
     int nb;
+    long long *stamps;       // diagnostics (mpqe_debug_tail_stamps): 4 words per workgroup, or NULL
     const ZMat *zmats;       // untouched gradient matrices, zero-filled by workgroups [wblocks, wblocks + zblocks)
     int zblocks, zper;       // zper = workgroups per matrix
     const long long *node_map;
@@ -721,6 +725,13 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
     // weight-gradient tiles only: the DMA ring takes 64 KB of LDS per workgroup, which would throttle the
     // thousands of light partial-sum / anchor workgroups to 2 per CU if they shared this kernel
     __shared__ __attribute__((aligned(16))) float smem[MODE == LD_FAST ? GWD_SMEM_FLOATS : GT_SMEM_FLOATS];
+#ifndef MPQE_EMU
+    if (ta.stamps && threadIdx.x == 0) {
+        ta.stamps[(long long)blockIdx.x * 4 + 0] = (long long)wall_clock64();
+        ta.stamps[(long long)blockIdx.x * 4 + 3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                                   ((long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+    }
+#endif
     if ((int)blockIdx.x >= ta.wblocks) {        // zero fill of a gradient matrix nobody writes (uniform branch)
         const int zb = (int)blockIdx.x - ta.wblocks;
         const ZMat zm = ta.zmats[zb / ta.zper];
@@ -738,6 +749,9 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
     }
     grad_w_block<MODE>(sd, ta.wsrc, ta.nwsrc, ta.wblock, H, GH, level_stride, ta.slabs, (int)blockIdx.x, ta.wblocks,
                        smem, gp, zeroed != 0);      // zeroed: this call zero-filled the gradients, a store suffices
+#ifndef MPQE_EMU
+    if (ta.stamps && threadIdx.x == 0) ta.stamps[(long long)blockIdx.x * 4 + 1] = (long long)wall_clock64();
+#endif
 }
 
 // bias / variable-row partial sums and anchor-table gradients: light, latency-bound roles in one launch
@@ -1472,6 +1486,12 @@ void make_key(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
 }  // namespace
 
 // diagnostics: phase time stamps of the chain kernel's workgroups (tools/chain_timeline.py)
+static long long *g_tail_stamps = nullptr;
+static size_t g_tail_stamp_blocks = 0;
+extern "C" void mpqe_debug_tail_stamps(void *device_buffer, size_t num_blocks) {
+    g_tail_stamps = reinterpret_cast<long long *>(device_buffer);
+    g_tail_stamp_blocks = num_blocks;
+}
 static long long *g_chain_stamps = nullptr;
 static size_t g_chain_stamp_blocks = 0;
 extern "C" void mpqe_debug_chain_stamps(void *device_buffer, size_t num_blocks) {
@@ -1703,11 +1723,13 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     ta.zmats = reinterpret_cast<const ZMat *>(db + hp.o_zmats);
     ta.zper = (int)(((long long)D * D + ZMAT_FLOATS_PER_BLOCK - 1) / ZMAT_FLOATS_PER_BLOCK);
     ta.zblocks = 0;
+    ta.stamps = nullptr;
     auto launch_grad_w = [&](hipStream_t on, int first, int count) {
         TailArgs tl = ta;
         tl.wblock = ta.wblock + first;
         tl.wblocks = count;
         if (first == 0 && (P->flags & MPQE_STEP_ZERO_GRADS)) tl.zblocks = (int)hp.zmats.size() * ta.zper;
+        tl.stamps = g_tail_stamps && (size_t)(count + tl.zblocks) <= g_tail_stamp_blocks ? g_tail_stamps : nullptr;
         if (count + tl.zblocks <= 0) return;
         dim3 tgrid((unsigned)(count + tl.zblocks));
         const int zeroed = (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0;

@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--readout', default='mp')
     ap.add_argument('--no-prune', action='store_true')
     ap.add_argument('--out', default='')
+    ap.add_argument('--tail', action='store_true', help='time stamps of the weight-gradient launch instead')
     ap.add_argument('--trace', action='store_true', help='CHAIN_DBG=6 builds: per-item cycle stamps of block 0')
     args = ap.parse_args()
     from mpqe_amd import ops, synthetic
@@ -50,6 +51,32 @@ def main():
     for _ in range(5):
         step.run(packed)
     torch.cuda.synchronize()
+    if args.tail:
+        tcap = 4096
+        tst = torch.zeros(tcap * 4, dtype=torch.int64, device=dev)
+        ops.lib().mpqe_debug_tail_stamps(tst.data_ptr(), tcap)
+        step.run(packed)
+        torch.cuda.synchronize()
+        ops.lib().mpqe_debug_tail_stamps(None, 0)
+        tt = tst.cpu().numpy().reshape(tcap, 4)
+        tt = tt[tt[:, 0] != 0]
+        t0 = tt[:, 0].min()
+        start, end = (tt[:, 0] - t0) * 0.01, (tt[:, 1] - t0) * 0.01
+        gw = tt[:, 1] != 0
+        hw, xcc = tt[:, 3] & 0xffffffff, (tt[:, 3] >> 32) & 0xf
+        place = xcc * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 0xf)
+        dur = end[gw] - start[gw]
+        print('weight-gradient launch: %d workgroups (%d tiles, %d zero-fill), tiles: start %.1f..%.1f us, duration mean '
+              '%.1f min %.1f max %.1f, last end %.1f us' % (len(tt), gw.sum(), (~gw).sum(), start[gw].min(),
+                                                            start[gw].max(), dur.mean(), dur.min(), dur.max(), end[gw].max()))
+        order = np.argsort(-end[gw])[:8]
+        for k in order:
+            i = np.nonzero(gw)[0][k]
+            print('   block %4d  start %5.1f  dur %5.1f  end %5.1f  on-CU mates %d' % (i, start[i], end[i] - start[i], end[i],
+                                                                                     int((place[gw] == place[i]).sum())))
+        hist = np.histogram(dur, bins=[0, 4, 6, 8, 10, 12, 14, 16, 20, 30])
+        print('   duration histogram (us):', list(zip(hist[1][:-1].tolist(), hist[0].tolist())))
+        return
     cap = 16 * sum((b + 15) // 16 for b in packed.sizes)     # the launch grid has holes (placement by XCD)
     stamps = torch.zeros(cap * 8, dtype=torch.int64, device=dev)
     ops.lib().mpqe_debug_chain_stamps(stamps.data_ptr(), cap)
