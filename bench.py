@@ -46,7 +46,8 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--path', default='auto', choices=['auto', 'modules', 'fused'])
     ap.add_argument('--lanes', type=int, default=1, help='HIP streams one fused step is spread over')
-    ap.add_argument('--graph', type=int, default=0, help='1: replay each step from a captured hipGraph')
+    ap.add_argument('--graph', type=int, default=0,
+                    help='1: replay each step from a captured hipGraph (level form only: needs --no-chain)')
     ap.add_argument('--no-prune', action='store_true', help='compute node states that cannot reach the readout too')
     ap.add_argument('--no-chain', action='store_true', help='one launch per message-passing level')
     ap.add_argument('--no-ksplit', action='store_true', help='dim 128: chain waves own 32 columns and all of K')
@@ -361,6 +362,9 @@ def main():
     pool = [StepData(schema, model, args.batch_size, rng, device) for _ in range(4)]
 
     use_fused = args.path in ('auto', 'fused') and args.readout in ('mp', 'sum', 'max')
+    if args.graph and not args.no_chain:
+        raise SystemExit('--graph 1 needs --no-chain: replaying the captured chain form faulted on this stack '
+                         '(mpqe_amd/fused.py: capture)')
     reducer = fstep = packed = captured = None
     if use_fused:
         from mpqe_amd.fused import FusedTrainStep
