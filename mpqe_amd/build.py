@@ -19,6 +19,10 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result',
          '-I' + os.path.join(ROOT, 'include')]
+# per-source extras. step.hip: MFMA accumulators in VGPRs (gfx90a+ allows it; 167 VGPRs leave the room) -- with
+# AGPR accumulators hipcc rotates the chain kernel's 16 accumulator registers through VGPRs at the top of
+# every K-loop item and reads them back one by one in every node-update epilogue
+EXTRA = {'step.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
 
 
 def _stale(target, deps):
@@ -41,8 +45,8 @@ def build(force=False, verbose=False):
     for s in srcs:
         o = os.path.join(OBJ_DIR, os.path.basename(s)[:-4] + '.o')
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            jobs.append([HIPCC] + FLAGS + ['-c', s, '-o', o])
+        if force or _stale(o, [s, os.path.abspath(__file__)] + hdrs):
+            jobs.append([HIPCC] + FLAGS + EXTRA.get(os.path.basename(s), []) + ['-c', s, '-o', o])
 
     def run(cmd):
         if verbose:

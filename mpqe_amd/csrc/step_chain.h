@@ -18,6 +18,7 @@
 // which loads its slice straight into registers one half-block (64 k) ahead of the MFMAs that use it.
 // Included by step.hip after StepDev / BatchDev / LayerPtrs / TablePtrs / pick_layer / table_row.
 #pragma once
+#include <type_traits>
 #include "gemm_core.h"
 
 #define CH_GB 16
@@ -82,6 +83,42 @@ __device__ __forceinline__ void chain_store(float *p, const float (&v)[NCB]) {
         for (int c = 0; c < NCB; ++c) q[c] = v[c];
     }
     *reinterpret_cast<typename chain_vec<NCB>::type *>(p) = q;
+}
+
+template <int NCB>
+__device__ __forceinline__ void chain_lload(float (&d)[NCB], const float *p) {
+    const typename chain_vec<NCB>::type q = *reinterpret_cast<const typename chain_vec<NCB>::type *>(p);
+    if constexpr (NCB == 1) d[0] = q;
+    else {
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) d[c] = q[c];
+    }
+}
+// ReLU of one output value + its mask bit, and the masking of one gradient value by that bit, at two VALU
+// instructions each: the bits of a lane's 4 x NCB values travel through the carry flag (forward: shifted
+// in at the bottom, first value ends up highest; backward: shifted out at the top, same order).
+// hipcc's own code for `v > 0 ? v : 0` plus `bits |= (v > 0) << n` is 4 - 5 instructions per value, and a
+// wave64 VALU instruction is 4 cycles: the node-update epilogue is instruction bound.
+__device__ __forceinline__ void chain_relu_push(float &v, unsigned &bits) {
+#ifdef MPQE_EMU
+    const bool p = v > 0.f;
+    v = p ? v : 0.f;
+    bits = (bits << 1) | (p ? 1u : 0u);
+#else
+    asm volatile("v_cmp_lt_f32 vcc, 0, %0\n\tv_cndmask_b32 %0, 0, %0, vcc\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
+                 : "+v"(v), "+v"(bits)
+                 :
+                 : "vcc");
+#endif
+}
+__device__ __forceinline__ void chain_mask_pop(float &v, unsigned &bits) {
+#ifdef MPQE_EMU
+    const bool p = (bits >> 31) != 0u;
+    bits <<= 1;
+    v = p ? v : 0.f;
+#else
+    asm volatile("v_add_co_u32 %1, vcc, %1, %1\n\tv_cndmask_b32 %0, 0, %0, vcc" : "+v"(v), "+v"(bits) : : "vcc");
+#endif
 }
 
 // B[k][n] = M[k][n] with M row-major: forward M = W, backward-x M = W^T (a transposed copy made by
@@ -180,7 +217,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS> &S, const int first_
     const int ks = wave / CW;                            // which part of K this wave multiplies
     const int kbase = ks * (D / KS);
     const int colb = (wave % CW) * 16 * NCB + NCB * j;   // this lane's NCB adjacent columns
-    const bool finisher = ks == KS - 1;
+    const bool finisher = __builtin_amdgcn_readfirstlane(ks) == KS - 1;      // (a scalar: real branches, not exec masks)
     auto get_op = [&](int it) -> ChainStep {
         const int k = first_op + (it < T ? it : T - 1) / IPO;
         const int w = __builtin_amdgcn_readfirstlane(S.opw[k][0]);
@@ -208,7 +245,10 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS> &S, const int first_
     float bs[NCB];          // backward: column sums of this level's gradient rows (bias gradient of the pass below)
 #pragma unroll
     for (int c = 0; c < NCB; ++c) bs[c] = 0.f;
-    auto item = [&](const ChainStep &op, int it, const WHalf<NCB> &f, WHalf<NCB> &fn, const float *wn) {
+    // (f and fn may be ONE buffer: every group of NCB MFMAs is then followed by the load that refills the registers
+    // it has just read with the next item's weights)
+    auto item = [&](const ChainStep &op, int it, WHalf<NCB> &f, WHalf<NCB> &fn, const float *wn, auto inplace_tag) {
+        constexpr bool INPLACE = decltype(inplace_tag)::value;
         const int h = it % IPO;
 #if CHAIN_DBG == 6
 #define CHAIN_TRACE(tag)                                                                        \
@@ -235,7 +275,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS> &S, const int first_
             const f32x4 a = av[t];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (CHAIN_DBG != 1) chain_gload<NCB>(fn.v[t][u], wn + (long long)(16 * t + u) * D);
+                if (CHAIN_DBG != 1 && !INPLACE) chain_gload<NCB>(fn.v[t][u], wn + (long long)(16 * t + u) * D);
                 __builtin_amdgcn_sched_barrier(0);
 #if CHAIN_DBG == 2
 #pragma unroll
@@ -246,97 +286,126 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS> &S, const int first_
                     acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], f.v[t][u][c], acc[c], 0, 0, 0);
 #endif
                 __builtin_amdgcn_sched_barrier(0);
+                if (CHAIN_DBG != 1 && INPLACE) {
+                    chain_gload<NCB>(f.v[t][u], wn + (long long)(16 * t + u) * D);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         CHAIN_TRACE(1)
         if (h != IPO - 1) return;
-        if ((op.flags & CH_LAST) && KS > 1) {
-            // K split: the waves of the other K parts hand their partial sums over through the node's LDS output
-            // tile (nobody reads it before the level ends), one part per barrier; the last part's waves finish
+        if (op.flags & CH_LAST) {
+            static_assert(KS <= 2, "the hand-off below is written for two K parts");
+            // K split: the first K part's waves park their partial sums in the node's LDS output tile (nobody
+            // reads it before the level ends); the last part's waves pick them up behind the barrier and finish
             float *Xn = S.xs + (cur ^ 1) * BUF;
-#pragma unroll
-            for (int part = 0; part + 1 < KS; ++part) {
-                if (ks == part) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v[NCB];
-#pragma unroll
-                        for (int c = 0; c < NCB; ++c) v[c] = acc[c][r];
-                        float *l = Xn + (op.node * CH_GB + 4 * kq + r) * LDX + colb;
-                        if (part > 0) {
-#pragma unroll
-                            for (int c = 0; c < NCB; ++c) v[c] += l[c];
-                        }
-                        chain_store<NCB>(l, v);
-                    }
-#pragma unroll
-                    for (int c = 0; c < NCB; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-                __syncthreads();
-            }
-            if (finisher) {
+            float *tile = Xn + (op.node * CH_GB + 4 * kq) * LDX + colb;     // this lane's 4 rows x NCB columns
+            if (KS > 1 && !finisher) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float *l = Xn + (op.node * CH_GB + 4 * kq + r) * LDX + colb;
+                    float pv[NCB];
 #pragma unroll
-                    for (int c = 0; c < NCB; ++c) acc[c][r] += l[c];
+                    for (int c = 0; c < NCB; ++c) pv[c] = acc[c][r];
+                    chain_store<NCB>(tile + r * LDX, pv);
                 }
             }
-        }
-        CHAIN_TRACE(2)
-        if ((op.flags & CH_LAST) && finisher) {
-            float *Xn = S.xs + (cur ^ 1) * BUF;
-            float *Xout = Xrows + (long long)op.level * level_stride;
-            const int mslot = ((op.level - 1) * 4 + op.node) * MT + (threadIdx.x & (MT - 1));   // levels 1 .. L-1
-            unsigned bits = 0;
-            if (BWD && (op.flags & CH_MASK)) bits = S.mbits[mslot];
+            float v[4][NCB];
             float bv[NCB];
+            if (finisher) {
 #pragma unroll
-            for (int c = 0; c < NCB; ++c) bv[c] = BWD ? 0.f : S.bias[op.layer * D + colb + c];
-            unsigned out_bits = 0;
-            float ns[NCB];          // this node's column sums over the block's graphs (backward)
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < NCB; ++c) ns[c] = 0.f;
+                    for (int c = 0; c < NCB; ++c) v[r][c] = acc[c][r];
+                if (!BWD) chain_lload<NCB>(bv, S.bias + op.layer * D + colb);
+            }
+            if (KS > 1) __syncthreads();
+            CHAIN_TRACE(2)
+            // MODE 0: plain, 1: ReLU + record the mask bits, 2: mask by the recorded bits. One straight-line
+            // body per mode (a shared tail makes hipcc copy the 16 values around the inline asm)
+            auto finish = [&](auto mode_tag) {
+                constexpr int MODE = decltype(mode_tag)::value;
+                if (KS > 1) {
+                    float l[4][NCB];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 4 * kq + r;
-                float v[NCB];
+                    for (int r = 0; r < 4; ++r) chain_lload<NCB>(l[r], tile + r * LDX);
 #pragma unroll
-                for (int c = 0; c < NCB; ++c) {
-                    v[c] = acc[c][r];
-                    if (!BWD) {
-                        v[c] += bv[c];
-                        if (op.flags & CH_RELU) {
-                            v[c] = v[c] > 0.f ? v[c] : 0.f;
-                            out_bits |= (v[c] > 0.f ? 1u : 0u) << (r * NCB + c);
-                        }
-                    } else if (op.flags & CH_MASK) {
-                        v[c] = (bits >> (r * NCB + c)) & 1u ? v[c] : 0.f;
-                    }
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < NCB; ++c) v[r][c] += l[r][c];
                 }
-                chain_store<NCB>(Xn + (op.node * CH_GB + row) * LDX + colb, v);
-                if (row < ng) {
-                    if (!(op.flags & CH_NOSTORE)) chain_store<NCB>(Xout + ((long long)row * N + op.node) * D + colb, v);
+                CHAIN_TRACE(4)
+                const int mslot = ((op.level - 1) * 4 + op.node) * MT + (threadIdx.x & (MT - 1));   // levels 1 .. L-1
+                if (!BWD) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < NCB; ++c) v[r][c] += bv[c];
+                }
+                if (MODE == 1) {
+                    unsigned bits = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < NCB; ++c) chain_relu_push(v[r][c], bits);
+                    S.mbits[mslot] = (typename chain_bits<NCB>::type)bits;
+                } else if (MODE == 2) {
+                    unsigned bits = (unsigned)S.mbits[mslot] << (32 - 4 * NCB);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < NCB; ++c) chain_mask_pop(v[r][c], bits);
+                }
+                CHAIN_TRACE(5)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) chain_store<NCB>(tile + r * LDX, v[r]);
+                CHAIN_TRACE(6)
+                // a variable row of gH[0]: its sum over the block's graphs is a mode-embedding gradient partial
+                // (level 0 has no bias gradient to collect: bs is free to hold the node's own sums)
+                const bool var_row = BWD && op.level == 0 && op.node >= A && var_part[op.node - A] >= 0;
+                if (var_row) {
+#pragma unroll
+                    for (int c = 0; c < NCB; ++c) bs[c] = 0.f;
+                }
+                float *Xout = Xrows + (long long)op.level * level_stride + ((long long)(4 * kq) * N + op.node) * D + colb;
+                if (ng == CH_GB) {          // (all but a batch's last block)
+                    if (!(op.flags & CH_NOSTORE)) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) chain_store<NCB>(Xout + (long long)r * N * D, v[r]);
+                    }
                     if (BWD) {
 #pragma unroll
-                        for (int c = 0; c < NCB; ++c) {
-                            bs[c] += v[c];
-                            ns[c] += v[c];
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int c = 0; c < NCB; ++c) bs[c] += v[r][c];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (4 * kq + r < ng) {
+                            if (!(op.flags & CH_NOSTORE)) chain_store<NCB>(Xout + (long long)r * N * D, v[r]);
+                            if (BWD) {
+#pragma unroll
+                                for (int c = 0; c < NCB; ++c) bs[c] += v[r][c];
+                            }
                         }
                     }
                 }
-            }
-            if (BWD && op.level == 0 && op.node >= A && var_part[op.node - A] >= 0) {
-                // a variable row of gH[0]: its sum over the block's graphs is a mode-embedding gradient partial
-                float t[NCB];
+                CHAIN_TRACE(7)
+                if (var_row) {
+                    float t[NCB];
 #pragma unroll
-                for (int c = 0; c < NCB; ++c) {
-                    t[c] = ns[c] + __shfl_xor(ns[c], 16, 64);
-                    t[c] += __shfl_xor(t[c], 32, 64);
+                    for (int c = 0; c < NCB; ++c) {
+                        t[c] = bs[c] + __shfl_xor(bs[c], 16, 64);
+                        t[c] += __shfl_xor(t[c], 32, 64);
+                    }
+                    if (kq == 0) chain_store<NCB>(parts + (long long)(var_part[op.node - A] + blk) * D + colb, t);
                 }
-                if (kq == 0) chain_store<NCB>(parts + (long long)(var_part[op.node - A] + blk) * D + colb, t);   // (finisher)
+            };
+            if (finisher) {
+                if (!BWD && (op.flags & CH_RELU)) finish(std::integral_constant<int, 1>());
+                else if (BWD && (op.flags & CH_MASK)) finish(std::integral_constant<int, 2>());
+                else finish(std::integral_constant<int, 0>());
             }
-            if (!BWD && (op.flags & CH_RELU)) S.mbits[mslot] = (typename chain_bits<NCB>::type)out_bits;
             // the next node update starts from zero (cleared here, inside the uniform branch, rather than by a
             // select at the top of every item: that select made hipcc park the accumulators in registers of
             // a load buffer whose loads were still in flight, and wait for them)
@@ -371,25 +440,25 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS> &S, const int first_
     ChainStep oc = get_op(0), on = get_op(1);       // ops of items it, it + 1
     int it = 0;
     if constexpr (NCB == 4 && KS == 2 && CHAIN_DBG != 5) {
-        // 64 registers per buffer and two workgroups per CU: two buffers; an item is 64 MFMAs (2048 cycles), so one
-        // item of distance covers what two cover in the other forms
-        WHalf<NCB> f0, f1;
+        // 64 registers of weights, ONE buffer refilled in place: a register is reloaded with the next item's value
+        // right behind the MFMAs that read it, so every load has exactly one item (64 MFMAs, 2048 cycles) to land,
+        // no register of the buffer is ever dead (hipcc put temporaries into the dead registers of a second
+        // buffer and then waited for the loads refilling it), and the K loop is one item long
+        WHalf<NCB> f0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) chain_load_t<NCB>(f0, wptr(0), D, t);
         __builtin_amdgcn_sched_barrier(0);
-#define CHAIN_STEP(F, FN)                       \
-    {                                           \
-        const ChainStep o2_ = get_op(it + 2);   \
-        item(oc, it, F, FN, wptr(it + 1));      \
-        if (++it >= T) break;                   \
-        oc = on;                                \
-        on = o2_;                               \
-    }
+        // (the matrix pointer of the next item's prefetch is read from LDS one item early, like the ops)
+        const float *wn1 = wptr(1);
         while (true) {
-            CHAIN_STEP(f0, f1)
-            CHAIN_STEP(f1, f0)
+            const ChainStep o2_ = get_op(it + 2);
+            const float *w2_ = wptr(it + 2);
+            item(oc, it, f0, f0, wn1, std::true_type());
+            if (++it >= T) break;
+            oc = on;
+            on = o2_;
+            wn1 = w2_;
         }
-#undef CHAIN_STEP
     } else if constexpr (NCB <= 2) {
         WHalf<NCB> f0, f1, f2, f3;
 #pragma unroll
@@ -402,7 +471,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS> &S, const int first_
 #define CHAIN_STEP(F, FN)                       \
     {                                           \
         const ChainStep o2_ = get_op(it + 2);   \
-        item(oc, it, F, FN, wptr(it + 3));      \
+        item(oc, it, F, FN, wptr(it + 3), std::false_type());      \
         if (++it >= T) break;                   \
         oc = on;                                \
         on = o2_;                               \
@@ -424,7 +493,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS> &S, const int first_
 #define CHAIN_STEP(F, FN)                       \
     {                                           \
         const ChainStep o2_ = get_op(it + 2);   \
-        item(oc, it, F, FN, wptr(it + 2));      \
+        item(oc, it, F, FN, wptr(it + 2), std::false_type());      \
         if (++it >= T) break;                   \
         oc = on;                                \
         on = o2_;                               \
@@ -612,6 +681,18 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     __syncthreads();
 
     chain_stamp(ca, 2);
+    // the + and - target rows of the score phase are requested NOW (16 lanes per graph: lane group g of wave w
+    // takes graph 4 w + g, lane s of the group the columns s + 16 cc) and ride through the forward levels in
+    // registers: their HBM round trip would otherwise sit between the two K loops
+    constexpr int CC = D / 16;
+    const int sc_i = 4 * wave + (lane >> 4), sl = lane & 15;
+    const float *pp_ = S.rowp[4 * CH_GB + sc_i], *pn_ = S.rowp[5 * CH_GB + sc_i];
+    float tp[CC], tn[CC];
+#pragma unroll
+    for (int cc = 0; cc < CC; ++cc) {
+        tp[cc] = pp_ ? gload1(pp_ + sl + 16 * cc) : 0.f;
+        tn[cc] = pn_ ? gload1(pn_ + sl + 16 * cc) : 0.f;
+    }
     // ---- forward levels
     int cur = 0;
     chain_run<NCB, KS, false>(S, 0, ref.fwd_count * IPO, N, ng, ca.H + row0 * D, ca.level_stride, cur);
@@ -619,27 +700,18 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     chain_stamp(ca, 3);
     // ---- readout, cosine scores against the + and - target, hinge terms (reference model.py:447-462,
     // 483-485); backward: d hinge -> d cosine -> d readout written over H[L] in LDS (a lane group owns whole
-    // graphs) and to gH[L]; target-table gradients through the normalisation. 16 lanes per graph: lane group
-    // g of wave w takes graph 4 w + g, lane s of the group the columns s + 16 cc.
+    // graphs) and to gH[L]; target-table gradients through the normalisation. 16 lanes per graph (see above).
     {
-        constexpr int CC = D / 16;
         float *Xc = S.xs + cur * BUF;
         float *GL = ca.GH + (long long)L * ca.level_stride + row0 * D;
-        const int i = 4 * wave + (lane >> 4), sl = lane & 15;
+        const int i = sc_i;
         const bool on = i < ng;
-        const float *pp_ = S.rowp[4 * CH_GB + i], *pn_ = S.rowp[5 * CH_GB + i];
         const int readout = sd->readout;
         auto gsum = [](float v) {
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
             return v;
         };
-        float tp[CC], tn[CC];
-#pragma unroll
-        for (int cc = 0; cc < CC; ++cc) {                 // both target rows of the group's graph in flight at once
-            tp[cc] = pp_ ? gload1(pp_ + sl + 16 * cc) : 0.f;
-            tn[cc] = pn_ ? gload1(pn_ + sl + 16 * cc) : 0.f;
-        }
         const float *h = Xc + i * LDX;                    // node n at h + n * CH_GB * LDX
         float q[CC];
         int arg[CC];

@@ -94,7 +94,8 @@ def main():
     used = np.nonzero(st[:, 6] != 0)[0]
     if args.trace:
         tr = trace_words.reshape(2, 2, 2048)                                 # [tracing wave][fwd / bwd][entry]
-        names = {0: 'item start', 1: 'mfma done', 2: 'handoff done', 3: 'epilogue done'}
+        names = {0: 'item start', 1: 'mfma done', 2: 'handoff done', 3: 'epilogue done', 4: 'partials added',
+                 5: 'transformed', 6: 'tile stored', 7: 'rows stored'}
         for w in range(2):
             for d, dn in enumerate(('fwd', 'bwd')):
                 v = tr[w, d]
@@ -104,6 +105,8 @@ def main():
                 t, tag = v >> 3, v & 7
                 print('wave %d (%s K part) %s: %d stamps, %d cycles total' % (2 * w, 'first' if w == 0 else 'last', dn,
                                                                               len(v), t[-1] - t[0]))
+                print('    sequence (tag:cycles since the previous stamp): '
+                      + ' '.join('%d:%d' % (int(tag[k]), int(t[k] - t[k - 1])) for k in range(1, len(v))))
                 seg = {}
                 for k in range(1, len(v)):
                     key = '%s -> %s' % (names[int(tag[k - 1])], names[int(tag[k])])
