@@ -330,8 +330,9 @@ int mpqe_sample_negatives(const int64_t *cand, int64_t n_cand, const int64_t *of
  * launch of G workgroups also writes its shader-clock ticks at the first / last stamp to words 0 / 1 of entry
  * G + g, so 2 G <= num_blocks is required. NULL turns it off. Process-global; tools/chain_timeline.py only. */
 void mpqe_debug_chain_stamps(void *device_buffer, size_t num_blocks);
-/* The same for the weight-gradient launch: 4 int64 per workgroup: wall clock at start [0] and end [1], HW_ID |
- * XCC_ID << 32 in [3].                                                                               */
+/* The same for the weight-gradient launch: 8 int64 per workgroup: wall clock at start [0] and end [1], shader-clock
+ * ticks start -> end [2], HW_ID | XCC_ID << 32 in [3], wall clock when the tile's record is read [4], when its first
+ * K-step has landed [5] and when its K loop ends [6].                                                */
 void mpqe_debug_tail_stamps(void *device_buffer, size_t num_blocks);
 
 #ifdef __cplusplus

@@ -37,8 +37,15 @@ typedef void __attribute__((address_space(3))) * gwd_lptr;
 __device__ __forceinline__ void grad_w_tile_dma(const float *__restrict__ x, const float *__restrict__ g, int Din,
                                                 int Dout, long long xs, long long xo, long long gs, long long go,
                                                 long long q0, int nsteps, int i0, int j0,
-                                                float *__restrict__ slab, float *smem, bool accumulate = false) {
+                                                float *__restrict__ slab, float *smem, bool accumulate = false,
+                                                long long *dbg = nullptr) {
     const int t = threadIdx.x;
+#ifndef MPQE_EMU      // diagnostics (mpqe_debug_tail_stamps): wall clock at the tile's phase boundaries
+#define GWD_STAMP(slot) if (dbg && t == 0) dbg[slot] = (long long)wall_clock64();
+#else
+#define GWD_STAMP(slot)
+#endif
+    GWD_STAMP(4)
     const int lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int i = lane & 31, h = lane >> 5;
@@ -76,6 +83,7 @@ __device__ __forceinline__ void grad_w_tile_dma(const float *__restrict__ x, con
     for (int s = 0; s < GWD_STAGES - 1; ++s) issue(s);
     for (int s = 0; s < nsteps; ++s) {
         __builtin_amdgcn_s_waitcnt(GWD_VMCNT(4 * (GWD_STAGES - 2)));
+        if (s == 0) GWD_STAMP(5)
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -92,6 +100,7 @@ __device__ __forceinline__ void grad_w_tile_dma(const float *__restrict__ x, con
     }
     // drain the surplus tail loads before the LDS can be reused by anyone
     __builtin_amdgcn_s_waitcnt(GWD_VMCNT(0));
+    GWD_STAMP(6)
     const int col = j0 + acc_col();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

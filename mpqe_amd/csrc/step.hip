@@ -571,7 +571,8 @@ __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, con
                                              int nsrc, const WBlock *__restrict__ block_start,
                                              const float *__restrict__ H, const float *__restrict__ GH,
                                              long long level_stride, float *__restrict__ slabs, int bid,
-                                             int wblocks_total, float *smem, const GradPtrs &gp, bool zeroed) {
+                                             int wblocks_total, float *smem, const GradPtrs &gp, bool zeroed,
+                                             long long *dbg = nullptr) {
     const int D = sd->D;
     const int tiles_j = (D + GT_BN - 1) / GT_BN, tiles = tiles_j * ((D + GT_BM - 1) / GT_BM);
     // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2: blocks b and b+8 share
@@ -604,7 +605,7 @@ __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, con
         // register buffers -- measured slower: 32 dword loads per 16 MFMAs cost more issue time than the ring's
         // four DMA pieces, a whole tile took 16.5 us against 14.5)
         grad_w_tile_dma(x, g, D, D, xs, xo, gs, go, q0, (int)((q1 - q0) / GT_BK), wk.i0, wk.j0, dst, smem,
-                        direct && !zeroed);
+                        direct && !zeroed, dbg);
     else
         tmpl_grad_w_tile<MODE>(x, g, out, D, D, 0, xs, xo, gs, go, q0, q1, wk.i0, wk.j0, dst, smem, direct && !zeroed);
 }
@@ -709,7 +710,7 @@ struct TailArgs {
     int nvsrc, vblocks;
     const int *anchor_off;
     int nb;
-    long long *stamps;       // diagnostics (mpqe_debug_tail_stamps): 4 words per workgroup, or NULL
+    long long *stamps;       // diagnostics (mpqe_debug_tail_stamps): 8 words per workgroup, or NULL
     const ZMat *zmats;       // untouched gradient matrices, zero-filled by workgroups [wblocks, wblocks + zblocks)
     int zblocks, zper;       // zper = workgroups per matrix
     const long long *node_map;
@@ -726,9 +727,11 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
     // thousands of light partial-sum / anchor workgroups to 2 per CU if they shared this kernel
     __shared__ __attribute__((aligned(16))) float smem[MODE == LD_FAST ? GWD_SMEM_FLOATS : GT_SMEM_FLOATS];
 #ifndef MPQE_EMU
+    long long tick0 = 0;
     if (ta.stamps && threadIdx.x == 0) {
-        ta.stamps[(long long)blockIdx.x * 4 + 0] = (long long)wall_clock64();
-        ta.stamps[(long long)blockIdx.x * 4 + 3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+        tick0 = (long long)__builtin_amdgcn_s_memtime();        // shader-clock ticks: word 2 = ticks start -> end
+        ta.stamps[(long long)blockIdx.x * 8 + 0] = (long long)wall_clock64();
+        ta.stamps[(long long)blockIdx.x * 8 + 3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
                                                    ((long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
     }
 #endif
@@ -748,9 +751,12 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
         return;
     }
     grad_w_block<MODE>(sd, ta.wsrc, ta.nwsrc, ta.wblock, H, GH, level_stride, ta.slabs, (int)blockIdx.x, ta.wblocks,
-                       smem, gp, zeroed != 0);      // zeroed: this call zero-filled the gradients, a store suffices
+                       smem, gp, zeroed != 0, ta.stamps ? ta.stamps + (long long)blockIdx.x * 8 : nullptr);      // zeroed: this call zero-filled the gradients, a store suffices
 #ifndef MPQE_EMU
-    if (ta.stamps && threadIdx.x == 0) ta.stamps[(long long)blockIdx.x * 4 + 1] = (long long)wall_clock64();
+    if (ta.stamps && threadIdx.x == 0) {
+        ta.stamps[(long long)blockIdx.x * 8 + 1] = (long long)wall_clock64();
+        ta.stamps[(long long)blockIdx.x * 8 + 2] = (long long)__builtin_amdgcn_s_memtime() - tick0;
+    }
 #endif
 }
 

@@ -135,7 +135,9 @@ static inline void __builtin_amdgcn_global_load_lds(const void __attribute__((ad
     char *dst = (char *)(void *)l + (threadIdx.x & 63) * size;
     memcpy(dst, src, size);
 }
-static inline void __builtin_amdgcn_s_waitcnt(int) {}
+// a wave runs in lockstep on the hardware: when its s_waitcnt returns, every lane's loads (LDS-DMA pieces included)
+// have landed. The fibers of a wave meet here (all call sites are wave-uniform).
+static inline void __builtin_amdgcn_s_waitcnt(int) { (void)emu::wave_exchange(0.f, 0, 0, 64); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_s_barrier() { emu::block_barrier(); }
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }

@@ -53,12 +53,12 @@ def main():
     torch.cuda.synchronize()
     if args.tail:
         tcap = 4096
-        tst = torch.zeros(tcap * 4, dtype=torch.int64, device=dev)
+        tst = torch.zeros(tcap * 8, dtype=torch.int64, device=dev)
         ops.lib().mpqe_debug_tail_stamps(tst.data_ptr(), tcap)
         step.run(packed)
         torch.cuda.synchronize()
         ops.lib().mpqe_debug_tail_stamps(None, 0)
-        tt = tst.cpu().numpy().reshape(tcap, 4)
+        tt = tst.cpu().numpy().reshape(tcap, 8)
         tt = tt[tt[:, 0] != 0]
         t0 = tt[:, 0].min()
         start, end = (tt[:, 0] - t0) * 0.01, (tt[:, 1] - t0) * 0.01
@@ -69,6 +69,11 @@ def main():
         print('weight-gradient launch: %d workgroups (%d tiles, %d zero-fill), tiles: start %.1f..%.1f us, duration mean '
               '%.1f min %.1f max %.1f, last end %.1f us' % (len(tt), gw.sum(), (~gw).sum(), start[gw].min(),
                                                             start[gw].max(), dur.mean(), dur.min(), dur.max(), end[gw].max()))
+        mhz = tt[gw, 2] / np.maximum(dur, 1e-3)
+        print('   shader clock while the tiles ran: mean %.0f MHz (min %.0f, max %.0f)' % (mhz.mean(), mhz.min(), mhz.max()))
+        ph = (tt[gw][:, [4, 5, 6, 1]] - tt[gw][:, [0, 4, 5, 6]]) * 0.01
+        print('   tile phases, mean us: record %.1f, first K-step landed %.1f, K loop %.1f, stores %.1f'
+              % tuple(ph.mean(axis=0)))
         order = np.argsort(-end[gw])[:8]
         for k in order:
             i = np.nonzero(gw)[0][k]
