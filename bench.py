@@ -51,6 +51,7 @@ def parse():
     ap.add_argument('--no-prune', action='store_true', help='compute node states that cannot reach the readout too')
     ap.add_argument('--no-chain', action='store_true', help='one launch per message-passing level')
     ap.add_argument('--no-ksplit', action='store_true', help='dim 128: chain waves own 32 columns and all of K')
+    ap.add_argument('--eight-waves', action='store_true', help='dim 128: chain workgroups of eight waves (experimental)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='nccl = RCCL over xGMI (the real path); gloo only to exercise the multi-rank code on one GPU')
     return ap.parse_args()
@@ -369,7 +370,7 @@ def main():
     if use_fused:
         from mpqe_amd.fused import FusedTrainStep
         fstep = FusedTrainStep(model, lanes=args.lanes, prune=not args.no_prune, chain=not args.no_chain,
-                               ksplit=not args.no_ksplit)
+                               ksplit=not args.no_ksplit, eight_waves=args.eight_waves)
         packed = [pack_for_fused(fstep, d, 1.0 / world) for d in pool]
         captured = [fstep.capture(p) for p in packed] if args.graph else None
     elif world > 1:

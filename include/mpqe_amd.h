@@ -223,6 +223,9 @@ int mpqe_hinge_bwd(const float *pos, const float *neg, int64_t n, float margin, 
 /* NO_KSPLIT   dim 128 only: the chain kernel's waves each own 32 columns and the whole K range (the first form)
  *             instead of 64 columns and half of K.                                                     */
 #define MPQE_STEP_NO_KSPLIT 8
+/* EIGHT_WAVES dim 128 only, experimental: chain workgroups of eight waves (a wave of each K half on every SIMD, 32
+ *             columns each) instead of four. Same results; measured 1 % slower on the AIFB mix.  */
+#define MPQE_STEP_EIGHT_WAVES 16
 
 typedef struct {
     int32_t query_type;        /* MPQE_Q_*                                                     */

@@ -131,7 +131,7 @@ def check(cdll, status, what):
         raise MpqeError('%s failed: %s (%d)' % (what, msg.decode() if msg else '?', status))
 
 
-STEP_NO_PRUNE, STEP_NO_CHAIN, STEP_ZERO_GRADS, STEP_NO_KSPLIT = 1, 2, 4, 8
+STEP_NO_PRUNE, STEP_NO_CHAIN, STEP_ZERO_GRADS, STEP_NO_KSPLIT, STEP_EIGHT_WAVES = 1, 2, 4, 8, 16
 
 
 def make_step_params(dim, num_relations, readout, table_ptrs, table_rows, node_map_ptr, node_map_len,

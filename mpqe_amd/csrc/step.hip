@@ -174,11 +174,11 @@ __device__ __forceinline__ long long table_row(const long long *__restrict__ nod
 
 #include "step_chain.h"
 
-template <int NCB, int KS>
-__global__ __launch_bounds__(256) void step_chain_kernel(const StepDev *__restrict__ sd, LayerPtrs lp, TablePtrs tabs,
-                                                         ChainArgs ca) {
-    __shared__ __attribute__((aligned(16))) ChainLds<NCB, KS> S;
-    chain_block<NCB, KS>(sd, lp, tabs, ca, S);
+template <int NCB, int KS, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void step_chain_kernel(const StepDev *__restrict__ sd, LayerPtrs lp,
+                                                             TablePtrs tabs, ChainArgs ca) {
+    __shared__ __attribute__((aligned(16))) ChainLds<NCB, KS, NW> S;
+    chain_block<NCB, KS, NW>(sd, lp, tabs, ca, S);
 }
 
 // Step prologue, one launch: (a) transposed copies of the matrices the backward chains multiply by (32x32
@@ -1468,7 +1468,7 @@ void make_key(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
               PlanKey *k) {
     memset(k, 0, sizeof(*k));
     k->dim = P->dim; k->num_layers = P->num_layers; k->num_relations = P->num_relations;
-    k->num_modes = P->num_modes; k->readout = P->readout; k->flags = P->flags & ~(MPQE_STEP_ZERO_GRADS | MPQE_STEP_NO_KSPLIT); k->nb = nb;
+    k->num_modes = P->num_modes; k->readout = P->readout; k->flags = P->flags & ~(MPQE_STEP_ZERO_GRADS | MPQE_STEP_NO_KSPLIT | MPQE_STEP_EIGHT_WAVES); k->nb = nb;
     k->nlanes = lanes ? lanes->num_lanes : 1;
     if (lanes)
         for (int l = 0; l <= MPQE_STEP_MAX_LANES; ++l) k->lane_begin[l] = lanes->batch_begin[l];
@@ -1784,7 +1784,10 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             if (D == 64) hipLaunchKernelGGL((step_chain_kernel<1, 1>), cgrid, dim3(256), 0, ls[l], sd, lp, tabs, cl);
             else if (D == 128 && (P->flags & MPQE_STEP_NO_KSPLIT))
                 hipLaunchKernelGGL((step_chain_kernel<2, 1>), cgrid, dim3(256), 0, ls[l], sd, lp, tabs, cl);
-            else if (D == 128) hipLaunchKernelGGL((step_chain_kernel<4, 2>), cgrid, dim3(256), 0, ls[l], sd, lp, tabs, cl);
+            else if (D == 128 && (P->flags & MPQE_STEP_EIGHT_WAVES))
+                hipLaunchKernelGGL((step_chain_kernel<2, 2, 8>), cgrid, dim3(512), 0, ls[l], sd, lp, tabs, cl);
+            else if (D == 128)
+                hipLaunchKernelGGL((step_chain_kernel<4, 2>), cgrid, dim3(256), 0, ls[l], sd, lp, tabs, cl);
             else hipLaunchKernelGGL((step_chain_kernel<4, 1>), cgrid, dim3(256), 0, ls[l], sd, lp, tabs, cl);
             mark(ls[l]);
         }

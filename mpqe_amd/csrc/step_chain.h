@@ -152,9 +152,9 @@ __device__ __forceinline__ void chain_mma(f32x4 (&acc)[NCB], const WHalf<NCB> &f
 // 4 waves = (D / (16 NCB)) column groups x KS.  D = 64: <1,1>.  D = 128: <4,2> (a wave owns 64 columns and half
 // of K: dwordx4 loads, 64 MFMAs per item; the two K-halves meet in the LDS output tile) -- <2,1> is the form
 // without the split (MPQE_STEP_NO_KSPLIT).  D = 256: <4,1>.
-template <int NCB, int KS>
+template <int NCB, int KS, int NW = 4>
 struct ChainLds {
-    static constexpr int D = 64 * NCB / KS, LDX = D + 4, BUF = 4 * CH_GB * LDX, MT = 256 / KS;
+    static constexpr int D = 16 * NCB * NW / KS, LDX = D + 4, BUF = 4 * CH_GB * LDX, MT = 64 * NW / KS;
     float xs[2 * BUF];                                   // node states, ping-pong: [node][graph][LDX]
     float bias[MPQE_STEP_MAX_LAYERS * D];                // every layer's bias
     typename chain_bits<NCB>::type mbits[CH_MASK_LEVELS * 4 * MT];    // ReLU bits per (level, node, finishing thread)
@@ -172,17 +172,19 @@ struct ChainLds {
 
 // parts[row][:] = sum over the block's graphs i < ng and the node slots in `mask` of the LDS rows of buffer
 // `X` (fixed order). Called by the whole workgroup, between barriers of its own.
-template <int NCB, int KS>
-__device__ __forceinline__ void chain_colsum(ChainLds<NCB, KS> &S, const float *X, unsigned mask, int ng,
+template <int NCB, int KS, int NW>
+__device__ __forceinline__ void chain_colsum(ChainLds<NCB, KS, NW> &S, const float *X, unsigned mask, int ng,
                                              float *__restrict__ dst) {
-    constexpr int D = 64 * NCB / KS, LDX = D + 4, NP = 256 / D;
+    constexpr int D = 16 * NCB * NW / KS, LDX = D + 4, NP = 256 / D;
     const int col = threadIdx.x % D, part = threadIdx.x / D;
-    float s = 0.f;
-    for (int n = 0; n < 4; ++n) {
-        if (!((mask >> n) & 1u)) continue;
-        for (int i = part; i < ng; i += NP) s += X[(n * CH_GB + i) * LDX + col];
+    if (threadIdx.x < 256) {        // (the first four waves; the others only keep the barriers)
+        float s = 0.f;
+        for (int n = 0; n < 4; ++n) {
+            if (!((mask >> n) & 1u)) continue;
+            for (int i = part; i < ng; i += NP) s += X[(n * CH_GB + i) * LDX + col];
+        }
+        S.red[threadIdx.x] = s;
     }
-    S.red[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x < D && dst) {
         float t = S.red[threadIdx.x];
@@ -203,15 +205,15 @@ struct ChainStep {
 // inside a branch makes hipcc's s_waitcnt bookkeeping fall back to vmcnt(0) at the join, which would
 // serialise every half-block behind the prefetch just issued for the next one; sched_barriers keep hipcc's
 // scheduler from sinking the prefetch loads down to the MFMAs that use them.
-template <int NCB, int KS, bool BWD>
-__device__ __forceinline__ void chain_run(ChainLds<NCB, KS> &S, const int first_op, int T /* items */, int N, int ng,
+template <int NCB, int KS, bool BWD, int NW>
+__device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int first_op, int T /* items */, int N, int ng,
                                           float *__restrict__ Xrows, long long level_stride, int &cur, int A = 0,
                                           const int *bias_part = nullptr, const int *var_part = nullptr,
                                           float *parts = nullptr, int blk = 0) {
-    constexpr int D = 64 * NCB / KS, LDX = D + 4, BUF = 4 * CH_GB * LDX;
-    constexpr int CW = 4 / KS;                  // column groups of 16 NCB columns
+    constexpr int D = 16 * NCB * NW / KS, LDX = D + 4, BUF = 4 * CH_GB * LDX;
+    constexpr int CW = NW / KS;                 // column groups of 16 NCB columns
     constexpr int IPO = D / KS / 64;            // items (64 k each) per K-block and wave
-    constexpr int MT = 256 / KS;                // threads that finish node updates (the last K part's waves)
+    constexpr int MT = 64 * NW / KS;            // threads that finish node updates (the last K part's waves)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kq = lane >> 4;
     const int ks = wave / CW;                            // which part of K this wave multiplies
@@ -439,7 +441,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS> &S, const int first_
     // (L2 hit rate ~75 %, the rest comes from the Infinity Cache): D <= 128 has the registers for PF = 3.
     ChainStep oc = get_op(0), on = get_op(1);       // ops of items it, it + 1
     int it = 0;
-    if constexpr (NCB == 4 && KS == 2 && CHAIN_DBG != 5) {
+    if constexpr (KS == 2 && CHAIN_DBG != 5) {
         // 64 registers of weights, ONE buffer refilled in place: a register is reloaded with the next item's value
         // right behind the MFMAs that read it, so every load has exactly one item (64 MFMAs, 2048 cycles) to land,
         // no register of the buffer is ever dead (hipcc put temporaries into the dead registers of a second
@@ -561,14 +563,18 @@ __device__ __forceinline__ void chain_stamp_where(const ChainArgs &ca) {
 #endif
 }
 
-template <int NCB, int KS>
+// NW = 8: the workgroup has eight waves, two per SIMD. Only the K loops use all of them (a wave of each K part on
+// every SIMD, so the node-update epilogue of one -- VALU work, which does not overlap with the MFMAs of its own
+// wave -- runs under the MFMAs of the other); the row-major phases stay with the first four waves (`four`).
+template <int NCB, int KS, int NW>
 __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, const LayerPtrs &lp, const TablePtrs &tabs,
-                                            const ChainArgs &ca, ChainLds<NCB, KS> &S) {
-    constexpr int D = 64 * NCB / KS, LDX = D + 4, BUF = 4 * CH_GB * LDX;
+                                            const ChainArgs &ca, ChainLds<NCB, KS, NW> &S) {
+    constexpr int D = 16 * NCB * NW / KS, LDX = D + 4, BUF = 4 * CH_GB * LDX;
     constexpr int DB = D / 64;                            // float4 passes of 256 threads over one node's 16 rows
     constexpr int IPO = D / KS / 64;                      // K-loop items per K-block and wave
     constexpr int LPR = D / 4;                            // lanes that share one row in the row-major phases
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool four = NW == 4 || tid < 256;
     const ChainRef ref = ca.refs[blockIdx.x];
     if (ref.batch < 0) return;                            // a hole of the placement grid (uniform)
     const BatchDev &b = sd->b[ref.batch];
@@ -623,7 +629,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
         }
         S.rowp[tid] = src;
     }
-    for (int f = tid; f < sd->num_layers * D; f += 256) {
+    for (int f = tid; f < sd->num_layers * D && four; f += 256) {
         const float *bp = pick_layer(lp.bias, f / D);
         S.bias[f] = bp ? bp[f % D] : 0.f;
     }
@@ -666,7 +672,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     // ---- phase A2: gather the rows, L2-normalise the anchors (reference encoders.py:41-43, no eps), write
     // LDS buffer 0 and H[0]. Thread t moves float4 number t + 256 k, k < N * DB; LPR adjacent lanes share a
     // row. All loads are issued before the first use.
-    {
+    if (four) {
         const int nk = N * DB;
         f32x4 v[4 * DB];
 #pragma unroll
@@ -705,8 +711,8 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     // takes graph 4 w + g, lane s of the group the columns s + 16 cc) and ride through the forward levels in
     // registers: their HBM round trip would otherwise sit between the two K loops
     constexpr int CC = D / 16;
-    const int sc_i = 4 * wave + (lane >> 4), sl = lane & 15;
-    const float *pp_ = S.rowp[4 * CH_GB + sc_i], *pn_ = S.rowp[5 * CH_GB + sc_i];
+    const int sc_i = four ? 4 * wave + (lane >> 4) : 0, sl = lane & 15;
+    const float *pp_ = four ? S.rowp[4 * CH_GB + sc_i] : nullptr, *pn_ = four ? S.rowp[5 * CH_GB + sc_i] : nullptr;
     float tp[CC], tn[CC];
 #pragma unroll
     for (int cc = 0; cc < CC; ++cc) {
@@ -715,14 +721,14 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     }
     // ---- forward levels
     int cur = 0;
-    chain_run<NCB, KS, false>(S, 0, ref.fwd_count * IPO, N, ng, ca.H + row0 * D, ca.level_stride, cur);
+    chain_run<NCB, KS, false, NW>(S, 0, ref.fwd_count * IPO, N, ng, ca.H + row0 * D, ca.level_stride, cur);
 
     chain_stamp(ca, 3);
-    if (ca.backward && ref.bwd_count > 0) warm(ref.fwd_count, ref.bwd_count);
+    if (ca.backward && ref.bwd_count > 0 && four) warm(ref.fwd_count, ref.bwd_count);
     // ---- readout, cosine scores against the + and - target, hinge terms (reference model.py:447-462,
     // 483-485); backward: d hinge -> d cosine -> d readout written over H[L] in LDS (a lane group owns whole
     // graphs) and to gH[L]; target-table gradients through the normalisation. 16 lanes per graph (see above).
-    {
+    if (four) {
         float *Xc = S.xs + cur * BUF;
         float *GL = ca.GH + (long long)L * ca.level_stride + row0 * D;
         const int i = sc_i;
@@ -852,17 +858,17 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     const int blk = g0 / CH_GB;
     {   // bias gradient of the last pass: column sums of gH[L]
         const int pr = cp.bias_part[L - 1];
-        chain_colsum<NCB, KS>(S, S.xs + cur * BUF, b.live[L], ng, pr >= 0 ? ca.parts + (long long)(pr + blk) * D : nullptr);
+        chain_colsum<NCB, KS, NW>(S, S.xs + cur * BUF, b.live[L], ng, pr >= 0 ? ca.parts + (long long)(pr + blk) * D : nullptr);
     }
 
     // ---- backward levels
-    chain_run<NCB, KS, true>(S, ref.fwd_count, ref.bwd_count * IPO, N, ng, ca.GH + row0 * D, ca.level_stride, cur, A,
+    chain_run<NCB, KS, true, NW>(S, ref.fwd_count, ref.bwd_count * IPO, N, ng, ca.GH + row0 * D, ca.level_stride, cur, A,
                          cp.bias_part, cp.var_part, ca.parts, blk);
 
     chain_stamp(ca, 5);
     // ---- anchor rows of gH[0] through the L2 normalisation into the entity-table gradients (fp32 atomics:
     // an entity can occur in several graphs). y comes back from H[0] (this workgroup wrote it; L2).
-    {
+    if (four) {
         const float *Xc = S.xs + cur * BUF;
         const float *H0 = ca.H + row0 * D;
         const int nk = N * DB;

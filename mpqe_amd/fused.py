@@ -66,7 +66,7 @@ class FusedTrainStep(object):
     gradients (include/mpqe_amd.h, mpqe_step_lanes_t). The split balances MFMA work and keeps
     batches of equal depth together (longest chains first)."""
 
-    def __init__(self, model, margin=1.0, lanes=1, prune=True, chain=True, ksplit=True):
+    def __init__(self, model, margin=1.0, lanes=1, prune=True, chain=True, ksplit=True, eight_waves=False):
         enc = model.enc
         if not hasattr(enc, 'table') or getattr(enc, 'node_maps', None) is None:
             raise ValueError('FusedTrainStep needs a DirectEncoder built with node_maps')
@@ -77,7 +77,7 @@ class FusedTrainStep(object):
         self.margin = float(margin)
         # speed switches of the library call (include/mpqe_amd.h): identical loss / scores / gradients
         self.flags = ((0 if prune else _capi.STEP_NO_PRUNE) | (0 if chain else _capi.STEP_NO_CHAIN) |
-                      (0 if ksplit else _capi.STEP_NO_KSPLIT))
+                      (0 if ksplit else _capi.STEP_NO_KSPLIT) | (_capi.STEP_EIGHT_WAVES if eight_waves else 0))
         self.device = next(model.parameters()).device
         if self.device.type != 'cuda':
             raise RuntimeError('mpqe_amd: the model must be on the GPU -- there is no CPU path')

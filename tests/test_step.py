@@ -249,6 +249,8 @@ def test_fused_step_chain_kernels(be, D, readout, adaptive, shared, L):
         runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_NO_PRUNE))
     if D == 128:      # the form whose waves own 32 columns and all of K (the default splits K between wave pairs)
         runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_NO_KSPLIT))
+        # eight waves per workgroup (the row-major phases stay with the first four)
+        runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_EIGHT_WAVES))
     for r in runs:
         assert r[4] == 0
         np.testing.assert_allclose(r[1], ref_sp, rtol=1e-5, atol=1e-6)
