@@ -695,8 +695,10 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
             if (k < nk) {
                 const bool anchor = n < A && S.rowp[r] != nullptr;
                 const float nrm = sqrtf(ss);
-                if (anchor) {
-                    q[0] /= nrm; q[1] /= nrm; q[2] /= nrm; q[3] /= nrm;
+                if (anchor) {      // one division per float4 (a wave64 IEEE division is ~12 VALU instructions, and VALU
+                                   // time is not hidden here): x * (1 / |v|), within 1 ulp of the reference's x / |v|
+                    const float inv = 1.f / nrm;
+                    q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
                     if ((f & (D / 4 - 1)) == 0) S.nrm[r] = nrm;
                 }
                 *reinterpret_cast<f32x4 *>(S.xs + (n * CH_GB + i) * LDX + 4 * c4) = q;
