@@ -94,6 +94,24 @@ __device__ __forceinline__ void chain_lload(float (&d)[NCB], const float *p) {
         for (int c = 0; c < NCB; ++c) d[c] = q[c];
     }
 }
+// v + (v of the lane `off` further, rotating inside the row of 16 lanes), off = 8 / 4 / 2 / 1 in turn: the sum over
+// a group of 16 lanes in every lane, by the same pairs as the xor butterfly (so bitwise the same result) but as
+// four DPP adds instead of four LDS permutes of ~100 cycles each.
+template <int OFF>
+__device__ __forceinline__ float chain_row_ror(float v) {
+#ifdef MPQE_EMU
+    return __shfl_xor(v, OFF, 64);      // (the sums are symmetric: xor and rotation pair the same partial sums)
+#else
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + OFF, 0xF, 0xF, false));
+#endif
+}
+__device__ __forceinline__ float chain_sum16(float v) {
+    v += chain_row_ror<8>(v);
+    v += chain_row_ror<4>(v);
+    v += chain_row_ror<2>(v);
+    v += chain_row_ror<1>(v);
+    return v;
+}
 // ReLU of one output value + its mask bit, and the masking of one gradient value by that bit, at two VALU
 // instructions each: the bits of a lane's 4 x NCB values travel through the carry flag (forward: shifted
 // in at the bottom, first value ends up highest; backward: shifted out at the top, same order).
@@ -691,7 +709,8 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
             f32x4 q = v[k];
             float ss = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
 #pragma unroll
-            for (int off = LPR >> 1; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+            for (int off = LPR >> 1; off >= 16; off >>= 1) ss += __shfl_xor(ss, off, 64);
+            ss = chain_sum16(ss);
             if (k < nk) {
                 const bool anchor = n < A && S.rowp[r] != nullptr;
                 const float nrm = sqrtf(ss);
@@ -736,11 +755,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
         const int i = sc_i;
         const bool on = i < ng;
         const int readout = sd->readout;
-        auto gsum = [](float v) {
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-            return v;
-        };
+        auto gsum = [](float v) { return chain_sum16(v); };
         const float *h = Xc + i * LDX;                    // node n at h + n * CH_GB * LDX
         float q[CC];
         int arg[CC];
@@ -891,7 +906,8 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
             const f32x4 g = *reinterpret_cast<const f32x4 *>(Xc + (n * CH_GB + i) * LDX + 4 * c4);
             float yg = y[k][0] * g[0] + y[k][1] * g[1] + y[k][2] * g[2] + y[k][3] * g[3];
 #pragma unroll
-            for (int off = LPR >> 1; off > 0; off >>= 1) yg += __shfl_xor(yg, off, 64);
+            for (int off = LPR >> 1; off >= 16; off >>= 1) yg += __shfl_xor(yg, off, 64);
+            yg = chain_sum16(yg);
             float *gd = on ? S.gradp[r] : nullptr;
             if (gd) {
                 const float inv = 1.f / S.nrm[r];
