@@ -759,6 +759,13 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
         const float *h = Xc + i * LDX;                    // node n at h + n * CH_GB * LDX
         float q[CC];
         int arg[CC];
+        if (readout == MPQE_READOUT_TM) {                 // (uniform) the target slot's row is the readout
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc) {
+                q[cc] = h[A * CH_GB * LDX + sl + 16 * cc];
+                arg[cc] = 0;
+            }
+        } else
 #pragma unroll
         for (int cc = 0; cc < CC; ++cc) {                 // branch-free: N <= 4 slots, predicated
             const int col = sl + 16 * cc;
@@ -832,6 +839,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
             const float ktp = rp > eps ? sp / (np_ * np_) : 0.f;
             const float ktn = rn > eps ? sn / (nn_ * nn_) : 0.f;
             const unsigned tmask = readout == MPQE_READOUT_SUM ? 0xFu : 1u << A;
+            const unsigned liveL = b.live[L];
             float yg_p = 0.f, yg_n = 0.f;
 #pragma unroll
             for (int cc = 0; cc < CC; ++cc) {
@@ -845,7 +853,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
                     const float gv = (takes >> n) & 1u ? gq : 0.f;
-                    if (n < N) {
+                    if (n < N && ((liveL >> n) & 1u)) {     // (rows of pruned slots: nothing reads them)
                         Xc[(n * CH_GB + i) * LDX + col] = gv;
                         if (on) GL[((long long)i * N + n) * D + col] = gv;
                     }
