@@ -94,6 +94,23 @@ __device__ __forceinline__ void chain_lload(float (&d)[NCB], const float *p) {
         for (int c = 0; c < NCB; ++c) d[c] = q[c];
     }
 }
+// 1 / sqrt(x) and 1 / x in one instruction (v_rsq_f32 / v_rcp_f32, 1 ulp) where the result only scales a row or a
+// gradient: the IEEE sequences hipcc emits for sqrtf and `/` are 10 - 15 VALU instructions each, none of them hidden
+// (the scores themselves keep the exact division).
+__device__ __forceinline__ float chain_rsq(float x) {
+#ifdef MPQE_EMU
+    return 1.f / sqrtf(x);
+#else
+    return __builtin_amdgcn_rsqf(x);
+#endif
+}
+__device__ __forceinline__ float chain_rcp(float x) {
+#ifdef MPQE_EMU
+    return 1.f / x;
+#else
+    return __builtin_amdgcn_rcpf(x);
+#endif
+}
 // v + (v of the lane `off` further, rotating inside the row of 16 lanes), off = 8 / 4 / 2 / 1 in turn: the sum over
 // a group of 16 lanes in every lane, by the same pairs as the xor butterfly (so bitwise the same result) but as
 // four DPP adds instead of four LDS permutes of ~100 cycles each.
@@ -178,7 +195,7 @@ struct ChainLds {
     typename chain_bits<NCB>::type mbits[CH_MASK_LEVELS * 4 * MT];    // ReLU bits per (level, node, finishing thread)
     const float *rowp[4 * CH_GB + 2 * CH_GB];            // source row of every node row, then +/- targets
     float *gradp[4 * CH_GB];                             // entity-table gradient row of every anchor row
-    float nrm[4 * CH_GB];                                // |v| of the anchor rows
+    float nrm[4 * CH_GB];                                // 1 / |v| of the anchor rows
     const float *wp[CH_MAX_OPS];                         // weight matrix of every op of the block's programme
     int opw[CH_MAX_OPS][2];                              // its (src | node << 8 | layer << 16 | level << 24, flags)
     float red[256];                                      // column-sum scratch
@@ -713,12 +730,10 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
             ss = chain_sum16(ss);
             if (k < nk) {
                 const bool anchor = n < A && S.rowp[r] != nullptr;
-                const float nrm = sqrtf(ss);
-                if (anchor) {      // one division per float4 (a wave64 IEEE division is ~12 VALU instructions, and VALU
-                                   // time is not hidden here): x * (1 / |v|), within 1 ulp of the reference's x / |v|
-                    const float inv = 1.f / nrm;
+                if (anchor) {      // x * (1 / |v|): within 2 ulp of the reference's x / |v|
+                    const float inv = chain_rsq(ss);
                     q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
-                    if ((f & (D / 4 - 1)) == 0) S.nrm[r] = nrm;
+                    if ((f & (D / 4 - 1)) == 0) S.nrm[r] = inv;
                 }
                 *reinterpret_cast<f32x4 *>(S.xs + (n * CH_GB + i) * LDX + 4 * c4) = q;
                 if (r < nrows) *reinterpret_cast<f32x4 *>(H0 + (long long)r * D + 4 * c4) = q;
@@ -795,7 +810,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
         }
         ssp = gsum(ssp);
         ssn = gsum(ssn);
-        const float ip0 = 1.f / sqrtf(ssp), in0 = 1.f / sqrtf(ssn);
+        const float ip0 = chain_rsq(ssp), in0 = chain_rsq(ssn);
         float dp = 0.f, dn = 0.f, qq = 0.f, pp = 0.f, nn = 0.f;
 #pragma unroll
         for (int cc = 0; cc < CC; ++cc) {
@@ -834,10 +849,10 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
             // d loss / d sp = -w/B on active terms, d/d sn = +w/B   (loss = sum_b w_b mean_b hinge)
             const float act = hv >= 0.f ? b.weight / (float)b.B : 0.f;
             const float gsp = -act, gsn = act;
-            const float inv_p = 1.f / (nq * np_), inv_n = 1.f / (nq * nn_);
-            const float kq_ = rq > eps ? (gsp * sp + gsn * sn) / (nq * nq) : 0.f;
-            const float ktp = rp > eps ? sp / (np_ * np_) : 0.f;
-            const float ktn = rn > eps ? sn / (nn_ * nn_) : 0.f;
+            const float inv_p = chain_rcp(nq * np_), inv_n = chain_rcp(nq * nn_);
+            const float kq_ = rq > eps ? (gsp * sp + gsn * sn) * chain_rcp(nq * nq) : 0.f;
+            const float ktp = rp > eps ? sp * chain_rcp(np_ * np_) : 0.f;
+            const float ktn = rn > eps ? sn * chain_rcp(nn_ * nn_) : 0.f;
             const unsigned tmask = readout == MPQE_READOUT_SUM ? 0xFu : 1u << A;
             const unsigned liveL = b.live[L];
             float yg_p = 0.f, yg_n = 0.f;
@@ -918,7 +933,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
             yg = chain_sum16(yg);
             float *gd = on ? S.gradp[r] : nullptr;
             if (gd) {
-                const float inv = 1.f / S.nrm[r];
+                const float inv = S.nrm[r];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) atomicAdd(gd + 4 * c4 + e, (g[e] - y[k][e] * yg) * inv);
             }
