@@ -159,6 +159,9 @@ __device__ __forceinline__ void chain_mask_pop(float &v, unsigned &bits) {
 // B[k][n] = M[k][n] with M row-major: forward M = W, backward-x M = W^T (a transposed copy made by
 // step_prep_kernel, so both directions read whole 128-byte row pieces: 16 lanes x NCB adjacent floats).
 // wp = M + (64 h + 4 kq) * D + n0 + NCB * j; one t-step = 16 k.
+#ifndef CHAIN_ZERO_C
+#define CHAIN_ZERO_C 1  // 0: clear the accumulators after every node update instead of starting the next one from C = 0
+#endif
 #ifndef CHAIN_DBG
 #define CHAIN_DBG 0     // experiments only: 1 = no weight loads in the K loop, 2 = no MFMAs
 #endif
@@ -318,9 +321,16 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
 #pragma unroll
                 for (int c = 0; c < NCB; ++c) asm volatile("" ::"v"(f.v[t][u][c]), "v"(a[u]));
 #else
+                if (CHAIN_ZERO_C && t == 0 && u == 0 && h == 0 && (op.flags & CH_FIRST)) {
+                    // a node update's first MFMAs take C = 0 instead of accumulators cleared by 4 NCB v_mov
 #pragma unroll
-                for (int c = 0; c < NCB; ++c)
-                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], f.v[t][u][c], acc[c], 0, 0, 0);
+                    for (int c = 0; c < NCB; ++c)
+                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], f.v[t][u][c], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NCB; ++c)
+                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], f.v[t][u][c], acc[c], 0, 0, 0);
+                }
 #endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (CHAIN_DBG != 1 && INPLACE) {
@@ -446,8 +456,10 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
             // the next node update starts from zero (cleared here, inside the uniform branch, rather than by a
             // select at the top of every item: that select made hipcc park the accumulators in registers of
             // a load buffer whose loads were still in flight, and wait for them)
+            if (!CHAIN_ZERO_C) {
 #pragma unroll
-            for (int c = 0; c < NCB; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int c = 0; c < NCB; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         CHAIN_TRACE(3)
         if (op.flags & CH_LEVEL_END) {       // uniform over the workgroup: every wave runs the same programme
