@@ -140,10 +140,14 @@ __device__ __forceinline__ void chain_relu_push(float &v, unsigned &bits) {
     v = p ? v : 0.f;
     bits = (bits << 1) | (p ? 1u : 0u);
 #else
-    asm volatile("v_cmp_lt_f32 vcc, 0, %0\n\tv_cndmask_b32 %0, 0, %0, vcc\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
-                 : "+v"(v), "+v"(bits)
-                 :
+    // (the value goes in and out through different operands: tied to one register, hipcc copied each value out of
+    // the register pair its packed add had produced)
+    float o;
+    asm volatile("v_cmp_lt_f32 vcc, 0, %2\n\tv_cndmask_b32 %0, 0, %2, vcc\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
+                 : "=&v"(o), "+v"(bits)
+                 : "v"(v)
                  : "vcc");
+    v = o;
 #endif
 }
 __device__ __forceinline__ void chain_mask_pop(float &v, unsigned &bits) {
@@ -152,7 +156,9 @@ __device__ __forceinline__ void chain_mask_pop(float &v, unsigned &bits) {
     bits <<= 1;
     v = p ? v : 0.f;
 #else
-    asm volatile("v_add_co_u32 %1, vcc, %1, %1\n\tv_cndmask_b32 %0, 0, %0, vcc" : "+v"(v), "+v"(bits) : : "vcc");
+    float o;
+    asm volatile("v_add_co_u32 %1, vcc, %1, %1\n\tv_cndmask_b32 %0, 0, %2, vcc" : "=&v"(o), "+v"(bits) : "v"(v) : "vcc");
+    v = o;
 #endif
 }
 
