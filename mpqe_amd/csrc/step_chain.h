@@ -291,6 +291,27 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
     float bs[NCB];          // backward: column sums of this level's gradient rows (bias gradient of the pass below)
 #pragma unroll
     for (int c = 0; c < NCB; ++c) bs[c] = 0.f;
+    // K split: the finished rows of a node update go to HBM (H / gH, for the weight-gradient launch) from the waves of
+    // the FIRST K part: they would otherwise idle until the finishing waves reach the next hand-off, and the stores
+    // (plus their address arithmetic: VALU time a wave cannot hide behind its own MFMAs) leave the finishing waves'
+    // path. They copy the node's LDS tile one barrier after it was written: behind the next hand-off / level barrier.
+    const float *pend_tile = nullptr;
+    float *pend_out = nullptr;
+    bool pend_on = false;
+    auto flush_rows = [&]() {
+        float l[4][NCB];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) chain_lload<NCB>(l[r], pend_tile + r * LDX);
+        if (ng == CH_GB) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) chain_store<NCB>(pend_out + (long long)r * N * D, l[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * kq + r < ng) chain_store<NCB>(pend_out + (long long)r * N * D, l[r]);
+        }
+        pend_on = false;
+    };
     // (f and fn may be ONE buffer: every group of NCB MFMAs is then followed by the load that refills the registers
     // it has just read with the next item's weights)
     auto item = [&](const ChainStep &op, int it, WHalf<NCB> &f, WHalf<NCB> &fn, const float *wn, auto inplace_tag) {
@@ -372,6 +393,12 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
                 if (!BWD) chain_lload<NCB>(bv, S.bias + op.layer * D + colb);
             }
             if (KS > 1) __syncthreads();
+            if (KS > 1 && !finisher) {
+                if (pend_on) flush_rows();
+                pend_on = !(op.flags & CH_NOSTORE);
+                pend_tile = tile;
+                pend_out = Xrows + (long long)op.level * level_stride + ((long long)(4 * kq) * N + op.node) * D + colb;
+            }
             CHAIN_TRACE(2)
             // MODE 0: plain, 1: ReLU + record the mask bits, 2: mask by the recorded bits. One straight-line
             // body per mode (a shared tail makes hipcc copy the 16 values around the inline asm)
@@ -421,7 +448,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
                 }
                 float *Xout = Xrows + (long long)op.level * level_stride + ((long long)(4 * kq) * N + op.node) * D + colb;
                 if (ng == CH_GB) {          // (all but a batch's last block)
-                    if (!(op.flags & CH_NOSTORE)) {
+                    if (KS == 1 && !(op.flags & CH_NOSTORE)) {      // (K split: the other K part's waves copy the rows out)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) chain_store<NCB>(Xout + (long long)r * N * D, v[r]);
                     }
@@ -435,7 +462,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (4 * kq + r < ng) {
-                            if (!(op.flags & CH_NOSTORE)) chain_store<NCB>(Xout + (long long)r * N * D, v[r]);
+                            if (KS == 1 && !(op.flags & CH_NOSTORE)) chain_store<NCB>(Xout + (long long)r * N * D, v[r]);
                             if (BWD) {
 #pragma unroll
                                 for (int c = 0; c < NCB; ++c) bs[c] += v[r][c];
@@ -483,6 +510,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
             }
             __syncthreads();
             cur ^= 1;
+            if (KS > 1 && !finisher && pend_on) flush_rows();     // (the level's last node update)
         }
     };
     if (T <= 0) return;
