@@ -295,20 +295,49 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
     // the FIRST K part: they would otherwise idle until the finishing waves reach the next hand-off, and the stores
     // (plus their address arithmetic: VALU time a wave cannot hide behind its own MFMAs) leave the finishing waves'
     // path. They copy the node's LDS tile one barrier after it was written: behind the next hand-off / level barrier.
+    // In the backward direction the same waves also form the rows' column sums (bias / variable-row partials).
     const float *pend_tile = nullptr;
     float *pend_out = nullptr;
-    bool pend_on = false;
+    bool pend_on = false, pend_store = false;
+    int pend_var = -1;              // >= 0: the rows are a variable row of gH[0]; its slot in `parts`
     auto flush_rows = [&]() {
         float l[4][NCB];
 #pragma unroll
         for (int r = 0; r < 4; ++r) chain_lload<NCB>(l[r], pend_tile + r * LDX);
-        if (ng == CH_GB) {
+        if (BWD && pend_var >= 0) {     // (level 0 has no bias gradient to collect: bs is free to hold the node's own sums)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) chain_store<NCB>(pend_out + (long long)r * N * D, l[r]);
+            for (int c = 0; c < NCB; ++c) bs[c] = 0.f;
+        }
+        if (ng == CH_GB) {
+            if (pend_store) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) chain_store<NCB>(pend_out + (long long)r * N * D, l[r]);
+            }
+            if (BWD) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < NCB; ++c) bs[c] += l[r][c];
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (4 * kq + r < ng) chain_store<NCB>(pend_out + (long long)r * N * D, l[r]);
+                if (4 * kq + r < ng) {
+                    if (pend_store) chain_store<NCB>(pend_out + (long long)r * N * D, l[r]);
+                    if (BWD) {
+#pragma unroll
+                        for (int c = 0; c < NCB; ++c) bs[c] += l[r][c];
+                    }
+                }
+        }
+        if (BWD && pend_var >= 0) {
+            float t[NCB];
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) {
+                t[c] = bs[c] + __shfl_xor(bs[c], 16, 64);
+                t[c] += __shfl_xor(t[c], 32, 64);
+            }
+            if (kq == 0) chain_store<NCB>(parts + (long long)(pend_var + blk) * D + colb, t);
         }
         pend_on = false;
     };
@@ -395,7 +424,9 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
             if (KS > 1) __syncthreads();
             if (KS > 1 && !finisher) {
                 if (pend_on) flush_rows();
-                pend_on = !(op.flags & CH_NOSTORE);
+                pend_store = !(op.flags & CH_NOSTORE);
+                pend_var = BWD && op.level == 0 && op.node >= A ? var_part[op.node - A] : -1;
+                pend_on = pend_store || BWD;
                 pend_tile = tile;
                 pend_out = Xrows + (long long)op.level * level_stride + ((long long)(4 * kq) * N + op.node) * D + colb;
             }
@@ -441,7 +472,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
                 CHAIN_TRACE(6)
                 // a variable row of gH[0]: its sum over the block's graphs is a mode-embedding gradient partial
                 // (level 0 has no bias gradient to collect: bs is free to hold the node's own sums)
-                const bool var_row = BWD && op.level == 0 && op.node >= A && var_part[op.node - A] >= 0;
+                const bool var_row = KS == 1 && BWD && op.level == 0 && op.node >= A && var_part[op.node - A] >= 0;
                 if (var_row) {
 #pragma unroll
                     for (int c = 0; c < NCB; ++c) bs[c] = 0.f;
@@ -452,7 +483,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
 #pragma unroll
                         for (int r = 0; r < 4; ++r) chain_store<NCB>(Xout + (long long)r * N * D, v[r]);
                     }
-                    if (BWD) {
+                    if (BWD && KS == 1) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -463,7 +494,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
                     for (int r = 0; r < 4; ++r) {
                         if (4 * kq + r < ng) {
                             if (KS == 1 && !(op.flags & CH_NOSTORE)) chain_store<NCB>(Xout + (long long)r * N * D, v[r]);
-                            if (BWD) {
+                            if (BWD && KS == 1) {
 #pragma unroll
                                 for (int c = 0; c < NCB; ++c) bs[c] += v[r][c];
                             }
@@ -496,8 +527,8 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
         }
         CHAIN_TRACE(3)
         if (op.flags & CH_LEVEL_END) {       // uniform over the workgroup: every wave runs the same programme
-            if (BWD) {      // gH[level] is complete: its column sums (rows 4 kq + r live in lane group kq; the wave
-                            // owns its columns) are pass level-1's bias gradient. Fixed order, no barrier.
+            auto level_sums = [&]() {      // gH[level] is complete: its column sums (rows 4 kq + r live in lane group
+                                           // kq; the wave owns its columns) are pass level-1's bias gradient. Fixed order.
                 float t[NCB];
 #pragma unroll
                 for (int c = 0; c < NCB; ++c) {
@@ -505,12 +536,16 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
                     t[c] += __shfl_xor(t[c], 32, 64);
                     bs[c] = 0.f;
                 }
-                if (op.level >= 1 && bias_part[op.level - 1] >= 0 && kq == 0 && finisher)
+                if (op.level >= 1 && bias_part[op.level - 1] >= 0 && kq == 0)
                     chain_store<NCB>(parts + (long long)(bias_part[op.level - 1] + blk) * D + colb, t);
-            }
+            };
+            if (BWD && KS == 1) level_sums();
             __syncthreads();
             cur ^= 1;
-            if (KS > 1 && !finisher && pend_on) flush_rows();     // (the level's last node update)
+            if (KS > 1 && !finisher) {
+                if (pend_on) flush_rows();     // (the level's last node update)
+                if (BWD) level_sums();
+            }
         }
     };
     if (T <= 0) return;
