@@ -38,6 +38,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--repeats', type=int, default=25,
+                    help='the timed block of --steps steps is repeated this many times; the median block is reported')
     ap.add_argument('--kg', default='aifb')
     ap.add_argument('--embed-dim', type=int, default=128)
     ap.add_argument('--batch-size', type=int, default=512)
@@ -47,7 +49,7 @@ def parse():
     ap.add_argument('--path', default='auto', choices=['auto', 'modules', 'fused'])
     ap.add_argument('--lanes', type=int, default=1, help='HIP streams one fused step is spread over')
     ap.add_argument('--graph', type=int, default=0,
-                    help='1: replay each step from a captured hipGraph (level form only: needs --no-chain)')
+                    help='1: replay each step from a captured hipGraph')
     ap.add_argument('--no-prune', action='store_true', help='compute node states that cannot reach the readout too')
     ap.add_argument('--no-chain', action='store_true', help='one launch per message-passing level')
     ap.add_argument('--no-ksplit', action='store_true', help='dim 128: chain waves own 32 columns and all of K')
@@ -103,6 +105,34 @@ def step_modules(model, data):
         loss = l if loss is None else loss + l
     loss.backward()
     return loss
+
+
+def self_check(model, fstep, packed, data, world):
+    """Before anything is timed: the fused step on the first packed step against the drop-in module path (itself
+    pinned to the oracle and the reference-generated goldens by tests/) on the same batches -- loss and every
+    parameter gradient. A mismatch ends the run with a non-zero status: no throughput line for wrong results."""
+    loss = fstep.run(packed)
+    fstep.check()
+    got = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    got_loss = float(loss[0].item())
+    for p in model.parameters():
+        p.grad = None
+    ref_loss = float(step_modules(model, data).item()) / world       # (the 1 / world of the mean is in the packed weights)
+    bad = []
+    if abs(got_loss - ref_loss) > 1e-5 * abs(ref_loss) + 1e-6:
+        bad.append('loss %.8g vs %.8g' % (got_loss, ref_loss))
+    for k, p in model.named_parameters():
+        ref = (torch.zeros_like(p) if p.grad is None else p.grad) / world
+        err = (got[k] - ref).abs()
+        tol = 1e-4 * ref.abs() + 2e-6
+        if bool((err > tol).any()):
+            bad.append('%s: max abs err %.3g' % (k, float(err.max())))
+    for p in model.parameters():
+        p.grad = None
+    fstep.bind_grads()
+    if bad:
+        sys.stderr.write('bench self-check FAILED (fused step vs module path): ' + '; '.join(bad) + '\n')
+        raise SystemExit(3)
 
 
 def pack_for_fused(step, data, scale=1.0):
@@ -173,10 +203,12 @@ def time_fused_kernels(step, packed, data, model, readout, reps=20):
 
 
 def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary that has it
-    (profiles/r01_*_pmc.json, made by tools/pmc_summary.py: separate FETCH_SIZE and WRITE_SIZE passes,
-    FETCH_SIZE doubled as the MI355X guide prescribes for gfx950). PMC counters need the rocprofv3 wrapper,
-    so they are not collected inside this process; None when no summary is committed for the kernel."""
+    """(bytes, source): HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
+    that has it (profiles/r*_pmc.json, made by tools/pmc_summary.py: separate FETCH_SIZE and WRITE_SIZE passes,
+    FETCH_SIZE doubled as the MI355X guide prescribes for gfx950), and the file it came from. PMC counters need
+    the rocprofv3 wrapper, so they are NOT collected by the process that prints the line: the value is the one
+    measured when that profile was taken (same command, same code when the file's round tag is current);
+    (None, None) when no summary is committed for the kernel."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json')), reverse=True):
         try:
@@ -185,8 +217,8 @@ def pmc_traffic(kernel):
             continue
         for name, rec in table.items():
             if name.split('<')[0] == kernel and isinstance(rec, dict) and rec.get('hbm_bytes') is not None:
-                return rec.get('hbm_bytes')
-    return None
+                return rec.get('hbm_bytes'), 'profiles/' + os.path.basename(path)
+    return None, None
 
 
 def layer_work(data, model):
@@ -263,7 +295,7 @@ def cpu_baseline(args, schema, model_state, node_maps, rel_ids, mode_ids, cfg, s
     encoder passes per loss: reference model.py:280-305, 478-482) timed on the host cores for a
     bounded sample of the same workload: whole formula batches of the full mix, forward + backward,
     drawn in mix order until the time budget is spent. The torch thread count is calibrated on one
-    3-chain batch (1, 8, 16, 32, all usable cores) and the fastest is used and reported."""
+    3-chain batch (1, 8, 16, 32, 64 threads at most) and the fastest is used and reported."""
     from mpqe_amd import synthetic
     from oracle import ref_cpu
     B = args.batch_size
@@ -286,7 +318,7 @@ def cpu_baseline(args, schema, model_state, node_maps, rel_ids, mode_ids, cfg, s
         loss.backward()
 
     avail = usable_cores()
-    cand = sorted(set(c for c in (1, 8, 16, 32, avail) if c <= avail))
+    cand = sorted(set(c for c in (1, 8, 16, 32, min(avail, 64)) if c <= avail))     # (256 threads: 50 s per batch)
     probe = make('3-chain')
     timing = {}
     for c in cand:
@@ -363,9 +395,6 @@ def main():
     pool = [StepData(schema, model, args.batch_size, rng, device) for _ in range(4)]
 
     use_fused = args.path in ('auto', 'fused') and args.readout in ('mp', 'sum', 'max')
-    if args.graph and not args.no_chain:
-        raise SystemExit('--graph 1 needs --no-chain: replaying the captured chain form faulted on this stack '
-                         '(mpqe_amd/fused.py: capture)')
     reducer = fstep = packed = captured = None
     if use_fused:
         from mpqe_amd.fused import FusedTrainStep
@@ -380,8 +409,7 @@ def main():
     def one_step(i):
         if use_fused:
             if captured is not None:
-                captured[i % len(pool)][0].replay()
-                loss = captured[i % len(pool)][1]
+                loss = captured[i % len(pool)].replay()
             else:
                 loss = fstep.run(packed[i % len(pool)])
             if world > 1:
@@ -399,19 +427,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if use_fused:
+        self_check(model, fstep, packed[0], pool[0], world)
     for i in range(args.warmup):
         one_step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # The timed region is EXACTLY `steps` steps between barrier + synchronize on both sides. At ~0.05 ms per step the
+    # driver's --steps 20 is a ~1 ms region, within launch / clock noise of a single sample: the same block is
+    # repeated `--repeats` times (each one bracketed the same way) and the MEDIAN block is the reported one,
+    # with min and max beside it. Per block the time is the max over ranks.
+    blocks = []
+    for r in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(i)
+        barrier()
+        blocks.append(time.perf_counter() - t0)
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], device=device if args.backend == 'nccl' else 'cpu', dtype=torch.float64)
+        t = torch.tensor(blocks, device=device if args.backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        blocks = [float(v) for v in t.tolist()]
+    elapsed = float(np.median(blocks))
 
     graphs_per_step = pool[0].num_graphs * world
     value = graphs_per_step * args.steps / elapsed
@@ -419,6 +456,9 @@ def main():
         'metric': 'query-graphs/sec (encoder fwd+bwd)', 'value': value, 'unit': 'query-graphs/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'timed_blocks': {'repeats': len(blocks), 'reported': 'median block of --steps steps',
+                         'ms_per_step_min': min(blocks) / args.steps * 1e3,
+                         'ms_per_step_max': max(blocks) / args.steps * 1e3},
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'AIFB-shaped full query mix: 11 batches x B=%d per step (1/2/3-chain, 2x each of '
                                '2-inter, 3-inter, 3-inter_chain, 3-chain_inter), embed_dim=%d, readout=%s, '
@@ -440,7 +480,8 @@ def main():
             out['roofline'] = {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['achieved'],
                                'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': dom['achieved'] / MFMA_F32_PEAK_TFLOPS,
-                               'traffic': pmc_traffic(dom['kernel']),
+                               'traffic': pmc_traffic(dom['kernel'])[0],
+                               'traffic_source': pmc_traffic(dom['kernel'])[1],
                                'avg_launch_us': dom['avg_launch_us'],
                                'algorithmic_flops_per_launch': dom['algorithmic_flops_per_launch'],
                                'launches_per_step': dom['launches_per_step']}
@@ -451,7 +492,8 @@ def main():
             if dom['kernel'] == 'step_chain_kernel':
                 gbs = bytes_all / (dom['avg_launch_us'] * 1e-6) / 1e9
                 out['roofline_hbm'] = {'bound': 'hbm', 'kernel': dom['kernel'], 'achieved': gbs, 'peak': HBM_PEAK_GBS,
-                                       'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': pmc_traffic(dom['kernel']),
+                                       'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': pmc_traffic(dom['kernel'])[0],
+                                       'traffic_source': pmc_traffic(dom['kernel'])[1],
                                        'algorithmic_bytes_per_launch': bytes_all}
         else:
             dur, ncalls = time_layer_forward(model, pool[0])

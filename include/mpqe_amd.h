@@ -226,6 +226,12 @@ int mpqe_hinge_bwd(const float *pos, const float *neg, int64_t n, float margin, 
 /* EIGHT_WAVES dim 128 only, experimental: chain workgroups of eight waves (a wave of each K half on every SIMD, 32
  *             columns each) instead of four. Same results; measured 1 % slower on the AIFB mix.  */
 #define MPQE_STEP_EIGHT_WAVES 16
+/* NO_UNIFORM  chain form: treat every node state as per-graph rows. Default: node states no anchor has reached yet
+ *             are ONE vector per batch (the variable rows of x0 are the same mode_embeddings row for every graph of
+ *             a batch, reference model.py:421), so their updates are matrix-VECTOR products done once per batch by a
+ *             pre-pass, their backward runs on column sums, and their weight gradients are rank-1 updates -- the
+ *             AIFB mix keeps 34 of its 66 live [B, D] x [D, D] products per direction.                       */
+#define MPQE_STEP_NO_UNIFORM 32
 
 typedef struct {
     int32_t query_type;        /* MPQE_Q_*                                                     */
@@ -277,14 +283,14 @@ typedef struct {
 } mpqe_step_lanes_t;
 
 size_t mpqe_step_workspace_bytes(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,
-                                 int num_batches);
+                                 int num_batches, const mpqe_step_lanes_t *lanes /* NULL = one lane */);
 /* The kernels read a small descriptor table (templates, relations, offsets, reduction groups). It
  * lives in a caller-owned device buffer `desc` (256-byte aligned): with upload_desc != 0 the call
  * first writes it (by kernel arguments, no host memory is read asynchronously); a packed step
  * that is run again unchanged passes upload_desc = 0 and re-uses it -- building it is part of
  * collation, like the reference's collate_fn building edge_index / edge_type.                  */
 size_t mpqe_step_desc_bytes(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,
-                            int num_batches);
+                            int num_batches, const mpqe_step_lanes_t *lanes /* the split the step will run with */);
 /* anchor_ids: per batch b a block of [A_b, B_b] ids (slot-major), blocks concatenated in batch
  * order; targets / negs: [sum_b B_b]. backward = 0 stops after the loss (grads may be NULL).
  * scores_pos / scores_neg: [sum_b B_b] or NULL. workspace must be 256-byte aligned.

@@ -569,4 +569,4 @@ extern "C" const char *mpqe_status_string(int status) {
         default: return "unknown status";
     }
 }
-extern "C" int mpqe_abi_version(void) { return 1; }
+extern "C" int mpqe_abi_version(void) { return 2; }

@@ -70,7 +70,7 @@ struct TablePtrs {
 // Tiles of one (batch, node slot) at one level: rt*ct tiles of equal K length. Per-CU MFMA time is
 // what bounds a level, and a level's workgroups are (almost always) all resident at once, dealt
 // round-robin over the 256 CUs: block i shares its CU with blocks i+256, i+512, i+768 (measured,
-// scratch/placement.hip; a speed assumption only, results do not depend on it). place_tiles() orders
+// tools/micro/placement.hip; a speed assumption only, results do not depend on it). place_tiles() orders
 // the table so that those per-CU sums are balanced (longest-processing-time-first bin packing).
 struct TileGroup {
     int batch, node, tile_off, steps;
@@ -1505,16 +1505,19 @@ extern "C" void mpqe_debug_chain_stamps(void *device_buffer, size_t num_blocks) 
     g_chain_stamp_blocks = num_blocks;
 }
 
-extern "C" size_t mpqe_step_workspace_bytes(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb) {
+extern "C" size_t mpqe_step_workspace_bytes(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb,
+                                            const mpqe_step_lanes_t *lanes) {
     HostPlan hp;
-    if (make_plan(P, B, nb, nullptr, &hp) != MPQE_OK) return 0;
+    if (make_plan(P, B, nb, lanes, &hp) != MPQE_OK) return 0;
     return hp.total;
 }
-extern "C" size_t mpqe_step_desc_bytes(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb) {
-    // lanes only split the tile tables between streams; their total size does not depend on the split
+extern "C" size_t mpqe_step_desc_bytes(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb,
+                                       const mpqe_step_lanes_t *lanes) {
+    // exact: every lane has its own chain grid (8 x its longest XCD bin, holes included) and its own per-level
+    // tile tables, so the table's size depends on the split
     HostPlan hp;
-    if (make_plan(P, B, nb, nullptr, &hp) != MPQE_OK) return 0;
-    return hp.desc_total + 256 * 2 * MPQE_STEP_MAX_LANES * STEP_MAX_LEVELS;
+    if (make_plan(P, B, nb, lanes, &hp) != MPQE_OK) return 0;
+    return hp.desc_total;
 }
 
 extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb,

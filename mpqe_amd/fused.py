@@ -59,6 +59,18 @@ def live_units(query_type, passes, readout, prune=True):
     return units
 
 
+class CapturedStep(object):
+    """A fused step recorded into a hipGraph together with everything its kernel nodes point at."""
+    __slots__ = ('graph', 'loss', 'workspace', 'packed')
+
+    def __init__(self, graph, loss, workspace, packed):
+        self.graph, self.loss, self.workspace, self.packed = graph, loss, workspace, packed
+
+    def replay(self):
+        self.graph.replay()
+        return self.loss
+
+
 class FusedTrainStep(object):
     """lanes: number of HIP streams a step is spread over (1 = everything on the current stream).
     A step is a chain of ~13 dependent, very short launches; with lanes > 1 the batches are split
@@ -66,7 +78,8 @@ class FusedTrainStep(object):
     gradients (include/mpqe_amd.h, mpqe_step_lanes_t). The split balances MFMA work and keeps
     batches of equal depth together (longest chains first)."""
 
-    def __init__(self, model, margin=1.0, lanes=1, prune=True, chain=True, ksplit=True, eight_waves=False):
+    def __init__(self, model, margin=1.0, lanes=1, prune=True, chain=True, ksplit=True, eight_waves=False,
+                 uniform=True):
         enc = model.enc
         if not hasattr(enc, 'table') or getattr(enc, 'node_maps', None) is None:
             raise ValueError('FusedTrainStep needs a DirectEncoder built with node_maps')
@@ -77,7 +90,8 @@ class FusedTrainStep(object):
         self.margin = float(margin)
         # speed switches of the library call (include/mpqe_amd.h): identical loss / scores / gradients
         self.flags = ((0 if prune else _capi.STEP_NO_PRUNE) | (0 if chain else _capi.STEP_NO_CHAIN) |
-                      (0 if ksplit else _capi.STEP_NO_KSPLIT) | (_capi.STEP_EIGHT_WAVES if eight_waves else 0))
+                      (0 if ksplit else _capi.STEP_NO_KSPLIT) | (_capi.STEP_EIGHT_WAVES if eight_waves else 0) |
+                      (0 if uniform else _capi.STEP_NO_UNIFORM))
         self.device = next(model.parameters()).device
         if self.device.type != 'cuda':
             raise RuntimeError('mpqe_amd: the model must be on the GPU -- there is no CPU path')
@@ -219,11 +233,11 @@ class FusedTrainStep(object):
         ps.targets = torch.cat(tg).to(self.device)
         ps.negs = torch.cat(ng).to(self.device)
         ps.num_graphs = int(sum(sizes))
-        ps.ws_bytes = ops.lib().mpqe_step_workspace_bytes(ctypes.byref(self.P), SB, nb)
+        ps.ws_bytes = ops.lib().mpqe_step_workspace_bytes(ctypes.byref(self.P), SB, nb, ps.lanes)
         if ps.ws_bytes == 0:
             raise _capi.MpqeError('mpqe_step_workspace_bytes rejected the step descriptors')
         # descriptor table of this step: written to HBM by the first run, re-used afterwards
-        ps.desc_bytes = ops.lib().mpqe_step_desc_bytes(ctypes.byref(self.P), SB, nb)
+        ps.desc_bytes = ops.lib().mpqe_step_desc_bytes(ctypes.byref(self.P), SB, nb, ps.lanes)
         ps.desc = torch.empty(ps.desc_bytes + 256, dtype=torch.uint8, device=self.device)
         ps.desc_ptr = (ps.desc.data_ptr() + 255) // 256 * 256
         ps.desc_resident = False
@@ -240,11 +254,13 @@ class FusedTrainStep(object):
             self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
         return (self._ws.data_ptr() + 255) // 256 * 256
 
-    def run(self, packed, backward=True, zero_grad=True, scores=False, events=None):
+    def run(self, packed, backward=True, zero_grad=True, scores=False, events=None, workspace=None):
         """Returns loss [1 + nb] on the device: loss[0] = weighted step loss, loss[1 + i] = mean hinge
         of library batch i = the caller's batch packed.order[i] (identity with one lane); scores come
         back in the same library order. With backward=True every p.grad then holds d loss[0] / d p
-        (accumulated on top of the previous content unless zero_grad)."""
+        (accumulated on top of the previous content unless zero_grad). workspace: a uint8 tensor of at
+        least packed.ws_bytes + 256 bytes to run in instead of the step object's shared arena (a
+        captured graph owns its arena: see capture())."""
         if backward:
             self.bind_grads()
         # the library zero-fills the gradient buffers itself (one launch with its other prologue work)
@@ -254,7 +270,12 @@ class FusedTrainStep(object):
         if scores:
             sp = torch.empty(packed.num_graphs, dtype=torch.float32, device=self.device)
             sn = torch.empty_like(sp)
-        wptr = self._workspace(packed.ws_bytes)
+        if workspace is None:
+            wptr = self._workspace(packed.ws_bytes)
+        else:
+            if workspace.numel() < packed.ws_bytes + 256 or workspace.device != self.device:
+                raise ValueError('workspace too small for this packed step')
+            wptr = (workspace.data_ptr() + 255) // 256 * 256
         with torch.cuda.device(self.device):
             st = ops.lib().mpqe_step_forward_backward(
                 ctypes.byref(self.P), packed.batches, packed.nb, packed.anchor_ids.data_ptr(),
@@ -270,21 +291,23 @@ class FusedTrainStep(object):
         return loss
 
     def capture(self, packed, backward=True, zero_grad=True):
-        """Record one step on `packed` into a hipGraph. Returns (graph, loss): graph.replay() re-runs
-        the step on the buffers of `packed` (refill them in place for a new set of queries of the same
-        formulas) and leaves the losses in `loss`. The library call is capturable because it neither
-        allocates nor synchronises once the descriptor table is resident, which the warm run ensures."""
-        if self.uses_chain(packed):
-            # measured on ROCm 7.2 / gfx950: replaying the captured chain form ended in a GPU memory access fault
-            # (the chain kernel's 80 KB of static LDS is the suspect: the level form, <= 64 KB per kernel, replays
-            # fine). Not worth a second fault to find out; the chain form is 4 launches per step anyway.
-            raise NotImplementedError('hipGraph capture covers the level form only: FusedTrainStep(model, chain=False)')
-        self.run(packed, backward, zero_grad)
+        """Record one step on `packed` into a hipGraph. Returns a CapturedStep: .replay() re-runs the step on
+        the buffers of `packed` (refill them in place for a new set of queries of the same formulas) and
+        leaves the losses in .loss. The library call is capturable because it neither allocates nor
+        synchronises once the descriptor table is resident, which the warm run ensures.
+
+        Every capture owns its workspace: the graph's kernel nodes hold the arena's ADDRESS, so it must stay
+        mapped for as long as the graph may be replayed. (Round 1 captured into the step object's shared arena,
+        which the next, larger packed step re-allocated -- torch.cuda.graph's empty_cache() then returned the
+        old block to the driver and an earlier graph replayed into unmapped memory: the 'memory access fault'
+        the chain form showed. The level form had the same exposure.)"""
+        ws = torch.empty(packed.ws_bytes + 256, dtype=torch.uint8, device=self.device)
+        self.run(packed, backward, zero_grad, workspace=ws)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            loss = self.run(packed, backward, zero_grad)
-        return graph, loss
+            loss = self.run(packed, backward, zero_grad, workspace=ws)
+        return CapturedStep(graph, loss, ws, packed)
 
     def check(self):
         """Raise IndexError if any kernel of a previous run saw an invalid entity id (one D2H read)."""

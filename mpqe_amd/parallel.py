@@ -34,11 +34,21 @@ class GradReducer(object):
         return self.flat.numel() * 4
 
     def all_reduce(self):
-        """grad <- (1/world) * sum over ranks of grad, for every parameter."""
-        have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
-        self.flat.zero_()
-        if have:
-            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        """grad <- (1/world) * sum over ranks of grad, for every parameter. After the first call every p.grad IS
+        its view of the bucket, and autograd (zero_grad(set_to_none=False), gradient accumulation) keeps
+        accumulating into it in place: such gradients are already where the all-reduce reads them and must
+        not be cleared; only parameters without a gradient contribute zeros, and gradients autograd allocated
+        elsewhere are copied in."""
+        copy_to, copy_from = [], []
+        for v, p in zip(self.views, self.params):
+            g = p.grad
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr() or g.shape != v.shape:
+                copy_to.append(v)
+                copy_from.append(g)
+        if copy_to:
+            torch._foreach_copy_(copy_to, copy_from)
         if self.world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         if self.scale != 1.0:

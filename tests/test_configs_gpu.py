@@ -62,7 +62,8 @@ def grads(model):
     return {k: p.grad.detach().clone() for k, p in model.named_parameters()}
 
 
-@pytest.mark.parametrize('kg,D,readout,adaptive', [('mutag', 256, 'sum', False),      # configs[2]
+@pytest.mark.parametrize('kg,D,readout,adaptive', [('aifb', 128, 'mp', True),        # configs[1], the benchmarked one
+                                                   ('mutag', 256, 'sum', False),      # configs[2]
                                                    ('am', 128, 'max', False)])        # configs[3]
 def test_full_mix_fused_equals_modules_and_oracle(kg, D, readout, adaptive):
     from mpqe_amd import ops, synthetic
@@ -145,3 +146,55 @@ def test_stress_shape_properties():
     _, p2, n2 = step.run(step.pack(shuffled), scores=True)
     for j in range(2):
         assert torch.equal(p2[j * B:(j + 1) * B], sp[j * B:(j + 1) * B][torch.from_numpy(perm).cuda()])
+
+
+BENCH_WEIGHTS = {'1-chain': 1.0, 'chain': 0.01, 'inter': 0.005}      # reference train_helpers.py:60-61, 97-112
+
+
+@pytest.mark.parametrize('flags', ['default', 'no_prune', 'no_uniform', 'no_chain'])
+def test_benchmarked_workload_against_oracle(flags):
+    """BASELINE.json configs[1] exactly as bench.py times it -- AIFB-shaped KG, the 11-batch post-burn-in mix at
+    B = 512, D = 128, readout mp (TM), adaptive, num_layers 3 unshared, the reference's loss weights -- through the
+    fused step (the chain kernel with liveness pruning, XCD placement with holes, paired blocks) against the CPU
+    oracle in the reference's op sequence on ALL 11 batches: every score (rtol 1e-5), the loss, every parameter
+    gradient (rtol 1e-4). Run with the speed switches on (default) and off."""
+    from mpqe_amd import synthetic
+    from mpqe_amd.fused import FusedTrainStep
+    from oracle import ref_cpu
+    schema, node_maps, model = build('aifb', 128, 'mp', True)
+    cpu_params = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    model = model.to('cuda:0')
+    rng = np.random.RandomState(1000)
+    batches = []
+    for qt, _ in synthetic.FULL_MIX:
+        b = draw(schema, qt, 512, rng)
+        b['weight'] = 1.0 if qt == '1-chain' else (BENCH_WEIGHTS['inter'] if 'inter' in qt else BENCH_WEIGHTS['chain'])
+        batches.append(b)
+    kw = dict(default={}, no_prune=dict(prune=False), no_uniform=dict(uniform=False), no_chain=dict(chain=False))[flags]
+    step = FusedTrainStep(model, **kw)
+    packed = step.pack(batches)
+    assert step.uses_chain(packed) == (flags != 'no_chain')
+    loss, sp, sn = step.run(packed, scores=True)
+    step.check()
+    sp, sn, loss = sp.cpu().numpy(), sn.cpu().numpy(), loss.cpu().numpy()
+    cfg = dict(readout='mp', scatter_op='add', num_layers=3, adaptive=True, weight_decay=0)
+    torch.set_num_threads(min(16, max(1, len(__import__('os').sched_getaffinity(0)))))
+    total, off = 0, 0
+    for i, b in enumerate(batches):
+        queries = [type('Q', (), {'anchor_nodes': tuple(int(v) for v in row)})() for row in b['anchor_ids']]
+        col = ref_cpu.collate(b['formula'], queries, model.rel_ids, model.mode_ids)
+        q = ref_cpu.encode_queries(cpu_params, cfg, node_maps, b['formula'], col)
+        pos = ref_cpu.score(cpu_params, node_maps, b['formula'], q, b['targets'])
+        neg = ref_cpu.score(cpu_params, node_maps, b['formula'], q, b['negs'])
+        np.testing.assert_allclose(sp[off:off + 512], pos.detach().numpy(), rtol=1e-5, atol=1e-6, err_msg='batch %d' % i)
+        np.testing.assert_allclose(sn[off:off + 512], neg.detach().numpy(), rtol=1e-5, atol=1e-6, err_msg='batch %d' % i)
+        l = torch.clamp(1.0 - (pos - neg), min=0).mean()
+        np.testing.assert_allclose(loss[1 + packed.order.index(i)], l.item(), rtol=1e-5, atol=1e-6)
+        total = total + b['weight'] * l
+        off += 512
+    np.testing.assert_allclose(loss[0], total.item(), rtol=1e-5, atol=1e-6)
+    total.backward()
+    for k, p in model.named_parameters():
+        ref = cpu_params[k].grad
+        ref = torch.zeros_like(cpu_params[k]) if ref is None else ref
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-6, err_msg=k)

@@ -191,3 +191,39 @@ def test_evaluation_loop_on_gpu_matches_oracle():
     assert abs(auc - auc_ref) < 1e-3 and abs(perc - perc_ref) < 0.2     # a near-tie may swap one pair
     for f in per:
         assert abs(per[f] - per_ref[f]) < 2e-3
+
+
+@pytest.mark.parametrize('chain', [True, False])
+def test_captured_steps_own_their_workspace(chain):
+    """hipGraph replay of the fused step, chain form and level form. Two packed steps whose workspaces differ in
+    size are captured one after the other (round 1 captured into ONE shared arena: capturing the second step
+    re-allocated it and the first graph replayed into freed memory -- the 'memory access fault' of the chain form);
+    then every graph is replayed, the first one last, and compared with a plain run of the same packed step."""
+    from mpqe_amd.fused import FusedTrainStep
+    model, batches = _setup('mp', True, False, D=64, B=96)
+    step = FusedTrainStep(model, chain=chain)
+    small = step.pack(batches[:4])
+    large = step.pack([dict(b) for b in batches] )
+    assert large.ws_bytes > small.ws_bytes
+    assert step.uses_chain(small) == chain
+    ref = {}
+    for name, p in (('small', small), ('large', large)):
+        loss = step.run(p)
+        ref[name] = (loss.clone(), {k: q.grad.clone() for k, q in model.named_parameters()})
+    cap_small = step.capture(small)
+    cap_large = step.capture(large)          # a second, larger arena: the first graph's must stay alive
+    torch.cuda.empty_cache()
+    junk = torch.full((64 << 20,), float('nan'), device='cuda:0')      # whatever was freed gets overwritten
+    del junk
+    for name, cap in (('large', cap_large), ('small', cap_small), ('large', cap_large), ('small', cap_small)):
+        for q in model.parameters():
+            q.grad.fill_(7.0)                 # the step zero-fills the gradients itself
+        loss = cap.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(loss.cpu().numpy(), ref[name][0].cpu().numpy())
+        for k, q in model.named_parameters():
+            if k.startswith('enc.'):          # entity tables: fp32 atomics, order-dependent last bits
+                np.testing.assert_allclose(q.grad.cpu().numpy(), ref[name][1][k].cpu().numpy(), rtol=1e-5, atol=1e-7)
+            else:
+                assert torch.equal(q.grad, ref[name][1][k]), (name, k)
+    step.check()

@@ -54,6 +54,19 @@ def _worker(rank, world, port, out):
         (model.w[rank].sum() * 2.0).backward()
         red.all_reduce()
         out[rank + world] = {k: p.grad.clone() for k, p in model.named_parameters()}
+        # third step under zero_grad(set_to_none=False): every p.grad is now a view of the bucket and autograd
+        # accumulates into it in place -- the reducer must reduce those values, not clear them first
+        model.zero_grad(set_to_none=False)
+        model.loss(ids[lo:hi], rank).backward()
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(red.params, red.views))
+        red.all_reduce()
+        out[rank + 2 * world] = {k: p.grad.clone() for k, p in model.named_parameters()}
+        # and gradient accumulation over two micro-batches without any zero_grad in between
+        model.zero_grad(set_to_none=False)
+        model.loss(ids[lo:hi], rank).backward()
+        model.loss(ids[lo:hi], rank).backward()
+        red.all_reduce()
+        out[rank + 3 * world] = {k: p.grad.clone() for k, p in model.named_parameters()}
     finally:
         dist.destroy_process_group()
 
@@ -76,6 +89,10 @@ def test_grad_bucket_allreduce_world2():
         np.testing.assert_array_equal(out[0][k].numpy(), out[1][k].numpy())
     assert float(out[2]['table'].abs().max()) == 0.0 and float(out[3]['table'].abs().max()) == 0.0
     np.testing.assert_allclose(out[2]['w'].numpy(), np.ones((2, 4, 4), np.float32))   # 2.0 * (1/2) each
+    for k, p in model.named_parameters():          # set_to_none=False: same gradient as the first step
+        np.testing.assert_allclose(out[4][k].numpy(), p.grad.numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_array_equal(out[4][k].numpy(), out[5][k].numpy())
+        np.testing.assert_allclose(out[6][k].numpy(), 2 * p.grad.numpy(), rtol=1e-6, atol=1e-7)   # accumulated twice
 
 
 @pytest.mark.parametrize('n,world', [(512, 8), (513, 8), (5, 8), (0, 2), (7, 3)])

@@ -123,19 +123,6 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
     d_tg = be.put(np.concatenate([b['targets'] for b in batches]))
     d_ng = be.put(np.concatenate([b['negs'] for b in batches]))
     Gtot = sum(b['B'] for b in batches)
-    wsb = be.lib.mpqe_step_workspace_bytes(ctypes.byref(P), SB, nb)
-    assert wsb > 0
-    ws = be.nbytes(wsb + 256)
-    if be.name == 'emu':          # node states the step skips must never be read: poison the arena
-        ws.fill(np.nan)
-    else:
-        ws.fill_(float('nan'))
-    wptr = (be.ptr(ws) + 255) // 256 * 256
-    dsb = be.lib.mpqe_step_desc_bytes(ctypes.byref(P), SB, nb)
-    dbuf = be.nbytes(dsb + 256)
-    dptr = (be.ptr(dbuf) + 255) // 256 * 256
-    loss = be.empty((1 + nb,))
-    sp, sn = be.empty((Gtot,)), be.empty((Gtot,))
     keep = []
     if lanes is not None:
         splits = lanes
@@ -158,6 +145,20 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
             for l in range(1, lanes.num_lanes):
                 lanes.aux_stream[l], lanes.join_event[l] = 1, 1
         lanes = ctypes.byref(lanes)
+    wsb = be.lib.mpqe_step_workspace_bytes(ctypes.byref(P), SB, nb, lanes)
+    if wsb == 0:
+        raise _capi.MpqeError('mpqe_step_workspace_bytes rejected the step descriptors')
+    ws = be.nbytes(wsb + 256)
+    if be.name == 'emu':          # node states the step skips must never be read: poison the arena
+        ws.fill(np.nan)
+    else:
+        ws.fill_(float('nan'))
+    wptr = (be.ptr(ws) + 255) // 256 * 256
+    dsb = be.lib.mpqe_step_desc_bytes(ctypes.byref(P), SB, nb, lanes)
+    dbuf = be.nbytes(dsb + 256)
+    dptr = (be.ptr(dbuf) + 255) // 256 * 256
+    loss = be.empty((1 + nb,))
+    sp, sn = be.empty((Gtot,)), be.empty((Gtot,))
     err = be.zeros((1,), np.int32)
     be.check(be.lib.mpqe_step_forward_backward(ctypes.byref(P), SB, nb, be.ptr(d_anchor), be.ptr(d_tg),
                                                be.ptr(d_ng), margin, ctypes.byref(G), backward, be.ptr(loss),
@@ -384,5 +385,5 @@ def test_fused_step_flags_bad_entity(be):
 def test_fused_step_rejects_bad_descriptors(be):
     P = _capi.StepParams()
     SB = (_capi.StepBatch * 1)()
-    assert be.lib.mpqe_step_workspace_bytes(ctypes.byref(P), SB, 1) == 0          # dim 0
-    assert be.lib.mpqe_step_workspace_bytes(ctypes.byref(P), SB, 17) == 0         # > MAX_BATCHES
+    assert be.lib.mpqe_step_workspace_bytes(ctypes.byref(P), SB, 1, None) == 0          # dim 0
+    assert be.lib.mpqe_step_workspace_bytes(ctypes.byref(P), SB, 17, None) == 0         # > MAX_BATCHES
