@@ -52,6 +52,8 @@ def parse():
                     help='1: replay each step from a captured hipGraph')
     ap.add_argument('--no-prune', action='store_true', help='compute node states that cannot reach the readout too')
     ap.add_argument('--no-chain', action='store_true', help='one launch per message-passing level')
+    ap.add_argument('--no-uniform', action='store_true',
+                    help='chain form: node states no anchor has reached yet as per-graph rows instead of one vector per batch')
     ap.add_argument('--no-ksplit', action='store_true', help='dim 128: chain waves own 32 columns and all of K')
     ap.add_argument('--eight-waves', action='store_true', help='dim 128: chain workgroups of eight waves (experimental)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
@@ -155,7 +157,8 @@ def time_fused_kernels(step, packed, data, model, readout, reps=20):
     # library batch i = bench batch packed.order[i]; lane l owns library batches [lane_begin[l], lane_begin[l+1])
     tmpl = [data.batches[j]['graph'].template for j in packed.order]
     Ls = [RGCNQueryDataset.query_diameters[t.query_type] if model.adaptive else model.num_layers for t in tmpl]
-    units = [live_units(t.query_type, L, readout, prune) for t, L in zip(tmpl, Ls)]
+    units = [live_units(t.query_type, L, readout, prune, step.uniform and step.uses_chain(packed))
+             for t, L in zip(tmpl, Ls)]
     Lmax = max(Ls)
 
     def flops(lo, hi, p):
@@ -165,9 +168,10 @@ def time_fused_kernels(step, packed, data, model, readout, reps=20):
     lanes = [(packed.lane_begin[l], packed.lane_begin[l + 1]) for l in range(len(packed.lane_begin) - 1)]
     lane_total = [sum(flops(lo, hi, p) for p in range(Lmax)) for lo, hi in lanes]
     if step.uses_chain(packed):
-        # per lane: forward + backward-x levels (+ gather, scores) in one launch; then per lane its weight gradients
-        plan += [('step_chain_kernel', 2.0 * t) for t in lane_total]
-        plan += [('step_tail_kernel', t) for t in lane_total]
+        # forward + backward-x levels (+ gather, scores) in one launch; then the weight gradients (the chain form
+        # runs on the caller's stream whatever the lane split)
+        plan += [('step_chain_kernel', 2.0 * total)]
+        plan += [('step_tail_kernel', total)]
     else:
         for p in range(Lmax):
             plan += [('step_layer_fwd_kernel', flops(lo, hi, p)) for lo, hi in lanes if max(Ls[lo:hi]) > p]
@@ -399,7 +403,7 @@ def main():
     if use_fused:
         from mpqe_amd.fused import FusedTrainStep
         fstep = FusedTrainStep(model, lanes=args.lanes, prune=not args.no_prune, chain=not args.no_chain,
-                               ksplit=not args.no_ksplit, eight_waves=args.eight_waves)
+                               ksplit=not args.no_ksplit, eight_waves=args.eight_waves, uniform=not args.no_uniform)
         packed = [pack_for_fused(fstep, d, 1.0 / world) for d in pool]
         captured = [fstep.capture(p) for p in packed] if args.graph else None
     elif world > 1:

@@ -41,6 +41,8 @@ extern "C" {
 #define MPQE_FLAG_BAD_EDGE 2         /* edge endpoint outside [0, num_nodes)           */
 #define MPQE_FLAG_BAD_RELATION 4     /* edge type outside [0, num_relations)           */
 #define MPQE_FLAG_BAD_INDEX 8        /* scatter index outside [0, dim_size)            */
+#define MPQE_FLAG_INTERNAL 16        /* a hand-off between workgroups inside a launch did
+                                        not arrive within its spin bound (library fault)  */
 
 /* query templates, reference data_utils.py:325-362 */
 enum {

@@ -50,6 +50,10 @@ struct BatchDev {
     // computed nor read: its gradient is exactly zero (MPQE_STEP_NO_PRUNE: all slots at every level).
     unsigned live[MPQE_STEP_MAX_LAYERS + 1];
     int pad2;
+    // chain form. uvL[n] >= 0: node slot n is still batch-uniform at level L; its state is that vector of the vector
+    // table (the readout reads it in every row). lpart[n] >= 0: first row in `parts` of the per-block column sums of
+    // gH[L][n] (row = lpart[n] + block index inside the batch).
+    int uvL[4], lpart[4];
 };
 
 struct StepDev {
@@ -109,11 +113,52 @@ struct VSource {
     int nblk, part_start, block_start, pad;
 };
 // one reduction group: out[...] += sum of `count` consecutive slabs/partials starting at `start`
+// (+ matrices, chain form with uniform node states: the sum of r1_count rank-1 terms u (x) v from `r1_start` on)
 struct RGroup {
     int kind;          // 0 basis, 1 root, 2 bias, 3 mode row
     int layer;         // layer index (kinds 0-2)
     long long row;     // relation id (kind 0) / mode id (kind 3)
     int start, count;
+    int r1_start, r1_count;
+};
+struct Rank1 {
+    int u, v;          // vector ids: out[i][j] += VT[u][i] * VT[v][j]
+};
+
+// ---- batch-uniform node states (chain form; include/mpqe_amd.h: MPQE_STEP_NO_UNIFORM) --------------------------
+// x0's variable rows are ONE mode_embeddings row for every graph of a batch (reference model.py:421), so a node state
+// that no anchor has reached yet is one vector per batch. Per batch and level p the node slots split into uniform
+// (U) and per-graph (NU) ones: U[0] = the variable slots, n in U[p+1] iff n and all sources of its in-edges are in
+// U[p]. Consequences, all exact:
+//   forward   a U node update is a matrix-VECTOR product chain, done once per batch (UOP_FWD, pre-pass, rides in the
+//             prologue launch). An NU node's U sources add a constant vector to its pre-activation: the pre-pass
+//             forms bias + that constant, the chain kernel's epilogue adds it where it added the bias.
+//   backward  everything downstream of a U node's gradient needs only its COLUMN SUM over the batch (its inputs
+//             are uniform, so its weight gradients are rank-1: u (x) colsum; its ReLU mask is uniform, so masking
+//             commutes with the sum; bias / variable-row gradients are column sums anyway). The chain kernel leaves
+//             per-block column sums of every NU node's gradient rows in `parts`; the post-pass (rides in the
+//             weight-gradient launch) sums them over the blocks (UOP_RED) and runs the U nodes' backward as
+//             vector-matrix^T products on those sums (UOP_BWD).
+// Vectors live in the vector table VT [id][D] of the workspace; vectors that are handed from one workgroup to
+// another INSIDE a launch also travel as {tag, value} granules (8 bytes, one agent-scope atomic store each: the data
+// is its own flag -- MI355X guide, inter-workgroup visibility, form R2) in the packed step's descriptor buffer.
+#define UOP_FWD 0      // out = act(bias[layer] + sum_t in_t . M_t)
+#define UOP_BWD 1      // out = mask(VT[mask_vec] > 0) * sum_t in_t . M_t^T
+#define UOP_RED 2      // out = sum of `nrows` consecutive rows of `parts` from row0
+#define UOP_COPY 3     // out = mode_emb[mode_row]
+#define UOP_MAX_TERMS 4
+struct UOp {
+    int kind, out_vec, out_gran;       // out_gran: granule slot of the output (-1: nobody reads it inside the launch)
+    int out_part;                      // >= 0: the output is also written to this row of `parts` (a reduction group's input)
+    int nterms;
+    int in_vec[UOP_MAX_TERMS];         // vector id (in_kind 0: read from its granules; 2: plain, written by an earlier launch)
+    int in_kind[UOP_MAX_TERMS];        // 0 granules, 1 row in_vec of mode_emb, 2 plain VT
+    int in_gran[UOP_MAX_TERMS];
+    int layer[UOP_MAX_TERMS], mat[UOP_MAX_TERMS];      // matrix: relation id or -1 = root, of layer `layer`
+    int bias_layer, relu;              // FWD
+    int mask_vec;                      // BWD: -1 = no mask
+    int row0, nrows;                   // RED
+    long long mode_row;                // COPY
 };
 
 struct Blob {
@@ -173,6 +218,7 @@ __device__ __forceinline__ long long table_row(const long long *__restrict__ nod
 }
 
 #include "step_chain.h"
+#include "step_uniform.h"
 
 template <int NCB, int KS, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void step_chain_kernel(const StepDev *__restrict__ sd, LayerPtrs lp,
@@ -196,9 +242,16 @@ struct ZeroSegs {
 };
 #define PREP_ZERO_FLOATS_PER_BLOCK 8192      // 256 threads x 8 x float4
 __global__ __launch_bounds__(256) void step_prep_kernel(LayerPtrs lp, const WtSlot *__restrict__ slots, int nslots, int D,
-                                                        float *__restrict__ WT, int tblocks, ZeroSegs zs) {
+                                                        float *__restrict__ WT, int tblocks, ZeroSegs zs, UArgs ua,
+                                                        int ublocks) {
     __shared__ float tile[32][33];
-    const int bid = blockIdx.x;
+    // the forward pre-pass of the batch-uniform node states takes the first workgroups of the launch (a dependence
+    // chain of up to L levels: started first, and its producers are dispatched before their consumers)
+    if ((int)blockIdx.x < ublocks) {
+        uop_block((int)blockIdx.x, D, lp, ua, &tile[0][0]);
+        return;
+    }
+    const int bid = (int)blockIdx.x - ublocks;
     if (bid < tblocks) {
         const int tpd = (D + 31) / 32, per = tpd * tpd;
         const int si = bid / per, tr = (bid % per) / tpd, tc = bid % tpd;
@@ -713,6 +766,7 @@ struct TailArgs {
     long long *stamps;       // diagnostics (mpqe_debug_tail_stamps): 8 words per workgroup, or NULL
     const ZMat *zmats;       // untouched gradient matrices, zero-filled by workgroups [wblocks, wblocks + zblocks)
     int zblocks, zper;       // zper = workgroups per matrix
+    int ublocks;             // the backward post-pass of the uniform node states: the FIRST ublocks workgroups
     const long long *node_map;
     long long map_len;
     const long long *anchor_ids;
@@ -722,7 +776,8 @@ struct TailArgs {
 template <int MODE>
 __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restrict__ sd, TailArgs ta,
                                                         const float *__restrict__ H, const float *__restrict__ GH,
-                                                        long long level_stride, GradPtrs gp, int zeroed) {
+                                                        long long level_stride, GradPtrs gp, int zeroed, LayerPtrs lp,
+                                                        UArgs ua) {
     // weight-gradient tiles only: the DMA ring takes 64 KB of LDS per workgroup, which would throttle the
     // thousands of light partial-sum / anchor workgroups to 2 per CU if they shared this kernel
     __shared__ __attribute__((aligned(16))) float smem[MODE == LD_FAST ? GWD_SMEM_FLOATS : GT_SMEM_FLOATS];
@@ -735,8 +790,13 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
                                                    ((long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
     }
 #endif
-    if ((int)blockIdx.x >= ta.wblocks) {        // zero fill of a gradient matrix nobody writes (uniform branch)
-        const int zb = (int)blockIdx.x - ta.wblocks;
+    if ((int)blockIdx.x < ta.ublocks) {         // uniform node states, backward: vector ops on column sums
+        uop_block((int)blockIdx.x, sd->D, lp, ua, smem);
+        return;
+    }
+    const int tb = (int)blockIdx.x - ta.ublocks;
+    if (tb >= ta.wblocks) {        // zero fill of a gradient matrix nobody writes (uniform branch)
+        const int zb = tb - ta.wblocks;
         const ZMat zm = ta.zmats[zb / ta.zper];
         float *base = pick_grad(gp.basis, zm.layer);
         if (!base) return;
@@ -750,7 +810,7 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
         }
         return;
     }
-    grad_w_block<MODE>(sd, ta.wsrc, ta.nwsrc, ta.wblock, H, GH, level_stride, ta.slabs, (int)blockIdx.x, ta.wblocks,
+    grad_w_block<MODE>(sd, ta.wsrc, ta.nwsrc, ta.wblock, H, GH, level_stride, ta.slabs, tb, ta.wblocks,
                        smem, gp, zeroed != 0, ta.stamps ? ta.stamps + (long long)blockIdx.x * 8 : nullptr);      // zeroed: this call zero-filled the gradients, a store suffices
 #ifndef MPQE_EMU
     if (ta.stamps && threadIdx.x == 0) {
@@ -785,12 +845,16 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restri
                                                           const StepDev *__restrict__ sd,
                                                           const float *__restrict__ terms,
                                                           float *__restrict__ loss, int zeroed, LossMeta lm,
-                                                          const float *__restrict__ bterms) {
+                                                          const float *__restrict__ bterms,
+                                                          const Rank1 *__restrict__ rank1,
+                                                          const float *__restrict__ VT, unsigned *epoch_b) {
     // zeroed: this call zero-filled the gradients, so `out` is known to be 0 -- a store replaces the
     // read-modify-write (whose read would be one more dependent round trip at the end of the chain)
     __shared__ f32x4 part[4][64];
     if ((int)blockIdx.y == ngroups) {       // one extra workgroup row: the loss reduction rides along
         if (blockIdx.x == 0) {
+            // the backward post-pass of this step is over: the next step's granules get a new tag (step_uniform.h)
+            if (epoch_b && threadIdx.x == 0) *epoch_b = *epoch_b + 1u;
             if (lm.chain) loss_block_chain(lm, bterms, loss, reinterpret_cast<float *>(part), 4);
             else loss_block(sd, terms, loss, reinterpret_cast<float *>(part), 4);
         }
@@ -866,10 +930,22 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restri
     __syncthreads();
     if (sg != 0 || !dst) return;
     const bool have_old = vec && !zeroed && idx + 3 < elems;
+    // rank-1 terms of a matrix group (sources whose input state is one vector per batch: out[i][j] += u[i] v[j],
+    // v = the column sum of the destination's gradient rows), added in table order after the slabs
+    f32x4 r1 = {0.f, 0.f, 0.f, 0.f};
+    if (g.kind <= 1 && g.r1_count > 0 && idx < elems) {
+        for (int t = 0; t < g.r1_count; ++t) {
+            const Rank1 rk = rank1[g.r1_start + t];
+            const float *u = VT + (long long)rk.u * D, *v = VT + (long long)rk.v * D;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (idx + k < elems) r1[k] += u[(idx + k) / D] * v[(idx + k) % D];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (idx + k < elems) {
-            const float sum = (part[0][el][k] + part[1][el][k]) + (part[2][el][k] + part[3][el][k]);
+            const float sum = ((part[0][el][k] + part[1][el][k]) + (part[2][el][k] + part[3][el][k])) + r1[k];
             dst[idx + k] = zeroed ? sum : (have_old ? old4[k] : dst[idx + k]) + sum;
         }
 }
@@ -900,12 +976,17 @@ struct HostPlan {
     int cref_begin[MPQE_STEP_MAX_LANES + 1];
     std::vector<ChainOp> cops;
     std::vector<WtSlot> wt_slots;     // matrices with a transposed copy (those of the backward programmes)
-    ChainParts cparts[MPQE_STEP_MAX_BATCHES];
+    // batch-uniform node states: vector ops of the forward pre-pass / backward post-pass, rank-1 weight-gradient terms
+    bool chain, uniform;
+    std::vector<UOp> uops_f, uops_b;
+    std::vector<Rank1> rank1;
+    int nvec, ngran;
+    size_t o_uopf, o_uopb, o_rank1, o_epoch, o_gran, o_VT;
     int blk_off[MPQE_STEP_MAX_BATCHES + 1];        // chain blocks before batch i (slots of block_terms)
     std::vector<ZMat> zmats;                       // relation matrices of the gradient that no source touches
     size_t o_zmats;
     size_t o_bterms;
-    size_t o_cref, o_cops, o_wtslots, o_cparts, o_WT;
+    size_t o_cref, o_cops, o_wtslots, o_WT;
     // workspace offsets (bytes)
     size_t o_sd, o_wsrc, o_wblock, o_vsrc, o_vblock, o_groups, o_anchor, desc_total;     // descriptor buffer
     size_t o_H, o_GH, o_tpos, o_tneg, o_spos, o_sneg, o_terms, o_slabs, o_parts, total;  // workspace
@@ -950,12 +1031,14 @@ void place_tiles(const std::vector<TileRef> &in, const std::vector<int> &steps, 
 }
 
 int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, const mpqe_step_lanes_t *lanes,
-              HostPlan *hp) {
+              bool chain, HostPlan *hp) {
     if (!P || !B || nb <= 0 || nb > MPQE_STEP_MAX_BATCHES) return MPQE_ERR_INVALID_ARG;
+    hp->chain = chain;
     hp->nlanes = 1;
     hp->lane_begin[0] = 0;
     hp->lane_begin[1] = nb;
-    if (lanes && lanes->num_lanes > 1) {
+    // (the chain form is ONE launch per step on the caller's stream: a lane split only re-orders the batches)
+    if (!chain && lanes && lanes->num_lanes > 1) {
         if (lanes->num_lanes > MPQE_STEP_MAX_LANES) return MPQE_ERR_INVALID_ARG;
         hp->nlanes = lanes->num_lanes;
         for (int l = 0; l <= hp->nlanes; ++l) hp->lane_begin[l] = lanes->batch_begin[l];
@@ -1039,7 +1122,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         hp->lane_Lmax[l] = 0;
         for (int i = hp->lane_begin[l]; i < hp->lane_begin[l + 1]; ++i)
             if (sd.b[i].L > hp->lane_Lmax[l]) hp->lane_Lmax[l] = sd.b[i].L;
-        for (int p = 0; p < STEP_MAX_LEVELS; ++p)
+        for (int p = 0; p < STEP_MAX_LEVELS && !chain; ++p)     // (the chain form has no per-level launches)
             for (int dir = 0; dir < 2; ++dir) {
                 std::vector<TileGroup> g;
                 for (int i = hp->lane_begin[l]; i < hp->lane_begin[l + 1]; ++i) {
@@ -1083,28 +1166,94 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                 break;
             }
     }
+    // ---- batch-uniform node states (see UOp): uni[i][p] = node slots of batch i that are one vector per batch at level p
+    const bool uniform = chain && !(P->flags & MPQE_STEP_NO_UNIFORM);
+    hp->uniform = uniform;
+    unsigned uni[MPQE_STEP_MAX_BATCHES][MPQE_STEP_MAX_LAYERS + 1];
+    for (int i = 0; i < nb; ++i) {
+        const BatchDev &d = sd.b[i];
+        const TmplArgs &tp = d.tp;
+        uni[i][0] = uniform ? (((1u << tp.N) - 1u) & ~((1u << d.A) - 1u)) : 0u;
+        for (int p = 0; p < d.L; ++p) {
+            unsigned m = uni[i][p];
+            for (int e = 0; e < tp.E; ++e)
+                if (!((uni[i][p] >> tp.src[e]) & 1u)) m &= ~(1u << tp.dst[e]);
+            uni[i][p + 1] = m;
+        }
+    }
+    // vector table ids: (kind, batch, level, node slot) -> row of VT; granule slots only for vectors another
+    // workgroup of the producing launch reads
+    enum { V_UV = 0, V_CV = 1, V_SV = 2 };
+    struct VecInfo {
+        int kind, batch, level, node;
+    };
+    std::vector<VecInfo> vinfo;
+    std::vector<int> gran_of;
+    std::unordered_map<long long, int> vec_of;
+    auto vec = [&](int kind, int i, int p, int n) -> int {
+        const long long key = (((long long)kind * MPQE_STEP_MAX_BATCHES + i) * (MPQE_STEP_MAX_LAYERS + 1) + p) * 4 + n;
+        auto it = vec_of.find(key);
+        if (it != vec_of.end()) return it->second;
+        const int id = (int)vinfo.size();
+        vinfo.push_back(VecInfo{kind, i, p, n});
+        gran_of.push_back(-1);
+        vec_of[key] = id;
+        return id;
+    };
+    int ngran = 0;
+    auto gran = [&](int v) -> int {
+        if (gran_of[v] < 0) gran_of[v] = ngran++;
+        return gran_of[v];
+    };
+    auto layer_of = [&](int i, int p) { return p < sd.b[i].L - 1 ? p : P->num_layers - 1; };      // reference model.py:435-441
+
     // weight-gradient sources, ordered by (unique layer, relation | root) so every reduction group
-    // owns a contiguous slab range
+    // owns a contiguous slab range. A source whose input state is batch-uniform is a rank-1 term u (x) colsum
+    // of the reduction instead of a K = batch tile.
     struct Key {
         int layer;
         long long rel;     // relation id, or -1 for root
         int batch, level, slot;
     };
+    struct R1Key {
+        int layer;
+        long long rel;
+        Rank1 t;
+    };
     std::vector<Key> keys;
+    std::vector<R1Key> r1keys;
+    std::vector<char> sv_needed;       // per vector id: somebody reads this column-sum vector
+    std::vector<int> copy_vecs;        // UV vectors of level 0 (mode rows) the rank-1 terms read
+    auto need_sv = [&](int v) {
+        if (sv_needed.size() <= (size_t)v) sv_needed.resize(v + 1, 0);
+        sv_needed[v] = 1;
+    };
     for (int i = 0; i < nb; ++i)
         for (int p = 0; p < sd.b[i].L; ++p) {
-            const int li = uid[p < sd.b[i].L - 1 ? p : P->num_layers - 1];
+            const int li = uid[layer_of(i, p)];
             const unsigned lout = sd.b[i].live[p + 1];
             const TmplArgs &tp = sd.b[i].tp;
+            auto add = [&](int slot, int s, int dnode, long long rel) {
+                if (!((uni[i][p] >> s) & 1u)) {
+                    keys.push_back(Key{li, rel, i, p, slot});
+                    return;
+                }
+                const size_t before = vinfo.size();
+                const int u = vec(V_UV, i, p, s), v = vec(V_SV, i, p + 1, dnode);
+                if (p == 0 && (size_t)u >= before) copy_vecs.push_back(u);      // (first use of this mode row's copy)
+                need_sv(v);
+                r1keys.push_back(R1Key{li, rel, Rank1{u, v}});
+            };
             for (int z = 0; z < tp.E; ++z)
-                if ((lout >> tp.dst[z]) & 1u) keys.push_back(Key{li, tp.rel[z], i, p, z});
+                if ((lout >> tp.dst[z]) & 1u) add(z, tp.src[z], tp.dst[z], tp.rel[z]);
             for (int n = 0; n < tp.N; ++n)          // root term: one source per live node slot
-                if ((lout >> n) & 1u) keys.push_back(Key{li, -1, i, p, tp.E + n});
+                if ((lout >> n) & 1u) add(tp.E + n, n, n, -1);
         }
-    std::stable_sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
-        if (a.layer != b.layer) return a.layer < b.layer;
-        return a.rel < b.rel;
-    });
+    auto key_less = [](int la, long long ra, int lb, long long rb) { return la != lb ? la < lb : ra < rb; };
+    std::stable_sort(keys.begin(), keys.end(),
+                     [&](const Key &a, const Key &b) { return key_less(a.layer, a.rel, b.layer, b.rel); });
+    std::stable_sort(r1keys.begin(), r1keys.end(),
+                     [&](const R1Key &a, const R1Key &b) { return key_less(a.layer, a.rel, b.layer, b.rel); });
     const int tiles = ct * ((D + GT_BM - 1) / GT_BM);
     // Balance: with one K-chunk per source the step has (sources x tiles) workgroups; a few more than there are
     // CUs (264 for the AIFB mix) means a handful of CUs run two whole tiles and the launch lasts twice a tile.
@@ -1133,7 +1282,6 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->wsrc.clear();
     hp->wblock.clear();
     hp->groups.clear();
-    std::vector<int> group_first_src;
     for (size_t k = 0; k < keys.size(); ++k) {
         const Key &key = keys[k];
         const BatchDev &d = sd.b[key.batch];
@@ -1154,39 +1302,55 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         s.rel = key.rel;
         hp->wsrc.push_back(s);
 
-        if (k == 0 || keys[k - 1].layer != key.layer || keys[k - 1].rel != key.rel) {
-            RGroup g;
-            g.kind = key.rel < 0 ? 1 : 0;
-            g.layer = key.layer;
-            g.row = key.rel < 0 ? 0 : key.rel;
-            g.start = slab;
-            g.count = 0;
-            hp->groups.push_back(g);
-            group_first_src.push_back((int)hp->wsrc.size() - 1);
-        }
-        hp->groups.back().count += s.nch;
         slab += s.nch;
         block += s.nch * tiles;
     }
     hp->wblocks_total = block;
     hp->total_slabs = slab;
-    // a gradient matrix with ONE contribution (one source, one K-chunk: most relation matrices, a relation
-    // rarely occurs in two batches of a step) needs no slab and no reduction: its tiles add straight into the
-    // gradient (deterministic: one writer per element)
+    // reduction groups of the gradient matrices: per (unique layer, relation | root) the slabs of its tile
+    // sources (contiguous: the sources are sorted) and its rank-1 terms. A matrix with ONE contribution that is a
+    // single-chunk tile source (most relation matrices: a relation rarely occurs in two batches of a step) needs no
+    // slab and no reduction: its tiles write straight into the gradient (deterministic: one writer per element).
     {
-        std::vector<RGroup> kept;
-        for (size_t gi = 0; gi < hp->groups.size(); ++gi) {
-            if (hp->groups[gi].count == 1) hp->wsrc[group_first_src[gi]].direct = hp->groups[gi].layer;
-            else kept.push_back(hp->groups[gi]);
-        }
-        hp->groups.swap(kept);
-        // every other relation matrix of every (unique) layer is untouched
+        hp->rank1.clear();
+        for (size_t k = 0; k < r1keys.size(); ++k) hp->rank1.push_back(r1keys[k].t);
         std::vector<char> written((size_t)P->num_layers * (size_t)P->num_relations, 0);
-        for (size_t k = 0; k < hp->wsrc.size(); ++k)
-            if (hp->wsrc[k].direct >= 0 && hp->wsrc[k].rel >= 0)
-                written[(size_t)hp->wsrc[k].direct * P->num_relations + hp->wsrc[k].rel] = 1;
-        for (size_t gi = 0; gi < hp->groups.size(); ++gi)
-            if (hp->groups[gi].kind == 0) written[(size_t)hp->groups[gi].layer * P->num_relations + hp->groups[gi].row] = 1;
+        size_t ks = 0, kr = 0;
+        while (ks < keys.size() || kr < r1keys.size()) {
+            int layer;
+            long long rel;
+            if (kr >= r1keys.size() || (ks < keys.size() && !key_less(r1keys[kr].layer, r1keys[kr].rel, keys[ks].layer,
+                                                                        keys[ks].rel))) {
+                layer = keys[ks].layer;
+                rel = keys[ks].rel;
+            } else {
+                layer = r1keys[kr].layer;
+                rel = r1keys[kr].rel;
+            }
+            RGroup g;
+            g.kind = rel < 0 ? 1 : 0;
+            g.layer = layer;
+            g.row = rel < 0 ? 0 : rel;
+            g.start = ks < keys.size() ? hp->wsrc[ks].slab_start : 0;
+            g.count = 0;
+            g.r1_start = (int)kr;
+            g.r1_count = 0;
+            const size_t first_src = ks;
+            int nsrc = 0;
+            while (ks < keys.size() && keys[ks].layer == layer && keys[ks].rel == rel) {
+                g.count += hp->wsrc[ks].nch;
+                ++nsrc;
+                ++ks;
+            }
+            while (kr < r1keys.size() && r1keys[kr].layer == layer && r1keys[kr].rel == rel) {
+                ++g.r1_count;
+                ++kr;
+            }
+            if (rel >= 0) written[(size_t)layer * P->num_relations + rel] = 1;
+            if (nsrc == 1 && g.count == 1 && g.r1_count == 0) hp->wsrc[first_src].direct = layer;
+            else hp->groups.push_back(g);
+        }
+        // every other relation matrix of every (unique) layer is untouched
         hp->zmats.clear();
         for (int l = 0; l < P->num_layers; ++l) {
             if (uid[l] != l) continue;
@@ -1225,64 +1389,224 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     }
     hp->wblock_begin[hp->nlanes] = (int)hp->wblock.size();
 
-    // vector partial sources: bias per (unique layer) and variable rows per mode id
-    struct VKey {
-        int kind, layer;
-        long long row;
-        int batch, lk;
-    };
-    std::vector<VKey> vk;
-    for (int i = 0; i < nb; ++i) {
-        for (int p = 0; p < sd.b[i].L; ++p)
-            vk.push_back(VKey{0, uid[p < sd.b[i].L - 1 ? p : P->num_layers - 1], 0, i, p});
-        for (int k = 0; k < sd.b[i].V; ++k)
-            if ((sd.b[i].live[0] >> (sd.b[i].A + k)) & 1u) vk.push_back(VKey{1, 0, sd.b[i].var_id[k], i, k});
-    }
-    std::stable_sort(vk.begin(), vk.end(), [](const VKey &a, const VKey &b) {
-        if (a.kind != b.kind) return a.kind < b.kind;
-        if (a.layer != b.layer) return a.layer < b.layer;
-        return a.row < b.row;
-    });
-    const int cchunks = (D + 63) / 64;
-    int part = 0, vblock = 0;
     hp->vsrc.clear();
     hp->vblock.clear();
-    for (int i = 0; i < MPQE_STEP_MAX_BATCHES; ++i) {
-        for (int q = 0; q < MPQE_STEP_MAX_LAYERS; ++q) hp->cparts[i].bias_part[q] = -1;
-        for (int k = 0; k < 3; ++k) hp->cparts[i].var_part[k] = -1;
-    }
-    for (size_t k = 0; k < vk.size(); ++k) {
-        const VKey &key = vk[k];
-        const BatchDev &d = sd.b[key.batch];
-        VSource s;
-        s.kind = key.kind;
-        s.batch = key.batch;
-        s.level_or_k = key.lk;
-        s.relu = 0;
-        s.nblk = (d.B + CH_GB - 1) / CH_GB;
-        // where the chain kernel's block `blk` of this batch writes its partial row: part_start + blk
-        if (key.kind == 0) hp->cparts[key.batch].bias_part[key.lk] = part;
-        else hp->cparts[key.batch].var_part[key.lk] = part;
-        s.part_start = part;
-        s.block_start = vblock;
-        s.pad = 0;
-        hp->vsrc.push_back(s);
-        for (int q = 0; q < s.nblk * cchunks; ++q) hp->vblock.push_back((int)hp->vsrc.size() - 1);
-        if (k == 0 || vk[k - 1].kind != key.kind || vk[k - 1].layer != key.layer || vk[k - 1].row != key.row) {
-            RGroup g;
-            g.kind = key.kind == 0 ? 2 : 3;
-            g.layer = key.layer;
-            g.row = key.row;
-            g.start = part;
-            g.count = 0;
-            hp->groups.push_back(g);
+    hp->vblocks_total = 0;
+    hp->uops_f.clear();
+    hp->uops_b.clear();
+    // part_row[i][p][n]: first row in `parts` of the column sums of gH[p][n] of batch i (-1: none)
+    int part_row[MPQE_STEP_MAX_BATCHES][MPQE_STEP_MAX_LAYERS + 1][4];
+    for (int i = 0; i < MPQE_STEP_MAX_BATCHES; ++i)
+        for (int q = 0; q <= MPQE_STEP_MAX_LAYERS; ++q)
+            for (int n = 0; n < 4; ++n) part_row[i][q][n] = -1;
+    if (!chain) {
+        // vector partial sources: bias per (unique layer) and variable rows per mode id
+        struct VKey {
+            int kind, layer;
+            long long row;
+            int batch, lk;
+        };
+        std::vector<VKey> vk;
+        for (int i = 0; i < nb; ++i) {
+            for (int p = 0; p < sd.b[i].L; ++p)
+                vk.push_back(VKey{0, uid[p < sd.b[i].L - 1 ? p : P->num_layers - 1], 0, i, p});
+            for (int k = 0; k < sd.b[i].V; ++k)
+                if ((sd.b[i].live[0] >> (sd.b[i].A + k)) & 1u) vk.push_back(VKey{1, 0, sd.b[i].var_id[k], i, k});
         }
-        hp->groups.back().count += s.nblk;
-        part += s.nblk;
-        vblock += s.nblk * cchunks;
+        std::stable_sort(vk.begin(), vk.end(), [](const VKey &a, const VKey &b) {
+            if (a.kind != b.kind) return a.kind < b.kind;
+            if (a.layer != b.layer) return a.layer < b.layer;
+            return a.row < b.row;
+        });
+        const int cchunks = (D + 63) / 64;
+        int part = 0, vblock = 0;
+        hp->vsrc.clear();
+        hp->vblock.clear();
+        for (size_t k = 0; k < vk.size(); ++k) {
+            const VKey &key = vk[k];
+            const BatchDev &d = sd.b[key.batch];
+            VSource s;
+            s.kind = key.kind;
+            s.batch = key.batch;
+            s.level_or_k = key.lk;
+            s.relu = 0;
+            s.nblk = (d.B + CH_GB - 1) / CH_GB;
+            s.part_start = part;
+            s.block_start = vblock;
+            s.pad = 0;
+            hp->vsrc.push_back(s);
+            for (int q = 0; q < s.nblk * cchunks; ++q) hp->vblock.push_back((int)hp->vsrc.size() - 1);
+            if (k == 0 || vk[k - 1].kind != key.kind || vk[k - 1].layer != key.layer || vk[k - 1].row != key.row) {
+                RGroup g;
+                g.kind = key.kind == 0 ? 2 : 3;
+                g.layer = key.layer;
+                g.row = key.row;
+                g.start = part;
+                g.count = 0;
+                g.r1_start = g.r1_count = 0;
+                hp->groups.push_back(g);
+            }
+            hp->groups.back().count += s.nblk;
+            part += s.nblk;
+            vblock += s.nblk * cchunks;
+        }
+        hp->vblocks_total = vblock;
+        hp->total_parts = part;
+    } else {
+        // Chain form: one row of `parts` per (batch, level >= 1, live node slot) and chain block -- the node's gradient
+        // rows summed over the block's graphs -- written by the chain kernel; a node slot that is batch-uniform below
+        // level L has ONE row instead, written by the backward post-pass (its column sum IS what the post-pass
+        // computes). Rows of one reduction group (bias of a unique layer; a mode_embeddings row) are contiguous.
+        struct VKey {
+            int kind, layer;
+            long long row;
+            int batch, level, node;
+        };
+        std::vector<VKey> vk;
+        for (int i = 0; i < nb; ++i) {
+            const BatchDev &d = sd.b[i];
+            for (int p = 1; p <= d.L; ++p)
+                for (int n = 0; n < d.tp.N; ++n)
+                    if ((d.live[p] >> n) & 1u) vk.push_back(VKey{0, uid[layer_of(i, p - 1)], 0, i, p, n});
+            for (int k = 0; k < d.V; ++k)
+                if ((d.live[0] >> (d.A + k)) & 1u) vk.push_back(VKey{1, 0, d.var_id[k], i, 0, d.A + k});
+        }
+        std::stable_sort(vk.begin(), vk.end(), [](const VKey &a, const VKey &b) {
+            if (a.kind != b.kind) return a.kind < b.kind;
+            if (a.layer != b.layer) return a.layer < b.layer;
+            return a.row < b.row;
+        });
+        int part = 0;
+        for (size_t k = 0; k < vk.size(); ++k) {
+            const VKey &key = vk[k];
+            const BatchDev &d = sd.b[key.batch];
+            const bool is_u = (uni[key.batch][key.level] >> key.node) & 1u;
+            const int rows = (is_u && key.level < d.L) ? 1 : (d.B + CH_GB - 1) / CH_GB;
+            part_row[key.batch][key.level][key.node] = part;
+            if (k == 0 || vk[k - 1].kind != key.kind || vk[k - 1].layer != key.layer || vk[k - 1].row != key.row) {
+                RGroup g;
+                g.kind = key.kind == 0 ? 2 : 3;
+                g.layer = key.layer;
+                g.row = key.row;
+                g.start = part;
+                g.count = 0;
+                g.r1_start = g.r1_count = 0;
+                hp->groups.push_back(g);
+            }
+            hp->groups.back().count += rows;
+            part += rows;
+        }
+        hp->total_parts = part;
+        for (int i = 0; i < nb; ++i)
+            for (int n = 0; n < 4; ++n) {
+                BatchDev &d = sd.b[i];
+                const bool liveL = n < d.tp.N && ((d.live[d.L] >> n) & 1u);
+                d.lpart[n] = liveL ? part_row[i][d.L][n] : -1;
+                d.uvL[n] = liveL && ((uni[i][d.L] >> n) & 1u) ? vec(V_UV, i, d.L, n) : -1;
+            }
+        if (uniform) {
+            // ---- forward pre-pass, level by level (a level's inputs are the outputs of the level before)
+            for (int p = 0; p < hp->Lmax; ++p)
+                for (int i = 0; i < nb; ++i) {
+                    const BatchDev &d = sd.b[i];
+                    if (d.L <= p) continue;
+                    const TmplArgs &tp = d.tp;
+                    const int li = layer_of(i, p);
+                    for (int n = 0; n < tp.N; ++n) {
+                        if (!((d.live[p + 1] >> n) & 1u)) continue;
+                        const bool nu = !((uni[i][p + 1] >> n) & 1u);
+                        UOp op;
+                        memset(&op, 0, sizeof(op));
+                        op.kind = UOP_FWD;
+                        op.out_gran = op.out_part = op.mask_vec = -1;
+                        auto add_in = [&](int src, int mat) {
+                            const int t = op.nterms++;
+                            op.layer[t] = li;
+                            op.mat[t] = mat;
+                            if (p == 0) {           // a variable row of x0 = a mode_embeddings row
+                                op.in_kind[t] = 1;
+                                op.in_vec[t] = (int)d.var_id[src - d.A];
+                            } else {
+                                op.in_kind[t] = 0;
+                                op.in_vec[t] = vec(V_UV, i, p, src);
+                                op.in_gran[t] = gran(op.in_vec[t]);
+                            }
+                        };
+                        for (int e = 0; e < tp.E; ++e)
+                            if (tp.dst[e] == n && ((uni[i][p] >> tp.src[e]) & 1u)) add_in(tp.src[e], (int)tp.rel[e]);
+                        if ((uni[i][p] >> n) & 1u) add_in(n, -1);
+                        if (nu && op.nterms == 0) continue;      // its constant is the layer's bias itself (ChainOp.aux = -1)
+                        op.out_vec = vec(nu ? V_CV : V_UV, i, p + 1, n);
+                        op.bias_layer = li;
+                        op.relu = (!nu && p < d.L - 1) ? 1 : 0;
+                        hp->uops_f.push_back(op);
+                    }
+                }
+            for (size_t k = 0; k < copy_vecs.size(); ++k) {      // mode rows the rank-1 weight-gradient terms read
+                const VecInfo &vi = vinfo[copy_vecs[k]];
+                UOp op;
+                memset(&op, 0, sizeof(op));
+                op.kind = UOP_COPY;
+                op.out_vec = copy_vecs[k];
+                op.out_gran = op.out_part = op.mask_vec = -1;
+                op.mode_row = sd.b[vi.batch].var_id[vi.node - sd.b[vi.batch].A];
+                hp->uops_f.push_back(op);
+            }
+            // ---- backward post-pass: the uniform nodes' gradient column sums, level L-1 down to 0
+            std::vector<UOp> bwd;
+            for (int p = hp->Lmax - 1; p >= 0; --p)
+                for (int i = 0; i < nb; ++i) {
+                    const BatchDev &d = sd.b[i];
+                    if (d.L <= p) continue;
+                    const TmplArgs &tp = d.tp;
+                    const int li = layer_of(i, p);
+                    for (int m = 0; m < tp.N; ++m) {
+                        if (!((d.live[p] >> m) & 1u) || !((uni[i][p] >> m) & 1u)) continue;
+                        UOp op;
+                        memset(&op, 0, sizeof(op));
+                        op.kind = UOP_BWD;
+                        op.out_gran = -1;
+                        op.out_vec = vec(V_SV, i, p, m);
+                        op.out_part = part_row[i][p][m];
+                        op.mask_vec = p >= 1 ? vec(V_UV, i, p, m) : -1;       // H[p] = ReLU(..) for 1 <= p <= L-1
+                        auto add_in = [&](int dnode, int mat) {
+                            const int t = op.nterms++;
+                            op.layer[t] = li;
+                            op.mat[t] = mat;
+                            op.in_kind[t] = 0;
+                            op.in_vec[t] = vec(V_SV, i, p + 1, dnode);
+                            op.in_gran[t] = gran(op.in_vec[t]);
+                            need_sv(op.in_vec[t]);
+                        };
+                        for (int e = 0; e < tp.E; ++e)
+                            if (tp.src[e] == m && ((d.live[p + 1] >> tp.dst[e]) & 1u)) add_in(tp.dst[e], (int)tp.rel[e]);
+                        if ((d.live[p + 1] >> m) & 1u) add_in(m, -1);
+                        bwd.push_back(op);
+                    }
+                }
+            // the column sums somebody reads and no BWD op produces: sums of the chain kernel's per-block rows
+            sv_needed.resize(vinfo.size(), 0);
+            for (size_t v = 0; v < vinfo.size(); ++v) {
+                const VecInfo &vi = vinfo[v];
+                if (vi.kind != V_SV || !sv_needed[v]) continue;
+                const bool is_u = (uni[vi.batch][vi.level] >> vi.node) & 1u;
+                if (is_u && vi.level < sd.b[vi.batch].L) continue;
+                UOp op;
+                memset(&op, 0, sizeof(op));
+                op.kind = UOP_RED;
+                op.out_vec = (int)v;
+                op.out_gran = op.out_part = op.mask_vec = -1;
+                op.row0 = part_row[vi.batch][vi.level][vi.node];
+                op.nrows = (sd.b[vi.batch].B + CH_GB - 1) / CH_GB;
+                hp->uops_b.push_back(op);
+            }
+            hp->uops_b.insert(hp->uops_b.end(), bwd.begin(), bwd.end());
+            for (size_t k = 0; k < hp->uops_f.size(); ++k) hp->uops_f[k].out_gran = gran_of[hp->uops_f[k].out_vec];
+            for (size_t k = 0; k < hp->uops_b.size(); ++k) hp->uops_b[k].out_gran = gran_of[hp->uops_b[k].out_vec];
+        }
     }
-    hp->vblocks_total = vblock;
-    hp->total_parts = part;
+    hp->nvec = (int)vinfo.size();
+    hp->ngran = ngran;
 
     hp->blk_off[0] = 0;
     for (int i = 0; i < nb; ++i) hp->blk_off[i + 1] = hp->blk_off[i] + (sd.b[i].B + CH_GB - 1) / CH_GB;
@@ -1301,6 +1625,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
             const TmplArgs &tp = d.tp;
             Prog pr;
             pr.batch = i;
+            int cv_slots = 0;
             for (int dir = 0; dir < 2; ++dir) {
                 const int begin = (int)hp->cops.size();
                 for (int q = 0; q < d.L; ++q) {
@@ -1313,8 +1638,14 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                     // the weight gradients read H[0 .. L-1] and gH[1 .. L]; H[L] feeds only the scores and gH[0]
                     // only the anchor / variable-row gradients, all inside the chain kernel
                     if ((!dir && p == d.L - 1) || (dir && p == 0)) lvl_flags |= CH_NOSTORE;
+                    const size_t level_first = hp->cops.size();
+                    // per-graph (NU) node slots only: a batch-uniform state is a vector of the pre-pass, its gradient
+                    // a column sum of the post-pass. The sources of an NU node's K-blocks are its NU sources (the
+                    // uniform ones are in the node's constant vector); backward, every destination of an NU node is NU.
+                    const unsigned uin = uni[i][p], uout = uni[i][p + 1];
                     for (int n = 0; n < tp.N; ++n) {
                         if (!(((dir ? lin : lout) >> n) & 1u)) continue;
+                        if (((dir ? uin : uout) >> n) & 1u) continue;
                         const size_t first = hp->cops.size();
                         auto push = [&](int src, int mat) {
                             ChainOp op;
@@ -1325,6 +1656,8 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                             op.mat = mat;
                             op.flags = lvl_flags;
                             op.wt_slot = 0;
+                            op.aux = -1;
+                            op.pad = 0;
                             if (dir) {      // shared layers alias one parameter set: one copy per unique (layer, matrix)
                                 size_t k = 0;
                                 for (; k < hp->wt_slots.size(); ++k)
@@ -1335,18 +1668,29 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                             hp->cops.push_back(op);
                         };
                         for (int e = 0; e < tp.E; ++e) {
-                            if (!dir && tp.dst[e] == n) push(tp.src[e], (int)tp.rel[e]);
+                            if (!dir && tp.dst[e] == n && !((uin >> tp.src[e]) & 1u)) push(tp.src[e], (int)tp.rel[e]);
                             if (dir && tp.src[e] == n && ((lout >> tp.dst[e]) & 1u)) push(tp.dst[e], (int)tp.rel[e]);
                         }
-                        if (!dir || ((lout >> n) & 1u)) push(n, -1);
+                        if (dir ? ((lout >> n) & 1u) != 0 : !((uin >> n) & 1u)) push(n, -1);
+                        if (hp->cops.size() == first) return MPQE_ERR_UNSUPPORTED;      // (cannot happen: see the liveness / uniformity rules)
                         hp->cops[first].flags |= CH_FIRST;
                         hp->cops.back().flags |= CH_LAST;
+                        if (!dir) {         // the node's constant: bias + its uniform sources' products (-1: the bias itself)
+                            const auto it = vec_of.find((((long long)V_CV * MPQE_STEP_MAX_BATCHES + i) *
+                                                         (MPQE_STEP_MAX_LAYERS + 1) + (p + 1)) * 4 + n);
+                            hp->cops.back().aux = it == vec_of.end() ? -1 : it->second;
+                            hp->cops.back().wt_slot = cv_slots++;
+                        } else {
+                            hp->cops.back().aux = part_row[i][p][n];       // (anchors at level 0: -1)
+                        }
                     }
-                    hp->cops.back().flags |= CH_LEVEL_END;
+                    if (hp->cops.size() > level_first) hp->cops.back().flags |= CH_LEVEL_END;
                 }
                 (dir ? pr.bb : pr.fb) = begin;
                 (dir ? pr.bc : pr.fc) = (int)hp->cops.size() - begin;
             }
+            // (the chain kernel's LDS tables: step_chain.h. Steps beyond them take the level form.)
+            if (chain && (cv_slots > CH_MAX_CV || pr.fc + pr.bc > CH_MAX_OPS)) return MPQE_ERR_UNSUPPORTED;
             pr.work = pr.fc + pr.bc;
             progs.push_back(pr);
         }
@@ -1413,7 +1757,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->o_vblock = take(hp->vblock.size() * sizeof(int));
     hp->o_groups = take(hp->groups.size() * sizeof(RGroup));
     hp->o_anchor = take(hp->anchor_off.size() * sizeof(int));
-    for (int l = 0; l < hp->nlanes; ++l)
+    for (int l = 0; l < hp->nlanes && !chain; ++l)
         for (int p = 0; p < hp->lane_Lmax[l]; ++p) {
             hp->o_tf[l][p] = take(hp->tfwd[l][p].size() * sizeof(TileRef));
             hp->o_tb[l][p] = take(hp->tbwd[l][p].size() * sizeof(TileRef));
@@ -1422,7 +1766,13 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->o_cops = take(hp->cops.size() * sizeof(ChainOp));
     hp->o_wtslots = take(hp->wt_slots.size() * sizeof(WtSlot));
     hp->o_zmats = take(hp->zmats.size() * sizeof(ZMat));
-    hp->o_cparts = take(sizeof(hp->cparts));
+    hp->o_uopf = take(hp->uops_f.size() * sizeof(UOp));
+    hp->o_uopb = take(hp->uops_b.size() * sizeof(UOp));
+    hp->o_rank1 = take(hp->rank1.size() * sizeof(Rank1));
+    // hand-off state of the packed step, zeroed when the table is uploaded: the two epoch words (forward pre-pass,
+    // backward post-pass), then the granules
+    hp->o_epoch = take(256);
+    hp->o_gran = take((size_t)hp->ngran * D * sizeof(u64));
     hp->desc_total = off;
     off = 0;
     hp->o_H = take((size_t)(hp->Lmax + 1) * rows * D * 4);
@@ -1436,6 +1786,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->o_parts = take((size_t)hp->total_parts * D * 4);
     hp->o_WT = take(hp->wt_slots.size() * (size_t)D * D * 4);
     hp->o_bterms = take((size_t)hp->blk_off[nb] * 4);
+    hp->o_VT = take((size_t)hp->nvec * D * 4);
     hp->total = off;
     return MPQE_OK;
 }
@@ -1450,9 +1801,20 @@ void upload(hipStream_t s, char *dst, const void *src, size_t n) {
     }
 }
 
+// chain form when the step qualifies (want_chain) and fits the chain kernel's tables, the level form otherwise
+int plan_auto(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, const mpqe_step_lanes_t *lanes,
+              bool chain, HostPlan *hp) {
+    if (chain) {
+        const int st = make_plan(P, B, nb, lanes, true, hp);
+        if (st != MPQE_ERR_UNSUPPORTED) return st;
+        *hp = HostPlan();
+    }
+    return make_plan(P, B, nb, lanes, false, hp);
+}
+
 // Everything make_plan() reads, field by field (struct padding never takes part in the comparison).
 struct PlanKey {
-    int dim, num_layers, num_relations, num_modes, readout, flags, nb, nlanes;
+    int dim, num_layers, num_relations, num_modes, readout, flags, nb, nlanes, chain;
     int lane_begin[MPQE_STEP_MAX_LANES + 1];
     int alias[MPQE_STEP_MAX_LAYERS];          // first layer with the same parameter buffers
     mpqe_step_batch_t b[MPQE_STEP_MAX_BATCHES];
@@ -1505,18 +1867,37 @@ extern "C" void mpqe_debug_chain_stamps(void *device_buffer, size_t num_blocks) 
     g_chain_stamp_blocks = num_blocks;
 }
 
+// Chain kernels (step_chain.h): D = 64 / 128 / 256 with 16-byte aligned weights, every batch within the number of
+// passes the kernel's LDS tables cover. Everything else takes the one-launch-per-level form.
+static bool want_chain(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb) {
+    if (!P || !B || nb < 1 || nb > MPQE_STEP_MAX_BATCHES) return false;
+    bool use_chain = !(P->flags & MPQE_STEP_NO_CHAIN) && (P->dim == 64 || P->dim == 128 || P->dim == 256);
+    if (!use_chain) return false;
+    long long graphs = 0;
+    for (int i = 0; i < nb; ++i) graphs += B[i].batch_size;
+    use_chain = graphs <= CHAIN_MAX_GRAPHS && P->num_layers > 0 && P->num_layers <= MPQE_STEP_MAX_LAYERS;
+    // (5 passes x (3 edges + 4 nodes) x 2 directions = 70 ops <= CH_MAX_OPS; a batch with more than CH_MAX_CV forward
+    // node updates is turned away by the planner: plan_auto)
+    for (int i = 0; i < nb; ++i) use_chain = use_chain && B[i].num_passes <= CH_MASK_LEVELS + 1;
+    for (int l = 0; use_chain && l < P->num_layers; ++l)
+        use_chain = P->basis[l] && P->root[l] && ptr_vec_ok(P->basis[l], P->dim) && ptr_vec_ok(P->root[l], P->dim) &&
+                    (!P->bias[l] || (uintptr_t)P->bias[l] % 16 == 0);
+    for (int m = 0; use_chain && m < P->num_modes && m < MPQE_STEP_MAX_MODES; ++m)
+        use_chain = P->tables[m] && (uintptr_t)P->tables[m] % 16 == 0;
+    return use_chain && P->mode_emb && (uintptr_t)P->mode_emb % 16 == 0;
+}
+
 extern "C" size_t mpqe_step_workspace_bytes(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb,
                                             const mpqe_step_lanes_t *lanes) {
     HostPlan hp;
-    if (make_plan(P, B, nb, lanes, &hp) != MPQE_OK) return 0;
+    if (plan_auto(P, B, nb, lanes, want_chain(P, B, nb), &hp) != MPQE_OK) return 0;
     return hp.total;
 }
 extern "C" size_t mpqe_step_desc_bytes(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb,
                                        const mpqe_step_lanes_t *lanes) {
-    // exact: every lane has its own chain grid (8 x its longest XCD bin, holes included) and its own per-level
-    // tile tables, so the table's size depends on the split
+    // exact: the level form's lanes have their own per-level tile tables, so the table's size depends on the split
     HostPlan hp;
-    if (make_plan(P, B, nb, lanes, &hp) != MPQE_OK) return 0;
+    if (plan_auto(P, B, nb, lanes, want_chain(P, B, nb), &hp) != MPQE_OK) return 0;
     return hp.desc_total;
 }
 
@@ -1528,30 +1909,14 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                                           size_t workspace_bytes, int32_t *err, const mpqe_step_lanes_t *lanes,
                                           void *const *events, int num_events, void *stream) {
     if (!P || !B || nb < 1 || nb > MPQE_STEP_MAX_BATCHES || !desc) return MPQE_ERR_INVALID_ARG;
-    // Chain kernels (step_chain.h): D = 64 / 128 / 256 with 16-byte aligned weights, and a step small
-    // enough that per-level launches cannot fill the chip (above CHAIN_MAX_GRAPHS the 64x64-tile level
-    // kernels re-use each weight tile 4x more often and win). With stream lanes every lane launches the chain
-    // kernel and then the weight-gradient kernel of ITS batches: a lane of light batches finishes early and
-    // its weight gradients run beside the long chains of the heavy lane.
-    bool use_chain = !(P->flags & MPQE_STEP_NO_CHAIN) && (P->dim == 64 || P->dim == 128 || P->dim == 256);
-    if (use_chain) {
-        long long graphs = 0;
-        for (int i = 0; i < nb; ++i) graphs += B[i].batch_size;
-        use_chain = graphs <= CHAIN_MAX_GRAPHS && P->num_layers <= MPQE_STEP_MAX_LAYERS;
-        // (5 passes x (3 edges + 4 nodes) x 2 directions = 70 ops <= CH_MAX_OPS)
-        for (int i = 0; i < nb; ++i) use_chain = use_chain && B[i].num_passes <= CH_MASK_LEVELS + 1;
-        for (int l = 0; use_chain && l < P->num_layers; ++l)
-            use_chain = P->basis[l] && P->root[l] && ptr_vec_ok(P->basis[l], P->dim) && ptr_vec_ok(P->root[l], P->dim);
-        for (int m = 0; use_chain && m < P->num_modes && m < MPQE_STEP_MAX_MODES; ++m)
-            use_chain = P->tables[m] && (uintptr_t)P->tables[m] % 16 == 0;
-        use_chain = use_chain && P->mode_emb && (uintptr_t)P->mode_emb % 16 == 0;
-    }
+    const bool ask_chain = want_chain(P, B, nb);
     // The launch plan is a pure function of the descriptors; it is kept on the host next to the device
     // table it describes (same key: the caller's desc buffer), so a steady-state call costs one lookup.
     std::shared_ptr<const CachedPlan> cached;
     {
         PlanKey key;
         make_key(P, B, nb, lanes, &key);
+        key.chain = ask_chain ? 1 : 0;
         std::lock_guard<std::mutex> lock(g_plan_mu);
         auto it = g_plans.find(desc);
         if (it != g_plans.end() && memcmp(&it->second->key, &key, sizeof(key)) == 0) cached = it->second;
@@ -1559,7 +1924,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         if (!cached) {
             std::shared_ptr<CachedPlan> fresh = std::make_shared<CachedPlan>();
             fresh->key = key;
-            int st = make_plan(P, B, nb, lanes, &fresh->hp);
+            int st = plan_auto(P, B, nb, lanes, ask_chain, &fresh->hp);
             if (st) return st;
             if (g_plans.size() >= 1024) g_plans.clear();      // plans in use stay alive through their shared_ptr
             g_plans[desc] = fresh;
@@ -1567,6 +1932,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         }
     }
     const HostPlan &hp = cached->hp;
+    const bool use_chain = hp.chain;
     for (int l = 1; l < hp.nlanes; ++l)           // handles are per call, not part of the cached plan
         if (!lanes->fork_event || !lanes->aux_stream[l] || !lanes->join_event[l]) return MPQE_ERR_INVALID_ARG;
     if (!anchor_ids || !targets || !negs || !loss || !workspace) return MPQE_ERR_INVALID_ARG;
@@ -1632,7 +1998,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         upload(s, db + hp.o_vblock, hp.vblock.data(), hp.vblock.size() * sizeof(int));
         upload(s, db + hp.o_groups, hp.groups.data(), hp.groups.size() * sizeof(RGroup));
         upload(s, db + hp.o_anchor, hp.anchor_off.data(), hp.anchor_off.size() * sizeof(int));
-        for (int l = 0; l < NL; ++l)
+        for (int l = 0; l < NL && !hp.chain; ++l)
             for (int p = 0; p < hp.lane_Lmax[l]; ++p) {
                 upload(s, db + hp.o_tf[l][p], hp.tfwd[l][p].data(), hp.tfwd[l][p].size() * sizeof(TileRef));
                 upload(s, db + hp.o_tb[l][p], hp.tbwd[l][p].data(), hp.tbwd[l][p].size() * sizeof(TileRef));
@@ -1641,8 +2007,23 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         upload(s, db + hp.o_cops, hp.cops.data(), hp.cops.size() * sizeof(ChainOp));
         upload(s, db + hp.o_wtslots, hp.wt_slots.data(), hp.wt_slots.size() * sizeof(WtSlot));
         upload(s, db + hp.o_zmats, hp.zmats.data(), hp.zmats.size() * sizeof(ZMat));
-        upload(s, db + hp.o_cparts, hp.cparts, sizeof(hp.cparts));
+        upload(s, db + hp.o_uopf, hp.uops_f.data(), hp.uops_f.size() * sizeof(UOp));
+        upload(s, db + hp.o_uopb, hp.uops_b.data(), hp.uops_b.size() * sizeof(UOp));
+        upload(s, db + hp.o_rank1, hp.rank1.data(), hp.rank1.size() * sizeof(Rank1));
+        // hand-off state of this packed step: epochs 0, every granule tagged 0 (a live tag is >= 1)
+        (void)hipMemsetAsync(db + hp.o_epoch, 0, hp.desc_total - hp.o_epoch, s);
     }
+    unsigned *epoch_f = reinterpret_cast<unsigned *>(db + hp.o_epoch), *epoch_b = epoch_f + 16;
+    float *VT = reinterpret_cast<float *>(wb + hp.o_VT);
+    UArgs ua;
+    memset(&ua, 0, sizeof(ua));
+    ua.chunks = D / 64;
+    ua.VT = VT;
+    ua.gran = reinterpret_cast<u64 *>(db + hp.o_gran);
+    ua.mode_emb = P->mode_emb;
+    ua.num_modes = (long long)P->num_modes;
+    ua.parts = reinterpret_cast<float *>(wb + hp.o_parts);
+    ua.err = err;
     float *H = reinterpret_cast<float *>(wb + hp.o_H), *GH = reinterpret_cast<float *>(wb + hp.o_GH);
     float *tpos = reinterpret_cast<float *>(wb + hp.o_tpos), *tneg = reinterpret_cast<float *>(wb + hp.o_tneg);
     float *spos = scores_pos ? scores_pos : reinterpret_cast<float *>(wb + hp.o_spos);
@@ -1662,12 +2043,13 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         gr0[l] = b < nb ? hp.sd.b[b].g_off : hp.sd.graphs_total;
     }
     float *WT = reinterpret_cast<float *>(wb + hp.o_WT);
-    if (backward) {
-        // prologue launch: transposed weight copies for the backward chains; zero fill of the gradients
+    {
+        // prologue launch: the forward pre-pass of the batch-uniform node states; backward: transposed weight copies
+        // for the backward chains, zero fill of the gradients
         ZeroSegs zs;
         memset(&zs, 0, sizeof(zs));
         long long zblocks = 0;
-        if (P->flags & MPQE_STEP_ZERO_GRADS) {
+        if (backward && (P->flags & MPQE_STEP_ZERO_GRADS)) {
             auto seg = [&](float *ptr, long long n) {
                 if (!ptr || n <= 0) return;
                 for (int k = 0; k < zs.count; ++k)
@@ -1690,11 +2072,16 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             zs.block0[zs.count] = zblocks;
         }
         const int tpd = (D + 31) / 32;
-        const int tblocks = use_chain ? (int)hp.wt_slots.size() * tpd * tpd : 0;
-        if (tblocks + zblocks > 0)
-            hipLaunchKernelGGL(step_prep_kernel, dim3((unsigned)(tblocks + zblocks)), dim3(256), 0, s, lp,
+        const int tblocks = use_chain && backward ? (int)hp.wt_slots.size() * tpd * tpd : 0;
+        UArgs uf = ua;
+        uf.ops = reinterpret_cast<const UOp *>(db + hp.o_uopf);
+        uf.nops = (int)hp.uops_f.size();
+        uf.epoch = epoch_f;
+        const int ublocks = uf.nops * uf.chunks;
+        if (ublocks + tblocks + zblocks > 0)
+            hipLaunchKernelGGL(step_prep_kernel, dim3((unsigned)(ublocks + tblocks + zblocks)), dim3(256), 0, s, lp,
                                reinterpret_cast<const WtSlot *>(db + hp.o_wtslots), (int)hp.wt_slots.size(), D, WT,
-                               tblocks, zs);
+                               tblocks, zs, uf, ublocks);
     }
     LossMeta lm;
     memset(&lm, 0, sizeof(lm));
@@ -1732,25 +2119,31 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     ta.zmats = reinterpret_cast<const ZMat *>(db + hp.o_zmats);
     ta.zper = (int)(((long long)D * D + ZMAT_FLOATS_PER_BLOCK - 1) / ZMAT_FLOATS_PER_BLOCK);
     ta.zblocks = 0;
+    ta.ublocks = 0;
     ta.stamps = nullptr;
+    UArgs ub = ua;
+    ub.ops = reinterpret_cast<const UOp *>(db + hp.o_uopb);
+    ub.nops = (int)hp.uops_b.size();
+    ub.epoch = epoch_b;
     auto launch_grad_w = [&](hipStream_t on, int first, int count) {
         TailArgs tl = ta;
         tl.wblock = ta.wblock + first;
         tl.wblocks = count;
         if (first == 0 && (P->flags & MPQE_STEP_ZERO_GRADS)) tl.zblocks = (int)hp.zmats.size() * ta.zper;
-        tl.stamps = g_tail_stamps && (size_t)(count + tl.zblocks) <= g_tail_stamp_blocks ? g_tail_stamps : nullptr;
-        if (count + tl.zblocks <= 0) return;
-        dim3 tgrid((unsigned)(count + tl.zblocks));
+        if (first == 0) tl.ublocks = ub.nops * ub.chunks;
+        tl.stamps = g_tail_stamps && (size_t)(tl.ublocks + count + tl.zblocks) <= g_tail_stamp_blocks ? g_tail_stamps : nullptr;
+        if (tl.ublocks + count + tl.zblocks <= 0) return;
+        dim3 tgrid((unsigned)(tl.ublocks + count + tl.zblocks));
         const int zeroed = (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0;
         if (fast && hp.whole_ksteps)
             hipLaunchKernelGGL(step_tail_kernel<LD_FAST>, tgrid, dim3(256), 0, on, sd, tl, (const float *)H,
-                               (const float *)GH, hp.level_stride, gp, zeroed);
+                               (const float *)GH, hp.level_stride, gp, zeroed, lp, ub);
         else if (vec)
             hipLaunchKernelGGL(step_tail_kernel<LD_PRED>, tgrid, dim3(256), 0, on, sd, tl, (const float *)H,
-                               (const float *)GH, hp.level_stride, gp, zeroed);
+                               (const float *)GH, hp.level_stride, gp, zeroed, lp, ub);
         else
             hipLaunchKernelGGL(step_tail_kernel<LD_SCALAR>, tgrid, dim3(256), 0, on, sd, tl, (const float *)H,
-                               (const float *)GH, hp.level_stride, gp, zeroed);
+                               (const float *)GH, hp.level_stride, gp, zeroed, lp, ub);
     };
     if (use_chain) {
         // assemble -> levels -> scores (-> levels back -> anchor-table gradients): one launch per lane
@@ -1767,7 +2160,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         ca.H = H;
         ca.GH = GH;
         ca.WT = WT;
-        ca.cparts = reinterpret_cast<const ChainParts *>(db + hp.o_cparts);
+        ca.VT = VT;
+        ca.epoch_f = epoch_f;
         ca.parts = reinterpret_cast<float *>(wb + hp.o_parts);
         ca.block_terms = reinterpret_cast<float *>(wb + hp.o_bterms);
         ca.level_stride = hp.level_stride;
@@ -1900,7 +2294,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         hipLaunchKernelGGL(step_reduce_kernel, grid, dim3(256), 0, s,
                            reinterpret_cast<const RGroup *>(db + hp.o_groups), (int)hp.groups.size(), D, gp,
                            (const float *)slabs, (const float *)parts, (int)(D % 4 == 0), sd, (const float *)terms,
-                           loss, (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0, lm, bterms);
+                           loss, (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0, lm, bterms,
+                           reinterpret_cast<const Rank1 *>(db + hp.o_rank1), (const float *)VT, epoch_b);
     }
     return mpqe_launch_status();
 }

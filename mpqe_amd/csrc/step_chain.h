@@ -29,7 +29,8 @@
 #define CH_MASK 16        // backward epilogue masks with the bits recorded for this (level, node)
 #define CH_NOSTORE 32     // the result stays in LDS: nothing after the chain kernel reads H[L] or gH[0]
 #define CH_MASK_LEVELS 4  // ReLU outputs live at levels 1 .. L-1: chains up to L = 5 passes
-#define CH_MAX_OPS 96     // forward + backward K-blocks of one batch (5 passes x 7 x 2 = 70 at most)
+#define CH_MAX_OPS 72     // forward + backward K-blocks of one batch (5 passes x 7 x 2 = 70 at most)
+#define CH_MAX_CV 12      // forward node updates of one batch (3 passes x 4 node slots; the host checks)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef const f32x2 __attribute__((address_space(1))) * gvec2_ptr;
@@ -41,7 +42,12 @@ __device__ __forceinline__ f32x2 gload2(const float *p) { return *(gvec2_ptr)(p)
 struct ChainOp {
     unsigned char src, node, layer, level;
     int mat, flags;
-    int wt_slot;          // backward ops: slot of the matrix's transposed copy in the step workspace
+    int wt_slot;          // backward ops: slot of the matrix's transposed copy in the step workspace;
+                          // forward, last K-block of a node update: the update's number in the forward programme (< CH_MAX_CV)
+    int aux;              // forward, last K-block of a node update: id of the node's constant vector (bias + the products
+                          // of its batch-uniform sources, formed once per batch by the pre-pass), -1 = the layer's bias;
+                          // backward, last K-block: first row in `parts` of the node's per-block column sums, -1 = none
+    int pad;
 };
 // one workgroup: graphs [g0, g0 + 16) of `batch`; its forward / backward programmes in the op table
 struct ChainRef {
@@ -200,14 +206,20 @@ template <int NCB, int KS, int NW = 4>
 struct ChainLds {
     static constexpr int D = 16 * NCB * NW / KS, LDX = D + 4, BUF = 4 * CH_GB * LDX, MT = 64 * NW / KS;
     float xs[2 * BUF];                                   // node states, ping-pong: [node][graph][LDX]
-    float bias[MPQE_STEP_MAX_LAYERS * D];                // every layer's bias
+    static constexpr int NCV = CH_MAX_CV;
+    // per forward node update: its constant vector (see ChainOp.aux). Dead once the forward levels are done: the
+    // column-sum scratch of the score / backward phases (`red`, 256 floats) lives in its first kilobyte.
+    float cv[NCV * D];
     typename chain_bits<NCB>::type mbits[CH_MASK_LEVELS * 4 * MT];    // ReLU bits per (level, node, finishing thread)
     const float *rowp[4 * CH_GB + 2 * CH_GB];            // source row of every node row, then +/- targets
     float *gradp[4 * CH_GB];                             // entity-table gradient row of every anchor row
     float nrm[4 * CH_GB];                                // 1 / |v| of the anchor rows
     const float *wp[CH_MAX_OPS];                         // weight matrix of every op of the block's programme
     int opw[CH_MAX_OPS][2];                              // its (src | node << 8 | layer << 16 | level << 24, flags)
-    float red[256];                                      // column-sum scratch
+    int opp[CH_MAX_OPS];                                 // backward ops: ChainOp.aux (row of the column sums in `parts`); forward: cv slot
+    int cvid[NCV];                                       // cv slot -> vector id (-1: the bias of layer cvl, -2: slot unused)
+    int cvl[NCV];
+    __device__ __forceinline__ float *red() { return cv; }
 #if CHAIN_DBG == 6
     long long *trace;                                    // diagnostic build: per-item cycle stamps of one wave
     int trace_n;
@@ -227,12 +239,12 @@ __device__ __forceinline__ void chain_colsum(ChainLds<NCB, KS, NW> &S, const flo
             if (!((mask >> n) & 1u)) continue;
             for (int i = part; i < ng; i += NP) s += X[(n * CH_GB + i) * LDX + col];
         }
-        S.red[threadIdx.x] = s;
+        S.red()[threadIdx.x] = s;
     }
     __syncthreads();
     if (threadIdx.x < D && dst) {
-        float t = S.red[threadIdx.x];
-        for (int q = 1; q < NP; ++q) t += S.red[threadIdx.x + q * D];
+        float t = S.red()[threadIdx.x];
+        for (int q = 1; q < NP; ++q) t += S.red()[threadIdx.x + q * D];
         dst[threadIdx.x] = t;
     }
     __syncthreads();
@@ -240,7 +252,7 @@ __device__ __forceinline__ void chain_colsum(ChainLds<NCB, KS, NW> &S, const flo
 // an op as the K loop sees it: wave-uniform, read from LDS (a vector load from HBM here would sit in vmcnt
 // behind the weight prefetch and drain it)
 struct ChainStep {
-    int src, node, layer, level, flags;
+    int src, node, layer, level, flags, part;
 };
 
 // The K loop of one direction: the block's programme (T half-blocks) as ONE software pipeline across node
@@ -251,8 +263,7 @@ struct ChainStep {
 // scheduler from sinking the prefetch loads down to the MFMAs that use them.
 template <int NCB, int KS, bool BWD, int NW>
 __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int first_op, int T /* items */, int N, int ng,
-                                          float *__restrict__ Xrows, long long level_stride, int &cur, int A = 0,
-                                          const int *bias_part = nullptr, const int *var_part = nullptr,
+                                          float *__restrict__ Xrows, long long level_stride, int &cur,
                                           float *parts = nullptr, int blk = 0) {
     constexpr int D = 16 * NCB * NW / KS, LDX = D + 4, BUF = 4 * CH_GB * LDX;
     constexpr int CW = NW / KS;                 // column groups of 16 NCB columns
@@ -273,6 +284,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
         o.layer = (w >> 16) & 0xff;
         o.level = (w >> 24) & 0xff;
         o.flags = __builtin_amdgcn_readfirstlane(S.opw[k][1]);
+        o.part = __builtin_amdgcn_readfirstlane(S.opp[k]);      // (forward: the node update's cv slot)
         return o;
     };
     // matrix pointers come from LDS (filled in phase A1): no scalar memory round trip, no branch, per item
@@ -288,23 +300,25 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
 #endif
     // one half-block: 4 t-steps of NCB x 4 MFMAs; the weights of the half-block two items ahead are loaded
     // into `fn` (from `wn`) on the way
-    float bs[NCB];          // backward: column sums of this level's gradient rows (bias gradient of the pass below)
+    float bs[NCB];          // backward: column sums of a node's gradient rows over the block's graphs
 #pragma unroll
     for (int c = 0; c < NCB; ++c) bs[c] = 0.f;
     // K split: the finished rows of a node update go to HBM (H / gH, for the weight-gradient launch) from the waves of
     // the FIRST K part: they would otherwise idle until the finishing waves reach the next hand-off, and the stores
     // (plus their address arithmetic: VALU time a wave cannot hide behind its own MFMAs) leave the finishing waves'
     // path. They copy the node's LDS tile one barrier after it was written: behind the next hand-off / level barrier.
-    // In the backward direction the same waves also form the rows' column sums (bias / variable-row partials).
+    // In the backward direction the same waves also form the rows' column sums: one row of `parts` per (level, node
+    // slot) and block -- summed over blocks they are the bias / variable-row gradients and what the batch-uniform
+    // part of the backward pass runs on (step.hip: uniform node states).
     const float *pend_tile = nullptr;
     float *pend_out = nullptr;
     bool pend_on = false, pend_store = false;
-    int pend_var = -1;              // >= 0: the rows are a variable row of gH[0]; its slot in `parts`
+    int pend_part = -1;             // >= 0: first row in `parts` of this node's column sums (row = pend_part + blk)
     auto flush_rows = [&]() {
         float l[4][NCB];
 #pragma unroll
         for (int r = 0; r < 4; ++r) chain_lload<NCB>(l[r], pend_tile + r * LDX);
-        if (BWD && pend_var >= 0) {     // (level 0 has no bias gradient to collect: bs is free to hold the node's own sums)
+        if (BWD) {
 #pragma unroll
             for (int c = 0; c < NCB; ++c) bs[c] = 0.f;
         }
@@ -330,14 +344,14 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
                     }
                 }
         }
-        if (BWD && pend_var >= 0) {
+        if (BWD && pend_part >= 0) {
             float t[NCB];
 #pragma unroll
             for (int c = 0; c < NCB; ++c) {
                 t[c] = bs[c] + __shfl_xor(bs[c], 16, 64);
                 t[c] += __shfl_xor(t[c], 32, 64);
             }
-            if (kq == 0) chain_store<NCB>(parts + (long long)(pend_var + blk) * D + colb, t);
+            if (kq == 0) chain_store<NCB>(parts + (long long)(pend_part + blk) * D + colb, t);
         }
         pend_on = false;
     };
@@ -419,14 +433,14 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int c = 0; c < NCB; ++c) v[r][c] = acc[c][r];
-                if (!BWD) chain_lload<NCB>(bv, S.bias + op.layer * D + colb);
+                if (!BWD) chain_lload<NCB>(bv, S.cv + op.part * D + colb);
             }
             if (KS > 1) __syncthreads();
             if (KS > 1 && !finisher) {
                 if (pend_on) flush_rows();
                 pend_store = !(op.flags & CH_NOSTORE);
-                pend_var = BWD && op.level == 0 && op.node >= A ? var_part[op.node - A] : -1;
-                pend_on = pend_store || BWD;
+                pend_part = op.part;
+                pend_on = pend_store || (BWD && pend_part >= 0);
                 pend_tile = tile;
                 pend_out = Xrows + (long long)op.level * level_stride + ((long long)(4 * kq) * N + op.node) * D + colb;
             }
@@ -470,9 +484,8 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
 #pragma unroll
                 for (int r = 0; r < 4; ++r) chain_store<NCB>(tile + r * LDX, v[r]);
                 CHAIN_TRACE(6)
-                // a variable row of gH[0]: its sum over the block's graphs is a mode-embedding gradient partial
-                // (level 0 has no bias gradient to collect: bs is free to hold the node's own sums)
-                const bool var_row = KS == 1 && BWD && op.level == 0 && op.node >= A && var_part[op.node - A] >= 0;
+                // the node's column sums over the block's graphs (one row of `parts`)
+                const bool var_row = KS == 1 && BWD && op.part >= 0;
                 if (var_row) {
 #pragma unroll
                     for (int c = 0; c < NCB; ++c) bs[c] = 0.f;
@@ -509,7 +522,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
                         t[c] = bs[c] + __shfl_xor(bs[c], 16, 64);
                         t[c] += __shfl_xor(t[c], 32, 64);
                     }
-                    if (kq == 0) chain_store<NCB>(parts + (long long)(var_part[op.node - A] + blk) * D + colb, t);
+                    if (kq == 0) chain_store<NCB>(parts + (long long)(op.part + blk) * D + colb, t);
                 }
             };
             if (finisher) {
@@ -527,24 +540,10 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
         }
         CHAIN_TRACE(3)
         if (op.flags & CH_LEVEL_END) {       // uniform over the workgroup: every wave runs the same programme
-            auto level_sums = [&]() {      // gH[level] is complete: its column sums (rows 4 kq + r live in lane group
-                                           // kq; the wave owns its columns) are pass level-1's bias gradient. Fixed order.
-                float t[NCB];
-#pragma unroll
-                for (int c = 0; c < NCB; ++c) {
-                    t[c] = bs[c] + __shfl_xor(bs[c], 16, 64);
-                    t[c] += __shfl_xor(t[c], 32, 64);
-                    bs[c] = 0.f;
-                }
-                if (op.level >= 1 && bias_part[op.level - 1] >= 0 && kq == 0)
-                    chain_store<NCB>(parts + (long long)(bias_part[op.level - 1] + blk) * D + colb, t);
-            };
-            if (BWD && KS == 1) level_sums();
             __syncthreads();
             cur ^= 1;
             if (KS > 1 && !finisher) {
                 if (pend_on) flush_rows();     // (the level's last node update)
-                if (BWD) level_sums();
             }
         }
     };
@@ -625,13 +624,6 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
     }
 }
 
-// where a block's partial column sums go (row of the step's `parts` array; -1 = none): bias gradient of
-// pass q = column sums of gH[q + 1] over the block's live rows; variable row k = sums of gH[0] rows of
-// node slot A + k. Row = entry + (block index inside the batch).
-struct ChainParts {
-    int bias_part[MPQE_STEP_MAX_LAYERS], var_part[3], pad;
-};
-
 struct ChainArgs {
     const ChainRef *refs;
     const ChainOp *ops;
@@ -642,7 +634,8 @@ struct ChainArgs {
     const long long *anchor_ids, *targets, *negs;
     float *H, *GH;
     const float *WT;        // transposed copies of the matrices the backward chains multiply by
-    const ChainParts *cparts;
+    const float *VT;        // vector table [vector id][D]: constants / uniform node states of the pre-pass (step.hip)
+    unsigned *epoch_f;      // forward hand-off epoch of this packed step: bumped once per chain launch (step.hip)
     float *parts;
     float *block_terms;     // [blocks of the step]: sum of the block's hinge terms (the loss reduction reads these)
     long long level_stride;
@@ -692,6 +685,8 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool four = NW == 4 || tid < 256;
     const ChainRef ref = ca.refs[blockIdx.x];
+    // the pre-pass of this step (an earlier launch) is over: the next step's forward granules get a new tag
+    if (blockIdx.x == 0 && tid == 0 && ca.epoch_f) *ca.epoch_f = *ca.epoch_f + 1u;
     if (ref.batch < 0) return;                            // a hole of the placement grid (uniform)
     const BatchDev &b = sd->b[ref.batch];
     const int N = b.tp.N, A = b.A, L = b.L, g0 = ref.g0;
@@ -745,10 +740,9 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
         }
         S.rowp[tid] = src;
     }
-    for (int f = tid; f < sd->num_layers * D && four; f += 256) {
-        const float *bp = pick_layer(lp.bias, f / D);
-        S.bias[f] = bp ? bp[f % D] : 0.f;
-    }
+    constexpr int NCV = ChainLds<NCB, KS, NW>::NCV;
+    if (tid < NCV) S.cvid[tid] = -2;
+    __syncthreads();
     {   // forward ops then backward ops of this block's programme (the host keeps them adjacent)
         const int nops = ref.fwd_count + ref.bwd_count;
         if (tid < nops) {
@@ -760,6 +754,11 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
                 S.wp[tid] = ca.WT + (long long)op.wt_slot * D * D;
             S.opw[tid][0] = op.src | (op.node << 8) | (op.layer << 16) | (op.level << 24);
             S.opw[tid][1] = op.flags;
+            S.opp[tid] = tid < ref.fwd_count ? op.wt_slot : op.aux;
+            if (tid < ref.fwd_count && (op.flags & CH_LAST)) {      // one slot per forward node update
+                S.cvid[op.wt_slot] = op.aux;
+                S.cvl[op.wt_slot] = op.layer;
+            }
         }
     }
     __syncthreads();
@@ -789,6 +788,16 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     // LDS buffer 0 and H[0]. Thread t moves float4 number t + 256 k, k < N * DB; LPR adjacent lanes share a
     // row. All loads are issued before the first use.
     if (four) {
+        // the constants of the forward node updates: bias + (uniform mode) the products of the node's batch-uniform
+        // sources, one vector per (level, node) written by the pre-pass -- requested before the row gather, used
+        // by the first epilogue at the earliest
+        for (int f = tid; f < NCV * (D / 4); f += 256) {
+            const int slot = f / (D / 4), c4 = f - slot * (D / 4);
+            const int id = S.cvid[slot];
+            if (id == -2) continue;
+            const float *src = id >= 0 ? ca.VT + (long long)id * D : pick_layer(lp.bias, S.cvl[slot]);
+            *reinterpret_cast<f32x4 *>(S.cv + slot * D + 4 * c4) = src ? gload4(src + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         const int nk = N * DB;
         f32x4 v[4 * DB];
 #pragma unroll
@@ -842,6 +851,20 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
 
     chain_stamp(ca, 3);
     if (ca.backward && ref.bwd_count > 0 && four) warm(ref.fwd_count, ref.bwd_count);
+    // node states that are still batch-uniform at level L (no anchor within L hops: possible when a batch runs fewer
+    // passes than its diameter) never went through the K loops: the readout sees the pre-pass' vector in every row
+    if (b.uvL[0] >= 0 || b.uvL[1] >= 0 || b.uvL[2] >= 0 || b.uvL[3] >= 0) {      // (uniform over the workgroup)
+        float *Xc = S.xs + cur * BUF;
+        for (int n = 0; n < N; ++n) {
+            const int id = b.uvL[n];
+            if (id < 0) continue;
+            for (int f = tid; f < CH_GB * (D / 4) && four; f += 256) {
+                const int i = f / (D / 4), c4 = f - i * (D / 4);
+                *reinterpret_cast<f32x4 *>(Xc + (n * CH_GB + i) * LDX + 4 * c4) = gload4(ca.VT + (long long)id * D + 4 * c4);
+            }
+        }
+        __syncthreads();
+    }
     // ---- readout, cosine scores against the + and - target, hinge terms (reference model.py:447-462,
     // 483-485); backward: d hinge -> d cosine -> d readout written over H[L] in LDS (a lane group owns whole
     // graphs) and to gH[L]; target-table gradients through the normalisation. 16 lanes per graph (see above).
@@ -924,7 +947,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
         {   // the wave's four graphs (every lane of a group holds its graph's term), then the four waves, in order
             float t4 = term + __shfl_xor(term, 16, 64);
             t4 += __shfl_xor(t4, 32, 64);
-            if (lane == 0) S.red[wave] = t4;
+            if (lane == 0) S.red()[wave] = t4;
         }
         if (ca.backward) {
             // d loss / d sp = -w/B on active terms, d/d sn = +w/B   (loss = sum_b w_b mean_b hinge)
@@ -972,19 +995,21 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
         }
     }
     __syncthreads();
-    if (tid == 0) ca.block_terms[ref.tb] = (S.red[0] + S.red[1]) + (S.red[2] + S.red[3]);
+    if (tid == 0) ca.block_terms[ref.tb] = (S.red()[0] + S.red()[1]) + (S.red()[2] + S.red()[3]);
     if (!ca.backward) return;
     chain_stamp(ca, 4);
-    const ChainParts &cp = ca.cparts[ref.batch];
     const int blk = g0 / CH_GB;
-    {   // bias gradient of the last pass: column sums of gH[L]
-        const int pr = cp.bias_part[L - 1];
-        chain_colsum<NCB, KS, NW>(S, S.xs + cur * BUF, b.live[L], ng, pr >= 0 ? ca.parts + (long long)(pr + blk) * D : nullptr);
+    // column sums of gH[L] per node slot (the readout's gradient rows): the last pass' bias gradient, and what
+    // the uniform part of the backward pass starts from
+    for (int n = 0; n < N; ++n) {
+        const int pr = b.lpart[n];
+        if (pr < 0) continue;           // (uniform over the workgroup)
+        chain_colsum<NCB, KS, NW>(S, S.xs + cur * BUF, 1u << n, ng, ca.parts + (long long)(pr + blk) * D);
     }
 
     // ---- backward levels
-    chain_run<NCB, KS, true, NW>(S, ref.fwd_count, ref.bwd_count * IPO, N, ng, ca.GH + row0 * D, ca.level_stride, cur, A,
-                         cp.bias_part, cp.var_part, ca.parts, blk);
+    chain_run<NCB, KS, true, NW>(S, ref.fwd_count, ref.bwd_count * IPO, N, ng, ca.GH + row0 * D, ca.level_stride, cur,
+                                 ca.parts, blk);
 
     chain_stamp(ca, 5);
     // ---- anchor rows of gH[0] through the L2 normalisation into the entity-table gradients (fp32 atomics:

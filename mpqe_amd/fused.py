@@ -39,23 +39,36 @@ _TEMPLATES = {   # query type -> (num anchors, num nodes, [(src, dst)]) : refere
 CHAIN_MAX_GRAPHS = 1 << 20          # csrc/step.hip
 
 
-def live_units(query_type, passes, readout, prune=True):
+def live_units(query_type, passes, readout, prune=True, uniform=False):
     """GEMM units ([B, D] x [D, D] products) the fused step executes per pass for one formula batch:
-    units[p] = edges whose destination state is live after pass p + live node slots (self terms). A
-    state is live when it can reach the readout (host mirror of the liveness masks in csrc/step.hip);
-    without pruning every pass has E + N units. Forward, backward-x and the weight
-    gradient each execute exactly these units."""
+    units[p] = (source slot, destination slot) pairs of pass p -- edges and self terms -- whose destination
+    state is live after pass p and whose source state is a per-graph one. A state is live when it can reach the
+    readout (host mirror of the liveness masks in csrc/step.hip); without pruning every pass has E + N units
+    (SURVEY.md 8d). uniform: states no anchor has reached yet are one vector per batch (csrc/step.hip: UOp) and
+    their products are matrix-vector work done once per batch, not counted here. Forward, backward-x and the
+    weight gradient each execute exactly these units."""
     A, N, edges = _TEMPLATES[query_type]
     full = (1 << N) - 1
-    live = (1 << A) if (prune and readout == 'mp') else full
-    units = [0] * passes
+    live = [0] * (passes + 1)
+    live[passes] = (1 << A) if (prune and readout == 'mp') else full
     for p in range(passes - 1, -1, -1):
-        units[p] = sum(1 for s, d in edges if (live >> d) & 1) + bin(live).count('1')
-        nxt = live
+        m = live[p + 1]
         for s, d in edges:
-            if (live >> d) & 1:
-                nxt |= 1 << s
-        live = nxt if prune else full
+            if (live[p + 1] >> d) & 1:
+                m |= 1 << s
+        live[p] = m if prune else full
+    uni = [0] * (passes + 1)
+    uni[0] = (full & ~((1 << A) - 1)) if uniform else 0
+    for p in range(passes):
+        m = uni[p]
+        for s, d in edges:
+            if not (uni[p] >> s) & 1:
+                m &= ~(1 << d)
+        uni[p + 1] = m
+    units = [0] * passes
+    for p in range(passes):
+        pairs = [(s, d) for s, d in edges] + [(n, n) for n in range(N)]
+        units[p] = sum(1 for s, d in pairs if (live[p + 1] >> d) & 1 and not (uni[p] >> s) & 1)
     return units
 
 
@@ -92,6 +105,7 @@ class FusedTrainStep(object):
         self.flags = ((0 if prune else _capi.STEP_NO_PRUNE) | (0 if chain else _capi.STEP_NO_CHAIN) |
                       (0 if ksplit else _capi.STEP_NO_KSPLIT) | (_capi.STEP_EIGHT_WAVES if eight_waves else 0) |
                       (0 if uniform else _capi.STEP_NO_UNIFORM))
+        self.uniform = bool(uniform and chain)
         self.device = next(model.parameters()).device
         if self.device.type != 'cuda':
             raise RuntimeError('mpqe_amd: the model must be on the GPU -- there is no CPU path')
@@ -167,7 +181,7 @@ class FusedTrainStep(object):
             # length), lane 1 = the rest -- the light lane finishes early and its weight-gradient launch runs
             # beside the heavy lane's chains
             prune = not (self.flags & _capi.STEP_NO_PRUNE)
-            work = [sum(live_units(b['formula'].query_type, p, m.readout_str, prune))
+            work = [sum(live_units(b['formula'].query_type, p, m.readout_str, prune, self.uniform))
                     for b, p in zip(batches, passes_of)]
             heavy = [i for i in range(nb) if work[i] >= 0.7 * max(work)]
             light = [i for i in range(nb) if i not in heavy]

@@ -60,6 +60,8 @@ def raise_on_flags(err):
                                   (2, 'edge endpoint outside [0, num_nodes)'),
                                   (4, 'edge type outside [0, num_relations)'),
                                   (8, 'scatter index outside [0, dim_size)')) if flags & bit]
+        if flags & 16:
+            raise RuntimeError('mpqe_amd: an in-launch hand-off between workgroups timed out (library fault)')
         raise IndexError('mpqe_amd: ' + '; '.join(names))
 
 

@@ -246,6 +246,8 @@ def test_fused_step_chain_kernels(be, D, readout, adaptive, shared, L):
     got = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0)
     lev = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_NO_CHAIN)
     runs = [got, lev]
+    # every node state as per-graph rows (the default treats states no anchor has reached yet as one vector per batch)
+    runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_NO_UNIFORM))
     if D == 64:
         runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_NO_PRUNE))
     if D == 128:      # the form whose waves own 32 columns and all of K (the default splits K between wave pairs)
