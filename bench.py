@@ -45,6 +45,8 @@ def parse():
     ap.add_argument('--batch-size', type=int, default=512)
     ap.add_argument('--readout', default='mp')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-self-check', action='store_true',
+                    help='skip the pre-timing comparison with the module path (timing experiments with builds that are wrong on purpose)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--path', default='auto', choices=['auto', 'modules', 'fused'])
     ap.add_argument('--lanes', type=int, default=1, help='HIP streams one fused step is spread over')
@@ -431,7 +433,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if use_fused:
+    if use_fused and not args.no_self_check:
         self_check(model, fstep, packed[0], pool[0], world)
     for i in range(args.warmup):
         one_step(i)

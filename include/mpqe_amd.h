@@ -293,6 +293,21 @@ size_t mpqe_step_workspace_bytes(const mpqe_step_params_t *params_host, const mp
  * collation, like the reference's collate_fn building edge_index / edge_type.                  */
 size_t mpqe_step_desc_bytes(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,
                             int num_batches, const mpqe_step_lanes_t *lanes /* the split the step will run with */);
+/* Entity-table gradients without float atomics ("touch plan"). The reference's autograd scatters the gradient rows
+ * of the looked-up entities into the dense tables with index_add (deterministic on the CPU). Which looked-up ids share
+ * a table row is a function of the ids alone, so it is found once per packed step, at collation time:
+ * mpqe_step_touch_build gathers (table, row) keys through node_map and sorts them (stable) into `touch`, a caller-owned
+ * device buffer (256-byte aligned, mpqe_step_touch_bytes; scratch: mpqe_step_touch_workspace_bytes, free after the
+ * call has run). Handed to mpqe_step_forward_backward (chain form), the step stores one gradient row per looked-up id
+ * and adds the rows of each table row in that fixed order: bit-reproducible, and no atomic traffic. touch = NULL keeps
+ * the fp32-atomic form (results equal up to the order of the additions). The ids must be the ones the step is run with. */
+size_t mpqe_step_touch_bytes(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,
+                             int num_batches);
+size_t mpqe_step_touch_workspace_bytes(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,
+                                       int num_batches);
+int mpqe_step_touch_build(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host, int num_batches,
+                          const int64_t *anchor_ids, const int64_t *targets, const int64_t *negs, void *touch,
+                          size_t touch_bytes, void *workspace, size_t workspace_bytes, void *stream);
 /* anchor_ids: per batch b a block of [A_b, B_b] ids (slot-major), blocks concatenated in batch
  * order; targets / negs: [sum_b B_b]. backward = 0 stops after the loss (grads may be NULL).
  * scores_pos / scores_neg: [sum_b B_b] or NULL. workspace must be 256-byte aligned.
@@ -310,7 +325,7 @@ int mpqe_step_forward_backward(const mpqe_step_params_t *params_host, const mpqe
                                float *scores_neg, void *desc, size_t desc_bytes, int upload_desc,
                                void *workspace, size_t workspace_bytes, int32_t *err,
                                const mpqe_step_lanes_t *lanes, void *const *events, int num_events,
-                               void *stream);
+                               const void *touch /* mpqe_step_touch_build's buffer, or NULL */, void *stream);
 
 /* ---- optimiser step ---------------------------------------------------------
  * reference train.py:83-88: optim.Adam(params, lr) / optim.SGD(params, lr, momentum=0) over every

@@ -95,7 +95,10 @@ PROTOTYPES = {
     'mpqe_step_desc_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, ctypes.POINTER(StepLanes)]),
     'mpqe_step_forward_backward': (I, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, P, P, P, F,
                                        ctypes.POINTER(StepGrads), I, P, P, P, P, Z, I, P, Z, P, ctypes.POINTER(StepLanes),
-                                       P, I, P]),
+                                       P, I, P, P]),
+    'mpqe_step_touch_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I]),
+    'mpqe_step_touch_workspace_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I]),
+    'mpqe_step_touch_build': (I, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, P, P, P, P, Z, P, Z, P]),
 }
 
 QUERY_TYPE_IDS = {'1-chain': 0, '2-chain': 1, '3-chain': 2, '2-inter': 3, '3-inter': 4,

@@ -124,6 +124,10 @@ struct RGroup {
 struct Rank1 {
     int u, v;          // vector ids: out[i][j] += VT[u][i] * VT[v][j]
 };
+#define R1_CHUNK 8
+#ifndef STEP_DBG
+#define STEP_DBG 0      // timing experiments only (wrong results): 1 = no table-sum rows in the reduction launch,
+#endif                  // 2 = no rank-1 terms, 3 = neither
 
 // ---- batch-uniform node states (chain form; include/mpqe_amd.h: MPQE_STEP_NO_UNIFORM) --------------------------
 // x0's variable rows are ONE mode_embeddings row for every graph of a batch (reference model.py:421), so a node state
@@ -219,6 +223,7 @@ __device__ __forceinline__ long long table_row(const long long *__restrict__ nod
 
 #include "step_chain.h"
 #include "step_uniform.h"
+#include "step_touch.h"
 
 template <int NCB, int KS, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void step_chain_kernel(const StepDev *__restrict__ sd, LayerPtrs lp,
@@ -244,7 +249,7 @@ struct ZeroSegs {
 __global__ __launch_bounds__(256) void step_prep_kernel(LayerPtrs lp, const WtSlot *__restrict__ slots, int nslots, int D,
                                                         float *__restrict__ WT, int tblocks, ZeroSegs zs, UArgs ua,
                                                         int ublocks) {
-    __shared__ float tile[32][33];
+    __shared__ __attribute__((aligned(16))) float tile[64][33];      // (transposes: the first 32 rows; vector ops: 2048 floats)
     // the forward pre-pass of the batch-uniform node states takes the first workgroups of the launch (a dependence
     // chain of up to L levels: started first, and its producers are dispatched before their consumers)
     if ((int)blockIdx.x < ublocks) {
@@ -847,10 +852,19 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restri
                                                           float *__restrict__ loss, int zeroed, LossMeta lm,
                                                           const float *__restrict__ bterms,
                                                           const Rank1 *__restrict__ rank1,
-                                                          const float *__restrict__ VT, unsigned *epoch_b) {
+                                                          const float *__restrict__ VT, unsigned *epoch_b,
+                                                          const char *__restrict__ touch, size_t touch_keys,
+                                                          size_t touch_perm, const float *__restrict__ DG,
+                                                          TablePtrs tabs) {
     // zeroed: this call zero-filled the gradients, so `out` is known to be 0 -- a store replaces the
     // read-modify-write (whose read would be one more dependent round trip at the end of the chain)
     __shared__ f32x4 part[4][64];
+    if ((int)blockIdx.y > ngroups) {        // further rows: entity-table gradients, per destination row (step_touch.h)
+        table_sum_block(reinterpret_cast<const TouchHeader *>(touch), reinterpret_cast<const tkey_t *>(touch + touch_keys),
+                        reinterpret_cast<const int *>(touch + touch_perm), DG, D, tabs, zeroed,
+                        (long long)((int)blockIdx.y - ngroups - 1) * gridDim.x + blockIdx.x);
+        return;
+    }
     if ((int)blockIdx.y == ngroups) {       // one extra workgroup row: the loss reduction rides along
         if (blockIdx.x == 0) {
             // the backward post-pass of this step is over: the next step's granules get a new tag (step_uniform.h)
@@ -928,20 +942,40 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restri
     }
     part[sg][el] = s;
     __syncthreads();
-    if (sg != 0 || !dst) return;
-    const bool have_old = vec && !zeroed && idx + 3 < elems;
     // rank-1 terms of a matrix group (sources whose input state is one vector per batch: out[i][j] += u[i] v[j],
-    // v = the column sum of the destination's gradient rows), added in table order after the slabs
+    // v = the column sum of the destination's gradient rows), added in table order after the slabs. The workgroup's
+    // 256 elements are rows [i0, i0 + 256 / D) x all D columns when D <= 256 (chain form: D = 64 / 128 / 256); the
+    // terms' records, then their u / v pieces, go through LDS in two cooperative rounds of independent loads per
+    // R1_CHUNK terms (a loop of dependent record -> vector loads per term was the launch's long pole).
     f32x4 r1 = {0.f, 0.f, 0.f, 0.f};
-    if (g.kind <= 1 && g.r1_count > 0 && idx < elems) {
-        for (int t = 0; t < g.r1_count; ++t) {
-            const Rank1 rk = rank1[g.r1_start + t];
-            const float *u = VT + (long long)rk.u * D, *v = VT + (long long)rk.v * D;
+    if (g.kind <= 1 && g.r1_count > 0 && !(STEP_DBG & 2)) {        // (uniform over the workgroup)
+        __shared__ Rank1 rrec[R1_CHUNK];
+        __shared__ float ru[R1_CHUNK][4], rv[R1_CHUNK][256];
+        const int rows = D <= 256 ? 256 / D : 1, cols = D <= 256 ? D : 256;
+        const long long e0 = (long long)blockIdx.x * 256;
+        const int i0 = (int)(e0 / D), j0 = (int)(e0 % D);
+        for (int t0 = 0; t0 < g.r1_count; t0 += R1_CHUNK) {
+            const int tc = g.r1_count - t0 < R1_CHUNK ? g.r1_count - t0 : R1_CHUNK;
+            if ((int)threadIdx.x < tc) rrec[threadIdx.x] = rank1[g.r1_start + t0 + threadIdx.x];
+            __syncthreads();
+            for (int q = threadIdx.x; q < tc * (rows + cols); q += 256) {
+                const int t = q / (rows + cols), w = q - t * (rows + cols);
+                if (w < rows) ru[t][w] = VT[(long long)rrec[t].u * D + i0 + w];
+                else rv[t][w - rows] = VT[(long long)rrec[t].v * D + j0 + (w - rows)];
+            }
+            __syncthreads();
+            if (sg == 0)
+                for (int t = 0; t < tc; ++t)
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (idx + k < elems) r1[k] += u[(idx + k) / D] * v[(idx + k) % D];
+                    for (int k = 0; k < 4; ++k) {
+                        const int o = (int)(idx + k - e0);
+                        r1[k] += ru[t][o / cols] * rv[t][o % cols];
+                    }
+            __syncthreads();
         }
     }
+    if (sg != 0 || !dst) return;
+    const bool have_old = vec && !zeroed && idx + 3 < elems;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (idx + k < elems) {
@@ -981,7 +1015,8 @@ struct HostPlan {
     std::vector<UOp> uops_f, uops_b;
     std::vector<Rank1> rank1;
     int nvec, ngran;
-    size_t o_uopf, o_uopb, o_rank1, o_epoch, o_gran, o_VT;
+    size_t o_uopf, o_uopb, o_rank1, o_epoch, o_gran, o_VT, o_DG;
+    long long touch_M;
     int blk_off[MPQE_STEP_MAX_BATCHES + 1];        // chain blocks before batch i (slots of block_terms)
     std::vector<ZMat> zmats;                       // relation matrices of the gradient that no source touches
     size_t o_zmats;
@@ -1787,6 +1822,8 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->o_WT = take(hp->wt_slots.size() * (size_t)D * D * 4);
     hp->o_bterms = take((size_t)hp->blk_off[nb] * 4);
     hp->o_VT = take((size_t)hp->nvec * D * 4);
+    hp->touch_M = anchors + 2 * graphs;
+    hp->o_DG = take(chain ? (size_t)hp->touch_M * D * 4 : 0);       // per-entry table-gradient rows (step_touch.h)
     hp->total = off;
     return MPQE_OK;
 }
@@ -1901,13 +1938,101 @@ extern "C" size_t mpqe_step_desc_bytes(const mpqe_step_params_t *P, const mpqe_s
     return hp.desc_total;
 }
 
+// ---- touch plan (step_touch.h)
+static int touch_dims(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, long long *M, int *row_bits,
+                      int *key_bits) {
+    if (!P || !B || nb < 1 || nb > MPQE_STEP_MAX_BATCHES || P->num_modes <= 0 || P->num_modes > MPQE_STEP_MAX_MODES)
+        return MPQE_ERR_INVALID_ARG;
+    *M = touch_entries(B, nb);
+    if (*M <= 0 || *M >= (1ll << 31)) return MPQE_ERR_INVALID_ARG;
+    long long rows = 1;
+    for (int m = 0; m < P->num_modes; ++m) rows = std::max(rows, (long long)P->table_rows[m]);
+    *row_bits = touch_bits(rows);
+    *key_bits = *row_bits + 5;          // table index (<= 16) above the row; an invalid entry has every bit set
+    return MPQE_OK;
+}
+extern "C" size_t mpqe_step_touch_bytes(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb) {
+    long long M;
+    int rb, kb;
+    if (touch_dims(P, B, nb, &M, &rb, &kb) != MPQE_OK) return 0;
+    return touch_layout(M, kb).total;
+}
+extern "C" size_t mpqe_step_touch_workspace_bytes(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb) {
+    long long M;
+    int rb, kb;
+    if (touch_dims(P, B, nb, &M, &rb, &kb) != MPQE_OK) return 0;
+    return touch_layout(M, kb).w_total;
+}
+extern "C" int mpqe_step_touch_build(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb,
+                                     const int64_t *anchor_ids, const int64_t *targets, const int64_t *negs,
+                                     void *touch, size_t touch_bytes, void *workspace, size_t workspace_bytes,
+                                     void *stream) {
+    long long M;
+    int rb, kb;
+    int st = touch_dims(P, B, nb, &M, &rb, &kb);
+    if (st) return st;
+    if (!anchor_ids || !targets || !negs || !touch || !workspace || !P->node_map) return MPQE_ERR_INVALID_ARG;
+    const TouchLayout L = touch_layout(M, kb);
+    if (touch_bytes < L.total || workspace_bytes < L.w_total) return MPQE_ERR_WORKSPACE;
+    if ((uintptr_t)touch % 256 != 0 || (uintptr_t)workspace % 256 != 0) return MPQE_ERR_INVALID_ARG;
+    hipStream_t s = as_stream(stream);
+    TouchMeta tm;
+    memset(&tm, 0, sizeof(tm));
+    tm.nb = nb;
+    tm.row_bits = rb;
+    long long anchors = 0, graphs = 0;
+    for (int i = 0; i < nb; ++i) {
+        const TemplateDesc &t = kTemplates[B[i].query_type];
+        tm.B[i] = B[i].batch_size;
+        tm.A[i] = t.A;
+        tm.anchor_off[i] = anchors;
+        tm.g_off[i] = graphs;
+        for (int a = 0; a < 3; ++a) {
+            tm.anchor_tab[i][a] = a < t.A ? B[i].anchor_mode[a] : 0;
+            if (a < t.A && (B[i].anchor_mode[a] < 0 || B[i].anchor_mode[a] >= P->num_modes)) return MPQE_ERR_INVALID_ARG;
+        }
+        if (B[i].target_mode < 0 || B[i].target_mode >= P->num_modes) return MPQE_ERR_INVALID_ARG;
+        tm.target_tab[i] = B[i].target_mode;
+        anchors += (long long)B[i].batch_size * t.A;
+        graphs += B[i].batch_size;
+    }
+    tm.anchor_off[nb] = anchors;
+    tm.g_off[nb] = graphs;
+    for (int m = 0; m < P->num_modes; ++m) tm.table_rows[m] = P->table_rows[m];
+    char *tb = reinterpret_cast<char *>(touch), *wb = reinterpret_cast<char *>(workspace);
+    TouchHeader th;
+    memset(&th, 0, sizeof(th));
+    th.M = M;
+    th.row_bits = rb;
+    th.key_bits = kb;
+    upload(s, tb, &th, sizeof(th));
+    tkey_t *keys = reinterpret_cast<tkey_t *>(wb + L.w_keys);
+    int *vals = reinterpret_cast<int *>(wb + L.w_vals);
+    hipLaunchKernelGGL(touch_keys_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, tm,
+                       reinterpret_cast<const long long *>(anchor_ids), reinterpret_cast<const long long *>(targets),
+                       reinterpret_cast<const long long *>(negs), reinterpret_cast<const long long *>(P->node_map),
+                       (long long)P->node_map_len, keys, vals, M);
+    size_t tmp_bytes = L.w_tmp_bytes;
+    // stable: entries of one destination row keep their entry order, so the per-row sums have ONE order
+    int *sorted_vals = reinterpret_cast<int *>(wb + L.w_keys);       // re-used after the sort below has consumed `keys`
+    if (rocprim::radix_sort_pairs(wb + L.w_tmp, tmp_bytes, (const tkey_t *)keys, reinterpret_cast<tkey_t *>(tb + L.keys),
+                                  (const int *)vals, reinterpret_cast<int *>(tb + L.perm), (size_t)M, 0u, (unsigned)kb,
+                                  s) != hipSuccess)
+        return MPQE_ERR_LAUNCH;
+    // entry -> rank: pos[perm[k]] = k, through a copy of perm (the inversion scatters over the array it reads)
+    (void)hipMemcpyAsync(sorted_vals, tb + L.perm, (size_t)M * sizeof(int), hipMemcpyDeviceToDevice, s);
+    hipLaunchKernelGGL(touch_invert_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, (const int *)sorted_vals,
+                       reinterpret_cast<int *>(tb + L.perm), M);
+    return mpqe_launch_status();
+}
+
 extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb,
                                           const int64_t *anchor_ids, const int64_t *targets, const int64_t *negs,
                                           float margin, const mpqe_step_grads_t *G, int backward,
                                           float *loss, float *scores_pos, float *scores_neg, void *desc,
                                           size_t desc_bytes, int upload_desc, void *workspace,
                                           size_t workspace_bytes, int32_t *err, const mpqe_step_lanes_t *lanes,
-                                          void *const *events, int num_events, void *stream) {
+                                          void *const *events, int num_events, const void *touch, void *stream) {
     if (!P || !B || nb < 1 || nb > MPQE_STEP_MAX_BATCHES || !desc) return MPQE_ERR_INVALID_ARG;
     const bool ask_chain = want_chain(P, B, nb);
     // The launch plan is a pure function of the descriptors; it is kept on the host next to the device
@@ -1933,6 +2058,13 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     }
     const HostPlan &hp = cached->hp;
     const bool use_chain = hp.chain;
+    // touch plan given: the chain form stores per-entry table-gradient rows and sums them per destination (no atomics)
+    bool use_touch = touch != nullptr && use_chain && backward;
+    if (use_touch) {
+        if ((uintptr_t)touch % 256 != 0) return MPQE_ERR_INVALID_ARG;
+        for (int m = 0; m < P->num_modes; ++m)
+            if (G->tables[m] && (uintptr_t)G->tables[m] % 16 != 0) return MPQE_ERR_INVALID_ARG;
+    }
     for (int l = 1; l < hp.nlanes; ++l)           // handles are per call, not part of the cached plan
         if (!lanes->fork_event || !lanes->aux_stream[l] || !lanes->join_event[l]) return MPQE_ERR_INVALID_ARG;
     if (!anchor_ids || !targets || !negs || !loss || !workspace) return MPQE_ERR_INVALID_ARG;
@@ -2162,6 +2294,11 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         ca.WT = WT;
         ca.VT = VT;
         ca.epoch_f = epoch_f;
+        ca.DG = use_touch ? reinterpret_cast<float *>(wb + hp.o_DG) : nullptr;
+        ca.dg_pos = use_touch ? reinterpret_cast<const int *>(reinterpret_cast<const char *>(touch) +
+                                                              touch_layout(hp.touch_M, 0).perm) : nullptr;
+        ca.Manchor = (long long)hp.anchor_off[nb];
+        ca.Gtot = hp.sd.graphs_total;
         ca.parts = reinterpret_cast<float *>(wb + hp.o_parts);
         ca.block_terms = reinterpret_cast<float *>(wb + hp.o_bterms);
         ca.level_stride = hp.level_stride;
@@ -2290,12 +2427,24 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     }
     {
         const long long elems = (long long)D * D;
-        dim3 grid((unsigned)((elems + 255) / 256), (unsigned)hp.groups.size() + 1);
+        const unsigned gx = (unsigned)((elems + 255) / 256);
+        // entity-table gradients from the per-entry rows: further grid rows, 256 / (D / 4) sorted positions per workgroup
+        TouchLayout tl;
+        memset(&tl, 0, sizeof(tl));
+        unsigned trows = 0;
+        if (use_touch) {
+            tl = touch_layout(hp.touch_M, 0);
+            const long long per = 256 / (D / 4), tblk = (hp.touch_M + per - 1) / per;
+            trows = (STEP_DBG & 1) ? 0u : (unsigned)((tblk + gx - 1) / gx);
+        }
+        dim3 grid(gx, (unsigned)hp.groups.size() + 1 + trows);
         hipLaunchKernelGGL(step_reduce_kernel, grid, dim3(256), 0, s,
                            reinterpret_cast<const RGroup *>(db + hp.o_groups), (int)hp.groups.size(), D, gp,
                            (const float *)slabs, (const float *)parts, (int)(D % 4 == 0), sd, (const float *)terms,
                            loss, (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0, lm, bterms,
-                           reinterpret_cast<const Rank1 *>(db + hp.o_rank1), (const float *)VT, epoch_b);
+                           reinterpret_cast<const Rank1 *>(db + hp.o_rank1), (const float *)VT, epoch_b,
+                           reinterpret_cast<const char *>(touch), tl.keys, tl.perm,
+                           (const float *)(wb + hp.o_DG), tabs);
     }
     return mpqe_launch_status();
 }

@@ -217,6 +217,7 @@ struct ChainLds {
     const float *wp[CH_MAX_OPS];                         // weight matrix of every op of the block's programme
     int opw[CH_MAX_OPS][2];                              // its (src | node << 8 | layer << 16 | level << 24, flags)
     int opp[CH_MAX_OPS];                                 // backward ops: ChainOp.aux (row of the column sums in `parts`); forward: cv slot
+    int dgrow[4 * CH_GB + 2 * CH_GB];                    // touch plan: row of DG of every node row / target (as rowp)
     int cvid[NCV];                                       // cv slot -> vector id (-1: the bias of layer cvl, -2: slot unused)
     int cvl[NCV];
     __device__ __forceinline__ float *red() { return cv; }
@@ -636,6 +637,10 @@ struct ChainArgs {
     const float *WT;        // transposed copies of the matrices the backward chains multiply by
     const float *VT;        // vector table [vector id][D]: constants / uniform node states of the pre-pass (step.hip)
     unsigned *epoch_f;      // forward hand-off epoch of this packed step: bumped once per chain launch (step.hip)
+    float *DG;              // touch plan (step_touch.h): the table-gradient row of entry e (anchors | + targets | - targets)
+                            // is stored to DG[dg_pos[e]] instead of added atomically; NULL = fp32 atomics into the tables
+    const int *dg_pos;
+    long long Manchor, Gtot;
     float *parts;
     float *block_terms;     // [blocks of the step]: sum of the block's hinge terms (the loss reduction reads these)
     long long level_stride;
@@ -662,12 +667,13 @@ __device__ __forceinline__ void chain_stamp(const ChainArgs &ca, int slot) {
     }
 #endif
 }
-__device__ __forceinline__ void chain_stamp_where(const ChainArgs &ca) {
+__device__ __forceinline__ void chain_stamp_where(const ChainArgs &ca, int batch, int fwd_ops) {
 #ifndef MPQE_EMU
     if (ca.stamps && threadIdx.x == 0) {
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_ID
         const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);         // XCC_ID[3:0]
-        ca.stamps[(long long)blockIdx.x * 8 + 7] = (long long)hw | ((long long)xcc << 32);
+        ca.stamps[(long long)blockIdx.x * 8 + 7] = (long long)hw | ((long long)xcc << 32) | ((long long)batch << 40) |
+                                                   ((long long)fwd_ops << 48);
     }
 #endif
 }
@@ -696,7 +702,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     const long long gi0 = b.g_off + g0;
 
     chain_stamp(ca, 0);
-    chain_stamp_where(ca);
+    chain_stamp_where(ca, ref.batch, ref.fwd_count);
 #if CHAIN_DBG == 6
     if (threadIdx.x == 0) {      // trace block 0 only: words [2 G * 8 ...) of the stamp buffer
         S.trace = (ca.stamps && blockIdx.x == 0) ? ca.stamps + (long long)gridDim.x * 16 : nullptr;
@@ -728,9 +734,11 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
                 }
             }
             S.gradp[tid] = gdst;
+            if (ca.dg_pos) S.dgrow[tid] = tid < nrows && n < A ? ca.dg_pos[b.anchor_off + (long long)n * b.B + g0 + i] : 0;
         } else {
             const int i = (tid - 4 * CH_GB) & (CH_GB - 1);
             const bool is_neg = tid >= 5 * CH_GB;
+            if (ca.dg_pos) S.dgrow[tid] = i < ng ? ca.dg_pos[ca.Manchor + (is_neg ? ca.Gtot : 0) + gi0 + i] : 0;
             if (i < ng) {
                 const int tab = b.target_tab;
                 const long long id = is_neg ? ca.negs[gi0 + i] : ca.targets[gi0 + i];
@@ -981,13 +989,24 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
             yg_p = gsum(yg_p);
             yg_n = gsum(yg_n);
             float *gt = tabs.grad[b.target_tab];
-            if (gt && on) {       // y = v / |v|:  dv = (g - y (y . g)) / |v|
+            if (ca.DG && on) {    // y = v / |v|:  dv = (g - y (y . g)) / |v|, stored as the entry's row (summed per table row later)
+                float *dp_ = ca.DG + (long long)S.dgrow[4 * CH_GB + i] * D, *dn_ = ca.DG + (long long)S.dgrow[5 * CH_GB + i] * D;
+#pragma unroll
+                for (int cc = 0; cc < CC; ++cc) {
+                    const int col = sl + 16 * cc;
+                    const float gyp = gsp * (q[cc] * inv_p - ktp * tp[cc]);
+                    const float gyn = gsn * (q[cc] * inv_n - ktn * tn[cc]);
+                    dp_[col] = pp_ ? (gyp - tp[cc] * yg_p) * ip0 : 0.f;
+                    dn_[col] = pn_ ? (gyn - tn[cc] * yg_n) * in0 : 0.f;
+                }
+            } else if (gt && on) {
                 const float *tb = tabs.table[b.target_tab];
 #pragma unroll
                 for (int cc = 0; cc < CC; ++cc) {
                     const int col = sl + 16 * cc;
                     const float gyp = gsp * (q[cc] * inv_p - ktp * tp[cc]);
                     const float gyn = gsn * (q[cc] * inv_n - ktn * tn[cc]);
+                    if (CHAIN_DBG == 8) continue;         // (timing experiment: no table atomics, wrong results)
                     if (pp_) atomicAdd(gt + (pp_ - tb) + col, (gyp - tp[cc] * yg_p) * ip0);
                     if (pn_) atomicAdd(gt + (pn_ - tb) + col, (gyn - tn[cc] * yg_n) * in0);
                 }
@@ -1037,8 +1056,19 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
 #pragma unroll
             for (int off = LPR >> 1; off >= 16; off >>= 1) yg += __shfl_xor(yg, off, 64);
             yg = chain_sum16(yg);
+            if (ca.DG) {          // the entry's gradient row, one 16-byte store (a pruned or invalid anchor: zeros)
+                if (k < nk && r < nrows && n < A) {
+                    const bool ok = on && S.rowp[r] != nullptr;
+                    const float inv = ok ? S.nrm[r] : 0.f;
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = ok ? (g[e] - y[k][e] * yg) * inv : 0.f;
+                    *reinterpret_cast<f32x4 *>(ca.DG + (long long)S.dgrow[r] * D + 4 * c4) = o;
+                }
+                continue;
+            }
             float *gd = on ? S.gradp[r] : nullptr;
-            if (gd) {
+            if (gd && CHAIN_DBG != 7 && CHAIN_DBG != 8) {
                 const float inv = S.nrm[r];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) atomicAdd(gd + 4 * c4 + e, (g[e] - y[k][e] * yg) * inv);

@@ -5,8 +5,8 @@
 //
 //   producer   one 8-byte agent-scope atomic store per element (tag in the high word, the float in the low one):
 //              the datum is its own flag, no fence, no separate flag word
-//   consumer   each lane re-reads the granules it needs with agent-scope atomic loads (they bypass this CU's L1)
-//              until the tag matches; bounded -- a hand-off that never arrives sets MPQE_FLAG_INTERNAL instead
+//   consumer   one thread per element re-reads its granules with agent-scope atomic loads (they bypass this CU's
+//              L1) until the tags match, then the vector goes through LDS to the workgroup; bounded -- a hand-off that never arrives sets MPQE_FLAG_INTERNAL instead
 //              of hanging the device
 //   tag        (epoch word of the packed step) + 1, the epoch being bumped by a LATER launch of the same step, so
 //              it is never a kernel argument (frozen under hipGraph replay) and stale granules of the previous
@@ -31,23 +31,6 @@ __device__ __forceinline__ void gran_store(u64 *g, unsigned tag, float v) {
     __hip_atomic_store((gu64_ptr)g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
-// value of granule g once its tag matches (per lane; lanes of a wave may wait for different granules)
-__device__ __forceinline__ float gran_wait(const u64 *g, unsigned tag, int32_t *err) {
-    for (int spins = 0; spins < UOP_SPIN_LIMIT; ++spins) {
-#ifdef MPQE_EMU
-        const u64 x = *g;
-#else
-        const u64 x = __hip_atomic_load((gu64_ptr)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-        if ((unsigned)(x >> 32) == tag) return __uint_as_float((unsigned)x);
-#ifndef MPQE_EMU
-        __builtin_amdgcn_s_sleep(1);
-#endif
-    }
-    flag_error(err, MPQE_FLAG_INTERNAL);
-    return 0.f;
-}
-
 struct UArgs {
     const UOp *ops;
     int nops, chunks;           // chunks = D / 64 workgroups per op
@@ -60,15 +43,73 @@ struct UArgs {
     int32_t *err;
 };
 
-// element e (0 .. D) of input t of `op`
-__device__ __forceinline__ float uop_input(const UOp &op, int t, int e, int D, const UArgs &ua, unsigned tag) {
-    const int kind = op.in_kind[t];
-    if (kind == 0) return gran_wait(ua.gran + (long long)op.in_gran[t] * D + e, tag, ua.err);
-    if (kind == 1) {
-        const long long m = op.in_vec[t];
-        return (m >= 0 && m < ua.num_modes) ? gload1(ua.mode_emb + m * D + e) : 0.f;      // (a bad id is flagged by the chain kernel)
+// The op's input vectors, all terms, into LDS (xs[t * D + e]) by the whole workgroup: every element is fetched by ONE
+// thread -- a granule is polled by one lane of the workgroup, not by every lane that multiplies by it -- and a thread's
+// NP elements are requested together and re-requested together until all of their tags match (one round trip per
+// attempt, not one per element). Ends with a workgroup barrier.
+template <int D>
+__device__ __forceinline__ void uop_fetch_inputs(const UOp &op, const UArgs &ua, unsigned tag, float *xs) {
+    constexpr int NP = UOP_MAX_TERMS * D / 256;          // elements per thread: element idx = tid + 256 q
+    const int tid = threadIdx.x, total = op.nterms * D;
+    float x[NP];
+    const u64 *gp[NP];
+    bool pend[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int idx = tid + 256 * q;
+        x[q] = 0.f;
+        gp[q] = nullptr;
+        pend[q] = false;
+        if (idx >= total) continue;
+        const int t = idx / D, e = idx - t * D;
+        const int kind = op.in_kind[t];
+        if (kind == 0) {
+            gp[q] = ua.gran + (long long)op.in_gran[t] * D + e;
+            pend[q] = true;
+        } else if (kind == 1) {
+            const long long m = op.in_vec[t];            // (a bad mode id is flagged by the chain kernel: zero row)
+            if (m >= 0 && m < ua.num_modes) x[q] = gload1(ua.mode_emb + m * D + e);
+        } else {
+            x[q] = gload1(ua.VT + (long long)op.in_vec[t] * D + e);
+        }
     }
-    return gload1(ua.VT + (long long)op.in_vec[t] * D + e);
+    for (int spins = 0;; ++spins) {
+        u64 g[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            g[q] = 0;
+            if (pend[q]) {
+#ifdef MPQE_EMU
+                g[q] = *gp[q];
+#else
+                g[q] = __hip_atomic_load((gu64_ptr)gp[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+            }
+        }
+        bool left = false;
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+            if (pend[q]) {
+                if ((unsigned)(g[q] >> 32) == tag) {
+                    x[q] = __uint_as_float((unsigned)g[q]);
+                    pend[q] = false;
+                } else {
+                    left = true;
+                }
+            }
+        if (!left) break;
+        if (spins >= UOP_SPIN_LIMIT) {           // (never, unless the launch is broken: report instead of hanging)
+            flag_error(ua.err, MPQE_FLAG_INTERNAL);
+            break;
+        }
+#ifndef MPQE_EMU
+        __builtin_amdgcn_s_sleep(1);
+#endif
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+        if (tid + 256 * q < total) xs[tid + 256 * q] = x[q];
+    __syncthreads();
 }
 
 __device__ __forceinline__ void uop_publish(const UOp &op, int e, int D, float v, const UArgs &ua, unsigned tag) {
@@ -107,6 +148,7 @@ __device__ __forceinline__ void uop_run(const UOp &op, int chunk, const LayerPtr
         const int c4 = tid & 15, kg = tid >> 4;
         const int col = chunk * 64 + 4 * c4;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float *xs = smem + 1024;
         for (int t0 = 0; t0 < op.nterms; t0 += 2) {
             f32x4 w[2][KI];
 #pragma unroll
@@ -117,14 +159,12 @@ __device__ __forceinline__ void uop_run(const UOp &op, int chunk, const LayerPtr
 #pragma unroll
                 for (int i = 0; i < KI; ++i) w[tt][i] = gload4(M + (long long)(kg + 16 * i) * D + col);
             }
+            if (t0 == 0) uop_fetch_inputs<D>(op, ua, tag, xs);      // (behind the first matrix requests)
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 if (t0 + tt >= op.nterms) break;
 #pragma unroll
-                for (int i = 0; i < KI; ++i) {
-                    const float x = uop_input(op, t0 + tt, kg + 16 * i, D, ua, tag);
-                    acc += x * w[tt][i];
-                }
+                for (int i = 0; i < KI; ++i) acc += xs[(t0 + tt) * D + kg + 16 * i] * w[tt][i];
             }
         }
 #pragma unroll
@@ -148,6 +188,7 @@ __device__ __forceinline__ void uop_run(const UOp &op, int chunk, const LayerPtr
     constexpr int CJ = D / 64;
     const int l = tid & 15, r = tid >> 4;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float *xs = smem + 1024;
     for (int t0 = 0; t0 < op.nterms; t0 += 2) {
         f32x4 w[2][4][CJ];
 #pragma unroll
@@ -161,14 +202,13 @@ __device__ __forceinline__ void uop_run(const UOp &op, int chunk, const LayerPtr
                 for (int c = 0; c < CJ; ++c)
                     w[tt][q][c] = gload4(M + (long long)(chunk * 64 + r + 16 * q) * D + 4 * l + 64 * c);
         }
+        if (t0 == 0) uop_fetch_inputs<D>(op, ua, tag, xs);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             if (t0 + tt >= op.nterms) break;
 #pragma unroll
             for (int c = 0; c < CJ; ++c) {
-                float sv[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sv[e] = uop_input(op, t0 + tt, 4 * l + 64 * c + e, D, ua, tag);
+                const f32x4 sv = *reinterpret_cast<const f32x4 *>(xs + (t0 + tt) * D + 4 * l + 64 * c);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll

@@ -22,7 +22,8 @@ from .data_utils import RGCNQueryDataset
 
 class PackedStep(object):
     __slots__ = ('batches', 'nb', 'anchor_ids', 'targets', 'negs', 'num_graphs', 'ws_bytes', 'sizes',
-                 'desc', 'desc_bytes', 'desc_ptr', 'desc_resident', 'lanes', 'order', 'lane_begin')
+                 'desc', 'desc_bytes', 'desc_ptr', 'desc_resident', 'lanes', 'order', 'lane_begin', 'touch',
+                 'touch_ptr')
 
 
 def _batch_work(query_type, passes):
@@ -92,7 +93,7 @@ class FusedTrainStep(object):
     batches of equal depth together (longest chains first)."""
 
     def __init__(self, model, margin=1.0, lanes=1, prune=True, chain=True, ksplit=True, eight_waves=False,
-                 uniform=True):
+                 uniform=True, touch=True):
         enc = model.enc
         if not hasattr(enc, 'table') or getattr(enc, 'node_maps', None) is None:
             raise ValueError('FusedTrainStep needs a DirectEncoder built with node_maps')
@@ -106,6 +107,8 @@ class FusedTrainStep(object):
                       (0 if ksplit else _capi.STEP_NO_KSPLIT) | (_capi.STEP_EIGHT_WAVES if eight_waves else 0) |
                       (0 if uniform else _capi.STEP_NO_UNIFORM))
         self.uniform = bool(uniform and chain)
+        # entity-table gradients summed per table row in a fixed order (touch plan) instead of fp32 atomics
+        self.touch = bool(touch and chain)
         self.device = next(model.parameters()).device
         if self.device.type != 'cuda':
             raise RuntimeError('mpqe_amd: the model must be on the GPU -- there is no CPU path')
@@ -255,7 +258,32 @@ class FusedTrainStep(object):
         ps.desc = torch.empty(ps.desc_bytes + 256, dtype=torch.uint8, device=self.device)
         ps.desc_ptr = (ps.desc.data_ptr() + 255) // 256 * 256
         ps.desc_resident = False
+        ps.touch, ps.touch_ptr = None, None
+        if self.touch:
+            self.build_touch(ps)
         return ps
+
+    def build_touch(self, ps):
+        """The touch plan of the packed step's ids (include/mpqe_amd.h: mpqe_step_touch_build): which looked-up
+        entities share a table row, sorted once here, so that the step adds their gradient rows in a fixed order
+        instead of with float atomics. Stream-ordered on the current stream, no synchronisation. Call it again
+        after refilling ps.anchor_ids / targets / negs in place with new ids."""
+        L = ops.lib()
+        nbytes = L.mpqe_step_touch_bytes(ctypes.byref(self.P), ps.batches, ps.nb)
+        wbytes = L.mpqe_step_touch_workspace_bytes(ctypes.byref(self.P), ps.batches, ps.nb)
+        if nbytes == 0:
+            raise _capi.MpqeError('mpqe_step_touch_bytes rejected the step descriptors')
+        if ps.touch is None:
+            ps.touch = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            ps.touch_ptr = (ps.touch.data_ptr() + 255) // 256 * 256
+        ws = torch.empty(wbytes + 256, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            st = L.mpqe_step_touch_build(ctypes.byref(self.P), ps.batches, ps.nb, ps.anchor_ids.data_ptr(),
+                                         ps.targets.data_ptr(), ps.negs.data_ptr(), ps.touch_ptr, nbytes,
+                                         (ws.data_ptr() + 255) // 256 * 256, wbytes,
+                                         torch.cuda.current_stream().cuda_stream)
+        _capi.check(L, st, 'mpqe_step_touch_build')
+        ws.record_stream(torch.cuda.current_stream())
 
     def uses_chain(self, packed):
         """True when the library runs the graph-block chain kernels for this step (csrc/step.hip)."""
@@ -297,7 +325,8 @@ class FusedTrainStep(object):
                 1 if backward else 0, loss.data_ptr(), None if sp is None else sp.data_ptr(),
                 None if sn is None else sn.data_ptr(), packed.desc_ptr, packed.desc_bytes,
                 0 if packed.desc_resident else 1, wptr, packed.ws_bytes, self.err.data_ptr(), packed.lanes,
-                events, 0 if events is None else len(events), torch.cuda.current_stream().cuda_stream)
+                events, 0 if events is None else len(events), packed.touch_ptr,
+                torch.cuda.current_stream().cuda_stream)
         _capi.check(ops.lib(), st, 'mpqe_step_forward_backward')
         packed.desc_resident = True
         if scores:

@@ -70,7 +70,7 @@ def oracle_step(params, cfg, node_map, batches, margin):
     return total.item(), per, np.concatenate(sp), np.concatenate(sn)
 
 
-def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=1, lanes=None, flags=0):
+def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=1, lanes=None, flags=0, touch=True):
     D = params['mode_embeddings.weight'].shape[1]
     L = cfg['num_layers']
     R = params['layers.0.basis'].shape[0]
@@ -160,10 +160,20 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
     loss = be.empty((1 + nb,))
     sp, sn = be.empty((Gtot,)), be.empty((Gtot,))
     err = be.zeros((1,), np.int32)
+    tptr = None
+    if touch:
+        tb = be.lib.mpqe_step_touch_bytes(ctypes.byref(P), SB, nb)
+        twb = be.lib.mpqe_step_touch_workspace_bytes(ctypes.byref(P), SB, nb)
+        assert tb > 0 and twb > 0
+        tbuf, twbuf = be.nbytes(tb + 256), be.nbytes(twb + 256)
+        tptr = (be.ptr(tbuf) + 255) // 256 * 256
+        be.check(be.lib.mpqe_step_touch_build(ctypes.byref(P), SB, nb, be.ptr(d_anchor), be.ptr(d_tg), be.ptr(d_ng), tptr, tb,
+                                              (be.ptr(twbuf) + 255) // 256 * 256, twb, be.stream), 'touch')
+        keep.extend([tbuf, twbuf])
     be.check(be.lib.mpqe_step_forward_backward(ctypes.byref(P), SB, nb, be.ptr(d_anchor), be.ptr(d_tg),
                                                be.ptr(d_ng), margin, ctypes.byref(G), backward, be.ptr(loss),
                                                be.ptr(sp), be.ptr(sn), dptr, dsb, 1, wptr, wsb, be.ptr(err), lanes, None, 0,
-                                               be.stream), 'step')
+                                               tptr, be.stream), 'step')
     grads = {'mode_embeddings.weight': be.get(gmode)}
     for m, g in zip(modes, gtabs):
         grads['enc.feat-%s.weight' % m] = be.get(g)
@@ -248,6 +258,11 @@ def test_fused_step_chain_kernels(be, D, readout, adaptive, shared, L):
     runs = [got, lev]
     # every node state as per-graph rows (the default treats states no anchor has reached yet as one vector per batch)
     runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_NO_UNIFORM))
+    # entity-table gradients by fp32 atomics instead of the per-row sums of the touch plan
+    runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, touch=False))
+    again = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0)
+    for k in got[3]:          # with the touch plan EVERY gradient is bit-reproducible, the entity tables included
+        np.testing.assert_array_equal(again[3][k], got[3][k], err_msg=k)
     if D == 64:
         runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_NO_PRUNE))
     if D == 128:      # the form whose waves own 32 columns and all of K (the default splits K between wave pairs)

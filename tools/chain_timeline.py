@@ -153,6 +153,14 @@ def main():
         print('  %4d  start %5.1f  ' % (bidx, t[bidx, 0]) + ' '.join('%5.1f' % (t[bidx, k + 1] - t[bidx, k]) for k in range(6))
               + '  total %5.1f  mates %d' % (dur[bidx], mates))
     print('workgroups per XCD: %s' % dict(zip(*np.unique(xcc, return_counts=True))))
+    batch, fops = (st[:, 7] >> 40) & 0xff, (st[:, 7] >> 48) & 0xff
+    print('per batch (library order): [batch, forward K-blocks, blocks, XCDs, mean of A1, A2, fwd, score, bwd, anchors, total; max end]')
+    for bi in np.unique(batch):
+        m = batch == bi
+        print('  %3d  kblocks %2d  blocks %3d  xcc %s  ' % (bi, int(fops[m][0]), int(m.sum()), sorted(set(xcc[m].tolist())))
+              + ' '.join('%5.1f' % (t[m, k + 1] - t[m, k]).mean() for k in range(6))
+              + '  total %5.1f  max end %5.1f  mates %.1f' % (dur[m].mean(), t[m, 6].max(),
+                                                              np.mean([(place == pl).sum() for pl in place[m]])))
     if args.out:
         json.dump(dict(t=t.tolist(), place=place.tolist()), open(args.out, 'w'))
 
