@@ -49,7 +49,7 @@ def parse():
                     help='skip the pre-timing comparison with the module path (timing experiments with builds that are wrong on purpose)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--path', default='auto', choices=['auto', 'modules', 'fused'])
-    ap.add_argument('--lanes', type=int, default=1, help='HIP streams one fused step is spread over')
+    ap.add_argument('--lanes', type=int, default=1, help='HIP streams one fused step is spread over (level form only)')
     ap.add_argument('--graph', type=int, default=0,
                     help='1: replay each step from a captured hipGraph')
     ap.add_argument('--no-prune', action='store_true', help='compute node states that cannot reach the readout too')

@@ -150,19 +150,23 @@ struct Rank1 {
 #define UOP_BWD 1      // out = mask(VT[mask_vec] > 0) * sum_t in_t . M_t^T
 #define UOP_RED 2      // out = sum of `nrows` consecutive rows of `parts` from row0
 #define UOP_COPY 3     // out = mode_emb[mode_row]
+#define UOP_R1 4       // gradient matrix (layer r1_layer, relation r1_rel | -1 root) = sum_t VT[u_vec[t]] (x) in_t: a matrix
+                       // whose only contributions are rank-1 terms is written here, not by the reduction launch
 #define UOP_MAX_TERMS 4
 struct UOp {
     int kind, out_vec, out_gran;       // out_gran: granule slot of the output (-1: nobody reads it inside the launch)
     int out_part;                      // >= 0: the output is also written to this row of `parts` (a reduction group's input)
     int nterms;
     int in_vec[UOP_MAX_TERMS];         // vector id (in_kind 0: read from its granules; 2: plain, written by an earlier launch)
-    int in_kind[UOP_MAX_TERMS];        // 0 granules, 1 row in_vec of mode_emb, 2 plain VT
+    int in_kind[UOP_MAX_TERMS];        // 0 granules, 1 row in_vec of mode_emb, 2 plain VT, 3 sum of in_gran rows of `parts` from row in_vec
     int in_gran[UOP_MAX_TERMS];
     int layer[UOP_MAX_TERMS], mat[UOP_MAX_TERMS];      // matrix: relation id or -1 = root, of layer `layer`
     int bias_layer, relu;              // FWD
     int mask_vec;                      // BWD: -1 = no mask
     int row0, nrows;                   // RED
     long long mode_row;                // COPY
+    int u_vec[UOP_MAX_TERMS];          // R1
+    int r1_layer, r1_rel;
 };
 
 struct Blob {
@@ -221,6 +225,18 @@ __device__ __forceinline__ long long table_row(const long long *__restrict__ nod
     return r;
 }
 
+struct GradPtrs {
+    float *basis[MPQE_STEP_MAX_LAYERS], *root[MPQE_STEP_MAX_LAYERS], *bias[MPQE_STEP_MAX_LAYERS];
+    float *mode_emb;
+};
+__device__ __forceinline__ float *pick_grad(float *const *arr, int li) {
+    float *r = arr[0];
+#pragma unroll
+    for (int l = 1; l < MPQE_STEP_MAX_LAYERS; ++l)
+        if (l == li) r = arr[l];
+    return r;
+}
+
 #include "step_chain.h"
 #include "step_uniform.h"
 #include "step_touch.h"
@@ -253,7 +269,7 @@ __global__ __launch_bounds__(256) void step_prep_kernel(LayerPtrs lp, const WtSl
     // the forward pre-pass of the batch-uniform node states takes the first workgroups of the launch (a dependence
     // chain of up to L levels: started first, and its producers are dispatched before their consumers)
     if ((int)blockIdx.x < ublocks) {
-        uop_block((int)blockIdx.x, D, lp, ua, &tile[0][0]);
+        uop_block((int)blockIdx.x, D, lp, ua, &tile[0][0], nullptr, 0);
         return;
     }
     const int bid = (int)blockIdx.x - ublocks;
@@ -611,18 +627,6 @@ __global__ __launch_bounds__(1024) void step_loss_kernel(const StepDev *__restri
     else loss_block(sd, terms, loss, mean, 16);
 }
 
-struct GradPtrs {
-    float *basis[MPQE_STEP_MAX_LAYERS], *root[MPQE_STEP_MAX_LAYERS], *bias[MPQE_STEP_MAX_LAYERS];
-    float *mode_emb;
-};
-__device__ __forceinline__ float *pick_grad(float *const *arr, int li) {
-    float *r = arr[0];
-#pragma unroll
-    for (int l = 1; l < MPQE_STEP_MAX_LAYERS; ++l)
-        if (l == li) r = arr[l];
-    return r;
-}
-
 // ------------------------------------------------------------------------------------ weight gradients
 template <int MODE>
 __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, const WSource *__restrict__ src,
@@ -772,6 +776,7 @@ struct TailArgs {
     const ZMat *zmats;       // untouched gradient matrices, zero-filled by workgroups [wblocks, wblocks + zblocks)
     int zblocks, zper;       // zper = workgroups per matrix
     int ublocks;             // the backward post-pass of the uniform node states: the FIRST ublocks workgroups
+
     const long long *node_map;
     long long map_len;
     const long long *anchor_ids;
@@ -796,7 +801,13 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
     }
 #endif
     if ((int)blockIdx.x < ta.ublocks) {         // uniform node states, backward: vector ops on column sums
-        uop_block((int)blockIdx.x, sd->D, lp, ua, smem);
+        uop_block((int)blockIdx.x, sd->D, lp, ua, smem, &gp, zeroed);
+#ifndef MPQE_EMU
+        if (ta.stamps && threadIdx.x == 0) {
+            ta.stamps[(long long)blockIdx.x * 8 + 5] = (long long)wall_clock64();       // (word 1 stays 0: not a tile)
+            ta.stamps[(long long)blockIdx.x * 8 + 6] = 1 + (long long)ua.ops[blockIdx.x / ua.chunks].kind;
+        }
+#endif
         return;
     }
     const int tb = (int)blockIdx.x - ta.ublocks;
@@ -854,15 +865,15 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restri
                                                           const Rank1 *__restrict__ rank1,
                                                           const float *__restrict__ VT, unsigned *epoch_b,
                                                           const char *__restrict__ touch, size_t touch_keys,
-                                                          size_t touch_perm, const float *__restrict__ DG,
-                                                          TablePtrs tabs) {
+                                                          const float *__restrict__ DG, TablePtrs tabs) {
     // zeroed: this call zero-filled the gradients, so `out` is known to be 0 -- a store replaces the
     // read-modify-write (whose read would be one more dependent round trip at the end of the chain)
     __shared__ f32x4 part[4][64];
-    if ((int)blockIdx.y > ngroups) {        // further rows: entity-table gradients, per destination row (step_touch.h)
+    if ((int)blockIdx.y > ngroups) {        // further rows: entity-table gradients, per destination row (step_touch.h).
+        // (As workgroups of the weight-gradient launch they are throttled to two per CU by its 64 KB of LDS: 23.6 us
+        // for that launch instead of 16.6; here they cost 2.6 us.)
         table_sum_block(reinterpret_cast<const TouchHeader *>(touch), reinterpret_cast<const tkey_t *>(touch + touch_keys),
-                        reinterpret_cast<const int *>(touch + touch_perm), DG, D, tabs, zeroed,
-                        (long long)((int)blockIdx.y - ngroups - 1) * gridDim.x + blockIdx.x);
+                        nullptr, DG, D, tabs, zeroed, (long long)((int)blockIdx.y - ngroups - 1) * gridDim.x + blockIdx.x);
         return;
     }
     if ((int)blockIdx.y == ngroups) {       // one extra workgroup row: the loss reduction rides along
@@ -918,6 +929,29 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restri
     else if (g.kind == 1) dst = gp.root[g.layer];
     else if (g.kind == 2) dst = gp.bias[g.layer];
     else dst = gp.mode_emb ? gp.mode_emb + g.row * D : nullptr;
+    // rank-1 terms of a matrix group (sources whose input state is one vector per batch: out[i][j] += u[i] v[j], v = the
+    // column sum of the destination's gradient rows; chain form, D % 64 == 0). Wave sg takes terms sg, sg + 4, ... in
+    // order into its partial sum: their records are requested together, then their u / v pieces together -- two round
+    // trips next to the slab loads whatever the count (a loop of dependent record -> vector loads per term, and then a
+    // staged version with two workgroup barriers per eight terms, were the launch's long pole).
+    if (g.kind <= 1 && g.r1_count > 0 && vec && idx + 3 < elems && !(STEP_DBG & 2)) {
+        const int i = (int)(idx / D), j = (int)(idx % D);
+        for (int t0 = sg; t0 < g.r1_count; t0 += 4 * R1_CHUNK) {
+            Rank1 rk[R1_CHUNK];
+#pragma unroll
+            for (int q = 0; q < R1_CHUNK; ++q) rk[q] = rank1[g.r1_start + (t0 + 4 * q < g.r1_count ? t0 + 4 * q : t0)];
+            float u[R1_CHUNK];
+            f32x4 v[R1_CHUNK];
+#pragma unroll
+            for (int q = 0; q < R1_CHUNK; ++q) {
+                u[q] = gload1(VT + (long long)rk[q].u * D + i);
+                v[q] = gload4(VT + (long long)rk[q].v * D + j);
+            }
+#pragma unroll
+            for (int q = 0; q < R1_CHUNK; ++q)
+                if (t0 + 4 * q < g.r1_count) s += u[q] * v[q];
+        }
+    }
     f32x4 old4 = {0.f, 0.f, 0.f, 0.f};       // accumulate mode: the old value travels with the slab loads, not after them
     if (vec && dst && !zeroed && sg == 0 && idx + 3 < elems) old4 = gload4(dst + idx);
     if (vec) {
@@ -942,44 +976,12 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restri
     }
     part[sg][el] = s;
     __syncthreads();
-    // rank-1 terms of a matrix group (sources whose input state is one vector per batch: out[i][j] += u[i] v[j],
-    // v = the column sum of the destination's gradient rows), added in table order after the slabs. The workgroup's
-    // 256 elements are rows [i0, i0 + 256 / D) x all D columns when D <= 256 (chain form: D = 64 / 128 / 256); the
-    // terms' records, then their u / v pieces, go through LDS in two cooperative rounds of independent loads per
-    // R1_CHUNK terms (a loop of dependent record -> vector loads per term was the launch's long pole).
-    f32x4 r1 = {0.f, 0.f, 0.f, 0.f};
-    if (g.kind <= 1 && g.r1_count > 0 && !(STEP_DBG & 2)) {        // (uniform over the workgroup)
-        __shared__ Rank1 rrec[R1_CHUNK];
-        __shared__ float ru[R1_CHUNK][4], rv[R1_CHUNK][256];
-        const int rows = D <= 256 ? 256 / D : 1, cols = D <= 256 ? D : 256;
-        const long long e0 = (long long)blockIdx.x * 256;
-        const int i0 = (int)(e0 / D), j0 = (int)(e0 % D);
-        for (int t0 = 0; t0 < g.r1_count; t0 += R1_CHUNK) {
-            const int tc = g.r1_count - t0 < R1_CHUNK ? g.r1_count - t0 : R1_CHUNK;
-            if ((int)threadIdx.x < tc) rrec[threadIdx.x] = rank1[g.r1_start + t0 + threadIdx.x];
-            __syncthreads();
-            for (int q = threadIdx.x; q < tc * (rows + cols); q += 256) {
-                const int t = q / (rows + cols), w = q - t * (rows + cols);
-                if (w < rows) ru[t][w] = VT[(long long)rrec[t].u * D + i0 + w];
-                else rv[t][w - rows] = VT[(long long)rrec[t].v * D + j0 + (w - rows)];
-            }
-            __syncthreads();
-            if (sg == 0)
-                for (int t = 0; t < tc; ++t)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int o = (int)(idx + k - e0);
-                        r1[k] += ru[t][o / cols] * rv[t][o % cols];
-                    }
-            __syncthreads();
-        }
-    }
     if (sg != 0 || !dst) return;
     const bool have_old = vec && !zeroed && idx + 3 < elems;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (idx + k < elems) {
-            const float sum = ((part[0][el][k] + part[1][el][k]) + (part[2][el][k] + part[3][el][k])) + r1[k];
+            const float sum = (part[0][el][k] + part[1][el][k]) + (part[2][el][k] + part[3][el][k]);
             dst[idx + k] = zeroed ? sum : (have_old ? old4[k] : dst[idx + k]) + sum;
         }
 }
@@ -1028,10 +1030,11 @@ struct HostPlan {
     long long level_stride;
 };
 
-void pick_chunks(long long count, int max_chunks, int *nch, int *ch) {
+void pick_chunks(long long count, int max_chunks, int *nch, int *ch, int rows = 512) {
     // ~512 rows (16 K-steps) per workgroup: long enough to amortise the pipeline fill and the
     // 16 KB slab store, short enough that the AIFB-sized step still yields ~500 workgroups
-    long long n = (count + 511) / 512;      // (256- and 128-row chunks measured slower: 0.102 vs 0.097 ms per step)
+    // (`rows`: the planner halves it while the step's tiles would leave most CUs without one)
+    long long n = (count + rows - 1) / rows;
     if (n < 1) n = 1;
     if (n > max_chunks) n = max_chunks;
     long long c = (count + n - 1) / n;
@@ -1294,12 +1297,32 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     // CUs (264 for the AIFB mix) means a handful of CUs run two whole tiles and the launch lasts twice a tile.
     // Then the surplus is taken out of a few ROOT sources (they go through the reduction anyway), cut into
     // four K-chunks: their short workgroups ride along on CUs that also hold one whole tile.
+    // K-chunk length: with few sources (the chain form's uniform node states leave 34 of the AIFB mix's 66) whole-batch
+    // chunks would put a 14 us tile on half of the CUs and nothing on the rest: halve the chunks until the launch has
+    // a workgroup for most CUs (the extra slabs go through the reduction)
+    int chunk_rows = 512;
+    {
+        const char *dbg = getenv("MPQE_DBG_CHUNK_ROWS");        // (timing experiments)
+        auto blocks_at = [&](int rows) {
+            long long nblk = 0;
+            for (size_t k = 0; k < keys.size(); ++k) {
+                int nch1, ch1;
+                pick_chunks(sd.b[keys[k].batch].B, 32, &nch1, &ch1, rows);
+                nblk += (long long)nch1 * tiles;
+            }
+            return nblk;
+        };
+        if (dbg && atoi(dbg) >= GT_BK) chunk_rows = atoi(dbg) / GT_BK * GT_BK;
+        (void)blocks_at;
+        // (measured on the AIFB mix, 136 whole-batch tiles of 13.8 us: 272 half-batch tiles take 8.2 us each but 16 CUs
+        // get two of them and the launch needs the reduction for every matrix: 22.6 us against 18.3. Kept at 512.)
+    }
     std::vector<char> split4(keys.size(), 0);
     {
         long long blocks1 = 0;
         for (size_t k = 0; k < keys.size(); ++k) {
             int nch1, ch1;
-            pick_chunks(sd.b[keys[k].batch].B, 32, &nch1, &ch1);
+            pick_chunks(sd.b[keys[k].batch].B, 32, &nch1, &ch1, chunk_rows);
             blocks1 += (long long)nch1 * tiles;
         }
         long long excess = blocks1 - STEP_CUS;
@@ -1307,12 +1330,13 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
             for (size_t k = keys.size(); k-- > 0 && excess > 0;) {
                 const int Bk = sd.b[keys[k].batch].B;
                 int nch1, ch1;
-                pick_chunks(Bk, 32, &nch1, &ch1);
+                pick_chunks(Bk, 32, &nch1, &ch1, chunk_rows);
                 if (keys[k].rel >= 0 || nch1 != 1 || Bk < 4 * 4 * GT_BK || Bk % (4 * GT_BK) != 0) continue;
                 split4[k] = 1;
                 excess -= tiles;
             }
     }
+    std::vector<RGroup> r1_only;
     int slab = 0, block = 0;
     hp->wsrc.clear();
     hp->wblock.clear();
@@ -1325,7 +1349,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         s.level = key.level;
         s.slot = key.slot;
         s.relu = 0;      // gH is stored as a pre-activation gradient (masked by its producer)
-        pick_chunks(d.B, 32, &s.nch, &s.ch);
+        pick_chunks(d.B, 32, &s.nch, &s.ch, chunk_rows);
         if (split4[k]) {
             s.nch = 4;
             s.ch = d.B / 4;
@@ -1349,6 +1373,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     {
         hp->rank1.clear();
         for (size_t k = 0; k < r1keys.size(); ++k) hp->rank1.push_back(r1keys[k].t);
+        r1_only.clear();
         std::vector<char> written((size_t)P->num_layers * (size_t)P->num_relations, 0);
         size_t ks = 0, kr = 0;
         while (ks < keys.size() || kr < r1keys.size()) {
@@ -1383,6 +1408,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
             }
             if (rel >= 0) written[(size_t)layer * P->num_relations + rel] = 1;
             if (nsrc == 1 && g.count == 1 && g.r1_count == 0) hp->wsrc[first_src].direct = layer;
+            else if (nsrc == 0 && g.r1_count <= UOP_MAX_TERMS) r1_only.push_back(g);    // written by the post-pass (UOP_R1)
             else hp->groups.push_back(g);
         }
         // every other relation matrix of every (unique) layer is untouched
@@ -1608,10 +1634,15 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                             const int t = op.nterms++;
                             op.layer[t] = li;
                             op.mat[t] = mat;
-                            op.in_kind[t] = 0;
-                            op.in_vec[t] = vec(V_SV, i, p + 1, dnode);
-                            op.in_gran[t] = gran(op.in_vec[t]);
-                            need_sv(op.in_vec[t]);
+                            if (((uni[i][p + 1] >> dnode) & 1u) && p + 1 < d.L) {
+                                op.in_kind[t] = 0;          // another op of this launch produces it: through its granules
+                                op.in_vec[t] = vec(V_SV, i, p + 1, dnode);
+                                op.in_gran[t] = gran(op.in_vec[t]);
+                            } else {                        // a sum of the chain kernel's per-block rows: formed on the fly
+                                op.in_kind[t] = 3;
+                                op.in_vec[t] = part_row[i][p + 1][dnode];
+                                op.in_gran[t] = (d.B + CH_GB - 1) / CH_GB;
+                            }
                         };
                         for (int e = 0; e < tp.E; ++e)
                             if (tp.src[e] == m && ((d.live[p + 1] >> tp.dst[e]) & 1u)) add_in(tp.dst[e], (int)tp.rel[e]);
@@ -1636,6 +1667,32 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                 hp->uops_b.push_back(op);
             }
             hp->uops_b.insert(hp->uops_b.end(), bwd.begin(), bwd.end());
+            // gradient matrices made of rank-1 terms only: u (x) v as soon as v (a column sum) exists
+            for (size_t k = 0; k < r1_only.size(); ++k) {
+                const RGroup &g = r1_only[k];
+                UOp op;
+                memset(&op, 0, sizeof(op));
+                op.kind = UOP_R1;
+                op.out_vec = op.out_gran = op.out_part = op.mask_vec = -1;
+                op.r1_layer = g.layer;
+                op.r1_rel = g.kind == 1 ? -1 : (int)g.row;
+                for (int t = 0; t < g.r1_count; ++t) {
+                    const Rank1 rk = hp->rank1[g.r1_start + t];
+                    const VecInfo &vi = vinfo[rk.v];
+                    op.u_vec[t] = rk.u;
+                    if (((uni[vi.batch][vi.level] >> vi.node) & 1u) && vi.level < sd.b[vi.batch].L) {
+                        op.in_kind[t] = 0;
+                        op.in_vec[t] = rk.v;
+                        op.in_gran[t] = gran(rk.v);
+                    } else {
+                        op.in_kind[t] = 3;
+                        op.in_vec[t] = part_row[vi.batch][vi.level][vi.node];
+                        op.in_gran[t] = (sd.b[vi.batch].B + CH_GB - 1) / CH_GB;
+                    }
+                    op.nterms++;
+                }
+                hp->uops_b.push_back(op);
+            }
             for (size_t k = 0; k < hp->uops_f.size(); ++k) hp->uops_f[k].out_gran = gran_of[hp->uops_f[k].out_vec];
             for (size_t k = 0; k < hp->uops_b.size(); ++k) hp->uops_b[k].out_gran = gran_of[hp->uops_b[k].out_vec];
         }
@@ -2263,9 +2320,10 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         tl.wblocks = count;
         if (first == 0 && (P->flags & MPQE_STEP_ZERO_GRADS)) tl.zblocks = (int)hp.zmats.size() * ta.zper;
         if (first == 0) tl.ublocks = ub.nops * ub.chunks;
-        tl.stamps = g_tail_stamps && (size_t)(tl.ublocks + count + tl.zblocks) <= g_tail_stamp_blocks ? g_tail_stamps : nullptr;
-        if (tl.ublocks + count + tl.zblocks <= 0) return;
-        dim3 tgrid((unsigned)(tl.ublocks + count + tl.zblocks));
+        const int nblocks = tl.ublocks + count + tl.zblocks;
+        tl.stamps = g_tail_stamps && (size_t)nblocks <= g_tail_stamp_blocks ? g_tail_stamps : nullptr;
+        if (nblocks <= 0) return;
+        dim3 tgrid((unsigned)nblocks);
         const int zeroed = (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0;
         if (fast && hp.whole_ksteps)
             hipLaunchKernelGGL(step_tail_kernel<LD_FAST>, tgrid, dim3(256), 0, on, sd, tl, (const float *)H,
@@ -2333,11 +2391,11 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss, lm, bterms);
             return mpqe_launch_status();
         }
-        for (int l = 0; l < NL; ++l) {      // each lane's weight gradients follow its own chains
-            mark(ls[l]);
-            launch_grad_w(ls[l], hp.wblock_begin[l], hp.wblock_begin[l + 1] - hp.wblock_begin[l]);
-            mark(ls[l]);
-        }
+        // (a side stream for the post-pass / table rows beside the tiles was measured: the cross-stream fork and join
+        // cost more than the overlap gains -- 93.8 us per step against 81.8 with everything on one stream)
+        mark(s);
+        launch_grad_w(s, 0, hp.wblocks_total);
+        mark(s);
     }
     // ---- forward
     for (int l = 0; !use_chain && l < NL; ++l) {
@@ -2428,14 +2486,10 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     {
         const long long elems = (long long)D * D;
         const unsigned gx = (unsigned)((elems + 255) / 256);
-        // entity-table gradients from the per-entry rows: further grid rows, 256 / (D / 4) sorted positions per workgroup
-        TouchLayout tl;
-        memset(&tl, 0, sizeof(tl));
-        unsigned trows = 0;
-        if (use_touch) {
-            tl = touch_layout(hp.touch_M, 0);
+        unsigned trows = 0;         // entity-table gradient rows: 256 / (D / 4) sorted positions per workgroup
+        if (use_touch && !(STEP_DBG & 1)) {
             const long long per = 256 / (D / 4), tblk = (hp.touch_M + per - 1) / per;
-            trows = (STEP_DBG & 1) ? 0u : (unsigned)((tblk + gx - 1) / gx);
+            trows = (unsigned)((tblk + gx - 1) / gx);
         }
         dim3 grid(gx, (unsigned)hp.groups.size() + 1 + trows);
         hipLaunchKernelGGL(step_reduce_kernel, grid, dim3(256), 0, s,
@@ -2443,7 +2497,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                            (const float *)slabs, (const float *)parts, (int)(D % 4 == 0), sd, (const float *)terms,
                            loss, (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0, lm, bterms,
                            reinterpret_cast<const Rank1 *>(db + hp.o_rank1), (const float *)VT, epoch_b,
-                           reinterpret_cast<const char *>(touch), tl.keys, tl.perm,
+                           reinterpret_cast<const char *>(touch), touch_layout(hp.touch_M, 0).keys,
                            (const float *)(wb + hp.o_DG), tabs);
     }
     return mpqe_launch_status();

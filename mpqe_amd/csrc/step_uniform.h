@@ -43,6 +43,21 @@ struct UArgs {
     int32_t *err;
 };
 
+// p[0] + p[D] + ... (nr terms, in that order)
+#define UOP_RED_AHEAD 32
+__device__ __forceinline__ float uop_row_sum(const float *pr, int nr, int D) {
+    float acc = 0.f;
+    for (int r0 = 0; r0 < nr; r0 += UOP_RED_AHEAD) {
+        float v[UOP_RED_AHEAD];
+#pragma unroll
+        for (int r = 0; r < UOP_RED_AHEAD; ++r) v[r] = gload1(pr + (long long)(r0 + r < nr ? r0 + r : r0) * D);
+#pragma unroll
+        for (int r = 0; r < UOP_RED_AHEAD; ++r)
+            if (r0 + r < nr) acc += v[r];
+    }
+    return acc;
+}
+
 // The op's input vectors, all terms, into LDS (xs[t * D + e]) by the whole workgroup: every element is fetched by ONE
 // thread -- a granule is polled by one lane of the workgroup, not by every lane that multiplies by it -- and a thread's
 // NP elements are requested together and re-requested together until all of their tags match (one round trip per
@@ -69,6 +84,11 @@ __device__ __forceinline__ void uop_fetch_inputs(const UOp &op, const UArgs &ua,
         } else if (kind == 1) {
             const long long m = op.in_vec[t];            // (a bad mode id is flagged by the chain kernel: zero row)
             if (m >= 0 && m < ua.num_modes) x[q] = gload1(ua.mode_emb + m * D + e);
+        } else if (kind == 3) {
+            // the column sum itself: rows in_vec .. in_vec + in_gran of `parts` (the chain kernel's per-block sums,
+            // an earlier launch), added in row order, UOP_RED_AHEAD requests at a time (B = 512: all 32 rows in one
+            // round trip) -- the same order and the same sum as the UOP_RED op of this vector, without waiting for it
+            x[q] = uop_row_sum(ua.parts + (long long)op.in_vec[t] * D + e, op.in_gran[t], D);
         } else {
             x[q] = gload1(ua.VT + (long long)op.in_vec[t] * D + e);
         }
@@ -119,9 +139,36 @@ __device__ __forceinline__ void uop_publish(const UOp &op, int e, int D, float v
 }
 
 template <int D>
-__device__ __forceinline__ void uop_run(const UOp &op, int chunk, const LayerPtrs &lp, const UArgs &ua, float *smem) {
+__device__ __forceinline__ void uop_run(const UOp &op, int chunk, const LayerPtrs &lp, const UArgs &ua, float *smem,
+                                        const GradPtrs *gp, int zeroed) {
     const int tid = threadIdx.x;
     const unsigned tag = *ua.epoch + 1u;
+    if (op.kind == UOP_R1) {
+        // rows [64 chunk, 64 chunk + 64) of the matrix: out[i][j] = sum_t u_t[i] v_t[j], t in table order (what the
+        // reduction launch computes for a group without slabs). Thread (r, c4): rows r + 8 q, columns 4 c4 + 128 cc.
+        if (!gp) return;
+        float *out = op.r1_rel >= 0 ? pick_grad(gp->basis, op.r1_layer) : pick_grad(gp->root, op.r1_layer);
+        if (out && op.r1_rel >= 0) out += (long long)op.r1_rel * D * D;
+        float *xs = smem + 1024;
+        float *us = smem;                                   // u_t[64 chunk + i]: [t][64]
+        for (int q = tid; q < op.nterms * 64; q += 256)
+            us[q] = gload1(ua.VT + (long long)op.u_vec[q / 64] * D + chunk * 64 + (q & 63));
+        uop_fetch_inputs<D>(op, ua, tag, xs);               // (ends with a workgroup barrier)
+        if (!out) return;
+        constexpr int C4 = D / 4;                           // float4 columns per row
+        for (int f = tid; f < 64 * C4; f += 256) {
+            const int i = f / C4, c4 = f - i * C4;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < op.nterms; ++t) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(xs + t * D + 4 * c4);
+                acc += us[t * 64 + i] * v;
+            }
+            f32x4 *dst = reinterpret_cast<f32x4 *>(out + (long long)(chunk * 64 + i) * D + 4 * c4);
+            if (zeroed) *dst = acc;
+            else *dst = *dst + acc;
+        }
+        return;
+    }
     if (op.kind == UOP_COPY) {
         if (tid < 64) {
             const int e = chunk * 64 + tid;
@@ -131,13 +178,11 @@ __device__ __forceinline__ void uop_run(const UOp &op, int chunk, const LayerPtr
         return;
     }
     if (op.kind == UOP_RED) {
-        // 64 columns x 4 row groups; row group g adds rows g, g + 4, ... in order, then (0 + 1) + (2 + 3): fixed order
-        const int cl = tid & 63, rg = tid >> 6, e = chunk * 64 + cl;
-        float acc = 0.f;
-        for (int r = rg; r < op.nrows; r += 4) acc += gload1(ua.parts + (long long)(op.row0 + r) * D + e);
-        smem[rg * 64 + cl] = acc;
-        __syncthreads();
-        if (tid < 64) uop_publish(op, e, D, (smem[cl] + smem[64 + cl]) + (smem[128 + cl] + smem[192 + cl]), ua, tag);
+        // rows added in row order (the order the in_kind 3 inputs of the UOP_BWD ops use: one value, bit for bit)
+        if (tid < 64) {
+            const int e = chunk * 64 + tid;
+            uop_publish(op, e, D, uop_row_sum(ua.parts + (long long)op.row0 * D + e, op.nrows, D), ua, tag);
+        }
         return;
     }
     if (op.kind == UOP_FWD) {
@@ -149,6 +194,11 @@ __device__ __forceinline__ void uop_run(const UOp &op, int chunk, const LayerPtr
         const int col = chunk * 64 + 4 * c4;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         float *xs = smem + 1024;
+        float bias_e = 0.f;                 // requested now, added after the hand-offs: off the dependence chain
+        if (tid < 64 && op.bias_layer >= 0) {
+            const float *bp = pick_layer(lp.bias, op.bias_layer);
+            if (bp) bias_e = gload1(bp + chunk * 64 + tid);
+        }
         for (int t0 = 0; t0 < op.nterms; t0 += 2) {
             f32x4 w[2][KI];
 #pragma unroll
@@ -174,10 +224,7 @@ __device__ __forceinline__ void uop_run(const UOp &op, int chunk, const LayerPtr
             const int e = chunk * 64 + tid;
             float v = 0.f;
             for (int g = 0; g < 16; ++g) v += smem[g * 64 + tid];
-            if (op.bias_layer >= 0) {
-                const float *bp = pick_layer(lp.bias, op.bias_layer);
-                if (bp) v += bp[e];
-            }
+            v += bias_e;
             if (op.relu) v = v > 0.f ? v : 0.f;
             uop_publish(op, e, D, v, ua, tag);
         }
@@ -189,6 +236,11 @@ __device__ __forceinline__ void uop_run(const UOp &op, int chunk, const LayerPtr
     const int l = tid & 15, r = tid >> 4;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     float *xs = smem + 1024;
+    float mval[4] = {1.f, 1.f, 1.f, 1.f};       // the forward state whose sign masks the row: requested before the hand-offs
+    if (l == 0 && op.mask_vec >= 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mval[q] = gload1(ua.VT + (long long)op.mask_vec * D + chunk * 64 + r + 16 * q);
+    }
     for (int t0 = 0; t0 < op.nterms; t0 += 2) {
         f32x4 w[2][4][CJ];
 #pragma unroll
@@ -220,18 +272,19 @@ __device__ __forceinline__ void uop_run(const UOp &op, int chunk, const LayerPtr
     for (int q = 0; q < 4; ++q) {
         const float y = chain_sum16(acc[q]);
         const int i = chunk * 64 + r + 16 * q;
-        if (l == 0) {
-            const bool on = op.mask_vec < 0 || gload1(ua.VT + (long long)op.mask_vec * D + i) > 0.f;
-            uop_publish(op, i, D, on ? y : 0.f, ua, tag);
-        }
+        if (l == 0) uop_publish(op, i, D, mval[q] > 0.f ? y : 0.f, ua, tag);
     }
 }
 
 // workgroup `ub` of a launch's vector ops (uniform branch: D is the step's dim, 64 / 128 / 256 in the chain form)
-__device__ __forceinline__ void uop_block(int ub, int D, const LayerPtrs &lp, const UArgs &ua, float *smem) {
+__device__ __forceinline__ void uop_block(int ub, int D, const LayerPtrs &lp, const UArgs &ua, float *smem,
+                                          const GradPtrs *gp, int zeroed) {
+#ifndef MPQE_EMU
+    __builtin_amdgcn_s_setprio(3);      // a latency chain next to throughput work (transposes / weight-gradient tiles)
+#endif
     const UOp &op = ua.ops[ub / ua.chunks];
     const int chunk = ub % ua.chunks;
-    if (D == 64) uop_run<64>(op, chunk, lp, ua, smem);
-    else if (D == 128) uop_run<128>(op, chunk, lp, ua, smem);
-    else uop_run<256>(op, chunk, lp, ua, smem);
+    if (D == 64) uop_run<64>(op, chunk, lp, ua, smem, gp, zeroed);
+    else if (D == 128) uop_run<128>(op, chunk, lp, ua, smem, gp, zeroed);
+    else uop_run<256>(op, chunk, lp, ua, smem, gp, zeroed);
 }

@@ -179,16 +179,10 @@ class FusedTrainStep(object):
         graphs = sum(len(b['targets']) for b in batches)
         chain = (not (self.flags & _capi.STEP_NO_CHAIN) and m.emb_dim in (64, 128, 256)
                  and graphs <= CHAIN_MAX_GRAPHS and max(passes_of) <= 5)
-        if chain and nl >= 2:
-            # chain form: lane 0 = the batches with the longest chains per block (their blocks set the kernel's
-            # length), lane 1 = the rest -- the light lane finishes early and its weight-gradient launch runs
-            # beside the heavy lane's chains
-            prune = not (self.flags & _capi.STEP_NO_PRUNE)
-            work = [sum(live_units(b['formula'].query_type, p, m.readout_str, prune, self.uniform))
-                    for b, p in zip(batches, passes_of)]
-            heavy = [i for i in range(nb) if work[i] >= 0.7 * max(work)]
-            light = [i for i in range(nb) if i not in heavy]
-            members = [heavy, light] if light else [heavy]
+        if chain:
+            # chain form: one launch sequence per step on the caller's stream whatever the split (the library ignores it;
+            # batch order is kept)
+            members = [list(range(nb))]
         else:
             load = [0.0] * nl
             members = [[] for _ in range(nl)]

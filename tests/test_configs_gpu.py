@@ -179,8 +179,9 @@ def test_benchmarked_workload_against_oracle(flags):
     sp, sn, loss = sp.cpu().numpy(), sn.cpu().numpy(), loss.cpu().numpy()
     cfg = dict(readout='mp', scatter_op='add', num_layers=3, adaptive=True, weight_decay=0)
     torch.set_num_threads(min(16, max(1, len(__import__('os').sched_getaffinity(0)))))
-    total, off = 0, 0
+    total = 0
     for i, b in enumerate(batches):
+        off = 512 * packed.order.index(i)           # scores come back in library batch order
         queries = [type('Q', (), {'anchor_nodes': tuple(int(v) for v in row)})() for row in b['anchor_ids']]
         col = ref_cpu.collate(b['formula'], queries, model.rel_ids, model.mode_ids)
         q = ref_cpu.encode_queries(cpu_params, cfg, node_maps, b['formula'], col)
@@ -191,7 +192,6 @@ def test_benchmarked_workload_against_oracle(flags):
         l = torch.clamp(1.0 - (pos - neg), min=0).mean()
         np.testing.assert_allclose(loss[1 + packed.order.index(i)], l.item(), rtol=1e-5, atol=1e-6)
         total = total + b['weight'] * l
-        off += 512
     np.testing.assert_allclose(loss[0], total.item(), rtol=1e-5, atol=1e-6)
     total.backward()
     for k, p in model.named_parameters():
