@@ -50,8 +50,8 @@ struct BatchDev {
     // computed nor read: its gradient is exactly zero (MPQE_STEP_NO_PRUNE: all slots at every level).
     unsigned live[MPQE_STEP_MAX_LAYERS + 1];
     int pad2;
-    // chain form. uvL[n] >= 0: node slot n is still batch-uniform at level L; its state is that vector of the vector
-    // table (the readout reads it in every row). lpart[n] >= 0: first row in `parts` of the per-block column sums of
+    // chain form. uvL[n] >= 0: node slot n is still batch-uniform at level L; its state is the pre-pass vector with that
+    // granule slot (the readout reads it in every row). lpart[n] >= 0: first row in `parts` of the per-block column sums of
     // gH[L][n] (row = lpart[n] + block index inside the batch).
     int uvL[4], lpart[4];
 };
@@ -241,16 +241,9 @@ __device__ __forceinline__ float *pick_grad(float *const *arr, int li) {
 #include "step_uniform.h"
 #include "step_touch.h"
 
-template <int NCB, int KS, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void step_chain_kernel(const StepDev *__restrict__ sd, LayerPtrs lp,
-                                                             TablePtrs tabs, ChainArgs ca) {
-    __shared__ __attribute__((aligned(16))) ChainLds<NCB, KS, NW> S;
-    chain_block<NCB, KS, NW>(sd, lp, tabs, ca, S);
-}
-
-// Step prologue, one launch: (a) transposed copies of the matrices the backward chains multiply by (32x32
-// tiles through LDS; ~35 matrices of 64 KB in the AIFB step), (b) with MPQE_STEP_ZERO_GRADS, zero fill of
-// every gradient buffer (what the caller's memset would do).
+// Prologue roles of the chain launch (they were a launch of their own, 9 us in front of the chain kernel): the forward
+// pre-pass of the batch-uniform node states (vector ops, step_uniform.h), transposed copies of the matrices the backward
+// chains multiply by (64 x 64 pieces through LDS), zero fill of the gradient buffers (MPQE_STEP_ZERO_GRADS).
 struct WtSlot {
     int layer, mat;       // mat < 0: root
 };
@@ -262,43 +255,78 @@ struct ZeroSegs {
     int count;
 };
 #define PREP_ZERO_FLOATS_PER_BLOCK 8192      // 256 threads x 8 x float4
-__global__ __launch_bounds__(256) void step_prep_kernel(LayerPtrs lp, const WtSlot *__restrict__ slots, int nslots, int D,
-                                                        float *__restrict__ WT, int tblocks, ZeroSegs zs, UArgs ua,
-                                                        int ublocks) {
-    __shared__ __attribute__((aligned(16))) float tile[64][33];      // (transposes: the first 32 rows; vector ops: 2048 floats)
-    // the forward pre-pass of the batch-uniform node states takes the first workgroups of the launch (a dependence
-    // chain of up to L levels: started first, and its producers are dispatched before their consumers)
-    if ((int)blockIdx.x < ublocks) {
-        uop_block((int)blockIdx.x, D, lp, ua, &tile[0][0], nullptr, 0);
-        return;
-    }
-    const int bid = (int)blockIdx.x - ublocks;
-    if (bid < tblocks) {
-        const int tpd = (D + 31) / 32, per = tpd * tpd;
-        const int si = bid / per, tr = (bid % per) / tpd, tc = bid % tpd;
-        const WtSlot sl = slots[si];
-        const float *W = sl.mat >= 0 ? pick_layer(lp.basis, sl.layer) + (long long)sl.mat * D * D
-                                     : pick_layer(lp.root, sl.layer);
-        float *T = WT + (long long)si * D * D;
-        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
-        for (int r = ty; r < 32; r += 8) {
-            const int row = tr * 32 + r, col = tc * 32 + tx;
-            tile[r][tx] = row < D && col < D ? W[(long long)row * D + col] : 0.f;
+struct PrepArgs {
+    UArgs ua;
+    int ublocks, tblocks;     // vector-op workgroups, transpose workgroups
+    int lead;                 // prologue workgroups in front of the chain workgroups: ublocks + tblocks rounded up to a
+                              // multiple of 8 (chain workgroup b keeps XCD b % 8)
+    int nchain;               // chain workgroups (holes of the placement grid included)
+    const WtSlot *slots;
+    float *WT;
+    unsigned *wt_count;
+    ZeroSegs zs;
+};
+
+// one 64 x 64 piece of a matrix, transposed: T[c][r] = W[r][c] (D % 64 == 0 in the chain form)
+__device__ __forceinline__ void prep_transpose_block(const LayerPtrs &lp, const PrepArgs &pa, int D, int tb, float *smem) {
+    float(*tile)[65] = reinterpret_cast<float(*)[65]>(smem);
+    const int tpd = D / 64, per = tpd * tpd;
+    const int si = tb / per, tr = (tb % per) / tpd, tc = tb % tpd;
+    const WtSlot sl = pa.slots[si];
+    const float *W = sl.mat >= 0 ? pick_layer(lp.basis, sl.layer) + (long long)sl.mat * D * D : pick_layer(lp.root, sl.layer);
+    float *T = pa.WT + (long long)si * D * D;
+    const int tid = threadIdx.x;
+    if (tid < 256) {
+        const int c4 = tid & 15, r0 = tid >> 4;               // 16 float4 columns x 16 rows per pass
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + 16 * q;
+            const f32x4 v = gload4(W + (long long)(tr * 64 + r) * D + tc * 64 + 4 * c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[r][4 * c4 + e] = v[e];
         }
-        __syncthreads();
-        for (int r = ty; r < 32; r += 8) {
-            const int row = tc * 32 + r, col = tr * 32 + tx;               // T[col of W][row of W]
-            if (row < D && col < D) T[(long long)row * D + col] = tile[tx][r];
-        }
-        return;
     }
-    const long long zb = bid - tblocks;
+    __syncthreads();
+    if (tid < 256) {
+        const int c4 = tid & 15, r0 = tid >> 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + 16 * q;                        // row of T = column of W
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = tile[4 * c4 + e][r];
+            *reinterpret_cast<f32x4 *>(T + (long long)(tc * 64 + r) * D + tr * 64 + 4 * c4) = v;
+        }
+    }
+    // publish: every storing wave drains its stores, the workgroup meets, ONE lane releases at agent scope and
+    // counts the workgroup in (the consumers: chain_block, before the backward levels)
+#ifndef MPQE_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    __syncthreads();
+    if (tid == 0) {
+#ifndef MPQE_EMU
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        atomicAdd(pa.wt_count, 1u);
+    }
+}
+
+__device__ __forceinline__ void prep_zero_block(const ZeroSegs &zs, long long zb) {
+    if (threadIdx.x >= 256) return;
     int sg = 0;
     for (int i = 1; i < zs.count; ++i)
         if (zs.block0[i] <= zb) sg = i;
     const long long base = (zb - zs.block0[sg]) * PREP_ZERO_FLOATS_PER_BLOCK;
-    float *p = zs.p[sg];
-    const long long n = zs.n[sg];
+    float *p = zs.p[0];
+    long long n = zs.n[0];
+#pragma unroll
+    for (int i = 1; i < PREP_MAX_SEGS; ++i)       // (a runtime index into the by-value table would spill it)
+        if (i == sg) {
+            p = zs.p[i];
+            n = zs.n[i];
+        }
     if (((uintptr_t)p & 15) == 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -311,6 +339,35 @@ __global__ __launch_bounds__(256) void step_prep_kernel(LayerPtrs lp, const WtSl
         for (long long i = base + threadIdx.x; i < base + PREP_ZERO_FLOATS_PER_BLOCK && i < n; i += 256) p[i] = 0.f;
     }
 }
+
+template <int NCB, int KS, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void step_chain_kernel(const StepDev *__restrict__ sd, LayerPtrs lp,
+                                                             TablePtrs tabs, ChainArgs ca, PrepArgs pa) {
+    __shared__ __attribute__((aligned(16))) ChainLds<NCB, KS, NW> S;
+    // role of this workgroup (uniform): chain workgroup, prologue work in front of / behind them, zero fill last
+    // [prologue][chain][zero fill]: a producer is never queued behind a consumer that waits for it
+    int bid = (int)blockIdx.x, role;
+    if (bid < pa.lead) role = 1;
+    else if (bid < pa.lead + pa.nchain) role = 0, bid -= pa.lead;
+    else role = 2, bid -= pa.lead + pa.nchain;
+    if (role == 0) {
+        ca.cb = bid;
+        ca.nchain = pa.nchain;
+        chain_block<NCB, KS, NW>(sd, lp, tabs, ca, S);
+    } else if (role == 1) {
+        constexpr int D = 16 * NCB * NW / KS;
+        if (bid < pa.ublocks) {
+            if (NW == 4 || threadIdx.x < 256) uop_block(bid, D, lp, pa.ua, S.xs, nullptr, 0);
+        } else if (bid < pa.ublocks + pa.tblocks) {
+            prep_transpose_block(lp, pa, D, bid - pa.ublocks, S.xs);
+        }       // (else: padding)
+    } else {
+        prep_zero_block(pa.zs, bid);
+    }
+}
+
+// level form: zero fill of the gradient buffers (MPQE_STEP_ZERO_GRADS) as a launch of its own
+__global__ __launch_bounds__(256) void step_zero_kernel(ZeroSegs zs) { prep_zero_block(zs, (long long)blockIdx.x); }
 
 // rows [0, rows_total) are node rows of H0, then G positive and G negative targets. D/4 adjacent lanes
 // own a row (two rows per wave at D = 128): the kernel is a chain of dependent gathers (id -> LUT ->
@@ -621,8 +678,10 @@ __device__ __forceinline__ void loss_block_chain(const LossMeta &lm, const float
 __global__ __launch_bounds__(1024) void step_loss_kernel(const StepDev *__restrict__ sd,
                                                          const float *__restrict__ terms,
                                                          float *__restrict__ loss, LossMeta lm,
-                                                         const float *__restrict__ bterms) {
+                                                         const float *__restrict__ bterms, unsigned *epoch_f) {
     __shared__ float mean[MPQE_STEP_MAX_BATCHES];
+    // (forward-only step: this is its last launch -- the next step's forward granules get a new tag, step_uniform.h)
+    if (epoch_f && threadIdx.x == 0) *epoch_f = *epoch_f + 1u;
     if (lm.chain) loss_block_chain(lm, bterms, loss, mean, 16);
     else loss_block(sd, terms, loss, mean, 16);
 }
@@ -878,8 +937,12 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restri
     }
     if ((int)blockIdx.y == ngroups) {       // one extra workgroup row: the loss reduction rides along
         if (blockIdx.x == 0) {
-            // the backward post-pass of this step is over: the next step's granules get a new tag (step_uniform.h)
-            if (epoch_b && threadIdx.x == 0) *epoch_b = *epoch_b + 1u;
+            // the step is over: the next step's granules (forward pre-pass, backward post-pass) get new tags, and the
+            // count of finished transpose workgroups a new target (step_uniform.h, step_chain.h)
+            if (epoch_b && threadIdx.x == 0) {
+                *epoch_b = *epoch_b + 1u;
+                *(epoch_b - 16) = *(epoch_b - 16) + 1u;       // epoch_f
+            }
             if (lm.chain) loss_block_chain(lm, bterms, loss, reinterpret_cast<float *>(part), 4);
             else loss_block(sd, terms, loss, reinterpret_cast<float *>(part), 4);
         }
@@ -989,6 +1052,9 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restri
 // ------------------------------------------------------------------------------------ host side
 namespace {
 
+#define STEP_CUS 256
+#define STEP_XCDS 8
+#define STEP_RESIDENT 4
 struct HostPlan {
     StepDev sd;
     int Lmax;
@@ -1049,9 +1115,6 @@ void pick_chunks(long long count, int max_chunks, int *nch, int *ch, int rows = 
 // `in` is sorted by descending K length. The first STEP_CUS * STEP_RESIDENT tiles start at once, block
 // b on CU b % STEP_CUS: give each to the least-loaded CU that still has a free position; the rest
 // follow in descending order and are picked up by whichever CU drains first.
-#define STEP_CUS 256
-#define STEP_XCDS 8
-#define STEP_RESIDENT 4
 void place_tiles(const std::vector<TileRef> &in, const std::vector<int> &steps, std::vector<TileRef> &out) {
     const size_t n = in.size();
     const size_t first = n < (size_t)STEP_CUS * STEP_RESIDENT ? n : (size_t)STEP_CUS * STEP_RESIDENT;
@@ -1563,7 +1626,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                 BatchDev &d = sd.b[i];
                 const bool liveL = n < d.tp.N && ((d.live[d.L] >> n) & 1u);
                 d.lpart[n] = liveL ? part_row[i][d.L][n] : -1;
-                d.uvL[n] = liveL && ((uni[i][d.L] >> n) & 1u) ? vec(V_UV, i, d.L, n) : -1;
+                d.uvL[n] = liveL && ((uni[i][d.L] >> n) & 1u) ? gran(vec(V_UV, i, d.L, n)) : -1;     // (its granule slot)
             }
         if (uniform) {
             // ---- forward pre-pass, level by level (a level's inputs are the outputs of the level before)
@@ -1598,6 +1661,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                         if ((uni[i][p] >> n) & 1u) add_in(n, -1);
                         if (nu && op.nterms == 0) continue;      // its constant is the layer's bias itself (ChainOp.aux = -1)
                         op.out_vec = vec(nu ? V_CV : V_UV, i, p + 1, n);
+                        if (nu) (void)gran(op.out_vec);      // read by the chain workgroups of the same launch
                         op.bias_layer = li;
                         op.relu = (!nu && p < d.L - 1) ? 1 : 0;
                         hp->uops_f.push_back(op);
@@ -1770,7 +1834,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                         if (!dir) {         // the node's constant: bias + its uniform sources' products (-1: the bias itself)
                             const auto it = vec_of.find((((long long)V_CV * MPQE_STEP_MAX_BATCHES + i) *
                                                          (MPQE_STEP_MAX_LAYERS + 1) + (p + 1)) * 4 + n);
-                            hp->cops.back().aux = it == vec_of.end() ? -1 : it->second;
+                            hp->cops.back().aux = it == vec_of.end() ? -1 : gran_of[it->second];      // (its granule slot)
                             hp->cops.back().wt_slot = cv_slots++;
                         } else {
                             hp->cops.back().aux = part_row[i][p][n];       // (anchors at level 0: -1)
@@ -2232,12 +2296,14 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         gr0[l] = b < nb ? hp.sd.b[b].g_off : hp.sd.graphs_total;
     }
     float *WT = reinterpret_cast<float *>(wb + hp.o_WT);
+    // prologue work: the forward pre-pass of the batch-uniform node states; backward: transposed weight copies for the
+    // backward chains, zero fill of the gradients. Chain form: roles of the chain launch itself (PrepArgs); level form:
+    // a zero-fill launch.
+    PrepArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    long long zblocks = 0;
     {
-        // prologue launch: the forward pre-pass of the batch-uniform node states; backward: transposed weight copies
-        // for the backward chains, zero fill of the gradients
-        ZeroSegs zs;
-        memset(&zs, 0, sizeof(zs));
-        long long zblocks = 0;
+        ZeroSegs &zs = pa.zs;
         if (backward && (P->flags & MPQE_STEP_ZERO_GRADS)) {
             auto seg = [&](float *ptr, long long n) {
                 if (!ptr || n <= 0) return;
@@ -2260,17 +2326,28 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             for (int m = 0; m < P->num_modes; ++m) seg(G->tables[m], (long long)P->table_rows[m] * D);
             zs.block0[zs.count] = zblocks;
         }
-        const int tpd = (D + 31) / 32;
-        const int tblocks = use_chain && backward ? (int)hp.wt_slots.size() * tpd * tpd : 0;
-        UArgs uf = ua;
-        uf.ops = reinterpret_cast<const UOp *>(db + hp.o_uopf);
-        uf.nops = (int)hp.uops_f.size();
-        uf.epoch = epoch_f;
-        const int ublocks = uf.nops * uf.chunks;
-        if (ublocks + tblocks + zblocks > 0)
-            hipLaunchKernelGGL(step_prep_kernel, dim3((unsigned)(ublocks + tblocks + zblocks)), dim3(256), 0, s, lp,
-                               reinterpret_cast<const WtSlot *>(db + hp.o_wtslots), (int)hp.wt_slots.size(), D, WT,
-                               tblocks, zs, uf, ublocks);
+        if (use_chain) {
+            const int tpd = D / 64;
+            pa.ua = ua;
+            pa.ua.ops = reinterpret_cast<const UOp *>(db + hp.o_uopf);
+            pa.ua.nops = (int)hp.uops_f.size();
+            pa.ua.epoch = epoch_f;
+            pa.ublocks = pa.ua.nops * pa.ua.chunks;
+            pa.tblocks = backward ? (int)hp.wt_slots.size() * tpd * tpd : 0;
+            // The chain workgroups wait for vectors / matrices that the prologue workgroups produce, so the prologue
+            // workgroups come first in the launch: a producer is never queued behind a consumer. (Every wait is bounded
+            // all the same: a launch that could not make progress reports MPQE_FLAG_INTERNAL instead of hanging.)
+            // (Dealing the prologue workgroups only to the XCDs the chain workgroups leave room on was measured and is
+            // worse: those are the XCDs of the heaviest batches, whose workgroups then lose their CU to themselves --
+            // chain kernel 53.5 us against 41.4 with the prologue spread over all eight.)
+            pa.lead = (pa.ublocks + pa.tblocks + 7) / 8 * 8;
+            pa.nchain = (int)hp.crefs.size();
+            pa.slots = reinterpret_cast<const WtSlot *>(db + hp.o_wtslots);
+            pa.WT = WT;
+            pa.wt_count = epoch_f + 32;
+        } else if (zblocks > 0) {
+            hipLaunchKernelGGL(step_zero_kernel, dim3((unsigned)zblocks), dim3(256), 0, s, zs);
+        }
     }
     LossMeta lm;
     memset(&lm, 0, sizeof(lm));
@@ -2367,28 +2444,33 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         ca.terms = terms;
         ca.err = err;
         ca.backward = backward ? 1 : 0;
-        ca.stamps = NL == 1 && g_chain_stamps && 2 * hp.crefs.size() <= g_chain_stamp_blocks ? g_chain_stamps : nullptr;
-        for (int l = 0; l < NL; ++l) {
-            ChainArgs cl = ca;
-            cl.refs = ca.refs + hp.cref_begin[l];
-            dim3 cgrid((unsigned)(hp.cref_begin[l + 1] - hp.cref_begin[l]));
-            mark(ls[l]);
-            if (D == 64) hipLaunchKernelGGL((step_chain_kernel<1, 1>), cgrid, dim3(256), 0, ls[l], sd, lp, tabs, cl);
+        ca.stamps = g_chain_stamps && 2 * hp.crefs.size() <= g_chain_stamp_blocks ? g_chain_stamps : nullptr;
+        {
+            ca.cb = 0;
+            ca.nchain = pa.nchain;
+            ca.cv_gran = pa.ublocks > 0 ? reinterpret_cast<const unsigned long long *>(db + hp.o_gran) : nullptr;
+            ca.epoch_b = epoch_b;
+            ca.wt_count = pa.tblocks > 0 ? pa.wt_count : nullptr;
+            ca.wt_blocks = pa.tblocks;
+            dim3 cgrid((unsigned)(pa.lead + pa.nchain + zblocks));
+            mark(s);
+            if (D == 64) hipLaunchKernelGGL((step_chain_kernel<1, 1>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa);
             else if (D == 128 && (P->flags & MPQE_STEP_NO_KSPLIT))
-                hipLaunchKernelGGL((step_chain_kernel<2, 1>), cgrid, dim3(256), 0, ls[l], sd, lp, tabs, cl);
+                hipLaunchKernelGGL((step_chain_kernel<2, 1>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa);
             else if (D == 128 && (P->flags & MPQE_STEP_EIGHT_WAVES))
-                hipLaunchKernelGGL((step_chain_kernel<2, 2, 8>), cgrid, dim3(512), 0, ls[l], sd, lp, tabs, cl);
+                hipLaunchKernelGGL((step_chain_kernel<2, 2, 8>), cgrid, dim3(512), 0, s, sd, lp, tabs, ca, pa);
             else if (D == 128)
-                hipLaunchKernelGGL((step_chain_kernel<4, 2>), cgrid, dim3(256), 0, ls[l], sd, lp, tabs, cl);
-            else hipLaunchKernelGGL((step_chain_kernel<4, 1>), cgrid, dim3(256), 0, ls[l], sd, lp, tabs, cl);
-            mark(ls[l]);
+                hipLaunchKernelGGL((step_chain_kernel<4, 2>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa);
+            else hipLaunchKernelGGL((step_chain_kernel<4, 1>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa);
+            mark(s);
         }
         if (!backward) {
             for (int l = 1; l < NL; ++l) {
                 (void)hipEventRecord(reinterpret_cast<hipEvent_t>(lanes->join_event[l]), ls[l]);
                 (void)hipStreamWaitEvent(s, reinterpret_cast<hipEvent_t>(lanes->join_event[l]), 0);
             }
-            hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss, lm, bterms);
+            hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss, lm, bterms,
+                               use_chain ? epoch_f : (unsigned *)nullptr);
             return mpqe_launch_status();
         }
         // (a side stream for the post-pass / table rows beside the tiles was measured: the cross-stream fork and join
@@ -2443,7 +2525,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     if (!backward) {      // (not reached with the chain kernel)
         for (int l = 0; l < NL; ++l) { LAUNCH_SCORE_D(false, (float *)nullptr, l); }
         join();
-        hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss, lm, bterms);
+        hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss, lm, bterms,
+                               use_chain ? epoch_f : (unsigned *)nullptr);
         return mpqe_launch_status();
     }
 

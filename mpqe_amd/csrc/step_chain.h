@@ -103,6 +103,43 @@ __device__ __forceinline__ void chain_lload(float (&d)[NCB], const float *p) {
 // 1 / sqrt(x) and 1 / x in one instruction (v_rsq_f32 / v_rcp_f32, 1 ulp) where the result only scales a row or a
 // gradient: the IEEE sequences hipcc emits for sqrtf and `/` are 10 - 15 VALU instructions each, none of them hidden
 // (the scores themselves keep the exact division).
+__device__ __forceinline__ unsigned long long chain_gran_load(const unsigned long long *g) {
+#ifdef MPQE_EMU
+    return *g;
+#else
+    typedef unsigned long long __attribute__((address_space(1))) * gp_t;
+    return __hip_atomic_load((gp_t)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ unsigned chain_count_load(const unsigned *p) {
+#ifdef MPQE_EMU
+    return *p;
+#else
+    typedef unsigned __attribute__((address_space(1))) * gu_t;
+    return __hip_atomic_load((gu_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+// four consecutive {tag, value} granules (step_uniform.h) once all their tags match; bounded
+__device__ __forceinline__ f32x4 chain_gran_read4(const unsigned long long *g, unsigned tag, int32_t *err) {
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+    for (int spins = 0;; ++spins) {
+        unsigned long long x[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = chain_gran_load(g + e);
+        bool ok = true;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ok = ok && (unsigned)(x[e] >> 32) == tag;
+            q[e] = __uint_as_float((unsigned)x[e]);
+        }
+        if (ok) break;
+        if (spins >= (1 << 18)) {           // (never, unless the launch is broken: report, do not hang)
+            flag_error(err, MPQE_FLAG_INTERNAL);
+            break;
+        }
+    }
+    return q;
+}
 __device__ __forceinline__ float chain_rsq(float x) {
 #ifdef MPQE_EMU
     return 1.f / sqrtf(x);
@@ -649,6 +686,13 @@ struct ChainArgs {
     int32_t *err;
     int backward;
     long long *stamps;      // diagnostics (mpqe_debug_chain_stamps): 8 words per workgroup, or NULL
+    // the launch also holds the step's prologue work (step.hip: step_chain_kernel): `cb` = this workgroup's number among
+    // the chain workgroups, `nchain` = how many there are
+    int cb, nchain;
+    const unsigned long long *cv_gran;   // granules of the pre-pass' vectors (this launch produces them): NULL = read VT
+    const unsigned *epoch_b;             // backward epoch of the packed step (bumped by the reduction launch)
+    const unsigned *wt_count;            // transposed-copy workgroups finished, ever (this launch adds wt_blocks)
+    int wt_blocks;
 };
 
 // phase time stamps of a workgroup: the 100 MHz wall clock is one time base for the whole device, so the
@@ -656,13 +700,13 @@ struct ChainArgs {
 __device__ __forceinline__ void chain_stamp(const ChainArgs &ca, int slot) {
 #ifndef MPQE_EMU
     if (ca.stamps && threadIdx.x == 0) {
-        ca.stamps[(long long)blockIdx.x * 8 + slot] = (long long)wall_clock64();
+        ca.stamps[(long long)ca.cb * 8 + slot] = (long long)wall_clock64();
         // shader-clock ticks at the first and the last stamp (beyond the 8 words of every block: second half
         // of the buffer): ticks / wall time = the clock the CU really ran at
         if (slot == 0 || slot == 6) {
             const long long t = (long long)__builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_waitcnt(0xC07F);
-            ca.stamps[((long long)gridDim.x + blockIdx.x) * 8 + (slot == 0 ? 0 : 1)] = t;
+            ca.stamps[((long long)ca.nchain + ca.cb) * 8 + (slot == 0 ? 0 : 1)] = t;
         }
     }
 #endif
@@ -672,7 +716,7 @@ __device__ __forceinline__ void chain_stamp_where(const ChainArgs &ca, int batch
     if (ca.stamps && threadIdx.x == 0) {
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_ID
         const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);         // XCC_ID[3:0]
-        ca.stamps[(long long)blockIdx.x * 8 + 7] = (long long)hw | ((long long)xcc << 32) | ((long long)batch << 40) |
+        ca.stamps[(long long)ca.cb * 8 + 7] = (long long)hw | ((long long)xcc << 32) | ((long long)batch << 40) |
                                                    ((long long)fwd_ops << 48);
     }
 #endif
@@ -690,9 +734,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     constexpr int LPR = D / 4;                            // lanes that share one row in the row-major phases
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool four = NW == 4 || tid < 256;
-    const ChainRef ref = ca.refs[blockIdx.x];
-    // the pre-pass of this step (an earlier launch) is over: the next step's forward granules get a new tag
-    if (blockIdx.x == 0 && tid == 0 && ca.epoch_f) *ca.epoch_f = *ca.epoch_f + 1u;
+    const ChainRef ref = ca.refs[ca.cb];
     if (ref.batch < 0) return;                            // a hole of the placement grid (uniform)
     const BatchDev &b = sd->b[ref.batch];
     const int N = b.tp.N, A = b.A, L = b.L, g0 = ref.g0;
@@ -705,7 +747,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     chain_stamp_where(ca, ref.batch, ref.fwd_count);
 #if CHAIN_DBG == 6
     if (threadIdx.x == 0) {      // trace block 0 only: words [2 G * 8 ...) of the stamp buffer
-        S.trace = (ca.stamps && blockIdx.x == 0) ? ca.stamps + (long long)gridDim.x * 16 : nullptr;
+        S.trace = (ca.stamps && ca.cb == 0) ? ca.stamps + (long long)ca.nchain * 16 : nullptr;
         S.trace_n = 0;
     }
 #endif
@@ -802,7 +844,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
         for (int f = tid; f < NCV * (D / 4); f += 256) {
             const int slot = f / (D / 4), c4 = f - slot * (D / 4);
             const int id = S.cvid[slot];
-            if (id == -2) continue;
+            if (id == -2 || (id >= 0 && ca.cv_gran)) continue;
             const float *src = id >= 0 ? ca.VT + (long long)id * D : pick_layer(lp.bias, S.cvl[slot]);
             *reinterpret_cast<f32x4 *>(S.cv + slot * D + 4 * c4) = src ? gload4(src + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -814,6 +856,18 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
             const int r = f / (D / 4), c4 = f - r * (D / 4);
             const float *src = S.rowp[r];
             v[k] = src ? gload4(src + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (ca.cv_gran) {
+            // constants the pre-pass workgroups of THIS launch produce: read as {tag, value} granules (step_uniform.h),
+            // four per thread and attempt, behind the row requests above (whose latency the wait shares)
+            const unsigned tag = *ca.epoch_f + 1u;
+            for (int f = tid; f < NCV * (D / 4); f += 256) {
+                const int slot = f / (D / 4), c4 = f - slot * (D / 4);
+                const int id = S.cvid[slot];            // (here: the vector's granule slot)
+                if (id < 0) continue;
+                *reinterpret_cast<f32x4 *>(S.cv + slot * D + 4 * c4) =
+                    chain_gran_read4(ca.cv_gran + (long long)id * D + 4 * c4, tag, ca.err);
+            }
         }
         float *H0 = ca.H + row0 * D;
 #pragma unroll
@@ -853,11 +907,37 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
         tp[cc] = pp_ ? gload1(pp_ + sl + 16 * cc) : 0.f;
         tn[cc] = pn_ ? gload1(pn_ + sl + 16 * cc) : 0.f;
     }
+    // (the count of finished transpose workgroups, for the wait in front of the backward levels: requested now)
+    unsigned wt_have0 = 0;
+    if (tid == 0 && ca.backward && ca.wt_count) wt_have0 = chain_count_load(ca.wt_count);
     // ---- forward levels
     int cur = 0;
     chain_run<NCB, KS, false, NW>(S, 0, ref.fwd_count * IPO, N, ng, ca.H + row0 * D, ca.level_stride, cur);
 
     chain_stamp(ca, 3);
+    if (ca.backward && ref.bwd_count > 0 && ca.wt_count) {
+        // The transposed copies the backward levels multiply by are written by workgroups of THIS launch, which
+        // publish them with an agent-scope release and count themselves in (step.hip: prep_transpose_block). One lane
+        // compares the count it requested before the forward levels (normally already complete) with the target and
+        // polls on only if it was not; then the workgroup's barrier. No acquire fence: it would invalidate this CU's L1,
+        // and no line of the copies can be in it (or in this XCD's L2) -- nothing reads them before this point in the
+        // launch, the warm-up requests below come after the barrier, and caches do not survive a launch boundary.
+        if (tid == 0) {
+            const unsigned want = (*ca.epoch_b + 1u) * (unsigned)ca.wt_blocks;
+            unsigned have = wt_have0;
+            for (int spins = 0; (int)(have - want) < 0; ++spins) {
+                if (spins >= (1 << 18)) {
+                    flag_error(ca.err, MPQE_FLAG_INTERNAL);
+                    break;
+                }
+#ifndef MPQE_EMU
+                __builtin_amdgcn_s_sleep(2);
+#endif
+                have = chain_count_load(ca.wt_count);
+            }
+        }
+        __syncthreads();
+    }
     if (ca.backward && ref.bwd_count > 0 && four) warm(ref.fwd_count, ref.bwd_count);
     // node states that are still batch-uniform at level L (no anchor within L hops: possible when a batch runs fewer
     // passes than its diameter) never went through the K loops: the readout sees the pre-pass' vector in every row
@@ -866,9 +946,12 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
         for (int n = 0; n < N; ++n) {
             const int id = b.uvL[n];
             if (id < 0) continue;
+            // (a vector of this launch's pre-pass workgroups: read through its granules, uvL = its granule slot)
+            const unsigned tag = *ca.epoch_f + 1u;
             for (int f = tid; f < CH_GB * (D / 4) && four; f += 256) {
                 const int i = f / (D / 4), c4 = f - i * (D / 4);
-                *reinterpret_cast<f32x4 *>(Xc + (n * CH_GB + i) * LDX + 4 * c4) = gload4(ca.VT + (long long)id * D + 4 * c4);
+                *reinterpret_cast<f32x4 *>(Xc + (n * CH_GB + i) * LDX + 4 * c4) =
+                    chain_gran_read4(ca.cv_gran + (long long)id * D + 4 * c4, tag, ca.err);
             }
         }
         __syncthreads();

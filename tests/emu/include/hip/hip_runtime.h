@@ -139,6 +139,7 @@ static inline void __builtin_amdgcn_global_load_lds(const void __attribute__((ad
 // have landed. The fibers of a wave meet here (all call sites are wave-uniform).
 static inline void __builtin_amdgcn_s_waitcnt(int) { (void)emu::wave_exchange(0.f, 0, 0, 64); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
 static inline void __builtin_amdgcn_s_barrier() { emu::block_barrier(); }
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
