@@ -5,14 +5,83 @@ int64, graph) -- but the graph's B-fold replicated tensors (edge_index, edge_typ
 expanded ON THE DEVICE from the <= 3-edge template by one kernel instead of B-way torch.cat
 on the host (reference: PyG Batch.from_data_list, data_utils.py:402-405).
 """
-from collections import OrderedDict
+import os
+import pickle
+from collections import OrderedDict, defaultdict
 
 import numpy as np
 import torch
 from torch.utils.data import DataLoader, Dataset
 
 from . import ops
-from .graph import reverse_relation
+from .graph import Graph, Query, reverse_relation
+
+
+# ------------------------------------------------------------------------------------- dataset files
+def load_graph(data_dir, embed_dim):
+    """reference: data_utils.py:18-37. `graph_data.pkl` = (relations {mode: [(to_mode, name)]}, adjacency
+    {(mode, name, to_mode): {entity: neighbours}}, node_maps {mode: [entity ids]}). Returns (graph,
+    feature_modules, node_maps) like the reference: per mode an nn.Embedding(count + 1, D) initialised N(0, 1/D) in
+    the relations' mode order (the same torch draws as the reference under the same seed), the int64 LUT global
+    entity id -> row of its mode's table (-1: of no mode), and the Graph container whose `features` closure is the
+    LUT lookup. Hand feature_modules + node_maps to DirectEncoder(graph.features, feature_modules, node_maps)."""
+    with open(os.path.join(data_dir, 'graph_data.pkl'), 'rb') as f:
+        rels, adj_lists, node_ids = pickle.load(f)
+    num_nodes = sum(len(ids) for ids in node_ids.values())
+    node_maps = torch.full((num_nodes + 1,), -1, dtype=torch.long)
+    for mode, ids in node_ids.items():
+        ids = torch.as_tensor(list(ids), dtype=torch.long)
+        if ids.numel() and bool((node_maps[ids] != -1).any()):
+            raise AssertionError('entity id listed under two modes')      # (the reference asserts, line 27)
+        node_maps[ids] = torch.arange(ids.shape[0])
+    feature_dims = {m: embed_dim for m in rels}
+    feature_modules = {m: torch.nn.Embedding(len(node_ids[m]) + 1, embed_dim) for m in rels}
+    for mode in rels:
+        feature_modules[mode].weight.data.normal_(0, 1. / embed_dim)
+
+    def features(nodes, mode):
+        w = feature_modules[mode].weight
+        return feature_modules[mode](node_maps.to(w.device)[torch.as_tensor(nodes, dtype=torch.long, device=w.device)])
+    graph = Graph(features, feature_dims, rels, adj_lists)
+    return graph, feature_modules, node_maps
+
+
+def _raw(data_file):
+    with open(data_file, 'rb') as f:
+        return pickle.load(f)
+
+
+def load_queries(data_file, keep_graph=False):
+    """reference: data_utils.py:150-152."""
+    return [Query.deserialize(info, keep_graph=keep_graph) for info in _raw(data_file)]
+
+
+def load_queries_by_formula(data_file):
+    """reference: data_utils.py:155-161: {query type: {formula: [Query]}} in file order."""
+    queries = defaultdict(lambda: defaultdict(list))
+    for raw_query in _raw(data_file):
+        query = Query.deserialize(raw_query)
+        queries[query.formula.query_type][query.formula].append(query)
+    return queries
+
+
+def load_queries_by_type(data_file, keep_graph=True):
+    """reference: data_utils.py:164-170."""
+    queries = defaultdict(list)
+    for raw_query in _raw(data_file):
+        query = Query.deserialize(raw_query, keep_graph=keep_graph)
+        queries[query.formula.query_type].append(query)
+    return queries
+
+
+def load_test_queries_by_formula(data_file):
+    """reference: data_utils.py:173-182: split by whether a query carries one negative or a full list."""
+    queries = {'full_neg': defaultdict(lambda: defaultdict(list)), 'one_neg': defaultdict(lambda: defaultdict(list))}
+    for raw_query in _raw(data_file):
+        neg_type = 'full_neg' if len(raw_query[1]) > 1 else 'one_neg'
+        query = Query.deserialize(raw_query)
+        queries[neg_type][query.formula.query_type][query.formula].append(query)
+    return queries
 
 
 class QueryGraphBatch(object):

@@ -5,6 +5,7 @@ reference's samplers, negative mining and self-checks are out of scope.
 
 The encoder is duck-typed: objects of the reference's own classes work too.
 """
+import random
 from collections import OrderedDict
 
 CHAIN_TYPES = ('1-chain', '2-chain', '3-chain')
@@ -91,7 +92,7 @@ class Query(object):
     (graph.py:62-77). Negative lists are kept as given (no sub-sampling)."""
 
     def __init__(self, query_graph, neg_samples=None, hard_neg_samples=None,
-                 keep_graph=False):
+                 keep_graph=False, neg_sample_max=None):
         qt = query_graph[0]
         edges = query_graph[1:]
         if qt in CHAIN_TYPES or qt in INTER_TYPES:
@@ -111,9 +112,34 @@ class Query(object):
         self.formula = Formula(qt, rels)
         self.target_node = edges[0][0]
         self.query_graph = query_graph if keep_graph else None
-        self.neg_samples = None if neg_samples is None else list(neg_samples)
-        self.hard_neg_samples = (None if hard_neg_samples is None
-                                 else list(hard_neg_samples))
+        # neg_sample_max (reference graph.py:81-88): lists at / above the cap are drawn WITHOUT replacement with
+        # python's `random` -- also when the cap equals the list's length, which is what deserialize() passes: the
+        # loaded negatives are a seeded permutation of the stored ones. None keeps the lists as given.
+        if neg_samples is None:
+            self.neg_samples = None
+        elif neg_sample_max is None or len(neg_samples) < neg_sample_max:
+            self.neg_samples = list(neg_samples)
+        else:
+            self.neg_samples = random.sample(list(neg_samples), neg_sample_max)
+        if hard_neg_samples is None:
+            self.hard_neg_samples = None
+        elif neg_sample_max is None or len(hard_neg_samples) <= neg_sample_max:
+            self.hard_neg_samples = list(hard_neg_samples)
+        else:
+            self.hard_neg_samples = random.sample(list(hard_neg_samples), neg_sample_max)
+
+    def serialize(self):
+        """(query_graph, neg_samples, hard_neg_samples): the record the reference's *_queries_*.pkl files hold
+        (graph.py:116-120)."""
+        if self.query_graph is None:
+            raise Exception('Cannot serialize query loaded with query graph!')
+        return (self.query_graph, self.neg_samples, self.hard_neg_samples)
+
+    @staticmethod
+    def deserialize(serial_info, keep_graph=False):
+        """reference graph.py:121-123: the cap on the negative lists is the stored list's own length."""
+        return Query(serial_info[0], serial_info[1], serial_info[2], keep_graph=keep_graph,
+                     neg_sample_max=None if serial_info[1] is None else len(serial_info[1]))
 
     def __hash__(self):
         return hash((self.formula, self.target_node, self.anchor_nodes))

@@ -283,6 +283,71 @@ QUERY_TYPES = ['1-chain', '2-chain', '3-chain', '2-inter', '3-inter',
 READOUTS = ['sum', 'max', 'mp', 'mlp', 'targetmlp', 'concat']
 
 
+def run_loader_case(seed=7):
+    """Dataset files in the reference's own formats, written with the reference's own classes
+    (Query.serialize, graph.py:116-120; graph_data.pkl = (rels, adj_lists, node_maps), data_utils.py:19) on a
+    small synthetic KG, plus what the reference's loaders make of them (load_graph, load_queries_by_formula,
+    load_test_queries_by_formula: data_utils.py:18-37, 155-186) under fixed python / torch seeds. The .pkl files
+    are DATA (nested tuples / lists / dicts of ints and strings); tests/test_loaders.py reads them with
+    mpqe_amd.data_utils and compares with the .json written here."""
+    import pickle
+    rmodel, rdata, rgraph, renc = _load_reference()
+    from mpqe_amd import synthetic
+    out = os.path.join(OUT, 'dataset')
+    os.makedirs(out, exist_ok=True)
+    schema = synthetic.make_schema(*synthetic.KG_SHAPES['tiny'], seed=seed)
+    adj = synthetic.make_adjacency(schema, degree=2, seed=seed)
+    node_maps = {m: [int(x) for x in schema.ids[m]] for m in schema.modes}
+    rels = {m: [tuple(r) for r in schema.relations[m]] for m in schema.relations}
+    adj_plain = {rel: {int(n): set(int(x) for x in nb) for n, nb in lists.items()} for rel, lists in adj.items()}
+    with open(os.path.join(out, 'graph_data.pkl'), 'wb') as f:
+        pickle.dump((rels, adj_plain, node_maps), f, protocol=2)
+    rng = np.random.RandomState(seed)
+    train, test = [], []
+    for qi, qt in enumerate(QUERY_TYPES):
+        for rep in range(2):
+            formula = synthetic.sample_formula(schema, qt, rng)
+            for q in synthetic.sample_queries(schema, formula, 3, rng, n_neg=4, n_hard=2):
+                train.append(rgraph.Query(q.query_graph, q.neg_samples, q.hard_neg_samples, 100, keep_graph=True))
+            # test files mix 'one negative' and 'full negative list' queries (load_test_queries_by_formula)
+            for k, q in enumerate(synthetic.sample_queries(schema, formula, 2, rng, n_neg=1 if rep == 0 else 5, n_hard=3)):
+                test.append(rgraph.Query(q.query_graph, q.neg_samples, q.hard_neg_samples, 100, keep_graph=True))
+    with open(os.path.join(out, 'train_queries.pkl'), 'wb') as f:
+        pickle.dump([q.serialize() for q in train], f, protocol=2)
+    with open(os.path.join(out, 'test_queries.pkl'), 'wb') as f:
+        pickle.dump([q.serialize() for q in test], f, protocol=2)
+
+    def qrec(q):
+        return dict(type=q.formula.query_type, rels=_jsonable(q.formula.rels), target_mode=q.formula.target_mode,
+                    anchor_modes=list(q.formula.anchor_modes), anchors=list(q.anchor_nodes), target=q.target_node,
+                    neg=q.neg_samples, hard=q.hard_neg_samples)
+    expect = {}
+    # what the reference's loaders return, under these seeds
+    random.seed(11)
+    by_formula = rdata.load_queries_by_formula(os.path.join(out, 'train_queries.pkl'))
+    expect['train'] = [[qt, [[_jsonable(f.rels), [qrec(q) for q in qs]] for f, qs in fs.items()]]
+                       for qt, fs in by_formula.items()]
+    random.seed(12)
+    tests_ = rdata.load_test_queries_by_formula(os.path.join(out, 'test_queries.pkl'))
+    expect['test'] = {neg: [[qt, [[_jsonable(f.rels), [qrec(q) for q in qs]] for f, qs in fs.items()]]
+                            for qt, fs in tests_[neg].items()] for neg in ('full_neg', 'one_neg')}
+    torch.manual_seed(13)
+    graph, feature_modules, node_map_t = rdata.load_graph(out, 8)
+    expect['graph'] = dict(
+        node_map=node_map_t.tolist(),
+        modes=list(feature_modules.keys()),
+        feature_rows={m: int(feature_modules[m].weight.shape[0]) for m in feature_modules},
+        feature_sum={m: float(feature_modules[m].weight.double().sum()) for m in feature_modules},
+        feature_first_row={m: feature_modules[m].weight[0].tolist() for m in feature_modules},
+        rel_edges=[[list(k), v] for k, v in graph.rel_edges.items()],
+        mode_weights=[[k, v] for k, v in graph.mode_weights.items()],
+        full_lists={m: sorted(graph.full_lists[m]) for m in graph.full_lists},
+        lookup=graph.features(torch.tensor([int(schema.ids[schema.modes[0]][1])]), schema.modes[0]).tolist())
+    with open(os.path.join(out, 'expect.json'), 'w') as f:
+        json.dump(expect, f)
+    print('dataset fixture: %d train / %d test queries' % (len(train), len(test)))
+
+
 def case_matrix():
     """7 query types x 6 readouts; the (adaptive / fixed L, shared / unshared,
     scatter op, hard negatives, scale) variant rotates so that every value is
@@ -327,6 +392,7 @@ def main():
                   isolated=False)
     run_sage_case('sage_depth1_plain', D=16, layer_norm=False, seed=5)
     run_sage_case('sage_depth1_ln', D=16, layer_norm=True, seed=6)
+    run_loader_case()
     print('wrote fixtures to', OUT)
 
 
