@@ -91,6 +91,8 @@ PROTOTYPES = {
     'mpqe_sample_negatives': (I, [P, L, P, L, P, L, ctypes.c_uint64, P, P, P]),
     'mpqe_adam_step': (I, [P, P, P, P, L, DBL, DBL, DBL, DBL, DBL, L, P]),
     'mpqe_sgd_step': (I, [P, P, L, DBL, DBL, P]),
+    'mpqe_adam_rows_step': (I, [P, ctypes.POINTER(StepBatch), I, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
+                                ctypes.POINTER(c_void_p), I, L, DBL, DBL, DBL, DBL, L, P]),
     'mpqe_step_workspace_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, ctypes.POINTER(StepLanes)]),
     'mpqe_step_desc_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, ctypes.POINTER(StepLanes)]),
     'mpqe_step_forward_backward': (I, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, P, P, P, F,
@@ -135,6 +137,7 @@ def check(cdll, status, what):
 
 
 STEP_NO_PRUNE, STEP_NO_CHAIN, STEP_ZERO_GRADS, STEP_NO_KSPLIT, STEP_EIGHT_WAVES, STEP_NO_UNIFORM = 1, 2, 4, 8, 16, 32
+STEP_SPARSE_TABLES = 64
 
 
 def make_step_params(dim, num_relations, readout, table_ptrs, table_rows, node_map_ptr, node_map_len,

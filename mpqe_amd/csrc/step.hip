@@ -924,7 +924,7 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restri
                                                           const Rank1 *__restrict__ rank1,
                                                           const float *__restrict__ VT, unsigned *epoch_b,
                                                           const char *__restrict__ touch, size_t touch_keys,
-                                                          const float *__restrict__ DG, TablePtrs tabs) {
+                                                          const float *__restrict__ DG, TablePtrs tabs, int table_store) {
     // zeroed: this call zero-filled the gradients, so `out` is known to be 0 -- a store replaces the
     // read-modify-write (whose read would be one more dependent round trip at the end of the chain)
     __shared__ f32x4 part[4][64];
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restri
         // (As workgroups of the weight-gradient launch they are throttled to two per CU by its 64 KB of LDS: 23.6 us
         // for that launch instead of 16.6; here they cost 2.6 us.)
         table_sum_block(reinterpret_cast<const TouchHeader *>(touch), reinterpret_cast<const tkey_t *>(touch + touch_keys),
-                        nullptr, DG, D, tabs, zeroed, (long long)((int)blockIdx.y - ngroups - 1) * gridDim.x + blockIdx.x);
+                        nullptr, DG, D, tabs, table_store, (long long)((int)blockIdx.y - ngroups - 1) * gridDim.x + blockIdx.x);
         return;
     }
     if ((int)blockIdx.y == ngroups) {       // one extra workgroup row: the loss reduction rides along
@@ -2147,6 +2147,86 @@ extern "C" int mpqe_step_touch_build(const mpqe_step_params_t *P, const mpqe_ste
     return mpqe_launch_status();
 }
 
+// ---- row-sparse Adam over the touched table rows (include/mpqe_amd.h: mpqe_adam_rows_step)
+struct RowAdamPtrs {
+    float *p[MPQE_STEP_MAX_MODES], *m[MPQE_STEP_MAX_MODES], *v[MPQE_STEP_MAX_MODES];
+    const float *g[MPQE_STEP_MAX_MODES];
+};
+__global__ __launch_bounds__(256) void adam_rows_kernel(const TouchHeader *__restrict__ th, const tkey_t *__restrict__ keys,
+                                                        int D, RowAdamPtrs rp, float omb1, float omb2, float eps,
+                                                        float neg_step_size) {
+    // one group of D / 4 lanes per sorted position; the first position of a run of equal keys owns the row
+    const int lpr = D / 4, per = 256 / lpr;
+    const long long k = (long long)blockIdx.x * per + threadIdx.x / lpr;
+    const int c = (threadIdx.x % lpr) * 4;
+    if (k >= th->M) return;
+    const tkey_t key = keys[k];
+    if (key == TOUCH_INVALID || (k > 0 && keys[k - 1] == key)) return;
+    const int tab = (int)(key >> th->row_bits);
+    const long long off = (long long)(key & ((1ull << th->row_bits) - 1ull)) * D + c;
+    float *p = rp.p[0], *m = rp.m[0], *v = rp.v[0];
+    const float *g = rp.g[0];
+#pragma unroll
+    for (int t = 1; t < MPQE_STEP_MAX_MODES; ++t)
+        if (t == tab) {
+            p = rp.p[t];
+            m = rp.m[t];
+            v = rp.v[t];
+            g = rp.g[t];
+        }
+    if (!p || !g || !m || !v) return;
+    const f32x4 gg = gload4(g + off);
+    f32x4 pp = *reinterpret_cast<f32x4 *>(p + off), mm = *reinterpret_cast<f32x4 *>(m + off);
+    f32x4 vv = *reinterpret_cast<f32x4 *>(v + off);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        // torch.optim.SparseAdam, operation for operation (no contraction into fused multiply-adds: the same roundings)
+        const float m_upd = __fmul_rn(__fsub_rn(gg[e], mm[e]), omb1);
+        const float v_upd = __fmul_rn(__fsub_rn(__fmul_rn(gg[e], gg[e]), vv[e]), omb2);
+        const float numer = __fadd_rn(m_upd, mm[e]);
+        const float v_new = __fadd_rn(v_upd, vv[e]);
+        const float denom = __fadd_rn(sqrtf(v_new), eps);
+        mm[e] = __fadd_rn(mm[e], m_upd);
+        vv[e] = v_new;
+        pp[e] = __fadd_rn(pp[e], __fmul_rn(neg_step_size, __fdiv_rn(numer, denom)));
+    }
+    *reinterpret_cast<f32x4 *>(p + off) = pp;
+    *reinterpret_cast<f32x4 *>(m + off) = mm;
+    *reinterpret_cast<f32x4 *>(v + off) = vv;
+}
+
+extern "C" int mpqe_adam_rows_step(const void *touch, const mpqe_step_batch_t *B, int nb, float *const *params,
+                                   const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
+                                   int num_modes, int64_t dim, double lr, double beta1, double beta2, double eps,
+                                   int64_t step, void *stream) {
+    if (!touch || !B || !params || !grads || !exp_avg || !exp_avg_sq || step < 1) return MPQE_ERR_INVALID_ARG;
+    if (num_modes <= 0 || num_modes > MPQE_STEP_MAX_MODES || dim <= 0 || dim % 4 != 0 || dim > 1024 || 256 % (dim / 4) != 0)
+        return MPQE_ERR_UNSUPPORTED;
+    if (!(beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1.)) return MPQE_ERR_INVALID_ARG;
+    const long long M = touch_entries(B, nb);
+    if (M <= 0) return MPQE_ERR_INVALID_ARG;
+    RowAdamPtrs rp;
+    memset(&rp, 0, sizeof(rp));
+    for (int m = 0; m < num_modes; ++m) {
+        rp.p[m] = params[m];
+        rp.g[m] = grads[m];
+        rp.m[m] = exp_avg[m];
+        rp.v[m] = exp_avg_sq[m];
+        if (((uintptr_t)rp.p[m] | (uintptr_t)rp.g[m] | (uintptr_t)rp.m[m] | (uintptr_t)rp.v[m]) % 16 != 0)
+            return MPQE_ERR_INVALID_ARG;
+    }
+    // torch.optim.SparseAdam: step_size = lr * sqrt(1 - b2^t) / (1 - b1^t) in double (python floats), 1 - beta too
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const float neg_step = (float)(-(lr * sqrt(bc2) / bc1));
+    const TouchLayout L = touch_layout(M, 0);
+    const char *tb = reinterpret_cast<const char *>(touch);
+    const long long per = 256 / (dim / 4);
+    hipLaunchKernelGGL(adam_rows_kernel, dim3((unsigned)((M + per - 1) / per)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const TouchHeader *>(tb), reinterpret_cast<const tkey_t *>(tb + L.keys), (int)dim, rp,
+                       (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, neg_step);
+    return mpqe_launch_status();
+}
+
 extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb,
                                           const int64_t *anchor_ids, const int64_t *targets, const int64_t *negs,
                                           float margin, const mpqe_step_grads_t *G, int backward,
@@ -2181,6 +2261,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     const bool use_chain = hp.chain;
     // touch plan given: the chain form stores per-entry table-gradient rows and sums them per destination (no atomics)
     bool use_touch = touch != nullptr && use_chain && backward;
+    const bool sparse_tables = (P->flags & MPQE_STEP_SPARSE_TABLES) != 0;
+    if (sparse_tables && backward && !use_touch) return MPQE_ERR_INVALID_ARG;      // (needs the touch plan and the chain form)
     if (use_touch) {
         if ((uintptr_t)touch % 256 != 0) return MPQE_ERR_INVALID_ARG;
         for (int m = 0; m < P->num_modes; ++m)
@@ -2323,7 +2405,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                 seg(G->bias[l], D);
             }
             seg(G->mode_emb, (long long)P->num_modes * D);
-            for (int m = 0; m < P->num_modes; ++m) seg(G->tables[m], (long long)P->table_rows[m] * D);
+            // (SPARSE_TABLES: only the touched rows of the table gradients are ever read; they are written, not accumulated)
+            for (int m = 0; m < P->num_modes && !sparse_tables; ++m) seg(G->tables[m], (long long)P->table_rows[m] * D);
             zs.block0[zs.count] = zblocks;
         }
         if (use_chain) {
@@ -2581,7 +2664,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                            loss, (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0, lm, bterms,
                            reinterpret_cast<const Rank1 *>(db + hp.o_rank1), (const float *)VT, epoch_b,
                            reinterpret_cast<const char *>(touch), touch_layout(hp.touch_M, 0).keys,
-                           (const float *)(wb + hp.o_DG), tabs);
+                           (const float *)(wb + hp.o_DG), tabs,
+                           (sparse_tables || (P->flags & MPQE_STEP_ZERO_GRADS)) ? 1 : 0);
     }
     return mpqe_launch_status();
 }

@@ -93,7 +93,7 @@ class FusedTrainStep(object):
     batches of equal depth together (longest chains first)."""
 
     def __init__(self, model, margin=1.0, lanes=1, prune=True, chain=True, ksplit=True, eight_waves=False,
-                 uniform=True, touch=True):
+                 uniform=True, touch=True, sparse_tables=False):
         enc = model.enc
         if not hasattr(enc, 'table') or getattr(enc, 'node_maps', None) is None:
             raise ValueError('FusedTrainStep needs a DirectEncoder built with node_maps')
@@ -109,6 +109,14 @@ class FusedTrainStep(object):
         self.uniform = bool(uniform and chain)
         # entity-table gradients summed per table row in a fixed order (touch plan) instead of fp32 atomics
         self.touch = bool(touch and chain)
+        # row-sparse entity-table gradients (include/mpqe_amd.h: MPQE_STEP_SPARSE_TABLES): only the rows a step's ids touch
+        # are written -- for FlatOptimizer(sparse_tables=True) / the row exchange; p.grad of a table is then NOT a
+        # dense gradient (untouched rows hold whatever they held)
+        self.sparse_tables = bool(sparse_tables)
+        if self.sparse_tables and not self.touch:
+            raise ValueError('sparse_tables needs the chain form with the touch plan')
+        if self.sparse_tables:
+            self.flags |= _capi.STEP_SPARSE_TABLES
         self.device = next(model.parameters()).device
         if self.device.type != 'cuda':
             raise RuntimeError('mpqe_amd: the model must be on the GPU -- there is no CPU path')

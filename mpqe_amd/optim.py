@@ -9,16 +9,37 @@ view of it: names, shapes and `state_dict()` are unchanged) and updates everythi
     step = FusedTrainStep(model)
     opt = FlatOptimizer(step, lr=0.01, opt='adam')
     loss = step.run(packed); opt.step()
+
+Row-sparse tables. Dense Adam over the entity tables streams 16 bytes per table element per step
+whether or not a row was touched (AM-sized tables: 191 MB, 1M entities at D = 256: 1 GB, against a few thousand touched
+rows), and needs the whole table gradient zero-filled first. `FlatOptimizer(step, sparse_tables=True)` with
+`FusedTrainStep(model, sparse_tables=True)` updates ONLY the rows the step's ids touched (`mpqe_adam_rows_step`, the
+rule of torch.optim.SparseAdam on the per-row gradient sums) and everything else densely as before:
+
+    step = FusedTrainStep(model, sparse_tables=True)
+    opt = FlatOptimizer(step, lr=0.01, sparse_tables=True)
+    loss = step.run(packed); opt.step(packed)          # the packed step's touch plan names the rows
+
+Deviation from the reference's dense Adam, stated: a row no step touches keeps its moments undecayed and does not move
+(dense Adam decays every row's m, v every step and keeps moving rows whose m is non-zero).
 """
+import ctypes
+
 import torch
 
 from . import _capi, ops
 
 
 class FlatOptimizer(object):
-    def __init__(self, fused_step, lr=0.01, opt='adam', betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, fused_step, lr=0.01, opt='adam', betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 sparse_tables=False):
         if opt not in ('adam', 'sgd'):
             raise ValueError('opt must be adam or sgd')           # reference train.py:83-88
+        if sparse_tables and (opt != 'adam' or weight_decay != 0.0):
+            raise ValueError('sparse_tables: Adam without weight decay (torch.optim.SparseAdam has none either)')
+        if sparse_tables and not fused_step.sparse_tables:
+            raise ValueError('sparse_tables needs FusedTrainStep(model, sparse_tables=True)')
+        self.sparse_tables = bool(sparse_tables)
         self.fused = fused_step
         self.lr, self.opt, self.betas, self.eps, self.weight_decay = float(lr), opt, betas, float(eps), float(weight_decay)
         self.t = 0
@@ -27,22 +48,59 @@ class FlatOptimizer(object):
         total = fused_step.flat_grad.numel()
         self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
         off = 0
+        offsets = {}
         with torch.no_grad():
             for p in params:                                      # same order as the gradient views
                 n = p.numel()
                 self.flat_param[off:off + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat_param[off:off + n].view(p.shape)
+                offsets[id(p)] = (off, n)
                 off += n
         fused_step._refresh_pointers()                             # the parameters moved
         self.exp_avg = torch.zeros_like(self.flat_param) if opt == 'adam' else None
         self.exp_avg_sq = torch.zeros_like(self.flat_param) if opt == 'adam' else None
+        # sparse tables: the entity tables' slices of the flat buffers (row-sparse update) and the runs in between
+        # (dense update, one launch per run: the tables are the first parameters, so normally one run)
+        self.table_slices, self.dense_runs = [], [(0, total)]
+        if self.sparse_tables:
+            m = fused_step.model
+            self.table_slices = [offsets[id(m.enc.table(mode))] for mode in fused_step.modes]
+            taken = sorted(self.table_slices)
+            self.dense_runs, cur = [], 0
+            for o, n in taken:
+                if o > cur:
+                    self.dense_runs.append((cur, o - cur))
+                cur = o + n
+            if cur < total:
+                self.dense_runs.append((cur, total - cur))
+            arr = ctypes.c_void_p * len(self.table_slices)
+            esz = 4
+            self._tab_p = arr(*[self.flat_param.data_ptr() + esz * o for o, _ in self.table_slices])
+            self._tab_g = arr(*[fused_step.flat_grad.data_ptr() + esz * o for o, _ in self.table_slices])
+            self._tab_m = arr(*[self.exp_avg.data_ptr() + esz * o for o, _ in self.table_slices])
+            self._tab_v = arr(*[self.exp_avg_sq.data_ptr() + esz * o for o, _ in self.table_slices])
 
-    def step(self):
+    def step(self, packed=None):
+        """packed: with sparse_tables, the packed step whose gradients are being applied (its touch plan lists the
+        table rows to update)."""
         self.t += 1
         g = self.fused.flat_grad
         with torch.cuda.device(self.fused.device):
             stream = torch.cuda.current_stream().cuda_stream
-            if self.opt == 'adam':
+            if self.opt == 'adam' and self.sparse_tables:
+                if packed is None or packed.touch_ptr is None:
+                    raise ValueError('sparse_tables: step(packed) needs the packed step (with its touch plan)')
+                L = ops.lib()
+                st = 0
+                for o, n in self.dense_runs:
+                    st = st or L.mpqe_adam_step(self.flat_param.data_ptr() + 4 * o, g.data_ptr() + 4 * o,
+                                                self.exp_avg.data_ptr() + 4 * o, self.exp_avg_sq.data_ptr() + 4 * o, n,
+                                                self.lr, self.betas[0], self.betas[1], self.eps, 0.0, self.t, stream)
+                st = st or L.mpqe_adam_rows_step(packed.touch_ptr, packed.batches, packed.nb, self._tab_p, self._tab_g,
+                                                 self._tab_m, self._tab_v, len(self.table_slices),
+                                                 self.fused.model.emb_dim, self.lr, self.betas[0], self.betas[1],
+                                                 self.eps, self.t, stream)
+            elif self.opt == 'adam':
                 st = ops.lib().mpqe_adam_step(self.flat_param.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(),
                                               self.exp_avg_sq.data_ptr(), g.numel(), self.lr, self.betas[0],
                                               self.betas[1], self.eps, self.weight_decay, self.t, stream)

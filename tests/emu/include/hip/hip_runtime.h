@@ -141,6 +141,10 @@ static inline void __builtin_amdgcn_s_waitcnt(int) { (void)emu::wave_exchange(0.
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 static inline void __builtin_amdgcn_s_barrier() { emu::block_barrier(); }
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4); return i; }

@@ -227,3 +227,68 @@ def test_captured_steps_own_their_workspace(chain):
             else:
                 assert torch.equal(q.grad, ref[name][1][k]), (name, k)
     step.check()
+
+
+def test_sparse_tables_training_loop():
+    """Row-sparse entity tables: FusedTrainStep(sparse_tables=True) writes only the touched rows of the
+    table gradients (no zero fill, no pass over the tables) and FlatOptimizer(sparse_tables=True) updates only those
+    rows with torch.optim.SparseAdam's rule. Three steps against the module path + torch.optim.SparseAdam on the touched
+    rows of its dense table gradients + torch.optim.Adam on everything else."""
+    import copy
+    from mpqe_amd import ops
+    from mpqe_amd.fused import FusedTrainStep
+    from mpqe_amd.optim import FlatOptimizer
+    model, batches = _setup('mp', True, False)
+    ref_model = copy.deepcopy(model)
+    tab_names = [k for k, _ in ref_model.named_parameters() if k.startswith('enc.')]
+    ref_tabs = [p for k, p in ref_model.named_parameters() if k.startswith('enc.')]
+    ref_rest = [p for k, p in ref_model.named_parameters() if not k.startswith('enc.')]
+    opt_tabs = torch.optim.SparseAdam(ref_tabs, lr=0.01)
+    opt_rest = torch.optim.Adam(ref_rest, lr=0.01)
+    step = FusedTrainStep(model, sparse_tables=True)
+    opt = FlatOptimizer(step, lr=0.01, sparse_tables=True)
+    packed = step.pack(batches)
+    node_maps = model.enc.node_maps.cpu()
+    # rows each table is touched in by this packed step: anchors of the batch's anchor modes, targets and negatives
+    touched = {m: set() for m in step.modes}
+    for b in batches:
+        f = b['formula']
+        for a, mode in enumerate(f.anchor_modes):
+            touched[mode].update(node_maps[torch.from_numpy(b['anchor_ids'][:, a])].tolist())
+        touched[f.target_mode].update(node_maps[torch.from_numpy(b['targets'])].tolist())
+        touched[f.target_mode].update(node_maps[torch.from_numpy(b['negs'])].tolist())
+    for it in range(3):
+        for q in model.parameters():
+            q.grad.fill_(7.0)                      # stale content: sparse mode must not rely on (or clear) it
+        step.run(packed)
+        step.check()
+        if it == 0:
+            for mode in step.modes:
+                g = model.enc.table(mode).grad
+                rows = sorted(touched[mode])
+                rest = sorted(set(range(g.shape[0])) - touched[mode])
+                assert bool((g[rest] == 7.0).all()), 'untouched rows of a sparse table gradient were written'
+                assert not bool((g[rows] == 7.0).all(dim=1).any()), 'a touched row was not written'
+        opt.step(packed)
+        ref_model.zero_grad(set_to_none=True)
+        total = None
+        for b in batches:
+            out = ref_model.encode(b['formula'], b['queries'])
+            l = ops.hinge(ref_model.score(b['formula'], out, b['targets'].tolist()),
+                          ref_model.score(b['formula'], out, b['negs'].tolist()), 1.0) * b['weight']
+            total = l if total is None else total + l
+        total.backward()
+        for name, p, mode in zip(tab_names, ref_tabs, step.modes):
+            assert name == 'enc.feat-%s.weight' % mode
+            rows = torch.tensor(sorted(touched[mode]), dtype=torch.long, device=p.device)
+            dense = torch.zeros_like(p) if p.grad is None else p.grad
+            p.grad = torch.sparse_coo_tensor(rows[None], dense[rows], p.shape)
+        for p in ref_rest:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        opt_tabs.step()
+        opt_rest.step()
+    ref = dict(ref_model.named_parameters())
+    for k, p in model.named_parameters():
+        # (Adam turns a last-bit difference of a near-zero gradient into lr-sized steps: the tolerance of the dense loop test)
+        np.testing.assert_allclose(p.detach().cpu().numpy(), ref[k].detach().cpu().numpy(), rtol=1e-3, atol=2e-3, err_msg=k)

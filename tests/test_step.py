@@ -404,3 +404,71 @@ def test_fused_step_rejects_bad_descriptors(be):
     SB = (_capi.StepBatch * 1)()
     assert be.lib.mpqe_step_workspace_bytes(ctypes.byref(P), SB, 1, None) == 0          # dim 0
     assert be.lib.mpqe_step_workspace_bytes(ctypes.byref(P), SB, 17, None) == 0         # > MAX_BATCHES
+
+
+def test_adam_rows_step_equals_torch_sparse_adam(be):
+    """mpqe_adam_rows_step on the rows of a touch plan == torch.optim.SparseAdam fed the same per-row gradients (three
+    steps, fresh gradients each), and rows outside the plan are not touched at all."""
+    rng = np.random.RandomState(5)
+    D, nmodes = 64, 3
+    rows_per = [7, 40, 13]
+    node_map = np.full(sum(rows_per) + 1, -1, np.int64)
+    ids_of = []
+    perm = rng.permutation(sum(rows_per))
+    o = 0
+    for m, r in enumerate(rows_per):
+        ids = np.sort(perm[o:o + r])
+        node_map[ids] = np.arange(r)
+        ids_of.append(ids)
+        o += r
+    # one 2-inter batch (anchors of modes 0 and 1, targets of mode 2) and one 1-chain batch (anchor mode 1, target mode 1)
+    B1, B2 = 9, 5
+    SB = (_capi.StepBatch * 2)()
+    SB[0] = _capi.make_step_batch('2-inter', 1, B1, [0, 0], [0], [0, 1], 2, 1.0)
+    SB[1] = _capi.make_step_batch('1-chain', 1, B2, [0], [0], [1], 1, 1.0)
+    pick = lambda m, n: ids_of[m][rng.randint(len(ids_of[m]), size=n)]
+    anchors = np.concatenate([pick(0, B1), pick(1, B1), pick(1, B2)])
+    targets = np.concatenate([pick(2, B1), pick(1, B2)])
+    negs = np.concatenate([pick(2, B1), pick(1, B2)])
+    negs[3] = sum(rows_per)                  # an id of no mode: not a row
+    tabs = [rng.randn(r + 1, D).astype(np.float32) for r in rows_per]
+    P = _capi.make_step_params(D, 4, 'mp', [0] * nmodes, [r + 1 for r in rows_per], 0, len(node_map), 0, [0], [0], [0])
+    d_nm = be.put(node_map)
+    P.node_map = be.ptr(d_nm)
+    d_a, d_t, d_n = be.put(anchors), be.put(targets), be.put(negs)
+    tb = be.lib.mpqe_step_touch_bytes(ctypes.byref(P), SB, 2)
+    twb = be.lib.mpqe_step_touch_workspace_bytes(ctypes.byref(P), SB, 2)
+    tbuf, twbuf = be.nbytes(tb + 256), be.nbytes(twb + 256)
+    tptr = (be.ptr(tbuf) + 255) // 256 * 256
+    be.check(be.lib.mpqe_step_touch_build(ctypes.byref(P), SB, 2, be.ptr(d_a), be.ptr(d_t), be.ptr(d_n), tptr, tb,
+                                          (be.ptr(twbuf) + 255) // 256 * 256, twb, be.stream), 'touch')
+    touched = [set() for _ in range(nmodes)]
+    for m, idl in ((0, anchors[:B1]), (1, anchors[B1:]), (2, targets[:B1]), (1, targets[B1:]), (2, negs[:B1]), (1, negs[B1:])):
+        for i in idl:
+            if 0 <= i < len(node_map) and node_map[i] >= 0:
+                touched[m].add(int(node_map[i]))
+    ref_p = [torch.nn.Parameter(torch.from_numpy(t.copy())) for t in tabs]
+    ref_opt = torch.optim.SparseAdam(ref_p, lr=0.05, betas=(0.9, 0.99), eps=1e-6)
+    d_p = [be.put(t) for t in tabs]
+    d_m = [be.zeros(t.shape) for t in tabs]
+    d_v = [be.zeros(t.shape) for t in tabs]
+    arr = ctypes.c_void_p * nmodes
+    for step in range(1, 4):
+        grads = [rng.randn(*t.shape).astype(np.float32) for t in tabs]
+        d_g = [be.put(g) for g in grads]
+        be.check(be.lib.mpqe_adam_rows_step(tptr, SB, 2, arr(*[be.ptr(x) for x in d_p]), arr(*[be.ptr(x) for x in d_g]),
+                                            arr(*[be.ptr(x) for x in d_m]), arr(*[be.ptr(x) for x in d_v]), nmodes, D,
+                                            0.05, 0.9, 0.99, 1e-6, step, be.stream), 'adam rows')
+        for m in range(nmodes):
+            rows = torch.tensor(sorted(touched[m]), dtype=torch.long)
+            ref_p[m].grad = torch.sparse_coo_tensor(rows[None], torch.from_numpy(grads[m])[rows], tabs[m].shape)
+        ref_opt.step()
+    for m in range(nmodes):
+        got = be.get(d_p[m])
+        np.testing.assert_allclose(got, ref_p[m].detach().numpy(), rtol=2e-6, atol=1e-7, err_msg='table %d' % m)
+        untouched = sorted(set(range(tabs[m].shape[0])) - touched[m])
+        np.testing.assert_array_equal(got[untouched], tabs[m][untouched])
+        np.testing.assert_array_equal(be.get(d_m[m])[untouched], 0)
+        state = ref_opt.state[ref_p[m]]
+        np.testing.assert_allclose(be.get(d_m[m]), state['exp_avg'].numpy(), rtol=2e-6, atol=1e-8)
+        np.testing.assert_allclose(be.get(d_v[m]), state['exp_avg_sq'].numpy(), rtol=2e-6, atol=1e-9)
