@@ -58,6 +58,9 @@ def parse():
                     help='chain form: node states no anchor has reached yet as per-graph rows instead of one vector per batch')
     ap.add_argument('--no-ksplit', action='store_true', help='dim 128: chain waves own 32 columns and all of K')
     ap.add_argument('--eight-waves', action='store_true', help='dim 128: chain workgroups of eight waves (experimental)')
+    ap.add_argument('--dense-allreduce', action='store_true',
+                    help='N > 1: all-reduce the whole flat gradient buffer (what a literal port would do) instead of the '
+                         'touched-matrix bucket + row exchange')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='nccl = RCCL over xGMI (the real path); gloo only to exercise the multi-rank code on one GPU')
     return ap.parse_args()
@@ -401,13 +404,19 @@ def main():
     pool = [StepData(schema, model, args.batch_size, rng, device) for _ in range(4)]
 
     use_fused = args.path in ('auto', 'fused') and args.readout in ('mp', 'sum', 'max')
-    reducer = fstep = packed = captured = None
+    reducer = fstep = packed = captured = exchange = xplans = None
     if use_fused:
         from mpqe_amd.fused import FusedTrainStep
         fstep = FusedTrainStep(model, lanes=args.lanes, prune=not args.no_prune, chain=not args.no_chain,
                                ksplit=not args.no_ksplit, eight_waves=args.eight_waves, uniform=not args.no_uniform)
         packed = [pack_for_fused(fstep, d, 1.0 / world) for d in pool]
         captured = [fstep.capture(p) for p in packed] if args.graph else None
+        if world > 1 and not args.dense_allreduce:
+            # gradient exchange of the packed steps (collective, at pack time): which relation matrices / table rows ANY
+            # rank touches -- one bucket all-reduce of those matrices + an all-gather of table rows per step
+            from mpqe_amd.parallel import StepExchange
+            exchange = StepExchange(fstep)
+            xplans = [exchange.plan(p) for p in packed]
     elif world > 1:
         from mpqe_amd.parallel import GradReducer
         reducer = GradReducer(model)
@@ -418,9 +427,11 @@ def main():
                 loss = captured[i % len(pool)].replay()
             else:
                 loss = fstep.run(packed[i % len(pool)])
-            if world > 1:
+            if exchange is not None:
+                exchange.reduce(xplans[i % len(pool)])    # (the 1 / world of the mean is in the batch weights)
+            elif world > 1:
                 import torch.distributed as dist
-                dist.all_reduce(fstep.flat_grad)          # one bucket: p.grad are views of it (1/world is in the weights)
+                dist.all_reduce(fstep.flat_grad)          # the literal form: every parameter's dense gradient
             return loss
         loss = step_modules(model, pool[i % len(pool)])
         if reducer is not None:
@@ -478,6 +489,35 @@ def main():
                                 % (args.lanes, ', replayed from a hipGraph' if args.graph else '') if use_fused
                                 else 'drop-in modules (one autograd graph per step)'},
     }
+    if world > 1 and use_fused:
+        dense_bytes = fstep.flat_grad.numel() * 4
+        out['exchange'] = ({'form': 'dense all-reduce of the flat gradient buffer', 'bytes_per_rank_per_step': int(2 * (world - 1) / world * dense_bytes)}
+                           if exchange is None else
+                           {'form': 'bucket all-reduce of the relation matrices some rank touches (+ root, bias, mode rows) and an '
+                                    'all-gather of touched entity-table rows',
+                            'bytes_per_rank_per_step': int(np.mean([x.wire_bytes for x in xplans])),
+                            'bucket_bytes': int(np.mean([x.bucket.numel() * 4 for x in xplans])),
+                            'table_rows_gathered': int(np.mean([x.entries for x in xplans])),
+                            'dense_gradient_bytes': dense_bytes})
+    if rank == 0 and use_fused and world == 1:
+        # host side of a step with FRESH formulas and ids (a training loop draws new ones every step): packing =
+        # descriptors + ids to the device + the touch plan's sort; first run = + the descriptor table upload. Outside
+        # `value` (SURVEY.md 8d excludes collation), reported so that it can be held against ms_per_step.
+        fresh = StepData(schema, model, args.batch_size, np.random.RandomState(4242), device)
+        torch.cuda.synchronize()
+        tp = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            pk = pack_for_fused(fstep, fresh)
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            fstep.run(pk)
+            torch.cuda.synchronize()
+            tp.append((t1 - t0, t2 - t0, time.perf_counter() - t2))
+        out['pack_ms'] = {'host_call': float(np.median([a for a, _, _ in tp])) * 1e3,
+                          'until_device_idle': float(np.median([b for _, b, _ in tp])) * 1e3,
+                          'first_run_with_descriptor_upload': float(np.median([c for _, _, c in tp])) * 1e3}
     if rank == 0:
         flops_fwd, flops_all, bytes_all, launches = layer_work(pool[0], model)
         if use_fused:

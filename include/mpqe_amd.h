@@ -310,6 +310,7 @@ size_t mpqe_step_touch_bytes(const mpqe_step_params_t *params_host, const mpqe_s
                              int num_batches);
 size_t mpqe_step_touch_workspace_bytes(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,
                                        int num_batches);
+int64_t mpqe_step_touch_entries(const mpqe_step_batch_t *batches_host, int num_batches);   /* looked-up ids of a step */
 int mpqe_step_touch_build(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host, int num_batches,
                           const int64_t *anchor_ids, const int64_t *targets, const int64_t *negs, void *touch,
                           size_t touch_bytes, void *workspace, size_t workspace_bytes, void *stream);
@@ -350,10 +351,25 @@ int mpqe_sgd_step(float *param, const float *grad, int64_t n, double lr, double 
  * undecayed and do not move (dense Adam decays m, v of every row every step and moves rows whose m is non-zero). In
  * exchange a step costs O(touched rows), not 16 bytes x every table element (AM: 191 MB tables, 1M entities: 1 GB).
  * params / grads / exp_avg / exp_avg_sq: [num_modes] host arrays of device pointers, tables [rows_t, dim]; step >= 1. */
-int mpqe_adam_rows_step(const void *touch, const mpqe_step_batch_t *batches_host /* of the touch plan */, int num_batches,
-                        float *const *params, const float *const *grads, float *const *exp_avg,
+int mpqe_adam_rows_step(const void *touch, int64_t num_entries /* of the plan: mpqe_step_touch_entries, or n of
+                        mpqe_rows_plan_build */, float *const *params, const float *const *grads, float *const *exp_avg,
                         float *const *exp_avg_sq, int num_modes, int64_t dim, double lr, double beta1, double beta2,
                         double eps, int64_t step, void *stream);
+
+/* ---- data-parallel exchange of entity-table gradient rows ("exchange touched rows only") ---------
+ * Every rank all-gathers the (table, row) keys its packed step touches (key = table << row_bits | row, ~0 = none: the
+ * touch plan's sorted keys without repeats, padded) ONCE at pack time and builds one plan over all ranks' keys
+ * (mpqe_rows_plan_build: stable sort, so equal keys stay in rank order). Per step each rank all-gathers its gradient
+ * rows in its own key order and mpqe_table_rows_sum adds, per key, the gathered rows in plan order into the dense table
+ * gradients: the same additions in the same order on every rank -- equal to the dense all-reduce (a sum), bit-identical
+ * replicas, and bytes on the wire proportional to the touched rows, not to the tables.                          */
+size_t mpqe_rows_plan_bytes(int64_t n);
+size_t mpqe_rows_plan_workspace_bytes(int64_t n, int key_bits);
+int mpqe_rows_plan_build(const uint64_t *keys /* [n], device */, int64_t n, int row_bits, int key_bits, void *plan,
+                         size_t plan_bytes, void *workspace, size_t workspace_bytes, void *stream);
+int mpqe_table_rows_sum(const void *plan, int64_t n, const float *rows /* [n, dim] in the order of `keys` */, int64_t dim,
+                        float *const *table_grads /* [num_modes] host array of device pointers */, int num_modes,
+                        int store /* 1: rows are written, 0: added to */, void *stream);
 
 /* ---- negative sampling on the device -------------------------------------------
  * reference model.py:466-476: one negative per query, random.choice over query.neg_samples /

@@ -91,7 +91,7 @@ PROTOTYPES = {
     'mpqe_sample_negatives': (I, [P, L, P, L, P, L, ctypes.c_uint64, P, P, P]),
     'mpqe_adam_step': (I, [P, P, P, P, L, DBL, DBL, DBL, DBL, DBL, L, P]),
     'mpqe_sgd_step': (I, [P, P, L, DBL, DBL, P]),
-    'mpqe_adam_rows_step': (I, [P, ctypes.POINTER(StepBatch), I, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
+    'mpqe_adam_rows_step': (I, [P, L, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
                                 ctypes.POINTER(c_void_p), I, L, DBL, DBL, DBL, DBL, L, P]),
     'mpqe_step_workspace_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, ctypes.POINTER(StepLanes)]),
     'mpqe_step_desc_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, ctypes.POINTER(StepLanes)]),
@@ -100,6 +100,11 @@ PROTOTYPES = {
                                        P, I, P, P]),
     'mpqe_step_touch_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I]),
     'mpqe_step_touch_workspace_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I]),
+    'mpqe_step_touch_entries': (L, [ctypes.POINTER(StepBatch), I]),
+    'mpqe_rows_plan_bytes': (Z, [L]),
+    'mpqe_rows_plan_workspace_bytes': (Z, [L, I]),
+    'mpqe_rows_plan_build': (I, [P, L, I, I, P, Z, P, Z, P]),
+    'mpqe_table_rows_sum': (I, [P, L, P, L, ctypes.POINTER(c_void_p), I, I, P]),
     'mpqe_step_touch_build': (I, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, P, P, P, P, Z, P, Z, P]),
 }
 

@@ -2195,16 +2195,78 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(const TouchHeader *__res
     *reinterpret_cast<f32x4 *>(v + off) = vv;
 }
 
-extern "C" int mpqe_adam_rows_step(const void *touch, const mpqe_step_batch_t *B, int nb, float *const *params,
+extern "C" int64_t mpqe_step_touch_entries(const mpqe_step_batch_t *B, int nb) {
+    if (!B || nb < 1 || nb > MPQE_STEP_MAX_BATCHES) return -1;
+    return touch_entries(B, nb);
+}
+
+// ---- a plan from (table, row) keys that are given, not looked up (the data-parallel row exchange: every rank's touched
+// rows, all-gathered): keys sorted (stable), perm[k] = index of sorted position k in the input order
+extern "C" size_t mpqe_rows_plan_bytes(int64_t n) { return n > 0 ? touch_layout(n, 0).total : 0; }
+extern "C" size_t mpqe_rows_plan_workspace_bytes(int64_t n, int key_bits) {
+    return n > 0 && key_bits > 0 && key_bits <= 64 ? touch_layout(n, key_bits).w_total : 0;
+}
+__global__ __launch_bounds__(256) void iota_kernel(int *__restrict__ v, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] = (int)i;
+}
+extern "C" int mpqe_rows_plan_build(const uint64_t *keys, int64_t n, int row_bits, int key_bits, void *plan,
+                                    size_t plan_bytes, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!keys || !plan || !workspace || n <= 0 || n >= (1ll << 31) || row_bits <= 0 || key_bits <= row_bits || key_bits > 64)
+        return MPQE_ERR_INVALID_ARG;
+    const TouchLayout L = touch_layout(n, key_bits);
+    if (plan_bytes < L.total || workspace_bytes < L.w_total) return MPQE_ERR_WORKSPACE;
+    if ((uintptr_t)plan % 256 != 0 || (uintptr_t)workspace % 256 != 0) return MPQE_ERR_INVALID_ARG;
+    hipStream_t s = as_stream(stream);
+    char *tb = reinterpret_cast<char *>(plan), *wb = reinterpret_cast<char *>(workspace);
+    TouchHeader th;
+    memset(&th, 0, sizeof(th));
+    th.M = n;
+    th.row_bits = row_bits;
+    th.key_bits = key_bits;
+    upload(s, tb, &th, sizeof(th));
+    int *vals = reinterpret_cast<int *>(wb + L.w_vals);
+    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, vals, (long long)n);
+    size_t tmp_bytes = L.w_tmp_bytes;
+    if (rocprim::radix_sort_pairs(wb + L.w_tmp, tmp_bytes, reinterpret_cast<const tkey_t *>(keys),
+                                  reinterpret_cast<tkey_t *>(tb + L.keys), (const int *)vals,
+                                  reinterpret_cast<int *>(tb + L.perm), (size_t)n, 0u, (unsigned)key_bits, s) != hipSuccess)
+        return MPQE_ERR_LAUNCH;
+    return mpqe_launch_status();
+}
+// table_grads[t][row] (= or +=) the sum of rows[perm[k]] over the plan's run of key (t, row), in sorted (= input) order
+__global__ __launch_bounds__(256) void rows_sum_kernel(const char *__restrict__ plan, size_t o_keys, size_t o_perm,
+                                                       const float *__restrict__ rows, int D, TablePtrs tabs, int store) {
+    table_sum_block(reinterpret_cast<const TouchHeader *>(plan), reinterpret_cast<const tkey_t *>(plan + o_keys),
+                    reinterpret_cast<const int *>(plan + o_perm), rows, D, tabs, store, (long long)blockIdx.x);
+}
+extern "C" int mpqe_table_rows_sum(const void *plan, int64_t n, const float *rows, int64_t dim, float *const *table_grads,
+                                   int num_modes, int store, void *stream) {
+    if (!plan || !rows || !table_grads || n <= 0 || num_modes <= 0 || num_modes > MPQE_STEP_MAX_MODES)
+        return MPQE_ERR_INVALID_ARG;
+    if (dim <= 0 || dim % 4 != 0 || dim > 1024 || 256 % (dim / 4) != 0 || (uintptr_t)rows % 16 != 0) return MPQE_ERR_UNSUPPORTED;
+    TablePtrs tabs;
+    memset(&tabs, 0, sizeof(tabs));
+    for (int m = 0; m < num_modes; ++m) {
+        tabs.grad[m] = table_grads[m];
+        if ((uintptr_t)table_grads[m] % 16 != 0) return MPQE_ERR_INVALID_ARG;
+    }
+    const TouchLayout L = touch_layout(n, 0);
+    const long long per = 256 / (dim / 4);
+    hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)((n + per - 1) / per)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const char *>(plan), L.keys, L.perm, rows, (int)dim, tabs, store);
+    return mpqe_launch_status();
+}
+
+extern "C" int mpqe_adam_rows_step(const void *touch, int64_t num_entries, float *const *params,
                                    const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
                                    int num_modes, int64_t dim, double lr, double beta1, double beta2, double eps,
                                    int64_t step, void *stream) {
-    if (!touch || !B || !params || !grads || !exp_avg || !exp_avg_sq || step < 1) return MPQE_ERR_INVALID_ARG;
+    if (!touch || num_entries <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || step < 1) return MPQE_ERR_INVALID_ARG;
     if (num_modes <= 0 || num_modes > MPQE_STEP_MAX_MODES || dim <= 0 || dim % 4 != 0 || dim > 1024 || 256 % (dim / 4) != 0)
         return MPQE_ERR_UNSUPPORTED;
     if (!(beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1.)) return MPQE_ERR_INVALID_ARG;
-    const long long M = touch_entries(B, nb);
-    if (M <= 0) return MPQE_ERR_INVALID_ARG;
+    const long long M = num_entries;
     RowAdamPtrs rp;
     memset(&rp, 0, sizeof(rp));
     for (int m = 0; m < num_modes; ++m) {

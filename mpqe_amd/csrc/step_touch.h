@@ -126,6 +126,8 @@ __global__ __launch_bounds__(256) void touch_invert_kernel(const int *__restrict
 // costs one round trip per TS_AHEAD rows, not two per row. store: the call zero-filled the gradients, the row is
 // written; otherwise added to what is there.
 #define TS_AHEAD 8
+// perm != NULL: the row of sorted position k is DG[perm[k]] (rows that arrive in another order: the data-parallel row
+// exchange, mpqe_table_rows_sum); NULL: DG[k] (the chain kernel stores its rows in sorted position).
 template <class TabsT>
 __device__ __forceinline__ void table_sum_block(const TouchHeader *__restrict__ th, const tkey_t *__restrict__ keys,
                                                 const int *__restrict__ perm, const float *__restrict__ DG, int D,
@@ -137,16 +139,27 @@ __device__ __forceinline__ void table_sum_block(const TouchHeader *__restrict__ 
     if (k >= M) return;
     const tkey_t key = keys[k];
     if (key == TOUCH_INVALID || (k > 0 && keys[k - 1] == key)) return;
-    (void)perm;
-    f32x4 acc = gload4(DG + k * D + c);
+    f32x4 acc = gload4(DG + (perm ? (long long)perm[k] : k) * D + c);
     for (long long j0 = k + 1; j0 < M; j0 += TS_AHEAD) {
         tkey_t kk[TS_AHEAD];
         f32x4 v[TS_AHEAD];
+        if (perm) {
+            long long pj[TS_AHEAD];
 #pragma unroll
-        for (int q = 0; q < TS_AHEAD; ++q) {
-            const long long j = j0 + q < M ? j0 + q : M - 1;
-            kk[q] = keys[j];
-            v[q] = gload4(DG + j * D + c);
+            for (int q = 0; q < TS_AHEAD; ++q) {
+                const long long j = j0 + q < M ? j0 + q : M - 1;
+                kk[q] = keys[j];
+                pj[q] = perm[j];
+            }
+#pragma unroll
+            for (int q = 0; q < TS_AHEAD; ++q) v[q] = gload4(DG + pj[q] * D + c);
+        } else {
+#pragma unroll
+            for (int q = 0; q < TS_AHEAD; ++q) {
+                const long long j = j0 + q < M ? j0 + q : M - 1;
+                kk[q] = keys[j];
+                v[q] = gload4(DG + j * D + c);
+            }
         }
         bool more = true;
 #pragma unroll

@@ -23,7 +23,7 @@ from .data_utils import RGCNQueryDataset
 class PackedStep(object):
     __slots__ = ('batches', 'nb', 'anchor_ids', 'targets', 'negs', 'num_graphs', 'ws_bytes', 'sizes',
                  'desc', 'desc_bytes', 'desc_ptr', 'desc_resident', 'lanes', 'order', 'lane_begin', 'touch',
-                 'touch_ptr')
+                 'touch_ptr', 'touch_entries')
 
 
 def _batch_work(query_type, passes):
@@ -261,6 +261,7 @@ class FusedTrainStep(object):
         ps.desc_ptr = (ps.desc.data_ptr() + 255) // 256 * 256
         ps.desc_resident = False
         ps.touch, ps.touch_ptr = None, None
+        ps.touch_entries = int(ops.lib().mpqe_step_touch_entries(SB, nb))
         if self.touch:
             self.build_touch(ps)
         return ps

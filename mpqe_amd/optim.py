@@ -80,9 +80,10 @@ class FlatOptimizer(object):
             self._tab_m = arr(*[self.exp_avg.data_ptr() + esz * o for o, _ in self.table_slices])
             self._tab_v = arr(*[self.exp_avg_sq.data_ptr() + esz * o for o, _ in self.table_slices])
 
-    def step(self, packed=None):
+    def step(self, packed=None, rows_plan=None):
         """packed: with sparse_tables, the packed step whose gradients are being applied (its touch plan lists the
-        table rows to update)."""
+        table rows to update). rows_plan: under data parallelism the (plan pointer, entries) of the row exchange
+        (mpqe_amd.parallel.StepExchange): the rows ANY rank touched -- every replica updates the same rows."""
         self.t += 1
         g = self.fused.flat_grad
         with torch.cuda.device(self.fused.device):
@@ -96,7 +97,8 @@ class FlatOptimizer(object):
                     st = st or L.mpqe_adam_step(self.flat_param.data_ptr() + 4 * o, g.data_ptr() + 4 * o,
                                                 self.exp_avg.data_ptr() + 4 * o, self.exp_avg_sq.data_ptr() + 4 * o, n,
                                                 self.lr, self.betas[0], self.betas[1], self.eps, 0.0, self.t, stream)
-                st = st or L.mpqe_adam_rows_step(packed.touch_ptr, packed.batches, packed.nb, self._tab_p, self._tab_g,
+                plan_ptr, entries = rows_plan if rows_plan is not None else (packed.touch_ptr, packed.touch_entries)
+                st = st or L.mpqe_adam_rows_step(plan_ptr, entries, self._tab_p, self._tab_g,
                                                  self._tab_m, self._tab_v, len(self.table_slices),
                                                  self.fused.model.emb_dim, self.lr, self.betas[0], self.betas[1],
                                                  self.eps, self.t, stream)

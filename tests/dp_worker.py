@@ -1,0 +1,85 @@
+"""Child process of tests/test_parallel_gpu.py: one data-parallel rank (FusedTrainStep + StepExchange). Started before
+it touches the GPU; writes its reduced flat gradient (and, rank 0, the single-process gradient of all ranks' batches)
+to the directory given on the command line."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def batches_of(schema, rank, B, scale):
+    from mpqe_amd import synthetic
+    rng = np.random.RandomState(1000 + rank)
+    out = []
+    for qt in ('1-chain', '3-chain', '2-inter', '3-inter_chain', '3-chain_inter'):
+        f = synthetic.sample_formula(schema, qt, rng)
+        anchors = np.stack([synthetic._pick(schema, m, rng, size=B) for m in f.anchor_modes], axis=1)
+        out.append(dict(formula=f, anchor_ids=anchors, targets=synthetic._pick(schema, f.target_mode, rng, size=B),
+                        negs=synthetic._pick(schema, f.target_mode, rng, size=B), weight=scale * (1.0 if qt == '1-chain' else 0.1)))
+    return out
+
+
+def main():
+    outdir, sparse = sys.argv[1], sys.argv[2] == '1'
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from mpqe_amd import synthetic
+    from mpqe_amd.data_utils import make_feature_modules
+    from mpqe_amd.encoders import DirectEncoder
+    from mpqe_amd.fused import FusedTrainStep
+    from mpqe_amd.model import RGCNEncoderDecoder
+    from mpqe_amd.optim import FlatOptimizer
+    from mpqe_amd.parallel import StepExchange
+    torch.manual_seed(0)
+    D, B = 64, 40
+    schema = synthetic.make_schema(*synthetic.KG_SHAPES['tiny'], seed=3)
+    graph = synthetic.SchemaGraph(schema, D)
+    fm, node_maps = make_feature_modules(schema.ids, D, schema.num_entities)
+    model = RGCNEncoderDecoder(graph, DirectEncoder(None, fm, node_maps), readout='mp', num_layers=3, shared_layers=False,
+                               adaptive=True, weight_decay=0).to('cuda:0')
+    with torch.no_grad():
+        for p in model.layers.parameters():
+            p.mul_(4.0)
+    step = FusedTrainStep(model, sparse_tables=sparse)
+    packed = step.pack(batches_of(schema, rank, B, 1.0 / world))
+    ex = StepExchange(step)
+    plan = ex.plan(packed)
+    for p in model.parameters():
+        p.grad.fill_(3.0)
+    step.run(packed)
+    ex.reduce(plan)
+    step.check()
+    torch.cuda.synchronize()
+    out = dict(flat=step.flat_grad.cpu().numpy(), wire=np.array([plan.wire_bytes]), dense=np.array([step.flat_grad.numel() * 4]))
+    # which table rows hold the reduced gradient (sparse mode leaves the others alone)
+    base = plan.plan_ptr - plan.plan.data_ptr()
+    keys = plan.plan[base + 256: base + 256 + 8 * plan.entries].view(torch.int64)
+    out['union_keys'] = torch.unique(keys[keys != -1]).cpu().numpy()
+    out['row_bits'] = np.array([ex.row_bits])
+    if rank == 0:   # single process, all ranks' batches in one step (dense tables)
+        ref_step = FusedTrainStep(model)
+        allb = []
+        for r in range(world):
+            allb += batches_of(schema, r, B, 1.0 / world)
+        ref_step.run(ref_step.pack(allb))
+        torch.cuda.synchronize()
+        out['ref'] = ref_step.flat_grad.cpu().numpy()
+        out['table_floats'] = np.array([sum(t.numel() for t in ex.tables)])
+    if sparse:      # one optimiser step on the union rows: replicas must stay identical
+        step.bind_grads()           # (the reference step above re-bound p.grad to its own buffer)
+        opt = FlatOptimizer(step, lr=0.01, sparse_tables=True)
+        opt.step(packed, rows_plan=ex.rows_plan(plan))
+        torch.cuda.synchronize()
+        out['params'] = opt.flat_param.cpu().numpy()
+    np.savez(os.path.join(outdir, 'rank%d.npz' % rank), **out)
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

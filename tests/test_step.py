@@ -456,7 +456,7 @@ def test_adam_rows_step_equals_torch_sparse_adam(be):
     for step in range(1, 4):
         grads = [rng.randn(*t.shape).astype(np.float32) for t in tabs]
         d_g = [be.put(g) for g in grads]
-        be.check(be.lib.mpqe_adam_rows_step(tptr, SB, 2, arr(*[be.ptr(x) for x in d_p]), arr(*[be.ptr(x) for x in d_g]),
+        be.check(be.lib.mpqe_adam_rows_step(tptr, be.lib.mpqe_step_touch_entries(SB, 2), arr(*[be.ptr(x) for x in d_p]), arr(*[be.ptr(x) for x in d_g]),
                                             arr(*[be.ptr(x) for x in d_m]), arr(*[be.ptr(x) for x in d_v]), nmodes, D,
                                             0.05, 0.9, 0.99, 1e-6, step, be.stream), 'adam rows')
         for m in range(nmodes):
