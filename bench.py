@@ -45,6 +45,7 @@ def parse():
     ap.add_argument('--batch-size', type=int, default=512)
     ap.add_argument('--readout', default='mp')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-scatter', action='store_true', help='skip the roofline_scatter record (general-graph scatter-aggregate)')
     ap.add_argument('--no-self-check', action='store_true',
                     help='skip the pre-timing comparison with the module path (timing experiments with builds that are wrong on purpose)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -290,6 +291,60 @@ def time_layer_forward(model, data, reps=20):
             total_ms += e0.elapsed_time(e1)
             n += 1
     return total_ms / n * 1e-3, len(calls)
+
+
+def time_scatter_aggregate(D=256, reps=20):
+    """The scatter-aggregate of the general-graph path -- the destination-sorted segmented sum `segment_sum_kernel`
+    (mpqe_rgcn_general_aggregate: out[i] = relu(bias + msg[E + i] + sum of the message rows of the edges into i)) --
+    timed alone, in this run, with events on the stream it is launched on, on 3-inter query graphs given as a plain
+    edge list: at BASELINE.json configs[4]'s shape (B = 8192, D = 256: 92 MB of rows, which the 256 MB Infinity Cache
+    holds) and at B = 65536 (738 MB: beyond it, so that one is an HBM rate). Algorithmic bytes per launch
+    4 D (E + 2 Nn); peak 8 TB/s."""
+    import ctypes
+    from mpqe_amd import ops
+    dev = torch.device('cuda', torch.cuda.current_device())
+    lib = ops.lib()
+    src, dst, N = np.array([0, 1, 2]), np.array([3, 3, 3]), 4          # 3-inter template (reference data_utils.py:346-350)
+    recs = []
+    for B in (8192, 65536):
+        offs = (np.arange(B, dtype=np.int64) * N)[:, None]
+        ei = torch.from_numpy(np.stack([(src[None] + offs).reshape(-1), (dst[None] + offs).reshape(-1)])).to(dev)
+        E, Nn, R = int(ei.shape[1]), B * N, 128
+        et = torch.randint(0, R, (E,), device=dev, dtype=torch.long)
+        plan = ops.GraphPlan(ei, et, Nn, R)
+        msg = torch.randn(E + Nn, D, device=dev)
+        bias = torch.randn(D, device=dev)
+        out = torch.empty(Nn, D, device=dev)
+        stream = torch.cuda.current_stream()
+
+        def launch():
+            st = lib.mpqe_rgcn_general_aggregate(plan.buf.data_ptr(), Nn, E, R, msg.data_ptr(), bias.data_ptr(), D, 1,
+                                                 out.data_ptr(), stream.cuda_stream)
+            assert st == 0
+        for _ in range(3):
+            launch()
+        torch.cuda.synchronize()
+        evs = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            launch()
+            e1.record(stream)
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        us = float(np.median([a.elapsed_time(b) for a, b in evs])) * 1e3
+        nbytes = 4 * D * (E + 2 * Nn)
+        # spot check against torch on a slice (the kernel is parity-tested in tests/test_kernels.py)
+        ref = torch.relu(bias + msg[E:E + 8] + msg[:24].view(8, 3, D).sum(1))
+        assert torch.allclose(out[:8], ref, rtol=1e-5, atol=1e-5)
+        recs.append({'graphs': B, 'nodes': Nn, 'edges': E, 'dim': D, 'algorithmic_bytes_per_launch': nbytes,
+                     'avg_launch_us': us, 'achieved': nbytes / (us * 1e-6) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     'working_set_vs_infinity_cache': 'inside (a fabric rate)' if nbytes < 256e6 else 'beyond (an HBM rate)'})
+        del plan, msg, out, ei, et
+    return {'bound': 'hbm', 'kernel': 'segment_sum_kernel', 'shapes': recs, 'frac': recs[-1]['frac'],
+            'achieved': recs[-1]['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'note': 'top-level achieved / frac = the shape beyond the Infinity Cache'}
 
 
 def usable_cores():
@@ -550,6 +605,8 @@ def main():
                                'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
                                'avg_launch_us': dur * 1e6, 'algorithmic_flops_per_launch': per_launch_flops,
                                'launches_per_step': launches}
+        if world == 1 and not args.no_scatter:
+            out['roofline_scatter'] = time_scatter_aggregate()
         out['step_work'] = {'layer_flops_fwd_bwd': flops_all, 'scatter_aggregate_bytes_fwd_bwd': bytes_all,
                             'layer_tflops_over_whole_step': flops_all / (elapsed / args.steps) / 1e12}
         if use_fused:       # flops_all is SURVEY 8d's count (every node state); executed = after pruning

@@ -1,6 +1,6 @@
 // grad_bias[j] += sum_q gpre[q][j] in a fixed order: per-block partial column sums over `rpb` rows
 // (4 row groups x 64 columns per workgroup, combined as (0+1)+(2+3)), then one pass over the <= 256
-// partial rows with the same shape (no atomics -> reproducible).
+// partial rows (16 row groups x 64 columns, summed in order; no atomics -> reproducible).
 #pragma once
 #include "common.h"
 
@@ -36,17 +36,34 @@ static __global__ __launch_bounds__(256) void bias_partial_kernel(long long rows
         partial[(long long)blockIdx.x * Dout + col] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
 }
 
-static __global__ __launch_bounds__(256) void bias_final_kernel(int nblk, int Dout, const float *__restrict__ partial,
-                                                                float *__restrict__ grad_bias) {
-    __shared__ float part[4][64];
+// One workgroup of 1024 threads per 64 columns: 16 row groups each add every 16th partial row (eight requests in flight),
+// then the 16 sums are added in order -- a fixed order. (The first form walked the <= 256 partial rows with 4 row groups
+// and one dependent load per step: 118 us per call at the stress shape; this one takes one or two round trips.)
+static __global__ __launch_bounds__(1024) void bias_final_kernel(int nblk, int Dout, const float *__restrict__ partial,
+                                                                 float *__restrict__ grad_bias) {
+    __shared__ float part[16][64];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + cl;
     float s = 0.f;
     if (col < Dout)
-        for (int b = rg; b < nblk; b += 4) s += partial[(long long)b * Dout + col];
+        for (int b0 = rg; b0 < nblk; b0 += 16 * 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int b = b0 + 16 * q;
+                v[q] = partial[(long long)(b < nblk ? b : b0) * Dout + col];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (b0 + 16 * q < nblk) s += v[q];
+        }
     part[rg][cl] = s;
     __syncthreads();
-    if (rg == 0 && col < Dout) grad_bias[col] += (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+    if (rg == 0 && col < Dout) {
+        float t = part[0][cl];
+        for (int q = 1; q < 16; ++q) t += part[q][cl];
+        grad_bias[col] += t;
+    }
 }
 
 static inline size_t bias_partial_bytes(long long rows, long long Dout) {
@@ -58,6 +75,6 @@ static inline void launch_bias_grad(long long rows, const float *g, const float 
     const int rpb = bias_rows_per_block(rows), nblk = bias_num_blocks(rows);
     hipLaunchKernelGGL(bias_partial_kernel, dim3(nblk, (unsigned)((Dout + 63) / 64)), dim3(256), 0, s, rows, rpb, g,
                        out, Dout, relu, partial);
-    hipLaunchKernelGGL(bias_final_kernel, dim3((unsigned)((Dout + 63) / 64)), dim3(256), 0, s, nblk, Dout, partial,
+    hipLaunchKernelGGL(bias_final_kernel, dim3((unsigned)((Dout + 63) / 64)), dim3(1024), 0, s, nblk, Dout, partial,
                        grad_bias);
 }

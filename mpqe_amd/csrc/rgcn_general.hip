@@ -495,22 +495,50 @@ __global__ __launch_bounds__(256) void rgcn_gen_grad_w_kernel(
     }
 }
 
+// grad[r] += sum of the K-chunk slabs of relation r (r == R: the root matrix), fixed order. A workgroup owns 256
+// consecutive elements (4 per lane, 16-byte loads); its 4 waves each add every 4th slab with four requests in flight,
+// the four sums are combined as (0+1)+(2+3). (One thread per element walking all slabs with dependent loads took
+// 72.7 us at the stress shape: the root matrix has one slab per 256 nodes.)
 __global__ __launch_bounds__(256) void rgcn_gen_reduce_w_kernel(const int *__restrict__ chunk_ptr, int R, int Din,
                                                                 int Dout, const float *__restrict__ slabs,
                                                                 float *__restrict__ grad_basis,
                                                                 float *__restrict__ grad_root) {
+    __shared__ f32x4 part[4][64];
     const int r = blockIdx.y;
     const long long elems = (long long)Din * Dout;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= elems) return;
+    const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const long long idx = ((long long)blockIdx.x * 64 + el) * 4;
     const int c0 = chunk_ptr[r], c1 = chunk_ptr[r + 1];
-    if (c0 == c1) return;
+    if (c0 == c1) return;               // (uniform over the workgroup)
     float *dst = r < R ? grad_basis : grad_root;
     if (!dst) return;
-    float s = 0.f;
-    for (int c = c0; c < c1; ++c) s += slabs[(long long)c * elems + idx];
-    if (r < R) dst[(long long)r * elems + idx] += s;
-    else dst[idx] += s;
+    if (r < R) dst += (long long)r * elems;
+    const bool vec = (elems % 4 == 0) && (((uintptr_t)slabs | (uintptr_t)dst) % 16 == 0);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const int count = c1 - c0;
+    if (idx < elems) {
+        const float *p = slabs + (long long)c0 * elems + idx;
+        if (vec) {
+            for (int i = sg; i < count; i += 16) {
+                f32x4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = gload4(p + (long long)(i + 4 * q < count ? i + 4 * q : i) * elems);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (i + 4 * q < count) s += v[q];
+            }
+        } else {
+            for (int i = sg; i < count; i += 4)
+                for (int k = 0; k < 4; ++k)
+                    if (idx + k < elems) s[k] += p[(long long)i * elems + k];
+        }
+    }
+    part[sg][el] = s;
+    __syncthreads();
+    if (sg != 0 || idx >= elems) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (idx + k < elems) dst[idx + k] += (part[0][el][k] + part[1][el][k]) + (part[2][el][k] + part[3][el][k]);
 }
 
 // ------------------------------------------------------------------------------------ host side
@@ -550,6 +578,23 @@ extern "C" int mpqe_rgcn_general_fwd(const void *plan, int64_t Nn, int64_t E, in
     const long long threads = Nn * (vec ? Dout / 4 : Dout);
     hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, P.dst_ptr,
                        P.dst_list, (long long)Nn, (long long)E, (int)Dout, (const float *)msg, bias, relu, out, vec);
+    return mpqe_launch_status();
+}
+
+// The scatter-aggregate step of the forward alone: out[i] = act(bias + msg[E + i] + sum of msg[e] over the edges INTO i
+// in edge order), msg = [E + Nn, dim] message rows laid out as mpqe_rgcn_general_fwd's gather-GEMM leaves them. For the
+// roofline measurement of bench.py (4 dim (E + 2 Nn) algorithmic bytes per launch) and for callers that form their
+// messages elsewhere.
+extern "C" int mpqe_rgcn_general_aggregate(const void *plan, int64_t Nn, int64_t E, int64_t R, const float *msg,
+                                           const float *bias, int64_t dim, int relu, float *out, void *stream) {
+    if (!plan || Nn < 0 || E < 0 || R < 0 || dim <= 0) return MPQE_ERR_INVALID_ARG;
+    if (Nn == 0) return MPQE_OK;
+    if (!msg || !out) return MPQE_ERR_INVALID_ARG;
+    PlanView P = plan_view(plan, Nn, E, R);
+    const int vec = dim % 4 == 0 && ptr_vec_ok(out, dim) && ptr_vec_ok(msg, dim) && (!bias || (uintptr_t)bias % 16 == 0);
+    const long long threads = Nn * (vec ? dim / 4 : dim);
+    hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), P.dst_ptr,
+                       P.dst_list, (long long)Nn, (long long)E, (int)dim, msg, bias, relu, out, vec);
     return mpqe_launch_status();
 }
 
