@@ -334,9 +334,13 @@ def time_scatter_aggregate(D=256, reps=20):
         torch.cuda.synchronize()
         us = float(np.median([a.elapsed_time(b) for a, b in evs])) * 1e3
         nbytes = 4 * D * (E + 2 * Nn)
-        # spot check against torch on a slice (the kernel is parity-tested in tests/test_kernels.py)
-        ref = torch.relu(bias + msg[E:E + 8] + msg[:24].view(8, 3, D).sum(1))
-        assert torch.allclose(out[:8], ref, rtol=1e-5, atol=1e-5)
+        # sanity (the kernel is parity-tested in tests/test_kernels.py): every message row is added exactly once --
+        # without the ReLU, the column sums of the output are the column sums of all message rows + Nn x bias
+        st = lib.mpqe_rgcn_general_aggregate(plan.buf.data_ptr(), Nn, E, R, msg.data_ptr(), bias.data_ptr(), D, 0,
+                                             out.data_ptr(), stream.cuda_stream)
+        assert st == 0
+        got, want = out.double().sum(0), msg.double().sum(0) + Nn * bias.double()
+        assert torch.allclose(got, want, rtol=1e-6, atol=1e-2), float((got - want).abs().max())
         recs.append({'graphs': B, 'nodes': Nn, 'edges': E, 'dim': D, 'algorithmic_bytes_per_launch': nbytes,
                      'avg_launch_us': us, 'achieved': nbytes / (us * 1e-6) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,

@@ -155,8 +155,9 @@ int mpqe_rgcn_general_fwd(const void *plan, int64_t num_nodes, int64_t num_edges
                           int64_t dim_in, int64_t dim_out, int relu, float *out,
                           void *workspace, size_t workspace_bytes, void *stream);
 /* The scatter-aggregate of the forward alone (the destination-sorted segmented sum): out[i] = act(bias + msg[E + i] +
- * sum of msg[e] over the edges into i, in edge order); msg [E + Nn, dim] as the gather-GEMM of mpqe_rgcn_general_fwd
- * leaves its messages (edge e at row e, self term of node i at row E + i). Algorithmic bytes: 4 dim (E + 2 Nn).  */
+ * sum over the edges into i, in edge order, of their message rows); msg [E + Nn, dim] in the plan's slot order, as the
+ * gather-GEMM of mpqe_rgcn_general_fwd leaves its messages (an edge's row = its position in the relation-sorted order,
+ * the self term of node i at row E + i). Algorithmic bytes: 4 dim (E + 2 Nn).                                    */
 int mpqe_rgcn_general_aggregate(const void *plan, int64_t num_nodes, int64_t num_edges, int64_t num_relations,
                                 const float *msg, const float *bias, int64_t dim, int relu, float *out, void *stream);
 int mpqe_rgcn_general_bwd(const void *plan, int64_t num_nodes, int64_t num_edges, int64_t num_relations,
