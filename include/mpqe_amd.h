@@ -190,6 +190,17 @@ int mpqe_scatter_bwd(int op, const float *grad_out, const int64_t *index, const 
                      int64_t n_src, int64_t dim, int64_t dim_size, float *grad_src,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- (a9) LayerNorm + ReLU of the GraphSAGE-style Encoder ---------------------------------------
+ * reference encoders.py:132-146 (unbiased std, eps added to the std) + the Encoder's ReLU (encoders.py:127-128):
+ *   y = act(gamma * (x - mean) / (std + eps) + beta), per row of x [rows, dim]; stats [rows, 2] = {mean, 1/(std+eps)}.
+ * bwd: grad_x overwritten; grad_gamma / grad_beta ACCUMULATED (fixed-order column sums).                */
+int mpqe_layernorm_relu_fwd(const float *x, int64_t rows, int64_t dim, const float *gamma, const float *beta, float eps,
+                            int relu, float *y, float *stats, void *stream);
+size_t mpqe_layernorm_relu_bwd_workspace_bytes(int64_t rows, int64_t dim);
+int mpqe_layernorm_relu_bwd(const float *grad_y, const float *x, const float *y, int64_t rows, int64_t dim,
+                            const float *gamma, const float *stats, float eps, int relu, float *grad_x,
+                            float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- (a6, a7) scoring and loss ------------------------------------------------------------
  * reference: F.cosine_similarity(q, t, dim=1) model.py:452, 458 (eps 1e-8 clamps each norm):
  *   scores[i] = q[qrow(i)] . t[i] / (max(||q||, eps) * max(||t||, eps))

@@ -83,6 +83,9 @@ PROTOTYPES = {
     'mpqe_scatter_workspace_bytes': (Z, [L, L]),
     'mpqe_scatter_fwd': (I, [I, P, P, L, L, L, P, P, P, Z, P, P]),
     'mpqe_scatter_bwd': (I, [I, P, P, P, L, L, L, P, P, Z, P]),
+    'mpqe_layernorm_relu_fwd': (I, [P, L, L, P, P, F, I, P, P, P]),
+    'mpqe_layernorm_relu_bwd_workspace_bytes': (Z, [L, L]),
+    'mpqe_layernorm_relu_bwd': (I, [P, P, P, L, L, P, P, F, I, P, P, P, P, Z, P]),
     'mpqe_cosine_fwd': (I, [P, P, P, L, L, F, P, P]),
     'mpqe_cosine_bwd': (I, [P, P, P, P, L, L, F, P, P, P]),
     'mpqe_hinge_fwd': (I, [P, P, L, F, P, P]),

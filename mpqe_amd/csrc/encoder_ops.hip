@@ -2,6 +2,7 @@
 // L2 normalise, variable rows, readouts, torch_scatter-style reductions, cosine
 // score and hinge loss -- forward and backward. One wave (64 lanes) owns one
 // embedding row; rows are read as 16-byte vectors when dim % 4 == 0.
+#include "bias_grad.h"
 #include "common.h"
 
 #define ROWS_PER_BLOCK 4   // 256 threads = 4 waves = 4 rows
@@ -555,6 +556,112 @@ extern "C" int mpqe_hinge_bwd(const float *pos, const float *neg, int64_t n, flo
     if (n <= 0 || !pos || !neg || !grad_loss) return MPQE_ERR_INVALID_ARG;
     hipLaunchKernelGGL(hinge_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), pos, neg,
                        (long long)n, margin, grad_loss, grad_pos, grad_neg);
+    return mpqe_launch_status();
+}
+
+// ------------------------------------------------------------------------------------ (a9) LayerNorm + ReLU
+// reference encoders.py:132-146 (LayerNorm of the GraphSAGE-style Encoder: UNBIASED standard deviation, eps added to the
+// standard deviation, not the variance) followed by the Encoder's ReLU (encoders.py:127-128), one wave per row:
+//   y = act(gamma * (x - mean) / (std + eps) + beta),  std = sqrt(sum (x - mean)^2 / (D - 1))
+// stats[row] = {mean, 1 / (std + eps)} for the backward.
+__global__ __launch_bounds__(256) void layernorm_relu_fwd_kernel(const float *__restrict__ x, long long rows, int D,
+                                                                 const float *__restrict__ gamma,
+                                                                 const float *__restrict__ beta, float eps, int relu,
+                                                                 float *__restrict__ y, float *__restrict__ stats) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float *xr = x + r * D;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float d = xr[c] - mean;
+        q += d * d;
+    }
+    const float sd = sqrtf(wave_sum(q) / (float)(D - 1));
+    const float inv = 1.f / (sd + eps);
+    for (int c = lane; c < D; c += 64) {
+        float v = gamma[c] * ((xr[c] - mean) * inv) + beta[c];
+        if (relu) v = v > 0.f ? v : 0.f;
+        y[r * D + c] = v;
+    }
+    if (lane == 0) {
+        stats[2 * r] = mean;
+        stats[2 * r + 1] = inv;
+    }
+}
+
+// grad_x, and per row the two summands of the parameter gradients (gg = g * xhat for gamma, gb = g for beta, g = grad_y
+// masked by the ReLU): their column sums over the rows are formed afterwards in a fixed order (bias_grad.h).
+__global__ __launch_bounds__(256) void layernorm_relu_bwd_kernel(const float *__restrict__ gy, const float *__restrict__ x,
+                                                                 const float *__restrict__ y, long long rows, int D,
+                                                                 const float *__restrict__ gamma,
+                                                                 const float *__restrict__ stats, float eps, int relu,
+                                                                 float *__restrict__ gx, float *__restrict__ gg,
+                                                                 float *__restrict__ gb) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float mean = stats[2 * r], inv = stats[2 * r + 1];
+    const float sd = 1.f / inv - eps;
+    float sum_d = 0.f, sum_dx = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        float g = gy[r * D + c];
+        if (relu && !(y[r * D + c] > 0.f)) g = 0.f;
+        const float xc = x[r * D + c] - mean;
+        const float d = g * gamma[c];           // d loss / d xhat
+        gg[r * D + c] = g * (xc * inv);
+        gb[r * D + c] = g;
+        sum_d += d;
+        sum_dx += d * xc;
+    }
+    sum_d = wave_sum(sum_d);
+    sum_dx = wave_sum(sum_dx);
+    // xhat_i = (x_i - mean) / s, s = std + eps:  d xhat_i / d x_j = (delta_ij - 1/D) / s - (x_i - mean)(x_j - mean) / ((D-1) std s^2)
+    const float k = sd > 0.f ? sum_dx * inv * inv / ((float)(D - 1) * sd) : 0.f;
+    for (int c = lane; c < D; c += 64) {
+        float g = gy[r * D + c];
+        if (relu && !(y[r * D + c] > 0.f)) g = 0.f;
+        const float xc = x[r * D + c] - mean;
+        gx[r * D + c] = (g * gamma[c] - sum_d / (float)D) * inv - xc * k;
+    }
+}
+
+extern "C" int mpqe_layernorm_relu_fwd(const float *x, int64_t rows, int64_t dim, const float *gamma, const float *beta,
+                                       float eps, int relu, float *y, float *stats, void *stream) {
+    if (rows < 0 || dim < 2 || !gamma || !beta) return MPQE_ERR_INVALID_ARG;
+    if (rows == 0) return MPQE_OK;
+    if (!x || !y || !stats) return MPQE_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(layernorm_relu_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), x,
+                       (long long)rows, (int)dim, gamma, beta, eps, relu, y, stats);
+    return mpqe_launch_status();
+}
+
+extern "C" size_t mpqe_layernorm_relu_bwd_workspace_bytes(int64_t rows, int64_t dim) {
+    if (rows <= 0 || dim <= 0) return 0;
+    return 2 * align_up((size_t)rows * (size_t)dim * 4, 256) + bias_partial_bytes(rows, dim) + 256;
+}
+
+extern "C" int mpqe_layernorm_relu_bwd(const float *grad_y, const float *x, const float *y, int64_t rows, int64_t dim,
+                                       const float *gamma, const float *stats, float eps, int relu, float *grad_x,
+                                       float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes,
+                                       void *stream) {
+    if (rows < 0 || dim < 2 || !gamma) return MPQE_ERR_INVALID_ARG;
+    if (rows == 0) return MPQE_OK;
+    if (!grad_y || !x || !y || !stats || !grad_x || !grad_gamma || !grad_beta || !workspace) return MPQE_ERR_INVALID_ARG;
+    if (workspace_bytes < mpqe_layernorm_relu_bwd_workspace_bytes(rows, dim)) return MPQE_ERR_WORKSPACE;
+    char *wb = reinterpret_cast<char *>(workspace);
+    const size_t plane = align_up((size_t)rows * (size_t)dim * 4, 256);
+    float *gg = reinterpret_cast<float *>(wb), *gb = reinterpret_cast<float *>(wb + plane);
+    float *part = reinterpret_cast<float *>(wb + 2 * plane);
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(layernorm_relu_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, grad_y, x, y,
+                       (long long)rows, (int)dim, gamma, stats, eps, relu, grad_x, gg, gb);
+    // grad_gamma / grad_beta += column sums, fixed order (the caller zero-fills them: torch accumulates gradients)
+    launch_bias_grad((long long)rows, gg, (const float *)nullptr, (int)dim, 0, part, grad_gamma, s);
+    launch_bias_grad((long long)rows, gb, (const float *)nullptr, (int)dim, 0, part, grad_beta, s);
     return mpqe_launch_status();
 }
 

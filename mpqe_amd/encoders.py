@@ -65,72 +65,82 @@ class DirectEncoder(nn.Module):
 
 
 class LayerNorm(nn.Module):
-    """reference: encoders.py:132-146 (unbiased std, eps added to the std, not the variance)."""
+    """The Encoder's normalisation (reference encoders.py:132-146): per row, UNBIASED standard deviation, eps added to
+    the standard deviation. Parameters `gamma` / `beta` as in the reference (state_dict keys `<mode>_ln.gamma|beta`).
+    One HIP kernel (mpqe_layernorm_relu_fwd / bwd); `relu=True` folds the Encoder's activation into it."""
 
     def __init__(self, feature_dim, eps=1e-6):
         super(LayerNorm, self).__init__()
-        self.gamma = nn.Parameter(torch.ones((feature_dim,)))
-        self.beta = nn.Parameter(torch.zeros((feature_dim,)))
+        self.gamma = nn.Parameter(torch.ones(feature_dim))
+        self.beta = nn.Parameter(torch.zeros(feature_dim))
         self.eps = eps
 
-    def forward(self, x):
-        mean = x.mean(-1, keepdim=True)
-        std = x.std(-1, keepdim=True)
-        return self.gamma * (x - mean) / (std + self.eps) + self.beta
+    def forward(self, x, relu=False):
+        lead = x.shape[:-1]
+        y = ops.layernorm_relu(x.reshape(-1, x.shape[-1]), self.gamma, self.beta, self.eps, relu)
+        return y.reshape(*lead, x.shape[-1])
 
 
 class Encoder(nn.Module):
-    """GraphSAGE-style entity encoder inherited from GQE (reference encoders.py:47-129, `--depth >= 1`):
-    per relation the sampled-neighbour mean (aggregator), concatenated with the node's own feature,
-    compressed by a per-mode matrix, optional LayerNorm, ReLU. Returns [out_dim, B] like the
-    reference. The neighbour mean runs in the scatter kernel; the compress GEMM is a plain library GEMM.
+    """GraphSAGE-style entity encoder the reference inherits from GQE (encoders.py:47-129, `--depth >= 1`; SURVEY.md 8 a9,
+    secondary row: unreachable from the R-GCN model in the reference itself). For a node of mode m:
 
-    Note: the reference's RGCNEncoderDecoder passes a tensor column as `nodes`,
-    which its own Encoder cannot use as dict keys; like the reference this class expects a python list
-    of entity ids (the GQE call protocol)."""
+        out = ReLU([LayerNorm](compress_m . [mean_r1 | ... | mean_rk | self]))        -> [out_dim, B]
+
+    with mean_r = mean feature of the neighbours SAMPLED for relation r (python `random`, the reference's draws in the
+    reference's order: aggregators.py). Constructor arguments, attribute names and state_dict keys (`<mode>_compress`,
+    `<mode>_ln.gamma|beta`, `feat-<name>.*`) are the reference's; the data path is this package's:
+      * ONE flat list of sampled neighbours per relation goes through the features closure and the scatter kernel
+        (mean mode) -- no dense [B, U] mask matrix, no per-node python set arithmetic on the device side;
+      * the concatenation is never materialised: compress_m is applied block by block (one library GEMM per relation
+        block and one for the self block, accumulated), which is the same sum;
+      * LayerNorm and the ReLU are one kernel (mpqe_layernorm_relu_fwd).
+    `nodes` is a python list of entity ids (the GQE call protocol; see SURVEY.md section 2 #5)."""
 
     def __init__(self, features, feature_dims, out_dims, relations, adj_lists, aggregator, base_model=None,
                  cuda=False, layer_norm=False, feature_modules={}):
         super(Encoder, self).__init__()
-        self.features = features
-        self.feat_dims = feature_dims
-        self.adj_lists = adj_lists
-        self.relations = relations
-        self.aggregator = aggregator
-        for name, module in feature_modules.items():
-            self.add_module('feat-' + name, module)
+        self.features, self.feat_dims, self.out_dims = features, feature_dims, out_dims
+        self.relations, self.adj_lists, self.aggregator = relations, adj_lists, aggregator
+        self.cuda, self.layer_norm = cuda, layer_norm
+        self.aggregator.cuda = cuda
         if base_model is not None:
             self.base_model = base_model
-        self.out_dims = out_dims
-        self.cuda = cuda
-        self.aggregator.cuda = cuda
-        self.layer_norm = layer_norm
-        self.compress_dims = {}
-        for source_mode in relations:
-            self.compress_dims[source_mode] = self.feat_dims[source_mode]
-            for (to_mode, _) in relations[source_mode]:
-                self.compress_dims[source_mode] += self.feat_dims[to_mode]
-        self.compress_params = {}
-        self.lns = {}
-        for mode in self.feat_dims:
-            if self.layer_norm:
+        for name, module in feature_modules.items():
+            self.add_module('feat-' + name, module)
+        # per mode: the column blocks of its compress matrix -- one per outgoing relation (width = feature dim of the
+        # relation's target mode), then the node's own features
+        self.blocks, self.compress_dims, self.compress_params, self.lns = {}, {}, {}, {}
+        for mode in relations:
+            widths = [feature_dims[to_mode] for (to_mode, _) in relations[mode]] + [feature_dims[mode]]
+            self.blocks[mode] = [(sum(widths[:k]), w) for k, w in enumerate(widths)]
+            self.compress_dims[mode] = sum(widths)
+        for mode in feature_dims:
+            if layer_norm:
                 self.lns[mode] = LayerNorm(out_dims[mode])
                 self.add_module(mode + '_ln', self.lns[mode])
-            self.compress_params[mode] = nn.Parameter(torch.FloatTensor(out_dims[mode], self.compress_dims[mode]))
-            nn.init.xavier_uniform_(self.compress_params[mode])
-            self.register_parameter(mode + '_compress', self.compress_params[mode])
+            w = nn.Parameter(torch.empty(out_dims[mode], self.compress_dims[mode]))
+            nn.init.xavier_uniform_(w)
+            self.compress_params[mode] = w
+            self.register_parameter(mode + '_compress', w)
 
     def forward(self, nodes, mode, keep_prob=0.5, max_keep=10):
-        self_feat = self.features(nodes, mode).t()
-        neigh_feats = []
-        for to_r in self.relations[mode]:
-            rel = (mode, to_r[1], to_r[0])
-            to_neighs = [[-1] if node == -1 else self.adj_lists[rel][node] for node in nodes]
-            to_neighs = [[-1] if len(l) == 0 else l for l in to_neighs]     # null neighbour, as the reference
-            neigh_feats.append(self.aggregator.forward(to_neighs, rel, keep_prob, max_keep).t())
-        neigh_feats.append(self_feat)
-        combined = torch.cat(neigh_feats, dim=0)
-        combined = self.compress_params[mode].mm(combined)
+        W = self.compress_params[mode]
+        blocks = self.blocks[mode]
+        out = None
+        for (to_mode, name), (off, width) in zip(self.relations[mode], blocks[:-1]):
+            rel = (mode, name, to_mode)
+            adj = self.adj_lists[rel]
+            # the null neighbour -1 stands in for a padding node and for a node without edges of this relation
+            neigh = [[-1] if (n == -1 or len(adj[n]) == 0) else adj[n] for n in nodes]
+            mean = self.aggregator.forward(neigh, rel, keep_prob, max_keep)                 # [B, width]
+            part = mean @ W[:, off:off + width].t()
+            out = part if out is None else out + part
+        off, width = blocks[-1]
+        part = self.features(nodes, mode) @ W[:, off:off + width].t()
+        out = part if out is None else out + part
         if self.layer_norm:
-            combined = self.lns[mode](combined.t()).t()
-        return F.relu(combined)
+            out = self.lns[mode](out, relu=True)
+        else:
+            out = F.relu(out)
+        return out.t()

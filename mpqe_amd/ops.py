@@ -393,6 +393,46 @@ def scatter_max(src, index, dim=0, out=None, dim_size=None, fill_value=None):
     return _scatter('max', src, index, dim, dim_size)
 
 
+# --------------------------------------------------------------------------------------------- (a9) LayerNorm + ReLU
+class _LayerNormReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu):
+        x, gamma, beta = _f(x, 'x'), _f(gamma, 'gamma'), _f(beta, 'beta')
+        rows, D = x.shape
+        if gamma.shape != (D,) or beta.shape != (D,):
+            raise ValueError('layer norm: gamma / beta must be [%d]' % D)
+        y = torch.empty_like(x)
+        stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _ck(lib().mpqe_layernorm_relu_fwd(_p(x), rows, D, _p(gamma), _p(beta), eps, int(relu), _p(y), _p(stats), _stream()),
+                'mpqe_layernorm_relu_fwd')
+        ctx.eps, ctx.relu = eps, bool(relu)
+        ctx.save_for_backward(x, y, gamma, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, gamma, stats = ctx.saved_tensors
+        gy = _f(gy, 'grad_out')
+        rows, D = x.shape
+        gx = torch.empty_like(x)
+        gg = torch.zeros(D, dtype=torch.float32, device=x.device)
+        gb = torch.zeros(D, dtype=torch.float32, device=x.device)
+        L = lib()
+        with torch.cuda.device(x.device):
+            wb = L.mpqe_layernorm_relu_bwd_workspace_bytes(rows, D)
+            ws = _ws(wb, x.device)
+            _ck(L.mpqe_layernorm_relu_bwd(_p(gy), _p(x), _p(y), rows, D, _p(gamma), _p(stats), ctx.eps, int(ctx.relu), _p(gx),
+                                          _p(gg), _p(gb), _p(ws), wb, _stream()), 'mpqe_layernorm_relu_bwd')
+        return gx, gg, gb, None, None
+
+
+def layernorm_relu(x, gamma, beta, eps=1e-6, relu=True):
+    """(a9) act(gamma * (x - mean) / (std + eps) + beta) per row, std UNBIASED (reference encoders.py:143-146), one kernel
+    with the Encoder's ReLU (encoders.py:127-128)."""
+    return _LayerNormReLU.apply(x, gamma, beta, float(eps), bool(relu))
+
+
 # --------------------------------------------------------------------------------------------- score / loss
 class _Cosine(torch.autograd.Function):
     @staticmethod

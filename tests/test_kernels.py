@@ -511,3 +511,34 @@ def test_sample_negatives_is_uniform(be):
                                           be.stream), 'sample')
     counts = np.bincount(be.get(out), minlength=10)
     assert counts.min() > 1800 and counts.max() < 2200
+
+
+# ------------------------------------------------------------------------------------------ (a9) LayerNorm + ReLU
+@pytest.mark.parametrize('rows,D,relu', [(37, 16, True), (5, 48, False), (300, 128, True), (1, 2, True)])
+def test_layernorm_relu_matches_reference_formula(be, rows, D, relu):
+    """mpqe_layernorm_relu_fwd / bwd against the reference's LayerNorm formula (encoders.py:143-146: unbiased std, eps
+    added to the std) followed by the Encoder's ReLU, evaluated by torch autograd."""
+    rng = np.random.RandomState(rows + D)
+    x = rng.randn(rows, D).astype(np.float32) * 2 + 0.3
+    gamma, beta = (rng.rand(D).astype(np.float32) + 0.5), rng.randn(D).astype(np.float32) * 0.3
+    gy = rng.randn(rows, D).astype(np.float32)
+    eps = 1e-6
+    xt, gt, bt = [torch.from_numpy(a.copy()).requires_grad_(True) for a in (x, gamma, beta)]
+    ref = gt * (xt - xt.mean(-1, keepdim=True)) / (xt.std(-1, keepdim=True) + eps) + bt
+    if relu:
+        ref = torch.relu(ref)
+    ref.backward(torch.from_numpy(gy))
+    dx, dg, db, dgy = be.put(x), be.put(gamma), be.put(beta), be.put(gy)
+    y, stats = be.empty((rows, D)), be.empty((rows, 2))
+    be.check(be.lib.mpqe_layernorm_relu_fwd(be.ptr(dx), rows, D, be.ptr(dg), be.ptr(db), eps, int(relu), be.ptr(y),
+                                            be.ptr(stats), be.stream), 'ln fwd')
+    close(be.get(y), ref.detach().numpy(), what='y')
+    gx, gg, gb = be.empty((rows, D)), be.zeros((D,)), be.zeros((D,))
+    wb = be.lib.mpqe_layernorm_relu_bwd_workspace_bytes(rows, D)
+    ws = be.nbytes(wb + 256)
+    be.check(be.lib.mpqe_layernorm_relu_bwd(be.ptr(dgy), be.ptr(dx), be.ptr(y), rows, D, be.ptr(dg), be.ptr(stats), eps,
+                                            int(relu), be.ptr(gx), be.ptr(gg), be.ptr(gb), (be.ptr(ws) + 255) // 256 * 256,
+                                            wb, be.stream), 'ln bwd')
+    close(be.get(gx), xt.grad.numpy(), rtol=1e-4, what='grad_x')
+    close(be.get(gg), gt.grad.numpy(), rtol=1e-4, what='grad_gamma')
+    close(be.get(gb), bt.grad.numpy(), rtol=1e-4, what='grad_beta')
