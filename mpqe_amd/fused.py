@@ -26,6 +26,15 @@ class PackedStep(object):
                  'touch_ptr', 'touch_entries')
 
 
+_INFO = {}
+
+
+def _template_info(query_type):
+    if query_type not in _INFO:
+        _INFO[query_type] = ops.template_info(query_type)
+    return _INFO[query_type]
+
+
 def _batch_work(query_type, passes):
     """Relative MFMA work of one batch per graph: passes * (edges + nodes) K-blocks."""
     e_n = {'1-chain': 3, '2-chain': 5, '3-chain': 7, '2-inter': 5, '3-inter': 7, '3-inter_chain': 7,
@@ -209,7 +218,7 @@ class FusedTrainStep(object):
         anchors, tg, ng, sizes = [], [], [], []
         for i, b in enumerate(batches):
             f = b['formula']
-            info = ops.template_info(f.query_type)
+            info = _template_info(f.query_type)
             a = torch.as_tensor(b['anchor_ids'], dtype=torch.long)
             B = a.shape[0]
             if a.shape[1] != info.num_anchors:
@@ -248,9 +257,15 @@ class FusedTrainStep(object):
                 L.aux_stream[l] = self._streams[l].cuda_stream
                 L.join_event[l] = self._joins[l].cuda_event
             ps.lanes = ctypes.pointer(L)
-        ps.anchor_ids = torch.cat(anchors).to(self.device)
-        ps.targets = torch.cat(tg).to(self.device)
-        ps.negs = torch.cat(ng).to(self.device)
+        # all ids of the step in ONE pinned staging buffer and ONE host-to-device copy: [anchors | targets | negatives]
+        na, ngr = sum(a.numel() for a in anchors), sum(sizes)
+        stage = self._staging(na + 2 * ngr)
+        torch.cat(anchors, out=stage[:na])
+        torch.cat(tg, out=stage[na:na + ngr])
+        torch.cat(ng, out=stage[na + ngr:])
+        ids = stage.to(self.device, non_blocking=True)
+        self._stage_events[self._stage_next].record()          # the buffer is free again once this copy has run
+        ps.anchor_ids, ps.targets, ps.negs = ids[:na], ids[na:na + ngr], ids[na + ngr:]
         ps.num_graphs = int(sum(sizes))
         ps.ws_bytes = ops.lib().mpqe_step_workspace_bytes(ctypes.byref(self.P), SB, nb, ps.lanes)
         if ps.ws_bytes == 0:
@@ -287,6 +302,20 @@ class FusedTrainStep(object):
                                          torch.cuda.current_stream().cuda_stream)
         _capi.check(L, st, 'mpqe_step_touch_build')
         ws.record_stream(torch.cuda.current_stream())
+
+    def _staging(self, n):
+        """A pinned host buffer of >= n int64 from a small ring (allocating pinned memory costs more than the rest of
+        pack()); a buffer is handed out again only after the copy that read it last has completed."""
+        if not hasattr(self, '_stage_ring'):
+            self._stage_ring, self._stage_events, self._stage_next = [None] * 4, [None] * 4, -1
+        k = self._stage_next = (self._stage_next + 1) % 4
+        if self._stage_events[k] is not None:
+            self._stage_events[k].synchronize()
+        else:
+            self._stage_events[k] = torch.cuda.Event()
+        if self._stage_ring[k] is None or self._stage_ring[k].numel() < n:
+            self._stage_ring[k] = torch.empty(max(n, 1 << 15), dtype=torch.long, pin_memory=True)
+        return self._stage_ring[k][:n]
 
     def uses_chain(self, packed):
         """True when the library runs the graph-block chain kernels for this step (csrc/step.hip)."""
