@@ -221,6 +221,8 @@ def test_fused_step_matches_oracle(be, readout, adaptive, shared, L, mix):
 
 @pytest.mark.parametrize('readout,adaptive,L', [('mp', True, 3), ('mp', False, 2), ('max', False, 3)])
 def test_fused_step_pruning_changes_nothing(be, readout, adaptive, L):
+    if be.name == 'emu' and readout == 'max':
+        pytest.skip('max readout keeps every state (pruning is a no-op): GPU only, for the CPU suite\'s time budget')
     """Node states that cannot reach the readout are skipped by default (MPQE_STEP_NO_PRUNE computes them
     all, as the reference does): same scores bit for bit, same gradients (the skipped terms are exact
     zeros; only the weight-gradient chunking differs)."""
@@ -258,17 +260,21 @@ def test_fused_step_chain_kernels(be, D, readout, adaptive, shared, L):
     runs = [got, lev]
     # every node state as per-graph rows (the default treats states no anchor has reached yet as one vector per batch)
     runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_NO_UNIFORM))
-    # entity-table gradients by fp32 atomics instead of the per-row sums of the touch plan
-    runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, touch=False))
-    again = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0)
-    for k in got[3]:          # with the touch plan EVERY gradient is bit-reproducible, the entity tables included
-        np.testing.assert_array_equal(again[3][k], got[3][k], err_msg=k)
+    # (the host emulator runs the further variants at D = 64 only: the CPU suite's time budget; the GPU runs them all)
+    every = be.name == 'hip' or D == 64
+    if every:
+        # entity-table gradients by fp32 atomics instead of the per-row sums of the touch plan
+        runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, touch=False))
+        again = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0)
+        for k in got[3]:          # with the touch plan EVERY gradient is bit-reproducible, the entity tables included
+            np.testing.assert_array_equal(again[3][k], got[3][k], err_msg=k)
     if D == 64:
         runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_NO_PRUNE))
     if D == 128:      # the form whose waves own 32 columns and all of K (the default splits K between wave pairs)
         runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_NO_KSPLIT))
         # eight waves per workgroup (the row-major phases stay with the first four)
-        runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_EIGHT_WAVES))
+        if be.name == 'hip' or readout == 'mp':
+            runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_EIGHT_WAVES))
     for r in runs:
         assert r[4] == 0
         np.testing.assert_allclose(r[1], ref_sp, rtol=1e-5, atol=1e-6)
