@@ -59,6 +59,9 @@ def parse():
                     help='chain form: node states no anchor has reached yet as per-graph rows instead of one vector per batch')
     ap.add_argument('--no-ksplit', action='store_true', help='dim 128: chain waves own 32 columns and all of K')
     ap.add_argument('--eight-waves', action='store_true', help='dim 128: chain workgroups of eight waves (experimental)')
+    ap.add_argument('--sparse-tables', action='store_true',
+                    help='row-sparse entity-table gradients (MPQE_STEP_SPARSE_TABLES): only the rows a step touches are '
+                         'written, no zero fill of the tables (for row-sparse consumers: mpqe_adam_rows_step, the row exchange)')
     ap.add_argument('--dense-allreduce', action='store_true',
                     help='N > 1: all-reduce the whole flat gradient buffer (what a literal port would do) instead of the '
                          'touched-matrix bucket + row exchange')
@@ -467,7 +470,8 @@ def main():
     if use_fused:
         from mpqe_amd.fused import FusedTrainStep
         fstep = FusedTrainStep(model, lanes=args.lanes, prune=not args.no_prune, chain=not args.no_chain,
-                               ksplit=not args.no_ksplit, eight_waves=args.eight_waves, uniform=not args.no_uniform)
+                               ksplit=not args.no_ksplit, eight_waves=args.eight_waves, uniform=not args.no_uniform,
+                               sparse_tables=args.sparse_tables)
         packed = [pack_for_fused(fstep, d, 1.0 / world) for d in pool]
         captured = [fstep.capture(p) for p in packed] if args.graph else None
         if world > 1 and not args.dense_allreduce:
@@ -503,7 +507,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if use_fused and not args.no_self_check:
+    if use_fused and not args.no_self_check and not args.sparse_tables:      # (the check compares DENSE gradients)
         self_check(model, fstep, packed[0], pool[0], world)
     for i in range(args.warmup):
         one_step(i)

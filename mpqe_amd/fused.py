@@ -23,7 +23,7 @@ from .data_utils import RGCNQueryDataset
 class PackedStep(object):
     __slots__ = ('batches', 'nb', 'anchor_ids', 'targets', 'negs', 'num_graphs', 'ws_bytes', 'sizes',
                  'desc', 'desc_bytes', 'desc_ptr', 'desc_resident', 'lanes', 'order', 'lane_begin', 'touch',
-                 'touch_ptr', 'touch_entries')
+                 'touch_ptr', 'touch_entries', 'touch_sizes')
 
 
 _INFO = {}
@@ -141,6 +141,7 @@ class FusedTrainStep(object):
         self.bind_grads()
         self.err = ops.new_error_word(self.device)
         self._ws = None
+        self._desc_cache, self._size_cache = {}, {}
         self.num_lanes = max(1, min(int(lanes), _capi.STEP_MAX_LANES))
         self._streams = [None] + [torch.cuda.Stream(device=self.device) for _ in range(self.num_lanes - 1)]
         self._fork = torch.cuda.Event()
@@ -214,35 +215,56 @@ class FusedTrainStep(object):
         for mm in members:
             lane_begin.append(lane_begin[-1] + len(mm))
         batches = [batches[i] for i in order]
+        # descriptors: per (formula, passes) everything that does not depend on the ids is cached (a training run
+        # draws from a finite set of formulas); ids go straight into ONE pinned staging buffer (numpy views, no
+        # per-batch tensors) and to the device in ONE copy: [anchors (slot-major per batch) | targets | negatives]
         SB = (_capi.StepBatch * nb)()
-        anchors, tg, ng, sizes = [], [], [], []
+        sizes, acols = [], []
         for i, b in enumerate(batches):
             f = b['formula']
-            info = _template_info(f.query_type)
-            a = torch.as_tensor(b['anchor_ids'], dtype=torch.long)
-            B = a.shape[0]
-            if a.shape[1] != info.num_anchors:
-                raise ValueError('anchor_ids must be [B, %d] for %s' % (info.num_anchors, f.query_type))
-            if m.adaptive:
-                passes = RGCNQueryDataset.query_diameters[f.query_type]
-                if passes > len(m.layers):
+            passes = passes_of[order[i]]
+            key = (f, passes)
+            proto = self._desc_cache.get(key)
+            if proto is None:
+                info = _template_info(f.query_type)
+                if m.adaptive and passes > len(m.layers):
                     raise ValueError(f'RGCN is adaptive with {len(m.layers)}'
                                      f' layers, but query requires {passes}.')
-            else:
-                passes = m.num_layers
-            nodes, rels = f.get_nodes(), f.get_rels()
-            edge_type = [m.rel_ids[(rels[info.rel_label[e]][2], rels[info.rel_label[e]][1],
-                                    rels[info.rel_label[e]][0])] for e in range(info.num_edges)]
-            var_ids = [m.mode_ids[nodes[info.var_node[k]]] for k in range(info.num_vars)]
-            SB[i] = _capi.make_step_batch(f.query_type, passes, B, edge_type, var_ids,
-                                          [m.mode_ids[x] for x in f.anchor_modes], m.mode_ids[f.target_mode],
-                                          float(b.get('weight', 1.0)))
-            anchors.append(a.t().contiguous().reshape(-1))
-            tg.append(torch.as_tensor(b['targets'], dtype=torch.long).reshape(-1))
-            ng.append(torch.as_tensor(b['negs'], dtype=torch.long).reshape(-1))
-            if tg[-1].shape[0] != B or ng[-1].shape[0] != B:
-                raise ValueError('targets / negs must have one id per query')
+                nodes, rels = f.get_nodes(), f.get_rels()
+                edge_type = [m.rel_ids[(rels[info.rel_label[e]][2], rels[info.rel_label[e]][1],
+                                        rels[info.rel_label[e]][0])] for e in range(info.num_edges)]
+                var_ids = [m.mode_ids[nodes[info.var_node[k]]] for k in range(info.num_vars)]
+                proto = (_capi.make_step_batch(f.query_type, passes, 1, edge_type, var_ids,
+                                               [m.mode_ids[x] for x in f.anchor_modes], m.mode_ids[f.target_mode], 1.0),
+                         info.num_anchors)
+                if len(self._desc_cache) > 65536:
+                    self._desc_cache.clear()
+                self._desc_cache[key] = proto
+            B = len(b['targets'])
+            ctypes.memmove(ctypes.addressof(SB[i]), ctypes.addressof(proto[0]), ctypes.sizeof(_capi.StepBatch))
+            SB[i].batch_size = B
+            SB[i].weight = float(b.get('weight', 1.0))
             sizes.append(B)
+            acols.append(proto[1])
+        na, ngr = sum(B * A for B, A in zip(sizes, acols)), sum(sizes)
+        stage = self._staging(na + 2 * ngr)
+        snp = stage.numpy()
+        oa, og = 0, 0
+        for b, B, A in zip(batches, sizes, acols):
+            a = b['anchor_ids']
+            a = a.cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+            if a.shape != (B, A):
+                raise ValueError('anchor_ids must be [B, %d] for %s' % (A, b['formula'].query_type))
+            snp[oa:oa + B * A].reshape(A, B)[...] = a.T
+            t, n = b['targets'], b['negs']
+            t = t.cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+            n = n.cpu().numpy() if torch.is_tensor(n) else np.asarray(n)
+            if t.shape != (B,) or n.shape != (B,):
+                raise ValueError('targets / negs must have one id per query')
+            snp[na + og:na + og + B] = t
+            snp[na + ngr + og:na + ngr + og + B] = n
+            oa += B * A
+            og += B
         ps = PackedStep()
         ps.batches, ps.nb, ps.sizes = SB, nb, sizes
         ps.order, ps.lane_begin = order, lane_begin
@@ -257,26 +279,34 @@ class FusedTrainStep(object):
                 L.aux_stream[l] = self._streams[l].cuda_stream
                 L.join_event[l] = self._joins[l].cuda_event
             ps.lanes = ctypes.pointer(L)
-        # all ids of the step in ONE pinned staging buffer and ONE host-to-device copy: [anchors | targets | negatives]
-        na, ngr = sum(a.numel() for a in anchors), sum(sizes)
-        stage = self._staging(na + 2 * ngr)
-        torch.cat(anchors, out=stage[:na])
-        torch.cat(tg, out=stage[na:na + ngr])
-        torch.cat(ng, out=stage[na + ngr:])
         ids = stage.to(self.device, non_blocking=True)
         self._stage_events[self._stage_next].record()          # the buffer is free again once this copy has run
         ps.anchor_ids, ps.targets, ps.negs = ids[:na], ids[na:na + ngr], ids[na + ngr:]
-        ps.num_graphs = int(sum(sizes))
-        ps.ws_bytes = ops.lib().mpqe_step_workspace_bytes(ctypes.byref(self.P), SB, nb, ps.lanes)
-        if ps.ws_bytes == 0:
-            raise _capi.MpqeError('mpqe_step_workspace_bytes rejected the step descriptors')
+        ps.num_graphs = int(ngr)
+        # sizes: functions of the descriptors alone -- cached per descriptor set (one planning pass on a miss; the
+        # step's first run takes that plan over)
+        skey = (bytes(SB), tuple(lane_begin))
+        sz = self._size_cache.get(skey)
+        if sz is None:
+            lib = ops.lib()
+            sz = (lib.mpqe_step_workspace_bytes(ctypes.byref(self.P), SB, nb, ps.lanes),
+                  lib.mpqe_step_desc_bytes(ctypes.byref(self.P), SB, nb, ps.lanes),
+                  lib.mpqe_step_touch_bytes(ctypes.byref(self.P), SB, nb),
+                  lib.mpqe_step_touch_workspace_bytes(ctypes.byref(self.P), SB, nb),
+                  int(lib.mpqe_step_touch_entries(SB, nb)))
+            if sz[0] == 0:
+                raise _capi.MpqeError('mpqe_step_workspace_bytes rejected the step descriptors')
+            if len(self._size_cache) > 4096:
+                self._size_cache.clear()
+            self._size_cache[skey] = sz
+        ps.ws_bytes, ps.desc_bytes = sz[0], sz[1]
         # descriptor table of this step: written to HBM by the first run, re-used afterwards
-        ps.desc_bytes = ops.lib().mpqe_step_desc_bytes(ctypes.byref(self.P), SB, nb, ps.lanes)
         ps.desc = torch.empty(ps.desc_bytes + 256, dtype=torch.uint8, device=self.device)
         ps.desc_ptr = (ps.desc.data_ptr() + 255) // 256 * 256
         ps.desc_resident = False
         ps.touch, ps.touch_ptr = None, None
-        ps.touch_entries = int(ops.lib().mpqe_step_touch_entries(SB, nb))
+        ps.touch_entries = sz[4]
+        ps.touch_sizes = (sz[2], sz[3])
         if self.touch:
             self.build_touch(ps)
         return ps
@@ -287,8 +317,7 @@ class FusedTrainStep(object):
         instead of with float atomics. Stream-ordered on the current stream, no synchronisation. Call it again
         after refilling ps.anchor_ids / targets / negs in place with new ids."""
         L = ops.lib()
-        nbytes = L.mpqe_step_touch_bytes(ctypes.byref(self.P), ps.batches, ps.nb)
-        wbytes = L.mpqe_step_touch_workspace_bytes(ctypes.byref(self.P), ps.batches, ps.nb)
+        nbytes, wbytes = ps.touch_sizes
         if nbytes == 0:
             raise _capi.MpqeError('mpqe_step_touch_bytes rejected the step descriptors')
         if ps.touch is None:
