@@ -240,6 +240,8 @@ __device__ __forceinline__ float *pick_grad(float *const *arr, int li) {
 #include "step_chain.h"
 #include "step_uniform.h"
 #include "step_touch.h"
+#include "grad_w_reg.h"
+#define LD_T 3          // weight-gradient launch of the chain form: register-only K loop (grad_w_reg.h)
 
 // Prologue roles of the chain launch (they were a launch of their own, 9 us in front of the chain kernel): the forward
 // pre-pass of the batch-uniform node states (vector ops, step_uniform.h), transposed copies of the matrices the backward
@@ -693,8 +695,7 @@ __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, con
                                              const float *__restrict__ H, const float *__restrict__ GH,
                                              long long level_stride, float *__restrict__ slabs, int bid,
                                              int wblocks_total, float *smem, const GradPtrs &gp, bool zeroed,
-                                             long long *dbg = nullptr) {
-    const int D = sd->D;
+                                             long long *dbg, int D) {
     const int tiles_j = (D + GT_BN - 1) / GT_BN, tiles = tiles_j * ((D + GT_BM - 1) / GT_BM);
     // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2: blocks b and b+8 share
     // one. The `tiles` output tiles of a K-chunk read the SAME rows of H and gH (different column
@@ -721,7 +722,10 @@ __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, con
             direct = true;
         }
     }
-    if (MODE == LD_FAST)      // whole K-steps, D % 64 == 0: deep LDS-DMA pipeline
+    if constexpr (MODE == LD_T) {      // chain form (D % 64 == 0, 16-byte aligned rows): register-only K loop
+        grad_w_tile_rows(x, g, D, xs, xo, go, q0, q1, wk.i0, wk.j0, dst, smem, direct && !zeroed, dbg);
+        (void)gs; (void)out;
+    } else if constexpr (MODE == LD_FAST)      // whole K-steps, D % 64 == 0: deep LDS-DMA pipeline
         // (a form with NO LDS -- every MFMA operand one coalesced global_load_dword into its register, four
         // register buffers -- measured slower: 32 dword loads per 16 MFMAs cost more issue time than the ring's
         // four DMA pieces, a whole tile took 16.5 us against 14.5)
@@ -835,6 +839,7 @@ struct TailArgs {
     const ZMat *zmats;       // untouched gradient matrices, zero-filled by workgroups [wblocks, wblocks + zblocks)
     int zblocks, zper;       // zper = workgroups per matrix
     int ublocks;             // the backward post-pass of the uniform node states: the FIRST ublocks workgroups
+    int D;                   // = sd->D, by value: a tile's record is then the first and only load in front of its rows
 
     const long long *node_map;
     long long map_len;
@@ -849,7 +854,8 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
                                                         UArgs ua) {
     // weight-gradient tiles only: the DMA ring takes 64 KB of LDS per workgroup, which would throttle the
     // thousands of light partial-sum / anchor workgroups to 2 per CU if they shared this kernel
-    __shared__ __attribute__((aligned(16))) float smem[MODE == LD_FAST ? GWD_SMEM_FLOATS : GT_SMEM_FLOATS];
+    // (LD_T, the chain form: the tiles meet in a 17 KB LDS tile at their end; the post-pass' vector ops use 8 KB)
+    __shared__ __attribute__((aligned(16))) float smem[MODE == LD_T ? GWR_SMEM_FLOATS : (MODE == LD_FAST ? GWD_SMEM_FLOATS : GT_SMEM_FLOATS)];
 #ifndef MPQE_EMU
     long long tick0 = 0;
     if (ta.stamps && threadIdx.x == 0) {
@@ -886,7 +892,7 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
         return;
     }
     grad_w_block<MODE>(sd, ta.wsrc, ta.nwsrc, ta.wblock, H, GH, level_stride, ta.slabs, tb, ta.wblocks,
-                       smem, gp, zeroed != 0, ta.stamps ? ta.stamps + (long long)blockIdx.x * 8 : nullptr);      // zeroed: this call zero-filled the gradients, a store suffices
+                       smem, gp, zeroed != 0, ta.stamps ? ta.stamps + (long long)blockIdx.x * 8 : nullptr, ta.D);      // zeroed: this call zero-filled the gradients, a store suffices
 #ifndef MPQE_EMU
     if (ta.stamps && threadIdx.x == 0) {
         ta.stamps[(long long)blockIdx.x * 8 + 1] = (long long)wall_clock64();
@@ -2564,6 +2570,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     ta.vblocks = hp.vblocks_total;
     ta.anchor_off = reinterpret_cast<const int *>(db + hp.o_anchor);
     ta.nb = nb;
+    ta.D = D;
     ta.node_map = nm;
     ta.map_len = (long long)P->node_map_len;
     ta.anchor_ids = ids;
@@ -2590,7 +2597,10 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         if (nblocks <= 0) return;
         dim3 tgrid((unsigned)nblocks);
         const int zeroed = (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0;
-        if (fast && hp.whole_ksteps)
+        if (use_chain)
+            hipLaunchKernelGGL(step_tail_kernel<LD_T>, tgrid, dim3(256), 0, on, sd, tl, (const float *)H,
+                               (const float *)GH, hp.level_stride, gp, zeroed, lp, ub);
+        else if (fast && hp.whole_ksteps)
             hipLaunchKernelGGL(step_tail_kernel<LD_FAST>, tgrid, dim3(256), 0, on, sd, tl, (const float *)H,
                                (const float *)GH, hp.level_stride, gp, zeroed, lp, ub);
         else if (vec)
