@@ -55,6 +55,10 @@ def parse():
                     help='1: replay each step from a captured hipGraph')
     ap.add_argument('--no-prune', action='store_true', help='compute node states that cannot reach the readout too')
     ap.add_argument('--no-chain', action='store_true', help='one launch per message-passing level')
+    ap.add_argument('--merge-tail', type=int, default=-1,
+                    help='chain form: weight-gradient tiles and backward post-pass as workgroups of the chain launch (1), '
+                         'as a launch of their own (0), or the library\'s choice by step size (-1, default; '
+                         'MPQE_STEP_MERGE_TAIL / MPQE_STEP_SPLIT_TAIL)')
     ap.add_argument('--no-uniform', action='store_true',
                     help='chain form: node states no anchor has reached yet as per-graph rows instead of one vector per batch')
     ap.add_argument('--no-ksplit', action='store_true', help='dim 128: chain waves own 32 columns and all of K')
@@ -179,8 +183,12 @@ def time_fused_kernels(step, packed, data, model, readout, reps=20):
     if step.uses_chain(packed):
         # forward + backward-x levels (+ gather, scores) in one launch; then the weight gradients (the chain form
         # runs on the caller's stream whatever the lane split)
-        plan += [('step_chain_kernel', 2.0 * total)]
-        plan += [('step_tail_kernel', total)]
+        if step.merged(packed):
+            # merged launch: the weight-gradient tiles are workgroups of the chain launch (second pair: empty)
+            plan += [('step_chain_kernel', 3.0 * total)]
+        else:
+            plan += [('step_chain_kernel', 2.0 * total)]
+            plan += [('step_tail_kernel', total)]
     else:
         for p in range(Lmax):
             plan += [('step_layer_fwd_kernel', flops(lo, hi, p)) for lo, hi in lanes if max(Ls[lo:hi]) > p]
@@ -471,7 +479,7 @@ def main():
         from mpqe_amd.fused import FusedTrainStep
         fstep = FusedTrainStep(model, lanes=args.lanes, prune=not args.no_prune, chain=not args.no_chain,
                                ksplit=not args.no_ksplit, eight_waves=args.eight_waves, uniform=not args.no_uniform,
-                               sparse_tables=args.sparse_tables)
+                               sparse_tables=args.sparse_tables, merge_tail=None if args.merge_tail < 0 else bool(args.merge_tail))
         packed = [pack_for_fused(fstep, d, 1.0 / world) for d in pool]
         captured = [fstep.capture(p) for p in packed] if args.graph else None
         if world > 1 and not args.dense_allreduce:

@@ -256,6 +256,15 @@ int mpqe_hinge_bwd(const float *pos, const float *neg, int64_t n, float margin, 
  *             left as it is -- no zero fill and no pass over tables of 10^5 .. 10^6 rows per step. For consumers that
  *             read only the touched rows: mpqe_adam_rows_step, the row exchange of the data-parallel path.      */
 #define MPQE_STEP_SPARSE_TABLES 64
+/* MERGE_TAIL / SPLIT_TAIL  (chain form) where the weight-gradient tiles and the backward post-pass run. Merged: as
+ *             workgroups of the chain launch itself, queued behind the chain workgroups and started per batch as soon
+ *             as that batch's chain workgroups have published their rows (two launches per step: chain, reduction).
+ *             Split: as a launch of their own behind the chain launch (three launches). Same results either way.
+ *             Default: merged while the step has at most 9/8 x 256 chain workgroups (16 query graphs each) -- there
+ *             it is 4 .. 12 % faster --, split beyond (the AIFB step of 11 x 512 graphs: merged is 4 % slower).
+ *             MERGE_TAIL forces the merged form, SPLIT_TAIL the split one.                                    */
+#define MPQE_STEP_MERGE_TAIL 128
+#define MPQE_STEP_SPLIT_TAIL 256
 
 typedef struct {
     int32_t query_type;        /* MPQE_Q_*                                                     */

@@ -147,6 +147,8 @@ def check(cdll, status, what):
 
 STEP_NO_PRUNE, STEP_NO_CHAIN, STEP_ZERO_GRADS, STEP_NO_KSPLIT, STEP_EIGHT_WAVES, STEP_NO_UNIFORM = 1, 2, 4, 8, 16, 32
 STEP_SPARSE_TABLES = 64
+STEP_MERGE_TAIL = 128
+STEP_SPLIT_TAIL = 256
 
 
 def make_step_params(dim, num_relations, readout, table_ptrs, table_rows, node_map_ptr, node_map_len,

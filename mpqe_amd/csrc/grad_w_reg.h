@@ -22,7 +22,7 @@
 #define GWR_PF 8            // loads in flight per wave, in iterations (16 graphs of the workgroup = 4 of the wave)
 #endif
 #define GWR_LDT 68          // row stride of an LDS tile (floats)
-#define GWR_SMEM_FLOATS (4 * 64 * GWR_LDT)          // one tile per wave
+#define GWR_SMEM_FLOATS (4 * 64 * GWR_LDT)          // one tile per wave (LDS_TILES = 4; 1: the waves take turns on one)
 
 // a value every lane of the wave holds, moved to SGPRs (the tile's record arrives through a vector load: hipcc cannot know)
 __device__ __forceinline__ long long gwr_uniform(long long v) {
@@ -31,6 +31,7 @@ __device__ __forceinline__ long long gwr_uniform(long long v) {
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
+template <int LDS_TILES = 4>
 __device__ __forceinline__ void grad_w_tile_rows(const float *__restrict__ x, const float *__restrict__ g, int D,
                                                  long long xs, long long xo, long long go, long long q0, long long q1,
                                                  int i0, int j0, float *__restrict__ dst, float *smem, bool accumulate,
@@ -118,22 +119,41 @@ __device__ __forceinline__ void grad_w_tile_rows(const float *__restrict__ x, co
     GWR_STAMP(6, "s_nop 0")
     // D[position row 4 kq + r][position col pos] of MFMA (m, n) = out[i0 + 4 (4 kq + r) + m][j0 + 4 pos + n]: a lane's four n
     // are 16 adjacent bytes. Every wave leaves its tile in LDS; the tiles are added in wave order (fixed: reproducible).
-    float *mine = smem + wave * (64 * GWR_LDT);
+    if constexpr (LDS_TILES == 4) {
+        float *mine = smem + wave * (64 * GWR_LDT);
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            *reinterpret_cast<f32x4 *>(mine + (4 * (4 * kq + r) + m) * GWR_LDT + 4 * pos) =
-                f32x4{acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
-    __syncthreads();
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<f32x4 *>(mine + (4 * (4 * kq + r) + m) * GWR_LDT + 4 * pos) =
+                    f32x4{acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
+        __syncthreads();
+    } else {                            // (a workgroup with less LDS: one tile, the waves add theirs one after the other)
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        f32x4 *t = reinterpret_cast<f32x4 *>(smem + (4 * (4 * kq + r) + m) * GWR_LDT + 4 * pos);
+                        f32x4 v = {acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
+                        if (w > 0) v += *t;
+                        *t = v;
+                    }
+            }
+            __syncthreads();
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int f = (int)threadIdx.x + 256 * k;
         const int row = f >> 4, c4 = f & 15;
         const float *t0 = smem + row * GWR_LDT + 4 * c4;
         f32x4 v = *reinterpret_cast<const f32x4 *>(t0);
+        if constexpr (LDS_TILES == 4) {
 #pragma unroll
-        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4 *>(t0 + w * (64 * GWR_LDT));
+            for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4 *>(t0 + w * (64 * GWR_LDT));
+        }
         f32x4 *o = reinterpret_cast<f32x4 *>(dst + (long long)(i0 + row) * D + j0 + 4 * c4);
         if (accumulate) v += *o;
         *o = v;

@@ -98,6 +98,16 @@ struct WBlock {
     int q0, q1;                 // the K-chunk: graphs [q0, q1)
     int i0, j0;                 // the output tile
     int direct;                 // >= 0: layer whose gradient matrix the tile writes itself; -1: slab
+    int d0, dn;                 // merged launch: the `done` counters [d0, d0 + dn) cover the chain workgroups of the K-chunk
+    int batch, pad;
+};
+// Merged launch (chain form): the weight-gradient tiles and the backward post-pass are workgroups of the CHAIN launch,
+// behind the chain workgroups. A chain workgroup counts itself into the `done` counter of its group of DONE_GRAPHS graphs
+// once its H / gH rows and column sums are out (release at agent scope); a tile / vector op waits for the counters of
+// the graphs it reads. Counters only grow: target = (merged-launch epoch + 1) x (chain workgroups of the group).
+#define DONE_GRAPHS 128
+struct DoneMeta {
+    int base[MPQE_STEP_MAX_BATCHES + 1];       // counters of batch b: [base[b], base[b + 1])
 };
 struct WSource {
     int batch, level, slot, relu;
@@ -167,6 +177,8 @@ struct UOp {
     long long mode_row;                // COPY
     int u_vec[UOP_MAX_TERMS];          // R1
     int r1_layer, r1_rel;
+    unsigned wait_mask;                // merged launch: bit b = the op reads rows the chain workgroups of batch b write
+    int pad;
 };
 
 struct Blob {
@@ -266,6 +278,7 @@ struct PrepArgs {
     const WtSlot *slots;
     float *WT;
     unsigned *wt_count;
+    unsigned *fwd_done;       // vector-op workgroups finished, ever (uop_wait_prepass); NULL: none
     ZeroSegs zs;
 };
 
@@ -342,17 +355,53 @@ __device__ __forceinline__ void prep_zero_block(const ZeroSegs &zs, long long zb
     }
 }
 
+// Merged launch: what used to be the weight-gradient launch -- zero fill of untouched relation matrices, the backward
+// post-pass of the uniform node states, the weight-gradient tiles -- as workgroups of the chain launch, behind its zero
+// fill: [prologue][chain][zero fill, padded to a multiple of 8][untouched matrices | post-pass, padded][tiles].
+// They wait for the chain workgroups whose rows they read (DoneMeta) and for nothing that comes after them in the
+// launch; with in-order dispatch per XCD every wait ends (and is bounded all the same).
+struct ZMat {
+    int layer, pad;
+    long long rel;
+};
+#define ZMAT_FLOATS_PER_BLOCK 8192
+struct WBlock;
+struct PostArgs {
+    int zpad;                 // zero-fill workgroups, padding included: the post roles start at lead + nchain + zpad; 0 = none
+    int zmblocks, ublocks;    // untouched-matrix workgroups, post-pass workgroups
+    int ppad;                 // zmblocks + ublocks rounded up to a multiple of 8 (tile workgroup t keeps XCD t % 8)
+    int wblocks, zper, D, zeroed;
+    UArgs ub;
+    const WBlock *wblock;
+    const ZMat *zmats;
+    float *slabs;
+    const float *H, *GH;
+    long long level_stride;
+    GradPtrs gp;
+    const unsigned *done;
+    const int *done_inc;
+    const unsigned *epoch_m;  // epoch of the merged launches of this packed step (bumped by the reduction launch)
+    int32_t *err;
+    long long *stamps;        // diagnostics (mpqe_debug_tail_stamps): 8 words per tile workgroup, or NULL
+};
+template <int LDS_TILES>
+__device__ __forceinline__ void post_block(const StepDev *__restrict__ sd, const LayerPtrs &lp, const PostArgs &po, int pb,
+                                           float *smem);
+
 template <int NCB, int KS, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void step_chain_kernel(const StepDev *__restrict__ sd, LayerPtrs lp,
-                                                             TablePtrs tabs, ChainArgs ca, PrepArgs pa) {
+                                                             TablePtrs tabs, ChainArgs ca, PrepArgs pa, PostArgs po) {
     __shared__ __attribute__((aligned(16))) ChainLds<NCB, KS, NW> S;
-    // role of this workgroup (uniform): chain workgroup, prologue work in front of / behind them, zero fill last
-    // [prologue][chain][zero fill]: a producer is never queued behind a consumer that waits for it
+    // role of this workgroup (uniform): chain workgroup, prologue work in front of / behind them, zero fill, then the
+    // post roles: a producer is never queued behind a consumer that waits for it
     int bid = (int)blockIdx.x, role;
     if (bid < pa.lead) role = 1;
     else if (bid < pa.lead + pa.nchain) role = 0, bid -= pa.lead;
     else role = 2, bid -= pa.lead + pa.nchain;
     if (role == 0) {
+#ifndef MPQE_EMU
+        if (po.zpad > 0) __builtin_amdgcn_s_setprio(1);      // (merged launch: over the tiles that may share the CU)
+#endif
         ca.cb = bid;
         ca.nchain = pa.nchain;
         chain_block<NCB, KS, NW>(sd, lp, tabs, ca, S);
@@ -360,11 +409,23 @@ __global__ __launch_bounds__(64 * NW) void step_chain_kernel(const StepDev *__re
         constexpr int D = 16 * NCB * NW / KS;
         if (bid < pa.ublocks) {
             if (NW == 4 || threadIdx.x < 256) uop_block(bid, D, lp, pa.ua, S.xs, nullptr, 0);
+            // merged launch: the post-pass reads the pre-pass' vectors from VT. Wave 0 made the stores (write-through):
+            // once they are acknowledged the workgroup counts itself in (uop_wait_prepass)
+            if (pa.fwd_done && threadIdx.x < 64) {
+#ifndef MPQE_EMU
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                if (threadIdx.x == 0) atomicAdd(pa.fwd_done, 1u);
+            }
         } else if (bid < pa.ublocks + pa.tblocks) {
             prep_transpose_block(lp, pa, D, bid - pa.ublocks, S.xs);
         }       // (else: padding)
+    } else if (po.zpad == 0 || bid < po.zpad) {
+        if ((long long)bid < pa.zs.block0[pa.zs.count]) prep_zero_block(pa.zs, bid);
     } else {
-        prep_zero_block(pa.zs, bid);
+        if (NW == 4 || threadIdx.x < 256)
+            post_block<(sizeof(S) >= 4 * 64 * GWR_LDT * sizeof(float)) ? 4 : 1>(sd, lp, po, bid - po.zpad,
+                                                                                reinterpret_cast<float *>(&S));
     }
 }
 
@@ -689,13 +750,13 @@ __global__ __launch_bounds__(1024) void step_loss_kernel(const StepDev *__restri
 }
 
 // ------------------------------------------------------------------------------------ weight gradients
-template <int MODE>
+template <int MODE, int LDS_TILES = 4>
 __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, const WSource *__restrict__ src,
                                              int nsrc, const WBlock *__restrict__ block_start,
                                              const float *__restrict__ H, const float *__restrict__ GH,
                                              long long level_stride, float *__restrict__ slabs, int bid,
                                              int wblocks_total, float *smem, const GradPtrs &gp, bool zeroed,
-                                             long long *dbg, int D) {
+                                             long long *dbg, int D, const PostArgs *po = nullptr) {
     const int tiles_j = (D + GT_BN - 1) / GT_BN, tiles = tiles_j * ((D + GT_BM - 1) / GT_BM);
     // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2: blocks b and b+8 share
     // one. The `tiles` output tiles of a K-chunk read the SAME rows of H and gH (different column
@@ -708,6 +769,18 @@ __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, con
         vb = grp * span + (r & 7) * tiles + (r >> 3);
     }
     const WBlock wk = block_start[vb];       // one record, no search, no second hop
+    if (po) {
+        // merged launch: the rows of the K-chunk are written by chain workgroups of THIS launch; wave 0 waits for their
+        // counters (agent-scope loads, bounded), then the workgroup's barrier. No acquire fence: nothing on this CU or
+        // XCD has read these lines before their writers released them (rows are written once per step, and caches do not
+        // survive a launch boundary).
+        if (threadIdx.x < 64) {
+            const unsigned ep = *po->epoch_m + 1u;
+            for (int c = wk.d0 + (int)threadIdx.x; c < wk.d0 + wk.dn; c += 64)
+                uop_wait_until(po->done + c, ep * (unsigned)po->done_inc[c], po->err);
+        }
+        __syncthreads();
+    }
     const long long xs = wk.xs, xo = wk.xo, gs = wk.xs, go = wk.go;
     const long long q0 = wk.q0, q1 = wk.q1;
     const float *x = H + wk.x_off;
@@ -723,7 +796,7 @@ __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, con
         }
     }
     if constexpr (MODE == LD_T) {      // chain form (D % 64 == 0, 16-byte aligned rows): register-only K loop
-        grad_w_tile_rows(x, g, D, xs, xo, go, q0, q1, wk.i0, wk.j0, dst, smem, direct && !zeroed, dbg);
+        grad_w_tile_rows<LDS_TILES>(x, g, D, xs, xo, go, q0, q1, wk.i0, wk.j0, dst, smem, direct && !zeroed, dbg);
         (void)gs; (void)out;
     } else if constexpr (MODE == LD_FAST)      // whole K-steps, D % 64 == 0: deep LDS-DMA pipeline
         // (a form with NO LDS -- every MFMA operand one coalesced global_load_dword into its register, four
@@ -817,12 +890,6 @@ __device__ __forceinline__ void anchor_bwd_block(const StepDev *__restrict__ sd,
 
 // A relation matrix of the gradient that nothing writes this step (with MPQE_STEP_ZERO_GRADS it must read zero
 // afterwards): zero-filled by spare workgroups of the weight-gradient launch instead of the step's prologue.
-struct ZMat {
-    int layer, pad;
-    long long rel;
-};
-#define ZMAT_FLOATS_PER_BLOCK 8192
-
 // Backward tail: weight-gradient tiles, bias / variable-row partial sums and anchor-table gradients
 // all depend only on H and gH and write disjoint outputs, so they share ONE launch (a role per block
 // range, heavy MFMA tiles first) instead of three half-empty ones.
@@ -846,6 +913,52 @@ struct TailArgs {
     const long long *anchor_ids;
     float *slabs, *parts;
 };
+
+// workgroup zb of the zero fill of the relation matrices nobody writes this step (zper workgroups per matrix)
+__device__ __forceinline__ void zmat_block(const ZMat *__restrict__ zmats, int zper, int zb, int D, const GradPtrs &gp) {
+    const ZMat zm = zmats[zb / zper];
+    float *base = pick_grad(gp.basis, zm.layer);
+    if (!base) return;
+    const long long elems = (long long)D * D;
+    float *p = base + zm.rel * elems;
+    const long long lo = (long long)(zb % zper) * ZMAT_FLOATS_PER_BLOCK;
+    for (long long i = lo + threadIdx.x * 4; i < lo + ZMAT_FLOATS_PER_BLOCK && i < elems; i += 1024) {
+        if (i + 3 < elems && ((uintptr_t)(p + i) & 15) == 0) *reinterpret_cast<f32x4 *>(p + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+        else
+            for (long long q = i; q < i + 4 && q < elems; ++q) p[q] = 0.f;
+    }
+}
+
+// post roles of the merged chain launch (declared with PostArgs, in front of step_chain_kernel)
+template <int LDS_TILES>
+__device__ __forceinline__ void post_block(const StepDev *__restrict__ sd, const LayerPtrs &lp, const PostArgs &po, int pb,
+                                           float *smem) {
+    if (pb < po.zmblocks) {
+        zmat_block(po.zmats, po.zper, pb, po.D, po.gp);
+    } else if (pb < po.zmblocks + po.ublocks) {
+        uop_block(pb - po.zmblocks, po.D, lp, po.ub, smem, &po.gp, po.zeroed);
+    } else if (pb >= po.ppad && pb < po.ppad + po.wblocks) {
+        const int tb = pb - po.ppad;
+        long long *dbg = po.stamps ? po.stamps + (long long)tb * 8 : nullptr;
+#ifndef MPQE_EMU
+        long long tick0 = 0;
+        if (dbg && threadIdx.x == 0) {
+            tick0 = (long long)__builtin_amdgcn_s_memtime();
+            dbg[0] = (long long)wall_clock64();
+            dbg[3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                     ((long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+        }
+#endif
+        grad_w_block<LD_T, LDS_TILES>(sd, nullptr, 0, po.wblock, po.H, po.GH, po.level_stride, po.slabs, tb, po.wblocks,
+                                      smem, po.gp, po.zeroed != 0, dbg, po.D, &po);
+#ifndef MPQE_EMU
+        if (dbg && threadIdx.x == 0) {
+            dbg[1] = (long long)wall_clock64();
+            dbg[2] = (long long)__builtin_amdgcn_s_memtime() - tick0;
+        }
+#endif
+    }       // (else: padding)
+}
 
 template <int MODE>
 __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restrict__ sd, TailArgs ta,
@@ -877,18 +990,7 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
     }
     const int tb = (int)blockIdx.x - ta.ublocks;
     if (tb >= ta.wblocks) {        // zero fill of a gradient matrix nobody writes (uniform branch)
-        const int zb = tb - ta.wblocks;
-        const ZMat zm = ta.zmats[zb / ta.zper];
-        float *base = pick_grad(gp.basis, zm.layer);
-        if (!base) return;
-        const long long elems = (long long)sd->D * sd->D;
-        float *p = base + zm.rel * elems;
-        const long long lo = (long long)(zb % ta.zper) * ZMAT_FLOATS_PER_BLOCK;
-        for (long long i = lo + threadIdx.x * 4; i < lo + ZMAT_FLOATS_PER_BLOCK && i < elems; i += 1024) {
-            if (i + 3 < elems && ((uintptr_t)(p + i) & 15) == 0) *reinterpret_cast<f32x4 *>(p + i) = f32x4{0.f, 0.f, 0.f, 0.f};
-            else
-                for (long long q = i; q < i + 4 && q < elems; ++q) p[q] = 0.f;
-        }
+        zmat_block(ta.zmats, ta.zper, tb - ta.wblocks, sd->D, gp);
         return;
     }
     grad_w_block<MODE>(sd, ta.wsrc, ta.nwsrc, ta.wblock, H, GH, level_stride, ta.slabs, tb, ta.wblocks,
@@ -938,7 +1040,7 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restri
         // (As workgroups of the weight-gradient launch they are throttled to two per CU by its 64 KB of LDS: 23.6 us
         // for that launch instead of 16.6; here they cost 2.6 us.)
         table_sum_block(reinterpret_cast<const TouchHeader *>(touch), reinterpret_cast<const tkey_t *>(touch + touch_keys),
-                        nullptr, DG, D, tabs, table_store, (long long)((int)blockIdx.y - ngroups - 1) * gridDim.x + blockIdx.x);
+                        nullptr, DG, D, tabs, table_store & 1, (long long)((int)blockIdx.y - ngroups - 1) * gridDim.x + blockIdx.x);
         return;
     }
     if ((int)blockIdx.y == ngroups) {       // one extra workgroup row: the loss reduction rides along
@@ -948,6 +1050,7 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restri
             if (epoch_b && threadIdx.x == 0) {
                 *epoch_b = *epoch_b + 1u;
                 *(epoch_b - 16) = *(epoch_b - 16) + 1u;       // epoch_f
+                if (table_store & 2) *(epoch_b + 32) = *(epoch_b + 32) + 1u;      // merged launch: its own epoch (DoneMeta)
             }
             if (lm.chain) loss_block_chain(lm, bterms, loss, reinterpret_cast<float *>(part), 4);
             else loss_block(sd, terms, loss, reinterpret_cast<float *>(part), 4);
@@ -1095,6 +1198,11 @@ struct HostPlan {
     int blk_off[MPQE_STEP_MAX_BATCHES + 1];        // chain blocks before batch i (slots of block_terms)
     std::vector<ZMat> zmats;                       // relation matrices of the gradient that no source touches
     size_t o_zmats;
+    size_t o_done_inc, o_done;        // merged launch: chain workgroups per `done` counter (table), the counters (hand-off state)
+    std::vector<int> done_inc;
+    DoneMeta dm;
+    std::vector<int> whole_roots;     // layers whose ROOT gradient matrix is written whole inside the chain launch (direct
+                                      // tiles / a rank-1-only op): the launch's zero fill must leave them alone
     size_t o_bterms;
     size_t o_cref, o_cops, o_wtslots, o_WT;
     // workspace offsets (bytes)
@@ -1442,6 +1550,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     // slab and no reduction: its tiles write straight into the gradient (deterministic: one writer per element).
     {
         hp->rank1.clear();
+        hp->whole_roots.clear();
         for (size_t k = 0; k < r1keys.size(); ++k) hp->rank1.push_back(r1keys[k].t);
         r1_only.clear();
         std::vector<char> written((size_t)P->num_layers * (size_t)P->num_relations, 0);
@@ -1477,9 +1586,15 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                 ++kr;
             }
             if (rel >= 0) written[(size_t)layer * P->num_relations + rel] = 1;
-            if (nsrc == 1 && g.count == 1 && g.r1_count == 0) hp->wsrc[first_src].direct = layer;
-            else if (nsrc == 0 && g.r1_count <= UOP_MAX_TERMS) r1_only.push_back(g);    // written by the post-pass (UOP_R1)
-            else hp->groups.push_back(g);
+            if (nsrc == 1 && g.count == 1 && g.r1_count == 0) {
+                hp->wsrc[first_src].direct = layer;
+                if (rel < 0) hp->whole_roots.push_back(layer);
+            } else if (nsrc == 0 && g.r1_count <= UOP_MAX_TERMS) {
+                r1_only.push_back(g);    // written by the post-pass (UOP_R1)
+                if (rel < 0) hp->whole_roots.push_back(layer);
+            } else {
+                hp->groups.push_back(g);
+            }
         }
         // every other relation matrix of every (unique) layer is untouched
         hp->zmats.clear();
@@ -1489,6 +1604,13 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                 if (!written[(size_t)l * P->num_relations + r]) hp->zmats.push_back(ZMat{l, 0, r});
         }
     }
+    hp->done_inc.clear();
+    for (int i = 0; i < nb; ++i) {                  // `done` counters: one per DONE_GRAPHS graphs of a batch
+        hp->dm.base[i] = (int)hp->done_inc.size();
+        const int nblk = (sd.b[i].B + CH_GB - 1) / CH_GB, per = DONE_GRAPHS / CH_GB;
+        for (int k = 0; k < nblk; k += per) hp->done_inc.push_back(nblk - k < per ? nblk - k : per);
+    }
+    for (int i = nb; i <= MPQE_STEP_MAX_BATCHES; ++i) hp->dm.base[i] = (int)hp->done_inc.size();
     for (int l = 0; l < hp->nlanes; ++l) {          // block table, grouped by stream lane (a lane launches its own)
         hp->wblock_begin[l] = (int)hp->wblock.size();
         for (int pass = 0; pass < 2; ++pass)        // whole-batch chunks first, the short ride-along chunks last
@@ -1514,6 +1636,10 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                     wkb.i0 = (tile / ct) * GT_BM;
                     wkb.j0 = (tile % ct) * GT_BN;
                     wkb.direct = ws.direct;
+                    wkb.batch = ws.batch;
+                    wkb.pad = 0;
+                    wkb.d0 = hp->dm.base[ws.batch] + wkb.q0 / DONE_GRAPHS;
+                    wkb.dn = (wkb.q1 - 1) / DONE_GRAPHS - wkb.q0 / DONE_GRAPHS + 1;
                     hp->wblock.push_back(wkb);
                 }
             }
@@ -1713,6 +1839,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                                 op.in_kind[t] = 3;
                                 op.in_vec[t] = part_row[i][p + 1][dnode];
                                 op.in_gran[t] = (d.B + CH_GB - 1) / CH_GB;
+                                op.wait_mask |= 1u << i;
                             }
                         };
                         for (int e = 0; e < tp.E; ++e)
@@ -1735,6 +1862,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                 op.out_gran = op.out_part = op.mask_vec = -1;
                 op.row0 = part_row[vi.batch][vi.level][vi.node];
                 op.nrows = (sd.b[vi.batch].B + CH_GB - 1) / CH_GB;
+                op.wait_mask = 1u << vi.batch;
                 hp->uops_b.push_back(op);
             }
             hp->uops_b.insert(hp->uops_b.end(), bwd.begin(), bwd.end());
@@ -1759,6 +1887,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                         op.in_kind[t] = 3;
                         op.in_vec[t] = part_row[vi.batch][vi.level][vi.node];
                         op.in_gran[t] = (sd.b[vi.batch].B + CH_GB - 1) / CH_GB;
+                        op.wait_mask |= 1u << vi.batch;
                     }
                     op.nterms++;
                 }
@@ -1878,8 +2007,14 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                     for (int x = 1; x < STEP_XCDS; ++x)
                         if (load[x] < load[best]) best = x;
                     for (int g0 = c0; g0 < Bk && g0 < c0 + (int)cus * CH_GB; g0 += CH_GB) {   // progs is sorted: bins stay sorted
+                        const BatchDev &bd = sd.b[progs[k].batch];
+                        const unsigned meta = (unsigned)bd.tp.N | (unsigned)bd.A << 4 |
+                                              (unsigned)(bd.anchor_tab[0] & 15) << 8 | (unsigned)(bd.anchor_tab[1] & 15) << 12 |
+                                              (unsigned)(bd.anchor_tab[2] & 15) << 16 | (unsigned)(bd.target_tab & 15) << 20;
                         bins[best].push_back(ChainRef{progs[k].batch, g0, progs[k].fb, progs[k].fc, progs[k].bb,
-                                                      progs[k].bc, hp->blk_off[progs[k].batch] + g0 / CH_GB, 0});
+                                                      progs[k].bc, hp->blk_off[progs[k].batch] + g0 / CH_GB,
+                                                      hp->dm.base[progs[k].batch] + g0 / DONE_GRAPHS,
+                                                      (int)(bd.anchor_off + g0), (int)(bd.g_off + g0), bd.B, meta});
                         load[best] += progs[k].work;
                     }
                 }
@@ -1900,9 +2035,27 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
             }
             for (size_t k = 0; k < longest; ++k)
                 for (int x = 0; x < STEP_XCDS; ++x)
-                    hp->crefs.push_back(k < bins[x].size() ? bins[x][k] : ChainRef{-1, 0, 0, 0, 0, 0, 0, 0});
+                    hp->crefs.push_back(k < bins[x].size() ? bins[x][k] : ChainRef{-1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0u});
         }
         hp->cref_begin[hp->nlanes] = (int)hp->crefs.size();
+        // Merged launch: the tiles queue behind the chain workgroups of their XCD and wait for the chain workgroups of
+        // their batch; the batches with the shortest programmes finish first, so their tiles go first (the `tiles`
+        // workgroups of a K-chunk stay adjacent: grad_w_block puts them on one XCD).
+        if (chain && hp->nlanes == 1 && !hp->wblock.empty()) {
+            int work[MPQE_STEP_MAX_BATCHES] = {0};
+            for (size_t k = 0; k < progs.size(); ++k) work[progs[k].batch] = progs[k].work;
+            const size_t nchunks = hp->wblock.size() / tiles;
+            std::vector<size_t> order(nchunks);
+            for (size_t c = 0; c < nchunks; ++c) order[c] = c;
+            std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+                return work[hp->wblock[a * tiles].batch] < work[hp->wblock[b * tiles].batch];
+            });
+            std::vector<WBlock> sorted;
+            sorted.reserve(hp->wblock.size());
+            for (size_t c = 0; c < nchunks; ++c)
+                for (int t = 0; t < tiles; ++t) sorted.push_back(hp->wblock[order[c] * tiles + t]);
+            hp->wblock.swap(sorted);
+        }
     }
 
     // workspace layout
@@ -1932,10 +2085,12 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->o_uopf = take(hp->uops_f.size() * sizeof(UOp));
     hp->o_uopb = take(hp->uops_b.size() * sizeof(UOp));
     hp->o_rank1 = take(hp->rank1.size() * sizeof(Rank1));
+    hp->o_done_inc = take(hp->done_inc.size() * sizeof(int));
     // hand-off state of the packed step, zeroed when the table is uploaded: the two epoch words (forward pre-pass,
     // backward post-pass), then the granules
     hp->o_epoch = take(256);
     hp->o_gran = take((size_t)hp->ngran * D * sizeof(u64));
+    hp->o_done = take(2 * hp->done_inc.size() * sizeof(unsigned));      // published | arrived
     hp->desc_total = off;
     off = 0;
     hp->o_H = take((size_t)(hp->Lmax + 1) * rows * D * 4);
@@ -1973,6 +2128,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         put(hp->o_uopf, hp->uops_f.data(), hp->uops_f.size() * sizeof(UOp));
         put(hp->o_uopb, hp->uops_b.data(), hp->uops_b.size() * sizeof(UOp));
         put(hp->o_rank1, hp->rank1.data(), hp->rank1.size() * sizeof(Rank1));
+        put(hp->o_done_inc, hp->done_inc.data(), hp->done_inc.size() * sizeof(int));
     }
     hp->o_VT = take((size_t)hp->nvec * D * 4);
     hp->touch_M = anchors + 2 * graphs;
@@ -2192,7 +2348,7 @@ extern "C" int mpqe_step_touch_build(const mpqe_step_params_t *P, const mpqe_ste
     hipLaunchKernelGGL(touch_keys_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, tm,
                        reinterpret_cast<const long long *>(anchor_ids), reinterpret_cast<const long long *>(targets),
                        reinterpret_cast<const long long *>(negs), reinterpret_cast<const long long *>(P->node_map),
-                       (long long)P->node_map_len, keys, vals, M);
+                       (long long)P->node_map_len, keys, vals, reinterpret_cast<int *>(tb + L.erow), M);
     size_t tmp_bytes = L.w_tmp_bytes;
     // stable: entries of one destination row keep their entry order, so the per-row sums have ONE order
     int *sorted_vals = reinterpret_cast<int *>(wb + L.w_keys);       // re-used after the sort below has consumed `keys`
@@ -2495,11 +2651,22 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     PrepArgs pa;
     memset(&pa, 0, sizeof(pa));
     long long zblocks = 0;
+    // merged launch: tiles + post-pass ride in the chain launch (include/mpqe_amd.h: MPQE_STEP_MERGE_TAIL)
+    // Measured (AIFB mix, D = 128, B per batch 32 / 64 / 128 / 256 / 384 / 512 / 8192): merged 51.8 / 53.7 / 58.1 / 60.5 /
+    // 60.6 / 68.3 / 569 us per step against 58.8 / 59.4 / 61.6 / 62.9 / 63.6 / 65.7 / 550 -- it wins while the chain
+    // workgroups leave a free slot on (almost) every CU, and loses once the tiles have to share CUs with running chain
+    // workgroups and queue behind them. Hence: merged up to 9/8 x CUs chain workgroups unless a flag says otherwise.
+    const bool merged = use_chain && backward && NL == 1 && !(P->flags & MPQE_STEP_SPLIT_TAIL) &&
+                        ((P->flags & MPQE_STEP_MERGE_TAIL) || hp.blk_off[nb] <= STEP_CUS + STEP_CUS / 8);
     {
         ZeroSegs &zs = pa.zs;
         if (backward && (P->flags & MPQE_STEP_ZERO_GRADS)) {
             auto seg = [&](float *ptr, long long n) {
                 if (!ptr || n <= 0) return;
+                // (merged launch: a root matrix that tiles / a rank-1 op of the SAME launch write whole is not zero-filled
+                // -- the fill would race with its writers, who store instead of adding)
+                for (size_t k = 0; merged && k < hp.whole_roots.size(); ++k)
+                    if (G->root[hp.whole_roots[k]] == ptr) return;
                 for (int k = 0; k < zs.count; ++k)
                     if (zs.p[k] == ptr) return;                  // shared layers repeat their buffers
                 if (zs.count >= PREP_MAX_SEGS) return;
@@ -2539,6 +2706,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             pa.slots = reinterpret_cast<const WtSlot *>(db + hp.o_wtslots);
             pa.WT = WT;
             pa.wt_count = epoch_f + 32;
+            pa.fwd_done = merged && pa.ublocks > 0 ? epoch_f + 33 : nullptr;
+            pa.ua.vt_through = merged ? 1 : 0;
         } else if (zblocks > 0) {
             hipLaunchKernelGGL(step_zero_kernel, dim3((unsigned)zblocks), dim3(256), 0, s, zs);
         }
@@ -2630,6 +2799,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         ca.DG = use_touch ? reinterpret_cast<float *>(wb + hp.o_DG) : nullptr;
         ca.dg_pos = use_touch ? reinterpret_cast<const int *>(reinterpret_cast<const char *>(touch) +
                                                               touch_layout(hp.touch_M, 0).perm) : nullptr;
+        ca.erow = use_touch ? reinterpret_cast<const int *>(reinterpret_cast<const char *>(touch) +
+                                                            touch_layout(hp.touch_M, 0).erow) : nullptr;
         ca.Manchor = (long long)hp.anchor_off[nb];
         ca.Gtot = hp.sd.graphs_total;
         ca.parts = reinterpret_cast<float *>(wb + hp.o_parts);
@@ -2650,16 +2821,55 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             ca.epoch_b = epoch_b;
             ca.wt_count = pa.tblocks > 0 ? pa.wt_count : nullptr;
             ca.wt_blocks = pa.tblocks;
-            dim3 cgrid((unsigned)(pa.lead + pa.nchain + zblocks));
+            // (counters and their epoch advance on merged steps only: targets are epoch x count)
+            ca.done = merged ? reinterpret_cast<unsigned *>(db + hp.o_done) : nullptr;
+            ca.arrive = ca.done ? ca.done + hp.done_inc.size() : nullptr;
+            ca.done_inc = reinterpret_cast<const int *>(db + hp.o_done_inc);
+            PostArgs po;
+            memset(&po, 0, sizeof(po));
+            long long grid_blocks = pa.lead + pa.nchain + zblocks;
+            if (merged) {
+                unsigned *done = reinterpret_cast<unsigned *>(db + hp.o_done);
+                po.zpad = (int)((zblocks + 7) / 8 * 8);
+                if (po.zpad == 0) po.zpad = 8;              // (> 0 marks the merged launch)
+                po.zmblocks = (P->flags & MPQE_STEP_ZERO_GRADS) ? (int)hp.zmats.size() * ta.zper : 0;
+                po.ublocks = ub.nops * ub.chunks;
+                po.ppad = (po.zmblocks + po.ublocks + 7) / 8 * 8;
+                po.wblocks = hp.wblocks_total;
+                po.zper = ta.zper;
+                po.D = D;
+                po.zeroed = (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0;
+                po.ub = ub;
+                po.ub.done = done;
+                po.ub.done_inc = reinterpret_cast<const int *>(db + hp.o_done_inc);
+                po.ub.dm = hp.dm;
+                po.ub.fwd_done = pa.fwd_done;
+                po.ub.epoch_m = epoch_f + 48;
+                po.ub.fwd_blocks = pa.ublocks;
+                po.wblock = ta.wblock;
+                po.zmats = ta.zmats;
+                po.slabs = slabs;
+                po.H = H;
+                po.GH = GH;
+                po.level_stride = hp.level_stride;
+                po.gp = gp;
+                po.done = done;
+                po.done_inc = po.ub.done_inc;
+                po.epoch_m = epoch_f + 48;
+                po.err = err;
+                po.stamps = g_tail_stamps && (size_t)po.wblocks <= g_tail_stamp_blocks ? g_tail_stamps : nullptr;
+                grid_blocks = pa.lead + pa.nchain + po.zpad + po.ppad + po.wblocks;
+            }
+            dim3 cgrid((unsigned)grid_blocks);
             mark(s);
-            if (D == 64) hipLaunchKernelGGL((step_chain_kernel<1, 1>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa);
+            if (D == 64) hipLaunchKernelGGL((step_chain_kernel<1, 1>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po);
             else if (D == 128 && (P->flags & MPQE_STEP_NO_KSPLIT))
-                hipLaunchKernelGGL((step_chain_kernel<2, 1>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa);
+                hipLaunchKernelGGL((step_chain_kernel<2, 1>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po);
             else if (D == 128 && (P->flags & MPQE_STEP_EIGHT_WAVES))
-                hipLaunchKernelGGL((step_chain_kernel<2, 2, 8>), cgrid, dim3(512), 0, s, sd, lp, tabs, ca, pa);
+                hipLaunchKernelGGL((step_chain_kernel<2, 2, 8>), cgrid, dim3(512), 0, s, sd, lp, tabs, ca, pa, po);
             else if (D == 128)
-                hipLaunchKernelGGL((step_chain_kernel<4, 2>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa);
-            else hipLaunchKernelGGL((step_chain_kernel<4, 1>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa);
+                hipLaunchKernelGGL((step_chain_kernel<4, 2>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po);
+            else hipLaunchKernelGGL((step_chain_kernel<4, 1>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po);
             mark(s);
         }
         if (!backward) {
@@ -2674,7 +2884,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         // (a side stream for the post-pass / table rows beside the tiles was measured: the cross-stream fork and join
         // cost more than the overlap gains -- 93.8 us per step against 81.8 with everything on one stream)
         mark(s);
-        launch_grad_w(s, 0, hp.wblocks_total);
+        if (!merged) launch_grad_w(s, 0, hp.wblocks_total);
         mark(s);
     }
     // ---- forward
@@ -2780,7 +2990,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                            reinterpret_cast<const Rank1 *>(db + hp.o_rank1), (const float *)VT, epoch_b,
                            reinterpret_cast<const char *>(touch), touch_layout(hp.touch_M, 0).keys,
                            (const float *)(wb + hp.o_DG), tabs,
-                           (sparse_tables || (P->flags & MPQE_STEP_ZERO_GRADS)) ? 1 : 0);
+                           ((sparse_tables || (P->flags & MPQE_STEP_ZERO_GRADS)) ? 1 : 0) | (merged ? 2 : 0));
     }
     return mpqe_launch_status();
 }

@@ -53,7 +53,12 @@ struct ChainOp {
 struct ChainRef {
     int batch, g0, fwd_begin, fwd_count, bwd_begin, bwd_count;
     int tb;               // number of this block among all blocks of the step (batch order): its slot in block_terms
-    int pad1;
+    int done;             // merged launch: the `done` counter of its group of graphs (step.hip: DoneMeta)
+    // what the first loads of the workgroup need, so that they depend on this record alone (not on the batch's):
+    int e0;               // entry (step_touch.h) of anchor slot 0 of graph g0: anchor_off + g0; slot n adds n * B
+    int gi0;              // number of graph g0 among the step's graphs: g_off + g0
+    int B;
+    unsigned meta;        // N | A << 4 | anchor table 0 / 1 / 2 << 8 / 12 / 16 | target table << 20
 };
 
 template <int NCB>
@@ -677,6 +682,7 @@ struct ChainArgs {
     float *DG;              // touch plan (step_touch.h): the table-gradient row of entry e (anchors | + targets | - targets)
                             // is stored to DG[dg_pos[e]] instead of added atomically; NULL = fp32 atomics into the tables
     const int *dg_pos;
+    const int *erow;        // touch plan: row of entry e in its table, resolved at pack time (-1 bad id, -2 resolve here)
     long long Manchor, Gtot;
     float *parts;
     float *block_terms;     // [blocks of the step]: sum of the block's hinge terms (the loss reduction reads these)
@@ -693,6 +699,10 @@ struct ChainArgs {
     const unsigned *epoch_b;             // backward epoch of the packed step (bumped by the reduction launch)
     const unsigned *wt_count;            // transposed-copy workgroups finished, ever (this launch adds wt_blocks)
     int wt_blocks;
+    unsigned *done;                      // merged launch: counters of finished chain workgroups (step.hip: DoneMeta); NULL:
+                                         // the weight gradients and the post-pass are a later launch
+    unsigned *arrive;                    // ... and of chain workgroups whose stores have reached the L2
+    const int *done_inc;                 // chain workgroups per counter and step
 };
 
 // phase time stamps of a workgroup: the 100 MHz wall clock is one time base for the whole device, so the
@@ -737,8 +747,8 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     const ChainRef ref = ca.refs[ca.cb];
     if (ref.batch < 0) return;                            // a hole of the placement grid (uniform)
     const BatchDev &b = sd->b[ref.batch];
-    const int N = b.tp.N, A = b.A, L = b.L, g0 = ref.g0;
-    const int ng = b.B - g0 < CH_GB ? b.B - g0 : CH_GB;
+    const int N = (int)(ref.meta & 15u), A = (int)((ref.meta >> 4) & 15u), L = b.L, g0 = ref.g0;
+    const int ng = ref.B - g0 < CH_GB ? ref.B - g0 : CH_GB;
     const int nrows = ng * N;
     const long long row0 = b.row_off + (long long)g0 * N;
     const long long gi0 = b.g_off + g0;
@@ -754,49 +764,78 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
 #if CHAIN_DBG == 4      // experiment: de-synchronise the blocks of an XCD (they read the same matrices in lockstep)
     for (int q = 0; q < (int)((blockIdx.x / 8) % 4) * 6; ++q) __builtin_amdgcn_s_sleep(127);
 #endif
-    // ---- phase A1: where every row comes from (threads 0 .. 95: node rows, + targets, - targets)
+    // ---- phase A1: where every row comes from (threads 0 .. 95: node rows, + targets, - targets). With a touch plan the
+    // id -> LUT -> row hops were done at pack time (erow) and the entry number comes from the workgroup's own record: ONE
+    // round trip (entry -> {row, position in DG}) stands between the record and the row gather; the programme's ops and
+    // the batch record travel beside it.
+    const int nops = ref.fwd_count + ref.bwd_count;
+    ChainOp op;
+    if (tid < nops) op = ca.ops[ref.fwd_begin + tid];
     if (tid < 4 * CH_GB + 2 * CH_GB) {
         const float *src = nullptr;
         float *gdst = nullptr;
+        const int rN = (int)(ref.meta & 15u), rA = (int)((ref.meta >> 4) & 15u);
         if (tid < 4 * CH_GB) {
-            const int i = tid / N, n = tid - i * N;       // row r = i * N + n, as in HBM
+            const int i = tid / rN, n = tid - i * rN;       // row r = i * N + n, as in HBM
+            int dgr = 0;
             if (tid < nrows) {
-                if (n < A) {
-                    const int tab = b.anchor_tab[n];
-                    const long long id = ca.anchor_ids[b.anchor_off + (long long)n * b.B + g0 + i];
-                    const long long row = table_row(ca.node_map, ca.map_len, id, tabs.rows[tab], ca.err);
+                if (n < rA) {
+                    const int tab = (int)((ref.meta >> (8 + 4 * n)) & 15u);
+                    const long long e = (long long)ref.e0 + (long long)n * ref.B + i;
+                    long long row;
+                    int er = -2;
+                    if (ca.erow) {
+                        er = ca.erow[e];
+                        dgr = ca.dg_pos[e];
+                    }
+                    if (er == -2) row = table_row(ca.node_map, ca.map_len, ca.anchor_ids[e], tabs.rows[tab], ca.err);
+                    else {
+                        row = er;
+                        if (er < 0) flag_error(ca.err, MPQE_FLAG_BAD_NODE_ID);
+                    }
                     if (row >= 0) {
                         src = tabs.table[tab] + row * D;
                         if (tabs.grad[tab]) gdst = tabs.grad[tab] + row * D;
                     }
                 } else {
-                    const long long m = b.var_id[n - A];
+                    const long long m = b.var_id[n - rA];
                     if (m < 0 || m >= ca.num_modes) flag_error(ca.err, MPQE_FLAG_BAD_NODE_ID);
                     else src = ca.mode_emb + m * D;
                 }
             }
             S.gradp[tid] = gdst;
-            if (ca.dg_pos) S.dgrow[tid] = tid < nrows && n < A ? ca.dg_pos[b.anchor_off + (long long)n * b.B + g0 + i] : 0;
+            if (ca.dg_pos) S.dgrow[tid] = dgr;
         } else {
             const int i = (tid - 4 * CH_GB) & (CH_GB - 1);
             const bool is_neg = tid >= 5 * CH_GB;
-            if (ca.dg_pos) S.dgrow[tid] = i < ng ? ca.dg_pos[ca.Manchor + (is_neg ? ca.Gtot : 0) + gi0 + i] : 0;
+            int dgr = 0;
             if (i < ng) {
-                const int tab = b.target_tab;
-                const long long id = is_neg ? ca.negs[gi0 + i] : ca.targets[gi0 + i];
-                const long long row = table_row(ca.node_map, ca.map_len, id, tabs.rows[tab], ca.err);
+                const int tab = (int)((ref.meta >> 20) & 15u);
+                const long long e = ca.Manchor + (is_neg ? ca.Gtot : 0) + ref.gi0 + i;
+                long long row;
+                int er = -2;
+                if (ca.erow) {
+                    er = ca.erow[e];
+                    dgr = ca.dg_pos[e];
+                }
+                if (er == -2)
+                    row = table_row(ca.node_map, ca.map_len, is_neg ? ca.negs[ref.gi0 + i] : ca.targets[ref.gi0 + i],
+                                    tabs.rows[tab], ca.err);
+                else {
+                    row = er;
+                    if (er < 0) flag_error(ca.err, MPQE_FLAG_BAD_NODE_ID);
+                }
                 if (row >= 0) src = tabs.table[tab] + row * D;
             }
+            if (ca.dg_pos) S.dgrow[tid] = dgr;
         }
         S.rowp[tid] = src;
     }
     constexpr int NCV = ChainLds<NCB, KS, NW>::NCV;
     if (tid < NCV) S.cvid[tid] = -2;
     __syncthreads();
-    {   // forward ops then backward ops of this block's programme (the host keeps them adjacent)
-        const int nops = ref.fwd_count + ref.bwd_count;
+    {   // forward ops then backward ops of this block's programme (the host keeps them adjacent; requested above)
         if (tid < nops) {
-            const ChainOp op = ca.ops[ref.fwd_begin + tid];
             if (tid < ref.fwd_count || CHAIN_DBG == 3)      // (3: timing experiment, wrong results)
                 S.wp[tid] = op.mat >= 0 ? pick_layer(lp.basis, op.layer) + (long long)op.mat * D * D
                                         : pick_layer(lp.root, op.layer);
@@ -1114,6 +1153,30 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
                                  ca.parts, blk);
 
     chain_stamp(ca, 5);
+    if (ca.done) {
+        // Merged launch: the H / gH rows and the column sums of this workgroup are what the weight-gradient tiles and
+        // the post-pass of its batch wait for (workgroups of THIS launch, behind the chain workgroups). Every wave drains
+        // its stores (they are in the XCD's L2 then), the workgroup meets and one lane counts it in as ARRIVED. The
+        // workgroup that completes its group of DONE_GRAPHS graphs -- all on one XCD: a batch is dealt out in chunks of 32
+        // workgroups per XCD -- writes the L2 back ONCE for the whole group (release at agent scope; a write-back per
+        // workgroup cost 16 us per step: each one walks the whole L2) and publishes the group. The anchor rows below are
+        // not part of it.
+#ifndef MPQE_EMU
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned inc = (unsigned)ca.done_inc[ref.done];
+            const unsigned before = atomicAdd(ca.arrive + ref.done, 1u);
+            if ((before + 1u) % inc == 0u) {
+#ifndef MPQE_EMU
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                atomicAdd(ca.done + ref.done, inc);
+            }
+        }
+    }
     // ---- anchor rows of gH[0] through the L2 normalisation into the entity-table gradients (fp32 atomics:
     // an entity can occur in several graphs). y comes back from H[0] (this workgroup wrote it; L2).
     if (four) {

@@ -26,7 +26,8 @@ struct TouchHeader {
     int pad[12];
 };
 struct TouchLayout {
-    size_t keys, perm, total;           // device buffer: header, sorted keys [M], pos [M] (entry -> rank in sorted order)
+    size_t keys, perm, erow, total;     // device buffer: header, sorted keys [M], pos [M] (entry -> rank in sorted order),
+                                        // erow [M] (entry -> row of its table, -1 = bad id: the LUT hop, done at pack time)
     size_t w_keys, w_vals, w_tmp, w_tmp_bytes, w_total;      // build workspace
 };
 
@@ -45,6 +46,8 @@ static inline TouchLayout touch_layout(long long M, int key_bits /* 0: the devic
     L.keys = off;
     off += align_up((size_t)M * sizeof(tkey_t), 256);
     L.perm = off;
+    off += align_up((size_t)M * sizeof(int), 256);
+    L.erow = off;
     off += align_up((size_t)M * sizeof(int), 256);
     L.total = off;
     if (key_bits <= 0) return L;
@@ -83,7 +86,8 @@ __global__ __launch_bounds__(256) void touch_keys_kernel(TouchMeta tm, const lon
                                                         const long long *__restrict__ targets,
                                                         const long long *__restrict__ negs,
                                                         const long long *__restrict__ node_map, long long map_len,
-                                                        tkey_t *__restrict__ keys, int *__restrict__ vals, long long M) {
+                                                        tkey_t *__restrict__ keys, int *__restrict__ vals,
+                                                        int *__restrict__ erow, long long M) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= M) return;
     const long long Manchor = tm.anchor_off[tm.nb], G = tm.g_off[tm.nb];
@@ -105,12 +109,17 @@ __global__ __launch_bounds__(256) void touch_keys_kernel(TouchMeta tm, const lon
         id = (e - Manchor) >= G ? negs[gi] : targets[gi];
     }
     tkey_t key = TOUCH_INVALID;
+    int er = -1;
     if (id >= 0 && id < map_len) {
         const long long r = node_map[id];
-        if (r >= 0 && r < tm.table_rows[tab]) key = ((tkey_t)tab << tm.row_bits) | (tkey_t)r;
+        if (r >= 0 && r < tm.table_rows[tab]) {
+            key = ((tkey_t)tab << tm.row_bits) | (tkey_t)r;
+            er = r <= 0x7fffffffll ? (int)r : -2;      // (-2: a table beyond 2^31 rows -- the step resolves the id itself)
+        }
     }
     keys[e] = key;          // (invalid ids sort to the end; the step itself flags them)
     vals[e] = (int)e;
+    if (erow) erow[e] = er;
 }
 
 // pos[vals_sorted[k]] = k

@@ -41,7 +41,57 @@ struct UArgs {
     long long num_modes;
     float *parts;
     int32_t *err;
+    // merged launch (the backward post-pass as workgroups of the chain launch, step.hip: DoneMeta): NULL = the rows of
+    // `parts` and the vectors of the pre-pass come from an EARLIER launch, nothing to wait for
+    const unsigned *done;       // counters of finished chain workgroups
+    const int *done_inc;        // chain workgroups per counter and step
+    DoneMeta dm;
+    const unsigned *fwd_done;   // pre-pass workgroups finished, ever (their plain VT stores are out)
+    const unsigned *epoch_m;    // epoch of the merged launches (targets of both counters)
+    int fwd_blocks;
+    int vt_through;             // merged launch, pre-pass: VT stores written through (uop_publish)
 };
+
+// Merged launch: wait until (a) the pre-pass workgroups of this launch have all finished -- the post-pass reads their
+// vectors from VT with plain loads -- and (b) the chain workgroups of the batches in `mask` have published their rows.
+// One thread per counter polls (agent-scope loads, bounded); ends with a workgroup barrier. Deadlock freedom: the
+// pre-pass and the chain workgroups come before every post-pass workgroup in the launch and wait for none of them.
+__device__ __forceinline__ unsigned uop_poll(const unsigned *p) {
+#ifdef MPQE_EMU
+    return *p;
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void uop_wait_until(const unsigned *p, unsigned want, int32_t *err) {
+    for (int spins = 0; (int)(uop_poll(p) - want) < 0; ++spins) {
+        if (spins >= UOP_SPIN_LIMIT) {
+            flag_error(err, MPQE_FLAG_INTERNAL);
+            break;
+        }
+#ifndef MPQE_EMU
+        __builtin_amdgcn_s_sleep(8);
+#endif
+    }
+}
+__device__ __forceinline__ void uop_wait_prepass(const UArgs &ua) {
+    if (!ua.done || !ua.fwd_done) return;           // (uniform)
+    if (threadIdx.x == 0) uop_wait_until(ua.fwd_done, (*ua.epoch_m + 1u) * (unsigned)ua.fwd_blocks, ua.err);
+    __syncthreads();
+}
+// (kept inline: a real call in these kernels costs a stack and the whole register budget -- measured 150 us per step
+// against 65 with one __noinline__ helper)
+__device__ __forceinline__ void uop_wait_chain(const UArgs &ua, unsigned mask) {
+    if (!ua.done || !mask) return;           // (uniform)
+    const int tid = threadIdx.x;
+    const unsigned ep = *ua.epoch_m + 1u;
+    for (int b = 0; b < MPQE_STEP_MAX_BATCHES; ++b) {
+        if (!((mask >> b) & 1u)) continue;
+        for (int c = ua.dm.base[b] + tid; c < ua.dm.base[b + 1]; c += 256)
+            uop_wait_until(ua.done + c, ep * (unsigned)ua.done_inc[c], ua.err);
+    }
+    __syncthreads();
+}
 
 // p[0] + p[D] + ... (nr terms, in that order)
 #define UOP_RED_AHEAD 32
@@ -66,6 +116,7 @@ template <int D>
 __device__ __forceinline__ void uop_fetch_inputs(const UOp &op, const UArgs &ua, unsigned tag, float *xs) {
     constexpr int NP = UOP_MAX_TERMS * D / 256;          // elements per thread: element idx = tid + 256 q
     const int tid = threadIdx.x, total = op.nterms * D;
+    uop_wait_chain(ua, op.wait_mask);                    // merged launch: the chain workgroups' rows of `parts` (in_kind 3)
     float x[NP];
     const u64 *gp[NP];
     bool pend[NP];
@@ -133,9 +184,18 @@ __device__ __forceinline__ void uop_fetch_inputs(const UOp &op, const UArgs &ua,
 }
 
 __device__ __forceinline__ void uop_publish(const UOp &op, int e, int D, float v, const UArgs &ua, unsigned tag) {
-    ua.VT[(long long)op.out_vec * D + e] = v;
+    if (op.out_gran >= 0) gran_store(ua.gran + (long long)op.out_gran * D + e, tag, v);      // (first: somebody may wait)
     if (op.out_part >= 0) ua.parts[(long long)op.out_part * D + e] = v;
-    if (op.out_gran >= 0) gran_store(ua.gran + (long long)op.out_gran * D + e, tag, v);
+#ifndef MPQE_EMU
+    if (ua.vt_through) {
+        // merged launch, pre-pass: the post-pass workgroups of the SAME launch read these vectors with plain loads, from
+        // other XCDs -- written through to memory at agent scope (the write-through store on the hand-off path of the
+        // post-pass cost 3.4 us per step: there the granule goes first and VT stays a plain store)
+        __hip_atomic_store(ua.VT + (long long)op.out_vec * D + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+#endif
+    ua.VT[(long long)op.out_vec * D + e] = v;
 }
 
 template <int D>
@@ -143,6 +203,8 @@ __device__ __forceinline__ void uop_run(const UOp &op, int chunk, const LayerPtr
                                         const GradPtrs *gp, int zeroed) {
     const int tid = threadIdx.x;
     const unsigned tag = *ua.epoch + 1u;
+    if (op.kind == UOP_R1 || op.kind == UOP_RED || op.kind == UOP_BWD) uop_wait_prepass(ua);
+    if (op.kind == UOP_RED) uop_wait_chain(ua, op.wait_mask);
     if (op.kind == UOP_R1) {
         // rows [64 chunk, 64 chunk + 64) of the matrix: out[i][j] = sum_t u_t[i] v_t[j], t in table order (what the
         // reduction launch computes for a group without slabs). Thread (r, c4): rows r + 8 q, columns 4 c4 + 128 cc.

@@ -102,7 +102,7 @@ class FusedTrainStep(object):
     batches of equal depth together (longest chains first)."""
 
     def __init__(self, model, margin=1.0, lanes=1, prune=True, chain=True, ksplit=True, eight_waves=False,
-                 uniform=True, touch=True, sparse_tables=False):
+                 uniform=True, touch=True, sparse_tables=False, merge_tail=None):
         enc = model.enc
         if not hasattr(enc, 'table') or getattr(enc, 'node_maps', None) is None:
             raise ValueError('FusedTrainStep needs a DirectEncoder built with node_maps')
@@ -114,7 +114,10 @@ class FusedTrainStep(object):
         # speed switches of the library call (include/mpqe_amd.h): identical loss / scores / gradients
         self.flags = ((0 if prune else _capi.STEP_NO_PRUNE) | (0 if chain else _capi.STEP_NO_CHAIN) |
                       (0 if ksplit else _capi.STEP_NO_KSPLIT) | (_capi.STEP_EIGHT_WAVES if eight_waves else 0) |
-                      (0 if uniform else _capi.STEP_NO_UNIFORM))
+                      (0 if uniform else _capi.STEP_NO_UNIFORM) | (0 if merge_tail is None else _capi.STEP_MERGE_TAIL if merge_tail else _capi.STEP_SPLIT_TAIL))
+        # chain form: weight-gradient tiles + backward post-pass as workgroups of the chain launch (True), as a launch of
+        # their own (False), or the library's choice by step size (None; include/mpqe_amd.h MPQE_STEP_MERGE_TAIL)
+        self.merge_tail = merge_tail
         self.uniform = bool(uniform and chain)
         # entity-table gradients summed per table row in a fixed order (touch plan) instead of fp32 atomics
         self.touch = bool(touch and chain)
@@ -351,6 +354,14 @@ class FusedTrainStep(object):
         passes = max(int(packed.batches[i].num_passes) for i in range(packed.nb))
         return (not (self.flags & _capi.STEP_NO_CHAIN) and self.model.emb_dim in (64, 128, 256)
                 and packed.num_graphs <= CHAIN_MAX_GRAPHS and passes <= 5)
+
+    def merged(self, packed):
+        """True when the weight-gradient tiles and the backward post-pass ride in the chain launch (two launches per
+        step; include/mpqe_amd.h MPQE_STEP_MERGE_TAIL -- the library's rule, mirrored for the bench's accounting)."""
+        if not self.uses_chain(packed) or len(packed.lane_begin) > 2 or self.merge_tail is False:
+            return False
+        blocks = sum((int(b) + 15) // 16 for b in packed.sizes)
+        return bool(self.merge_tail) or blocks <= 256 + 256 // 8
 
     def _workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes + 256:

@@ -70,7 +70,7 @@ def oracle_step(params, cfg, node_map, batches, margin):
     return total.item(), per, np.concatenate(sp), np.concatenate(sn)
 
 
-def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=1, lanes=None, flags=0, touch=True):
+def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=1, lanes=None, flags=0, touch=True, repeat=1):
     D = params['mode_embeddings.weight'].shape[1]
     L = cfg['num_layers']
     R = params['layers.0.basis'].shape[0]
@@ -170,10 +170,11 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
         be.check(be.lib.mpqe_step_touch_build(ctypes.byref(P), SB, nb, be.ptr(d_anchor), be.ptr(d_tg), be.ptr(d_ng), tptr, tb,
                                               (be.ptr(twbuf) + 255) // 256 * 256, twb, be.stream), 'touch')
         keep.extend([tbuf, twbuf])
-    be.check(be.lib.mpqe_step_forward_backward(ctypes.byref(P), SB, nb, be.ptr(d_anchor), be.ptr(d_tg),
-                                               be.ptr(d_ng), margin, ctypes.byref(G), backward, be.ptr(loss),
-                                               be.ptr(sp), be.ptr(sn), dptr, dsb, 1, wptr, wsb, be.ptr(err), lanes, None, 0,
-                                               tptr, be.stream), 'step')
+    for rep in range(repeat):       # (repeat > 1: the same packed step again -- its hand-off epochs / counters carry on)
+        be.check(be.lib.mpqe_step_forward_backward(ctypes.byref(P), SB, nb, be.ptr(d_anchor), be.ptr(d_tg),
+                                                   be.ptr(d_ng), margin, ctypes.byref(G), backward, be.ptr(loss),
+                                                   be.ptr(sp), be.ptr(sn), dptr, dsb, 1 if rep == 0 else 0, wptr, wsb,
+                                                   be.ptr(err), lanes, None, 0, tptr, be.stream), 'step')
     grads = {'mode_embeddings.weight': be.get(gmode)}
     for m, g in zip(modes, gtabs):
         grads['enc.feat-%s.weight' % m] = be.get(g)
@@ -262,6 +263,16 @@ def test_fused_step_chain_kernels(be, D, readout, adaptive, shared, L):
     runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_NO_UNIFORM))
     # (the host emulator runs the further variants at D = 64 only: the CPU suite's time budget; the GPU runs them all)
     every = be.name == 'hip' or D == 64
+    if every or readout == 'mp':
+        # merged launch (MPQE_STEP_MERGE_TAIL): weight-gradient tiles + post-pass as workgroups of the chain launch; run
+        # twice -- the second run's counters start from the first one's (targets are epoch x count) -- and with the
+        # call's own zero fill (the whole-root rule)
+        merged = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_MERGE_TAIL)
+        runs.append(merged)
+        for k in got[3]:
+            np.testing.assert_array_equal(merged[3][k], got[3][k], err_msg=k)
+        runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0,
+                             flags=_capi.STEP_MERGE_TAIL | _capi.STEP_ZERO_GRADS, repeat=3))
     if every:
         # entity-table gradients by fp32 atomics instead of the per-row sums of the touch plan
         runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, touch=False))

@@ -27,6 +27,8 @@ def main():
     ap.add_argument('--no-prune', action='store_true')
     ap.add_argument('--out', default='')
     ap.add_argument('--tail', action='store_true', help='time stamps of the weight-gradient launch instead')
+    ap.add_argument('--merged', action='store_true', help='merged launch: chain workgroups and tiles on one clock')
+    ap.add_argument('--merge-tail', action='store_true', help='force the merged launch')
     ap.add_argument('--trace', action='store_true', help='CHAIN_DBG=6 builds: per-item cycle stamps of block 0')
     args = ap.parse_args()
     from mpqe_amd import ops, synthetic
@@ -45,12 +47,51 @@ def main():
                                shared_layers=False, adaptive=adaptive, weight_decay=0).to(dev)
     model.validate = False
     data = bench.StepData(schema, model, args.batch_size, np.random.RandomState(1000), dev)
-    step = FusedTrainStep(model, prune=not args.no_prune)
+    step = FusedTrainStep(model, prune=not args.no_prune, merge_tail=True if (args.merge_tail or args.merged) else None)
     packed = bench.pack_for_fused(step, data)
     assert step.uses_chain(packed), 'this step does not take the chain kernel'
     for _ in range(5):
         step.run(packed)
     torch.cuda.synchronize()
+    if args.merged:
+        # merged launch: chain workgroups and weight-gradient tiles on ONE clock (both stamp sets, one run)
+        cap = 16 * sum((b + 15) // 16 for b in packed.sizes)
+        stamps = torch.zeros(cap * 8, dtype=torch.int64, device=dev)
+        tcap = 4096
+        tst = torch.zeros(tcap * 8, dtype=torch.int64, device=dev)
+        ops.lib().mpqe_debug_chain_stamps(stamps.data_ptr(), cap)
+        ops.lib().mpqe_debug_tail_stamps(tst.data_ptr(), tcap)
+        step.run(packed)
+        torch.cuda.synchronize()
+        ops.lib().mpqe_debug_chain_stamps(None, 0)
+        ops.lib().mpqe_debug_tail_stamps(None, 0)
+        st = stamps.cpu().numpy().reshape(cap, 8)
+        tt = tst.cpu().numpy().reshape(tcap, 8)
+        used = st[:, 6] != 0
+        used[len(used) // 2:] = False                 # (second half of the buffer: shader-clock ticks)
+        st = st[used]
+        t0 = st[:, 0].min()
+        batch = (st[:, 7] >> 40) & 0xff
+        print('chain workgroups: %d, rows published (stamp 5) %.1f..%.1f us, end %.1f..%.1f us'
+              % (len(st), (st[:, 5].min() - t0) * 0.01, (st[:, 5].max() - t0) * 0.01, (st[:, 6].min() - t0) * 0.01,
+                 (st[:, 6].max() - t0) * 0.01))
+        for b in np.unique(batch):
+            m = batch == b
+            print('   batch %2d: %3d workgroups, start %5.1f..%5.1f, rows out %5.1f..%5.1f, end %5.1f'
+                  % (b, m.sum(), (st[m, 0].min() - t0) * 0.01, (st[m, 0].max() - t0) * 0.01, (st[m, 5].min() - t0) * 0.01,
+                     (st[m, 5].max() - t0) * 0.01, (st[m, 6].max() - t0) * 0.01))
+        tt = tt[tt[:, 0] != 0]
+        if len(tt):
+            us = lambda c: (tt[:, c] - t0) * 0.01
+            print('tiles: %d; dispatched %.1f..%.1f us, rows ready (waited) %.1f..%.1f, end %.1f..%.1f'
+                  % (len(tt), us(0).min(), us(0).max(), us(4).min(), us(4).max(), us(1).min(), us(1).max()))
+            order = np.argsort(us(1))
+            print('   [tile, dispatched, ready, first rows, K loop done, end]')
+            for k in list(order[:6]) + list(order[len(order) // 2 - 3: len(order) // 2 + 3]) + list(order[-12:]):
+                print('   %4d  %6.1f %6.1f %6.1f %6.1f %6.1f' % (k, us(0)[k], us(4)[k], us(5)[k], us(6)[k], us(1)[k]))
+            print('   run time after ready: mean %.1f min %.1f max %.1f us' % ((us(1) - us(4)).mean(), (us(1) - us(4)).min(),
+                                                                               (us(1) - us(4)).max()))
+        return
     if args.tail:
         tcap = 4096
         tst = torch.zeros(tcap * 8, dtype=torch.int64, device=dev)
