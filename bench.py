@@ -586,9 +586,23 @@ def main():
             fstep.run(pk)
             torch.cuda.synchronize()
             tp.append((t1 - t0, t2 - t0, time.perf_counter() - t2))
+        # ... and the training-loop regime: pack + run back to back, no synchronisation (the host packs step k + 1 while
+        # the device runs step k): host seconds per step of such a loop
+        t0 = time.perf_counter()
+        for _ in range(100):
+            pk = pack_for_fused(fstep, fresh)
+        t_pack = (time.perf_counter() - t0) / 100
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            fstep.run(pack_for_fused(fstep, fresh))
+        torch.cuda.synchronize()
+        t_loop = (time.perf_counter() - t0) / 100
         out['pack_ms'] = {'host_call': float(np.median([a for a, _, _ in tp])) * 1e3,
                           'until_device_idle': float(np.median([b for _, b, _ in tp])) * 1e3,
-                          'first_run_with_descriptor_upload': float(np.median([c for _, _, c in tp])) * 1e3}
+                          'first_run_with_descriptor_upload': float(np.median([c for _, _, c in tp])) * 1e3,
+                          'host_call_back_to_back': t_pack * 1e3,
+                          'pack_and_run_loop_per_step': t_loop * 1e3}
     if rank == 0:
         flops_fwd, flops_all, bytes_all, launches = layer_work(pool[0], model)
         if use_fused:

@@ -2342,22 +2342,22 @@ extern "C" int mpqe_step_touch_build(const mpqe_step_params_t *P, const mpqe_ste
     th.M = M;
     th.row_bits = rb;
     th.key_bits = kb;
-    upload(s, tb, &th, sizeof(th));
+    // (the header rides along as an argument of the keys kernel, and the sort leaves its permutation in the workspace
+    // for the inversion to read: three launches + the sort's own instead of five + one copy -- pack time is host time)
     tkey_t *keys = reinterpret_cast<tkey_t *>(wb + L.w_keys);
     int *vals = reinterpret_cast<int *>(wb + L.w_vals);
     hipLaunchKernelGGL(touch_keys_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, tm,
                        reinterpret_cast<const long long *>(anchor_ids), reinterpret_cast<const long long *>(targets),
                        reinterpret_cast<const long long *>(negs), reinterpret_cast<const long long *>(P->node_map),
-                       (long long)P->node_map_len, keys, vals, reinterpret_cast<int *>(tb + L.erow), M);
+                       (long long)P->node_map_len, keys, vals, reinterpret_cast<int *>(tb + L.erow), M, th,
+                       reinterpret_cast<TouchHeader *>(tb));
     size_t tmp_bytes = L.w_tmp_bytes;
     // stable: entries of one destination row keep their entry order, so the per-row sums have ONE order
-    int *sorted_vals = reinterpret_cast<int *>(wb + L.w_keys);       // re-used after the sort below has consumed `keys`
+    int *sorted_vals = reinterpret_cast<int *>(wb + L.w_svals);
     if (rocprim::radix_sort_pairs(wb + L.w_tmp, tmp_bytes, (const tkey_t *)keys, reinterpret_cast<tkey_t *>(tb + L.keys),
-                                  (const int *)vals, reinterpret_cast<int *>(tb + L.perm), (size_t)M, 0u, (unsigned)kb,
-                                  s) != hipSuccess)
+                                  (const int *)vals, sorted_vals, (size_t)M, 0u, (unsigned)kb, s) != hipSuccess)
         return MPQE_ERR_LAUNCH;
-    // entry -> rank: pos[perm[k]] = k, through a copy of perm (the inversion scatters over the array it reads)
-    (void)hipMemcpyAsync(sorted_vals, tb + L.perm, (size_t)M * sizeof(int), hipMemcpyDeviceToDevice, s);
+    // entry -> rank: pos[sorted_vals[k]] = k
     hipLaunchKernelGGL(touch_invert_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, (const int *)sorted_vals,
                        reinterpret_cast<int *>(tb + L.perm), M);
     return mpqe_launch_status();

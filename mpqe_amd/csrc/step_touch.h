@@ -28,7 +28,7 @@ struct TouchHeader {
 struct TouchLayout {
     size_t keys, perm, erow, total;     // device buffer: header, sorted keys [M], pos [M] (entry -> rank in sorted order),
                                         // erow [M] (entry -> row of its table, -1 = bad id: the LUT hop, done at pack time)
-    size_t w_keys, w_vals, w_tmp, w_tmp_bytes, w_total;      // build workspace
+    size_t w_keys, w_vals, w_svals, w_tmp, w_tmp_bytes, w_total;      // build workspace
 };
 
 static inline long long touch_entries(const mpqe_step_batch_t *B, int nb) {
@@ -55,6 +55,8 @@ static inline TouchLayout touch_layout(long long M, int key_bits /* 0: the devic
     L.w_keys = off;
     off += align_up((size_t)M * sizeof(tkey_t), 256);
     L.w_vals = off;
+    off += align_up((size_t)M * sizeof(int), 256);
+    L.w_svals = off;
     off += align_up((size_t)M * sizeof(int), 256);
     size_t bytes = 0;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, (const tkey_t *)nullptr, (tkey_t *)nullptr, (const int *)nullptr,
@@ -87,8 +89,10 @@ __global__ __launch_bounds__(256) void touch_keys_kernel(TouchMeta tm, const lon
                                                         const long long *__restrict__ negs,
                                                         const long long *__restrict__ node_map, long long map_len,
                                                         tkey_t *__restrict__ keys, int *__restrict__ vals,
-                                                        int *__restrict__ erow, long long M) {
+                                                        int *__restrict__ erow, long long M, TouchHeader th,
+                                                        TouchHeader *__restrict__ th_out) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e == 0 && th_out) *th_out = th;
     if (e >= M) return;
     const long long Manchor = tm.anchor_off[tm.nb], G = tm.g_off[tm.nb];
     long long id;

@@ -12,6 +12,7 @@ mpqe_step_forward_backward (~15 kernel launches), instead of one launch per op p
 exchange is a single all-reduce of that buffer with no packing copies (mpqe_amd/parallel.py).
 """
 import ctypes
+import time
 
 import numpy as np
 import torch
@@ -221,6 +222,8 @@ class FusedTrainStep(object):
         # descriptors: per (formula, passes) everything that does not depend on the ids is cached (a training run
         # draws from a finite set of formulas); ids go straight into ONE pinned staging buffer (numpy views, no
         # per-batch tensors) and to the device in ONE copy: [anchors (slot-major per batch) | targets | negatives]
+        prof = getattr(self, '_prof', None)       # (tools/pack_profile.py: seconds per section, or None)
+        t0 = time.perf_counter() if prof is not None else 0.0
         SB = (_capi.StepBatch * nb)()
         sizes, acols = [], []
         for i, b in enumerate(batches):
@@ -249,25 +252,37 @@ class FusedTrainStep(object):
             SB[i].weight = float(b.get('weight', 1.0))
             sizes.append(B)
             acols.append(proto[1])
+        if prof is not None:
+            t1 = time.perf_counter(); prof['descriptors'] = prof.get('descriptors', 0.0) + t1 - t0; t0 = t1
         na, ngr = sum(B * A for B, A in zip(sizes, acols)), sum(sizes)
         stage = self._staging(na + 2 * ngr)
         snp = stage.numpy()
-        oa, og = 0, 0
+        oa = 0
+        tl, nl_ = [], []
         for b, B, A in zip(batches, sizes, acols):
-            a = b['anchor_ids']
-            a = a.cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+            a, t, n = b['anchor_ids'], b['targets'], b['negs']
+            if not isinstance(a, np.ndarray):
+                a = a.cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+            if not isinstance(t, np.ndarray):
+                t = t.cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+            if not isinstance(n, np.ndarray):
+                n = n.cpu().numpy() if torch.is_tensor(n) else np.asarray(n)
             if a.shape != (B, A):
                 raise ValueError('anchor_ids must be [B, %d] for %s' % (A, b['formula'].query_type))
-            snp[oa:oa + B * A].reshape(A, B)[...] = a.T
-            t, n = b['targets'], b['negs']
-            t = t.cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
-            n = n.cpu().numpy() if torch.is_tensor(n) else np.asarray(n)
             if t.shape != (B,) or n.shape != (B,):
                 raise ValueError('targets / negs must have one id per query')
-            snp[na + og:na + og + B] = t
-            snp[na + ngr + og:na + ngr + og + B] = n
+            if A == 1:
+                snp[oa:oa + B] = a[:, 0]
+            else:
+                np.copyto(snp[oa:oa + B * A].reshape(A, B), a.T)
+            tl.append(t)
+            nl_.append(n)
             oa += B * A
-            og += B
+        # (targets and negatives of all batches: one concatenation each, straight into the staging buffer)
+        np.concatenate(tl, out=snp[na:na + ngr], casting='unsafe')
+        np.concatenate(nl_, out=snp[na + ngr:na + 2 * ngr], casting='unsafe')
+        if prof is not None:
+            t1 = time.perf_counter(); prof['ids to staging'] = prof.get('ids to staging', 0.0) + t1 - t0; t0 = t1
         ps = PackedStep()
         ps.batches, ps.nb, ps.sizes = SB, nb, sizes
         ps.order, ps.lane_begin = order, lane_begin
@@ -286,6 +301,8 @@ class FusedTrainStep(object):
         self._stage_events[self._stage_next].record()          # the buffer is free again once this copy has run
         ps.anchor_ids, ps.targets, ps.negs = ids[:na], ids[na:na + ngr], ids[na + ngr:]
         ps.num_graphs = int(ngr)
+        if prof is not None:
+            t1 = time.perf_counter(); prof['copy to device'] = prof.get('copy to device', 0.0) + t1 - t0; t0 = t1
         # sizes: functions of the descriptors alone -- cached per descriptor set (one planning pass on a miss; the
         # step's first run takes that plan over)
         skey = (bytes(SB), tuple(lane_begin))
@@ -310,8 +327,12 @@ class FusedTrainStep(object):
         ps.touch, ps.touch_ptr = None, None
         ps.touch_entries = sz[4]
         ps.touch_sizes = (sz[2], sz[3])
+        if prof is not None:
+            t1 = time.perf_counter(); prof['sizes + descriptor buffer'] = prof.get('sizes + descriptor buffer', 0.0) + t1 - t0; t0 = t1
         if self.touch:
             self.build_touch(ps)
+        if prof is not None:
+            t1 = time.perf_counter(); prof['touch plan'] = prof.get('touch plan', 0.0) + t1 - t0
         return ps
 
     def build_touch(self, ps):
@@ -326,14 +347,26 @@ class FusedTrainStep(object):
         if ps.touch is None:
             ps.touch = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
             ps.touch_ptr = (ps.touch.data_ptr() + 255) // 256 * 256
-        ws = torch.empty(wbytes + 256, dtype=torch.uint8, device=self.device)
-        with torch.cuda.device(self.device):
+        # (build workspace: ONE buffer per step object, grown on demand -- every build runs on the current stream, so the
+        # next build's kernels are ordered behind this one's; pack time is host time, and an allocation + record_stream
+        # per pack was a quarter of the touch plan's)
+        ws = getattr(self, '_touch_ws', None)
+        if ws is None or ws.numel() < wbytes + 256:
+            ws = self._touch_ws = torch.empty(max(wbytes + 256, 1 << 20), dtype=torch.uint8, device=self.device)
+        stream = torch.cuda.current_stream(self.device)
+        if getattr(self, '_touch_ws_stream', None) not in (None, stream.cuda_stream):
+            stream.wait_stream(self._touch_ws_stream_obj)      # (a caller that switched streams: order the re-use)
+        self._touch_ws_stream, self._touch_ws_stream_obj = stream.cuda_stream, stream
+        if torch.cuda.current_device() != self.device.index:
+            with torch.cuda.device(self.device):
+                st = L.mpqe_step_touch_build(ctypes.byref(self.P), ps.batches, ps.nb, ps.anchor_ids.data_ptr(),
+                                             ps.targets.data_ptr(), ps.negs.data_ptr(), ps.touch_ptr, nbytes,
+                                             (ws.data_ptr() + 255) // 256 * 256, wbytes, stream.cuda_stream)
+        else:
             st = L.mpqe_step_touch_build(ctypes.byref(self.P), ps.batches, ps.nb, ps.anchor_ids.data_ptr(),
                                          ps.targets.data_ptr(), ps.negs.data_ptr(), ps.touch_ptr, nbytes,
-                                         (ws.data_ptr() + 255) // 256 * 256, wbytes,
-                                         torch.cuda.current_stream().cuda_stream)
+                                         (ws.data_ptr() + 255) // 256 * 256, wbytes, stream.cuda_stream)
         _capi.check(L, st, 'mpqe_step_touch_build')
-        ws.record_stream(torch.cuda.current_stream())
 
     def _staging(self, n):
         """A pinned host buffer of >= n int64 from a small ring (allocating pinned memory costs more than the rest of

@@ -18,6 +18,15 @@ step = FusedTrainStep(model)
 for _ in range(3):
     pk = bench.pack_for_fused(step, data); step.run(pk)
 torch.cuda.synchronize()
+step._prof = {}
+N = 200
+t = time.perf_counter()
+for _ in range(N):
+    pk = bench.pack_for_fused(step, data)
+tot = time.perf_counter() - t
+torch.cuda.synchronize()
+print('pack: %.1f us per call; sections (us):' % (tot / N * 1e6), {k: round(v / N * 1e6, 1) for k, v in step._prof.items()})
+step._prof = None
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(20):
