@@ -12,6 +12,7 @@ mpqe_step_forward_backward (~15 kernel launches), instead of one launch per op p
 exchange is a single all-reduce of that buffer with no packing copies (mpqe_amd/parallel.py).
 """
 import ctypes
+import sys
 import time
 
 import numpy as np
@@ -24,7 +25,7 @@ from .data_utils import RGCNQueryDataset
 class PackedStep(object):
     __slots__ = ('batches', 'nb', 'anchor_ids', 'targets', 'negs', 'num_graphs', 'ws_bytes', 'sizes',
                  'desc', 'desc_bytes', 'desc_ptr', 'desc_resident', 'lanes', 'order', 'lane_begin', 'touch',
-                 'touch_ptr', 'touch_entries', 'touch_sizes')
+                 'touch_ptr', 'touch_entries', 'touch_sizes', 'desc_ent')
 
 
 _INFO = {}
@@ -145,7 +146,7 @@ class FusedTrainStep(object):
         self.bind_grads()
         self.err = ops.new_error_word(self.device)
         self._ws = None
-        self._desc_cache, self._size_cache = {}, {}
+        self._desc_cache, self._size_cache, self._desc_pool = {}, {}, {}
         self.num_lanes = max(1, min(int(lanes), _capi.STEP_MAX_LANES))
         self._streams = [None] + [torch.cuda.Stream(device=self.device) for _ in range(self.num_lanes - 1)]
         self._fork = torch.cuda.Event()
@@ -320,10 +321,28 @@ class FusedTrainStep(object):
                 self._size_cache.clear()
             self._size_cache[skey] = sz
         ps.ws_bytes, ps.desc_bytes = sz[0], sz[1]
-        # descriptor table of this step: written to HBM by the first run, re-used afterwards
-        ps.desc = torch.empty(ps.desc_bytes + 256, dtype=torch.uint8, device=self.device)
+        # descriptor table of this step: written to HBM by the first run, re-used afterwards. The table is a function of
+        # the descriptor set alone (not of the ids), so a buffer whose packed step is gone serves the next step with the
+        # same set as it is -- table resident, hand-off epochs carried on (they only ever grow): a training loop that
+        # draws fresh ids for a recurring set of formulas uploads nothing. (One stream per FusedTrainStep, as for the
+        # workspace: a re-used buffer's previous step must be ordered before the next one.)
+        pool = self._desc_pool.get(skey)
+        if pool is None:
+            if len(self._desc_pool) > 1024:
+                self._desc_pool.clear()
+            pool = self._desc_pool[skey] = []
+        ent = None
+        for e in pool:
+            if sys.getrefcount(e[0]) == 2:          # (the pool's own reference + getrefcount's argument: nobody else)
+                ent = e
+                break
+        if ent is None:
+            ent = [torch.empty(ps.desc_bytes + 256, dtype=torch.uint8, device=self.device), False]
+            if len(pool) < 8:
+                pool.append(ent)
+        ps.desc, ps.desc_ent = ent[0], ent
         ps.desc_ptr = (ps.desc.data_ptr() + 255) // 256 * 256
-        ps.desc_resident = False
+        ps.desc_resident = ent[1]
         ps.touch, ps.touch_ptr = None, None
         ps.touch_entries = sz[4]
         ps.touch_sizes = (sz[2], sz[3])
@@ -423,17 +442,23 @@ class FusedTrainStep(object):
             if workspace.numel() < packed.ws_bytes + 256 or workspace.device != self.device:
                 raise ValueError('workspace too small for this packed step')
             wptr = (workspace.data_ptr() + 255) // 256 * 256
-        with torch.cuda.device(self.device):
-            st = ops.lib().mpqe_step_forward_backward(
-                ctypes.byref(self.P), packed.batches, packed.nb, packed.anchor_ids.data_ptr(),
+        L = ops.lib()
+        args = (ctypes.byref(self.P), packed.batches, packed.nb, packed.anchor_ids.data_ptr(),
                 packed.targets.data_ptr(), packed.negs.data_ptr(), self.margin, ctypes.byref(self.G),
                 1 if backward else 0, loss.data_ptr(), None if sp is None else sp.data_ptr(),
                 None if sn is None else sn.data_ptr(), packed.desc_ptr, packed.desc_bytes,
                 0 if packed.desc_resident else 1, wptr, packed.ws_bytes, self.err.data_ptr(), packed.lanes,
                 events, 0 if events is None else len(events), packed.touch_ptr,
-                torch.cuda.current_stream().cuda_stream)
-        _capi.check(ops.lib(), st, 'mpqe_step_forward_backward')
+                torch.cuda.current_stream(self.device).cuda_stream)
+        if torch.cuda.current_device() != self.device.index:        # (the context manager costs ~10 us of host time)
+            with torch.cuda.device(self.device):
+                st = L.mpqe_step_forward_backward(*args)
+        else:
+            st = L.mpqe_step_forward_backward(*args)
+        _capi.check(L, st, 'mpqe_step_forward_backward')
         packed.desc_resident = True
+        if getattr(packed, 'desc_ent', None) is not None:
+            packed.desc_ent[1] = True
         if scores:
             return loss, sp, sn
         return loss
