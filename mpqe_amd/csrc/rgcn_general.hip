@@ -21,7 +21,8 @@
 #include "bias_grad.h"
 #include "gemm_core.h"
 
-#define GEN_CHUNK 256   // message slots per weight-gradient K chunk
+#define GEN_CHUNK 512   // message slots per weight-gradient K chunk (256 before the register-only tiles: a tile's fixed
+                        // cost -- records, row ids, first rows, the combine -- is ~3 us against 7.4 us of MFMA time now)
 
 // ------------------------------------------------------------------------------------ plan layout
 struct PlanLayout {
@@ -386,7 +387,13 @@ __global__ __launch_bounds__(256) void rgcn_gen_gemm_kernel(
     const float *__restrict__ a, const float *__restrict__ mask, const float *__restrict__ basis,
     const float *__restrict__ root, int Din, int Dout, float *__restrict__ msg) {
     __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
-    const int t = blockIdx.x;
+    // 1-D grid, 8 row tiles x `ct` column tiles per group: the column tiles of one row tile read the SAME gathered rows,
+    // so they go to ONE XCD (workgroup b runs on XCD b % 8) next to each other -- the rows come from HBM once and from
+    // that XCD's L2 for the other column tiles. (Row tiles along x and column tiles along y ran the column tiles of a
+    // row tile far apart in time: every gathered row from HBM once per column tile.)
+    const int ct = ((TRANS ? Din : Dout) + GT_BN - 1) / GT_BN;
+    const int grp = (int)blockIdx.x / (8 * ct), rem = (int)blockIdx.x - grp * (8 * ct);
+    const int t = grp * 8 + (rem & 7), by = rem >> 3;
     if (t >= tile_ptr[R + 1]) return;
     const int r = find_group(tile_ptr, R + 1, t);
     const int start = rel_ptr[r] + (t - tile_ptr[r]) * GT_BM;
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(256) void rgcn_gen_gemm_kernel(
     const float *W = r < R ? basis + (long long)r * Din * Dout : root;
     const int K = TRANS ? Dout : Din;       // length of an A row
     const int C = TRANS ? Din : Dout;       // output columns
-    const int n0 = blockIdx.y * GT_BN;
+    const int n0 = by * GT_BN;
     const int nsteps = (K + GT_BK - 1) / GT_BK;
 
     f32x16 acc;
@@ -495,6 +502,167 @@ __global__ __launch_bounds__(256) void rgcn_gen_grad_w_kernel(
     }
 }
 
+// The same 64 x 64 tile of one K-chunk with a register-only K loop (Din, Dout multiples of 64, 16-byte aligned rows): the
+// form of the fused step's weight-gradient tiles (grad_w_reg.h) on GATHERED rows. v_mfma_f32_16x16x4_f32: lane (pos, kq)
+// loads the 16 bytes x[row_fwd(q)][i0 + 4 pos ..] and g[row_bwd(q)][j0 + 4 pos ..] of message slot q = q0 + 16 t + 4 wave
+// + kq; MFMA (m, n) takes component m of one and n of the other, so its position (pr, pc) is output element (i0 + 4 pr + m,
+// j0 + 4 pc + n). Two 16-byte row loads (three with the ReLU mask) and two row-id loads feed 16 MFMAs; the row ids are
+// requested 2 x GGR_PF iterations ahead, the rows GGR_PF ahead (a row address needs its id). No LDS, no barrier in the
+// K loop; the four waves split the slots and meet once in LDS, added in wave order (fixed: reproducible).
+// (The LDS-staged 32x32x2 core above spends its K loop on VALU / LDS instructions: 140.9 us = 0.34 of the fp32 MFMA roof
+// at the stress shape.)
+#ifndef GGR_PF
+#define GGR_PF 3        // (2 / 3 / 4 / 6 / 8 measured: 99.4 / 99.2 / 101.4 / 113 / 109 us at the stress shape)
+#endif
+#define GGR_LDT 68
+#ifndef GGR_LDS_TILES
+#define GGR_LDS_TILES 1     // 4: a combine tile per wave, one barrier (2 workgroups per CU); 1: the waves take turns on one tile
+                            // (102.1 against 101.4 us at prefetch 4: the kernel is bound by its gathered reads, not by either)
+#endif
+template <bool RELU>
+__global__ __launch_bounds__(256) void rgcn_gen_grad_w_rows_kernel(
+    const int *__restrict__ rows_fwd, const int *__restrict__ rows_bwd, const int *__restrict__ rel_ptr,
+    const int *__restrict__ chunk_ptr, int R, const float *__restrict__ x, const float *__restrict__ g,
+    const float *__restrict__ out, int Din, int Dout, float *__restrict__ slabs) {
+    __shared__ __attribute__((aligned(16))) float smem[GGR_LDS_TILES * 64 * GGR_LDT];
+    // The tiles of one K-chunk read the SAME rows (each 256-byte piece of an x row by Dout / 64 tiles, of a g row by
+    // Din / 64): they are given to ONE XCD (workgroup b runs on XCD b % 8) and dispatched together, so a piece comes
+    // from HBM once and from that XCD's L2 for the other tiles. 1-D grid; 8 chunks x `tiles` workgroups per group.
+    // (With chunks along x and tiles along y the tiles of a chunk ran far apart in time: every piece from HBM for
+    // every tile, ~700 MB per launch at the stress shape -- the kernel was bandwidth-bound, not MFMA-bound.)
+    const int tiles = (Din / 64) * (Dout / 64);
+    const int grp = (int)blockIdx.x / (8 * tiles), rem = (int)blockIdx.x - grp * (8 * tiles);
+    const int c = grp * 8 + (rem & 7), tile = rem >> 3;
+    // which relation the chunk belongs to: both pointer tables go to LDS in ONE round trip and the search runs there (a
+    // binary search over global memory is ~7 dependent loads in front of a tile of 7 us)
+    int r, q0, q1;
+    if (2 * (R + 2) <= GGR_LDS_TILES * 64 * GGR_LDT) {
+        int *sp = reinterpret_cast<int *>(smem), *sr = sp + (R + 2);
+        for (int i = threadIdx.x; i < R + 2; i += 256) {
+            sp[i] = chunk_ptr[i];
+            sr[i] = rel_ptr[i];
+        }
+        __syncthreads();
+        if (c >= sp[R + 1]) return;         // (uniform)
+        r = find_group(sp, R + 1, c);
+        q0 = sr[r] + (c - sp[r]) * GEN_CHUNK;
+        q1 = q0 + GEN_CHUNK;
+        if (q1 > sr[r + 1]) q1 = sr[r + 1];
+        __syncthreads();                    // (the tables' LDS is the waves' combine space below)
+    } else {
+        if (c >= chunk_ptr[R + 1]) return;
+        r = find_group(chunk_ptr, R + 1, c);
+        q0 = rel_ptr[r] + (c - chunk_ptr[r]) * GEN_CHUNK;
+        q1 = q0 + GEN_CHUNK;
+        if (q1 > rel_ptr[r + 1]) q1 = rel_ptr[r + 1];
+    }
+    const int tiles_j = Dout / 64;
+    const int i0 = (tile / tiles_j) * 64, j0 = (tile % tiles_j) * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pos = lane & 15, kq = lane >> 4;
+    const int niter = (q1 - q0 + 15) / 16;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (q1 > q0) {
+        const float *xa = x + i0 + 4 * pos, *gb = g + j0 + 4 * pos, *ob = RELU ? out + j0 + 4 * pos : nullptr;
+        int IA[GGR_PF], IB[GGR_PF];
+        float live[GGR_PF], live_use[GGR_PF];     // 1 / 0 per slot: ids stage, rows stage (the ids stage runs PF ahead)
+        f32x4 A[GGR_PF], B[GGR_PF], M[RELU ? GGR_PF : 1];
+        auto load_ids = [&](int s, int t) {
+            const int q = q0 + 16 * t + 4 * wave + kq;
+            const int qc = q < q1 ? q : q1 - 1;        // (clamped: a slot beyond the chunk contributes zero)
+            IA[s] = rows_fwd[qc];
+            IB[s] = rows_bwd[qc];
+            live[s] = q < q1 ? 1.f : 0.f;
+        };
+        auto load_rows = [&](int s) {
+            live_use[s] = live[s];
+            A[s] = gload4(xa + (long long)IA[s] * Din);       // (the zero of a slot beyond the chunk is applied at the USE:
+                                                              // a multiply right behind the load would wait for it)
+            B[s] = gload4(gb + (long long)IB[s] * Dout);
+            if (RELU) M[s] = gload4(ob + (long long)IB[s] * Dout);
+        };
+        auto mma = [&](int s) {
+            f32x4 b = B[s];
+            const f32x4 a = A[s] * live_use[s];
+            if (RELU) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) b[k] = M[s][k] > 0.f ? b[k] : 0.f;
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
+        };
+        // prologue: ids of iterations [0, PF), their rows, then the ids of [PF, 2 PF)
+#pragma unroll
+        for (int s = 0; s < GGR_PF; ++s) {
+            load_ids(s, s);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < GGR_PF; ++s) {
+            load_rows(s);
+            __builtin_amdgcn_sched_barrier(0);
+            load_ids(s, s + GGR_PF);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int t = 0; t < niter; t += GGR_PF) {
+#pragma unroll
+            for (int s = 0; s < GGR_PF; ++s) {
+                mma(s);                 // iteration t + s (beyond the chunk: zero operand)
+                __builtin_amdgcn_sched_barrier(0);
+                load_rows(s);           // rows of iteration t + s + PF (ids requested PF iterations ago)
+                __builtin_amdgcn_sched_barrier(0);
+                load_ids(s, t + s + 2 * GGR_PF);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // D[position row 4 kq + r][position col pos] of MFMA (m, n) = element (i0 + 4 (4 kq + r) + m, j0 + 4 pos + n)
+#if GGR_LDS_TILES == 4
+    float *mine = smem + wave * (64 * GGR_LDT);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+            *reinterpret_cast<f32x4 *>(mine + (4 * (4 * kq + rr) + m) * GGR_LDT + 4 * pos) =
+                f32x4{acc[m][0][rr], acc[m][1][rr], acc[m][2][rr], acc[m][3][rr]};
+    __syncthreads();
+#else
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    f32x4 *t = reinterpret_cast<f32x4 *>(smem + (4 * (4 * kq + rr) + m) * GGR_LDT + 4 * pos);
+                    f32x4 v = {acc[m][0][rr], acc[m][1][rr], acc[m][2][rr], acc[m][3][rr]};
+                    if (w > 0) v += *t;
+                    *t = v;
+                }
+        }
+        __syncthreads();
+    }
+#endif
+    float *dst = slabs + (long long)c * Din * Dout;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int f = (int)threadIdx.x + 256 * k;
+        const int row = f >> 4, c4 = f & 15;
+        const float *t0 = smem + row * GGR_LDT + 4 * c4;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(t0);
+#if GGR_LDS_TILES == 4
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4 *>(t0 + w * (64 * GGR_LDT));
+#endif
+        *reinterpret_cast<f32x4 *>(dst + (long long)(i0 + row) * Dout + j0 + 4 * c4) = v;
+    }
+}
+
 // grad[r] += sum of the K-chunk slabs of relation r (r == R: the root matrix), fixed order. A workgroup owns 256
 // consecutive elements (4 per lane, 16-byte loads); its 4 waves each add every 4th slab with four requests in flight,
 // the four sums are combined as (0+1)+(2+3). (One thread per element walking all slabs with dependent loads took
@@ -566,7 +734,7 @@ extern "C" int mpqe_rgcn_general_fwd(const void *plan, int64_t Nn, int64_t E, in
     float *msg = reinterpret_cast<float *>(workspace);
     const bool gvec = (!basis || ptr_vec_ok(basis, Dout)) && ptr_vec_ok(root, Dout) && (Din * Dout) % 4 == 0 &&
                       ptr_vec_ok(x, Din);
-    dim3 grid((unsigned)tile_bound(Nn, E, R), (unsigned)((Dout + GT_BN - 1) / GT_BN));
+    dim3 grid((unsigned)(((tile_bound(Nn, E, R) + 7) / 8 * 8) * ((Dout + GT_BN - 1) / GT_BN)));      // (1-D: see the kernel)
     if (gvec)
         hipLaunchKernelGGL((rgcn_gen_gemm_kernel<false, LD_PRED>), grid, dim3(256), 0, s, P.rows_fwd, P.rel_ptr,
                            P.tile_ptr, (int)R, x, (const float *)nullptr, basis, root, (int)Din, (int)Dout, msg);
@@ -619,7 +787,7 @@ extern "C" int mpqe_rgcn_general_bwd(const void *plan, int64_t Nn, int64_t E, in
                       ptr_vec_ok(grad_out, Dout) && (!relu || ptr_vec_ok(out, Dout)) && ptr_vec_ok(x, Din);
     const float *mask = relu ? out : nullptr;
     if (grad_x) {
-        dim3 grid((unsigned)tile_bound(Nn, E, R), (unsigned)((Din + GT_BN - 1) / GT_BN));
+        dim3 grid((unsigned)(((tile_bound(Nn, E, R) + 7) / 8 * 8) * ((Din + GT_BN - 1) / GT_BN)));
         if (gvec)
             hipLaunchKernelGGL((rgcn_gen_gemm_kernel<true, LD_PRED>), grid, dim3(256), 0, s, P.rows_bwd, P.rel_ptr,
                                P.tile_ptr, (int)R, grad_out, mask, basis, root, (int)Din, (int)Dout, gmsg);
@@ -635,7 +803,15 @@ extern "C" int mpqe_rgcn_general_bwd(const void *plan, int64_t Nn, int64_t E, in
     if (grad_basis || grad_root) {
         const int tiles = (int)(((Din + GT_BM - 1) / GT_BM) * ((Dout + GT_BN - 1) / GT_BN));
         dim3 grid((unsigned)chunk_bound(Nn, E, R), tiles);
-        if (gvec)
+        const bool rows64 = gvec && Din % 64 == 0 && Dout % 64 == 0 && !getenv("MPQE_DBG_GEN_LDS_GRADW");
+        const dim3 grid1((unsigned)(((chunk_bound(Nn, E, R) + 7) / 8 * 8) * tiles));      // (rows kernel: 1-D, see there)
+        if (rows64 && relu && !getenv("MPQE_DBG_GEN_NOMASK"))
+            hipLaunchKernelGGL(rgcn_gen_grad_w_rows_kernel<true>, grid1, dim3(256), 0, s, P.rows_fwd, P.rows_bwd, P.rel_ptr,
+                               P.chunk_ptr, (int)R, x, grad_out, mask, (int)Din, (int)Dout, slabs);
+        else if (rows64)
+            hipLaunchKernelGGL(rgcn_gen_grad_w_rows_kernel<false>, grid1, dim3(256), 0, s, P.rows_fwd, P.rows_bwd, P.rel_ptr,
+                               P.chunk_ptr, (int)R, x, grad_out, mask, (int)Din, (int)Dout, slabs);
+        else if (gvec)
             hipLaunchKernelGGL(rgcn_gen_grad_w_kernel<LD_PRED>, grid, dim3(256), 0, s, P.rows_fwd, P.rows_bwd, P.rel_ptr,
                                P.chunk_ptr, (int)R, x, grad_out, mask, (int)Din, (int)Dout, relu, slabs);
         else

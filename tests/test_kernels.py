@@ -212,6 +212,30 @@ def test_general_layer_heavy_relation_and_odd_dims(be):
         close(g, r, rtol=1e-4, what=k)
 
 
+@pytest.mark.parametrize('relu', [0, 1])
+def test_general_layer_dims_of_64_register_tiles(be, relu):
+    """Din, Dout multiples of 64: the weight gradients take the register-only tile kernel (gathered rows straight
+    into MFMA operands, csrc/rgcn_general.hip: rgcn_gen_grad_w_rows_kernel). Din != Dout, a relation with several K
+    chunks and a ragged last one, a relation with no edge, many edges into one node."""
+    rng = np.random.RandomState(23 + relu)
+    Nn, E, R, Din, Dout = 300, 1100, 5, 128, 64
+    src = rng.randint(0, Nn, size=E)
+    dst = rng.randint(0, Nn, size=E)
+    dst[:150] = 7
+    et = rng.choice([0, 1, 3, 4], size=E, p=[0.6, 0.2, 0.15, 0.05]).astype(np.int64)      # relation 2: no edge
+    ei = np.stack([src, dst]).astype(np.int64)
+    x = rng.randn(Nn, Din).astype(np.float32)
+    basis = (rng.randn(R, Din, Dout) * 0.2).astype(np.float32)
+    root = (rng.randn(Din, Dout) * 0.2).astype(np.float32)
+    bias = rng.randn(Dout).astype(np.float32)
+    gout = rng.randn(Nn, Dout).astype(np.float32)
+    ref = layer_oracle(x, ei, et, basis, root, bias, relu, gout)
+    got, err = run_general(be, x, ei, et, basis, root, bias, relu, gout, Nn)
+    assert err == 0
+    for g, r, k in zip(got, ref, ('out', 'grad_x', 'grad_basis', 'grad_root', 'grad_bias')):
+        close(g, r, rtol=1e-4, what=k)
+
+
 def test_general_plan_flags_bad_indices(be):
     Nn, R = 5, 3
     ei = np.array([[0, 1, 9], [1, -1, 2]], dtype=np.int64)
