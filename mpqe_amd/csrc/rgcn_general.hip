@@ -421,6 +421,128 @@ __global__ __launch_bounds__(256) void rgcn_gen_gemm_kernel(
     }
 }
 
+// The same product with every operand loaded straight into MFMA registers (dims multiples of 64, 16-byte aligned rows):
+// no LDS staging, no barrier. v_mfma_f32_16x16x4_f32 sums over its four k slots in any order and lets the kernel choose
+// which column a lane position stands for:
+//   A   lane (pos, kq) loads the 16 bytes a[row(16 g + pos)][16 it + 4 kq ..]: component u is the A value of MFMA (u, .)
+//       -- k = 16 it + 4 kq + u -- for row group g (a workgroup's 64 gathered rows = 4 groups);
+//   B   for the same k: W[k][n0 + 4 pos .. + 3] (one 16-byte load per u; TRANS: W[n0 + 4 pos + n][16 it + 4 kq ..], one per
+//       n), so position pos stands for the four columns 4 pos + n of MFMAs (., n);
+//   D   lane (pos, kq) ends with out[16 g + 4 kq + r][n0 + 4 pos + n], n = 0..3: 16-byte stores, 256 bytes per row.
+// A wave owns 64 columns and ALL 64 rows of the tile: 8 (12 with the ReLU mask) 16-byte loads feed 64 MFMAs, and the four
+// waves of a workgroup share the gathered rows (one HBM / L2 fetch, L1 hits for the other three). With 256 columns a
+// workgroup covers whole output rows: every gathered row is fetched once per launch.
+// (The LDS-staged 32x32x2 core above: 96 / 111 us forward / transposed at the stress shape = 0.50 / 0.43 of the roof.)
+#ifndef GGM_PF
+#define GGM_PF 2
+#endif
+template <bool TRANS, bool RELU>
+__global__ __launch_bounds__(256) void rgcn_gen_gemm_rows_kernel(
+    const int *__restrict__ rows, const int *__restrict__ rel_ptr, const int *__restrict__ tile_ptr, int R,
+    const float *__restrict__ a, const float *__restrict__ mask, const float *__restrict__ basis,
+    const float *__restrict__ root, int Din, int Dout, float *__restrict__ msg) {
+    // Occupancy by LDS footprint: the forward form runs ONE workgroup per CU (144 KB claimed, 8 KB used), the transposed form
+    // two. Measured at the stress shape, forward: 3 / 2 / 1 workgroups per CU = 139.8 / 114.5 / 86.6 us (transposed: - /
+    // 106.8 / 113.3): with more workgroups in flight the gathered half-lines and the streamed matrices evict each other
+    // from L1 / L2 before their second use, and the MFMA pipe is already full with one wave per SIMD.
+    __shared__ int sp[TRANS ? 2 * 1026 : 36000];
+    const int K = TRANS ? Dout : Din, C = TRANS ? Din : Dout;
+    const int cg = (C + 255) / 256;                        // workgroups per row tile (4 column blocks of 64 each)
+    // (one contiguous eighth of the row tiles per XCD -- a relation's tiles and its matrix on one L2 -- was measured and
+    // is slower: 158 / 127 us forward / transposed against 140 / 106 dealt round-robin, at three / two workgroups per CU)
+    const int grp = (int)blockIdx.x / (8 * cg), rem = (int)blockIdx.x - grp * (8 * cg);
+    const int t = grp * 8 + (rem & 7), by = rem >> 3;
+    int r, start, nrows;
+    if (R + 2 <= 1026) {            // both pointer tables in ONE round trip, the search in LDS
+        int *sr = sp + 1026;
+        for (int i = threadIdx.x; i < R + 2; i += 256) {
+            sp[i] = tile_ptr[i];
+            sr[i] = rel_ptr[i];
+        }
+        __syncthreads();
+        if (t >= sp[R + 1]) return;
+        r = find_group(sp, R + 1, t);
+        start = sr[r] + (t - sp[r]) * GT_BM;
+        nrows = sr[r + 1] - start;
+    } else {
+        if (t >= tile_ptr[R + 1]) return;
+        r = find_group(tile_ptr, R + 1, t);
+        start = rel_ptr[r] + (t - tile_ptr[r]) * GT_BM;
+        nrows = rel_ptr[r + 1] - start;
+    }
+    if (nrows > GT_BM) nrows = GT_BM;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pos = lane & 15, kq = lane >> 4;
+    const int n0 = (by * 4 + wave) * 64;
+    if (n0 >= C || nrows <= 0) return;                     // (no barrier below: a wave without a column block just leaves)
+    const float *W = r < R ? basis + (long long)r * Din * Dout : root;
+    const float *pa[4], *pm[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int rr = 16 * g + pos;
+        const long long id = rows[start + (rr < nrows ? rr : nrows - 1)];      // (clamped: rows beyond the tile are not stored)
+        pa[g] = a + id * K + 4 * kq;
+        pm[g] = RELU ? mask + id * K + 4 * kq : nullptr;
+    }
+    // B: non-TRANS W[(16 it + 4 kq + u)][n0 + 4 pos ..]; TRANS W[(n0 + 4 pos + n)][16 it + 4 kq ..]   (W is [Din][Dout])
+    const float *pw = TRANS ? W + (long long)(n0 + 4 * pos) * Dout + 4 * kq : W + (long long)(4 * kq) * Dout + n0 + 4 * pos;
+    const long long wstep = TRANS ? 16 : 16ll * Dout;      // floats per iteration
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int niter = K / 16;
+    f32x4 A[GGM_PF][4], M[RELU ? GGM_PF : 1][4], B[GGM_PF][4];
+    auto load = [&](int s, int it) {
+        const int ic = it < niter ? it : niter - 1;        // (beyond the end: the last piece again, unused)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            A[s][g] = gload4(pa[g] + 16 * ic);
+            if (RELU) M[s][g] = gload4(pm[g] + 16 * ic);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) B[s][q] = gload4(pw + (long long)ic * wstep + (long long)q * Dout);
+    };
+    auto mma = [&](int s) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 av = A[s][g];
+            if (RELU) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) av[u] = M[s][g][u] > 0.f ? av[u] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], TRANS ? B[s][n][u] : B[s][u][n], acc[g][n], 0, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < GGM_PF; ++s) {
+        load(s, s);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int it = 0; it < niter; it += GGM_PF) {
+#pragma unroll
+        for (int s = 0; s < GGM_PF; ++s) {
+            mma(s);             // iteration it + s (niter is a multiple of 4: K % 64 == 0; GGM_PF divides 4)
+            __builtin_amdgcn_sched_barrier(0);
+            load(s, it + s + GGM_PF);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = 16 * g + 4 * kq + rr;
+            if (row < nrows)
+                *reinterpret_cast<f32x4 *>(msg + (long long)(start + row) * C + n0 + 4 * pos) =
+                    f32x4{acc[g][0][rr], acc[g][1][rr], acc[g][2][rr], acc[g][3][rr]};
+        }
+}
+
 // ------------------------------------------------------------------------------------ segmented sum
 // out[i] = act(bias + msg[E+i] + sum_{k in [ptr[i], ptr[i+1])} msg[list[k]]): one thread owns 4
 // consecutive columns of one row, so a row is read by D/4 adjacent lanes in 16-byte pieces
@@ -735,6 +857,12 @@ extern "C" int mpqe_rgcn_general_fwd(const void *plan, int64_t Nn, int64_t E, in
     const bool gvec = (!basis || ptr_vec_ok(basis, Dout)) && ptr_vec_ok(root, Dout) && (Din * Dout) % 4 == 0 &&
                       ptr_vec_ok(x, Din);
     dim3 grid((unsigned)(((tile_bound(Nn, E, R) + 7) / 8 * 8) * ((Dout + GT_BN - 1) / GT_BN)));      // (1-D: see the kernel)
+    const bool rows64 = gvec && Din % 64 == 0 && Dout % 64 == 0 && !getenv("MPQE_DBG_GEN_LDS_GEMM");
+    if (rows64) {
+        dim3 g1((unsigned)(((tile_bound(Nn, E, R) + 7) / 8 * 8) * ((Dout + 255) / 256)));
+        hipLaunchKernelGGL((rgcn_gen_gemm_rows_kernel<false, false>), g1, dim3(256), 0, s, P.rows_fwd, P.rel_ptr, P.tile_ptr,
+                           (int)R, x, (const float *)nullptr, basis, root, (int)Din, (int)Dout, msg);
+    } else
     if (gvec)
         hipLaunchKernelGGL((rgcn_gen_gemm_kernel<false, LD_PRED>), grid, dim3(256), 0, s, P.rows_fwd, P.rel_ptr,
                            P.tile_ptr, (int)R, x, (const float *)nullptr, basis, root, (int)Din, (int)Dout, msg);
@@ -788,7 +916,15 @@ extern "C" int mpqe_rgcn_general_bwd(const void *plan, int64_t Nn, int64_t E, in
     const float *mask = relu ? out : nullptr;
     if (grad_x) {
         dim3 grid((unsigned)(((tile_bound(Nn, E, R) + 7) / 8 * 8) * ((Din + GT_BN - 1) / GT_BN)));
-        if (gvec)
+        const bool rows64g = gvec && Din % 64 == 0 && Dout % 64 == 0 && !getenv("MPQE_DBG_GEN_LDS_GEMM");
+        dim3 g1((unsigned)(((tile_bound(Nn, E, R) + 7) / 8 * 8) * ((Din + 255) / 256)));
+        if (rows64g && relu)
+            hipLaunchKernelGGL((rgcn_gen_gemm_rows_kernel<true, true>), g1, dim3(256), 0, s, P.rows_bwd, P.rel_ptr, P.tile_ptr,
+                               (int)R, grad_out, mask, basis, root, (int)Din, (int)Dout, gmsg);
+        else if (rows64g)
+            hipLaunchKernelGGL((rgcn_gen_gemm_rows_kernel<true, false>), g1, dim3(256), 0, s, P.rows_bwd, P.rel_ptr, P.tile_ptr,
+                               (int)R, grad_out, mask, basis, root, (int)Din, (int)Dout, gmsg);
+        else if (gvec)
             hipLaunchKernelGGL((rgcn_gen_gemm_kernel<true, LD_PRED>), grid, dim3(256), 0, s, P.rows_bwd, P.rel_ptr,
                                P.tile_ptr, (int)R, grad_out, mask, basis, root, (int)Din, (int)Dout, gmsg);
         else

@@ -23,11 +23,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def run(qt, D, B, R, dev, iters=20):
     from mpqe_amd.model import RGCNConv
-    from oracle import ref_cpu  # template tables only (host ints)
-    t = ref_cpu.TEMPLATES[qt]
-    N = 1 + max(t['src'] + t['dst'])
+    from mpqe_amd.fused import _TEMPLATES            # query type -> (anchors, nodes, [(src, dst)])
+    _, N, edges = _TEMPLATES[qt]
+    src, dst = np.array([e[0] for e in edges]), np.array([e[1] for e in edges])
     offs = (np.arange(B, dtype=np.int64) * N)[:, None]
-    ei = np.stack([(np.array(t['src'])[None] + offs).reshape(-1), (np.array(t['dst'])[None] + offs).reshape(-1)])
+    ei = np.stack([(src[None] + offs).reshape(-1), (dst[None] + offs).reshape(-1)])
     et = np.random.RandomState(0).randint(0, R, size=ei.shape[1]).astype(np.int64)
     conv = RGCNConv(D, D, R, 0).to(dev)
     x = torch.randn(B * N, D, device=dev, requires_grad=True)
