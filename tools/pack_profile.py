@@ -36,3 +36,27 @@ torch.cuda.synchronize()
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(28)
 print(s.getvalue()[:6000])
+
+# the three loops, no synchronisation inside: pack only, run only (one packed step), pack + run
+def loop(fn, n=200):
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n):
+        fn()
+    host = (time.perf_counter() - t) / n
+    torch.cuda.synchronize()
+    return host * 1e6, (time.perf_counter() - t) / n * 1e6
+pk = bench.pack_for_fused(step, data)
+step.run(pk)
+print('pack only: host %.1f us, with device %.1f us per iteration' % loop(lambda: bench.pack_for_fused(step, data)))
+print('run only:  host %.1f us, with device %.1f us per iteration' % loop(lambda: step.run(pk)))
+print('pack+run:  host %.1f us, with device %.1f us per iteration' % loop(lambda: step.run(bench.pack_for_fused(step, data))))
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(50):
+    step.run(bench.pack_for_fused(step, data))
+pr.disable()
+torch.cuda.synchronize()
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(14)
+print(s.getvalue()[:3500])
