@@ -264,13 +264,17 @@ def test_fused_step_chain_kernels(be, D, readout, adaptive, shared, L):
     # (the host emulator runs the further variants at D = 64 only: the CPU suite's time budget; the GPU runs them all)
     every = be.name == 'hip' or D == 64
     if every or readout == 'mp':
-        # merged launch (MPQE_STEP_MERGE_TAIL): weight-gradient tiles + post-pass as workgroups of the chain launch; run
-        # twice -- the second run's counters start from the first one's (targets are epoch x count) -- and with the
-        # call's own zero fill (the whole-root rule)
-        merged = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_MERGE_TAIL)
-        runs.append(merged)
+        # Where the weight-gradient tiles + post-pass run. A step this small takes the MERGED launch by default (workgroups
+        # of the chain launch: include/mpqe_amd.h MPQE_STEP_MERGE_TAIL); the benchmarked step is larger and takes the
+        # SPLIT form (a launch of their own) -- forced here: same gradients bit for bit. Then the merged form forced, three
+        # runs on one descriptor buffer -- the later runs' counters start from the earlier ones' (targets are epoch x
+        # count) -- with the call's own zero fill (the whole-root rule).
+        split = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_SPLIT_TAIL)
+        runs.append(split)
         for k in got[3]:
-            np.testing.assert_array_equal(merged[3][k], got[3][k], err_msg=k)
+            np.testing.assert_array_equal(split[3][k], got[3][k], err_msg=k)
+        runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0,
+                             flags=_capi.STEP_SPLIT_TAIL | _capi.STEP_ZERO_GRADS, repeat=2))
         runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0,
                              flags=_capi.STEP_MERGE_TAIL | _capi.STEP_ZERO_GRADS, repeat=3))
     if every:
