@@ -83,17 +83,10 @@ struct TouchMeta {
     int row_bits;
 };
 
-// entry e -> key (table << row_bits | row of the entity in its table), value e
-__global__ __launch_bounds__(256) void touch_keys_kernel(TouchMeta tm, const long long *__restrict__ anchor_ids,
-                                                        const long long *__restrict__ targets,
-                                                        const long long *__restrict__ negs,
-                                                        const long long *__restrict__ node_map, long long map_len,
-                                                        tkey_t *__restrict__ keys, int *__restrict__ vals,
-                                                        int *__restrict__ erow, long long M, TouchHeader th,
-                                                        TouchHeader *__restrict__ th_out) {
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e == 0 && th_out) *th_out = th;
-    if (e >= M) return;
+// entry e -> key (table << row_bits | row of the entity in its table; TOUCH_INVALID for a bad id) and its table row
+__device__ __forceinline__ tkey_t touch_key_of(const TouchMeta &tm, long long e, const long long *__restrict__ anchor_ids,
+                                               const long long *__restrict__ targets, const long long *__restrict__ negs,
+                                               const long long *__restrict__ node_map, long long map_len, int *er_out) {
     const long long Manchor = tm.anchor_off[tm.nb], G = tm.g_off[tm.nb];
     long long id;
     int tab;
@@ -121,10 +114,30 @@ __global__ __launch_bounds__(256) void touch_keys_kernel(TouchMeta tm, const lon
             er = r <= 0x7fffffffll ? (int)r : -2;      // (-2: a table beyond 2^31 rows -- the step resolves the id itself)
         }
     }
-    keys[e] = key;          // (invalid ids sort to the end; the step itself flags them)
-    vals[e] = (int)e;
+    *er_out = er;
+    return key;
+}
+__global__ __launch_bounds__(256) void touch_keys_kernel(TouchMeta tm, const long long *__restrict__ anchor_ids,
+                                                        const long long *__restrict__ targets,
+                                                        const long long *__restrict__ negs,
+                                                        const long long *__restrict__ node_map, long long map_len,
+                                                        tkey_t *__restrict__ keys, int *__restrict__ vals,
+                                                        int *__restrict__ erow, long long M, TouchHeader th,
+                                                        TouchHeader *__restrict__ th_out) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e == 0 && th_out) *th_out = th;
+    if (e >= M) return;
+    int er;
+    keys[e] = touch_key_of(tm, e, anchor_ids, targets, negs, node_map, map_len, &er);   // (invalid ids sort to the end; the
+    vals[e] = (int)e;                                                                   // step itself flags them)
     if (erow) erow[e] = er;
 }
+
+// (A single-workgroup sort of the whole plan -- one launch instead of rocPRIM's chain of ~6 -- was built and measured: a
+// stable 4-bit LSD radix sort by 1024 threads, 28 entries each. Host time of the build 25 -> 13 us, but 254 us on the
+// device against 45: at 128 VGPRs per thread the entries spill to scratch, and one CU's memory latency is all there is
+// to hide. Not kept. Replaying copy + keys + library sort + inversion as ONE hipGraph costs 10 - 21 us of host time and
+// reproduces the plan (tools/graph_pack_probe.py): the next step for the host side of pack.)
 
 // pos[vals_sorted[k]] = k
 __global__ __launch_bounds__(256) void touch_invert_kernel(const int *__restrict__ sorted_vals, int *__restrict__ pos,
