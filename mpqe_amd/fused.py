@@ -104,7 +104,7 @@ class FusedTrainStep(object):
     batches of equal depth together (longest chains first)."""
 
     def __init__(self, model, margin=1.0, lanes=1, prune=True, chain=True, ksplit=True, eight_waves=False,
-                 uniform=True, touch=True, sparse_tables=False, merge_tail=None):
+                 uniform=True, touch=True, sparse_tables=False, merge_tail=None, graph_pack=True):
         enc = model.enc
         if not hasattr(enc, 'table') or getattr(enc, 'node_maps', None) is None:
             raise ValueError('FusedTrainStep needs a DirectEncoder built with node_maps')
@@ -147,6 +147,7 @@ class FusedTrainStep(object):
         self.err = ops.new_error_word(self.device)
         self._ws = None
         self._desc_cache, self._size_cache, self._desc_pool = {}, {}, {}
+        self.graph_pack, self._slots = bool(graph_pack), []
         self.num_lanes = max(1, min(int(lanes), _capi.STEP_MAX_LANES))
         self._streams = [None] + [torch.cuda.Stream(device=self.device) for _ in range(self.num_lanes - 1)]
         self._fork = torch.cuda.Event()
@@ -256,7 +257,67 @@ class FusedTrainStep(object):
         if prof is not None:
             t1 = time.perf_counter(); prof['descriptors'] = prof.get('descriptors', 0.0) + t1 - t0; t0 = t1
         na, ngr = sum(B * A for B, A in zip(sizes, acols)), sum(sizes)
-        stage = self._staging(na + 2 * ngr)
+        ps = PackedStep()
+        ps.lanes = None
+        if len(members) > 1:
+            L = _capi.StepLanes()
+            L.num_lanes = len(members)
+            for i, v in enumerate(lane_begin):
+                L.batch_begin[i] = v
+            L.fork_event = self._fork.cuda_event
+            for l in range(1, len(members)):
+                L.aux_stream[l] = self._streams[l].cuda_stream
+                L.join_event[l] = self._joins[l].cuda_event
+            ps.lanes = ctypes.pointer(L)
+        # sizes: functions of the descriptors alone -- cached per descriptor set (one planning pass on a miss; the
+        # step's first run takes that plan over)
+        skey = (bytes(SB), tuple(lane_begin))
+        sz = self._size_cache.get(skey)
+        if sz is None:
+            lib = ops.lib()
+            sz = (lib.mpqe_step_workspace_bytes(ctypes.byref(self.P), SB, nb, ps.lanes),
+                  lib.mpqe_step_desc_bytes(ctypes.byref(self.P), SB, nb, ps.lanes),
+                  lib.mpqe_step_touch_bytes(ctypes.byref(self.P), SB, nb),
+                  lib.mpqe_step_touch_workspace_bytes(ctypes.byref(self.P), SB, nb),
+                  int(lib.mpqe_step_touch_entries(SB, nb)))
+            if sz[0] == 0:
+                raise _capi.MpqeError('mpqe_step_workspace_bytes rejected the step descriptors')
+            if len(self._size_cache) > 4096:
+                self._size_cache.clear()
+            self._size_cache[skey] = sz
+        ps.ws_bytes, ps.desc_bytes = sz[0], sz[1]
+        # descriptor table of this step: written to HBM by the first run, re-used afterwards. The table is a function of
+        # the descriptor set alone (not of the ids), so a buffer whose packed step is gone serves the next step with the
+        # same set as it is -- table resident, hand-off epochs carried on (they only ever grow): a training loop that
+        # draws fresh ids for a recurring set of formulas uploads nothing. (One stream per FusedTrainStep, as for the
+        # workspace: a re-used buffer's previous step must be ordered before the next one.)
+        pool = self._desc_pool.get(skey)
+        if pool is None:
+            if len(self._desc_pool) > 1024:
+                self._desc_pool.clear()
+                self._slots = []
+            pool = self._desc_pool[skey] = []
+        ent = None
+        for e in pool:
+            if sys.getrefcount(e[0]) == 2:          # (the pool's own reference + getrefcount's argument: nobody else)
+                ent = e
+                break
+        if ent is None:
+            ent = [torch.empty(ps.desc_bytes + 256, dtype=torch.uint8, device=self.device), False, 0]
+            if len(pool) < 8:
+                pool.append(ent)
+        ps.desc, ps.desc_ent = ent[0], ent
+        ps.desc_ptr = (ps.desc.data_ptr() + 255) // 256 * 256
+        ps.desc_resident = ent[1]
+        # A descriptor set that keeps coming back (>= 3 packs) gets a SLOT: its own pinned staging buffer, device id
+        # buffer, touch plan buffer and ONE captured hipGraph of {host-to-device copy, touch-plan build}; from then on a
+        # pack of that set is numpy work + one graph launch (host time of copy + build ~50 -> ~15 us).
+        slot = ent[3] if len(ent) > 3 else None
+        if slot is not None:
+            slot['event'].synchronize()          # (its previous copy has read the staging buffer: long done)
+            stage = slot['stage']
+        else:
+            stage = self._staging(na + 2 * ngr)
         snp = stage.numpy()
         oa = 0
         tl, nl_ = [], []
@@ -284,75 +345,61 @@ class FusedTrainStep(object):
         np.concatenate(nl_, out=snp[na + ngr:na + 2 * ngr], casting='unsafe')
         if prof is not None:
             t1 = time.perf_counter(); prof['ids to staging'] = prof.get('ids to staging', 0.0) + t1 - t0; t0 = t1
-        ps = PackedStep()
         ps.batches, ps.nb, ps.sizes = SB, nb, sizes
         ps.order, ps.lane_begin = order, lane_begin
-        ps.lanes = None
-        if len(members) > 1:
-            L = _capi.StepLanes()
-            L.num_lanes = len(members)
-            for i, v in enumerate(lane_begin):
-                L.batch_begin[i] = v
-            L.fork_event = self._fork.cuda_event
-            for l in range(1, len(members)):
-                L.aux_stream[l] = self._streams[l].cuda_stream
-                L.join_event[l] = self._joins[l].cuda_event
-            ps.lanes = ctypes.pointer(L)
+        ps.num_graphs = int(ngr)
+        ps.touch_entries = sz[4]
+        ps.touch_sizes = (sz[2], sz[3])
+        if slot is not None:
+            slot['graph'].replay()               # copy + touch plan, one launch on the current stream
+            slot['event'].record()
+            ids = slot['ids']
+            ps.anchor_ids, ps.targets, ps.negs = ids[:na], ids[na:na + ngr], ids[na + ngr:]
+            ps.touch, ps.touch_ptr = slot['touch'], slot['touch_ptr']
+            if prof is not None:
+                t1 = time.perf_counter(); prof['graph replay'] = prof.get('graph replay', 0.0) + t1 - t0
+            return ps
         ids = stage.to(self.device, non_blocking=True)
         self._stage_events[self._stage_next].record()          # the buffer is free again once this copy has run
         ps.anchor_ids, ps.targets, ps.negs = ids[:na], ids[na:na + ngr], ids[na + ngr:]
-        ps.num_graphs = int(ngr)
         if prof is not None:
             t1 = time.perf_counter(); prof['copy to device'] = prof.get('copy to device', 0.0) + t1 - t0; t0 = t1
-        # sizes: functions of the descriptors alone -- cached per descriptor set (one planning pass on a miss; the
-        # step's first run takes that plan over)
-        skey = (bytes(SB), tuple(lane_begin))
-        sz = self._size_cache.get(skey)
-        if sz is None:
-            lib = ops.lib()
-            sz = (lib.mpqe_step_workspace_bytes(ctypes.byref(self.P), SB, nb, ps.lanes),
-                  lib.mpqe_step_desc_bytes(ctypes.byref(self.P), SB, nb, ps.lanes),
-                  lib.mpqe_step_touch_bytes(ctypes.byref(self.P), SB, nb),
-                  lib.mpqe_step_touch_workspace_bytes(ctypes.byref(self.P), SB, nb),
-                  int(lib.mpqe_step_touch_entries(SB, nb)))
-            if sz[0] == 0:
-                raise _capi.MpqeError('mpqe_step_workspace_bytes rejected the step descriptors')
-            if len(self._size_cache) > 4096:
-                self._size_cache.clear()
-            self._size_cache[skey] = sz
-        ps.ws_bytes, ps.desc_bytes = sz[0], sz[1]
-        # descriptor table of this step: written to HBM by the first run, re-used afterwards. The table is a function of
-        # the descriptor set alone (not of the ids), so a buffer whose packed step is gone serves the next step with the
-        # same set as it is -- table resident, hand-off epochs carried on (they only ever grow): a training loop that
-        # draws fresh ids for a recurring set of formulas uploads nothing. (One stream per FusedTrainStep, as for the
-        # workspace: a re-used buffer's previous step must be ordered before the next one.)
-        pool = self._desc_pool.get(skey)
-        if pool is None:
-            if len(self._desc_pool) > 1024:
-                self._desc_pool.clear()
-            pool = self._desc_pool[skey] = []
-        ent = None
-        for e in pool:
-            if sys.getrefcount(e[0]) == 2:          # (the pool's own reference + getrefcount's argument: nobody else)
-                ent = e
-                break
-        if ent is None:
-            ent = [torch.empty(ps.desc_bytes + 256, dtype=torch.uint8, device=self.device), False]
-            if len(pool) < 8:
-                pool.append(ent)
-        ps.desc, ps.desc_ent = ent[0], ent
-        ps.desc_ptr = (ps.desc.data_ptr() + 255) // 256 * 256
-        ps.desc_resident = ent[1]
         ps.touch, ps.touch_ptr = None, None
-        ps.touch_entries = sz[4]
-        ps.touch_sizes = (sz[2], sz[3])
-        if prof is not None:
-            t1 = time.perf_counter(); prof['sizes + descriptor buffer'] = prof.get('sizes + descriptor buffer', 0.0) + t1 - t0; t0 = t1
         if self.touch:
             self.build_touch(ps)
         if prof is not None:
             t1 = time.perf_counter(); prof['touch plan'] = prof.get('touch plan', 0.0) + t1 - t0
+        ent[2] += 1
+        if (self.graph_pack and self.touch and ent[2] >= 3 and len(ent) == 3 and ps.lanes is None
+                and len(self._slots) < 64 and ent in self._desc_pool.get(skey, ())):
+            self._make_slot(ent, ps, na, ngr)
         return ps
+
+    def _make_slot(self, ent, ps, na, ngr):
+        """Capture {ids host -> device, touch-plan build} of this descriptor set into a hipGraph over buffers the slot
+        owns (see pack()). One-off cost: torch.cuda.graph synchronises and trims the allocator."""
+        L = ops.lib()
+        n = na + 2 * ngr
+        nbytes, wbytes = ps.touch_sizes
+        slot = {'stage': torch.empty(n, dtype=torch.long, pin_memory=True),
+                'ids': torch.empty(n, dtype=torch.long, device=self.device),
+                'touch': torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device),
+                'ws': torch.empty(wbytes + 256, dtype=torch.uint8, device=self.device),
+                'event': torch.cuda.Event(), 'graph': torch.cuda.CUDAGraph()}
+        slot['touch_ptr'] = (slot['touch'].data_ptr() + 255) // 256 * 256
+        wptr = (slot['ws'].data_ptr() + 255) // 256 * 256
+        ids = slot['ids']
+        side = torch.cuda.Stream(self.device)
+        with torch.cuda.device(self.device):
+            with torch.cuda.graph(slot['graph'], stream=side):
+                ids.copy_(slot['stage'], non_blocking=True)
+                st = L.mpqe_step_touch_build(ctypes.byref(self.P), ps.batches, ps.nb, ids.data_ptr(),
+                                             ids.data_ptr() + 8 * na, ids.data_ptr() + 8 * (na + ngr), slot['touch_ptr'],
+                                             nbytes, wptr, wbytes, torch.cuda.current_stream().cuda_stream)
+        _capi.check(L, st, 'mpqe_step_touch_build (capture)')
+        slot['event'].record()
+        ent.append(slot)
+        self._slots.append(slot)
 
     def build_touch(self, ps):
         """The touch plan of the packed step's ids (include/mpqe_amd.h: mpqe_step_touch_build): which looked-up

@@ -292,3 +292,33 @@ def test_sparse_tables_training_loop():
     for k, p in model.named_parameters():
         # (Adam turns a last-bit difference of a near-zero gradient into lr-sized steps: the tolerance of the dense loop test)
         np.testing.assert_allclose(p.detach().cpu().numpy(), ref[k].detach().cpu().numpy(), rtol=1e-3, atol=2e-3, err_msg=k)
+
+
+def test_pack_of_a_recurring_descriptor_set_replays_a_graph():
+    """From its third pack on, a descriptor set (same formulas, sizes, weights) is packed by refilling a pinned
+    staging buffer and replaying ONE captured hipGraph {ids to the device, touch-plan build} over buffers its slot
+    owns (FusedTrainStep.pack). Fresh ids every pack, two packed steps alive at a time (two slots): losses, scores and
+    every gradient equal those of a step object that packs eagerly (graph_pack=False), bit for bit."""
+    from mpqe_amd.fused import FusedTrainStep
+    model, batches = _setup('mp', True, False)
+    eager = FusedTrainStep(model, graph_pack=False)
+    step = FusedTrainStep(model)
+    rng = np.random.RandomState(3)
+    prev, slots = None, 0
+    for it in range(9):
+        fresh = []
+        for b in batches:                       # same formulas and sizes, ids permuted between the queries
+            p = rng.permutation(len(b['targets']))
+            fresh.append(dict(b, anchor_ids=b['anchor_ids'][p], targets=b['targets'][p], negs=b['negs'][rng.permutation(len(p))]))
+        pk = step.pack(fresh)
+        slots += int(pk.desc_ent is not None and len(pk.desc_ent) > 3)
+        loss, sp, sn = step.run(pk, scores=True)
+        got = {k: p.grad.clone() for k, p in model.named_parameters()}
+        loss, sp, sn = loss.clone(), sp.clone(), sn.clone()
+        rl, rsp, rsn = eager.run(eager.pack(fresh), scores=True)
+        assert torch.equal(loss, rl) and torch.equal(sp, rsp) and torch.equal(sn, rsn), it
+        for k, p in model.named_parameters():
+            assert torch.equal(got[k], p.grad), (it, k)
+        prev = pk                               # (keeps the previous packed step alive: the next pack takes another slot)
+    assert slots >= 4                           # the later packs came out of captured slots
+    assert int(step.err.item()) == 0
