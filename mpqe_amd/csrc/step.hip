@@ -2342,6 +2342,24 @@ extern "C" int mpqe_step_touch_build(const mpqe_step_params_t *P, const mpqe_ste
     th.M = M;
     th.row_bits = rb;
     th.key_bits = kb;
+#ifndef MPQE_EMU
+    if (M <= (long long)TSORT_MAX_BLOCKS * TSORT_THREADS && kb <= 31 && !getenv("MPQE_DBG_TOUCH_ROCPRIM")) {
+        // the whole plan in one launch (step_touch.h: touch_sort_kernel) behind the 4-byte clear of its barrier counter
+        const int nblk = (int)((M + TSORT_THREADS - 1) / TSORT_THREADS);
+        const size_t Mp = (size_t)nblk * TSORT_THREADS;
+        unsigned *ka = reinterpret_cast<unsigned *>(wb + L.w_keys), *kbuf = ka + Mp;      // (the 8-byte key array, halved)
+        unsigned *va = reinterpret_cast<unsigned *>(wb + L.w_vals), *vb = reinterpret_cast<unsigned *>(wb + L.w_svals);
+        unsigned *hist = reinterpret_cast<unsigned *>(wb + L.w_hist), *counter = hist + 4 * 64 * 256;
+        (void)hipMemsetAsync(counter, 0, sizeof(unsigned), s);
+        hipLaunchKernelGGL(touch_sort_kernel, dim3((unsigned)nblk), dim3(TSORT_THREADS), 0, s, tm,
+                           reinterpret_cast<const long long *>(anchor_ids), reinterpret_cast<const long long *>(targets),
+                           reinterpret_cast<const long long *>(negs), reinterpret_cast<const long long *>(P->node_map),
+                           (long long)P->node_map_len, ka, va, kbuf, vb, hist, counter,
+                           reinterpret_cast<tkey_t *>(tb + L.keys), reinterpret_cast<int *>(tb + L.perm),
+                           reinterpret_cast<int *>(tb + L.erow), (int)M, kb, th, reinterpret_cast<TouchHeader *>(tb));
+        return mpqe_launch_status();
+    }
+#endif
     // (the header rides along as an argument of the keys kernel, and the sort leaves its permutation in the workspace
     // for the inversion to read: three launches + the sort's own instead of five + one copy -- pack time is host time)
     tkey_t *keys = reinterpret_cast<tkey_t *>(wb + L.w_keys);

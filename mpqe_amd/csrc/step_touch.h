@@ -28,7 +28,7 @@ struct TouchHeader {
 struct TouchLayout {
     size_t keys, perm, erow, total;     // device buffer: header, sorted keys [M], pos [M] (entry -> rank in sorted order),
                                         // erow [M] (entry -> row of its table, -1 = bad id: the LUT hop, done at pack time)
-    size_t w_keys, w_vals, w_svals, w_tmp, w_tmp_bytes, w_total;      // build workspace
+    size_t w_keys, w_vals, w_svals, w_hist, w_tmp, w_tmp_bytes, w_total;      // build workspace
 };
 
 static inline long long touch_entries(const mpqe_step_batch_t *B, int nb) {
@@ -52,12 +52,15 @@ static inline TouchLayout touch_layout(long long M, int key_bits /* 0: the devic
     L.total = off;
     if (key_bits <= 0) return L;
     off = 0;
+    const size_t Mp = ((size_t)M + 1023) / 1024 * 1024;      // (the one-launch sort works on whole workgroups of 1024)
     L.w_keys = off;
-    off += align_up((size_t)M * sizeof(tkey_t), 256);
+    off += align_up(Mp * sizeof(tkey_t), 256);
     L.w_vals = off;
-    off += align_up((size_t)M * sizeof(int), 256);
+    off += align_up(Mp * sizeof(int), 256);
     L.w_svals = off;
-    off += align_up((size_t)M * sizeof(int), 256);
+    off += align_up(Mp * sizeof(int), 256);
+    L.w_hist = off;                                           // [4 passes][64 workgroups][256] digit counts + the barrier counter
+    off += 4 * 64 * 256 * sizeof(unsigned) + 256;
     size_t bytes = 0;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, (const tkey_t *)nullptr, (tkey_t *)nullptr, (const int *)nullptr,
                                     (int *)nullptr, (size_t)(M > 0 ? M : 1), 0u, (unsigned)key_bits, (hipStream_t) nullptr);
@@ -138,6 +141,145 @@ __global__ __launch_bounds__(256) void touch_keys_kernel(TouchMeta tm, const lon
 // device against 45: at 128 VGPRs per thread the entries spill to scratch, and one CU's memory latency is all there is
 // to hide. Not kept. Replaying copy + keys + library sort + inversion as ONE hipGraph costs 10 - 21 us of host time and
 // reproduces the plan (tools/graph_pack_probe.py): the next step for the host side of pack.)
+
+#ifndef MPQE_EMU
+// The whole touch plan in ONE launch (plans of up to 64 K entries; the library sort is a chain of ~6 launches of 3 - 8 us
+// each, latency-bound at these sizes: ~54 us of device time and ~8 launch calls per pack). NB = ceil(M / 1024) workgroups
+// of 1024 threads, ONE entry per thread, all resident at once; a stable LSD radix sort, 8 bits per pass:
+//   1  digit d of my key; my rank among the entries of MY WAVE with the same digit (eight ballots build the mask of
+//      equal-digit lanes), the wave's count per digit to LDS; thread d adds the 16 wave counts -> the workgroup's count of
+//      digit d, stored to hist[workgroup][d]
+//   -- grid barrier --
+//   2  thread d sums hist[.][d] over ALL workgroups (total of the digit) and over the workgroups before mine; a
+//      256-wide scan of the totals; destination = (entries with a smaller digit) + (same digit, earlier workgroups) +
+//      (same digit, earlier waves of mine) + (same digit, lower lanes of my wave): stable
+//   3  scatter (key, entry) to the other buffer     -- grid barrier --     next pass reads its entry from there;
+//      the LAST pass writes the plan itself: sorted key (64-bit, invalid = all ones) and pos[entry] = rank.
+// Everything that crosses workgroups (keys, entries, histograms) moves through agent-scope atomic stores / loads -- written
+// through to memory, read past the L1 -- so the grid barrier is a counter and nothing else: no L2 write-back, no
+// invalidate. The barrier counter is zeroed by the host before the launch; spins are bounded (a launch that cannot make
+// progress leaves the header's `pad[0]` = 1 instead of hanging).
+#define TSORT_THREADS 1024
+#define TSORT_MAX_BLOCKS 64
+__device__ __forceinline__ unsigned tsort_ld(const unsigned *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void tsort_st(unsigned *p, unsigned v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool tsort_grid_barrier(unsigned *counter, unsigned target) {
+    __shared__ int ok;
+    __syncthreads();            // (every wave's stores are issued; agent-scope stores complete in order with the add below)
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int good = 1;
+        for (int spins = 0; (int)(tsort_ld(counter) - target) < 0; ++spins) {
+            if (spins >= (1 << 22)) {
+                good = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        ok = good;
+    }
+    __syncthreads();
+    return ok != 0;
+}
+__global__ __launch_bounds__(TSORT_THREADS) void touch_sort_kernel(
+    TouchMeta tm, const long long *__restrict__ anchor_ids, const long long *__restrict__ targets,
+    const long long *__restrict__ negs, const long long *__restrict__ node_map, long long map_len, unsigned *ka,
+    unsigned *va, unsigned *kb, unsigned *vb, unsigned *hist /*[workgroups][256]*/, unsigned *counter,
+    tkey_t *__restrict__ keys_out, int *__restrict__ pos, int *__restrict__ erow, int M, int key_bits, TouchHeader th,
+    TouchHeader *__restrict__ th_out) {
+    __shared__ unsigned whist[TSORT_THREADS / 64][256];
+    __shared__ unsigned gbase[256], scan[256];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x, nblk = gridDim.x;
+    const int i = b * TSORT_THREADS + t;
+    unsigned k = 0xffffffffu, v = (unsigned)i;              // (threads beyond M: a key behind every real one, never stored)
+    if (i < M) {
+        int er;
+        const tkey_t key = touch_key_of(tm, i, anchor_ids, targets, negs, node_map, map_len, &er);
+        k = key == TOUCH_INVALID ? 0xffffffffu : (unsigned)key;
+        erow[i] = er;
+    }
+    const int passes = (key_bits + 7) / 8;
+    unsigned *dk = ka, *dv = va;
+    unsigned bar = 0;
+    bool good = true;
+    for (int p = 0; p < passes; ++p) {
+        const unsigned d = (k >> (8 * p)) & 255u;
+        for (int q = t; q < (TSORT_THREADS / 64) * 256; q += TSORT_THREADS) (&whist[0][0])[q] = 0;
+        __syncthreads();
+        unsigned long long peers = ~0ull;                  // lanes of my wave with my digit
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const unsigned long long m = __ballot((d >> bit) & 1u);
+            peers &= ((d >> bit) & 1u) ? m : ~m;
+        }
+        const unsigned below = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
+        if (below == 0) whist[wave][d] = (unsigned)__popcll(peers);
+        __syncthreads();
+        if (t < 256) {                                     // exclusive prefix over my workgroup's waves; its count of digit t
+            unsigned run = 0;
+#pragma unroll
+            for (int w = 0; w < TSORT_THREADS / 64; ++w) {
+                const unsigned c = whist[w][t];
+                whist[w][t] = run;
+                run += c;
+            }
+            tsort_st(hist + ((size_t)p * TSORT_MAX_BLOCKS + b) * 256 + t, run);
+        }
+        bar += (unsigned)nblk;
+        good = tsort_grid_barrier(counter, bar) && good;
+        if (t < 256) {
+            unsigned tot = 0, before = 0;
+            // (plain loads, all in flight together: every pass has its own histogram rows, so no cache of this XCD can hold
+            // a line of them from before their writers' write-through stores -- an agent-scope load per workgroup in a
+            // dependent row was 28 round trips per pass)
+            const unsigned *hp = hist + (size_t)p * TSORT_MAX_BLOCKS * 256 + t;
+            for (int b0 = 0; b0 < nblk; b0 += 16) {
+                unsigned h[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) h[q] = b0 + q < nblk ? hp[(size_t)(b0 + q) * 256] : 0u;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    tot += h[q];
+                    if (b0 + q < b) before += h[q];
+                }
+            }
+            scan[t] = tot;
+            gbase[t] = before - tot;                       // (+ the inclusive scan below = entries with a smaller digit + before)
+        }
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {          // inclusive scan of the digit totals
+            unsigned x = 0;
+            if (t < 256 && t >= off) x = scan[t - off];
+            __syncthreads();
+            if (t < 256) scan[t] += x;
+            __syncthreads();
+        }
+        const unsigned at = gbase[d] + scan[d] + whist[wave][d] + below;
+        if (p + 1 < passes) {
+            tsort_st(dk + at, k);                          // (the padding keys travel too: they stay behind every real key)
+            tsort_st(dv + at, v);
+            bar += (unsigned)nblk;
+            good = tsort_grid_barrier(counter, bar) && good;
+            k = tsort_ld(dk + i);
+            v = tsort_ld(dv + i);
+            dk = dk == ka ? kb : ka;
+            dv = dv == va ? vb : va;
+        } else if (v < (unsigned)M) {                      // the plan: sorted key, rank of the entry
+            keys_out[at] = k == 0xffffffffu ? TOUCH_INVALID : (tkey_t)k;
+            pos[v] = (int)at;
+        }
+    }
+    if (b == 0 && t == 0) {
+        if (!good) th.pad[0] = 1;
+        *th_out = th;
+    }
+}
+#endif
 
 // pos[vals_sorted[k]] = k
 __global__ __launch_bounds__(256) void touch_invert_kernel(const int *__restrict__ sorted_vals, int *__restrict__ pos,

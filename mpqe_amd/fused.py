@@ -297,11 +297,16 @@ class FusedTrainStep(object):
                 self._desc_pool.clear()
                 self._slots = []
             pool = self._desc_pool[skey] = []
+        # (at least three buffers per set take turns even when each packed step dies at once: the pack that re-uses a
+        # buffer waits for the copy that last read its staging memory, three packs back -- never the one just queued)
         ent = None
-        for e in pool:
-            if sys.getrefcount(e[0]) == 2:          # (the pool's own reference + getrefcount's argument: nobody else)
-                ent = e
-                break
+        if len(pool) >= 3:
+            for _ in range(len(pool)):
+                e = pool.pop(0)
+                pool.append(e)
+                if sys.getrefcount(e[0]) == 2:      # (the pool's own reference + getrefcount's argument: nobody else)
+                    ent = e
+                    break
         if ent is None:
             ent = [torch.empty(ps.desc_bytes + 256, dtype=torch.uint8, device=self.device), False, 0]
             if len(pool) < 8:
@@ -371,7 +376,7 @@ class FusedTrainStep(object):
             t1 = time.perf_counter(); prof['touch plan'] = prof.get('touch plan', 0.0) + t1 - t0
         ent[2] += 1
         if (self.graph_pack and self.touch and ent[2] >= 3 and len(ent) == 3 and ps.lanes is None
-                and len(self._slots) < 64 and ent in self._desc_pool.get(skey, ())):
+                and len(self._slots) < 64 and any(e is ent for e in self._desc_pool.get(skey, ()))):
             self._make_slot(ent, ps, na, ngr)
         return ps
 

@@ -305,7 +305,7 @@ def test_pack_of_a_recurring_descriptor_set_replays_a_graph():
     step = FusedTrainStep(model)
     rng = np.random.RandomState(3)
     prev, slots = None, 0
-    for it in range(9):
+    for it in range(15):                        # (three buffers per set take turns; each is captured at its third pack)
         fresh = []
         for b in batches:                       # same formulas and sizes, ids permuted between the queries
             p = rng.permutation(len(b['targets']))

@@ -427,6 +427,77 @@ def test_fused_step_rejects_bad_descriptors(be):
     assert be.lib.mpqe_step_workspace_bytes(ctypes.byref(P), SB, 17, None) == 0         # > MAX_BATCHES
 
 
+@pytest.mark.parametrize('sizes', [(9, 5), (700, 333), (3000, 1111), (11000, 2500)])
+def test_touch_plan_one_launch_equals_library_sort(be, sizes):
+    """The touch plan built in ONE launch (keys, a grid-synchronised stable 8-bit LSD radix sort with one entry per thread,
+    inverse permutation: csrc/step_touch.h touch_sort_kernel; plans of up to 65 536 looked-up ids) is byte for byte the plan
+    of the keys kernel + rocPRIM radix_sort_pairs + inversion (MPQE_DBG_TOUCH_ROCPRIM=1) -- a stable sort has one answer.
+    1 to 61 workgroups, bad ids included. (The host emulator runs workgroups one after the other and has no grid barrier:
+    there both builds take the library-sort stand-in and the test only pins the layout.)"""
+    import os
+    rng = np.random.RandomState(sizes[0])
+    nmodes, rows_per = 3, [70, 40000, 130]
+    node_map = np.full(sum(rows_per) + 1, -1, np.int64)
+    ids_of, o = [], 0
+    perm = rng.permutation(sum(rows_per))
+    for m, r in enumerate(rows_per):
+        ids = np.sort(perm[o:o + r])
+        node_map[ids] = np.arange(r)
+        ids_of.append(ids)
+        o += r
+    B1, B2 = sizes
+    SB = (_capi.StepBatch * 2)()
+    SB[0] = _capi.make_step_batch('3-inter', 1, B1, [0, 0, 0], [0], [0, 1, 1], 2, 1.0)
+    SB[1] = _capi.make_step_batch('1-chain', 1, B2, [0], [0], [1], 1, 1.0)
+    pick = lambda m, n: ids_of[m][rng.randint(len(ids_of[m]), size=n)]
+    anchors = np.concatenate([pick(0, B1), pick(1, B1), pick(1, B1), pick(1, B2)])
+    targets = np.concatenate([pick(2, B1), pick(1, B2)])
+    negs = np.concatenate([pick(2, B1), pick(1, B2)])
+    negs[3] = sum(rows_per)                  # an id of no mode
+    anchors[1] = -7                          # out of range
+    P = _capi.make_step_params(64, 4, 'mp', [0] * nmodes, [r + 1 for r in rows_per], 0, len(node_map), 0, [0], [0], [0])
+    d_nm = be.put(node_map)
+    P.node_map = be.ptr(d_nm)
+    d_a, d_t, d_n = be.put(anchors), be.put(targets), be.put(negs)
+    tb = be.lib.mpqe_step_touch_bytes(ctypes.byref(P), SB, 2)
+    twb = be.lib.mpqe_step_touch_workspace_bytes(ctypes.byref(P), SB, 2)
+    got = []
+    for force_library in (False, True, False):
+        if force_library:
+            os.environ['MPQE_DBG_TOUCH_ROCPRIM'] = '1'
+        try:
+            tbuf, twbuf = be.nbytes(tb + 256), be.nbytes(twb + 256)
+            if be.name == 'emu':
+                tbuf.fill(0)
+                twbuf.fill(0xa5)
+            else:
+                tbuf.zero_()
+                twbuf.fill_(0xa5)             # (the workspace arrives as garbage)
+            tptr = (be.ptr(tbuf) + 255) // 256 * 256
+            be.check(be.lib.mpqe_step_touch_build(ctypes.byref(P), SB, 2, be.ptr(d_a), be.ptr(d_t), be.ptr(d_n), tptr, tb,
+                                                  (be.ptr(twbuf) + 255) // 256 * 256, twb, be.stream), 'touch')
+            raw = np.asarray(be.get(tbuf)).view(np.uint8)
+            off = tptr - be.ptr(tbuf)
+            got.append(raw[off:off + tb].copy())
+        finally:
+            os.environ.pop('MPQE_DBG_TOUCH_ROCPRIM', None)
+    M = int(be.lib.mpqe_step_touch_entries(SB, 2))
+    assert M == 5 * B1 + 3 * B2
+    # header | keys [M] u64 | pos [M] i32 | erow [M] i32, each region 256-byte aligned: compare the used bytes
+    al = lambda n: (n + 255) // 256 * 256
+    o_keys, o_pos = 256, 256 + al(8 * M)
+    o_erow = o_pos + al(4 * M)
+    for other in (got[1], got[2]):
+        np.testing.assert_array_equal(got[0][:64], other[:64])
+        for name, lo, n in (('keys', o_keys, 8 * M), ('pos', o_pos, 4 * M), ('erow', o_erow, 4 * M)):
+            np.testing.assert_array_equal(got[0][lo:lo + n], other[lo:lo + n], err_msg=name)
+    keys = got[0][o_keys:o_keys + 8 * M].view(np.uint64)
+    assert (np.diff(keys.astype(np.float64)) >= 0).all()
+    assert int((keys == np.uint64(2 ** 64 - 1)).sum()) == 2          # the two bad ids, sorted to the end
+    pos = got[0][o_pos:o_pos + 4 * M].view(np.int32)
+    assert sorted(pos.tolist()) == list(range(M))
+
+
 def test_adam_rows_step_equals_torch_sparse_adam(be):
     """mpqe_adam_rows_step on the rows of a touch plan == torch.optim.SparseAdam fed the same per-row gradients (three
     steps, fresh gradients each), and rows outside the plan are not touched at all."""
