@@ -1032,14 +1032,15 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restri
                                                           const Rank1 *__restrict__ rank1,
                                                           const float *__restrict__ VT, unsigned *epoch_b,
                                                           const char *__restrict__ touch, size_t touch_keys,
-                                                          const float *__restrict__ DG, TablePtrs tabs, int table_store) {
+                                                          const float *__restrict__ DG, TablePtrs tabs, int table_store,
+                                                          long long touch_M, int touch_row_bits) {
     // zeroed: this call zero-filled the gradients, so `out` is known to be 0 -- a store replaces the
     // read-modify-write (whose read would be one more dependent round trip at the end of the chain)
     __shared__ f32x4 part[4][64];
     if ((int)blockIdx.y > ngroups) {        // further rows: entity-table gradients, per destination row (step_touch.h).
         // (As workgroups of the weight-gradient launch they are throttled to two per CU by its 64 KB of LDS: 23.6 us
         // for that launch instead of 16.6; here they cost 2.6 us.)
-        table_sum_block(reinterpret_cast<const TouchHeader *>(touch), reinterpret_cast<const tkey_t *>(touch + touch_keys),
+        table_sum_block(touch_M, touch_row_bits, reinterpret_cast<const tkey_t *>(touch + touch_keys),
                         nullptr, DG, D, tabs, table_store & 1, (long long)((int)blockIdx.y - ngroups - 1) * gridDim.x + blockIdx.x);
         return;
     }
@@ -2471,7 +2472,8 @@ extern "C" int mpqe_rows_plan_build(const uint64_t *keys, int64_t n, int row_bit
 // table_grads[t][row] (= or +=) the sum of rows[perm[k]] over the plan's run of key (t, row), in sorted (= input) order
 __global__ __launch_bounds__(256) void rows_sum_kernel(const char *__restrict__ plan, size_t o_keys, size_t o_perm,
                                                        const float *__restrict__ rows, int D, TablePtrs tabs, int store) {
-    table_sum_block(reinterpret_cast<const TouchHeader *>(plan), reinterpret_cast<const tkey_t *>(plan + o_keys),
+    const TouchHeader *th = reinterpret_cast<const TouchHeader *>(plan);
+    table_sum_block(th->M, th->row_bits, reinterpret_cast<const tkey_t *>(plan + o_keys),
                     reinterpret_cast<const int *>(plan + o_perm), rows, D, tabs, store, (long long)blockIdx.x);
 }
 extern "C" int mpqe_table_rows_sum(const void *plan, int64_t n, const float *rows, int64_t dim, float *const *table_grads,
@@ -2565,7 +2567,11 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     bool use_touch = touch != nullptr && use_chain && backward;
     const bool sparse_tables = (P->flags & MPQE_STEP_SPARSE_TABLES) != 0;
     if (sparse_tables && backward && !use_touch) return MPQE_ERR_INVALID_ARG;      // (needs the touch plan and the chain form)
+    int touch_row_bits = 1;         // (= the header of the caller's plan: mpqe_step_touch_build derives it the same way)
     if (use_touch) {
+        long long trows = 1;
+        for (int m = 0; m < P->num_modes; ++m) trows = std::max(trows, (long long)P->table_rows[m]);
+        touch_row_bits = touch_bits(trows);
         if ((uintptr_t)touch % 256 != 0) return MPQE_ERR_INVALID_ARG;
         for (int m = 0; m < P->num_modes; ++m)
             if (G->tables[m] && (uintptr_t)G->tables[m] % 16 != 0) return MPQE_ERR_INVALID_ARG;
@@ -3008,7 +3014,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                            reinterpret_cast<const Rank1 *>(db + hp.o_rank1), (const float *)VT, epoch_b,
                            reinterpret_cast<const char *>(touch), touch_layout(hp.touch_M, 0).keys,
                            (const float *)(wb + hp.o_DG), tabs,
-                           ((sparse_tables || (P->flags & MPQE_STEP_ZERO_GRADS)) ? 1 : 0) | (merged ? 2 : 0));
+                           ((sparse_tables || (P->flags & MPQE_STEP_ZERO_GRADS)) ? 1 : 0) | (merged ? 2 : 0),
+                           (long long)hp.touch_M, touch_row_bits);
     }
     return mpqe_launch_status();
 }

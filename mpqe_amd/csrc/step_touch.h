@@ -296,12 +296,13 @@ __global__ __launch_bounds__(256) void touch_invert_kernel(const int *__restrict
 #define TS_AHEAD 8
 // perm != NULL: the row of sorted position k is DG[perm[k]] (rows that arrive in another order: the data-parallel row
 // exchange, mpqe_table_rows_sum); NULL: DG[k] (the chain kernel stores its rows in sorted position).
+// (M, row_bits: the plan header's fields, by value where the caller knows them -- the fused step does: one round trip less
+// in front of the keys)
 template <class TabsT>
-__device__ __forceinline__ void table_sum_block(const TouchHeader *__restrict__ th, const tkey_t *__restrict__ keys,
+__device__ __forceinline__ void table_sum_block(long long M, int row_bits, const tkey_t *__restrict__ keys,
                                                 const int *__restrict__ perm, const float *__restrict__ DG, int D,
                                                 const TabsT &tabs, int store, long long block) {
     const int lpr = D / 4, per = 256 / lpr;          // positions per workgroup (D = 64 / 128 / 256: 16 / 8 / 4)
-    const long long M = th->M;
     const long long k = block * per + threadIdx.x / lpr;
     const int c = (threadIdx.x % lpr) * 4;
     if (k >= M) return;
@@ -337,8 +338,8 @@ __device__ __forceinline__ void table_sum_block(const TouchHeader *__restrict__ 
         }
         if (!more) break;
     }
-    const int tab = (int)(key >> th->row_bits);
-    const long long row = (long long)(key & ((1ull << th->row_bits) - 1ull));
+    const int tab = (int)(key >> row_bits);
+    const long long row = (long long)(key & ((1ull << row_bits) - 1ull));
     float *g = tabs.grad[0];      // (a runtime index into the by-value table would spill it to scratch)
 #pragma unroll
     for (int m = 1; m < MPQE_STEP_MAX_MODES; ++m)
