@@ -145,6 +145,17 @@ __device__ __forceinline__ f32x4 chain_gran_read4(const unsigned long long *g, u
     }
     return q;
 }
+// one granule (bounded like the above)
+__device__ __forceinline__ float chain_gran_read1(const unsigned long long *g, unsigned tag, int32_t *err) {
+    for (int spins = 0;; ++spins) {
+        const unsigned long long x = chain_gran_load(g);
+        if ((unsigned)(x >> 32) == tag) return __uint_as_float((unsigned)x);
+        if (spins >= (1 << 18)) {
+            flag_error(err, MPQE_FLAG_INTERNAL);
+            return 0.f;
+        }
+    }
+}
 __device__ __forceinline__ float chain_rsq(float x) {
 #ifdef MPQE_EMU
     return 1.f / sqrtf(x);
@@ -307,7 +318,9 @@ struct ChainStep {
 template <int NCB, int KS, bool BWD, int NW>
 __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int first_op, int T /* items */, int N, int ng,
                                           float *__restrict__ Xrows, long long level_stride, int &cur,
-                                          float *parts = nullptr, int blk = 0) {
+                                          float *parts = nullptr, int blk = 0,
+                                          const unsigned long long *cv_gran = nullptr, unsigned cv_tag = 0,
+                                          int32_t *cv_err = nullptr) {
     constexpr int D = 16 * NCB * NW / KS, LDX = D + 4, BUF = 4 * CH_GB * LDX;
     constexpr int CW = NW / KS;                 // column groups of 16 NCB columns
     constexpr int IPO = D / KS / 64;            // items (64 k each) per K-block and wave
@@ -476,9 +489,12 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int c = 0; c < NCB; ++c) v[r][c] = acc[c][r];
-                if (!BWD) chain_lload<NCB>(bv, S.cv + op.part * D + colb);
+                if (!BWD && KS == 1) chain_lload<NCB>(bv, S.cv + op.part * D + colb);
             }
             if (KS > 1) __syncthreads();
+            // (K split: the constant is read BEHIND the hand-off barrier -- the other K part's waves may have fetched it
+            // into LDS only just before they arrived there, see below)
+            if (KS > 1 && finisher && !BWD) chain_lload<NCB>(bv, S.cv + op.part * D + colb);
             if (KS > 1 && !finisher) {
                 if (pend_on) flush_rows();
                 pend_store = !(op.flags & CH_NOSTORE);
@@ -486,6 +502,19 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
                 pend_on = pend_store || (BWD && pend_part >= 0);
                 pend_tile = tile;
                 pend_out = Xrows + (long long)op.level * level_stride + ((long long)(4 * kq) * N + op.node) * D + colb;
+                if (!BWD && cv_gran) {
+                    // K split, forward: the constant vector of the NEXT node update (a pre-pass vector of this launch:
+                    // bias + the products of the node's batch-uniform sources) is fetched HERE, by the waves that do not
+                    // finish node updates, one update ahead of its use -- the gather phase waits only for the FIRST
+                    // update's constant (the later levels' are published microseconds later: waiting for all of them in
+                    // the gather phase held every workgroup until ~8 us into the launch).
+                    constexpr int NCVc = ChainLds<NCB, KS, NW>::NCV;
+                    const int ns = op.part + 1;
+                    if (ns < NCVc && (int)threadIdx.x < D) {
+                        const int id = S.cvid[ns];
+                        if (id >= 0) S.cv[ns * D + threadIdx.x] = chain_gran_read1(cv_gran + (long long)id * D + threadIdx.x, cv_tag, cv_err);
+                    }
+                }
             }
             CHAIN_TRACE(2)
             // MODE 0: plain, 1: ReLU + record the mask bits, 2: mask by the recorded bits. One straight-line
@@ -900,7 +929,8 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
             // constants the pre-pass workgroups of THIS launch produce: read as {tag, value} granules (step_uniform.h),
             // four per thread and attempt, behind the row requests above (whose latency the wait shares)
             const unsigned tag = *ca.epoch_f + 1u;
-            for (int f = tid; f < NCV * (D / 4); f += 256) {
+            // (K split: only the first node update's constant -- the others are fetched one update ahead, chain_run)
+            for (int f = tid; f < (KS > 1 ? 1 : NCV) * (D / 4); f += 256) {
                 const int slot = f / (D / 4), c4 = f - slot * (D / 4);
                 const int id = S.cvid[slot];            // (here: the vector's granule slot)
                 if (id < 0) continue;
@@ -951,7 +981,8 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     if (tid == 0 && ca.backward && ca.wt_count) wt_have0 = chain_count_load(ca.wt_count);
     // ---- forward levels
     int cur = 0;
-    chain_run<NCB, KS, false, NW>(S, 0, ref.fwd_count * IPO, N, ng, ca.H + row0 * D, ca.level_stride, cur);
+    chain_run<NCB, KS, false, NW>(S, 0, ref.fwd_count * IPO, N, ng, ca.H + row0 * D, ca.level_stride, cur, nullptr, 0,
+                                  ca.cv_gran, ca.cv_gran ? *ca.epoch_f + 1u : 0u, ca.err);
 
     chain_stamp(ca, 3);
     if (ca.backward && ref.bwd_count > 0 && ca.wt_count) {
