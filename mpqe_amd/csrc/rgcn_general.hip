@@ -433,8 +433,11 @@ __global__ __launch_bounds__(256) void rgcn_gen_gemm_kernel(
 // waves of a workgroup share the gathered rows (one HBM / L2 fetch, L1 hits for the other three). With 256 columns a
 // workgroup covers whole output rows: every gathered row is fetched once per launch.
 // (The LDS-staged 32x32x2 core above: 96 / 111 us forward / transposed at the stress shape = 0.50 / 0.43 of the roof.)
-#ifndef GGM_PF
-#define GGM_PF 2
+#ifndef GGM_PF_FWD
+#define GGM_PF_FWD 2        // prefetch distance in iterations (forward form at one workgroup per CU: 2 / 4 = 87.3 / 89.5 us)
+#endif
+#ifndef GGM_PF_TRANS
+#define GGM_PF_TRANS 2
 #endif
 template <bool TRANS, bool RELU>
 __global__ __launch_bounds__(256) void rgcn_gen_gemm_rows_kernel(
@@ -492,6 +495,7 @@ __global__ __launch_bounds__(256) void rgcn_gen_gemm_rows_kernel(
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int niter = K / 16;
+    constexpr int GGM_PF = TRANS ? GGM_PF_TRANS : GGM_PF_FWD;
     f32x4 A[GGM_PF][4], M[RELU ? GGM_PF : 1][4], B[GGM_PF][4];
     auto load = [&](int s, int it) {
         const int ic = it < niter ? it : niter - 1;        // (beyond the end: the last piece again, unused)

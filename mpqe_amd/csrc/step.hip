@@ -2825,6 +2825,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                                                               touch_layout(hp.touch_M, 0).perm) : nullptr;
         ca.erow = use_touch ? reinterpret_cast<const int *>(reinterpret_cast<const char *>(touch) +
                                                             touch_layout(hp.touch_M, 0).erow) : nullptr;
+        ca.touch_bad = use_touch ? reinterpret_cast<const TouchHeader *>(touch)->pad : nullptr;
         ca.Manchor = (long long)hp.anchor_off[nb];
         ca.Gtot = hp.sd.graphs_total;
         ca.parts = reinterpret_cast<float *>(wb + hp.o_parts);

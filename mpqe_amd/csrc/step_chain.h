@@ -712,6 +712,7 @@ struct ChainArgs {
                             // is stored to DG[dg_pos[e]] instead of added atomically; NULL = fp32 atomics into the tables
     const int *dg_pos;
     const int *erow;        // touch plan: row of entry e in its table, resolved at pack time (-1 bad id, -2 resolve here)
+    const int *touch_bad;   // touch plan header: != 0 when its one-launch build could not finish (step_touch.h) -> INTERNAL
     long long Manchor, Gtot;
     float *parts;
     float *block_terms;     // [blocks of the step]: sum of the block's hinge terms (the loss reduction reads these)
@@ -784,6 +785,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
 
     chain_stamp(ca, 0);
     chain_stamp_where(ca, ref.batch, ref.fwd_count);
+    if (ca.cb == 0 && tid == 0 && ca.touch_bad && *ca.touch_bad) flag_error(ca.err, MPQE_FLAG_INTERNAL);
 #if CHAIN_DBG == 6
     if (threadIdx.x == 0) {      // trace block 0 only: words [2 G * 8 ...) of the stamp buffer
         S.trace = (ca.stamps && ca.cb == 0) ? ca.stamps + (long long)ca.nchain * 16 : nullptr;
