@@ -105,6 +105,7 @@ struct WBlock {
 // behind the chain workgroups. A chain workgroup counts itself into the `done` counter of its group of DONE_GRAPHS graphs
 // once its H / gH rows and column sums are out (release at agent scope); a tile / vector op waits for the counters of
 // the graphs it reads. Counters only grow: target = (merged-launch epoch + 1) x (chain workgroups of the group).
+#define STEP_XCDS_MAX 8
 #define DONE_GRAPHS 128
 struct DoneMeta {
     int base[MPQE_STEP_MAX_BATCHES + 1];       // counters of batch b: [base[b], base[b + 1])
@@ -369,7 +370,9 @@ struct WBlock;
 struct PostArgs {
     int zpad;                 // zero-fill workgroups, padding included: the post roles start at lead + nchain + zpad; 0 = none
     int zmblocks, ublocks;    // untouched-matrix workgroups, post-pass workgroups
-    int ppad;                 // zmblocks + ublocks rounded up to a multiple of 8 (tile workgroup t keeps XCD t % 8)
+    int ppad;                 // zmblocks + ublocks rounded up to a multiple of na
+    int na;                   // XCDs the post roles are dealt to; xrank: 4 bits per XCD, rank + 1 (0 = none)
+    unsigned xrank;
     int wblocks, zper, D, zeroed;
     UArgs ub;
     const WBlock *wblock;
@@ -423,8 +426,11 @@ __global__ __launch_bounds__(64 * NW) void step_chain_kernel(const StepDev *__re
     } else if (po.zpad == 0 || bid < po.zpad) {
         if ((long long)bid < pa.zs.block0[pa.zs.count]) prep_zero_block(pa.zs, bid);
     } else {
-        if (NW == 4 || threadIdx.x < 256)
-            post_block<(sizeof(S) >= 4 * 64 * GWR_LDT * sizeof(float)) ? 4 : 1>(sd, lp, po, bid - po.zpad,
+        // (post roles only on the XCDs picked for them: workgroup b runs on XCD b % 8; the others leave at once)
+        const int pb = bid - po.zpad;
+        const int rk = (int)((po.xrank >> (4 * (pb & 7))) & 15u) - 1;
+        if (rk >= 0 && (NW == 4 || threadIdx.x < 256))
+            post_block<(sizeof(S) >= 4 * 64 * GWR_LDT * sizeof(float)) ? 4 : 1>(sd, lp, po, (pb >> 3) * po.na + rk,
                                                                                 reinterpret_cast<float *>(&S));
     }
 }
@@ -762,11 +768,12 @@ __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, con
     // one. The `tiles` output tiles of a K-chunk read the SAME rows of H and gH (different column
     // halves), so they are mapped to blocks 8 apart -> one XCD, one L2 fetch of the rows instead of
     // `tiles`. Pure placement: correctness never depends on it.
-    const int span = 8 * tiles;
+    const int nx = po ? po->na : 8;              // XCDs the tile workgroups are dealt to (bid % nx = the XCD's rank)
+    const int span = nx * tiles;
     int vb = bid;
     if (bid < (wblocks_total / span) * span) {
         const int grp = bid / span, r = bid - grp * span;
-        vb = grp * span + (r & 7) * tiles + (r >> 3);
+        vb = grp * span + (r % nx) * tiles + (r / nx);
     }
     const WBlock wk = block_start[vb];       // one record, no search, no second hop
     if (po) {
@@ -1202,6 +1209,7 @@ struct HostPlan {
     size_t o_done_inc, o_done;        // merged launch: chain workgroups per `done` counter (table), the counters (hand-off state)
     std::vector<int> done_inc;
     DoneMeta dm;
+    int post_na, post_rank[STEP_XCDS_MAX];      // merged launch: the XCDs the post roles are dealt to (rank, or -1)
     std::vector<int> whole_roots;     // layers whose ROOT gradient matrix is written whole inside the chain launch (direct
                                       // tiles / a rank-1-only op): the launch's zero fill must leave them alone
     size_t o_bterms;
@@ -2020,6 +2028,44 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                     }
                 }
             }
+            if (l == 0) {
+                // Merged launch: where the post roles (weight-gradient tiles, post-pass) run. They wait in a slot of a CU
+                // until their batch's chain workgroups are done and then compete with the chain workgroups that still
+                // run there -- harmless on the XCDs of LIGHT batches (their chain workgroups are not the launch's
+                // critical path), costly on the XCDs of the heaviest ones. Pick the XCDs that have a free slot per CU
+                // (at most one chain workgroup per CU) and do not host a workgroup of the heaviest programme; failing
+                // that, every XCD.
+                int wmax = 0;
+                for (size_t k = 0; k < progs.size(); ++k) wmax = std::max(wmax, progs[k].work);
+                bool heavy[STEP_XCDS];
+                for (int x = 0; x < STEP_XCDS; ++x) {
+                    heavy[x] = false;
+                    for (size_t k = 0; k < bins[x].size(); ++k)
+                        heavy[x] = heavy[x] || (bins[x][k].fwd_count + bins[x][k].bwd_count) >= wmax;
+                }
+                // ... with room for all of them at once (two workgroups per CU): first the XCDs with a free slot on every CU
+                // that host no workgroup of the heaviest programme, then every XCD without one, then all. (AIFB mix, D = 128,
+                // B per batch 64 / 128: 50.0 / 52.5 us per step with this rule against 51.7 / 55.2 on all XCDs; B = 384:
+                // the first choice is short of room -- 63.0 against 61.0.)
+                const long long need = (long long)hp->wblock.size() + (long long)hp->uops_b.size() * (D / 64);
+                const char *pm = getenv("MPQE_DBG_POST_MODE");      // (timing experiments: force a choice)
+                int na = 0;
+                for (int mode = pm ? atoi(pm) : 0; mode < 3; ++mode) {
+                    long long room = 0;
+                    na = 0;
+                    for (int x = 0; x < STEP_XCDS; ++x) {
+                        const bool ok = mode == 2 || (!heavy[x] && (mode == 1 || bins[x].size() <= cus));
+                        hp->post_rank[x] = ok ? na++ : -1;
+                        if (ok) room += std::max<long long>(0, 2 * (long long)cus - (long long)bins[x].size());
+                    }
+                    if (na > 0 && (room >= need || mode == 2 || pm)) break;
+                }
+                if (na == 0) {
+                    na = STEP_XCDS;
+                    for (int x = 0; x < STEP_XCDS; ++x) hp->post_rank[x] = x;
+                }
+                hp->post_na = na;
+            }
             size_t longest = 0;
             for (int x = 0; x < STEP_XCDS; ++x) {
                 std::vector<ChainRef> &v = bins[x];
@@ -2676,8 +2722,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     memset(&pa, 0, sizeof(pa));
     long long zblocks = 0;
     // merged launch: tiles + post-pass ride in the chain launch (include/mpqe_amd.h: MPQE_STEP_MERGE_TAIL)
-    // Measured (AIFB mix, D = 128, B per batch 32 / 64 / 128 / 256 / 384 / 512 / 8192): merged 51.8 / 53.7 / 58.1 / 60.5 /
-    // 60.6 / 68.3 / 569 us per step against 58.8 / 59.4 / 61.6 / 62.9 / 63.6 / 65.7 / 550 -- it wins while the chain
+    // Measured (AIFB mix, D = 128, B per batch 32 / 64 / 128 / 256 / 384 / 512 / 8192): merged 48.9 / 50.3 / 52.6 / 56.8 /
+    // 61.3 / 68.4 / 569 us per step against 59.8 / 59.4 / 62.0 / 62.9 / 64.8 / 65.2 / 550 -- it wins while the chain
     // workgroups leave a free slot on (almost) every CU, and loses once the tiles have to share CUs with running chain
     // workgroups and queue behind them. Hence: merged up to 9/8 x CUs chain workgroups unless a flag says otherwise.
     const bool merged = use_chain && backward && NL == 1 && !(P->flags & MPQE_STEP_SPLIT_TAIL) &&
@@ -2859,7 +2905,10 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                 if (po.zpad == 0) po.zpad = 8;              // (> 0 marks the merged launch)
                 po.zmblocks = (P->flags & MPQE_STEP_ZERO_GRADS) ? (int)hp.zmats.size() * ta.zper : 0;
                 po.ublocks = ub.nops * ub.chunks;
-                po.ppad = (po.zmblocks + po.ublocks + 7) / 8 * 8;
+                po.na = hp.post_na;
+                po.xrank = 0;
+                for (int x = 0; x < STEP_XCDS; ++x) po.xrank |= (unsigned)(hp.post_rank[x] + 1) << (4 * x);
+                po.ppad = (po.zmblocks + po.ublocks + po.na - 1) / po.na * po.na;
                 po.wblocks = hp.wblocks_total;
                 po.zper = ta.zper;
                 po.D = D;
@@ -2883,7 +2932,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                 po.epoch_m = epoch_f + 48;
                 po.err = err;
                 po.stamps = g_tail_stamps && (size_t)po.wblocks <= g_tail_stamp_blocks ? g_tail_stamps : nullptr;
-                grid_blocks = pa.lead + pa.nchain + po.zpad + po.ppad + po.wblocks;
+                grid_blocks = pa.lead + pa.nchain + po.zpad +
+                              (long long)(po.ppad + po.wblocks + po.na - 1) / po.na * 8;       // (8 workgroups per `na` items)
             }
             dim3 cgrid((unsigned)grid_blocks);
             mark(s);
