@@ -395,13 +395,18 @@ class FusedTrainStep(object):
         wptr = (slot['ws'].data_ptr() + 255) // 256 * 256
         ids = slot['ids']
         side = torch.cuda.Stream(self.device)
-        with torch.cuda.device(self.device):
-            with torch.cuda.graph(slot['graph'], stream=side):
-                ids.copy_(slot['stage'], non_blocking=True)
-                st = L.mpqe_step_touch_build(ctypes.byref(self.P), ps.batches, ps.nb, ids.data_ptr(),
-                                             ids.data_ptr() + 8 * na, ids.data_ptr() + 8 * (na + ngr), slot['touch_ptr'],
-                                             nbytes, wptr, wbytes, torch.cuda.current_stream().cuda_stream)
-        _capi.check(L, st, 'mpqe_step_touch_build (capture)')
+        try:
+            # (thread_local: other threads of the process -- a collective library's watchdog -- may go on calling the runtime)
+            with torch.cuda.device(self.device):
+                with torch.cuda.graph(slot['graph'], stream=side, capture_error_mode='thread_local'):
+                    ids.copy_(slot['stage'], non_blocking=True)
+                    st = L.mpqe_step_touch_build(ctypes.byref(self.P), ps.batches, ps.nb, ids.data_ptr(),
+                                                 ids.data_ptr() + 8 * na, ids.data_ptr() + 8 * (na + ngr), slot['touch_ptr'],
+                                                 nbytes, wptr, wbytes, torch.cuda.current_stream().cuda_stream)
+            _capi.check(L, st, 'mpqe_step_touch_build (capture)')
+        except Exception:
+            self.graph_pack = False         # (a runtime that cannot capture here: packs stay eager, nothing else changes)
+            return
         slot['event'].record()
         ent.append(slot)
         self._slots.append(slot)
