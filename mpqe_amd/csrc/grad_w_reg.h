@@ -31,7 +31,14 @@ __device__ __forceinline__ long long gwr_uniform(long long v) {
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
-template <int LDS_TILES = 4>
+template <int NJ> struct gwr_bvec;
+template <> struct gwr_bvec<4> { typedef f32x4 type; typedef gvec4_ptr gptr; };
+template <> struct gwr_bvec<2> {
+    typedef f32x2 type;
+    typedef const f32x2 __attribute__((address_space(1))) * gptr;
+};
+// NJ: columns of g per lane -- 4: a 64 x 64 tile (16-byte g loads, 16 MFMAs per iteration), 2: 64 x 32 (8-byte g loads, 8 MFMAs)
+template <int LDS_TILES = 4, int NJ = 4>
 __device__ __forceinline__ void grad_w_tile_rows(const float *__restrict__ x, const float *__restrict__ g, int D,
                                                  long long xs, long long xo, long long go, long long q0, long long q1,
                                                  int i0, int j0, float *__restrict__ dst, float *smem, bool accumulate,
@@ -55,15 +62,18 @@ __device__ __forceinline__ void grad_w_tile_rows(const float *__restrict__ x, co
         gwr_uniform(reinterpret_cast<long long>(x + xo * D + i0 + (q0 + 4 * wave) * stride)));
     const char *gw = reinterpret_cast<const char *>(
         gwr_uniform(reinterpret_cast<long long>(g + go * D + j0 + (q0 + 4 * wave) * stride)));
-    const unsigned loff = (unsigned)((kq * stride + 4 * pos) * 4);
+    typedef typename gwr_bvec<NJ>::type bvec;
+    typedef typename gwr_bvec<NJ>::gptr bptr;
+    const unsigned loff = (unsigned)((kq * stride + 4 * pos) * 4), goff = (unsigned)((kq * stride + NJ * pos) * 4);
     const long long step = gwr_uniform(16 * stride * 4);  // bytes per iteration (16 graphs of the workgroup)
     const int nfull = __builtin_amdgcn_readfirstlane((int)((q1 - q0) / 16));     // iterations with all 16 graphs inside
-    f32x4 acc[4][4];
+    f32x4 acc[4][NJ];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 A[GWR_PF], B[GWR_PF];
+        for (int n = 0; n < NJ; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 A[GWR_PF];
+    bvec B[GWR_PF];
     auto load = [&](int slot, int t) {      // t: uniform; beyond the last whole iteration the last one is loaded again (unused)
 #if GWR_DBG == 1                    // (timing experiment: every load hits the same rows)
         const int tc = 0;
@@ -72,9 +82,9 @@ __device__ __forceinline__ void grad_w_tile_rows(const float *__restrict__ x, co
 #endif
         const char *xt = xw + (long long)tc * step, *gt = gw + (long long)tc * step;       // (SALU)
         A[slot] = *(gvec4_ptr)(xt + loff);      // global_load_dwordx4 v, v_loff, s[base]
-        B[slot] = *(gvec4_ptr)(gt + loff);
+        B[slot] = *(bptr)(gt + goff);
     };
-    auto mma = [&](const f32x4 &a, const f32x4 &b) {
+    auto mma = [&](const f32x4 &a, const bvec &b) {
 #if GWR_DBG == 2                    // (timing experiment: loads only)
         asm volatile("" ::"v"(a), "v"(b));
         return;
@@ -82,7 +92,7 @@ __device__ __forceinline__ void grad_w_tile_rows(const float *__restrict__ x, co
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+            for (int n = 0; n < NJ; ++n)
                 acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
     };
     if (nfull > 0) {
@@ -112,7 +122,7 @@ __device__ __forceinline__ void grad_w_tile_rows(const float *__restrict__ x, co
         const long long q = q0 + 16ll * nfull + 4 * wave + kq;
         const long long qc = q < q1 ? q : q1 - 1;
         f32x4 a = gload4(x + xo * D + i0 + 4 * pos + qc * stride);
-        const f32x4 b = gload4(g + go * D + j0 + 4 * pos + qc * stride);
+        const bvec b = *(bptr)(g + go * D + j0 + NJ * pos + qc * stride);
         if (q >= q1) a = f32x4{0.f, 0.f, 0.f, 0.f};
         mma(a, b);
     }
@@ -125,8 +135,12 @@ __device__ __forceinline__ void grad_w_tile_rows(const float *__restrict__ x, co
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                *reinterpret_cast<f32x4 *>(mine + (4 * (4 * kq + r) + m) * GWR_LDT + 4 * pos) =
-                    f32x4{acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
+            {
+                bvec v;
+#pragma unroll
+                for (int n = 0; n < NJ; ++n) v[n] = acc[m][n][r];
+                *reinterpret_cast<bvec *>(mine + (4 * (4 * kq + r) + m) * GWR_LDT + NJ * pos) = v;
+            }
         __syncthreads();
     } else {                            // (a workgroup with less LDS: one tile, the waves add theirs one after the other)
         for (int w = 0; w < 4; ++w) {
@@ -135,8 +149,10 @@ __device__ __forceinline__ void grad_w_tile_rows(const float *__restrict__ x, co
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        f32x4 *t = reinterpret_cast<f32x4 *>(smem + (4 * (4 * kq + r) + m) * GWR_LDT + 4 * pos);
-                        f32x4 v = {acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
+                        bvec *t = reinterpret_cast<bvec *>(smem + (4 * (4 * kq + r) + m) * GWR_LDT + NJ * pos);
+                        bvec v;
+#pragma unroll
+                        for (int n = 0; n < NJ; ++n) v[n] = acc[m][n][r];
                         if (w > 0) v += *t;
                         *t = v;
                     }
@@ -145,9 +161,9 @@ __device__ __forceinline__ void grad_w_tile_rows(const float *__restrict__ x, co
         }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NJ; ++k) {              // the tile's 64 x 4 NJ float4s
         const int f = (int)threadIdx.x + 256 * k;
-        const int row = f >> 4, c4 = f & 15;
+        const int row = f / (4 * NJ), c4 = f % (4 * NJ);
         const float *t0 = smem + row * GWR_LDT + 4 * c4;
         f32x4 v = *reinterpret_cast<const f32x4 *>(t0);
         if constexpr (LDS_TILES == 4) {

@@ -374,6 +374,7 @@ struct PostArgs {
     int na;                   // XCDs the post roles are dealt to; xrank: 4 bits per XCD, rank + 1 (0 = none)
     unsigned xrank;
     int wblocks, zper, D, zeroed;
+    int tile_n;               // columns per weight-gradient tile
     UArgs ub;
     const WBlock *wblock;
     const ZMat *zmats;
@@ -762,8 +763,8 @@ __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, con
                                              const float *__restrict__ H, const float *__restrict__ GH,
                                              long long level_stride, float *__restrict__ slabs, int bid,
                                              int wblocks_total, float *smem, const GradPtrs &gp, bool zeroed,
-                                             long long *dbg, int D, const PostArgs *po = nullptr) {
-    const int tiles_j = (D + GT_BN - 1) / GT_BN, tiles = tiles_j * ((D + GT_BM - 1) / GT_BM);
+                                             long long *dbg, int D, const PostArgs *po = nullptr, int tile_n = GT_BN) {
+    const int tiles_j = (D + tile_n - 1) / tile_n, tiles = tiles_j * ((D + GT_BM - 1) / GT_BM);
     // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2: blocks b and b+8 share
     // one. The `tiles` output tiles of a K-chunk read the SAME rows of H and gH (different column
     // halves), so they are mapped to blocks 8 apart -> one XCD, one L2 fetch of the rows instead of
@@ -803,7 +804,8 @@ __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, con
         }
     }
     if constexpr (MODE == LD_T) {      // chain form (D % 64 == 0, 16-byte aligned rows): register-only K loop
-        grad_w_tile_rows<LDS_TILES>(x, g, D, xs, xo, go, q0, q1, wk.i0, wk.j0, dst, smem, direct && !zeroed, dbg);
+        if (tile_n == 32) grad_w_tile_rows<LDS_TILES, 2>(x, g, D, xs, xo, go, q0, q1, wk.i0, wk.j0, dst, smem, direct && !zeroed, dbg);
+        else grad_w_tile_rows<LDS_TILES, 4>(x, g, D, xs, xo, go, q0, q1, wk.i0, wk.j0, dst, smem, direct && !zeroed, dbg);
         (void)gs; (void)out;
     } else if constexpr (MODE == LD_FAST)      // whole K-steps, D % 64 == 0: deep LDS-DMA pipeline
         // (a form with NO LDS -- every MFMA operand one coalesced global_load_dword into its register, four
@@ -914,6 +916,7 @@ struct TailArgs {
     int zblocks, zper;       // zper = workgroups per matrix
     int ublocks;             // the backward post-pass of the uniform node states: the FIRST ublocks workgroups
     int D;                   // = sd->D, by value: a tile's record is then the first and only load in front of its rows
+    int tile_n;              // columns per weight-gradient tile
 
     const long long *node_map;
     long long map_len;
@@ -957,7 +960,7 @@ __device__ __forceinline__ void post_block(const StepDev *__restrict__ sd, const
         }
 #endif
         grad_w_block<LD_T, LDS_TILES>(sd, nullptr, 0, po.wblock, po.H, po.GH, po.level_stride, po.slabs, tb, po.wblocks,
-                                      smem, po.gp, po.zeroed != 0, dbg, po.D, &po);
+                                      smem, po.gp, po.zeroed != 0, dbg, po.D, &po, po.tile_n);
 #ifndef MPQE_EMU
         if (dbg && threadIdx.x == 0) {
             dbg[1] = (long long)wall_clock64();
@@ -1001,7 +1004,7 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
         return;
     }
     grad_w_block<MODE>(sd, ta.wsrc, ta.nwsrc, ta.wblock, H, GH, level_stride, ta.slabs, tb, ta.wblocks,
-                       smem, gp, zeroed != 0, ta.stamps ? ta.stamps + (long long)blockIdx.x * 8 : nullptr, ta.D);      // zeroed: this call zero-filled the gradients, a store suffices
+                       smem, gp, zeroed != 0, ta.stamps ? ta.stamps + (long long)blockIdx.x * 8 : nullptr, ta.D, nullptr, ta.tile_n);      // zeroed: this call zero-filled the gradients, a store suffices
 #ifndef MPQE_EMU
     if (ta.stamps && threadIdx.x == 0) {
         ta.stamps[(long long)blockIdx.x * 8 + 1] = (long long)wall_clock64();
@@ -1209,6 +1212,7 @@ struct HostPlan {
     size_t o_done_inc, o_done;        // merged launch: chain workgroups per `done` counter (table), the counters (hand-off state)
     std::vector<int> done_inc;
     DoneMeta dm;
+    int tile_n;                       // columns per weight-gradient tile (64; chain form: 32 when tiles would be few)
     int post_na, post_rank[STEP_XCDS_MAX];      // merged launch: the XCDs the post roles are dealt to (rank, or -1)
     std::vector<int> whole_roots;     // layers whose ROOT gradient matrix is written whole inside the chain launch (direct
                                       // tiles / a rank-1-only op): the launch's zero fill must leave them alone
@@ -1479,7 +1483,18 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                      [&](const Key &a, const Key &b) { return key_less(a.layer, a.rel, b.layer, b.rel); });
     std::stable_sort(r1keys.begin(), r1keys.end(),
                      [&](const R1Key &a, const R1Key &b) { return key_less(a.layer, a.rel, b.layer, b.rel); });
-    const int tiles = ct * ((D + GT_BM - 1) / GT_BM);
+    // Weight-gradient tiles of the chain form: 64 x 64 outputs per workgroup. (64 x 32 -- twice as many tiles at half the
+    // MFMA time each, no K split, so no extra slab -- is built in, MPQE_DBG_TILE_N=32, and was measured on the AIFB step:
+    // the tiles end at 11.0 us instead of 14.8, but 320 of them next to the post-pass' 100 vector-op workgroups slow ITS
+    // latency chain from 15 to 18.9 us, and the launch from 19.7 to 23.5.)
+    int tile_n = GT_BN;
+    if (chain && D % 64 == 0) {
+        const char *tn = getenv("MPQE_DBG_TILE_N");         // (timing experiments)
+        if (tn && atoi(tn) == 32) tile_n = 32;
+    }
+    hp->tile_n = tile_n;
+    const int wct = (D + tile_n - 1) / tile_n;            // column tiles of a weight gradient
+    const int tiles = wct * ((D + GT_BM - 1) / GT_BM);
     // Balance: with one K-chunk per source the step has (sources x tiles) workgroups; a few more than there are
     // CUs (264 for the AIFB mix) means a handful of CUs run two whole tiles and the launch lasts twice a tile.
     // Then the surplus is taken out of a few ROOT sources (they go through the reduction anyway), cut into
@@ -1642,8 +1657,8 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                     wkb.go = is_root ? ws.slot - bd.tp.E : bd.tp.dst[ws.slot];
                     wkb.q0 = c * ws.ch;
                     wkb.q1 = wkb.q0 + ws.ch < bd.B ? wkb.q0 + ws.ch : bd.B;
-                    wkb.i0 = (tile / ct) * GT_BM;
-                    wkb.j0 = (tile % ct) * GT_BN;
+                    wkb.i0 = (tile / wct) * GT_BM;
+                    wkb.j0 = (tile % wct) * tile_n;
                     wkb.direct = ws.direct;
                     wkb.batch = ws.batch;
                     wkb.pad = 0;
@@ -2810,6 +2825,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     ta.anchor_off = reinterpret_cast<const int *>(db + hp.o_anchor);
     ta.nb = nb;
     ta.D = D;
+    ta.tile_n = hp.tile_n;
     ta.node_map = nm;
     ta.map_len = (long long)P->node_map_len;
     ta.anchor_ids = ids;
@@ -2912,6 +2928,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                 po.wblocks = hp.wblocks_total;
                 po.zper = ta.zper;
                 po.D = D;
+                po.tile_n = hp.tile_n;
                 po.zeroed = (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0;
                 po.ub = ub;
                 po.ub.done = done;
