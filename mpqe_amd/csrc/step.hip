@@ -763,13 +763,14 @@ __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, con
                                              const float *__restrict__ H, const float *__restrict__ GH,
                                              long long level_stride, float *__restrict__ slabs, int bid,
                                              int wblocks_total, float *smem, const GradPtrs &gp, bool zeroed,
-                                             long long *dbg, int D, const PostArgs *po = nullptr, int tile_n = GT_BN) {
+                                             long long *dbg, int D, const PostArgs *po = nullptr, int tile_n = GT_BN,
+                                             int nxcd = 8) {
     const int tiles_j = (D + tile_n - 1) / tile_n, tiles = tiles_j * ((D + GT_BM - 1) / GT_BM);
     // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2: blocks b and b+8 share
     // one. The `tiles` output tiles of a K-chunk read the SAME rows of H and gH (different column
     // halves), so they are mapped to blocks 8 apart -> one XCD, one L2 fetch of the rows instead of
     // `tiles`. Pure placement: correctness never depends on it.
-    const int nx = po ? po->na : 8;              // XCDs the tile workgroups are dealt to (bid % nx = the XCD's rank)
+    const int nx = po ? po->na : nxcd;           // XCDs the tile workgroups are dealt to (bid % nx = the XCD's rank)
     const int span = nx * tiles;
     int vb = bid;
     if (bid < (wblocks_total / span) * span) {
@@ -917,6 +918,7 @@ struct TailArgs {
     int ublocks;             // the backward post-pass of the uniform node states: the FIRST ublocks workgroups
     int D;                   // = sd->D, by value: a tile's record is then the first and only load in front of its rows
     int tile_n;              // columns per weight-gradient tile
+    int ux;                  // > 0: XCDs set aside for the post-pass' vector ops (step_tail_kernel)
 
     const long long *node_map;
     long long map_len;
@@ -988,23 +990,38 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
                                                    ((long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
     }
 #endif
-    if ((int)blockIdx.x < ta.ublocks) {         // uniform node states, backward: vector ops on column sums
-        uop_block((int)blockIdx.x, sd->D, lp, ua, smem, &gp, zeroed);
+    // role of the workgroup. ta.ux > 0 (chain form): the post-pass' vector ops take the last ta.ux XCDs of the chip and the
+    // tiles the others (workgroup b runs on XCD b % 8) -- the vector ops are a latency chain of small loads and polls, the
+    // tiles stream ~40 MB through their XCDs' L2s and fabric ports
+    int ub = -1, tb;
+    if (ta.ux > 0) {
+        const int x = (int)blockIdx.x & 7, r = (int)blockIdx.x >> 3, tx = 8 - ta.ux;
+        if (x >= tx) {
+            ub = r * ta.ux + (x - tx);
+            if (ub >= ta.ublocks) return;
+        }
+        tb = r * tx + x;
+    } else {
+        if ((int)blockIdx.x < ta.ublocks) ub = (int)blockIdx.x;
+        tb = (int)blockIdx.x - ta.ublocks;
+    }
+    if (ub >= 0) {         // uniform node states, backward: vector ops on column sums
+        uop_block(ub, sd->D, lp, ua, smem, &gp, zeroed);
 #ifndef MPQE_EMU
         if (ta.stamps && threadIdx.x == 0) {
             ta.stamps[(long long)blockIdx.x * 8 + 5] = (long long)wall_clock64();       // (word 1 stays 0: not a tile)
-            ta.stamps[(long long)blockIdx.x * 8 + 6] = 1 + (long long)ua.ops[blockIdx.x / ua.chunks].kind;
+            ta.stamps[(long long)blockIdx.x * 8 + 6] = 1 + (long long)ua.ops[ub / ua.chunks].kind;
         }
 #endif
         return;
     }
-    const int tb = (int)blockIdx.x - ta.ublocks;
     if (tb >= ta.wblocks) {        // zero fill of a gradient matrix nobody writes (uniform branch)
-        zmat_block(ta.zmats, ta.zper, tb - ta.wblocks, sd->D, gp);
+        if (tb - ta.wblocks < ta.zblocks) zmat_block(ta.zmats, ta.zper, tb - ta.wblocks, sd->D, gp);
         return;
     }
     grad_w_block<MODE>(sd, ta.wsrc, ta.nwsrc, ta.wblock, H, GH, level_stride, ta.slabs, tb, ta.wblocks,
-                       smem, gp, zeroed != 0, ta.stamps ? ta.stamps + (long long)blockIdx.x * 8 : nullptr, ta.D, nullptr, ta.tile_n);      // zeroed: this call zero-filled the gradients, a store suffices
+                       smem, gp, zeroed != 0, ta.stamps ? ta.stamps + (long long)blockIdx.x * 8 : nullptr, ta.D, nullptr, ta.tile_n,
+                       ta.ux > 0 ? 8 - ta.ux : 8);      // zeroed: this call zero-filled the gradients, a store suffices
 #ifndef MPQE_EMU
     if (ta.stamps && threadIdx.x == 0) {
         ta.stamps[(long long)blockIdx.x * 8 + 1] = (long long)wall_clock64();
@@ -2826,6 +2843,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     ta.nb = nb;
     ta.D = D;
     ta.tile_n = hp.tile_n;
+    ta.ux = 0;
     ta.node_map = nm;
     ta.map_len = (long long)P->node_map_len;
     ta.anchor_ids = ids;
@@ -2847,7 +2865,19 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         tl.wblocks = count;
         if (first == 0 && (P->flags & MPQE_STEP_ZERO_GRADS)) tl.zblocks = (int)hp.zmats.size() * ta.zper;
         if (first == 0) tl.ublocks = ub.nops * ub.chunks;
-        const int nblocks = tl.ublocks + count + tl.zblocks;
+        int nblocks = tl.ublocks + count + tl.zblocks;
+        {
+            // chain form: two of the eight XCDs for the post-pass' vector ops, six for the tiles (AIFB step, same box,
+            // three runs each: 64.95 / 65.15 / 65.04 us against 65.70 / 65.60 / 65.47 with both kinds everywhere; one
+            // or three XCDs: 65.8 / 66.0). MPQE_DBG_TAIL_UX overrides (0 = everywhere).
+            const char *ux = getenv("MPQE_DBG_TAIL_UX");
+            const int uxv = ux ? atoi(ux) : 2;
+            if (use_chain && first == 0 && tl.ublocks >= 4 && uxv > 0 && uxv < 8) {
+                tl.ux = uxv;
+                const int ra = (tl.ublocks + tl.ux - 1) / tl.ux, rb = (count + tl.zblocks + (8 - tl.ux) - 1) / (8 - tl.ux);
+                nblocks = 8 * (ra > rb ? ra : rb);
+            }
+        }
         tl.stamps = g_tail_stamps && (size_t)nblocks <= g_tail_stamp_blocks ? g_tail_stamps : nullptr;
         if (nblocks <= 0) return;
         dim3 tgrid((unsigned)nblocks);
