@@ -439,6 +439,14 @@ __global__ __launch_bounds__(256) void rgcn_gen_gemm_kernel(
 #ifndef GGM_PF_TRANS
 #define GGM_PF_TRANS 2
 #endif
+#ifndef GGM_KW_FWD
+#define GGM_KW_FWD 4        // consecutive k per lane and iteration: 4 (one 16-byte load per row piece) or 8 (two: whole lines).
+                            // Measured at the stress shape: forward 85.4 (4) / 89.4 (8) us, transposed 107 (4) / 123.8 (8, two
+                            // stages in flight) / 107.5 (8, one stage) -- half-line loads are not what bounds these kernels
+#endif
+#ifndef GGM_KW_TRANS
+#define GGM_KW_TRANS 4
+#endif
 template <bool TRANS, bool RELU>
 __global__ __launch_bounds__(256) void rgcn_gen_gemm_rows_kernel(
     const int *__restrict__ rows, const int *__restrict__ rel_ptr, const int *__restrict__ tile_ptr, int R,
@@ -449,6 +457,7 @@ __global__ __launch_bounds__(256) void rgcn_gen_gemm_rows_kernel(
     // 106.8 / 113.3): with more workgroups in flight the gathered half-lines and the streamed matrices evict each other
     // from L1 / L2 before their second use, and the MFMA pipe is already full with one wave per SIMD.
     __shared__ int sp[TRANS ? 2 * 1026 : 36000];
+    constexpr int KW = TRANS ? GGM_KW_TRANS : GGM_KW_FWD, H = KW / 4;
     const int K = TRANS ? Dout : Din, C = TRANS ? Din : Dout;
     const int cg = (C + 255) / 256;                        // workgroups per row tile (4 column blocks of 64 each)
     // (one contiguous eighth of the row tiles per XCD -- a relation's tiles and its matrix on one L2 -- was measured and
@@ -483,44 +492,53 @@ __global__ __launch_bounds__(256) void rgcn_gen_gemm_rows_kernel(
     for (int g = 0; g < 4; ++g) {
         const int rr = 16 * g + pos;
         const long long id = rows[start + (rr < nrows ? rr : nrows - 1)];      // (clamped: rows beyond the tile are not stored)
-        pa[g] = a + id * K + 4 * kq;
-        pm[g] = RELU ? mask + id * K + 4 * kq : nullptr;
+        pa[g] = a + id * K + KW * kq;
+        pm[g] = RELU ? mask + id * K + KW * kq : nullptr;
     }
-    // B: non-TRANS W[(16 it + 4 kq + u)][n0 + 4 pos ..]; TRANS W[(n0 + 4 pos + n)][16 it + 4 kq ..]   (W is [Din][Dout])
-    const float *pw = TRANS ? W + (long long)(n0 + 4 * pos) * Dout + 4 * kq : W + (long long)(4 * kq) * Dout + n0 + 4 * pos;
-    const long long wstep = TRANS ? 16 : 16ll * Dout;      // floats per iteration
+    // A lane takes KW = 4 H consecutive k of its row per iteration (H 16-byte loads: with H = 2 the four kq groups cover a
+    // whole 128-byte line of the row per load pair). MFMA (h, u) multiplies the k slots {4 KW it + KW kq + 4 h + u}.
+    // B: non-TRANS W[(4 KW it + KW kq + 4 h + u)][n0 + 4 pos ..]; TRANS W[(n0 + 4 pos + n)][4 KW it + KW kq + 4 h ..]
+    const float *pw = TRANS ? W + (long long)(n0 + 4 * pos) * Dout + KW * kq : W + (long long)(KW * kq) * Dout + n0 + 4 * pos;
+    const long long wstep = TRANS ? 4 * KW : 4ll * KW * Dout;      // floats per iteration
     f32x4 acc[4][4];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int niter = K / 16;
+    const int niter = K / (4 * KW);
     constexpr int GGM_PF = TRANS ? GGM_PF_TRANS : GGM_PF_FWD;
-    f32x4 A[GGM_PF][4], M[RELU ? GGM_PF : 1][4], B[GGM_PF][4];
+    f32x4 A[GGM_PF][4][H], M[RELU ? GGM_PF : 1][4][H], B[GGM_PF][4 * H];
     auto load = [&](int s, int it) {
         const int ic = it < niter ? it : niter - 1;        // (beyond the end: the last piece again, unused)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            A[s][g] = gload4(pa[g] + 16 * ic);
-            if (RELU) M[s][g] = gload4(pm[g] + 16 * ic);
-        }
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) B[s][q] = gload4(pw + (long long)ic * wstep + (long long)q * Dout);
+            for (int h = 0; h < H; ++h) {
+                A[s][g][h] = gload4(pa[g] + 4 * KW * ic + 4 * h);
+                if (RELU) M[s][g][h] = gload4(pm[g] + 4 * KW * ic + 4 * h);
+            }
+#pragma unroll
+        for (int q = 0; q < 4 * H; ++q)      // non-TRANS: q = 4 h + u, a row of W each; TRANS: q = H n + h
+            B[s][q] = TRANS ? gload4(pw + (long long)ic * wstep + (long long)(q / H) * Dout + 4 * (q % H))
+                            : gload4(pw + (long long)ic * wstep + (long long)q * Dout);
     };
     auto mma = [&](int s) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 av = A[s][g];
-            if (RELU) {
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) av[u] = M[s][g][u] > 0.f ? av[u] : 0.f;
+            for (int h = 0; h < H; ++h) {
+                f32x4 av = A[s][g][h];
+                if (RELU) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) av[u] = M[s][g][h][u] > 0.f ? av[u] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], TRANS ? B[s][H * n + h][u] : B[s][4 * h + u][n],
+                                                                         acc[g][n], 0, 0, 0);
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], TRANS ? B[s][n][u] : B[s][u][n], acc[g][n], 0, 0, 0);
-        }
     };
 #pragma unroll
     for (int s = 0; s < GGM_PF; ++s) {
@@ -530,7 +548,7 @@ __global__ __launch_bounds__(256) void rgcn_gen_gemm_rows_kernel(
     for (int it = 0; it < niter; it += GGM_PF) {
 #pragma unroll
         for (int s = 0; s < GGM_PF; ++s) {
-            mma(s);             // iteration it + s (niter is a multiple of 4: K % 64 == 0; GGM_PF divides 4)
+            mma(s);             // iteration it + s (K % 64 == 0: niter is a multiple of 2 at KW = 8, of 4 at KW = 4)
             __builtin_amdgcn_sched_barrier(0);
             load(s, it + s + GGM_PF);
             __builtin_amdgcn_sched_barrier(0);
