@@ -220,7 +220,8 @@ int mpqe_hinge_bwd(const float *pos, const float *neg, int64_t n, float margin, 
 /* ---- fused training step -------------------------------------------------------------------
  * Forward + backward of RGCNEncoderDecoder.margin_loss (reference model.py:464-494) for ALL the
  * formula batches of one training step (reference train_helpers.py:76-120 draws 11 after
- * burn-in), each with explicit positive and negative targets, in ~15 launches:
+ * burn-in), each with explicit positive and negative targets, in 2 - 3 launches (dim 64 / 128 / 256: the
+ * graph-block chain form; ~15 launches in the level form, MPQE_STEP_NO_CHAIN or other dims):
  *     loss[0] = sum_b weight_b * mean_i clamp(margin - (pos_bi - neg_bi), 0);  loss[1+b] = that mean
  * Gradients of every parameter are ACCUMULATED into `grads` (dense, like the reference's
  * autograd). Readouts: sum / max / mp(TM). The query embedding is computed once per batch and
