@@ -53,7 +53,7 @@ def run(qt, D, B, R, dev, iters=20):
 
 def main():
     dev = torch.device('cuda:0')
-    D, B, R = 256, 8192, 128
+    D, B, R = int(os.environ.get('SCATTER_BENCH_D', 256)), int(os.environ.get('SCATTER_BENCH_B', 8192)), 128
     out = {}
     for k, qt in enumerate(('3-inter', '3-chain', '3-inter')):
         out['%d:%s' % (k, qt)] = run(qt, D, B, R, dev)
