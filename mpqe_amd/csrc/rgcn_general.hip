@@ -460,109 +460,140 @@ __global__ __launch_bounds__(256) void rgcn_gen_gemm_rows_kernel(
     constexpr int KW = TRANS ? GGM_KW_TRANS : GGM_KW_FWD, H = KW / 4;
     const int K = TRANS ? Dout : Din, C = TRANS ? Din : Dout;
     const int cg = (C + 255) / 256;                        // workgroups per row tile (4 column blocks of 64 each)
-    // (one contiguous eighth of the row tiles per XCD -- a relation's tiles and its matrix on one L2 -- was measured and
-    // is slower: 158 / 127 us forward / transposed against 140 / 106 dealt round-robin, at three / two workgroups per CU)
-    const int grp = (int)blockIdx.x / (8 * cg), rem = (int)blockIdx.x - grp * (8 * cg);
-    const int t = grp * 8 + (rem & 7), by = rem >> 3;
-    int r, start, nrows;
-    if (R + 2 <= 1026) {            // both pointer tables in ONE round trip, the search in LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pos = lane & 15, kq = lane >> 4;
+    const bool lds_tables = R + 2 <= 1026;
+    if (lds_tables) {               // both pointer tables in ONE round trip, every search in LDS
         int *sr = sp + 1026;
         for (int i = threadIdx.x; i < R + 2; i += 256) {
             sp[i] = tile_ptr[i];
             sr[i] = rel_ptr[i];
         }
         __syncthreads();
-        if (t >= sp[R + 1]) return;
-        r = find_group(sp, R + 1, t);
-        start = sr[r] + (t - sp[r]) * GT_BM;
-        nrows = sr[r + 1] - start;
-    } else {
-        if (t >= tile_ptr[R + 1]) return;
-        r = find_group(tile_ptr, R + 1, t);
-        start = rel_ptr[r] + (t - tile_ptr[r]) * GT_BM;
-        nrows = rel_ptr[r + 1] - start;
     }
-    if (nrows > GT_BM) nrows = GT_BM;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pos = lane & 15, kq = lane >> 4;
-    const int n0 = (by * 4 + wave) * 64;
-    if (n0 >= C || nrows <= 0) return;                     // (no barrier below: a wave without a column block just leaves)
-    const float *W = r < R ? basis + (long long)r * Din * Dout : root;
-    const float *pa[4], *pm[4];
+    const int *tp = lds_tables ? sp : tile_ptr, *rp = lds_tables ? sp + 1026 : rel_ptr;
+    // PERSISTENT: the launch has one workgroup per CU slot; a workgroup takes the items b, b + G, b + 2 G, ... (item =
+    // row tile x column group, eight row tiles of a group on eight XCDs: the column groups of a row tile on ONE XCD). The
+    // pointer tables are read once, the next tile's row ids are requested while the current tile multiplies -- a tile's
+    // start-up (tables -> ids -> rows -> first MFMA, ~5 us at one workgroup per CU) is paid once per workgroup, not per
+    // tile. No barrier below: the four waves walk the same tiles on their own.
+    // (one contiguous eighth of the row tiles per XCD -- a relation's tiles and its matrix on one L2 -- was measured and
+    // is slower: 158 / 127 us forward / transposed against 140 / 106 dealt round-robin, at three / two workgroups per CU)
+    const int ntile = tp[R + 1];
+    auto tile_of = [&](int item, int &r, int &start, int &nrows, int &by) -> bool {
+        const int grp = item / (8 * cg), rem = item - grp * (8 * cg);
+        const int t = grp * 8 + (rem & 7);
+        by = rem >> 3;
+        if (t >= ntile) return false;
+        r = find_group(tp, R + 1, t);
+        start = rp[r] + (t - tp[r]) * GT_BM;
+        nrows = rp[r + 1] - start;
+        if (nrows > GT_BM) nrows = GT_BM;
+        return true;
+    };
+    auto load_ids = [&](int start, int nrows, int (&id)[4]) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int rr = 16 * g + pos;
-        const long long id = rows[start + (rr < nrows ? rr : nrows - 1)];      // (clamped: rows beyond the tile are not stored)
-        pa[g] = a + id * K + KW * kq;
-        pm[g] = RELU ? mask + id * K + KW * kq : nullptr;
-    }
-    // A lane takes KW = 4 H consecutive k of its row per iteration (H 16-byte loads: with H = 2 the four kq groups cover a
-    // whole 128-byte line of the row per load pair). MFMA (h, u) multiplies the k slots {4 KW it + KW kq + 4 h + u}.
-    // B: non-TRANS W[(4 KW it + KW kq + 4 h + u)][n0 + 4 pos ..]; TRANS W[(n0 + 4 pos + n)][4 KW it + KW kq + 4 h ..]
-    const float *pw = TRANS ? W + (long long)(n0 + 4 * pos) * Dout + KW * kq : W + (long long)(KW * kq) * Dout + n0 + 4 * pos;
-    const long long wstep = TRANS ? 4 * KW : 4ll * KW * Dout;      // floats per iteration
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < 4; ++g) {
+            const int rr = 16 * g + pos;
+            id[g] = nrows > 0 ? rows[start + (rr < nrows ? rr : nrows - 1)] : 0;      // (clamped: rows beyond the tile are not stored)
+        }
+    };
+    int item = (int)blockIdx.x, r, start, nrows, by;
+    if (!tile_of(item, r, start, nrows, by)) return;       // (items only grow: nothing further either)
+    const int n0 = (by * 4 + wave) * 64;                   // (`by` is the same for every item of a workgroup)
+    if (n0 >= C) return;                                   // a wave without a column block just leaves
+    int idc[4];
+    load_ids(start, nrows, idc);
     const int niter = K / (4 * KW);
     constexpr int GGM_PF = TRANS ? GGM_PF_TRANS : GGM_PF_FWD;
-    f32x4 A[GGM_PF][4][H], M[RELU ? GGM_PF : 1][4][H], B[GGM_PF][4 * H];
-    auto load = [&](int s, int it) {
-        const int ic = it < niter ? it : niter - 1;        // (beyond the end: the last piece again, unused)
+    for (;;) {
+        int r2 = 0, start2 = 0, nrows2 = 0, by2 = 0, idn[4] = {0, 0, 0, 0};
+        const bool more = tile_of(item + (int)gridDim.x, r2, start2, nrows2, by2);
+        if (more) load_ids(start2, nrows2, idn);           // (in flight under this tile's K loop)
+        if (nrows > 0) {
+            const float *W = r < R ? basis + (long long)r * Din * Dout : root;
+            const float *pa[4], *pm[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                A[s][g][h] = gload4(pa[g] + 4 * KW * ic + 4 * h);
-                if (RELU) M[s][g][h] = gload4(pm[g] + 4 * KW * ic + 4 * h);
+            for (int g = 0; g < 4; ++g) {
+                pa[g] = a + (long long)idc[g] * K + KW * kq;
+                pm[g] = RELU ? mask + (long long)idc[g] * K + KW * kq : nullptr;
             }
+            // A lane takes KW = 4 H consecutive k of its row per iteration (H 16-byte loads: with H = 2 the four kq groups
+            // cover a whole 128-byte line of the row per load pair). MFMA (h, u) multiplies the k slots
+            // {4 KW it + KW kq + 4 h + u}.
+            // B: non-TRANS W[(4 KW it + KW kq + 4 h + u)][n0 + 4 pos ..]; TRANS W[(n0 + 4 pos + n)][4 KW it + KW kq + 4 h ..]
+            const float *pw = TRANS ? W + (long long)(n0 + 4 * pos) * Dout + KW * kq
+                                    : W + (long long)(KW * kq) * Dout + n0 + 4 * pos;
+            const long long wstep = TRANS ? 4 * KW : 4ll * KW * Dout;      // floats per iteration
+            f32x4 acc[4][4];
 #pragma unroll
-        for (int q = 0; q < 4 * H; ++q)      // non-TRANS: q = 4 h + u, a row of W each; TRANS: q = H n + h
-            B[s][q] = TRANS ? gload4(pw + (long long)ic * wstep + (long long)(q / H) * Dout + 4 * (q % H))
-                            : gload4(pw + (long long)ic * wstep + (long long)q * Dout);
-    };
-    auto mma = [&](int s) {
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+                for (int n = 0; n < 4; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 A[GGM_PF][4][H], M[RELU ? GGM_PF : 1][4][H], B[GGM_PF][4 * H];
+            auto load = [&](int s, int it) {
+                const int ic = it < niter ? it : niter - 1;        // (beyond the end: the last piece again, unused)
 #pragma unroll
-            for (int h = 0; h < H; ++h) {
-                f32x4 av = A[s][g][h];
-                if (RELU) {
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) av[u] = M[s][g][h][u] > 0.f ? av[u] : 0.f;
+                    for (int h = 0; h < H; ++h) {
+                        A[s][g][h] = gload4(pa[g] + 4 * KW * ic + 4 * h);
+                        if (RELU) M[s][g][h] = gload4(pm[g] + 4 * KW * ic + 4 * h);
+                    }
+#pragma unroll
+                for (int q = 0; q < 4 * H; ++q)      // non-TRANS: q = 4 h + u, a row of W each; TRANS: q = H n + h
+                    B[s][q] = TRANS ? gload4(pw + (long long)ic * wstep + (long long)(q / H) * Dout + 4 * (q % H))
+                                    : gload4(pw + (long long)ic * wstep + (long long)q * Dout);
+            };
+            auto mma = [&](int s) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        f32x4 av = A[s][g][h];
+                        if (RELU) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) av[u] = M[s][g][h][u] > 0.f ? av[u] : 0.f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int n = 0; n < 4; ++n)
+                                acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                    av[u], TRANS ? B[s][H * n + h][u] : B[s][4 * h + u][n], acc[g][n], 0, 0, 0);
+                    }
+            };
+#pragma unroll
+            for (int s = 0; s < GGM_PF; ++s) {
+                load(s, s);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            for (int it = 0; it < niter; it += GGM_PF) {
+#pragma unroll
+                for (int s = 0; s < GGM_PF; ++s) {
+                    mma(s);             // iteration it + s (K % 64 == 0: niter is a multiple of 2 at KW = 8, of 4 at KW = 4)
+                    __builtin_amdgcn_sched_barrier(0);
+                    load(s, it + s + GGM_PF);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int n = 0; n < 4; ++n)
-                        acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], TRANS ? B[s][H * n + h][u] : B[s][4 * h + u][n],
-                                                                         acc[g][n], 0, 0, 0);
             }
-    };
 #pragma unroll
-    for (int s = 0; s < GGM_PF; ++s) {
-        load(s, s);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    for (int it = 0; it < niter; it += GGM_PF) {
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int s = 0; s < GGM_PF; ++s) {
-            mma(s);             // iteration it + s (K % 64 == 0: niter is a multiple of 2 at KW = 8, of 4 at KW = 4)
-            __builtin_amdgcn_sched_barrier(0);
-            load(s, it + s + GGM_PF);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int row = 16 * g + 4 * kq + rr;
+                    if (row < nrows)
+                        *reinterpret_cast<f32x4 *>(msg + (long long)(start + row) * C + n0 + 4 * pos) =
+                            f32x4{acc[g][0][rr], acc[g][1][rr], acc[g][2][rr], acc[g][3][rr]};
+                }
         }
+        if (!more) break;
+        item += (int)gridDim.x;
+        r = r2;
+        start = start2;
+        nrows = nrows2;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) idc[g] = idn[g];
     }
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int row = 16 * g + 4 * kq + rr;
-            if (row < nrows)
-                *reinterpret_cast<f32x4 *>(msg + (long long)(start + row) * C + n0 + 4 * pos) =
-                    f32x4{acc[g][0][rr], acc[g][1][rr], acc[g][2][rr], acc[g][3][rr]};
-        }
 }
 
 // ------------------------------------------------------------------------------------ segmented sum
@@ -881,7 +912,11 @@ extern "C" int mpqe_rgcn_general_fwd(const void *plan, int64_t Nn, int64_t E, in
     dim3 grid((unsigned)(((tile_bound(Nn, E, R) + 7) / 8 * 8) * ((Dout + GT_BN - 1) / GT_BN)));      // (1-D: see the kernel)
     const bool rows64 = gvec && Din % 64 == 0 && Dout % 64 == 0 && !getenv("MPQE_DBG_GEN_LDS_GEMM");
     if (rows64) {
-        dim3 g1((unsigned)(((tile_bound(Nn, E, R) + 7) / 8 * 8) * ((Dout + 255) / 256)));
+        // persistent: one workgroup per CU (the kernel claims the LDS for that), whole groups of 8 x column groups
+        const long long items1 = ((tile_bound(Nn, E, R) + 7) / 8 * 8) * ((Dout + 255) / 256);
+        const char *fs = getenv("MPQE_DBG_GEN_SLOTS");      // (tests: a small grid, so that workgroups walk several tiles)
+        const long long per1 = 8 * ((Dout + 255) / 256), slots1 = (fs ? atoi(fs) : 256) / per1 * per1;
+        dim3 g1((unsigned)(items1 < slots1 || slots1 == 0 || getenv("MPQE_DBG_GEN_NOT_PERSISTENT") ? items1 : slots1));
         hipLaunchKernelGGL((rgcn_gen_gemm_rows_kernel<false, false>), g1, dim3(256), 0, s, P.rows_fwd, P.rel_ptr, P.tile_ptr,
                            (int)R, x, (const float *)nullptr, basis, root, (int)Din, (int)Dout, msg);
     } else
@@ -939,7 +974,10 @@ extern "C" int mpqe_rgcn_general_bwd(const void *plan, int64_t Nn, int64_t E, in
     if (grad_x) {
         dim3 grid((unsigned)(((tile_bound(Nn, E, R) + 7) / 8 * 8) * ((Din + GT_BN - 1) / GT_BN)));
         const bool rows64g = gvec && Din % 64 == 0 && Dout % 64 == 0 && !getenv("MPQE_DBG_GEN_LDS_GEMM");
-        dim3 g1((unsigned)(((tile_bound(Nn, E, R) + 7) / 8 * 8) * ((Din + 255) / 256)));
+        const long long items1 = ((tile_bound(Nn, E, R) + 7) / 8 * 8) * ((Din + 255) / 256);
+        const char *fs = getenv("MPQE_DBG_GEN_SLOTS");
+        const long long per1 = 8 * ((Din + 255) / 256), slots1 = (fs ? atoi(fs) : 512) / per1 * per1;       // (two workgroups per CU)
+        dim3 g1((unsigned)(items1 < slots1 || slots1 == 0 || getenv("MPQE_DBG_GEN_NOT_PERSISTENT") ? items1 : slots1));
         if (rows64g && relu)
             hipLaunchKernelGGL((rgcn_gen_gemm_rows_kernel<true, true>), g1, dim3(256), 0, s, P.rows_bwd, P.rel_ptr, P.tile_ptr,
                                (int)R, grad_out, mask, basis, root, (int)Din, (int)Dout, gmsg);
