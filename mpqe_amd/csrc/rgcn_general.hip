@@ -459,8 +459,14 @@ __global__ __launch_bounds__(256) void rgcn_gen_gemm_rows_kernel(
     __shared__ int sp[TRANS ? 2 * 1026 : 36000];
     constexpr int KW = TRANS ? GGM_KW_TRANS : GGM_KW_FWD, H = KW / 4;
     const int K = TRANS ? Dout : Din, C = TRANS ? Din : Dout;
-    const int cg = (C + 255) / 256;                        // workgroups per row tile (4 column blocks of 64 each)
+    // A workgroup's four waves take four (row tile, 64-column block) pairs: with 256 or more columns the four blocks of one
+    // row tile (cg workgroups per row tile), with 128 / 64 columns the blocks of 2 / 4 consecutive row tiles -- else half /
+    // three quarters of the SIMDs idle at one workgroup per CU (D = 128 forward: 46 us = 0.26 of the roof before).
+    const int cb = C / 64;                                 // column blocks of a row tile
+    const int rt = cb >= 4 ? 1 : (cb == 3 ? 1 : 4 / cb);   // row tiles per workgroup
+    const int cg = cb >= 4 ? (cb + 3) / 4 : 1;             // workgroups per row tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pos = lane & 15, kq = lane >> 4;
+    const int sub = rt > 1 ? wave / cb : 0, wcol = rt > 1 ? wave % cb : wave;
     const bool lds_tables = R + 2 <= 1026;
     if (lds_tables) {               // both pointer tables in ONE round trip, every search in LDS
         int *sr = sp + 1026;
@@ -481,7 +487,7 @@ __global__ __launch_bounds__(256) void rgcn_gen_gemm_rows_kernel(
     const int ntile = tp[R + 1];
     auto tile_of = [&](int item, int &r, int &start, int &nrows, int &by) -> bool {
         const int grp = item / (8 * cg), rem = item - grp * (8 * cg);
-        const int t = grp * 8 + (rem & 7);
+        const int t = (grp * 8 + (rem & 7)) * rt + sub;
         by = rem >> 3;
         if (t >= ntile) return false;
         r = find_group(tp, R + 1, t);
@@ -499,7 +505,7 @@ __global__ __launch_bounds__(256) void rgcn_gen_gemm_rows_kernel(
     };
     int item = (int)blockIdx.x, r, start, nrows, by;
     if (!tile_of(item, r, start, nrows, by)) return;       // (items only grow: nothing further either)
-    const int n0 = (by * 4 + wave) * 64;                   // (`by` is the same for every item of a workgroup)
+    const int n0 = (by * 4 + wcol) * 64;                   // (`by` is the same for every item of a workgroup)
     if (n0 >= C) return;                                   // a wave without a column block just leaves
     int idc[4];
     load_ids(start, nrows, idc);
@@ -913,9 +919,10 @@ extern "C" int mpqe_rgcn_general_fwd(const void *plan, int64_t Nn, int64_t E, in
     const bool rows64 = gvec && Din % 64 == 0 && Dout % 64 == 0 && !getenv("MPQE_DBG_GEN_LDS_GEMM");
     if (rows64) {
         // persistent: one workgroup per CU (the kernel claims the LDS for that), whole groups of 8 x column groups
-        const long long items1 = ((tile_bound(Nn, E, R) + 7) / 8 * 8) * ((Dout + 255) / 256);
+        const long long cb1 = Dout / 64, rt1 = (cb1 >= 3 || cb1 == 0) ? 1 : 4 / cb1, cg1 = cb1 >= 4 ? (cb1 + 3) / 4 : 1;
+        const long long items1 = (((tile_bound(Nn, E, R) + rt1 - 1) / rt1 + 7) / 8 * 8) * cg1;
         const char *fs = getenv("MPQE_DBG_GEN_SLOTS");      // (tests: a small grid, so that workgroups walk several tiles)
-        const long long per1 = 8 * ((Dout + 255) / 256), slots1 = (fs ? atoi(fs) : 256) / per1 * per1;
+        const long long per1 = 8 * cg1, slots1 = (fs ? atoi(fs) : 256) / per1 * per1;
         dim3 g1((unsigned)(items1 < slots1 || slots1 == 0 || getenv("MPQE_DBG_GEN_NOT_PERSISTENT") ? items1 : slots1));
         hipLaunchKernelGGL((rgcn_gen_gemm_rows_kernel<false, false>), g1, dim3(256), 0, s, P.rows_fwd, P.rel_ptr, P.tile_ptr,
                            (int)R, x, (const float *)nullptr, basis, root, (int)Din, (int)Dout, msg);
@@ -974,9 +981,10 @@ extern "C" int mpqe_rgcn_general_bwd(const void *plan, int64_t Nn, int64_t E, in
     if (grad_x) {
         dim3 grid((unsigned)(((tile_bound(Nn, E, R) + 7) / 8 * 8) * ((Din + GT_BN - 1) / GT_BN)));
         const bool rows64g = gvec && Din % 64 == 0 && Dout % 64 == 0 && !getenv("MPQE_DBG_GEN_LDS_GEMM");
-        const long long items1 = ((tile_bound(Nn, E, R) + 7) / 8 * 8) * ((Din + 255) / 256);
+        const long long cb1 = Din / 64, rt1 = (cb1 >= 3 || cb1 == 0) ? 1 : 4 / cb1, cg1 = cb1 >= 4 ? (cb1 + 3) / 4 : 1;
+        const long long items1 = (((tile_bound(Nn, E, R) + rt1 - 1) / rt1 + 7) / 8 * 8) * cg1;
         const char *fs = getenv("MPQE_DBG_GEN_SLOTS");
-        const long long per1 = 8 * ((Din + 255) / 256), slots1 = (fs ? atoi(fs) : 512) / per1 * per1;       // (two workgroups per CU)
+        const long long per1 = 8 * cg1, slots1 = (fs ? atoi(fs) : 512) / per1 * per1;       // (two workgroups per CU)
         dim3 g1((unsigned)(items1 < slots1 || slots1 == 0 || getenv("MPQE_DBG_GEN_NOT_PERSISTENT") ? items1 : slots1));
         if (rows64g && relu)
             hipLaunchKernelGGL((rgcn_gen_gemm_rows_kernel<true, true>), g1, dim3(256), 0, s, P.rows_bwd, P.rel_ptr, P.tile_ptr,
