@@ -11,14 +11,21 @@ embed_dim 128, readout 'mp' (TM), adaptive, num_layers 3, unshared layers. A ste
 assembly -> L layers -> readout -> cosine scores vs positive and negative targets -> hinge,
 forward and backward to every parameter gradient, with all inputs already resident in HBM.
 Collation from python objects and the optimiser are outside the metric.
-Each rank runs the same-sized workload (weak scaling); N > 1 adds one RCCL all-reduce of
-the flattened gradients per step.
+EVERY timed step runs on ids it has not seen before (pre-drawn, resident in HBM, one set per step):
+the id -> table-row lookups and the ordering of the embedding-gradient accumulation happen inside the
+step (reference train_helpers.py:76-120 draws a new batch per call; encoders.py:40-43 and the embedding
+backward resolve ids inside forward / backward). Formulas come from a pool of 4 formula sets.
+Each rank runs the same-sized workload (weak scaling); N > 1 adds the gradient exchange (RCCL) per step.
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(a child `python -m torch.distributed.run`, before this process touches a GPU).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -69,6 +76,16 @@ def parse():
     ap.add_argument('--dense-allreduce', action='store_true',
                     help='N > 1: all-reduce the whole flat gradient buffer (what a literal port would do) instead of the '
                          'touched-matrix bucket + row exchange')
+    ap.add_argument('--debug-opt', action='append', default=[], metavar='NAME=VALUE',
+                    help='timing experiments: a diagnostics switch of the library (mpqe_debug_option), e.g. TAIL_UX=0')
+    ap.add_argument('--replay', action='store_true',
+                    help='time the replay of 4 pre-packed steps (round 2\'s headline) instead of fresh ids per step')
+    ap.add_argument('--touch', default='step', choices=['step', 'pack', 'atomics'],
+                    help="entity-table gradients: per-row sums with the plan built inside the step (default), built by "
+                         "pack(), or fp32 atomics")
+    ap.add_argument('--fresh-sets', type=int, default=4096,
+                    help='distinct pre-drawn id sets (176 KB each at the default shape); the timed steps walk through them, '
+                         'wrapping around only when steps x repeats exceeds it')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='nccl = RCCL over xGMI (the real path); gloo only to exercise the multi-rank code on one GPU')
     return ap.parse_args()
@@ -98,6 +115,28 @@ class StepData(object):
                 targets=torch.from_numpy(targets).to(device), negs=torch.from_numpy(negs).to(device),
                 anchor_np=anchors, targets_np=targets, negs_np=negs))
         self.num_graphs = B * len(self.batches)
+
+
+def draw_ids_device(schema, data, nsets, seed, device):
+    """nsets fresh id sets for the formulas of `data`, drawn ON the device: an int64 tensor [nsets, n_ids] whose rows have
+    the layout of FusedTrainStep.flatten_ids -- [anchors of batch 0, slot-major | ... | targets | negatives]; every id
+    uniform over the ids of its slot's mode (the same distribution as StepData's host draws)."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    ids_of = {m: torch.from_numpy(np.asarray(v)).to(device) for m, v in schema.ids.items()}
+
+    def pick(mode, B):
+        pool = ids_of[mode]
+        return pool[torch.randint(len(pool), (nsets, B), device=device, generator=gen)]
+    cols = []
+    for b in data.batches:
+        B = len(b['targets_np'])
+        for m in b['formula'].anchor_modes:
+            cols.append(pick(m, B))
+    for _ in range(2):                                   # targets, then negatives
+        for b in data.batches:
+            cols.append(pick(b['formula'].target_mode, len(b['targets_np'])))
+    return torch.cat(cols, dim=1).contiguous()
 
 
 class _Q(object):
@@ -148,6 +187,53 @@ def self_check(model, fstep, packed, data, world):
     if bad:
         sys.stderr.write('bench self-check FAILED (fused step vs module path): ' + '; '.join(bad) + '\n')
         raise SystemExit(3)
+
+
+def fresh_check(fstep, desc, ids, data):
+    """The timed loop's form of a step -- descriptors + a flat id tensor already on the device, the touch plan built
+    inside the step -- against pack() from host arrays of the same ids: same loss and gradients, bit for bit."""
+    loss_a = fstep.run(fstep.pack(desc, ids=ids)).clone()
+    ga = fstep.flat_grad.clone()
+    h = ids.cpu().numpy()
+    batches, oa = [], 0
+    na = sum(len(b['targets_np']) * b['A'] for b in data.batches)
+    ng = sum(len(b['targets_np']) for b in data.batches)
+    og = 0
+    for d, b in zip(desc, data.batches):
+        B, A = len(b['targets_np']), b['A']
+        batches.append(dict(formula=d['formula'], weight=d['weight'], anchor_ids=h[oa:oa + A * B].reshape(A, B).T.copy(),
+                            targets=h[na + og:na + og + B].copy(), negs=h[na + ng + og:na + ng + og + B].copy()))
+        oa += A * B
+        og += B
+    loss_b = fstep.run(fstep.pack(batches))
+    fstep.check()
+    if not (torch.equal(loss_a, loss_b) and torch.equal(ga, fstep.flat_grad)):
+        sys.stderr.write('bench self-check FAILED: device-resident ids vs host ids differ\n')
+        raise SystemExit(3)
+
+
+def exchange_check(fstep, exchange, xplan, packed):
+    """One step reduced both ways: StepExchange.reduce against a dense all-reduce of the whole flat gradient. Returns None
+    when they agree, else the reason the dense form is used."""
+    import torch.distributed as dist
+    try:
+        fstep.run(packed)
+        ref = fstep.flat_grad.clone()
+        if exchange.backend == 'gloo':
+            h = ref.cpu()
+            dist.all_reduce(h)
+            ref.copy_(h)
+        else:
+            dist.all_reduce(ref)
+        exchange.reduce(xplan)
+        torch.cuda.synchronize()
+        err = float((fstep.flat_grad - ref).abs().max())
+        tol = 1e-6 * max(1.0, float(ref.abs().max()))
+        bad = torch.tensor([1.0 if not (err <= tol) else 0.0], device='cpu' if exchange.backend == 'gloo' else ref.device)
+        dist.all_reduce(bad)                              # (every rank takes the same branch)
+        return None if float(bad) == 0.0 else 'exchange differed from the dense all-reduce (max abs %.3g): dense form used' % err
+    except Exception as e:                                # noqa: BLE001 -- any failure of the untested N-rank path: say so
+        return 'exchange failed (%s: %s): dense form used' % (type(e).__name__, e)
 
 
 def pack_for_fused(step, data, scale=1.0):
@@ -435,11 +521,32 @@ def cpu_baseline(args, schema, model_state, node_maps, rel_ids, mode_ids, cfg, s
                           ', '.join('%d: %.2f' % (c, t) for c, t in sorted(timing.items()))))
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks as a child `torch.distributed.run` -- this
+    process has not touched a GPU (counting devices does not) and only relays the child's exit status."""
+    ndev = torch.cuda.device_count()
+    if args.backend == 'nccl' and ndev < args.gpus:
+        sys.stderr.write('bench.py --gpus %d: only %d GPU(s) visible (one process per GPU)\n' % (args.gpus, ndev))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU)' % (args.gpus, world))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -451,14 +558,18 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local % ndev))
         else:
             dist.init_process_group('gloo')
+        assert dist.get_world_size() == args.gpus
     else:
         torch.cuda.set_device(0)
     device = torch.device('cuda', torch.cuda.current_device())
 
-    from mpqe_amd import synthetic
+    from mpqe_amd import ops, synthetic
     from mpqe_amd.data_utils import make_feature_modules
     from mpqe_amd.encoders import DirectEncoder
     from mpqe_amd.model import RGCNEncoderDecoder
+    for kv in args.debug_opt:
+        name, _, val = kv.partition('=')
+        ops.lib().mpqe_debug_option(name.encode(), int(val or 1), 1)
     torch.manual_seed(0)                                  # identical replicas on every rank
     D = args.embed_dim
     schema = synthetic.make_schema(*synthetic.KG_SHAPES[args.kg], seed=0)
@@ -471,40 +582,54 @@ def main():
     model = model.to(device)
     model.validate = False                                # no per-call D2H flag read in the timed loop
     rng = np.random.RandomState(1000 + rank)
-    pool = [StepData(schema, model, args.batch_size, rng, device) for _ in range(4)]
+    pool = [StepData(schema, model, args.batch_size, rng, device) for _ in range(4)]      # 4 formula sets
 
     use_fused = args.path in ('auto', 'fused') and args.readout in ('mp', 'sum', 'max')
-    reducer = fstep = packed = captured = exchange = xplans = None
+    fresh = use_fused and not args.replay and not args.graph
+    reducer = fstep = packed = captured = exchange = xplans = fresh_ids = descs = None
+    n_total = args.warmup + args.steps * max(1, args.repeats)
     if use_fused:
         from mpqe_amd.fused import FusedTrainStep
+        touch = {'step': 'step', 'pack': 'pack', 'atomics': False}[args.touch]
         fstep = FusedTrainStep(model, lanes=args.lanes, prune=not args.no_prune, chain=not args.no_chain,
                                ksplit=not args.no_ksplit, eight_waves=args.eight_waves, uniform=not args.no_uniform,
-                               sparse_tables=args.sparse_tables, merge_tail=None if args.merge_tail < 0 else bool(args.merge_tail))
+                               touch=touch, sparse_tables=args.sparse_tables,
+                               merge_tail=None if args.merge_tail < 0 else bool(args.merge_tail))
         packed = [pack_for_fused(fstep, d, 1.0 / world) for d in pool]
         captured = [fstep.capture(p) for p in packed] if args.graph else None
+        if fresh:
+            # the timed steps' inputs: per formula set its descriptors (formula, weight, size) and, resident in HBM before
+            # the timed region starts, one NEVER-SEEN id set per step
+            descs = [[dict(formula=b['formula'], weight=b['weight'] / world, batch_size=len(b['targets_np']))
+                      for b in d.batches] for d in pool]
+            per_set = (min(n_total, max(args.fresh_sets, len(pool))) + len(pool) - 1) // len(pool)
+            fresh_ids = [draw_ids_device(schema, d, per_set, 77000 + 16 * rank + j, device) for j, d in enumerate(pool)]
         if world > 1 and not args.dense_allreduce:
-            # gradient exchange of the packed steps (collective, at pack time): which relation matrices / table rows ANY
-            # rank touches -- one bucket all-reduce of those matrices + an all-gather of table rows per step
+            # gradient exchange of the steps (collective, once per formula set): which relation matrices ANY rank touches
             from mpqe_amd.parallel import StepExchange
             exchange = StepExchange(fstep)
-            xplans = [exchange.plan(p) for p in packed]
+            xplans = [exchange.plan(p, key=j) for j, p in enumerate(packed)]
     elif world > 1:
         from mpqe_amd.parallel import GradReducer
         reducer = GradReducer(model)
 
     def one_step(i):
+        j = i % len(pool)
         if use_fused:
             if captured is not None:
-                loss = captured[i % len(pool)].replay()
+                loss = captured[j].replay()
+            elif fresh:
+                ids = fresh_ids[j][(i // len(pool)) % fresh_ids[j].shape[0]]
+                loss = fstep.run(fstep.pack(descs[j], ids=ids))
             else:
-                loss = fstep.run(packed[i % len(pool)])
+                loss = fstep.run(packed[j])
             if exchange is not None:
-                exchange.reduce(xplans[i % len(pool)])    # (the 1 / world of the mean is in the batch weights)
+                exchange.reduce(xplans[j])                # (the 1 / world of the mean is in the batch weights)
             elif world > 1:
                 import torch.distributed as dist
                 dist.all_reduce(fstep.flat_grad)          # the literal form: every parameter's dense gradient
             return loss
-        loss = step_modules(model, pool[i % len(pool)])
+        loss = step_modules(model, pool[j])
         if reducer is not None:
             reducer.all_reduce()
         return loss
@@ -517,26 +642,52 @@ def main():
 
     if use_fused and not args.no_self_check and not args.sparse_tables:      # (the check compares DENSE gradients)
         self_check(model, fstep, packed[0], pool[0], world)
+        if fresh:
+            fresh_check(fstep, descs[0], fresh_ids[0][0], pool[0])
+    xnote = None
+    if exchange is not None:
+        # the exchange against the literal dense all-reduce on one step (N-rank hardware is not available to the tests):
+        # a mismatch falls back to the dense form, and says so
+        xnote = exchange_check(fstep, exchange, xplans[0], packed[0])
+        if xnote is not None:
+            exchange = None
+    step_no = 0
     for i in range(args.warmup):
-        one_step(i)
-    # The timed region is EXACTLY `steps` steps between barrier + synchronize on both sides. At ~0.05 ms per step the
-    # driver's --steps 20 is a ~1 ms region, within launch / clock noise of a single sample: the same block is
-    # repeated `--repeats` times (each one bracketed the same way) and the MEDIAN block is the reported one,
-    # with min and max beside it. Per block the time is the max over ranks.
+        one_step(step_no)
+        step_no += 1
+    # The timed region is EXACTLY `steps` steps between barrier + synchronize on both sides. At ~0.07 ms per step the
+    # driver's --steps 20 is a ~1.4 ms region, within launch / clock noise of a single sample: the same block is
+    # repeated `--repeats` times (each one bracketed the same way, each step on the next fresh id set) and the MEDIAN
+    # block is the reported one, with min and max beside it. Per block the time is the max over ranks.
     blocks = []
     for r in range(max(1, args.repeats)):
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            one_step(i)
+            one_step(step_no + i)
         barrier()
         blocks.append(time.perf_counter() - t0)
+        step_no += args.steps
+    if use_fused:
+        fstep.check()                                     # an invalid id / a failed hand-off inside any timed step
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor(blocks, device=device if args.backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         blocks = [float(v) for v in t.tolist()]
     elapsed = float(np.median(blocks))
+    replay_ms = None
+    if fresh and rank == 0 and world == 1:
+        # secondary figure: the replay of 4 pre-packed steps (round 2's headline; nothing id-dependent left in the loop)
+        rb = []
+        for r in range(max(1, min(args.repeats, 9))):
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                fstep.run(packed[i % len(pool)])
+            barrier()
+            rb.append(time.perf_counter() - t0)
+        replay_ms = float(np.median(rb)) / args.steps * 1e3
 
     graphs_per_step = pool[0].num_graphs * world
     value = graphs_per_step * args.steps / elapsed
@@ -558,8 +709,16 @@ def main():
                                   if world > 1 else 'single GPU',
                    'host_path': 'fused step: one C-ABI call per step, %d stream lane(s)%s'
                                 % (args.lanes, ', replayed from a hipGraph' if args.graph else '') if use_fused
-                                else 'drop-in modules (one autograd graph per step)'},
+                                else 'drop-in modules (one autograd graph per step)',
+                   'ids': ('fresh every step: %d pre-drawn id sets resident in HBM, 4 formula sets; id -> row lookups and the '
+                           'touch plan (%s) inside the timed step' % (sum(int(t.shape[0]) for t in fresh_ids), args.touch))
+                          if fresh else 'replay of 4 pre-packed steps'},
     }
+    if replay_ms is not None:
+        out['replay'] = {'ms_per_step': replay_ms, 'value': graphs_per_step / (replay_ms * 1e-3),
+                         'note': '4 pre-packed steps replayed (no fresh ids): secondary figure'}
+    if xnote is not None:
+        out['exchange_note'] = xnote
     if world > 1 and use_fused:
         dense_bytes = fstep.flat_grad.numel() * 4
         out['exchange'] = ({'form': 'dense all-reduce of the flat gradient buffer', 'bytes_per_rank_per_step': int(2 * (world - 1) / world * dense_bytes)}
@@ -567,45 +726,69 @@ def main():
                            {'form': 'bucket all-reduce of the relation matrices some rank touches (+ root, bias, mode rows) and an '
                                     'all-gather of touched entity-table rows',
                             'bytes_per_rank_per_step': int(np.mean([x.wire_bytes for x in xplans])),
-                            'bucket_bytes': int(np.mean([x.bucket.numel() * 4 for x in xplans])),
+                            'bucket_bytes': int(np.mean([x.bucket_bytes for x in xplans])),
                             'table_rows_gathered': int(np.mean([x.entries for x in xplans])),
+                            'forms': sorted(set(x.form for x in xplans)),
                             'dense_gradient_bytes': dense_bytes})
     if rank == 0 and use_fused and world == 1:
-        # host side of a step with FRESH formulas and ids (a training loop draws new ones every step): packing =
-        # descriptors + ids to the device + the touch plan's sort; first run = + the descriptor table upload. Outside
-        # `value` (SURVEY.md 8d excludes collation), reported so that it can be held against ms_per_step.
-        fresh = StepData(schema, model, args.batch_size, np.random.RandomState(4242), device)
+        # host side of a step whose ids arrive from the HOST (a data loader's numpy arrays): packing = descriptors (cached
+        # per formula) + ids into pinned staging + ONE host-to-device copy on the copy stream, overlapped with the step
+        # that is running; the step waits for its own copy only. Outside `value` (SURVEY.md 8d excludes collation;
+        # `value` itself runs on fresh ids that are already resident), reported so that it can be held against ms_per_step.
+        host = StepData(schema, model, args.batch_size, np.random.RandomState(4242), device)
         torch.cuda.synchronize()
         tp = []
         for _ in range(5):
             t0 = time.perf_counter()
-            pk = pack_for_fused(fstep, fresh)
+            pk = pack_for_fused(fstep, host)
             t1 = time.perf_counter()
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             fstep.run(pk)
             torch.cuda.synchronize()
             tp.append((t1 - t0, t2 - t0, time.perf_counter() - t2))
-        # ... and the training-loop regime: pack + run back to back, no synchronisation (the host packs step k + 1 while
-        # the device runs step k): host seconds per step of such a loop
-        for _ in range(8):           # (steady state: a descriptor set that recurs gets its copy + plan build captured
-            pk = pack_for_fused(fstep, fresh)       # as one hipGraph at its third pack -- a one-off of a few ms)
+        for _ in range(8):
+            pk = pack_for_fused(fstep, host)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(100):
-            pk = pack_for_fused(fstep, fresh)
+            pk = pack_for_fused(fstep, host)
         t_pack = (time.perf_counter() - t0) / 100
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(100):
-            fstep.run(pack_for_fused(fstep, fresh))
+        for _ in range(200):
+            fstep.run(pack_for_fused(fstep, host))
         torch.cuda.synchronize()
-        t_loop = (time.perf_counter() - t0) / 100
+        t_loop = (time.perf_counter() - t0) / 200
+        t_dev = t_flat = None
+        if fresh:
+            # ... and ids the collate function wrote in the library's layout (one int64 array per step, pinned or not):
+            # descriptors + ONE staging copy + the host-to-device copy; a different id set every step
+            hids = [fresh_ids[0][k].cpu().numpy() for k in range(min(64, fresh_ids[0].shape[0]))]
+            for k in range(8):
+                fstep.run(fstep.pack(descs[0], ids=hids[k % len(hids)]))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(200):
+                fstep.run(fstep.pack(descs[0], ids=hids[k % len(hids)]))
+            torch.cuda.synchronize()
+            t_flat = (time.perf_counter() - t0) / 200
+            d0, i0 = descs[0], fresh_ids[0]
+            for k in range(8):
+                fstep.pack(d0, ids=i0[k])
+            t0 = time.perf_counter()
+            for k in range(200):
+                fstep.pack(d0, ids=i0[k % i0.shape[0]])
+            t_dev = (time.perf_counter() - t0) / 200
         out['pack_ms'] = {'host_call': float(np.median([a for a, _, _ in tp])) * 1e3,
                           'until_device_idle': float(np.median([b for _, b, _ in tp])) * 1e3,
                           'first_run_with_descriptor_upload': float(np.median([c for _, _, c in tp])) * 1e3,
                           'host_call_back_to_back': t_pack * 1e3,
-                          'pack_and_run_loop_per_step': t_loop * 1e3}
+                          'host_call_device_resident_ids': None if t_dev is None else t_dev * 1e3,
+                          'pack_and_run_loop_per_step': t_loop * 1e3,
+                          'flat_host_ids_loop_per_step': None if t_flat is None else t_flat * 1e3,
+                          'note': 'pack_and_run_loop_per_step: per-batch host arrays [B, A] / [B] -> layout conversion + copy '
+                                  '+ step; flat_host_ids_loop_per_step: host ids already in the library layout -> copy + step'}
     if rank == 0:
         flops_fwd, flops_all, bytes_all, launches = layer_work(pool[0], model)
         if use_fused:

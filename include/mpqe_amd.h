@@ -11,8 +11,13 @@
  *   - floats are fp32, contiguous row-major; indices are int64 like the
  *     reference's LongTensors; sizes are int64_t;
  *   - the caller owns every buffer, including workspaces (query the size
- *     first); the library never allocates and holds no global mutable state,
- *     so it is re-entrant per stream;
+ *     first); the library never allocates device memory and is re-entrant per
+ *     stream. Host-side state, all behind one mutex: a cache of launch plans
+ *     (pure functions of the descriptors, keyed by the caller's `desc`
+ *     buffer). The library never reads the environment. The three
+ *     mpqe_debug_* entry points at the end of this file are DIAGNOSTICS:
+ *     process-global, off by default, to be set from one thread while no
+ *     call is in flight; nothing in the data path depends on them;
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream);
  *   - every function returns MPQE_OK or a negative MPQE_ERR_* code and never
  *     synchronises. Data-dependent faults (an index outside its table) cannot
@@ -266,6 +271,14 @@ int mpqe_hinge_bwd(const float *pos, const float *neg, int64_t n, float margin, 
  *             MERGE_TAIL forces the merged form, SPLIT_TAIL the split one.                                    */
 #define MPQE_STEP_MERGE_TAIL 128
 #define MPQE_STEP_SPLIT_TAIL 256
+/* BUILD_TOUCH  (chain form, backward) the step builds the touch plan of the ids it is called with ITSELF, by workgroups
+ *             that lead its first launch and run beside the forward / backward chains (step_touch.h): `touch` is then an
+ *             OUTPUT buffer (mpqe_step_touch_bytes; valid once the call has run: mpqe_adam_rows_step and the row exchange
+ *             read its keys), and a step with fresh ids costs no more than a replayed one -- nothing id-dependent is left
+ *             for collation time (the reference resolves ids and accumulates embedding gradients inside forward /
+ *             backward: encoders.py:40-43, data_utils.py:35). Steps of more than 262 144 looked-up ids, the level form
+ *             and EIGHT_WAVES return MPQE_ERR_UNSUPPORTED: build the plan with mpqe_step_touch_build instead.       */
+#define MPQE_STEP_BUILD_TOUCH 512
 
 typedef struct {
     int32_t query_type;        /* MPQE_Q_*                                                     */
@@ -358,7 +371,13 @@ int mpqe_step_forward_backward(const mpqe_step_params_t *params_host, const mpqe
                                float *scores_neg, void *desc, size_t desc_bytes, int upload_desc,
                                void *workspace, size_t workspace_bytes, int32_t *err,
                                const mpqe_step_lanes_t *lanes, void *const *events, int num_events,
-                               const void *touch /* mpqe_step_touch_build's buffer, or NULL */, void *stream);
+                               void *touch /* mpqe_step_touch_build's buffer (read), the plan buffer to fill (MPQE_STEP_BUILD_TOUCH), or
+                                              NULL */, void *stream);
+
+/* Ids of the next step from pinned host memory to the device on `stream` (hipMemcpyAsync; stream-ordered, returns at
+ * once): the reference moves its index tensors with .to(device) per call (utils.py:17-23). For host mirrors without a
+ * HIP binding of their own.                                                                          */
+int mpqe_copy_to_device(void *dst, const void *src_host, size_t bytes, void *stream);
 
 /* ---- optimiser step ---------------------------------------------------------
  * reference train.py:83-88: optim.Adam(params, lr) / optim.SGD(params, lr, momentum=0) over every
@@ -420,6 +439,10 @@ void mpqe_debug_chain_stamps(void *device_buffer, size_t num_blocks);
  * ticks start -> end [2], HW_ID | XCC_ID << 32 in [3], wall clock when the tile's record is read [4], when its first
  * K-step has landed [5] and when its K loop ends [6].                                                */
 void mpqe_debug_tail_stamps(void *device_buffer, size_t num_blocks);
+/* Named diagnostics switches (timing experiments; tests that force a rarely taken path, e.g. "TOUCH_ROCPRIM" = the
+ * library sort instead of the one-launch sort, "GEN_SLOTS" = grid size of the persistent gather-GEMMs). set != 0
+ * stores `value` under `name`, set == 0 removes it. Process-global (see Conventions).                    */
+void mpqe_debug_option(const char *name, int value, int set);
 
 #ifdef __cplusplus
 }

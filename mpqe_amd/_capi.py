@@ -92,6 +92,8 @@ PROTOTYPES = {
     'mpqe_hinge_bwd': (I, [P, P, L, F, P, P, P, P]),
     'mpqe_debug_chain_stamps': (None, [P, Z]),
     'mpqe_debug_tail_stamps': (None, [P, Z]),
+    'mpqe_debug_option': (None, [c_char_p, I, I]),
+    'mpqe_copy_to_device': (I, [P, P, Z, P]),
     'mpqe_sample_negatives': (I, [P, L, P, L, P, L, ctypes.c_uint64, P, P, P]),
     'mpqe_adam_step': (I, [P, P, P, P, L, DBL, DBL, DBL, DBL, DBL, L, P]),
     'mpqe_sgd_step': (I, [P, P, L, DBL, DBL, P]),
@@ -149,6 +151,8 @@ STEP_NO_PRUNE, STEP_NO_CHAIN, STEP_ZERO_GRADS, STEP_NO_KSPLIT, STEP_EIGHT_WAVES,
 STEP_SPARSE_TABLES = 64
 STEP_MERGE_TAIL = 128
 STEP_SPLIT_TAIL = 256
+STEP_BUILD_TOUCH = 512
+TSORT_MAX_ENTRIES = 256 * 1024        # csrc/step_touch.h: the in-step touch plan covers this many looked-up ids
 
 
 def make_step_params(dim, num_relations, readout, table_ptrs, table_rows, node_map_ptr, node_map_len,

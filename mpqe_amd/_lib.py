@@ -11,8 +11,12 @@ _lib = None
 
 
 def load():
-    global _lib
+    """MPQE_AMD_LIB (development aid: same-box A/B of builds, tools/ab.sh) names another build of the SAME library to load
+    instead of the installed one; it must exist and bind every symbol like the installed one -- there is no fallback."""
+    global _lib, LIB_PATH
     if _lib is None:
+        if os.environ.get('MPQE_AMD_LIB'):
+            LIB_PATH = os.environ['MPQE_AMD_LIB']
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 'mpqe_amd: %s not found. Build it with `python -m mpqe_amd.build` '

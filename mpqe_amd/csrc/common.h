@@ -19,6 +19,11 @@ static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Diagnostics switches (debug.hip): the value set by mpqe_debug_option(name, ...), `unset` otherwise. The library
+// never reads the environment.
+int mpqe_dbg_value(const char *name, int unset);
+static inline bool dbg_on(const char *name) { return mpqe_dbg_value(name, 0) != 0; }
+
 // Host-side copy of the template tables (reference data_utils.py:325-362).
 struct TemplateDesc {
     int A, V, N, E, diam;

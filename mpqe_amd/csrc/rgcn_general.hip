@@ -916,14 +916,14 @@ extern "C" int mpqe_rgcn_general_fwd(const void *plan, int64_t Nn, int64_t E, in
     const bool gvec = (!basis || ptr_vec_ok(basis, Dout)) && ptr_vec_ok(root, Dout) && (Din * Dout) % 4 == 0 &&
                       ptr_vec_ok(x, Din);
     dim3 grid((unsigned)(((tile_bound(Nn, E, R) + 7) / 8 * 8) * ((Dout + GT_BN - 1) / GT_BN)));      // (1-D: see the kernel)
-    const bool rows64 = gvec && Din % 64 == 0 && Dout % 64 == 0 && !getenv("MPQE_DBG_GEN_LDS_GEMM");
+    const bool rows64 = gvec && Din % 64 == 0 && Dout % 64 == 0 && !dbg_on("GEN_LDS_GEMM");
     if (rows64) {
         // persistent: one workgroup per CU (the kernel claims the LDS for that), whole groups of 8 x column groups
         const long long cb1 = Dout / 64, rt1 = (cb1 >= 3 || cb1 == 0) ? 1 : 4 / cb1, cg1 = cb1 >= 4 ? (cb1 + 3) / 4 : 1;
         const long long items1 = (((tile_bound(Nn, E, R) + rt1 - 1) / rt1 + 7) / 8 * 8) * cg1;
-        const char *fs = getenv("MPQE_DBG_GEN_SLOTS");      // (tests: a small grid, so that workgroups walk several tiles)
-        const long long per1 = 8 * cg1, slots1 = (fs ? atoi(fs) : 256) / per1 * per1;
-        dim3 g1((unsigned)(items1 < slots1 || slots1 == 0 || getenv("MPQE_DBG_GEN_NOT_PERSISTENT") ? items1 : slots1));
+        // (GEN_SLOTS, tests: a small grid, so that workgroups walk several tiles)
+        const long long per1 = 8 * cg1, slots1 = mpqe_dbg_value("GEN_SLOTS", 256) / per1 * per1;
+        dim3 g1((unsigned)(items1 < slots1 || slots1 == 0 || dbg_on("GEN_NOT_PERSISTENT") ? items1 : slots1));
         hipLaunchKernelGGL((rgcn_gen_gemm_rows_kernel<false, false>), g1, dim3(256), 0, s, P.rows_fwd, P.rel_ptr, P.tile_ptr,
                            (int)R, x, (const float *)nullptr, basis, root, (int)Din, (int)Dout, msg);
     } else
@@ -980,12 +980,11 @@ extern "C" int mpqe_rgcn_general_bwd(const void *plan, int64_t Nn, int64_t E, in
     const float *mask = relu ? out : nullptr;
     if (grad_x) {
         dim3 grid((unsigned)(((tile_bound(Nn, E, R) + 7) / 8 * 8) * ((Din + GT_BN - 1) / GT_BN)));
-        const bool rows64g = gvec && Din % 64 == 0 && Dout % 64 == 0 && !getenv("MPQE_DBG_GEN_LDS_GEMM");
+        const bool rows64g = gvec && Din % 64 == 0 && Dout % 64 == 0 && !dbg_on("GEN_LDS_GEMM");
         const long long cb1 = Din / 64, rt1 = (cb1 >= 3 || cb1 == 0) ? 1 : 4 / cb1, cg1 = cb1 >= 4 ? (cb1 + 3) / 4 : 1;
         const long long items1 = (((tile_bound(Nn, E, R) + rt1 - 1) / rt1 + 7) / 8 * 8) * cg1;
-        const char *fs = getenv("MPQE_DBG_GEN_SLOTS");
-        const long long per1 = 8 * cg1, slots1 = (fs ? atoi(fs) : 512) / per1 * per1;       // (two workgroups per CU)
-        dim3 g1((unsigned)(items1 < slots1 || slots1 == 0 || getenv("MPQE_DBG_GEN_NOT_PERSISTENT") ? items1 : slots1));
+        const long long per1 = 8 * cg1, slots1 = mpqe_dbg_value("GEN_SLOTS", 512) / per1 * per1;       // (two workgroups per CU)
+        dim3 g1((unsigned)(items1 < slots1 || slots1 == 0 || dbg_on("GEN_NOT_PERSISTENT") ? items1 : slots1));
         if (rows64g && relu)
             hipLaunchKernelGGL((rgcn_gen_gemm_rows_kernel<true, true>), g1, dim3(256), 0, s, P.rows_bwd, P.rel_ptr, P.tile_ptr,
                                (int)R, grad_out, mask, basis, root, (int)Din, (int)Dout, gmsg);
@@ -1007,9 +1006,9 @@ extern "C" int mpqe_rgcn_general_bwd(const void *plan, int64_t Nn, int64_t E, in
     if (grad_basis || grad_root) {
         const int tiles = (int)(((Din + GT_BM - 1) / GT_BM) * ((Dout + GT_BN - 1) / GT_BN));
         dim3 grid((unsigned)chunk_bound(Nn, E, R), tiles);
-        const bool rows64 = gvec && Din % 64 == 0 && Dout % 64 == 0 && !getenv("MPQE_DBG_GEN_LDS_GRADW");
+        const bool rows64 = gvec && Din % 64 == 0 && Dout % 64 == 0 && !dbg_on("GEN_LDS_GRADW");
         const dim3 grid1((unsigned)(((chunk_bound(Nn, E, R) + 7) / 8 * 8) * tiles));      // (rows kernel: 1-D, see there)
-        if (rows64 && relu && !getenv("MPQE_DBG_GEN_NOMASK"))
+        if (rows64 && relu && !dbg_on("GEN_NOMASK"))
             hipLaunchKernelGGL(rgcn_gen_grad_w_rows_kernel<true>, grid1, dim3(256), 0, s, P.rows_fwd, P.rows_bwd, P.rel_ptr,
                                P.chunk_ptr, (int)R, x, grad_out, mask, (int)Din, (int)Dout, slabs);
         else if (rows64)

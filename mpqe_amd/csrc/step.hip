@@ -272,9 +272,14 @@ struct ZeroSegs {
 #define PREP_ZERO_FLOATS_PER_BLOCK 8192      // 256 threads x 8 x float4
 struct PrepArgs {
     UArgs ua;
+    TSortArgs ts;             // the touch plan's sort (MPQE_STEP_BUILD_TOUCH): workgroups [0, sblocks) of the launch --
+    int sblocks;              // dealt to the XCDs of `sxrank` only (4 bits per XCD: rank + 1, 0 = none; workgroup b of a
+    int sna;                  // launch runs on XCD b % 8): the first sblocks = 8 x rows workgroups of the launch are ROWS of
+    unsigned sxrank;          // eight -- the sort's XCDs take sort workgroups, the others go on with the prologue's items
+    int strail;               // != 0: the launch's LAST strail workgroups instead (diagnostics switch TSORT_TRAIL)
     int ublocks, tblocks;     // vector-op workgroups, transpose workgroups
-    int lead;                 // prologue workgroups in front of the chain workgroups: ublocks + tblocks rounded up to a
-                              // multiple of 8 (chain workgroup b keeps XCD b % 8)
+    int lead;                 // prologue workgroups in front of the chain workgroups: sblocks + ublocks + tblocks rounded
+                              // up to a multiple of 8 (chain workgroup b keeps XCD b % 8)
     int nchain;               // chain workgroups (holes of the placement grid included)
     const WtSlot *slots;
     float *WT;
@@ -399,6 +404,10 @@ __global__ __launch_bounds__(64 * NW) void step_chain_kernel(const StepDev *__re
     // role of this workgroup (uniform): chain workgroup, prologue work in front of / behind them, zero fill, then the
     // post roles: a producer is never queued behind a consumer that waits for it
     int bid = (int)blockIdx.x, role;
+    if (pa.strail && bid >= (int)gridDim.x - pa.strail) {
+        if (NW == 4 || threadIdx.x < TSORT_THREADS) tsort_block(pa.ts, bid - ((int)gridDim.x - pa.strail), reinterpret_cast<unsigned *>(S.xs));
+        return;
+    }
     if (bid < pa.lead) role = 1;
     else if (bid < pa.lead + pa.nchain) role = 0, bid -= pa.lead;
     else role = 2, bid -= pa.lead + pa.nchain;
@@ -411,6 +420,26 @@ __global__ __launch_bounds__(64 * NW) void step_chain_kernel(const StepDev *__re
         chain_block<NCB, KS, NW>(sd, lp, tabs, ca, S);
     } else if (role == 1) {
         constexpr int D = 16 * NCB * NW / KS;
+        // The touch plan of THIS step's ids (step_touch.h): the first workgroups of the launch, so all of them are
+        // resident before any other workgroup is dispatched (they synchronise among themselves); nothing in the launch
+        // waits for them -- the plan is read by the step's last launch.
+        if (bid < pa.sblocks) {
+            static_assert(sizeof(S.xs) >= TSORT_LDS_WORDS * sizeof(unsigned), "the sort's LDS tables live in the state buffers");
+            const int rk = (int)((pa.sxrank >> (4 * (bid & 7))) & 15u) - 1;
+            if (rk >= 0) {
+                const int sb = (bid >> 3) * pa.sna + rk;
+                if (sb < pa.ts.nblk && (NW == 4 || threadIdx.x < TSORT_THREADS))
+                    tsort_block(pa.ts, sb, reinterpret_cast<unsigned *>(S.xs));
+                return;
+            }
+            // (not one of the sort's XCDs: the next prologue item -- no hole in front of the chain workgroups of the XCDs
+            // whose CUs are all needed; its rank among the other XCDs)
+            int orank = 0;
+            for (int x = 0; x < (bid & 7); ++x) orank += ((pa.sxrank >> (4 * x)) & 15u) == 0u;
+            bid = (bid >> 3) * (8 - pa.sna) + orank;
+        } else {
+            bid -= pa.sblocks / 8 * pa.sna;               // (items the rows above have taken: sblocks / 8 x (8 - sna))
+        }
         if (bid < pa.ublocks) {
             if (NW == 4 || threadIdx.x < 256) uop_block(bid, D, lp, pa.ua, S.xs, nullptr, 0);
             // merged launch: the post-pass reads the pre-pass' vectors from VT. Wave 0 made the stores (write-through):
@@ -1060,7 +1089,8 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restri
                                                           const float *__restrict__ VT, unsigned *epoch_b,
                                                           const char *__restrict__ touch, size_t touch_keys,
                                                           const float *__restrict__ DG, TablePtrs tabs, int table_store,
-                                                          long long touch_M, int touch_row_bits) {
+                                                          long long touch_M, int touch_row_bits, size_t touch_perm,
+                                                          int32_t *err) {
     // zeroed: this call zero-filled the gradients, so `out` is known to be 0 -- a store replaces the
     // read-modify-write (whose read would be one more dependent round trip at the end of the chain)
     __shared__ f32x4 part[4][64];
@@ -1068,7 +1098,8 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restri
         // (As workgroups of the weight-gradient launch they are throttled to two per CU by its 64 KB of LDS: 23.6 us
         // for that launch instead of 16.6; here they cost 2.6 us.)
         table_sum_block(touch_M, touch_row_bits, reinterpret_cast<const tkey_t *>(touch + touch_keys),
-                        nullptr, DG, D, tabs, table_store & 1, (long long)((int)blockIdx.y - ngroups - 1) * gridDim.x + blockIdx.x);
+                        reinterpret_cast<const int *>(touch + touch_perm), DG, D, tabs, table_store & 1,
+                        (long long)((int)blockIdx.y - ngroups - 1) * gridDim.x + blockIdx.x);
         return;
     }
     if ((int)blockIdx.y == ngroups) {       // one extra workgroup row: the loss reduction rides along
@@ -1079,7 +1110,10 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restri
                 *epoch_b = *epoch_b + 1u;
                 *(epoch_b - 16) = *(epoch_b - 16) + 1u;       // epoch_f
                 if (table_store & 2) *(epoch_b + 32) = *(epoch_b + 32) + 1u;      // merged launch: its own epoch (DoneMeta)
+                *(epoch_b + 24) = 0u;       // the grid barrier of the next step's in-launch sort starts from zero (step_touch.h)
             }
+            // a touch plan whose build could not finish (its workgroups were not all resident: step_touch.h)
+            if (touch && threadIdx.x == 0 && reinterpret_cast<const TouchHeader *>(touch)->pad[0]) flag_error(err, MPQE_FLAG_INTERNAL);
             if (lm.chain) loss_block_chain(lm, bterms, loss, reinterpret_cast<float *>(part), 4);
             else loss_block(sd, terms, loss, reinterpret_cast<float *>(part), 4);
         }
@@ -1223,6 +1257,11 @@ struct HostPlan {
     size_t o_uopf, o_uopb, o_rank1, o_epoch, o_gran, o_VT, o_DG;
     std::vector<char> image;      // the descriptor table as uploaded ([0, o_epoch) of the desc buffer)
     long long touch_M;
+    // touch plan built inside the step (MPQE_STEP_BUILD_TOUCH; step_touch.h: tsort_block): sort workgroups, key widths,
+    // the batch table in the descriptor image, the sort's buffers in the workspace; ts_blocks = 0: not in this plan
+    int ts_blocks, ts_key_bits, ts_row_bits;
+    int sort_na, sort_rank[STEP_XCDS_MAX];       // the XCDs the sort's workgroups are dealt to (rank, or -1)
+    size_t o_tmeta, o_tsort;
     int blk_off[MPQE_STEP_MAX_BATCHES + 1];        // chain blocks before batch i (slots of block_terms)
     std::vector<ZMat> zmats;                       // relation matrices of the gradient that no source touches
     size_t o_zmats;
@@ -1501,13 +1540,12 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     std::stable_sort(r1keys.begin(), r1keys.end(),
                      [&](const R1Key &a, const R1Key &b) { return key_less(a.layer, a.rel, b.layer, b.rel); });
     // Weight-gradient tiles of the chain form: 64 x 64 outputs per workgroup. (64 x 32 -- twice as many tiles at half the
-    // MFMA time each, no K split, so no extra slab -- is built in, MPQE_DBG_TILE_N=32, and was measured on the AIFB step:
+    // MFMA time each, no K split, so no extra slab -- is built in, mpqe_debug_option TILE_N = 32, and was measured on the AIFB step:
     // the tiles end at 11.0 us instead of 14.8, but 320 of them next to the post-pass' 100 vector-op workgroups slow ITS
     // latency chain from 15 to 18.9 us, and the launch from 19.7 to 23.5.)
     int tile_n = GT_BN;
     if (chain && D % 64 == 0) {
-        const char *tn = getenv("MPQE_DBG_TILE_N");         // (timing experiments)
-        if (tn && atoi(tn) == 32) tile_n = 32;
+        if (mpqe_dbg_value("TILE_N", 0) == 32) tile_n = 32;       // (timing experiments)
     }
     hp->tile_n = tile_n;
     const int wct = (D + tile_n - 1) / tile_n;            // column tiles of a weight gradient
@@ -1521,7 +1559,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     // a workgroup for most CUs (the extra slabs go through the reduction)
     int chunk_rows = 512;
     {
-        const char *dbg = getenv("MPQE_DBG_CHUNK_ROWS");        // (timing experiments)
+        const int dbg = mpqe_dbg_value("CHUNK_ROWS", 0);        // (timing experiments)
         auto blocks_at = [&](int rows) {
             long long nblk = 0;
             for (size_t k = 0; k < keys.size(); ++k) {
@@ -1531,7 +1569,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
             }
             return nblk;
         };
-        if (dbg && atoi(dbg) >= GT_BK) chunk_rows = atoi(dbg) / GT_BK * GT_BK;
+        if (dbg >= GT_BK) chunk_rows = dbg / GT_BK * GT_BK;
         (void)blocks_at;
         // (measured on the AIFB mix, 136 whole-batch tiles of 13.8 us: 272 half-batch tiles take 8.2 us each but 16 CUs
         // get two of them and the launch needs the reduction for every matrix: 22.6 us against 18.3. Kept at 512.)
@@ -2080,9 +2118,10 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                 // B per batch 64 / 128: 50.0 / 52.5 us per step with this rule against 51.7 / 55.2 on all XCDs; B = 384:
                 // the first choice is short of room -- 63.0 against 61.0.)
                 const long long need = (long long)hp->wblock.size() + (long long)hp->uops_b.size() * (D / 64);
-                const char *pm = getenv("MPQE_DBG_POST_MODE");      // (timing experiments: force a choice)
+                const int pmv = mpqe_dbg_value("POST_MODE", -1);    // (timing experiments: force a choice)
+                const bool pm = pmv >= 0;
                 int na = 0;
-                for (int mode = pm ? atoi(pm) : 0; mode < 3; ++mode) {
+                for (int mode = pm ? pmv : 0; mode < 3; ++mode) {
                     long long room = 0;
                     na = 0;
                     for (int x = 0; x < STEP_XCDS; ++x) {
@@ -2097,6 +2136,20 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                     for (int x = 0; x < STEP_XCDS; ++x) hp->post_rank[x] = x;
                 }
                 hp->post_na = na;
+                // The touch plan's sort (MPQE_STEP_BUILD_TOUCH) holds a slot of a CU for most of the launch: on an XCD whose
+                // CUs all take two chain workgroups that slot is missing (AIFB step: 22 chain workgroups started 20 us late,
+                // launch 43 -> 57 us). Same choice as above: the XCDs with a free slot per CU and no workgroup of the
+                // heaviest programme, then those with a free slot, then all (a step that fills every XCD many times over).
+                int sna = 0;
+                const int smv = mpqe_dbg_value("SORT_MODE", 0);     // (timing experiments: force a choice)
+                for (int mode = smv; mode < 3 && sna == 0; ++mode) {
+                    sna = 0;
+                    for (int x = 0; x < STEP_XCDS; ++x) {
+                        const bool ok = mode == 2 || (bins[x].size() <= cus && (mode == 1 || !heavy[x]));
+                        hp->sort_rank[x] = ok ? sna++ : -1;
+                    }
+                }
+                hp->sort_na = sna;
             }
             size_t longest = 0;
             for (int x = 0; x < STEP_XCDS; ++x) {
@@ -2165,6 +2218,36 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->o_uopb = take(hp->uops_b.size() * sizeof(UOp));
     hp->o_rank1 = take(hp->rank1.size() * sizeof(Rank1));
     hp->o_done_inc = take(hp->done_inc.size() * sizeof(int));
+    TouchMeta tmeta;
+    memset(&tmeta, 0, sizeof(tmeta));
+    hp->ts_blocks = 0;
+    hp->ts_key_bits = hp->ts_row_bits = 0;
+    {
+        long long trows = 1;
+        for (int m = 0; m < P->num_modes && m < MPQE_STEP_MAX_MODES; ++m) trows = std::max(trows, (long long)P->table_rows[m]);
+        const int rb = touch_bits(trows), kb = rb + 5;
+        const long long M = anchors + 2 * graphs;
+        if (chain && (P->flags & MPQE_STEP_BUILD_TOUCH) && M <= TSORT_MAX_ENTRIES && kb <= 31) {
+            hp->ts_blocks = (int)((M + TSORT_PER_BLOCK - 1) / TSORT_PER_BLOCK);
+            hp->ts_key_bits = kb;
+            hp->ts_row_bits = rb;
+            tmeta.nb = nb;
+            tmeta.row_bits = rb;
+            for (int i = 0; i < nb; ++i) {
+                const TemplateDesc &t = kTemplates[B[i].query_type];
+                tmeta.B[i] = B[i].batch_size;
+                tmeta.A[i] = t.A;
+                tmeta.anchor_off[i] = sd.b[i].anchor_off;
+                tmeta.g_off[i] = sd.b[i].g_off;
+                for (int a = 0; a < 3; ++a) tmeta.anchor_tab[i][a] = a < t.A ? B[i].anchor_mode[a] : 0;
+                tmeta.target_tab[i] = B[i].target_mode;
+            }
+            tmeta.anchor_off[nb] = anchors;
+            tmeta.g_off[nb] = graphs;
+            for (int m = 0; m < P->num_modes && m < MPQE_STEP_MAX_MODES; ++m) tmeta.table_rows[m] = P->table_rows[m];
+        }
+    }
+    hp->o_tmeta = take(hp->ts_blocks ? sizeof(TouchMeta) : 0);
     // hand-off state of the packed step, zeroed when the table is uploaded: the two epoch words (forward pre-pass,
     // backward post-pass), then the granules
     hp->o_epoch = take(256);
@@ -2208,10 +2291,13 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         put(hp->o_uopb, hp->uops_b.data(), hp->uops_b.size() * sizeof(UOp));
         put(hp->o_rank1, hp->rank1.data(), hp->rank1.size() * sizeof(Rank1));
         put(hp->o_done_inc, hp->done_inc.data(), hp->done_inc.size() * sizeof(int));
+        if (hp->ts_blocks) put(hp->o_tmeta, &tmeta, sizeof(tmeta));
     }
     hp->o_VT = take((size_t)hp->nvec * D * 4);
     hp->touch_M = anchors + 2 * graphs;
     hp->o_DG = take(chain ? (size_t)hp->touch_M * D * 4 : 0);       // per-entry table-gradient rows (step_touch.h)
+    // in-step sort: (key, entry) ping-pong buffers [4][blocks x 1024] + digit counts [4 passes][blocks][256]
+    hp->o_tsort = take(hp->ts_blocks ? (size_t)hp->ts_blocks * (4 * TSORT_PER_BLOCK + 4 * 256) * sizeof(unsigned) : 0);
     hp->total = off;
     return MPQE_OK;
 }
@@ -2242,6 +2328,7 @@ struct PlanKey {
     int dim, num_layers, num_relations, num_modes, readout, flags, nb, nlanes, chain;
     int lane_begin[MPQE_STEP_MAX_LANES + 1];
     int alias[MPQE_STEP_MAX_LAYERS];          // first layer with the same parameter buffers
+    long long table_rows[MPQE_STEP_MAX_MODES];      // (the in-step touch plan's key widths and batch table)
     mpqe_step_batch_t b[MPQE_STEP_MAX_BATCHES];
 };
 struct CachedPlan {
@@ -2259,6 +2346,7 @@ void make_key(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     k->dim = P->dim; k->num_layers = P->num_layers; k->num_relations = P->num_relations;
     k->num_modes = P->num_modes; k->readout = P->readout; k->flags = P->flags & ~(MPQE_STEP_ZERO_GRADS | MPQE_STEP_NO_KSPLIT | MPQE_STEP_EIGHT_WAVES); k->nb = nb;
     k->nlanes = lanes ? lanes->num_lanes : 1;
+    for (int m = 0; m < P->num_modes && m < MPQE_STEP_MAX_MODES; ++m) k->table_rows[m] = P->table_rows[m];
     if (lanes)
         for (int l = 0; l <= MPQE_STEP_MAX_LANES; ++l) k->lane_begin[l] = lanes->batch_begin[l];
     for (int l = 0; l < P->num_layers && l < MPQE_STEP_MAX_LAYERS; ++l) {
@@ -2421,26 +2509,41 @@ extern "C" int mpqe_step_touch_build(const mpqe_step_params_t *P, const mpqe_ste
     th.M = M;
     th.row_bits = rb;
     th.key_bits = kb;
-#ifndef MPQE_EMU
-    if (M <= (long long)TSORT_MAX_BLOCKS * TSORT_THREADS && kb <= 31 && !getenv("MPQE_DBG_TOUCH_ROCPRIM")) {
-        // the whole plan in one launch (step_touch.h: touch_sort_kernel) behind the 4-byte clear of its barrier counter
-        const int nblk = (int)((M + TSORT_THREADS - 1) / TSORT_THREADS);
-        const size_t Mp = (size_t)nblk * TSORT_THREADS;
-        unsigned *ka = reinterpret_cast<unsigned *>(wb + L.w_keys), *kbuf = ka + Mp;      // (the 8-byte key array, halved)
-        unsigned *va = reinterpret_cast<unsigned *>(wb + L.w_vals), *vb = reinterpret_cast<unsigned *>(wb + L.w_svals);
-        unsigned *hist = reinterpret_cast<unsigned *>(wb + L.w_hist), *counter = hist + 4 * 64 * 256;
-        (void)hipMemsetAsync(counter, 0, sizeof(unsigned), s);
-        hipLaunchKernelGGL(touch_sort_kernel, dim3((unsigned)nblk), dim3(TSORT_THREADS), 0, s, tm,
-                           reinterpret_cast<const long long *>(anchor_ids), reinterpret_cast<const long long *>(targets),
-                           reinterpret_cast<const long long *>(negs), reinterpret_cast<const long long *>(P->node_map),
-                           (long long)P->node_map_len, ka, va, kbuf, vb, hist, counter,
-                           reinterpret_cast<tkey_t *>(tb + L.keys), reinterpret_cast<int *>(tb + L.perm),
-                           reinterpret_cast<int *>(tb + L.erow), (int)M, kb, th, reinterpret_cast<TouchHeader *>(tb));
+    static_assert(sizeof(TouchMeta) <= 2048, "touch_layout reserves 2 KB for the batch table");
+    if (M <= TSORT_MAX_ENTRIES && kb <= 31 && !dbg_on("TOUCH_ROCPRIM")) {
+        // the whole plan in one launch (step_touch.h: tsort_block) behind the clear of its barrier counter and the
+        // upload of the batch table
+        const int nblk = (int)((M + TSORT_PER_BLOCK - 1) / TSORT_PER_BLOCK);
+        const size_t Mp = (size_t)nblk * TSORT_PER_BLOCK;
+        TSortArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.ka = reinterpret_cast<unsigned *>(wb + L.w_keys);
+        sa.kb = sa.ka + Mp;                                   // (the 8-byte key array, halved)
+        sa.va = reinterpret_cast<unsigned *>(wb + L.w_vals);
+        sa.vb = reinterpret_cast<unsigned *>(wb + L.w_svals);
+        sa.hist = reinterpret_cast<unsigned *>(wb + L.w_hist);
+        sa.counter = sa.hist + 4 * 256 * 256;
+        TouchMeta *tmd = reinterpret_cast<TouchMeta *>(sa.counter + 64);
+        sa.tm = tmd;
+        (void)hipMemsetAsync(sa.counter, 0, sizeof(unsigned), s);
+        upload(s, reinterpret_cast<char *>(tmd), &tm, sizeof(tm));
+        sa.anchor_ids = reinterpret_cast<const long long *>(anchor_ids);
+        sa.targets = reinterpret_cast<const long long *>(targets);
+        sa.negs = reinterpret_cast<const long long *>(negs);
+        sa.node_map = reinterpret_cast<const long long *>(P->node_map);
+        sa.map_len = (long long)P->node_map_len;
+        sa.keys_out = reinterpret_cast<tkey_t *>(tb + L.keys);
+        sa.perm = reinterpret_cast<int *>(tb + L.perm);
+        sa.erow = reinterpret_cast<int *>(tb + L.erow);
+        sa.th_out = reinterpret_cast<TouchHeader *>(tb);
+        sa.M = (int)M;
+        sa.key_bits = kb;
+        sa.row_bits = rb;
+        sa.nblk = nblk;
+        hipLaunchKernelGGL(touch_sort_kernel, dim3((unsigned)nblk), dim3(TSORT_THREADS), 0, s, sa);
         return mpqe_launch_status();
     }
-#endif
-    // (the header rides along as an argument of the keys kernel, and the sort leaves its permutation in the workspace
-    // for the inversion to read: three launches + the sort's own instead of five + one copy -- pack time is host time)
+    // (the header rides along as an argument of the keys kernel; the sort leaves perm = the entries in sorted order)
     tkey_t *keys = reinterpret_cast<tkey_t *>(wb + L.w_keys);
     int *vals = reinterpret_cast<int *>(wb + L.w_vals);
     hipLaunchKernelGGL(touch_keys_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, tm,
@@ -2450,13 +2553,10 @@ extern "C" int mpqe_step_touch_build(const mpqe_step_params_t *P, const mpqe_ste
                        reinterpret_cast<TouchHeader *>(tb));
     size_t tmp_bytes = L.w_tmp_bytes;
     // stable: entries of one destination row keep their entry order, so the per-row sums have ONE order
-    int *sorted_vals = reinterpret_cast<int *>(wb + L.w_svals);
     if (rocprim::radix_sort_pairs(wb + L.w_tmp, tmp_bytes, (const tkey_t *)keys, reinterpret_cast<tkey_t *>(tb + L.keys),
-                                  (const int *)vals, sorted_vals, (size_t)M, 0u, (unsigned)kb, s) != hipSuccess)
+                                  (const int *)vals, reinterpret_cast<int *>(tb + L.perm), (size_t)M, 0u, (unsigned)kb,
+                                  s) != hipSuccess)
         return MPQE_ERR_LAUNCH;
-    // entry -> rank: pos[sorted_vals[k]] = k
-    hipLaunchKernelGGL(touch_invert_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, (const int *)sorted_vals,
-                       reinterpret_cast<int *>(tb + L.perm), M);
     return mpqe_launch_status();
 }
 
@@ -2609,7 +2709,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                                           float *loss, float *scores_pos, float *scores_neg, void *desc,
                                           size_t desc_bytes, int upload_desc, void *workspace,
                                           size_t workspace_bytes, int32_t *err, const mpqe_step_lanes_t *lanes,
-                                          void *const *events, int num_events, const void *touch, void *stream) {
+                                          void *const *events, int num_events, void *touch, void *stream) {
     if (!P || !B || nb < 1 || nb > MPQE_STEP_MAX_BATCHES || !desc) return MPQE_ERR_INVALID_ARG;
     const bool ask_chain = want_chain(P, B, nb);
     // The launch plan is a pure function of the descriptors; it is kept on the host next to the device
@@ -2643,6 +2743,11 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     const bool use_chain = hp.chain;
     // touch plan given: the chain form stores per-entry table-gradient rows and sums them per destination (no atomics)
     bool use_touch = touch != nullptr && use_chain && backward;
+    // ... BUILD_TOUCH: `touch` is an OUTPUT -- the step builds the plan of the ids it is called with inside its chain launch
+    // (the level form has no use for a plan and leaves the buffer alone, as it ignores a plan built at pack time)
+    const bool build_touch = use_touch && (P->flags & MPQE_STEP_BUILD_TOUCH) != 0;
+    if (build_touch && (hp.ts_blocks <= 0 || (P->flags & MPQE_STEP_EIGHT_WAVES) || hp.nlanes > 1))
+        return MPQE_ERR_UNSUPPORTED;        // (a step beyond TSORT_MAX_ENTRIES ids: build the plan at pack time)
     const bool sparse_tables = (P->flags & MPQE_STEP_SPARSE_TABLES) != 0;
     if (sparse_tables && backward && !use_touch) return MPQE_ERR_INVALID_ARG;      // (needs the touch plan and the chain form)
     int touch_row_bits = 1;         // (= the header of the caller's plan: mpqe_step_touch_build derives it the same way)
@@ -2797,13 +2902,50 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             pa.ua.epoch = epoch_f;
             pa.ublocks = pa.ua.nops * pa.ua.chunks;
             pa.tblocks = backward ? (int)hp.wt_slots.size() * tpd * tpd : 0;
+            pa.sblocks = 0;
+            if (build_touch) {
+                const TouchLayout TL = touch_layout(hp.touch_M, 0);
+                char *tb = reinterpret_cast<char *>(touch);
+                const size_t Mp = (size_t)hp.ts_blocks * TSORT_PER_BLOCK;
+                TSortArgs &ts = pa.ts;
+                ts.tm = reinterpret_cast<const TouchMeta *>(db + hp.o_tmeta);
+                ts.anchor_ids = ids;
+                ts.targets = tg;
+                ts.negs = ng;
+                ts.node_map = nm;
+                ts.map_len = (long long)P->node_map_len;
+                ts.ka = reinterpret_cast<unsigned *>(wb + hp.o_tsort);
+                ts.kb = ts.ka + Mp;
+                ts.va = ts.kb + Mp;
+                ts.vb = ts.va + Mp;
+                ts.hist = ts.vb + Mp;
+                ts.counter = epoch_f + 40;
+                ts.keys_out = reinterpret_cast<tkey_t *>(tb + TL.keys);
+                ts.perm = reinterpret_cast<int *>(tb + TL.perm);
+                ts.erow = nullptr;
+                ts.th_out = reinterpret_cast<TouchHeader *>(tb);
+                ts.M = (int)hp.touch_M;
+                ts.key_bits = hp.ts_key_bits;
+                ts.row_bits = hp.ts_row_bits;
+                ts.nblk = hp.ts_blocks;
+                ts.stamps = nullptr;
+                if (dbg_on("TSORT_TRAIL")) pa.strail = hp.ts_blocks;
+                else {
+                    pa.sna = hp.sort_na;
+                    pa.sxrank = 0;
+                    for (int x = 0; x < STEP_XCDS; ++x) pa.sxrank |= (unsigned)(hp.sort_rank[x] + 1) << (4 * x);
+                    pa.sblocks = (hp.ts_blocks + pa.sna - 1) / pa.sna * 8;
+                }
+            }
             // The chain workgroups wait for vectors / matrices that the prologue workgroups produce, so the prologue
             // workgroups come first in the launch: a producer is never queued behind a consumer. (Every wait is bounded
             // all the same: a launch that could not make progress reports MPQE_FLAG_INTERNAL instead of hanging.)
             // (Dealing the prologue workgroups only to the XCDs the chain workgroups leave room on was measured and is
             // worse: those are the XCDs of the heaviest batches, whose workgroups then lose their CU to themselves --
             // chain kernel 53.5 us against 41.4 with the prologue spread over all eight.)
-            pa.lead = (pa.ublocks + pa.tblocks + 7) / 8 * 8;
+            // (sblocks = 8 x rows; a row holds sna sort workgroups and 8 - sna prologue items)
+            pa.lead = (pa.sblocks / 8 * pa.sna + pa.ublocks + pa.tblocks + 7) / 8 * 8;
+            if (pa.lead < pa.sblocks) pa.lead = pa.sblocks;
             pa.nchain = (int)hp.crefs.size();
             pa.slots = reinterpret_cast<const WtSlot *>(db + hp.o_wtslots);
             pa.WT = WT;
@@ -2869,9 +3011,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         {
             // chain form: two of the eight XCDs for the post-pass' vector ops, six for the tiles (AIFB step, same box,
             // three runs each: 64.95 / 65.15 / 65.04 us against 65.70 / 65.60 / 65.47 with both kinds everywhere; one
-            // or three XCDs: 65.8 / 66.0). MPQE_DBG_TAIL_UX overrides (0 = everywhere).
-            const char *ux = getenv("MPQE_DBG_TAIL_UX");
-            const int uxv = ux ? atoi(ux) : 2;
+            // or three XCDs: 65.8 / 66.0). mpqe_debug_option TAIL_UX overrides (0 = everywhere).
+            const int uxv = mpqe_dbg_value("TAIL_UX", 2);
             if (use_chain && first == 0 && tl.ublocks >= 4 && uxv > 0 && uxv < 8) {
                 tl.ux = uxv;
                 const int ra = (tl.ublocks + tl.ux - 1) / tl.ux, rb = (count + tl.zblocks + (8 - tl.ux) - 1) / (8 - tl.ux);
@@ -2913,11 +3054,10 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         ca.VT = VT;
         ca.epoch_f = epoch_f;
         ca.DG = use_touch ? reinterpret_cast<float *>(wb + hp.o_DG) : nullptr;
-        ca.dg_pos = use_touch ? reinterpret_cast<const int *>(reinterpret_cast<const char *>(touch) +
-                                                              touch_layout(hp.touch_M, 0).perm) : nullptr;
-        ca.erow = use_touch ? reinterpret_cast<const int *>(reinterpret_cast<const char *>(touch) +
-                                                            touch_layout(hp.touch_M, 0).erow) : nullptr;
-        ca.touch_bad = use_touch ? reinterpret_cast<const TouchHeader *>(touch)->pad : nullptr;
+        // (a plan built at pack time also holds the id -> table row hop of every entry; a step that builds its own plan
+        // resolves the ids itself)
+        ca.erow = use_touch && !build_touch ? reinterpret_cast<const int *>(reinterpret_cast<const char *>(touch) +
+                                                                            touch_layout(hp.touch_M, 0).erow) : nullptr;
         ca.Manchor = (long long)hp.anchor_off[nb];
         ca.Gtot = hp.sd.graphs_total;
         ca.parts = reinterpret_cast<float *>(wb + hp.o_parts);
@@ -2930,7 +3070,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         ca.terms = terms;
         ca.err = err;
         ca.backward = backward ? 1 : 0;
-        ca.stamps = g_chain_stamps && 2 * hp.crefs.size() <= g_chain_stamp_blocks ? g_chain_stamps : nullptr;
+        ca.stamps = g_chain_stamps && 2 * hp.crefs.size() + (size_t)hp.ts_blocks <= g_chain_stamp_blocks ? g_chain_stamps : nullptr;
+        if (ca.stamps && build_touch) pa.ts.stamps = g_chain_stamps + 16 * (long long)hp.crefs.size();     // (behind the chain entries)
         {
             ca.cb = 0;
             ca.nchain = pa.nchain;
@@ -2982,6 +3123,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                 grid_blocks = pa.lead + pa.nchain + po.zpad +
                               (long long)(po.ppad + po.wblocks + po.na - 1) / po.na * 8;       // (8 workgroups per `na` items)
             }
+            grid_blocks += pa.strail;
             dim3 cgrid((unsigned)grid_blocks);
             mark(s);
             if (D == 64) hipLaunchKernelGGL((step_chain_kernel<1, 1>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po);
@@ -3113,7 +3255,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                            reinterpret_cast<const char *>(touch), touch_layout(hp.touch_M, 0).keys,
                            (const float *)(wb + hp.o_DG), tabs,
                            ((sparse_tables || (P->flags & MPQE_STEP_ZERO_GRADS)) ? 1 : 0) | (merged ? 2 : 0),
-                           (long long)hp.touch_M, touch_row_bits);
+                           (long long)hp.touch_M, touch_row_bits, touch_layout(hp.touch_M, 0).perm, err);
     }
     return mpqe_launch_status();
 }

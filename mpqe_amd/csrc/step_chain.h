@@ -270,7 +270,6 @@ struct ChainLds {
     const float *wp[CH_MAX_OPS];                         // weight matrix of every op of the block's programme
     int opw[CH_MAX_OPS][2];                              // its (src | node << 8 | layer << 16 | level << 24, flags)
     int opp[CH_MAX_OPS];                                 // backward ops: ChainOp.aux (row of the column sums in `parts`); forward: cv slot
-    int dgrow[4 * CH_GB + 2 * CH_GB];                    // touch plan: row of DG of every node row / target (as rowp)
     int cvid[NCV];                                       // cv slot -> vector id (-1: the bias of layer cvl, -2: slot unused)
     int cvl[NCV];
     __device__ __forceinline__ float *red() { return cv; }
@@ -709,10 +708,8 @@ struct ChainArgs {
     const float *VT;        // vector table [vector id][D]: constants / uniform node states of the pre-pass (step.hip)
     unsigned *epoch_f;      // forward hand-off epoch of this packed step: bumped once per chain launch (step.hip)
     float *DG;              // touch plan (step_touch.h): the table-gradient row of entry e (anchors | + targets | - targets)
-                            // is stored to DG[dg_pos[e]] instead of added atomically; NULL = fp32 atomics into the tables
-    const int *dg_pos;
-    const int *erow;        // touch plan: row of entry e in its table, resolved at pack time (-1 bad id, -2 resolve here)
-    const int *touch_bad;   // touch plan header: != 0 when its one-launch build could not finish (step_touch.h) -> INTERNAL
+                            // is stored to DG[e] instead of added atomically; NULL = fp32 atomics into the tables
+    const int *erow;        // pack-time touch plan: row of entry e in its table (-1 bad id, -2 resolve here); NULL: resolve here
     long long Manchor, Gtot;
     float *parts;
     float *block_terms;     // [blocks of the step]: sum of the block's hinge terms (the loss reduction reads these)
@@ -785,7 +782,6 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
 
     chain_stamp(ca, 0);
     chain_stamp_where(ca, ref.batch, ref.fwd_count);
-    if (ca.cb == 0 && tid == 0 && ca.touch_bad && *ca.touch_bad) flag_error(ca.err, MPQE_FLAG_INTERNAL);
 #if CHAIN_DBG == 6
     if (threadIdx.x == 0) {      // trace block 0 only: words [2 G * 8 ...) of the stamp buffer
         S.trace = (ca.stamps && ca.cb == 0) ? ca.stamps + (long long)ca.nchain * 16 : nullptr;
@@ -795,10 +791,10 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
 #if CHAIN_DBG == 4      // experiment: de-synchronise the blocks of an XCD (they read the same matrices in lockstep)
     for (int q = 0; q < (int)((blockIdx.x / 8) % 4) * 6; ++q) __builtin_amdgcn_s_sleep(127);
 #endif
-    // ---- phase A1: where every row comes from (threads 0 .. 95: node rows, + targets, - targets). With a touch plan the
-    // id -> LUT -> row hops were done at pack time (erow) and the entry number comes from the workgroup's own record: ONE
-    // round trip (entry -> {row, position in DG}) stands between the record and the row gather; the programme's ops and
-    // the batch record travel beside it.
+    // ---- phase A1: where every row comes from (threads 0 .. 95: node rows, + targets, - targets). The entry number
+    // comes from the workgroup's own record; with a pack-time touch plan the id -> LUT -> row hops were done there (erow:
+    // ONE round trip between the record and the row gather), otherwise they are done here (two); the programme's ops and
+    // the batch record travel beside them.
     const int nops = ref.fwd_count + ref.bwd_count;
     ChainOp op;
     if (tid < nops) op = ca.ops[ref.fwd_begin + tid];
@@ -808,17 +804,13 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
         const int rN = (int)(ref.meta & 15u), rA = (int)((ref.meta >> 4) & 15u);
         if (tid < 4 * CH_GB) {
             const int i = tid / rN, n = tid - i * rN;       // row r = i * N + n, as in HBM
-            int dgr = 0;
             if (tid < nrows) {
                 if (n < rA) {
                     const int tab = (int)((ref.meta >> (8 + 4 * n)) & 15u);
                     const long long e = (long long)ref.e0 + (long long)n * ref.B + i;
                     long long row;
                     int er = -2;
-                    if (ca.erow) {
-                        er = ca.erow[e];
-                        dgr = ca.dg_pos[e];
-                    }
+                    if (ca.erow) er = ca.erow[e];
                     if (er == -2) row = table_row(ca.node_map, ca.map_len, ca.anchor_ids[e], tabs.rows[tab], ca.err);
                     else {
                         row = er;
@@ -835,20 +827,15 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
                 }
             }
             S.gradp[tid] = gdst;
-            if (ca.dg_pos) S.dgrow[tid] = dgr;
         } else {
             const int i = (tid - 4 * CH_GB) & (CH_GB - 1);
             const bool is_neg = tid >= 5 * CH_GB;
-            int dgr = 0;
             if (i < ng) {
                 const int tab = (int)((ref.meta >> 20) & 15u);
                 const long long e = ca.Manchor + (is_neg ? ca.Gtot : 0) + ref.gi0 + i;
                 long long row;
                 int er = -2;
-                if (ca.erow) {
-                    er = ca.erow[e];
-                    dgr = ca.dg_pos[e];
-                }
+                if (ca.erow) er = ca.erow[e];
                 if (er == -2)
                     row = table_row(ca.node_map, ca.map_len, is_neg ? ca.negs[ref.gi0 + i] : ca.targets[ref.gi0 + i],
                                     tabs.rows[tab], ca.err);
@@ -858,7 +845,6 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
                 }
                 if (row >= 0) src = tabs.table[tab] + row * D;
             }
-            if (ca.dg_pos) S.dgrow[tid] = dgr;
         }
         S.rowp[tid] = src;
     }
@@ -1145,7 +1131,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
             yg_n = gsum(yg_n);
             float *gt = tabs.grad[b.target_tab];
             if (ca.DG && on) {    // y = v / |v|:  dv = (g - y (y . g)) / |v|, stored as the entry's row (summed per table row later)
-                float *dp_ = ca.DG + (long long)S.dgrow[4 * CH_GB + i] * D, *dn_ = ca.DG + (long long)S.dgrow[5 * CH_GB + i] * D;
+                float *dp_ = ca.DG + (ca.Manchor + ref.gi0 + i) * D, *dn_ = dp_ + ca.Gtot * D;      // entries of the + / - target
 #pragma unroll
                 for (int cc = 0; cc < CC; ++cc) {
                     const int col = sl + 16 * cc;
@@ -1242,7 +1228,8 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
                     f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = ok ? (g[e] - y[k][e] * yg) * inv : 0.f;
-                    *reinterpret_cast<f32x4 *>(ca.DG + (long long)S.dgrow[r] * D + 4 * c4) = o;
+                    // (entry of anchor slot n of graph i: the batch's anchor ids are slot-major)
+                    *reinterpret_cast<f32x4 *>(ca.DG + ((long long)ref.e0 + (long long)n * ref.B + i) * D + 4 * c4) = o;
                 }
                 continue;
             }

@@ -8,11 +8,17 @@
 //
 // Instead: every looked-up id is an ENTRY e (anchors in the order of the step's anchor_ids array, then the
 // positive targets, then the negative ones: the order of the id arrays the caller hands over). The chain kernel
-// stores the gradient row of entry e (through the L2 normalisation) with plain 16-byte stores; which entries share a
-// destination row is a function of the ids alone, so it is found ONCE per packed step, at pack time
-// (mpqe_step_touch_build: LUT gather -> (table, row) keys -> one stable radix sort -> pos[e] = rank of entry e), not
-// in the step. The row of entry e goes to DG[pos[e]], so the rows of one destination are ADJACENT, in entry order, and
-// table_sum_block adds each run in that fixed order with no indirection: deterministic, every gradient row read once.
+// stores the gradient row of entry e (through the L2 normalisation) to DG[e] with plain 16-byte stores and needs
+// nothing else. Which entries share a destination row is a function of the ids alone: LUT gather -> (table, row)
+// keys -> one stable radix sort -> sorted keys + perm[k] = entry of sorted position k; table_sum_block (reduction
+// launch) adds, per run of equal keys, the rows DG[perm[k]] in sorted = entry order: deterministic, every gradient
+// row read once. The sort is needed only by the step's LAST launch, so it has two homes:
+//   * INSIDE the step (MPQE_STEP_BUILD_TOUCH): tsort_block workgroups lead the chain launch's grid and run beside the
+//     chain workgroups -- a step with fresh ids costs what a replayed one costs, and nothing id-dependent happens
+//     outside mpqe_step_forward_backward (round 2 built the plan at pack time: 21 us of sort + the id -> row hop per
+//     step that the timed loop never saw);
+//   * at pack time (mpqe_step_touch_build), for callers that want the plan before the step runs (the data-parallel
+//     row exchange plans with its keys) or whose steps exceed TSORT_MAX_ENTRIES.
 // Included by step.hip.
 #pragma once
 #include <rocprim/device/device_radix_sort.hpp>
@@ -26,8 +32,8 @@ struct TouchHeader {
     int pad[12];
 };
 struct TouchLayout {
-    size_t keys, perm, erow, total;     // device buffer: header, sorted keys [M], pos [M] (entry -> rank in sorted order),
-                                        // erow [M] (entry -> row of its table, -1 = bad id: the LUT hop, done at pack time)
+    size_t keys, perm, erow, total;     // device buffer: header, sorted keys [M], perm [M] (sorted position -> entry),
+                                        // erow [M] (entry -> row of its table, -1 = bad id: the LUT hop; pack-time build only)
     size_t w_keys, w_vals, w_svals, w_hist, w_tmp, w_tmp_bytes, w_total;      // build workspace
 };
 
@@ -52,15 +58,15 @@ static inline TouchLayout touch_layout(long long M, int key_bits /* 0: the devic
     L.total = off;
     if (key_bits <= 0) return L;
     off = 0;
-    const size_t Mp = ((size_t)M + 1023) / 1024 * 1024;      // (the one-launch sort works on whole workgroups of 1024)
+    const size_t Mp = ((size_t)M + 1023) / 1024 * 1024;      // (the one-launch sort works on whole workgroups of 1024 entries)
     L.w_keys = off;
     off += align_up(Mp * sizeof(tkey_t), 256);
     L.w_vals = off;
     off += align_up(Mp * sizeof(int), 256);
     L.w_svals = off;
     off += align_up(Mp * sizeof(int), 256);
-    L.w_hist = off;                                           // [4 passes][64 workgroups][256] digit counts + the barrier counter
-    off += 4 * 64 * 256 * sizeof(unsigned) + 256;
+    L.w_hist = off;                                           // [4 passes][256 workgroups][256] digit counts, the barrier
+    off += 4 * 256 * 256 * sizeof(unsigned) + 256 + 2048;     // counter (256 bytes), the batch table (TouchMeta, < 2 KB)
     size_t bytes = 0;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, (const tkey_t *)nullptr, (tkey_t *)nullptr, (const int *)nullptr,
                                     (int *)nullptr, (size_t)(M > 0 ? M : 1), 0u, (unsigned)key_bits, (hipStream_t) nullptr);
@@ -142,106 +148,145 @@ __global__ __launch_bounds__(256) void touch_keys_kernel(TouchMeta tm, const lon
 // to hide. Not kept. Replaying copy + keys + library sort + inversion as ONE hipGraph costs 10 - 21 us of host time and
 // reproduces the plan (tools/graph_pack_probe.py): the next step for the host side of pack.)
 
-#ifndef MPQE_EMU
-// The whole touch plan in ONE launch (plans of up to 64 K entries; the library sort is a chain of ~6 launches of 3 - 8 us
-// each, latency-bound at these sizes: ~54 us of device time and ~8 launch calls per pack). NB = ceil(M / 1024) workgroups
-// of 1024 threads, ONE entry per thread, all resident at once; a stable LSD radix sort, 8 bits per pass:
-//   1  digit d of my key; my rank among the entries of MY WAVE with the same digit (eight ballots build the mask of
-//      equal-digit lanes), the wave's count per digit to LDS; thread d adds the 16 wave counts -> the workgroup's count of
-//      digit d, stored to hist[workgroup][d]
+// The whole touch plan by workgroups that synchronise among themselves (the library sort is a chain of ~6 launches of
+// 3 - 8 us each, latency-bound at these sizes: ~54 us of device time). NB = ceil(M / 1024) workgroups of 256 threads,
+// FOUR entries per thread (entry = 1024 b + 256 r + t in round r: a round is a "virtual" group of four waves), all
+// workgroups resident at once; a stable LSD radix sort, 8 bits per pass:
+//   1  digit d of my key; my rank among the entries of MY WAVE AND ROUND with the same digit (eight ballots build the
+//      mask of equal-digit lanes), the count per (round, wave, digit) to LDS; thread d turns the 16 counts of digit d into
+//      an exclusive prefix -> the workgroup's count of digit d, stored to hist[pass][workgroup][d]
 //   -- grid barrier --
 //   2  thread d sums hist[.][d] over ALL workgroups (total of the digit) and over the workgroups before mine; a
 //      256-wide scan of the totals; destination = (entries with a smaller digit) + (same digit, earlier workgroups) +
-//      (same digit, earlier waves of mine) + (same digit, lower lanes of my wave): stable
-//   3  scatter (key, entry) to the other buffer     -- grid barrier --     next pass reads its entry from there;
-//      the LAST pass writes the plan itself: sorted key (64-bit, invalid = all ones) and pos[entry] = rank.
+//      (same digit, earlier rounds / waves of mine) + (same digit, lower lanes of my wave): stable
+//   3  scatter (key, entry) to the other buffer     -- grid barrier --     next pass reads its entries from there;
+//      the LAST pass writes the plan itself: sorted key (64-bit, invalid = all ones) and perm[rank] = entry.
 // Everything that crosses workgroups (keys, entries, histograms) moves through agent-scope atomic stores / loads -- written
 // through to memory, read past the L1 -- so the grid barrier is a counter and nothing else: no L2 write-back, no
-// invalidate. The barrier counter is zeroed by the host before the launch; spins are bounded (a launch that cannot make
-// progress leaves the header's `pad[0]` = 1 instead of hanging).
-#define TSORT_THREADS 1024
-#define TSORT_MAX_BLOCKS 64
+// invalidate. EVERY wave drains its stores (s_waitcnt vmcnt(0)) before the workgroup's barrier in front of the counter
+// add: a wave's relaxed stores may otherwise still be in flight when another workgroup passes the barrier. The counter
+// is zero when the launch starts (pack-time build: a 4-byte memset in front of it; inside the step: the reduction launch
+// of the previous step leaves it zero); spins are bounded (a launch that cannot make progress leaves the header's
+// `pad[0]` = 1 instead of hanging -- e.g. when not all NB workgroups fit on the device together).
+#define TSORT_THREADS 256
+#define TSORT_ROUNDS 4
+#define TSORT_PER_BLOCK (TSORT_THREADS * TSORT_ROUNDS)
+#define TSORT_MAX_BLOCKS 256
+#define TSORT_MAX_ENTRIES ((long long)TSORT_MAX_BLOCKS * TSORT_PER_BLOCK)
+#define TSORT_META_WORDS 512      // sizeof(TouchMeta) / 4, rounded up
+#define TSORT_LDS_WORDS (TSORT_ROUNDS * 4 * 256 + 256 + 256 + 4 + TSORT_META_WORDS)
+struct TSortArgs {
+    const TouchMeta *tm;        // device copy (the packed step's descriptor table / the build's workspace)
+    const long long *anchor_ids, *targets, *negs, *node_map;
+    long long map_len;
+    unsigned *ka, *va, *kb, *vb;        // ping-pong (key, entry) buffers, [nblk * 1024] each
+    unsigned *hist;                     // [passes][nblk][256]
+    unsigned *counter;                  // the grid barrier
+    tkey_t *keys_out;
+    int *perm, *erow;                   // erow: NULL = not wanted
+    TouchHeader *th_out;
+    int M, key_bits, row_bits, nblk;
+    long long *stamps;                  // diagnostics (mpqe_debug_chain_stamps): 8 words per sort workgroup, or NULL
+};
+#ifndef MPQE_EMU
 __device__ __forceinline__ unsigned tsort_ld(const unsigned *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void tsort_st(unsigned *p, unsigned v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ bool tsort_grid_barrier(unsigned *counter, unsigned target) {
-    __shared__ int ok;
-    __syncthreads();            // (every wave's stores are issued; agent-scope stores complete in order with the add below)
+__device__ __forceinline__ bool tsort_grid_barrier(unsigned *counter, unsigned target, unsigned *ok) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: my agent-scope stores have been acknowledged
+    __syncthreads();
     if (threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int good = 1;
+        unsigned good = 1;
         for (int spins = 0; (int)(tsort_ld(counter) - target) < 0; ++spins) {
-            if (spins >= (1 << 22)) {
+            if (spins >= (1 << 21)) {
                 good = 0;
                 break;
             }
             __builtin_amdgcn_s_sleep(2);
         }
-        ok = good;
+        *ok = good;
     }
     __syncthreads();
-    return ok != 0;
+    return *ok != 0;
 }
-__global__ __launch_bounds__(TSORT_THREADS) void touch_sort_kernel(
-    TouchMeta tm, const long long *__restrict__ anchor_ids, const long long *__restrict__ targets,
-    const long long *__restrict__ negs, const long long *__restrict__ node_map, long long map_len, unsigned *ka,
-    unsigned *va, unsigned *kb, unsigned *vb, unsigned *hist /*[workgroups][256]*/, unsigned *counter,
-    tkey_t *__restrict__ keys_out, int *__restrict__ pos, int *__restrict__ erow, int M, int key_bits, TouchHeader th,
-    TouchHeader *__restrict__ th_out) {
-    __shared__ unsigned whist[TSORT_THREADS / 64][256];
-    __shared__ unsigned gbase[256], scan[256];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x, nblk = gridDim.x;
-    const int i = b * TSORT_THREADS + t;
-    unsigned k = 0xffffffffu, v = (unsigned)i;              // (threads beyond M: a key behind every real one, never stored)
-    if (i < M) {
-        int er;
-        const tkey_t key = touch_key_of(tm, i, anchor_ids, targets, negs, node_map, map_len, &er);
-        k = key == TOUCH_INVALID ? 0xffffffffu : (unsigned)key;
-        erow[i] = er;
+// one workgroup of the sort; `smem`: TSORT_LDS_WORDS words. Threads >= TSORT_THREADS of a larger workgroup must not call.
+__device__ __forceinline__ void tsort_block(const TSortArgs &sa, int b, unsigned *smem) {
+    unsigned(*whist)[256] = reinterpret_cast<unsigned(*)[256]>(smem);       // [round * 4 + wave][digit]
+    unsigned *gbase = smem + TSORT_ROUNDS * 4 * 256, *scan = gbase + 256, *ok = scan + 256;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nblk = sa.nblk, M = sa.M;
+    // the batch table through LDS: touch_key_of walks it per entry (from memory that was five dependent round trips in
+    // front of the first id load -- 9 to 16 us next to running chain workgroups)
+    static_assert(sizeof(TouchMeta) <= TSORT_META_WORDS * 4 && sizeof(TouchMeta) % 4 == 0, "TSORT_META_WORDS");
+    unsigned *mw = ok + 4;
+    for (int q = t; q < (int)(sizeof(TouchMeta) / 4); q += TSORT_THREADS) mw[q] = reinterpret_cast<const unsigned *>(sa.tm)[q];
+    __syncthreads();
+    const TouchMeta &tm = *reinterpret_cast<const TouchMeta *>(mw);
+    int stamp_i = 0;
+    auto stamp = [&]() {         // wall clock (100 MHz) at: start, keys, then after every grid barrier, end (slot 7)
+        if (sa.stamps && t == 0 && stamp_i < 7) sa.stamps[(long long)b * 8 + stamp_i++] = (long long)wall_clock64();
+    };
+    stamp();
+    unsigned k[TSORT_ROUNDS], v[TSORT_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < TSORT_ROUNDS; ++r) {
+        const int i = b * TSORT_PER_BLOCK + r * TSORT_THREADS + t;
+        k[r] = 0xffffffffu;                                 // (slots beyond M: a key behind every real one, never stored)
+        v[r] = (unsigned)i;
+        if (i < M) {
+            int er;
+            const tkey_t key = touch_key_of(tm, i, sa.anchor_ids, sa.targets, sa.negs, sa.node_map, sa.map_len, &er);
+            k[r] = key == TOUCH_INVALID ? 0xffffffffu : (unsigned)key;
+            if (sa.erow) sa.erow[i] = er;
+        }
     }
-    const int passes = (key_bits + 7) / 8;
-    unsigned *dk = ka, *dv = va;
+    const int passes = (sa.key_bits + 7) / 8;
+    unsigned *dk = sa.ka, *dv = sa.va;
     unsigned bar = 0;
     bool good = true;
+    stamp();
     for (int p = 0; p < passes; ++p) {
-        const unsigned d = (k >> (8 * p)) & 255u;
-        for (int q = t; q < (TSORT_THREADS / 64) * 256; q += TSORT_THREADS) (&whist[0][0])[q] = 0;
+        for (int q = t; q < TSORT_ROUNDS * 4 * 256; q += TSORT_THREADS) smem[q] = 0;
         __syncthreads();
-        unsigned long long peers = ~0ull;                  // lanes of my wave with my digit
+        unsigned below[TSORT_ROUNDS];
 #pragma unroll
-        for (int bit = 0; bit < 8; ++bit) {
-            const unsigned long long m = __ballot((d >> bit) & 1u);
-            peers &= ((d >> bit) & 1u) ? m : ~m;
+        for (int r = 0; r < TSORT_ROUNDS; ++r) {
+            const unsigned d = (k[r] >> (8 * p)) & 255u;
+            unsigned long long peers = ~0ull;              // lanes of my wave whose entry of this round has my digit
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const unsigned long long m = __ballot((d >> bit) & 1u);
+                peers &= ((d >> bit) & 1u) ? m : ~m;
+            }
+            below[r] = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
+            if (below[r] == 0) whist[r * 4 + wave][d] = (unsigned)__popcll(peers);
         }
-        const unsigned below = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
-        if (below == 0) whist[wave][d] = (unsigned)__popcll(peers);
         __syncthreads();
-        if (t < 256) {                                     // exclusive prefix over my workgroup's waves; its count of digit t
+        {   // exclusive prefix over my workgroup's (round, wave) groups; its count of digit t
             unsigned run = 0;
 #pragma unroll
-            for (int w = 0; w < TSORT_THREADS / 64; ++w) {
+            for (int w = 0; w < TSORT_ROUNDS * 4; ++w) {
                 const unsigned c = whist[w][t];
                 whist[w][t] = run;
                 run += c;
             }
-            tsort_st(hist + ((size_t)p * TSORT_MAX_BLOCKS + b) * 256 + t, run);
+            tsort_st(sa.hist + ((size_t)p * nblk + b) * 256 + t, run);
         }
         bar += (unsigned)nblk;
-        good = tsort_grid_barrier(counter, bar) && good;
-        if (t < 256) {
+        good = tsort_grid_barrier(sa.counter, bar, ok) && good;
+        stamp();
+        {
             unsigned tot = 0, before = 0;
-            // (plain loads, all in flight together: every pass has its own histogram rows, so no cache of this XCD can hold
-            // a line of them from before their writers' write-through stores -- an agent-scope load per workgroup in a
-            // dependent row was 28 round trips per pass)
-            const unsigned *hp = hist + (size_t)p * TSORT_MAX_BLOCKS * 256 + t;
+            // (agent-scope loads -- the rows are re-used by the next step's sort, a line of them may sit in this XCD's L2 --
+            // 16 in flight together: one load per workgroup in a dependent row was 28 round trips per pass)
+            const unsigned *hp = sa.hist + (size_t)p * nblk * 256 + t;
             for (int b0 = 0; b0 < nblk; b0 += 16) {
                 unsigned h[16];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) h[q] = b0 + q < nblk ? hp[(size_t)(b0 + q) * 256] : 0u;
+                for (int q = 0; q < 16; ++q) h[q] = b0 + q < nblk ? tsort_ld(hp + (size_t)(b0 + q) * 256) : 0u;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     tot += h[q];
@@ -251,41 +296,95 @@ __global__ __launch_bounds__(TSORT_THREADS) void touch_sort_kernel(
             scan[t] = tot;
             gbase[t] = before - tot;                       // (+ the inclusive scan below = entries with a smaller digit + before)
         }
-        __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {          // inclusive scan of the digit totals
-            unsigned x = 0;
-            if (t < 256 && t >= off) x = scan[t - off];
+        {   // inclusive scan of the 256 digit totals: inside each wave by shuffles, the waves' sums through LDS
+            unsigned x = scan[t];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned y = __shfl_up(x, off, 64);
+                if (lane >= off) x += y;
+            }
+            if (lane == 63) ok[1 + wave] = x;              // (ok[1..3]: the sums of waves 0..2; 4 words were reserved)
             __syncthreads();
-            if (t < 256) scan[t] += x;
-            __syncthreads();
+            unsigned pre = 0;
+            for (int w = 0; w < wave; ++w) pre += ok[1 + w];
+            scan[t] = x + pre;
         }
-        const unsigned at = gbase[d] + scan[d] + whist[wave][d] + below;
+        __syncthreads();
+        unsigned at[TSORT_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < TSORT_ROUNDS; ++r) {
+            const unsigned d = (k[r] >> (8 * p)) & 255u;
+            at[r] = gbase[d] + scan[d] + whist[r * 4 + wave][d] + below[r];
+        }
         if (p + 1 < passes) {
-            tsort_st(dk + at, k);                          // (the padding keys travel too: they stay behind every real key)
-            tsort_st(dv + at, v);
+#pragma unroll
+            for (int r = 0; r < TSORT_ROUNDS; ++r) {
+                tsort_st(dk + at[r], k[r]);                // (the padding keys travel too: they stay behind every real key)
+                tsort_st(dv + at[r], v[r]);
+            }
             bar += (unsigned)nblk;
-            good = tsort_grid_barrier(counter, bar) && good;
-            k = tsort_ld(dk + i);
-            v = tsort_ld(dv + i);
-            dk = dk == ka ? kb : ka;
-            dv = dv == va ? vb : va;
-        } else if (v < (unsigned)M) {                      // the plan: sorted key, rank of the entry
-            keys_out[at] = k == 0xffffffffu ? TOUCH_INVALID : (tkey_t)k;
-            pos[v] = (int)at;
+            good = tsort_grid_barrier(sa.counter, bar, ok) && good;
+            stamp();
+#pragma unroll
+            for (int r = 0; r < TSORT_ROUNDS; ++r) {
+                const int i = b * TSORT_PER_BLOCK + r * TSORT_THREADS + t;
+                k[r] = tsort_ld(dk + i);
+                v[r] = tsort_ld(dv + i);
+            }
+            dk = dk == sa.ka ? sa.kb : sa.ka;
+            dv = dv == sa.va ? sa.vb : sa.va;
+        } else {
+#pragma unroll
+            for (int r = 0; r < TSORT_ROUNDS; ++r)
+                if (v[r] < (unsigned)M) {                  // the plan: sorted key, entry of the rank
+                    sa.keys_out[at[r]] = k[r] == 0xffffffffu ? TOUCH_INVALID : (tkey_t)k[r];
+                    sa.perm[at[r]] = (int)v[r];
+                }
         }
     }
-    if (b == 0 && t == 0) {
-        if (!good) th.pad[0] = 1;
-        *th_out = th;
+    if (sa.stamps && t == 0) sa.stamps[(long long)b * 8 + 7] = (long long)wall_clock64();
+    if (t == 0 && (b == 0 || !good)) {                     // (a workgroup that gave up says so, whichever it is)
+        TouchHeader th;
+        memset(&th, 0, sizeof(th));
+        th.M = M;
+        th.row_bits = sa.row_bits;
+        th.key_bits = sa.key_bits;
+        if (b == 0 && good) *sa.th_out = th;
+        else if (!good) {
+            if (b == 0) *sa.th_out = th;
+            __hip_atomic_store(&sa.th_out->pad[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
+#else
+// emulator (workgroups run one after another: no grid barrier): workgroup 0's first thread sorts the whole plan
+__device__ __forceinline__ void tsort_block(const TSortArgs &sa, int b, unsigned *) {
+    if (b != 0 || threadIdx.x != 0) return;
+    const int M = sa.M;
+    std::vector<std::pair<tkey_t, int>> e((size_t)M);
+    for (int i = 0; i < M; ++i) {
+        int er;
+        e[i].first = touch_key_of(*sa.tm, i, sa.anchor_ids, sa.targets, sa.negs, sa.node_map, sa.map_len, &er);
+        e[i].second = i;
+        if (sa.erow) sa.erow[i] = er;
+    }
+    std::stable_sort(e.begin(), e.end(), [](const std::pair<tkey_t, int> &x, const std::pair<tkey_t, int> &y) { return x.first < y.first; });
+    for (int i = 0; i < M; ++i) {
+        sa.keys_out[i] = e[i].first;
+        sa.perm[i] = e[i].second;
+    }
+    TouchHeader th;
+    memset(&th, 0, sizeof(th));
+    th.M = M;
+    th.row_bits = sa.row_bits;
+    th.key_bits = sa.key_bits;
+    *sa.th_out = th;
+}
 #endif
-
-// pos[vals_sorted[k]] = k
-__global__ __launch_bounds__(256) void touch_invert_kernel(const int *__restrict__ sorted_vals, int *__restrict__ pos,
-                                                          long long M) {
-    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (k < M) pos[sorted_vals[k]] = (int)k;
+// pack-time build: the sort as a launch of its own
+__global__ __launch_bounds__(TSORT_THREADS) void touch_sort_kernel(TSortArgs sa) {
+    __shared__ unsigned smem[TSORT_LDS_WORDS];
+    tsort_block(sa, (int)blockIdx.x, smem);
 }
 
 // One group of LPR = D / 4 lanes per sorted position k: if k starts a run of equal keys, add the run's gradient rows
@@ -294,8 +393,8 @@ __global__ __launch_bounds__(256) void touch_invert_kernel(const int *__restrict
 // costs one round trip per TS_AHEAD rows, not two per row. store: the call zero-filled the gradients, the row is
 // written; otherwise added to what is there.
 #define TS_AHEAD 8
-// perm != NULL: the row of sorted position k is DG[perm[k]] (rows that arrive in another order: the data-parallel row
-// exchange, mpqe_table_rows_sum); NULL: DG[k] (the chain kernel stores its rows in sorted position).
+// perm != NULL: the row of sorted position k is DG[perm[k]] (the chain kernel stores its rows in entry order; the
+// data-parallel row exchange, mpqe_table_rows_sum, in gathered order); NULL: DG[k].
 // (M, row_bits: the plan header's fields, by value where the caller knows them -- the fused step does: one round trip less
 // in front of the keys)
 template <class TabsT>

@@ -22,10 +22,36 @@ from . import _capi, ops
 from .data_utils import RGCNQueryDataset
 
 
+class StepBuffers(object):
+    """Device buffers ONE packed step owns while it lives: the descriptor table (a function of the descriptor set alone:
+    a recurring set finds it resident, hand-off epochs carried on), the id buffer (when the ids came from the host) and
+    the touch plan. Handed back to the step object's pool by PackedStep.__del__ -- explicit ownership: a buffer set is
+    either in the pool's free list or referenced by exactly one live PackedStep."""
+    __slots__ = ('desc', 'desc_resident', 'ids', 'touch', 'touch_ptr', 'last_use', 'copied', 'skey')
+
+    def __init__(self):
+        self.desc = self.ids = self.touch = self.touch_ptr = self.last_use = self.copied = self.skey = None
+        self.desc_resident = False
+
+
 class PackedStep(object):
     __slots__ = ('batches', 'nb', 'anchor_ids', 'targets', 'negs', 'num_graphs', 'ws_bytes', 'sizes',
-                 'desc', 'desc_bytes', 'desc_ptr', 'desc_resident', 'lanes', 'order', 'lane_begin', 'touch',
-                 'touch_ptr', 'touch_entries', 'touch_sizes', 'desc_ent')
+                 'desc', 'desc_bytes', 'desc_ptr', 'lanes', 'order', 'lane_begin', 'touch',
+                 'touch_ptr', 'touch_entries', 'touch_sizes', 'bufs', 'owner', 'ids_ref', 'step_flags', 'touch_mode', 'copy_waited', 'captured')
+
+    @property
+    def desc_resident(self):
+        return self.bufs.desc_resident
+
+    def __del__(self):
+        owner, bufs = getattr(self, 'owner', None), getattr(self, 'bufs', None)
+        if owner is not None and bufs is not None:
+            self.owner = self.bufs = None
+            owner._release(bufs)
+
+
+def _bsize(b):
+    return int(b['batch_size']) if 'batch_size' in b else len(b['targets'])
 
 
 _INFO = {}
@@ -104,7 +130,13 @@ class FusedTrainStep(object):
     batches of equal depth together (longest chains first)."""
 
     def __init__(self, model, margin=1.0, lanes=1, prune=True, chain=True, ksplit=True, eight_waves=False,
-                 uniform=True, touch=True, sparse_tables=False, merge_tail=None, graph_pack=True):
+                 uniform=True, touch=True, sparse_tables=False, merge_tail=None):
+        """touch: how the entity-table gradients are accumulated (chain form; include/mpqe_amd.h) --
+        True / 'step': per-entry gradient rows summed per table row in a fixed order, the plan (which looked-up ids share
+        a row) built INSIDE the step by workgroups of its first launch (MPQE_STEP_BUILD_TOUCH): nothing id-dependent
+        happens outside run(); steps too large for it fall back to 'pack'. 'pack': the same sums, the plan built by pack()
+        (mpqe_step_touch_build) -- for callers that need the plan's keys before the step runs (StepExchange's row
+        exchange). False: fp32 atomics."""
         enc = model.enc
         if not hasattr(enc, 'table') or getattr(enc, 'node_maps', None) is None:
             raise ValueError('FusedTrainStep needs a DirectEncoder built with node_maps')
@@ -121,8 +153,10 @@ class FusedTrainStep(object):
         # their own (False), or the library's choice by step size (None; include/mpqe_amd.h MPQE_STEP_MERGE_TAIL)
         self.merge_tail = merge_tail
         self.uniform = bool(uniform and chain)
-        # entity-table gradients summed per table row in a fixed order (touch plan) instead of fp32 atomics
+        if touch not in (True, False, 'step', 'pack'):
+            raise ValueError("touch: True / 'step', 'pack' or False")
         self.touch = bool(touch and chain)
+        self.touch_mode = ('pack' if touch == 'pack' or eight_waves or lanes > 1 else 'step') if self.touch else None
         # row-sparse entity-table gradients (include/mpqe_amd.h: MPQE_STEP_SPARSE_TABLES): only the rows a step's ids touch
         # are written -- for FlatOptimizer(sparse_tables=True) / the row exchange; p.grad of a table is then NOT a
         # dense gradient (untouched rows hold whatever they held)
@@ -146,8 +180,8 @@ class FusedTrainStep(object):
         self.bind_grads()
         self.err = ops.new_error_word(self.device)
         self._ws = None
-        self._desc_cache, self._size_cache, self._desc_pool = {}, {}, {}
-        self.graph_pack, self._slots = bool(graph_pack), []
+        self._desc_cache, self._size_cache, self._pool = {}, {}, {}
+        self._copy_stream = torch.cuda.Stream(device=self.device)      # ids host -> device, beside the running step
         self.num_lanes = max(1, min(int(lanes), _capi.STEP_MAX_LANES))
         self._streams = [None] + [torch.cuda.Stream(device=self.device) for _ in range(self.num_lanes - 1)]
         self._fork = torch.cuda.Event()
@@ -157,6 +191,14 @@ class FusedTrainStep(object):
             for e in self._joins[1:]:
                 e.record()
         self._refresh_pointers()
+
+    POOL_PER_SET = 8
+
+    def _release(self, bufs):
+        """A packed step is gone: its buffers serve the next step of the same descriptor set (PackedStep.__del__)."""
+        free = self._pool.get(bufs.skey)
+        if free is not None and len(free) < self.POOL_PER_SET:
+            free.append(bufs)
 
     def bind_grads(self):
         """Make every p.grad the parameter's view of the flat gradient buffer (again). Anything that
@@ -185,9 +227,50 @@ class FusedTrainStep(object):
             [l.bias.grad.data_ptr() for l in layers])
         self._keep = (tabs, layers)
 
-    def pack(self, batches):
+    def flatten_ids(self, batches, out=None):
+        """The ids of a step in the layout the library reads: [anchors of batch 0 (slot-major: [A, B]) | ... | targets of
+        all batches | negatives of all batches], as one int64 numpy array (`out`: write there). batches: dicts with
+        formula, anchor_ids [B, A], targets [B], negs [B]."""
+        acols = [_TEMPLATES[b['formula'].query_type][0] for b in batches]
+        sizes = [len(b['targets']) for b in batches]
+        na, ngr = sum(B * A for B, A in zip(sizes, acols)), sum(sizes)
+        snp = np.empty(na + 2 * ngr, dtype=np.int64) if out is None else out
+        if snp.shape != (na + 2 * ngr,):
+            raise ValueError('flatten_ids: out must hold %d ids' % (na + 2 * ngr))
+        oa = 0
+        tl, nl_ = [], []
+        for b, B, A in zip(batches, sizes, acols):
+            a, t, n = b['anchor_ids'], b['targets'], b['negs']
+            if not isinstance(a, np.ndarray):
+                a = a.cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+            if not isinstance(t, np.ndarray):
+                t = t.cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+            if not isinstance(n, np.ndarray):
+                n = n.cpu().numpy() if torch.is_tensor(n) else np.asarray(n)
+            if a.shape != (B, A):
+                raise ValueError('anchor_ids must be [B, %d] for %s' % (A, b['formula'].query_type))
+            if t.shape != (B,) or n.shape != (B,):
+                raise ValueError('targets / negs must have one id per query')
+            if A == 1:
+                snp[oa:oa + B] = a[:, 0]
+            else:
+                np.copyto(snp[oa:oa + B * A].reshape(A, B), a.T)
+            tl.append(t)
+            nl_.append(n)
+            oa += B * A
+        # (targets and negatives of all batches: one concatenation each, straight into the buffer)
+        np.concatenate(tl, out=snp[na:na + ngr], casting='unsafe')
+        np.concatenate(nl_, out=snp[na + ngr:na + 2 * ngr], casting='unsafe')
+        return snp
+
+    def pack(self, batches, ids=None):
         """batches: list of dicts with keys formula, anchor_ids ([B, A] int64 tensor/array),
-        targets, negs ([B] ids), weight. Returns the HBM-resident packed step."""
+        targets, negs ([B] ids), weight. Returns the HBM-resident packed step.
+        ids: the step's ids as ONE int64 array in flatten_ids' layout -- the batches then need only formula, weight and
+        their size (`batch_size`, or `targets` for its length). A CUDA tensor (a loader that stages ids itself, ids drawn
+        on the device): pack() does no device work at all; the step reads the tensor when it runs, keep its contents
+        until then. A numpy array / CPU tensor (a collate function that writes this layout directly): one copy into
+        pinned staging + one host-to-device copy on the copy stream."""
         m = self.model
         nb = len(batches)
         if nb == 0 or nb > _capi.STEP_MAX_BATCHES:
@@ -200,7 +283,7 @@ class FusedTrainStep(object):
             qt = b['formula'].query_type
             passes_of.append(RGCNQueryDataset.query_diameters[qt] if m.adaptive else m.num_layers)
         nl = min(self.num_lanes, nb)
-        graphs = sum(len(b['targets']) for b in batches)
+        graphs = sum(_bsize(b) for b in batches)
         chain = (not (self.flags & _capi.STEP_NO_CHAIN) and m.emb_dim in (64, 128, 256)
                  and graphs <= CHAIN_MAX_GRAPHS and max(passes_of) <= 5)
         if chain:
@@ -214,7 +297,7 @@ class FusedTrainStep(object):
                                                                                     passes_of[i]))):
                 l = min(range(nl), key=lambda l: load[l])
                 members[l].append(i)
-                load[l] += _batch_work(batches[i]['formula'].query_type, passes_of[i]) * len(batches[i]['targets'])
+                load[l] += _batch_work(batches[i]['formula'].query_type, passes_of[i]) * _bsize(batches[i])
         members = [sorted(mm) for mm in members if mm]
         order = [i for mm in members for i in mm]
         lane_begin = [0]
@@ -248,7 +331,7 @@ class FusedTrainStep(object):
                 if len(self._desc_cache) > 65536:
                     self._desc_cache.clear()
                 self._desc_cache[key] = proto
-            B = len(b['targets'])
+            B = _bsize(b)
             ctypes.memmove(ctypes.addressof(SB[i]), ctypes.addressof(proto[0]), ctypes.sizeof(_capi.StepBatch))
             SB[i].batch_size = B
             SB[i].weight = float(b.get('weight', 1.0))
@@ -271,10 +354,17 @@ class FusedTrainStep(object):
             ps.lanes = ctypes.pointer(L)
         # sizes: functions of the descriptors alone -- cached per descriptor set (one planning pass on a miss; the
         # step's first run takes that plan over)
-        skey = (bytes(SB), tuple(lane_begin))
+        # where the touch plan is built: inside the step (nothing id-dependent left for pack), or here
+        mode = self.touch_mode
+        if mode == 'step' and (not chain or na + 2 * ngr > _capi.TSORT_MAX_ENTRIES):
+            mode = 'pack'
+        ps.touch_mode = mode
+        ps.step_flags = _capi.STEP_BUILD_TOUCH if mode == 'step' else 0
+        skey = (bytes(SB), tuple(lane_begin), mode)
         sz = self._size_cache.get(skey)
         if sz is None:
             lib = ops.lib()
+            self.P.flags = self.flags | ps.step_flags         # (the launch plan, hence the sizes, depend on it)
             sz = (lib.mpqe_step_workspace_bytes(ctypes.byref(self.P), SB, nb, ps.lanes),
                   lib.mpqe_step_desc_bytes(ctypes.byref(self.P), SB, nb, ps.lanes),
                   lib.mpqe_step_touch_bytes(ctypes.byref(self.P), SB, nb),
@@ -286,130 +376,84 @@ class FusedTrainStep(object):
                 self._size_cache.clear()
             self._size_cache[skey] = sz
         ps.ws_bytes, ps.desc_bytes = sz[0], sz[1]
-        # descriptor table of this step: written to HBM by the first run, re-used afterwards. The table is a function of
-        # the descriptor set alone (not of the ids), so a buffer whose packed step is gone serves the next step with the
-        # same set as it is -- table resident, hand-off epochs carried on (they only ever grow): a training loop that
-        # draws fresh ids for a recurring set of formulas uploads nothing. (One stream per FusedTrainStep, as for the
-        # workspace: a re-used buffer's previous step must be ordered before the next one.)
-        pool = self._desc_pool.get(skey)
-        if pool is None:
-            if len(self._desc_pool) > 1024:
-                self._desc_pool.clear()
-                self._slots = []
-            pool = self._desc_pool[skey] = []
-        # (at least three buffers per set take turns even when each packed step dies at once: the pack that re-uses a
-        # buffer waits for the copy that last read its staging memory, three packs back -- never the one just queued)
-        ent = None
-        if len(pool) >= 3:
-            for _ in range(len(pool)):
-                e = pool.pop(0)
-                pool.append(e)
-                if sys.getrefcount(e[0]) == 2:      # (the pool's own reference + getrefcount's argument: nobody else)
-                    ent = e
-                    break
-        if ent is None:
-            ent = [torch.empty(ps.desc_bytes + 256, dtype=torch.uint8, device=self.device), False, 0]
-            if len(pool) < 8:
-                pool.append(ent)
-        ps.desc, ps.desc_ent = ent[0], ent
-        ps.desc_ptr = (ps.desc.data_ptr() + 255) // 256 * 256
-        ps.desc_resident = ent[1]
-        # A descriptor set that keeps coming back (>= 3 packs) gets a SLOT: its own pinned staging buffer, device id
-        # buffer, touch plan buffer and ONE captured hipGraph of {host-to-device copy, touch-plan build}; from then on a
-        # pack of that set is numpy work + one graph launch (host time of copy + build ~50 -> ~15 us).
-        slot = ent[3] if len(ent) > 3 else None
-        if slot is not None:
-            slot['event'].synchronize()          # (its previous copy has read the staging buffer: long done)
-            stage = slot['stage']
+        # Buffers of this packed step (StepBuffers): from the free list of its descriptor set, or new. The descriptor table
+        # is a function of the set alone (not of the ids), so a buffer set whose packed step is gone serves the next step
+        # as it is -- table resident, hand-off epochs carried on (they only ever grow): a training loop that draws fresh
+        # ids for a recurring set of formulas uploads nothing. (One stream per FusedTrainStep, as for the workspace: a
+        # re-used buffer's previous step is ordered before the next one.)
+        free = self._pool.get(skey)
+        if free is None:
+            if len(self._pool) > 1024:
+                self._pool.clear()
+            free = self._pool[skey] = []
+        # (FIFO, and at least three sets take turns before one is used again: the copy that refills a set's id buffer waits
+        # for the step that read it last -- three packs back that step is done, one pack back it is the step still running)
+        if len(free) >= 3:
+            bufs = free.pop(0)
         else:
-            stage = self._staging(na + 2 * ngr)
-        snp = stage.numpy()
-        oa = 0
-        tl, nl_ = [], []
-        for b, B, A in zip(batches, sizes, acols):
-            a, t, n = b['anchor_ids'], b['targets'], b['negs']
-            if not isinstance(a, np.ndarray):
-                a = a.cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
-            if not isinstance(t, np.ndarray):
-                t = t.cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
-            if not isinstance(n, np.ndarray):
-                n = n.cpu().numpy() if torch.is_tensor(n) else np.asarray(n)
-            if a.shape != (B, A):
-                raise ValueError('anchor_ids must be [B, %d] for %s' % (A, b['formula'].query_type))
-            if t.shape != (B,) or n.shape != (B,):
-                raise ValueError('targets / negs must have one id per query')
-            if A == 1:
-                snp[oa:oa + B] = a[:, 0]
-            else:
-                np.copyto(snp[oa:oa + B * A].reshape(A, B), a.T)
-            tl.append(t)
-            nl_.append(n)
-            oa += B * A
-        # (targets and negatives of all batches: one concatenation each, straight into the staging buffer)
-        np.concatenate(tl, out=snp[na:na + ngr], casting='unsafe')
-        np.concatenate(nl_, out=snp[na + ngr:na + 2 * ngr], casting='unsafe')
-        if prof is not None:
-            t1 = time.perf_counter(); prof['ids to staging'] = prof.get('ids to staging', 0.0) + t1 - t0; t0 = t1
+            bufs = StepBuffers()
+            bufs.skey = skey
+            bufs.desc = torch.empty(ps.desc_bytes + 256, dtype=torch.uint8, device=self.device)
+        ps.bufs, ps.owner = bufs, self
+        ps.desc = bufs.desc
+        ps.desc_ptr = (ps.desc.data_ptr() + 255) // 256 * 256
         ps.batches, ps.nb, ps.sizes = SB, nb, sizes
         ps.order, ps.lane_begin = order, lane_begin
         ps.num_graphs = int(ngr)
         ps.touch_entries = sz[4]
         ps.touch_sizes = (sz[2], sz[3])
-        if slot is not None:
-            slot['graph'].replay()               # copy + touch plan, one launch on the current stream
-            slot['event'].record()
-            ids = slot['ids']
-            ps.anchor_ids, ps.targets, ps.negs = ids[:na], ids[na:na + ngr], ids[na + ngr:]
-            ps.touch, ps.touch_ptr = slot['touch'], slot['touch_ptr']
-            if prof is not None:
-                t1 = time.perf_counter(); prof['graph replay'] = prof.get('graph replay', 0.0) + t1 - t0
-            return ps
-        ids = stage.to(self.device, non_blocking=True)
-        self._stage_events[self._stage_next].record()          # the buffer is free again once this copy has run
-        ps.anchor_ids, ps.targets, ps.negs = ids[:na], ids[na:na + ngr], ids[na + ngr:]
-        if prof is not None:
-            t1 = time.perf_counter(); prof['copy to device'] = prof.get('copy to device', 0.0) + t1 - t0; t0 = t1
         ps.touch, ps.touch_ptr = None, None
+        ps.copy_waited, ps.captured = True, False
+        n_ids = na + 2 * ngr
+        if ids is not None and torch.is_tensor(ids) and ids.is_cuda:
+            if not (ids.dtype == torch.long and ids.is_contiguous() and ids.numel() == n_ids and ids.device == self.device):
+                raise ValueError('ids: a contiguous int64 tensor of %d ids (flatten_ids layout)' % n_ids)
+            ps.ids_ref = dev = ids
+        else:
+            # ids -> ONE pinned staging buffer (numpy views, no per-batch tensors) -> the device in ONE copy, on the copy
+            # stream: it overlaps with the step that is running; run() makes the step wait for it
+            stage = self._staging(n_ids)
+            if ids is None:
+                self.flatten_ids(batches, out=stage.numpy())
+            else:
+                h = ids.numpy() if torch.is_tensor(ids) else ids
+                if not (isinstance(h, np.ndarray) and h.dtype == np.int64 and h.shape == (n_ids,)):
+                    raise ValueError('ids: an int64 array of %d ids (flatten_ids layout)' % n_ids)
+                np.copyto(stage.numpy(), h)
+            if prof is not None:
+                t1 = time.perf_counter(); prof['ids to staging'] = prof.get('ids to staging', 0.0) + t1 - t0; t0 = t1
+            if bufs.ids is None or bufs.ids.numel() < n_ids:
+                bufs.ids = torch.empty(n_ids, dtype=torch.long, device=self.device)
+                bufs.last_use = None
+            dev = bufs.ids[:n_ids]
+            cs = self._copy_stream
+            if bufs.last_use is not None:
+                cs.wait_event(bufs.last_use)          # (the step that read these ids last)
+            # (the library's own hipMemcpyAsync wrapper: `with torch.cuda.stream(...)` + copy_ is ~25 us of host time)
+            st = ops.lib().mpqe_copy_to_device(dev.data_ptr(), stage.data_ptr(), 8 * n_ids, cs.cuda_stream)
+            _capi.check(ops.lib(), st, 'mpqe_copy_to_device')
+            self._stage_events[self._stage_next].record(cs)      # the staging buffer is free again once this copy has run
+            if bufs.copied is None:
+                bufs.copied = torch.cuda.Event()
+            bufs.copied.record(cs)
+            ps.copy_waited = False
+            ps.ids_ref = bufs.ids
+            if prof is not None:
+                t1 = time.perf_counter(); prof['copy to device'] = prof.get('copy to device', 0.0) + t1 - t0; t0 = t1
+        ps.anchor_ids, ps.targets, ps.negs = dev[:na], dev[na:na + ngr], dev[na + ngr:]
         if self.touch:
-            self.build_touch(ps)
-        if prof is not None:
-            t1 = time.perf_counter(); prof['touch plan'] = prof.get('touch plan', 0.0) + t1 - t0
-        ent[2] += 1
-        if (self.graph_pack and self.touch and ent[2] >= 3 and len(ent) == 3 and ps.lanes is None
-                and len(self._slots) < 64 and any(e is ent for e in self._desc_pool.get(skey, ()))):
-            self._make_slot(ent, ps, na, ngr)
+            if bufs.touch is None:
+                bufs.touch = torch.empty(sz[2] + 256, dtype=torch.uint8, device=self.device)
+                bufs.touch_ptr = (bufs.touch.data_ptr() + 255) // 256 * 256
+            ps.touch, ps.touch_ptr = bufs.touch, bufs.touch_ptr
+            if mode == 'pack':
+                if not ps.copy_waited:
+                    torch.cuda.current_stream(self.device).wait_event(bufs.copied)
+                    ps.copy_waited = True
+                self.build_touch(ps)
+            if prof is not None:
+                t1 = time.perf_counter(); prof['touch plan'] = prof.get('touch plan', 0.0) + t1 - t0
         return ps
-
-    def _make_slot(self, ent, ps, na, ngr):
-        """Capture {ids host -> device, touch-plan build} of this descriptor set into a hipGraph over buffers the slot
-        owns (see pack()). One-off cost: torch.cuda.graph synchronises and trims the allocator."""
-        L = ops.lib()
-        n = na + 2 * ngr
-        nbytes, wbytes = ps.touch_sizes
-        slot = {'stage': torch.empty(n, dtype=torch.long, pin_memory=True),
-                'ids': torch.empty(n, dtype=torch.long, device=self.device),
-                'touch': torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device),
-                'ws': torch.empty(wbytes + 256, dtype=torch.uint8, device=self.device),
-                'event': torch.cuda.Event(), 'graph': torch.cuda.CUDAGraph()}
-        slot['touch_ptr'] = (slot['touch'].data_ptr() + 255) // 256 * 256
-        wptr = (slot['ws'].data_ptr() + 255) // 256 * 256
-        ids = slot['ids']
-        side = torch.cuda.Stream(self.device)
-        try:
-            # (thread_local: other threads of the process -- a collective library's watchdog -- may go on calling the runtime)
-            with torch.cuda.device(self.device):
-                with torch.cuda.graph(slot['graph'], stream=side, capture_error_mode='thread_local'):
-                    ids.copy_(slot['stage'], non_blocking=True)
-                    st = L.mpqe_step_touch_build(ctypes.byref(self.P), ps.batches, ps.nb, ids.data_ptr(),
-                                                 ids.data_ptr() + 8 * na, ids.data_ptr() + 8 * (na + ngr), slot['touch_ptr'],
-                                                 nbytes, wptr, wbytes, torch.cuda.current_stream().cuda_stream)
-            _capi.check(L, st, 'mpqe_step_touch_build (capture)')
-        except Exception:
-            self.graph_pack = False         # (a runtime that cannot capture here: packs stay eager, nothing else changes)
-            return
-        slot['event'].record()
-        ent.append(slot)
-        self._slots.append(slot)
 
     def build_touch(self, ps):
         """The touch plan of the packed step's ids (include/mpqe_amd.h: mpqe_step_touch_build): which looked-up
@@ -487,7 +531,12 @@ class FusedTrainStep(object):
         if backward:
             self.bind_grads()
         # the library zero-fills the gradient buffers itself (one launch with its other prologue work)
-        self.P.flags = self.flags | (_capi.STEP_ZERO_GRADS if (backward and zero_grad) else 0)
+        self.P.flags = self.flags | packed.step_flags | (_capi.STEP_ZERO_GRADS if (backward and zero_grad) else 0)
+        bufs = packed.bufs
+        stream = torch.cuda.current_stream(self.device)
+        if not packed.copy_waited:
+            stream.wait_event(bufs.copied)              # the ids' host-to-device copy (pack(), on the copy stream)
+            packed.copy_waited = True
         loss = torch.empty(1 + packed.nb, dtype=torch.float32, device=self.device)
         sp = sn = None
         if scores:
@@ -504,18 +553,20 @@ class FusedTrainStep(object):
                 packed.targets.data_ptr(), packed.negs.data_ptr(), self.margin, ctypes.byref(self.G),
                 1 if backward else 0, loss.data_ptr(), None if sp is None else sp.data_ptr(),
                 None if sn is None else sn.data_ptr(), packed.desc_ptr, packed.desc_bytes,
-                0 if packed.desc_resident else 1, wptr, packed.ws_bytes, self.err.data_ptr(), packed.lanes,
+                0 if bufs.desc_resident else 1, wptr, packed.ws_bytes, self.err.data_ptr(), packed.lanes,
                 events, 0 if events is None else len(events), packed.touch_ptr,
-                torch.cuda.current_stream(self.device).cuda_stream)
+                stream.cuda_stream)
         if torch.cuda.current_device() != self.device.index:        # (the context manager costs ~10 us of host time)
             with torch.cuda.device(self.device):
                 st = L.mpqe_step_forward_backward(*args)
         else:
             st = L.mpqe_step_forward_backward(*args)
         _capi.check(L, st, 'mpqe_step_forward_backward')
-        packed.desc_resident = True
-        if getattr(packed, 'desc_ent', None) is not None:
-            packed.desc_ent[1] = True
+        bufs.desc_resident = True
+        if packed.ids_ref is bufs.ids and bufs.ids is not None and not packed.captured:
+            if bufs.last_use is None:
+                bufs.last_use = torch.cuda.Event()
+            bufs.last_use.record(stream)                # (the id buffer may be refilled once this step has run)
         if scores:
             return loss, sp, sn
         return loss
@@ -532,12 +583,25 @@ class FusedTrainStep(object):
         old block to the driver and an earlier graph replayed into unmapped memory: the 'memory access fault'
         the chain form showed. The level form had the same exposure.)"""
         ws = torch.empty(packed.ws_bytes + 256, dtype=torch.uint8, device=self.device)
+        # (the graph replays on this packed step's buffers for as long as it lives: they never go back to the pool, and
+        # no event of the eager path is recorded inside the capture)
+        packed.captured = True
+        packed.bufs.skey = None
         self.run(packed, backward, zero_grad, workspace=ws)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             loss = self.run(packed, backward, zero_grad, workspace=ws)
         return CapturedStep(graph, loss, ws, packed)
+
+    def check_touch(self, packed):
+        """Raise if the touch plan of `packed` could not be built (its sort's workgroups were not all resident at once:
+        csrc/step_touch.h). One D2H read of the plan's header: for callers that read the plan's keys themselves."""
+        if packed.touch is None:
+            return
+        base = packed.touch_ptr - packed.touch.data_ptr()
+        if int(packed.touch[base + 16: base + 20].view(torch.int32).item()) != 0:
+            raise _capi.MpqeError('touch plan: the one-launch sort could not finish (MPQE_FLAG_INTERNAL)')
 
     def check(self):
         """Raise IndexError if any kernel of a previous run saw an invalid entity id (one D2H read)."""

@@ -72,7 +72,10 @@ class Formula(object):
         return (self.query_type, self.rels)
 
     def __hash__(self):
-        return hash(self._key())
+        h = self.__dict__.get('_hash')          # (formulas are dictionary keys on the packing path: hash once)
+        if h is None:
+            h = self.__dict__['_hash'] = hash(self._key())
+        return h
 
     def __eq__(self, other):
         return self._key() == (other.query_type, other.rels)

@@ -147,8 +147,8 @@ def _touch_bits(v):
 
 
 class ExchangePlan(object):
-    __slots__ = ('grad_views', 'bucket', 'bucket_views', 'n_own', 'cap', 'gidx', 'send', 'recv', 'plan', 'plan_ptr',
-                 'entries', 'wire_bytes', 'union')
+    __slots__ = ('form', 'grad_views', 'bucket', 'bucket_views', 'bucket_bytes', 'rows', 'n_own', 'cap', 'gidx', 'send',
+                 'recv', 'plan', 'plan_ptr', 'entries', 'wire_bytes', 'union')
 
 
 class StepExchange(object):
@@ -157,21 +157,30 @@ class StepExchange(object):
     data-parallel port would all-reduce EVERY parameter's dense gradient: 19 MB per step for the AIFB model, of which
     a step touches ~35 of 270 relation matrices, and 191 MB - 1 GB of entity tables at the AM / 1M-entity sizes. Here:
 
-      * relation matrices: which (layer, relation) matrices a rank's step touches is known from its formulas at pack
-        time; the ranks exchange those lists ONCE per packed step (host side, plan()), and only the union -- with the
-        root matrices, biases and mode rows -- goes into ONE contiguous bucket that is all-reduced (sum; the 1 / world
-        of the mean is already in the batch weights). Matrices no rank touched are zero on every rank and stay home.
-      * entity tables: only rows. At pack time every rank all-gathers the (table, row) keys it touches and all build
-        the same plan over all of them (mpqe_rows_plan_build); per step a rank all-gathers its gradient rows and
-        mpqe_table_rows_sum adds the gathered rows per key in plan order -- equal to the dense all-reduce, the same
-        additions in the same order on every rank. No host synchronisation in reduce().
+      * relation matrices: which (layer, relation) matrices a rank's step touches is known from its formulas; the
+        ranks exchange those lists ONCE per formula set (plan(packed, key=...): cached under the caller's key, no
+        collective and no host work when the set recurs), and only the union -- with the root matrices, biases and mode
+        rows -- goes through ONE all-reduce (sum; the 1 / world of the mean is already in the batch weights): copied
+        into a contiguous bucket and back ('bucket' form), or, when the union is most of the gradient anyway (>= 60 %:
+        many ranks, few relations), all-reduced IN PLACE in the flat gradient buffer with no copy at all ('dense'
+        form). Matrices no rank touched are zero on every rank and stay home.
+      * entity tables: small tables (<= 32 MB in all: AIFB 1.3 MB, MUTAG 23 MB) ride in the same all-reduce, dense.
+        Large ones (AM 191 MB, 1M entities 1 GB) exchange only rows: every rank all-gathers the (table, row) keys of
+        its touch plan (a plan built at pack time: FusedTrainStep(touch='pack')) and all build the same plan over all
+        of them (mpqe_rows_plan_build); per step a rank all-gathers its gradient rows and mpqe_table_rows_sum adds the
+        gathered rows per key in plan order -- equal to the dense all-reduce, the same additions in the same order on
+        every rank.
+      No host synchronisation and no object collectives in reduce(): one all-reduce (+ one all-gather and one kernel
+      with the row exchange).
 
         ex = StepExchange(fused_step)
-        plan = ex.plan(packed)          # collective, at pack time
+        plan = ex.plan(packed, key=formula_set_id)     # collective on a key's first use
         loss = fused_step.run(packed); ex.reduce(plan); optimizer.step(packed, rows_plan=ex.rows_plan(plan))
     """
+    DENSE_TABLE_BYTES = 32 << 20
+    DENSE_FRACTION = 0.6
 
-    def __init__(self, fused_step, group=None):
+    def __init__(self, fused_step, group=None, tables='auto'):
         self.fused = fused_step
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -195,6 +204,12 @@ class StepExchange(object):
         self.tab2d = fused_step.flat_grad[lo:hi].view(-1, self.D)
         self.row_base = [(self.off[id(t)] - lo) // self.D for t in self.tables]
         self.row_bits = _touch_bits(max(t.shape[0] for t in self.tables))
+        if tables not in ('auto', 'dense', 'rows'):
+            raise ValueError("tables: 'auto', 'dense' or 'rows'")
+        self.table_mode = tables if tables != 'auto' else ('dense' if 4 * (hi - lo) <= self.DENSE_TABLE_BYTES else 'rows')
+        if self.table_mode == 'rows' and fused_step.touch_mode != 'pack':
+            raise ValueError("the row exchange plans with the touch plan's keys: FusedTrainStep(touch='pack')")
+        self._plans = {}
         import ctypes
         self._tab_g = (ctypes.c_void_p * len(self.tables))(
             *[fused_step.flat_grad.data_ptr() + 4 * self.off[id(t)] for t in self.tables])
@@ -221,11 +236,17 @@ class StepExchange(object):
         else:
             dist.all_gather_into_tensor(out, t, group=self.group)
 
-    def plan(self, packed):
-        """Collective: every rank calls it with ITS packed step (same number of calls in the same order)."""
+    def plan(self, packed, key=None):
+        """Collective: every rank calls it with ITS packed step (same number of calls in the same order).
+        key: the caller's name for what recurs across steps -- the formula sets of ALL ranks at this step (e.g. the index
+        into a common schedule of formula sets). A key seen before returns its cached plan with no collective; the caller
+        vouches that the same key means the same descriptor sets on every rank. Only with dense tables (the row exchange
+        depends on the ids)."""
         import ctypes
         from . import _capi, ops
-        from .data_utils import RGCNQueryDataset
+        rows = self.table_mode == 'rows'
+        if key is not None and not rows and key in self._plans:
+            return self._plans[key]
         f = self.fused
         m = f.model
         layers = list(m.layers)
@@ -237,44 +258,73 @@ class StepExchange(object):
             L = int(b.num_passes)
             for p in range(L):
                 li = p if p < L - 1 else len(layers) - 1
-                key = [k for k, l in enumerate(layers) if l.basis is layers[li].basis][0]     # shared layers: one buffer
+                kk = [k for k, l in enumerate(layers) if l.basis is layers[li].basis][0]     # shared layers: one buffer
                 for e in range(info.num_edges):
-                    mine.add((key, int(b.edge_type[e])))
+                    mine.add((kk, int(b.edge_type[e])))
         gathered = [None] * self.world
         if self.world > 1:
             dist.all_gather_object(gathered, sorted(mine), group=self.group)
         else:
             gathered = [sorted(mine)]
         union = sorted(set().union(*[set(map(tuple, g)) for g in gathered]))
-        segs = []
+        segs, full = [], []
         DD = self.D * self.D
         for p in f.params:
-            if id(p) in self.table_ids:
-                continue
             o = self.off[id(p)]
+            if id(p) in self.table_ids:
+                if not rows:
+                    segs.append((o, p.numel()))
+                    full.append((o, p.numel()))
+                continue
+            full.append((o, p.numel()))
             owner = [k for k, l in enumerate(layers) if l.basis is p]
             if owner:
-                segs.extend((o + rel * DD, DD) for key, rel in union if key == owner[0])
+                segs.extend((o + rel * DD, DD) for kk, rel in union if kk == owner[0])
             else:
                 segs.append((o, p.numel()))
-        segs.sort()
-        merged = []
-        for o, n in segs:
-            if merged and merged[-1][0] + merged[-1][1] == o:
-                merged[-1][1] += n
-            else:
-                merged.append([o, n])
+
+        def merge(ss):
+            out = []
+            for o, n in sorted(ss):
+                if out and out[-1][0] + out[-1][1] == o:
+                    out[-1][1] += n
+                else:
+                    out.append([o, n])
+            return out
+        merged, spans = merge(segs), merge(full)
         ep = ExchangePlan()
         ep.union = union
-        ep.grad_views = [f.flat_grad[o:o + n] for o, n in merged]
-        ep.bucket = torch.zeros(sum(n for _, n in merged), dtype=torch.float32, device=self.dev)
-        ep.bucket_views, o = [], 0
-        for _, n in merged:
-            ep.bucket_views.append(ep.bucket[o:o + n])
-            o += n
+        ep.rows = rows
+        nsel, nfull = sum(n for _, n in merged), sum(n for _, n in spans)
+        if nsel >= self.DENSE_FRACTION * nfull:
+            # most of the gradient is touched by some rank: all-reduce the parameter spans where they lie, no copies
+            ep.form = 'dense'
+            ep.grad_views = [f.flat_grad[o:o + n] for o, n in spans]
+            ep.bucket, ep.bucket_views, ep.bucket_bytes = None, None, 4 * nfull
+        else:
+            ep.form = 'bucket'
+            ep.grad_views = [f.flat_grad[o:o + n] for o, n in merged]
+            ep.bucket = torch.zeros(nsel, dtype=torch.float32, device=self.dev)
+            ep.bucket_views, o = [], 0
+            for _, n in merged:
+                ep.bucket_views.append(ep.bucket[o:o + n])
+                o += n
+            ep.bucket_bytes = 4 * nsel
+        w = self.world
+        ep.wire_bytes = int(2 * (w - 1) / max(w, 1) * ep.bucket_bytes)
+        ep.n_own = ep.cap = ep.entries = 0
+        ep.gidx = ep.send = ep.recv = ep.plan = ep.plan_ptr = None
+        if not rows:
+            if key is not None:
+                if len(self._plans) > 4096:
+                    self._plans.clear()
+                self._plans[key] = ep
+            return ep
         # ---- rows: this rank's distinct keys from its touch plan, all ranks' keys, one plan over all of them
-        if packed.touch is None:
-            raise ValueError('StepExchange needs a packed step with a touch plan (chain form)')
+        if packed.touch is None or packed.touch_mode != 'pack':
+            raise ValueError("the row exchange needs a packed step whose touch plan was built by pack(): "
+                             "FusedTrainStep(touch='pack')")
+        f.check_touch(packed)
         base = packed.touch_ptr - packed.touch.data_ptr()
         M = packed.touch_entries
         keys = packed.touch[base + 256: base + 256 + 8 * M].view(torch.int64)
@@ -308,21 +358,26 @@ class StepExchange(object):
         ep.gidx = base_t[tab] + row
         ep.send = torch.zeros(ep.cap, self.D, dtype=torch.float32, device=self.dev)
         ep.recv = torch.empty(self.world * ep.cap, self.D, dtype=torch.float32, device=self.dev)
-        w = self.world
-        ep.wire_bytes = int(2 * (w - 1) / max(w, 1) * ep.bucket.numel() * 4 + (w - 1) * ep.cap * self.D * 4)
+        ep.wire_bytes += int((w - 1) * ep.cap * self.D * 4)
         return ep
 
     def rows_plan(self, ep):
-        """(plan pointer, entries) for FlatOptimizer.step(packed, rows_plan=...): the rows ANY rank touched."""
-        return ep.plan_ptr, ep.entries
+        """(plan pointer, entries) for FlatOptimizer.step(packed, rows_plan=...): the rows ANY rank touched (row exchange
+        only; None with dense tables)."""
+        return (ep.plan_ptr, ep.entries) if ep.rows else None
 
     def reduce(self, ep):
         """After fused_step.run(packed): every p.grad <- sum over ranks (stream-ordered, no host read)."""
         from . import _capi, ops
-        if ep.bucket.numel():
+        if ep.form == 'dense':
+            for v in ep.grad_views:
+                self._all_reduce(v)
+        elif ep.bucket.numel():
             torch._foreach_copy_(ep.bucket_views, ep.grad_views)
             self._all_reduce(ep.bucket)
             torch._foreach_copy_(ep.grad_views, ep.bucket_views)
+        if not ep.rows:
+            return
         if ep.n_own:
             torch.index_select(self.tab2d, 0, ep.gidx, out=ep.send[:ep.n_own])
         self._all_gather(ep.recv, ep.send)

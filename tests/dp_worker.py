@@ -25,7 +25,7 @@ def batches_of(schema, rank, B, scale):
 
 
 def main():
-    outdir, sparse = sys.argv[1], sys.argv[2] == '1'
+    outdir, sparse, tables = sys.argv[1], sys.argv[2] == '1', sys.argv[3]
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.cuda.set_device(0)
@@ -46,10 +46,14 @@ def main():
     with torch.no_grad():
         for p in model.layers.parameters():
             p.mul_(4.0)
-    step = FusedTrainStep(model, sparse_tables=sparse)
+    # tables = 'rows': the row exchange (plans with the keys of a touch plan built at pack time); 'dense': the tables ride in
+    # the all-reduce and the step builds its touch plan itself (the default)
+    step = FusedTrainStep(model, sparse_tables=sparse, touch='pack' if tables == 'rows' else 'step')
     packed = step.pack(batches_of(schema, rank, B, 1.0 / world))
-    ex = StepExchange(step)
-    plan = ex.plan(packed)
+    ex = StepExchange(step, tables=tables)
+    plan = ex.plan(packed, key='set0')
+    if tables == 'dense':
+        assert ex.plan(packed, key='set0') is plan          # a recurring key: no collective, the cached plan
     for p in model.parameters():
         p.grad.fill_(3.0)
     step.run(packed)
@@ -57,10 +61,12 @@ def main():
     step.check()
     torch.cuda.synchronize()
     out = dict(flat=step.flat_grad.cpu().numpy(), wire=np.array([plan.wire_bytes]), dense=np.array([step.flat_grad.numel() * 4]))
-    # which table rows hold the reduced gradient (sparse mode leaves the others alone)
-    base = plan.plan_ptr - plan.plan.data_ptr()
-    keys = plan.plan[base + 256: base + 256 + 8 * plan.entries].view(torch.int64)
-    out['union_keys'] = torch.unique(keys[keys != -1]).cpu().numpy()
+    out['form'] = np.array([plan.form])
+    if tables == 'rows':
+        # which table rows hold the reduced gradient (sparse mode leaves the others alone)
+        base = plan.plan_ptr - plan.plan.data_ptr()
+        keys = plan.plan[base + 256: base + 256 + 8 * plan.entries].view(torch.int64)
+        out['union_keys'] = torch.unique(keys[keys != -1]).cpu().numpy()
     out['row_bits'] = np.array([ex.row_bits])
     if rank == 0:   # single process, all ranks' batches in one step (dense tables)
         ref_step = FusedTrainStep(model)

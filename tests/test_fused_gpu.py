@@ -294,31 +294,76 @@ def test_sparse_tables_training_loop():
         np.testing.assert_allclose(p.detach().cpu().numpy(), ref[k].detach().cpu().numpy(), rtol=1e-3, atol=2e-3, err_msg=k)
 
 
-def test_pack_of_a_recurring_descriptor_set_replays_a_graph():
-    """From its third pack on, a descriptor set (same formulas, sizes, weights) is packed by refilling a pinned
-    staging buffer and replaying ONE captured hipGraph {ids to the device, touch-plan build} over buffers its slot
-    owns (FusedTrainStep.pack). Fresh ids every pack, two packed steps alive at a time (two slots): losses, scores and
-    every gradient equal those of a step object that packs eagerly (graph_pack=False), bit for bit."""
+def test_fresh_ids_every_step_in_step_plan_equals_pack_time_plan():
+    """The training-loop regime: fresh ids every step for a recurring descriptor set. The step that builds its touch
+    plan itself (default) from (a) host arrays -- staged and copied on the copy stream -- and (b) a flat id tensor
+    already on the device, against a step object that builds the plan in pack() (touch='pack'): losses, scores and
+    every gradient bit for bit, 15 steps, two packed steps alive at a time (their buffers come from the step object's
+    pool and go back to it when the packed step dies)."""
     from mpqe_amd.fused import FusedTrainStep
     model, batches = _setup('mp', True, False)
-    eager = FusedTrainStep(model, graph_pack=False)
+    at_pack = FusedTrainStep(model, touch='pack')
     step = FusedTrainStep(model)
+    assert step.touch_mode == 'step' and at_pack.touch_mode == 'pack'
     rng = np.random.RandomState(3)
-    prev, slots = None, 0
-    for it in range(15):                        # (three buffers per set take turns; each is captured at its third pack)
+    prev, seen_bufs = None, set()
+    for it in range(15):
         fresh = []
         for b in batches:                       # same formulas and sizes, ids permuted between the queries
             p = rng.permutation(len(b['targets']))
             fresh.append(dict(b, anchor_ids=b['anchor_ids'][p], targets=b['targets'][p], negs=b['negs'][rng.permutation(len(p))]))
         pk = step.pack(fresh)
-        slots += int(pk.desc_ent is not None and len(pk.desc_ent) > 3)
+        assert pk.step_flags != 0 and pk.bufs is not (prev.bufs if prev is not None else None)
+        seen_bufs.add(id(pk.bufs))
         loss, sp, sn = step.run(pk, scores=True)
         got = {k: p.grad.clone() for k, p in model.named_parameters()}
         loss, sp, sn = loss.clone(), sp.clone(), sn.clone()
-        rl, rsp, rsn = eager.run(eager.pack(fresh), scores=True)
+        # (b) the same ids as one device tensor, descriptors only
+        flat = torch.from_numpy(step.flatten_ids(fresh)).cuda()
+        desc = [dict(formula=b['formula'], weight=b.get('weight', 1.0), batch_size=len(b['targets'])) for b in fresh]
+        dl, dsp, dsn = step.run(step.pack(desc, ids=flat), scores=True)
+        assert torch.equal(loss, dl) and torch.equal(sp, dsp) and torch.equal(sn, dsn), it
+        for k, p in model.named_parameters():
+            assert torch.equal(got[k], p.grad), (it, k)
+        rl, rsp, rsn = at_pack.run(at_pack.pack(fresh), scores=True)
         assert torch.equal(loss, rl) and torch.equal(sp, rsp) and torch.equal(sn, rsn), it
         for k, p in model.named_parameters():
             assert torch.equal(got[k], p.grad), (it, k)
-        prev = pk                               # (keeps the previous packed step alive: the next pack takes another slot)
-    assert slots >= 4                           # the later packs came out of captured slots
-    assert int(step.err.item()) == 0
+        # the plan the step left behind == the plan pack() builds (keys and permutation)
+        M = pk.touch_entries
+        a0 = pk.touch_ptr - pk.touch.data_ptr()
+        ref_pk = at_pack.pack(fresh)
+        torch.cuda.synchronize()
+        b0 = ref_pk.touch_ptr - ref_pk.touch.data_ptr()
+        al = lambda n: (n + 255) // 256 * 256
+        assert torch.equal(pk.touch[a0 + 256:a0 + 256 + 8 * M], ref_pk.touch[b0 + 256:b0 + 256 + 8 * M])
+        o = 256 + al(8 * M)
+        assert torch.equal(pk.touch[a0 + o:a0 + o + 4 * M], ref_pk.touch[b0 + o:b0 + o + 4 * M])
+        prev = pk                               # (keeps the previous packed step alive: the next pack takes other buffers)
+    assert len(seen_bufs) <= step.POOL_PER_SET  # the pool recycles: buffers of dead packed steps serve later ones
+    step.check()
+    at_pack.check()
+
+
+def test_packed_steps_own_their_buffers():
+    """Explicit ownership of the pooled buffers: a live packed step's descriptor table / ids / plan are never handed to
+    another pack; they return to the pool exactly when the packed step dies."""
+    from mpqe_amd.fused import FusedTrainStep
+    model, batches = _setup('mp', True, False)
+    step = FusedTrainStep(model)
+    live = [step.pack(batches) for _ in range(5)]
+    assert len(set(id(p.bufs) for p in live)) == 5
+    skey = live[0].bufs.skey
+    assert len(step._pool[skey]) == 0
+    ref = step.run(live[0]).clone()
+    g0 = step.flat_grad.clone()
+    for p in live[1:]:
+        assert torch.equal(step.run(p), ref) and torch.equal(step.flat_grad, g0)
+    ids = [id(p.bufs) for p in live]
+    del p
+    live = live[:2]
+    assert len(step._pool[skey]) == 3           # the three dead steps' buffers are back
+    again = step.pack(batches)
+    assert id(again.bufs) in ids[2:] and again.desc_resident      # ... table still resident: nothing to upload
+    assert torch.equal(step.run(again), ref) and torch.equal(step.flat_grad, g0)
+    step.check()

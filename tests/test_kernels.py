@@ -215,12 +215,13 @@ def test_general_layer_heavy_relation_and_odd_dims(be):
 @pytest.mark.parametrize('slots', [None, 16])
 @pytest.mark.parametrize('dims', [(128, 64), (64, 320)])
 @pytest.mark.parametrize('relu', [0, 1])
-def test_general_layer_dims_of_64_register_tiles(be, relu, dims, slots, monkeypatch):
+def test_general_layer_dims_of_64_register_tiles(be, relu, dims, slots, request):
     """Din, Dout multiples of 64: the gather-GEMMs and the weight gradients take the register-operand kernels (gathered
     rows straight into MFMA operands, csrc/rgcn_general.hip: rgcn_gen_gemm_rows_kernel, rgcn_gen_grad_w_rows_kernel). Din != Dout, a relation with several K
     chunks and a ragged last one, a relation with no edge, many edges into one node."""
     if slots is not None:       # the gather-GEMMs are persistent: a grid of 16 workgroups walks the ~30 row tiles
-        monkeypatch.setenv('MPQE_DBG_GEN_SLOTS', str(slots))
+        be.lib.mpqe_debug_option(b'GEN_SLOTS', slots, 1)
+        request.addfinalizer(lambda: be.lib.mpqe_debug_option(b'GEN_SLOTS', 0, 0))
     rng = np.random.RandomState(23 + relu)
     Nn, E, R = 300, 1100, 5
     Din, Dout = dims          # (64, 320): five column blocks -- a second workgroup per row tile with one wave at work

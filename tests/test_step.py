@@ -70,8 +70,15 @@ def oracle_step(params, cfg, node_map, batches, margin):
     return total.item(), per, np.concatenate(sp), np.concatenate(sn)
 
 
-def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=1, lanes=None, flags=0, touch=True, repeat=1):
+def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=1, lanes=None, flags=0, touch='step', repeat=1,
+             plan_out=None):
+    """touch: 'step' = the step builds the touch plan of its ids itself (MPQE_STEP_BUILD_TOUCH, the product's default),
+    'pack' = mpqe_step_touch_build in front of it, False = fp32 atomics. plan_out: a list that receives the plan's bytes."""
     D = params['mode_embeddings.weight'].shape[1]
+    if touch == 'step' and ((flags & _capi.STEP_EIGHT_WAVES) or lanes is not None):
+        touch = 'pack'
+    if touch == 'step':
+        flags |= _capi.STEP_BUILD_TOUCH
     L = cfg['num_layers']
     R = params['layers.0.basis'].shape[0]
     modes = list(schema.modes)
@@ -167,14 +174,19 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
         assert tb > 0 and twb > 0
         tbuf, twbuf = be.nbytes(tb + 256), be.nbytes(twb + 256)
         tptr = (be.ptr(tbuf) + 255) // 256 * 256
-        be.check(be.lib.mpqe_step_touch_build(ctypes.byref(P), SB, nb, be.ptr(d_anchor), be.ptr(d_tg), be.ptr(d_ng), tptr, tb,
-                                              (be.ptr(twbuf) + 255) // 256 * 256, twb, be.stream), 'touch')
+        if touch == 'pack':
+            be.check(be.lib.mpqe_step_touch_build(ctypes.byref(P), SB, nb, be.ptr(d_anchor), be.ptr(d_tg), be.ptr(d_ng), tptr, tb,
+                                                  (be.ptr(twbuf) + 255) // 256 * 256, twb, be.stream), 'touch')
         keep.extend([tbuf, twbuf])
     for rep in range(repeat):       # (repeat > 1: the same packed step again -- its hand-off epochs / counters carry on)
         be.check(be.lib.mpqe_step_forward_backward(ctypes.byref(P), SB, nb, be.ptr(d_anchor), be.ptr(d_tg),
                                                    be.ptr(d_ng), margin, ctypes.byref(G), backward, be.ptr(loss),
                                                    be.ptr(sp), be.ptr(sn), dptr, dsb, 1 if rep == 0 else 0, wptr, wsb,
                                                    be.ptr(err), lanes, None, 0, tptr, be.stream), 'step')
+    if plan_out is not None and touch:
+        raw = np.asarray(be.get(tbuf)).view(np.uint8)
+        off = tptr - be.ptr(tbuf)
+        plan_out.append(raw[off:off + tb].copy())
     grads = {'mode_embeddings.weight': be.get(gmode)}
     for m, g in zip(modes, gtabs):
         grads['enc.feat-%s.weight' % m] = be.get(g)
@@ -283,6 +295,19 @@ def test_fused_step_chain_kernels(be, D, readout, adaptive, shared, L):
         again = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0)
         for k in got[3]:          # with the touch plan EVERY gradient is bit-reproducible, the entity tables included
             np.testing.assert_array_equal(again[3][k], got[3][k], err_msg=k)
+        # the plan built at pack time (mpqe_step_touch_build) instead of inside the step: the same plan, the same bits
+        plans = [[], []]
+        packed = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, touch='pack', plan_out=plans[0])
+        run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, touch='step', plan_out=plans[1], repeat=2)
+        runs.append(packed)
+        for k in got[3]:
+            np.testing.assert_array_equal(packed[3][k], got[3][k], err_msg=k)
+        M = sum(b['B'] * (len(b['formula'].anchor_modes) + 2) for b in batches)
+        al = lambda n: (n + 255) // 256 * 256
+        np.testing.assert_array_equal(plans[0][0][:64], plans[1][0][:64])                       # header
+        np.testing.assert_array_equal(plans[0][0][256:256 + 8 * M], plans[1][0][256:256 + 8 * M])   # sorted keys
+        o = 256 + al(8 * M)
+        np.testing.assert_array_equal(plans[0][0][o:o + 4 * M], plans[1][0][o:o + 4 * M])       # perm
     if D == 64:
         runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_NO_PRUNE))
     if D == 128:      # the form whose waves own 32 columns and all of K (the default splits K between wave pairs)
@@ -427,14 +452,15 @@ def test_fused_step_rejects_bad_descriptors(be):
     assert be.lib.mpqe_step_workspace_bytes(ctypes.byref(P), SB, 17, None) == 0         # > MAX_BATCHES
 
 
-@pytest.mark.parametrize('sizes', [(9, 5), (700, 333), (3000, 1111), (11000, 2500)])
+@pytest.mark.parametrize('sizes', [(9, 5), (700, 333), (3000, 1111), (11000, 2500), (45000, 10000)])
 def test_touch_plan_one_launch_equals_library_sort(be, sizes):
     """The touch plan built in ONE launch (keys, a grid-synchronised stable 8-bit LSD radix sort with one entry per thread,
     inverse permutation: csrc/step_touch.h touch_sort_kernel; plans of up to 65 536 looked-up ids) is byte for byte the plan
-    of the keys kernel + rocPRIM radix_sort_pairs + inversion (MPQE_DBG_TOUCH_ROCPRIM=1) -- a stable sort has one answer.
+    of the keys kernel + rocPRIM radix_sort_pairs (mpqe_debug_option TOUCH_ROCPRIM) -- a stable sort has one answer.
     1 to 61 workgroups, bad ids included. (The host emulator runs workgroups one after the other and has no grid barrier:
     there both builds take the library-sort stand-in and the test only pins the layout.)"""
-    import os
+    if be.name == 'emu' and sizes[0] > 11000:
+        pytest.skip('250 workgroups: GPU only (the CPU suite\'s time budget)')
     rng = np.random.RandomState(sizes[0])
     nmodes, rows_per = 3, [70, 40000, 130]
     node_map = np.full(sum(rows_per) + 1, -1, np.int64)
@@ -463,8 +489,7 @@ def test_touch_plan_one_launch_equals_library_sort(be, sizes):
     twb = be.lib.mpqe_step_touch_workspace_bytes(ctypes.byref(P), SB, 2)
     got = []
     for force_library in (False, True, False):
-        if force_library:
-            os.environ['MPQE_DBG_TOUCH_ROCPRIM'] = '1'
+        be.lib.mpqe_debug_option(b'TOUCH_ROCPRIM', 1, 1 if force_library else 0)
         try:
             tbuf, twbuf = be.nbytes(tb + 256), be.nbytes(twb + 256)
             if be.name == 'emu':
@@ -480,22 +505,33 @@ def test_touch_plan_one_launch_equals_library_sort(be, sizes):
             off = tptr - be.ptr(tbuf)
             got.append(raw[off:off + tb].copy())
         finally:
-            os.environ.pop('MPQE_DBG_TOUCH_ROCPRIM', None)
+            be.lib.mpqe_debug_option(b'TOUCH_ROCPRIM', 0, 0)
     M = int(be.lib.mpqe_step_touch_entries(SB, 2))
     assert M == 5 * B1 + 3 * B2
-    # header | keys [M] u64 | pos [M] i32 | erow [M] i32, each region 256-byte aligned: compare the used bytes
+    # header | keys [M] u64 | perm [M] i32 | erow [M] i32, each region 256-byte aligned: compare the used bytes
     al = lambda n: (n + 255) // 256 * 256
     o_keys, o_pos = 256, 256 + al(8 * M)
     o_erow = o_pos + al(4 * M)
     for other in (got[1], got[2]):
         np.testing.assert_array_equal(got[0][:64], other[:64])
-        for name, lo, n in (('keys', o_keys, 8 * M), ('pos', o_pos, 4 * M), ('erow', o_erow, 4 * M)):
+        for name, lo, n in (('keys', o_keys, 8 * M), ('perm', o_pos, 4 * M), ('erow', o_erow, 4 * M)):
             np.testing.assert_array_equal(got[0][lo:lo + n], other[lo:lo + n], err_msg=name)
     keys = got[0][o_keys:o_keys + 8 * M].view(np.uint64)
     assert (np.diff(keys.astype(np.float64)) >= 0).all()
     assert int((keys == np.uint64(2 ** 64 - 1)).sum()) == 2          # the two bad ids, sorted to the end
-    pos = got[0][o_pos:o_pos + 4 * M].view(np.int32)
-    assert sorted(pos.tolist()) == list(range(M))
+    perm_got = got[0][o_pos:o_pos + 4 * M].view(np.int32)
+    # ... and against numpy: key of every entry (table << row_bits | row; all ones for a bad id), stable argsort
+    tabs = np.concatenate([np.full(B1, 0), np.full(B1, 1), np.full(B1, 1), np.full(B2, 1), np.full(B1, 2), np.full(B2, 1),
+                           np.full(B1, 2), np.full(B2, 1)])
+    ids_all = np.concatenate([anchors, targets, negs])
+    ok = (ids_all >= 0) & (ids_all < len(node_map))
+    rows = np.where(ok, node_map[np.clip(ids_all, 0, len(node_map) - 1)], -1)
+    row_bits = int(np.frombuffer(got[0][8:12].tobytes(), np.int32)[0])
+    want_keys = np.where(rows >= 0, (tabs.astype(np.uint64) << np.uint64(row_bits)) | rows.astype(np.uint64),
+                         np.uint64(2 ** 64 - 1))
+    order = np.argsort(want_keys, kind='stable')
+    np.testing.assert_array_equal(perm_got, order.astype(np.int32))
+    np.testing.assert_array_equal(keys, want_keys[order])
 
 
 def test_adam_rows_step_equals_torch_sparse_adam(be):

@@ -30,12 +30,18 @@ def main():
     ap.add_argument('--merged', action='store_true', help='merged launch: chain workgroups and tiles on one clock')
     ap.add_argument('--merge-tail', action='store_true', help='force the merged launch')
     ap.add_argument('--trace', action='store_true', help='CHAIN_DBG=6 builds: per-item cycle stamps of block 0')
+    ap.add_argument('--touch', default='step', choices=['step', 'pack'])
+    ap.add_argument('--reps', type=int, default=1)
+    ap.add_argument('--debug-opt', action='append', default=[], metavar='NAME=VALUE')
     args = ap.parse_args()
     from mpqe_amd import ops, synthetic
     from mpqe_amd.data_utils import make_feature_modules
     from mpqe_amd.encoders import DirectEncoder
     from mpqe_amd.fused import FusedTrainStep
     from mpqe_amd.model import RGCNEncoderDecoder
+    for kv in args.debug_opt:
+        name, _, val = kv.partition('=')
+        ops.lib().mpqe_debug_option(name.encode(), int(val or 1), 1)
     torch.manual_seed(0)
     dev = torch.device('cuda:0')
     D = args.embed_dim
@@ -47,7 +53,8 @@ def main():
                                shared_layers=False, adaptive=adaptive, weight_decay=0).to(dev)
     model.validate = False
     data = bench.StepData(schema, model, args.batch_size, np.random.RandomState(1000), dev)
-    step = FusedTrainStep(model, prune=not args.no_prune, merge_tail=True if (args.merge_tail or args.merged) else None)
+    step = FusedTrainStep(model, prune=not args.no_prune, merge_tail=True if (args.merge_tail or args.merged) else None,
+                          touch=args.touch)
     packed = bench.pack_for_fused(step, data)
     assert step.uses_chain(packed), 'this step does not take the chain kernel'
     for _ in range(5):
@@ -136,16 +143,40 @@ def main():
     cap = 16 * sum((b + 15) // 16 for b in packed.sizes)     # the launch grid has holes (placement by XCD)
     stamps = torch.zeros(cap * 8, dtype=torch.int64, device=dev)
     ops.lib().mpqe_debug_chain_stamps(stamps.data_ptr(), cap)
-    step.run(packed)
-    torch.cuda.synchronize()
+    import ctypes
+    worst = None
+    for rep in range(args.reps):        # several stamped runs: [launch duration by events | chain makespan | sort end] per run
+        stamps.zero_()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        for e in evs:
+            e.record()
+        step.run(packed, events=(ctypes.c_void_p * 4)(*[e.cuda_event for e in evs]))
+        torch.cuda.synchronize()
+        r = stamps.cpu().numpy()
+        s8 = r.reshape(cap, 8)
+        nre = sum((b + 15) // 16 for b in packed.sizes)
+        g = (nre + 7) // 8 * 8
+        while int((s8[:g, 6] != 0).sum()) < nre or bool((s8[g:2 * g, 6] != 0).any()):
+            g += 8
+        m = s8[:g][s8[:g, 6] != 0]
+        ns = (packed.touch_entries + 1023) // 1024 if packed.step_flags else 0
+        so = r[g * 16: g * 16 + 8 * ns].reshape(ns, 8)
+        print('run %d: chain launch %.1f us (events), tail %.1f; chain workgroups %.1f .. %.1f us; sort %s'
+              % (rep, evs[0].elapsed_time(evs[1]) * 1e3, evs[2].elapsed_time(evs[3]) * 1e3, 0.0, (m[:, 6].max() - m[:, 0].min()) * 0.01,
+                 ('%.1f .. %.1f' % ((so[:, 0].min() - m[:, 0].min()) * 0.01, (so[:, 7].max() - m[:, 0].min()) * 0.01)) if ns else '-'))
+        span = m[:, 6].max() - m[:, 0].min()
+        if worst is None or span > worst[0]:
+            worst = (span, r.copy())
     ops.lib().mpqe_debug_chain_stamps(None, 0)
-    raw = stamps.cpu().numpy()
+    raw = worst[1]                                  # the details below: the slowest of the runs
     st = raw.reshape(cap, 8)
     nreal = sum((b + 15) // 16 for b in packed.sizes)
     grid = (nreal + 7) // 8 * 8                     # the launch grid: 8 x (longest XCD list), holes included
     while int((st[:grid, 6] != 0).sum()) < nreal or bool((st[grid:2 * grid, 6] != 0).any()):
         grid += 8
     trace_words = raw[grid * 16: grid * 16 + 8192].copy()
+    nsort = (packed.touch_entries + 1023) // 1024 if packed.step_flags else 0
+    sort_st = raw[grid * 16: grid * 16 + 8 * nsort].reshape(nsort, 8).copy()     # (the in-step sort's workgroups: behind the chain entries)
     st[2 * grid:] = 0                               # (a CHAIN_DBG=6 build keeps its trace behind the stamps)
     used = np.nonzero(st[:, 6] != 0)[0]
     if args.trace:
@@ -186,6 +217,12 @@ def main():
     names = ['A1 ids', 'A2 gather', 'forward', 'score', 'backward', 'anchors']
     print('workgroups %d, makespan %.1f us (first start %.1f, last start %.1f)'
           % (nblk, t[:, 6].max(), t[:, 0].min(), t[:, 0].max()))
+    if nsort and sort_st[:, 7].all():
+        ts = (sort_st - st[:, 0].min()) * 0.01
+        n_st = int((sort_st[0, :7] != 0).sum())
+        print('touch-plan sort: %d workgroups; start %.1f..%.1f us, keys done %.1f..%.1f, after grid barriers %s, end %.1f..%.1f'
+              % (nsort, ts[:, 0].min(), ts[:, 0].max(), ts[:, 1].min(), ts[:, 1].max(),
+                 ' | '.join('%.1f..%.1f' % (ts[:, k].min(), ts[:, k].max()) for k in range(2, n_st)), ts[:, 7].min(), ts[:, 7].max()))
     uniq, cnt = np.unique(place, return_counts=True)
     print('distinct CUs used %d; workgroups per CU: %s' % (len(uniq), dict(zip(*np.unique(cnt, return_counts=True)))))
     # which batch a block belongs to cannot be read back from the library; durations by total time instead

@@ -54,6 +54,11 @@ def run(qt, D, B, R, dev, iters=20):
 def main():
     dev = torch.device('cuda:0')
     D, B, R = int(os.environ.get('SCATTER_BENCH_D', 256)), int(os.environ.get('SCATTER_BENCH_B', 8192)), 128
+    # timing experiments: SCATTER_BENCH_OPTS="NAME=VALUE,..." -> the library's diagnostics switches (mpqe_debug_option)
+    from mpqe_amd import ops
+    for kv in filter(None, os.environ.get('SCATTER_BENCH_OPTS', '').split(',')):
+        name, _, val = kv.partition('=')
+        ops.lib().mpqe_debug_option(name.encode(), int(val or 1), 1)
     out = {}
     for k, qt in enumerate(('3-inter', '3-chain', '3-inter')):
         out['%d:%s' % (k, qt)] = run(qt, D, B, R, dev)
