@@ -31,8 +31,10 @@ def load_graph(data_dir, embed_dim):
     node_maps = torch.full((num_nodes + 1,), -1, dtype=torch.long)
     for mode, ids in node_ids.items():
         ids = torch.as_tensor(list(ids), dtype=torch.long)
-        if ids.numel() and bool((node_maps[ids] != -1).any()):
-            raise AssertionError('entity id listed under two modes')      # (the reference asserts, line 27)
+        # (the reference asserts per element that the id is not mapped yet, line 27: an id listed under two modes, or twice
+        # under one, fails there)
+        if ids.numel() and (bool((node_maps[ids] != -1).any()) or ids.unique().numel() != ids.numel()):
+            raise AssertionError('entity id listed twice (under two modes, or repeated inside one)')
         node_maps[ids] = torch.arange(ids.shape[0])
     feature_dims = {m: embed_dim for m in rels}
     feature_modules = {m: torch.nn.Embedding(len(node_ids[m]) + 1, embed_dim) for m in rels}

@@ -151,17 +151,46 @@ def test_stress_shape_properties():
 BENCH_WEIGHTS = {'1-chain': 1.0, 'chain': 0.01, 'inter': 0.005}      # reference train_helpers.py:60-61, 97-112
 
 
-@pytest.mark.parametrize('flags', ['default', 'no_prune', 'no_uniform', 'no_chain'])
-def test_benchmarked_workload_against_oracle(flags):
+def _queries(b):
+    return [type('Q', (), {'anchor_nodes': tuple(int(v) for v in row)})() for row in b['anchor_ids']]
+
+
+def drop_near_ties(batches, cpu_params, cfg, node_maps, model, tol=1e-6):
+    """max readout: the reference takes, per graph and column, the largest of the N final node states (model.py:384);
+    where the two largest are within `tol` of each other the fp32 summation order decides which node wins -- a discrete,
+    equally valid choice that routes that column's gradient to another node. Those graphs (a handful per batch) are
+    taken out of BOTH sides, so that everything left is compared at the plain tolerances."""
+    from oracle import ref_cpu
+    out, dropped = [], 0
+    with torch.no_grad():
+        for b in batches:
+            col = ref_cpu.collate(b['formula'], _queries(b), model.rel_ids, model.mode_ids)
+            keep = {}
+            ref_cpu.encode_queries(cpu_params, cfg, node_maps, b['formula'], col, keep=keep)
+            h = keep['layers'][-1].reshape(col['B'], col['N'], -1)
+            top2 = torch.topk(h, 2, dim=1).values
+            ok = ((top2[:, 0] - top2[:, 1]) > tol).all(dim=1).numpy()
+            dropped += int((~ok).sum())
+            out.append(sub(b, np.nonzero(ok)[0]))
+    return out, dropped
+
+
+@pytest.mark.parametrize('kg,D,readout,adaptive,flags', [
+    ('aifb', 128, 'mp', True, 'default'), ('aifb', 128, 'mp', True, 'no_prune'), ('aifb', 128, 'mp', True, 'no_uniform'),
+    ('aifb', 128, 'mp', True, 'no_chain'),            # configs[1], the benchmarked one, with the speed switches on and off
+    ('mutag', 256, 'sum', False, 'default'),          # configs[2]
+    ('am', 128, 'max', False, 'default')])            # configs[3]
+def test_benchmarked_workload_against_oracle(kg, D, readout, adaptive, flags):
     """BASELINE.json configs[1] exactly as bench.py times it -- AIFB-shaped KG, the 11-batch post-burn-in mix at
     B = 512, D = 128, readout mp (TM), adaptive, num_layers 3 unshared, the reference's loss weights -- through the
-    fused step (the chain kernel with liveness pruning, XCD placement with holes, paired blocks) against the CPU
-    oracle in the reference's op sequence on ALL 11 batches: every score (rtol 1e-5), the loss, every parameter
-    gradient (rtol 1e-4). Run with the speed switches on (default) and off."""
+    fused step (the chain kernel with liveness pruning, XCD placement with holes, paired blocks; ids fresh, the touch
+    plan built inside the step) against the CPU oracle in the reference's op sequence on ALL 11 batches: every score
+    (rtol 1e-5), the loss, every parameter gradient (rtol 1e-4). And the same for configs[2] (MUTAG-shaped, D = 256,
+    sum, 3 layers) and configs[3] (AM-shaped: 372 584 entities, D = 128, max) at their full shapes."""
     from mpqe_amd import synthetic
     from mpqe_amd.fused import FusedTrainStep
     from oracle import ref_cpu
-    schema, node_maps, model = build('aifb', 128, 'mp', True)
+    schema, node_maps, model = build(kg, D, readout, adaptive)
     cpu_params = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
     model = model.to('cuda:0')
     rng = np.random.RandomState(1000)
@@ -170,6 +199,11 @@ def test_benchmarked_workload_against_oracle(flags):
         b = draw(schema, qt, 512, rng)
         b['weight'] = 1.0 if qt == '1-chain' else (BENCH_WEIGHTS['inter'] if 'inter' in qt else BENCH_WEIGHTS['chain'])
         batches.append(b)
+    cfg = dict(readout=readout, scatter_op='add', num_layers=3, adaptive=adaptive, weight_decay=0)
+    torch.set_num_threads(min(16, max(1, len(__import__('os').sched_getaffinity(0)))))
+    if readout == 'max':
+        batches, dropped = drop_near_ties(batches, cpu_params, cfg, node_maps, model)
+        assert dropped < 0.05 * 11 * 512, dropped       # (a handful of graphs, not a loophole)
     kw = dict(default={}, no_prune=dict(prune=False), no_uniform=dict(uniform=False), no_chain=dict(chain=False))[flags]
     step = FusedTrainStep(model, **kw)
     packed = step.pack(batches)
@@ -177,20 +211,19 @@ def test_benchmarked_workload_against_oracle(flags):
     loss, sp, sn = step.run(packed, scores=True)
     step.check()
     sp, sn, loss = sp.cpu().numpy(), sn.cpu().numpy(), loss.cpu().numpy()
-    cfg = dict(readout='mp', scatter_op='add', num_layers=3, adaptive=True, weight_decay=0)
-    torch.set_num_threads(min(16, max(1, len(__import__('os').sched_getaffinity(0)))))
+    starts = np.concatenate([[0], np.cumsum([len(batches[i]['targets']) for i in packed.order])])
     total = 0
     for i, b in enumerate(batches):
-        off = 512 * packed.order.index(i)           # scores come back in library batch order
-        queries = [type('Q', (), {'anchor_nodes': tuple(int(v) for v in row)})() for row in b['anchor_ids']]
-        col = ref_cpu.collate(b['formula'], queries, model.rel_ids, model.mode_ids)
+        k = packed.order.index(i)                   # scores come back in library batch order
+        off, n = int(starts[k]), len(b['targets'])
+        col = ref_cpu.collate(b['formula'], _queries(b), model.rel_ids, model.mode_ids)
         q = ref_cpu.encode_queries(cpu_params, cfg, node_maps, b['formula'], col)
         pos = ref_cpu.score(cpu_params, node_maps, b['formula'], q, b['targets'])
         neg = ref_cpu.score(cpu_params, node_maps, b['formula'], q, b['negs'])
-        np.testing.assert_allclose(sp[off:off + 512], pos.detach().numpy(), rtol=1e-5, atol=1e-6, err_msg='batch %d' % i)
-        np.testing.assert_allclose(sn[off:off + 512], neg.detach().numpy(), rtol=1e-5, atol=1e-6, err_msg='batch %d' % i)
+        np.testing.assert_allclose(sp[off:off + n], pos.detach().numpy(), rtol=1e-5, atol=1e-6, err_msg='batch %d' % i)
+        np.testing.assert_allclose(sn[off:off + n], neg.detach().numpy(), rtol=1e-5, atol=1e-6, err_msg='batch %d' % i)
         l = torch.clamp(1.0 - (pos - neg), min=0).mean()
-        np.testing.assert_allclose(loss[1 + packed.order.index(i)], l.item(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(loss[1 + k], l.item(), rtol=1e-5, atol=1e-6)
         total = total + b['weight'] * l
     np.testing.assert_allclose(loss[0], total.item(), rtol=1e-5, atol=1e-6)
     total.backward()
@@ -198,3 +231,43 @@ def test_benchmarked_workload_against_oracle(flags):
         ref = cpu_params[k].grad
         ref = torch.zeros_like(cpu_params[k]) if ref is None else ref
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.parametrize('qt', ['3-chain', '3-inter'])
+def test_stress_shape_against_oracle(qt):
+    """configs[4] (1M entities / 8 modes / 64 relation names, D = 256, sum, 3 layers): the oracle in the reference's op
+    sequence on a 96-graph batch of each of its two query types, on the full-size KG -- scores, loss, every gradient
+    (the entity tables' 1M x 256 included). The properties test above covers B = 8192."""
+    from mpqe_amd.fused import FusedTrainStep
+    from oracle import ref_cpu
+    schema, node_maps, model = build('stress', 256, 'sum', False)
+    cpu_params = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    model = model.to('cuda:0')
+    rng = np.random.RandomState(5)
+    b = draw(schema, qt, 96, rng)
+    b['anchor_ids'][:8] = b['anchor_ids'][8:16]           # entities that occur in several graphs
+    cfg = dict(readout='sum', scatter_op='add', num_layers=3, adaptive=False, weight_decay=0)
+    step = FusedTrainStep(model)
+    loss, sp, sn = step.run(step.pack([b]), scores=True)
+    step.check()
+    col = ref_cpu.collate(b['formula'], _queries(b), model.rel_ids, model.mode_ids)
+    q = ref_cpu.encode_queries(cpu_params, cfg, node_maps, b['formula'], col)
+    pos = ref_cpu.score(cpu_params, node_maps, b['formula'], q, b['targets'])
+    neg = ref_cpu.score(cpu_params, node_maps, b['formula'], q, b['negs'])
+    np.testing.assert_allclose(sp.cpu().numpy(), pos.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sn.cpu().numpy(), neg.detach().numpy(), rtol=1e-5, atol=1e-6)
+    ref_loss = torch.clamp(1.0 - (pos - neg), min=0).mean()
+    np.testing.assert_allclose(loss[0].item(), ref_loss.item(), rtol=1e-5, atol=1e-6)
+    ref_loss.backward()
+    for k, p in model.named_parameters():
+        ref = cpu_params[k].grad
+        if ref is None:
+            assert float(p.grad.abs().max()) == 0.0, k
+            continue
+        g = p.grad
+        if ref.shape[0] > 100000:                   # an entity table: compare the touched rows, the rest must be exactly zero
+            rows = torch.nonzero(ref.abs().sum(1) > 0).flatten()
+            np.testing.assert_allclose(g[rows.cuda()].cpu().numpy(), ref[rows].numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+            assert int((g.abs().sum(1) > 0).sum().item()) <= len(rows), k
+        else:
+            np.testing.assert_allclose(g.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-6, err_msg=k)

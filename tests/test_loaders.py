@@ -110,3 +110,18 @@ def test_loaded_graph_feeds_the_encoder_ids():
     assert list(mode_ids.keys()) == [k for k, _ in EXPECT['graph']['mode_weights']]
     assert len(rel_ids) == len(EXPECT['graph']['rel_edges'])
     assert [list(k) for k in rel_ids.keys()] == [k for k, _ in EXPECT['graph']['rel_edges']]
+
+
+def test_load_graph_rejects_ids_listed_twice(tmp_path):
+    """reference data_utils.py:27 asserts, id by id, that an entity is not mapped yet: an id under two modes fails there,
+    and so does an id repeated inside ONE mode's list."""
+    import pickle
+    import pytest
+    rels = {'a': [('b', 'r')], 'b': [('a', 'r')]}
+    for node_ids in ({'a': [0, 1, 2], 'b': [2, 3]}, {'a': [0, 1, 1], 'b': [2, 3]}):
+        d = tmp_path / ('g%d' % len(node_ids['a']) + str(node_ids['b'][0] == 2 and node_ids['a'][2]))
+        d.mkdir()
+        with open(d / 'graph_data.pkl', 'wb') as f:
+            pickle.dump((rels, {}, node_ids), f)
+        with pytest.raises(AssertionError):
+            data_utils.load_graph(str(d), 8)

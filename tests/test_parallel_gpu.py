@@ -55,3 +55,28 @@ def test_two_ranks_equal_single_process(tmp_path, sparse, tables):
         np.testing.assert_array_equal(r[0]['union_keys'], r[1]['union_keys'])
     assert r[0]['wire'][0] <= r[0]['dense'][0], (r[0]['wire'], r[0]['dense'])   # (tiny KG, 8 relations: most are in the union)
     assert str(r[0]['form'][0]) == str(r[1]['form'][0])
+
+
+def test_bench_gpus_flag_starts_its_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (a child torch.distributed.run,
+    before the parent touches the GPU) and report n_gpus = 2 with the exchange record; here over gloo, both ranks on the
+    one GPU of the box (RCCL refuses two ranks on one device)."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2',
+                        '--warmup', '1', '--repeats', '1', '--no-cpu-baseline', '--no-scatter'], env=env, cwd=root,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak'
+    assert d['config']['global_query_graphs_per_step'] == 2 * 11 * 512
+    assert 'exchange' in d and d['exchange']['bytes_per_rank_per_step'] > 0
+    assert 'exchange_note' not in d, d.get('exchange_note')        # the exchange equals the dense all-reduce
+    # more ranks than GPUs with the RCCL backend: a refusal, not a one-rank run that claims more
+    q = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '64', '--steps', '1', '--warmup', '0'],
+                       env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert q.returncode != 0 and b'n_gpus' not in q.stdout
