@@ -165,12 +165,30 @@ int mpqe_rgcn_general_fwd(const void *plan, int64_t num_nodes, int64_t num_edges
  * the self term of node i at row E + i). Algorithmic bytes: 4 dim (E + 2 Nn).                                    */
 int mpqe_rgcn_general_aggregate(const void *plan, int64_t num_nodes, int64_t num_edges, int64_t num_relations,
                                 const float *msg, const float *bias, int64_t dim, int relu, float *out, void *stream);
+/* overwrite = 0: grad_basis / grad_root / grad_bias are ACCUMULATED into (the caller zero-fills them); 1: every one of
+ * them is WRITTEN whole, once -- the gradient, or zeros for a relation without an edge -- so the caller neither fills
+ * [R, dim_in, dim_out] with zeros nor pays a read-modify-write of it (33 MB each at the stress shape). grad_x is always
+ * written.                                                                                              */
 int mpqe_rgcn_general_bwd(const void *plan, int64_t num_nodes, int64_t num_edges, int64_t num_relations,
                           const float *x, const float *out, const float *grad_out,
                           const float *basis, const float *root,
-                          int64_t dim_in, int64_t dim_out, int relu,
+                          int64_t dim_in, int64_t dim_out, int relu, int overwrite,
                           float *grad_x, float *grad_basis, float *grad_root, float *grad_bias,
                           void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- dense layer (the MLP readouts' nn.Linear, model.py:497-553; Encoder's compress product, encoders.py:120-124) ----
+ * y [rows, dim_out] = [relu]( (accumulate ? y : 0) + x [rows, dim_in] . W^T + bias ), W [dim_out, dim_in] as nn.Linear
+ * stores it, with row stride ldw >= dim_in (a column block of a wider matrix: the compress matrix applied to one
+ * neighbour block at a time, the products accumulated, so the reference's concatenation is never materialised).
+ * x, y, grad_y, grad_x contiguous. Backward: y = the layer's post-activation output (read only when relu != 0);
+ * grad_x is written; grad_W [dim_out, .] (row stride ldgw) and grad_bias are accumulated into, or written
+ * (overwrite = 1). Fixed-order reductions (no float atomics).                                              */
+int mpqe_linear_fwd(const float *x, int64_t rows, const float *W, int64_t ldw, const float *bias, int64_t dim_in,
+                    int64_t dim_out, int relu, int accumulate, float *y, void *stream);
+size_t mpqe_linear_bwd_workspace_bytes(int64_t rows, int64_t dim_in, int64_t dim_out);
+int mpqe_linear_bwd(const float *x, int64_t rows, const float *W, int64_t ldw, const float *y, const float *grad_y,
+                    int64_t dim_in, int64_t dim_out, int relu, int overwrite, float *grad_x, float *grad_W, int64_t ldgw,
+                    float *grad_bias, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- (a5) readouts ----------------------------------------------------------------------
  * Regular form for template batches (batch_idx = b repeated N):

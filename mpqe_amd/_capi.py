@@ -77,7 +77,10 @@ PROTOTYPES = {
     'mpqe_rgcn_general_workspace_bytes': (Z, [L, L, L, L, L, I]),
     'mpqe_rgcn_general_fwd': (I, [P, L, L, L, P, P, P, P, L, L, I, P, P, Z, P]),
     'mpqe_rgcn_general_aggregate': (I, [P, L, L, L, P, P, L, I, P, P]),
-    'mpqe_rgcn_general_bwd': (I, [P, L, L, L, P, P, P, P, P, L, L, I, P, P, P, P, P, Z, P]),
+    'mpqe_rgcn_general_bwd': (I, [P, L, L, L, P, P, P, P, P, L, L, I, I, P, P, P, P, P, Z, P]),
+    'mpqe_linear_fwd': (I, [P, L, P, L, P, L, L, I, I, P, P]),
+    'mpqe_linear_bwd_workspace_bytes': (Z, [L, L, L]),
+    'mpqe_linear_bwd': (I, [P, L, P, L, P, P, L, L, I, I, P, P, L, P, P, Z, P]),
     'mpqe_readout_fwd': (I, [I, P, L, L, L, L, P, P, P]),
     'mpqe_readout_bwd': (I, [I, P, P, L, L, L, L, P, P]),
     'mpqe_scatter_workspace_bytes': (Z, [L, L]),

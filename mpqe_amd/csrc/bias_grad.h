@@ -40,7 +40,7 @@ static __global__ __launch_bounds__(256) void bias_partial_kernel(long long rows
 // then the 16 sums are added in order -- a fixed order. (The first form walked the <= 256 partial rows with 4 row groups
 // and one dependent load per step: 118 us per call at the stress shape; this one takes one or two round trips.)
 static __global__ __launch_bounds__(1024) void bias_final_kernel(int nblk, int Dout, const float *__restrict__ partial,
-                                                                 float *__restrict__ grad_bias) {
+                                                                 float *__restrict__ grad_bias, int overwrite) {
     __shared__ float part[16][64];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + cl;
@@ -62,7 +62,7 @@ static __global__ __launch_bounds__(1024) void bias_final_kernel(int nblk, int D
     if (rg == 0 && col < Dout) {
         float t = part[0][cl];
         for (int q = 1; q < 16; ++q) t += part[q][cl];
-        grad_bias[col] += t;
+        grad_bias[col] = overwrite ? t : grad_bias[col] + t;
     }
 }
 
@@ -71,10 +71,10 @@ static inline size_t bias_partial_bytes(long long rows, long long Dout) {
 }
 
 static inline void launch_bias_grad(long long rows, const float *g, const float *out, int Dout, int relu,
-                                    float *partial, float *grad_bias, hipStream_t s) {
+                                    float *partial, float *grad_bias, hipStream_t s, int overwrite = 0) {
     const int rpb = bias_rows_per_block(rows), nblk = bias_num_blocks(rows);
     hipLaunchKernelGGL(bias_partial_kernel, dim3(nblk, (unsigned)((Dout + 63) / 64)), dim3(256), 0, s, rows, rpb, g,
                        out, Dout, relu, partial);
     hipLaunchKernelGGL(bias_final_kernel, dim3((unsigned)((Dout + 63) / 64)), dim3(1024), 0, s, nblk, Dout, partial,
-                       grad_bias);
+                       grad_bias, overwrite);
 }

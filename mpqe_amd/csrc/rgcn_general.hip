@@ -851,17 +851,25 @@ __global__ __launch_bounds__(256) void rgcn_gen_grad_w_rows_kernel(
 __global__ __launch_bounds__(256) void rgcn_gen_reduce_w_kernel(const int *__restrict__ chunk_ptr, int R, int Din,
                                                                 int Dout, const float *__restrict__ slabs,
                                                                 float *__restrict__ grad_basis,
-                                                                float *__restrict__ grad_root) {
+                                                                float *__restrict__ grad_root, int overwrite) {
+    // overwrite: every gradient matrix is WRITTEN, once -- the sum of its slabs, or zeros for a relation without an edge:
+    // no zero fill in front of the call and no read-modify-write (accumulate mode reads and rewrites every touched matrix
+    // behind a 33 MB fill at the stress shape)
     __shared__ f32x4 part[4][64];
     const int r = blockIdx.y;
     const long long elems = (long long)Din * Dout;
     const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const long long idx = ((long long)blockIdx.x * 64 + el) * 4;
     const int c0 = chunk_ptr[r], c1 = chunk_ptr[r + 1];
-    if (c0 == c1) return;               // (uniform over the workgroup)
     float *dst = r < R ? grad_basis : grad_root;
     if (!dst) return;
     if (r < R) dst += (long long)r * elems;
+    if (c0 == c1) {                     // (uniform over the workgroup)
+        if (overwrite && sg == 0)
+            for (int k = 0; k < 4; ++k)
+                if (idx + k < elems) dst[idx + k] = 0.f;
+        return;
+    }
     const bool vec = (elems % 4 == 0) && (((uintptr_t)slabs | (uintptr_t)dst) % 16 == 0);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     const int count = c1 - c0;
@@ -887,7 +895,10 @@ __global__ __launch_bounds__(256) void rgcn_gen_reduce_w_kernel(const int *__res
     if (sg != 0 || idx >= elems) return;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        if (idx + k < elems) dst[idx + k] += (part[0][el][k] + part[1][el][k]) + (part[2][el][k] + part[3][el][k]);
+        if (idx + k < elems) {
+            const float t = (part[0][el][k] + part[1][el][k]) + (part[2][el][k] + part[3][el][k]);
+            dst[idx + k] = overwrite ? t : dst[idx + k] + t;
+        }
 }
 
 // ------------------------------------------------------------------------------------ host side
@@ -960,11 +971,18 @@ extern "C" int mpqe_rgcn_general_aggregate(const void *plan, int64_t Nn, int64_t
 
 extern "C" int mpqe_rgcn_general_bwd(const void *plan, int64_t Nn, int64_t E, int64_t R, const float *x,
                                      const float *out, const float *grad_out, const float *basis, const float *root,
-                                     int64_t Din, int64_t Dout, int relu, float *grad_x, float *grad_basis,
+                                     int64_t Din, int64_t Dout, int relu, int overwrite, float *grad_x, float *grad_basis,
                                      float *grad_root, float *grad_bias, void *workspace, size_t workspace_bytes,
                                      void *stream) {
     if (!plan || Nn < 0 || E < 0 || R < 0 || Din <= 0 || Dout <= 0) return MPQE_ERR_INVALID_ARG;
-    if (Nn == 0) return MPQE_OK;
+    if (Nn == 0) {
+        if (overwrite) {
+            if (grad_basis && R > 0) (void)hipMemsetAsync(grad_basis, 0, (size_t)R * Din * Dout * 4, as_stream(stream));
+            if (grad_root) (void)hipMemsetAsync(grad_root, 0, (size_t)Din * Dout * 4, as_stream(stream));
+            if (grad_bias) (void)hipMemsetAsync(grad_bias, 0, (size_t)Dout * 4, as_stream(stream));
+        }
+        return MPQE_OK;
+    }
     if (!x || !grad_out || !root || (R > 0 && !basis) || (relu && !out)) return MPQE_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < mpqe_rgcn_general_workspace_bytes(Nn, E, R, Din, Dout, 1))
         return MPQE_ERR_WORKSPACE;
@@ -1023,8 +1041,8 @@ extern "C" int mpqe_rgcn_general_bwd(const void *plan, int64_t Nn, int64_t E, in
         const long long elems = (long long)Din * Dout;
         dim3 rgrid((unsigned)((elems + 255) / 256), (unsigned)(R + 1));
         hipLaunchKernelGGL(rgcn_gen_reduce_w_kernel, rgrid, dim3(256), 0, s, P.chunk_ptr, (int)R, (int)Din,
-                           (int)Dout, (const float *)slabs, grad_basis, grad_root);
+                           (int)Dout, (const float *)slabs, grad_basis, grad_root, overwrite);
     }
-    if (grad_bias) launch_bias_grad((long long)Nn, grad_out, mask, (int)Dout, relu, bias_part, grad_bias, s);
+    if (grad_bias) launch_bias_grad((long long)Nn, grad_out, mask, (int)Dout, relu, bias_part, grad_bias, s, overwrite);
     return mpqe_launch_status();
 }

@@ -92,8 +92,8 @@ class Encoder(nn.Module):
     `<mode>_ln.gamma|beta`, `feat-<name>.*`) are the reference's; the data path is this package's:
       * ONE flat list of sampled neighbours per relation goes through the features closure and the scatter kernel
         (mean mode) -- no dense [B, U] mask matrix, no per-node python set arithmetic on the device side;
-      * the concatenation is never materialised: compress_m is applied block by block (one library GEMM per relation
-        block and one for the self block, accumulated), which is the same sum;
+      * the concatenation is never materialised: compress_m is applied block by block (one mpqe_linear_fwd per relation
+        block and one for the self block, accumulating), which is the same sum;
       * LayerNorm and the ReLU are one kernel (mpqe_layernorm_relu_fwd).
     `nodes` is a python list of entity ids (the GQE call protocol; see SURVEY.md section 2 #5)."""
 
@@ -127,18 +127,17 @@ class Encoder(nn.Module):
     def forward(self, nodes, mode, keep_prob=0.5, max_keep=10):
         W = self.compress_params[mode]
         blocks = self.blocks[mode]
-        out = None
+        feats = []
         for (to_mode, name), (off, width) in zip(self.relations[mode], blocks[:-1]):
             rel = (mode, name, to_mode)
             adj = self.adj_lists[rel]
             # the null neighbour -1 stands in for a padding node and for a node without edges of this relation
             neigh = [[-1] if (n == -1 or len(adj[n]) == 0) else adj[n] for n in nodes]
-            mean = self.aggregator.forward(neigh, rel, keep_prob, max_keep)                 # [B, width]
-            part = mean @ W[:, off:off + width].t()
-            out = part if out is None else out + part
-        off, width = blocks[-1]
-        part = self.features(nodes, mode) @ W[:, off:off + width].t()
-        out = part if out is None else out + part
+            feats.append(self.aggregator.forward(neigh, rel, keep_prob, max_keep).contiguous())    # [B, width]
+        feats.append(self.features(nodes, mode).contiguous())
+        # compress_m applied block by block on the library's own MFMA tiles (mpqe_linear_fwd, accumulating): the column
+        # blocks of W are read in place, the concatenation of the reference (encoders.py:120) is never built
+        out = ops.blocks_linear(feats, W, blocks)
         if self.layer_norm:
             out = self.lns[mode](out, relu=True)
         else:

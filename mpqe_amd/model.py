@@ -277,9 +277,16 @@ class RGCNEncoderDecoder(nn.Module):
         return loss
 
 
+def _mlp(layers, x):
+    """nn.Sequential(Linear, ReLU, Linear) of the readouts through ops.linear."""
+    h = ops.linear(x.contiguous(), layers[0].weight, layers[0].bias, relu=True)
+    return ops.linear(h, layers[2].weight, layers[2].bias)
+
+
 class MLPReadout(nn.Module):
-    """reference: model.py:497-515. Linear-ReLU-Linear per node (rocBLAS GEMMs through
-    nn.Linear -- a plain library GEMM), then the scatter reduction kernel."""
+    """reference: model.py:497-515. Linear-ReLU-Linear per node, then the scatter reduction kernel. The nn.Linear
+    modules hold the parameters (state_dict keys layers.0 / layers.2, the reference's init); the arithmetic runs on the
+    library's own MFMA tiles (ops.linear: mpqe_linear_fwd / bwd, the ReLU fused into the first product's epilogue)."""
 
     def __init__(self, input_dim, output_dim, scatter_fn):
         super(MLPReadout, self).__init__()
@@ -289,7 +296,7 @@ class MLPReadout(nn.Module):
         self.scatter_fn = scatter_fn
 
     def forward(self, embs, batch_idx, batch_size=None, **kwargs):
-        x = self.layers(embs)
+        x = _mlp(self.layers, embs)
         x = self.scatter_fn(x, batch_idx, dim=0, dim_size=batch_size)
         if isinstance(x, tuple):
             x = x[0]
@@ -314,7 +321,7 @@ class TargetMLPReadout(nn.Module):
         targets = embs[:, num_anchors:num_anchors + 1].expand_as(non_targets)
         x = torch.cat((targets, non_targets), dim=-1)
         x = x.reshape(batch_size * (num_nodes - 1), -1).contiguous()
-        x = self.layers(x)
+        x = _mlp(self.layers, x)
         x = self.scatter_fn(x, batch_idx, dim=0, dim_size=batch_size)
         if isinstance(x, tuple):
             x = x[0]

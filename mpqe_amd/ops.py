@@ -172,9 +172,12 @@ class _RGCNLayer(torch.autograd.Function):
         L = lib()
         need_x, need_b, need_r, need_bias = ctx.needs_input_grad[:4]
         gx = torch.empty_like(x) if need_x else None
-        gb = torch.zeros_like(basis) if need_b else None
-        gr = torch.zeros_like(root) if need_r else None
-        gbias = torch.zeros(Dout, dtype=torch.float32, device=x.device) if (need_bias and ctx.has_bias) else None
+        general = not isinstance(graph, Template)
+        # (general graphs: the call writes every gradient buffer whole -- no zero fill, no read-modify-write)
+        gb = (torch.empty_like(basis) if general else torch.zeros_like(basis)) if need_b else None
+        gr = (torch.empty_like(root) if general else torch.zeros_like(root)) if need_r else None
+        gbias = ((torch.empty if general else torch.zeros)(Dout, dtype=torch.float32, device=x.device)
+                 if (need_bias and ctx.has_bias) else None)
         with torch.cuda.device(x.device):
             if isinstance(graph, Template):
                 wb = L.mpqe_rgcn_template_bwd_workspace_bytes(graph.qid, graph.B, Din, Dout)
@@ -186,7 +189,7 @@ class _RGCNLayer(torch.autograd.Function):
                 wb = L.mpqe_rgcn_general_workspace_bytes(graph.Nn, graph.E, R, Din, Dout, 1)
                 ws = _ws(wb, x.device)
                 _ck(L.mpqe_rgcn_general_bwd(_p(graph.buf), graph.Nn, graph.E, R, _p(x), _p(out), _p(g), _p(basis),
-                                            _p(root), Din, Dout, int(relu), _p(gx), _p(gb), _p(gr), _p(gbias),
+                                            _p(root), Din, Dout, int(relu), 1, _p(gx), _p(gb), _p(gr), _p(gbias),
                                             _p(ws), wb, _stream()), 'mpqe_rgcn_general_bwd')
         return gx, gb, gr, gbias, None, None
 
@@ -194,6 +197,75 @@ class _RGCNLayer(torch.autograd.Function):
 def rgcn_layer(x, basis, root, bias, graph, relu=False):
     """out = [relu](sum_e x[src_e].basis[type_e] + x.root + bias); graph is a Template or a GraphPlan."""
     return _RGCNLayer.apply(x, basis, root, bias, graph, relu)
+
+
+# --------------------------------------------------------------------------------------------- dense layer
+class _Linear(torch.autograd.Function):
+    """y = [relu](sum_k x_k . W[:, off_k : off_k + w_k]^T + bias): nn.Linear's arithmetic on the library's own MFMA tiles
+    (mpqe_linear_fwd / mpqe_linear_bwd). One block = a plain dense layer; several = one wide matrix applied block by
+    block to inputs that are never concatenated (Encoder.forward's compress product, reference encoders.py:120-124);
+    the column blocks of W -- and of its gradient -- are read and written in place through the row stride."""
+
+    @staticmethod
+    def forward(ctx, W, bias, relu, blocks, *xs):
+        W = _f(W, 'weight')
+        xs = [_f(x, 'x') for x in xs]
+        bias = None if bias is None else _f(bias, 'bias')
+        if W.dim() != 2 or len(xs) != len(blocks) or not xs:
+            raise ValueError('one column block of the weight per input')
+        dout, total = W.shape
+        rows = xs[0].shape[0]
+        for x, (off, width) in zip(xs, blocks):
+            if x.dim() != 2 or x.shape[0] != rows or x.shape[1] != width or off < 0 or off + width > total:
+                raise ValueError('shape mismatch: x %s, weight block [%d, %d:%d]' % (tuple(x.shape), dout, off, off + width))
+        y = torch.empty((rows, dout), dtype=torch.float32, device=W.device)
+        L = lib()
+        with torch.cuda.device(y.device):
+            for k, (x, (off, width)) in enumerate(zip(xs, blocks)):
+                last = k == len(xs) - 1
+                _ck(L.mpqe_linear_fwd(_p(x), rows, W.data_ptr() + 4 * off, total, _p(bias) if last else None, width, dout,
+                                      int(bool(relu) and last), int(k > 0), _p(y), _stream()), 'mpqe_linear_fwd')
+        ctx.relu, ctx.blocks, ctx.has_bias = bool(relu), list(blocks), bias is not None
+        ctx.save_for_backward(W, y if relu else None, *xs)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        W, y = ctx.saved_tensors[:2]
+        xs = ctx.saved_tensors[2:]
+        g = _f(g, 'grad_out')
+        rows, dout = g.shape
+        total = W.shape[1]
+        L = lib()
+        need_w, need_bias = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and ctx.has_bias
+        pos, covered = 0, True
+        for o, w in sorted(ctx.blocks):
+            covered, pos = covered and o == pos, o + w
+        covered = covered and pos == total
+        gW = ((torch.empty_like(W) if covered else torch.zeros_like(W)) if need_w else None)    # (blocks that tile W: written whole)
+        gbias = torch.empty(dout, dtype=torch.float32, device=g.device) if need_bias else None
+        gxs = []
+        with torch.cuda.device(g.device):
+            for k, (x, (off, width)) in enumerate(zip(xs, ctx.blocks)):
+                gx = torch.empty_like(x) if ctx.needs_input_grad[4 + k] else None
+                wb = L.mpqe_linear_bwd_workspace_bytes(rows, width, dout)
+                ws = _ws(wb, g.device)
+                _ck(L.mpqe_linear_bwd(_p(x), rows, W.data_ptr() + 4 * off, total, _p(y), _p(g), width, dout, int(ctx.relu), 1,
+                                      _p(gx), None if gW is None else gW.data_ptr() + 4 * off, total,
+                                      _p(gbias) if k == 0 else None, _p(ws), wb, _stream()), 'mpqe_linear_bwd')
+                gxs.append(gx)
+        return (gW, gbias, None, None) + tuple(gxs)
+
+
+def linear(x, weight, bias=None, relu=False):
+    """[relu](x . weight^T + bias), weight [out, in] as nn.Linear stores it."""
+    return _Linear.apply(weight, bias, relu, [(0, weight.shape[1])], x)
+
+
+def blocks_linear(xs, weight, blocks, bias=None, relu=False):
+    """[relu](sum_k xs[k] . weight[:, off_k : off_k + w_k]^T + bias), blocks = [(off_k, w_k)]: one wide matrix applied block
+    by block, the inputs never concatenated."""
+    return _Linear.apply(weight, bias, relu, list(blocks), *xs)
 
 
 # --------------------------------------------------------------------------------------------- embeddings

@@ -153,10 +153,23 @@ def run_general(be, x, ei, et, basis, root, bias, relu, gout, Nn):
     wb = be.lib.mpqe_rgcn_general_workspace_bytes(Nn, E, R, Din, Dout, 1)
     ws2 = be.nbytes(wb)
     gx = be.empty((Nn, Din))
+    # overwrite mode (what the host mirror uses): the gradient buffers arrive as garbage and are written whole, a relation
+    # without an edge as zeros; accumulate mode on top of a known content gives content + gradient
     gb, gr, gbi = be.zeros(basis.shape), be.zeros(root.shape), be.zeros(bias.shape)
+    for t in (gb, gr, gbi):
+        t.fill(np.nan) if be.name == 'emu' else t.fill_(float('nan'))
     be.check(be.lib.mpqe_rgcn_general_bwd(be.ptr(plan), Nn, E, R, be.ptr(dx), be.ptr(out), be.ptr(dg), be.ptr(db),
-                                          be.ptr(dr), Din, Dout, relu, be.ptr(gx), be.ptr(gb), be.ptr(gr),
+                                          be.ptr(dr), Din, Dout, relu, 1, be.ptr(gx), be.ptr(gb), be.ptr(gr),
                                           be.ptr(gbi), be.ptr(ws2), wb, be.stream), 'bwd')
+    ab, ar, abi = be.zeros(basis.shape), be.zeros(root.shape), be.zeros(bias.shape)
+    for t in (ab, ar, abi):
+        t.fill(0.5) if be.name == 'emu' else t.fill_(0.5)
+    gx2 = be.empty((Nn, Din))
+    be.check(be.lib.mpqe_rgcn_general_bwd(be.ptr(plan), Nn, E, R, be.ptr(dx), be.ptr(out), be.ptr(dg), be.ptr(db),
+                                          be.ptr(dr), Din, Dout, relu, 0, be.ptr(gx2), be.ptr(ab), be.ptr(ar),
+                                          be.ptr(abi), be.ptr(ws2), wb, be.stream), 'bwd (accumulate)')
+    for acc, wr in ((ab, gb), (ar, gr), (abi, gbi)):
+        np.testing.assert_allclose(np.asarray(be.get(acc)), np.asarray(be.get(wr)) + 0.5, rtol=1e-6, atol=1e-6)
     return [be.get(a) for a in (out, gx, gb, gr, gbi)], int(be.get(err)[0])
 
 
@@ -572,3 +585,50 @@ def test_layernorm_relu_matches_reference_formula(be, rows, D, relu):
     close(be.get(gx), xt.grad.numpy(), rtol=1e-4, what='grad_x')
     close(be.get(gg), gt.grad.numpy(), rtol=1e-4, what='grad_gamma')
     close(be.get(gb), bt.grad.numpy(), rtol=1e-4, what='grad_beta')
+
+
+@pytest.mark.parametrize('rows,din,dout,pad,relu', [(70, 48, 20, 0, 1), (256, 128, 128, 0, 1), (256, 128, 128, 64, 0),
+                                                   (33, 50, 130, 6, 1), (192, 64, 64, 128, 1)])
+def test_dense_layer_matches_nn_linear(be, rows, din, dout, pad, relu):
+    """mpqe_linear_fwd / bwd (the MLP readouts' nn.Linear, Encoder's compress blocks) against torch on the CPU:
+    y = [relu](y0 + x W^T + b) with W a column block (row stride din + pad) of a wider matrix; grad_x, grad_W (written
+    into the same column block), grad_bias; overwrite and accumulate modes; dims on and off the 64-wide fast path."""
+    import torch
+    rng = np.random.RandomState(rows + din)
+    ld = din + pad
+    x = rng.randn(rows, din).astype(np.float32)
+    Wfull = (rng.randn(dout, ld) * 0.2).astype(np.float32)
+    bias = rng.randn(dout).astype(np.float32)
+    y0 = rng.randn(rows, dout).astype(np.float32)
+    g = rng.randn(rows, dout).astype(np.float32)
+    off = pad // 2
+    tx = torch.tensor(x, requires_grad=True)
+    tW = torch.tensor(Wfull, requires_grad=True)
+    tb = torch.tensor(bias, requires_grad=True)
+    ty = torch.tensor(y0) + tx @ tW[:, off:off + din].t() + tb
+    if relu:
+        ty = torch.relu(ty)
+    ty.backward(torch.tensor(g))
+    dx, dW, db, dy, dg = be.put(x), be.put(Wfull), be.put(bias), be.put(y0), be.put(g)
+    be.check(be.lib.mpqe_linear_fwd(be.ptr(dx), rows, be.ptr(dW) + 4 * off, ld, be.ptr(db), din, dout, relu, 1, be.ptr(dy),
+                                    be.stream), 'linear fwd')
+    close(np.asarray(be.get(dy)), ty.detach().numpy(), rtol=1e-5, what='y')
+    wb = be.lib.mpqe_linear_bwd_workspace_bytes(rows, din, dout)
+    ws = be.nbytes(wb)
+    gx, gW, gb = be.empty((rows, din)), be.zeros((dout, ld)), be.empty((dout,))
+    for t, v in ((gW, 0.25), (gb, np.nan)):
+        t.fill(v) if be.name == 'emu' else t.fill_(float(v))
+    be.check(be.lib.mpqe_linear_bwd(be.ptr(dx), rows, be.ptr(dW) + 4 * off, ld, be.ptr(dy), be.ptr(dg), din, dout, relu, 1,
+                                    be.ptr(gx), be.ptr(gW) + 4 * off, ld, be.ptr(gb), be.ptr(ws), wb, be.stream), 'linear bwd')
+    close(np.asarray(be.get(gx)), tx.grad.numpy(), rtol=1e-4, what='grad_x')
+    got_W = np.asarray(be.get(gW))
+    close(got_W[:, off:off + din], tW.grad.numpy()[:, off:off + din], rtol=1e-4, what='grad_W')
+    mask = np.ones(ld, bool)
+    mask[off:off + din] = False
+    assert (got_W[:, mask] == 0.25).all()                  # the other column blocks are not touched
+    close(np.asarray(be.get(gb)), tb.grad.numpy(), rtol=1e-4, what='grad_bias')
+    # accumulate mode: on top of what is there
+    be.check(be.lib.mpqe_linear_bwd(be.ptr(dx), rows, be.ptr(dW) + 4 * off, ld, be.ptr(dy), be.ptr(dg), din, dout, relu, 0,
+                                    None, be.ptr(gW) + 4 * off, ld, be.ptr(gb), be.ptr(ws), wb, be.stream), 'linear bwd +=')
+    close(np.asarray(be.get(gW))[:, off:off + din], 2 * tW.grad.numpy()[:, off:off + din], rtol=1e-4, what='grad_W x2')
+    close(np.asarray(be.get(gb)), 2 * tb.grad.numpy(), rtol=1e-4, what='grad_bias x2')
