@@ -22,7 +22,8 @@
 #define GWR_PF 8            // loads in flight per wave, in iterations (16 graphs of the workgroup = 4 of the wave)
 #endif
 #define GWR_LDT 68          // row stride of an LDS tile (floats)
-#define GWR_SMEM_FLOATS (4 * 64 * GWR_LDT)          // one tile per wave (LDS_TILES = 4; 1: the waves take turns on one)
+#define GWR_SMEM_FLOATS (4 * 64 * GWR_LDT)          // one tile per wave (LDS_TILES = 4; 1: the waves take turns on one;
+#define GWR_SMEM_FLOATS2 (2 * 64 * GWR_LDT)         // 2: waves 2, 3 add theirs onto the tiles of waves 0, 1 -- 34 KB)
 
 // a value every lane of the wave holds, moved to SGPRs (the tile's record arrives through a vector load: hipcc cannot know)
 __device__ __forceinline__ long long gwr_uniform(long long v) {
@@ -42,7 +43,9 @@ template <int LDS_TILES = 4, int NJ = 4>
 __device__ __forceinline__ void grad_w_tile_rows(const float *__restrict__ x, const float *__restrict__ g, int D,
                                                  long long xs, long long xo, long long go, long long q0, long long q1,
                                                  int i0, int j0, float *__restrict__ dst, float *smem, bool accumulate,
-                                                 long long *dbg = nullptr) {
+                                                 long long *dbg = nullptr, bool through = false) {
+    // through: the tile is a slab that workgroups of the SAME launch read (fused tail, step.hip): written through to memory
+    // at agent scope instead of left dirty in this XCD's L2
 #ifndef MPQE_EMU
 #define GWR_STAMP(slot, wait)                                 \
     if (dbg && threadIdx.x == 0) {                            \
@@ -142,6 +145,24 @@ __device__ __forceinline__ void grad_w_tile_rows(const float *__restrict__ x, co
                 *reinterpret_cast<bvec *>(mine + (4 * (4 * kq + r) + m) * GWR_LDT + NJ * pos) = v;
             }
         __syncthreads();
+    } else if constexpr (LDS_TILES == 2) {      // two tiles: waves 0, 1 store, waves 2, 3 add onto them -- (w0 + w2) + (w1 + w3)
+        float *mine = smem + (wave & 1) * (64 * GWR_LDT);
+        for (int half = 0; half < 2; ++half) {
+            if ((wave >> 1) == half) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        bvec *t = reinterpret_cast<bvec *>(mine + (4 * (4 * kq + r) + m) * GWR_LDT + NJ * pos);
+                        bvec v;
+#pragma unroll
+                        for (int n = 0; n < NJ; ++n) v[n] = acc[m][n][r];
+                        if (half) v += *t;
+                        *t = v;
+                    }
+            }
+            __syncthreads();
+        }
     } else {                            // (a workgroup with less LDS: one tile, the waves add theirs one after the other)
         for (int w = 0; w < 4; ++w) {
             if (wave == w) {
@@ -169,9 +190,21 @@ __device__ __forceinline__ void grad_w_tile_rows(const float *__restrict__ x, co
         if constexpr (LDS_TILES == 4) {
 #pragma unroll
             for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4 *>(t0 + w * (64 * GWR_LDT));
+        } else if constexpr (LDS_TILES == 2) {
+            v += *reinterpret_cast<const f32x4 *>(t0 + 64 * GWR_LDT);
         }
         f32x4 *o = reinterpret_cast<f32x4 *>(dst + (long long)(i0 + row) * D + j0 + 4 * c4);
         if (accumulate) v += *o;
+#ifndef MPQE_EMU
+        if (through) {
+            unsigned long long *o8 = reinterpret_cast<unsigned long long *>(o);
+            __hip_atomic_store(o8, (unsigned long long)__float_as_uint(v[0]) | ((unsigned long long)__float_as_uint(v[1]) << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(o8 + 1, (unsigned long long)__float_as_uint(v[2]) | ((unsigned long long)__float_as_uint(v[3]) << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+#endif
         *o = v;
     }
 }

@@ -179,7 +179,8 @@ struct UOp {
     int u_vec[UOP_MAX_TERMS];          // R1
     int r1_layer, r1_rel;
     unsigned wait_mask;                // merged launch: bit b = the op reads rows the chain workgroups of batch b write
-    int pad;
+    int through;                       // fused tail: the op's output is read by the reduction (a rank-1 term's v, a row of
+                                       // `parts`): written through, so that the same launch's reduction workgroups see it
 };
 
 struct Blob {
@@ -277,6 +278,7 @@ struct PrepArgs {
     int sna;                  // launch runs on XCD b % 8): the first sblocks = 8 x rows workgroups of the launch are ROWS of
     unsigned sxrank;          // eight -- the sort's XCDs take sort workgroups, the others go on with the prologue's items
     int strail;               // != 0: the launch's LAST strail workgroups instead (diagnostics switch TSORT_TRAIL)
+    unsigned *tail_arrive;    // fused tail: the arrival counter of the step's weight-gradient launch, zeroed here; or NULL
     int ublocks, tblocks;     // vector-op workgroups, transpose workgroups
     int lead;                 // prologue workgroups in front of the chain workgroups: sblocks + ublocks + tblocks rounded
                               // up to a multiple of 8 (chain workgroup b keeps XCD b % 8)
@@ -404,6 +406,7 @@ __global__ __launch_bounds__(64 * NW) void step_chain_kernel(const StepDev *__re
     // role of this workgroup (uniform): chain workgroup, prologue work in front of / behind them, zero fill, then the
     // post roles: a producer is never queued behind a consumer that waits for it
     int bid = (int)blockIdx.x, role;
+    if (bid == 0 && threadIdx.x == 0 && pa.tail_arrive) *pa.tail_arrive = 0u;       // (read by the NEXT launch)
     if (pa.strail && bid >= (int)gridDim.x - pa.strail) {
         if (NW == 4 || threadIdx.x < TSORT_THREADS) tsort_block(pa.ts, bid - ((int)gridDim.x - pa.strail), reinterpret_cast<unsigned *>(S.xs));
         return;
@@ -793,7 +796,7 @@ __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, con
                                              long long level_stride, float *__restrict__ slabs, int bid,
                                              int wblocks_total, float *smem, const GradPtrs &gp, bool zeroed,
                                              long long *dbg, int D, const PostArgs *po = nullptr, int tile_n = GT_BN,
-                                             int nxcd = 8) {
+                                             int nxcd = 8, bool through = false) {
     const int tiles_j = (D + tile_n - 1) / tile_n, tiles = tiles_j * ((D + GT_BM - 1) / GT_BM);
     // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2: blocks b and b+8 share
     // one. The `tiles` output tiles of a K-chunk read the SAME rows of H and gH (different column
@@ -834,8 +837,9 @@ __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, con
         }
     }
     if constexpr (MODE == LD_T) {      // chain form (D % 64 == 0, 16-byte aligned rows): register-only K loop
-        if (tile_n == 32) grad_w_tile_rows<LDS_TILES, 2>(x, g, D, xs, xo, go, q0, q1, wk.i0, wk.j0, dst, smem, direct && !zeroed, dbg);
-        else grad_w_tile_rows<LDS_TILES, 4>(x, g, D, xs, xo, go, q0, q1, wk.i0, wk.j0, dst, smem, direct && !zeroed, dbg);
+        // (through: a slab of the fused tail is read by the reduction workgroups of the same launch)
+        if (tile_n == 32) grad_w_tile_rows<LDS_TILES, 2>(x, g, D, xs, xo, go, q0, q1, wk.i0, wk.j0, dst, smem, direct && !zeroed, dbg, through && !direct);
+        else grad_w_tile_rows<LDS_TILES, 4>(x, g, D, xs, xo, go, q0, q1, wk.i0, wk.j0, dst, smem, direct && !zeroed, dbg, through && !direct);
         (void)gs; (void)out;
     } else if constexpr (MODE == LD_FAST)      // whole K-steps, D % 64 == 0: deep LDS-DMA pipeline
         // (a form with NO LDS -- every MFMA operand one coalesced global_load_dword into its register, four
@@ -932,6 +936,226 @@ __device__ __forceinline__ void anchor_bwd_block(const StepDev *__restrict__ sd,
 // Backward tail: weight-gradient tiles, bias / variable-row partial sums and anchor-table gradients
 // all depend only on H and gH and write disjoint outputs, so they share ONE launch (a role per block
 // range, heavy MFMA tiles first) instead of three half-empty ones.
+// out += sum of the group's slabs / partial rows. A workgroup owns 256 consecutive elements (4 per
+// lane, 16-byte loads); its 4 waves each add every 4th slab (two loads in flight), the four sums
+// are combined as (0+1)+(2+3): a fixed order. (A one-thread-per-16-elements variant that walked all
+// slabs serially measured 2.5x slower: the 40-slab root group became the long pole.)
+struct ReduceArgs {
+    const RGroup *groups;
+    int ngroups, D;
+    GradPtrs gp;
+    const float *slabs, *partial;
+    int vec, zeroed;
+    const StepDev *sd;
+    const float *terms;
+    float *loss;
+    LossMeta lm;
+    const float *bterms;
+    const Rank1 *rank1;
+    const float *VT;
+    unsigned *epoch_b;
+    const char *touch;
+    size_t touch_keys, touch_perm;
+    const float *DG;
+    TablePtrs tabs;
+    int table_store;
+    long long touch_M;
+    int touch_row_bits;
+    int32_t *err;
+    // fused tail (the reduction as trailing workgroups of the weight-gradient launch): the groups and the loss workgroup
+    // wait until `arrive` has counted the launch's `phase1` tile and vector-op workgroups; NULL: a launch of its own
+    const unsigned *arrive;
+    unsigned phase1;
+};
+// workgroup (bx, by) of the reduction: by < ngroups: 256 elements of group by (gx workgroups along x); by == ngroups: the
+// loss (bx 0); beyond: entity-table rows
+__device__ __forceinline__ void reduce_block(const ReduceArgs &ra, int bx, int by, int gx, f32x4 (*part)[64]) {
+    const RGroup *__restrict__ groups = ra.groups;
+    const int ngroups = ra.ngroups, D = ra.D, vec = ra.vec, zeroed = ra.zeroed, table_store = ra.table_store;
+    const GradPtrs &gp = ra.gp;
+    const float *__restrict__ slabs = ra.slabs, *__restrict__ partial = ra.partial, *__restrict__ VT = ra.VT;
+    const Rank1 *__restrict__ rank1 = ra.rank1;
+    unsigned *epoch_b = ra.epoch_b;
+    const char *__restrict__ touch = ra.touch;
+    // zeroed: this call zero-filled the gradients, so `out` is known to be 0 -- a store replaces the
+    // read-modify-write (whose read would be one more dependent round trip at the end of the chain)
+    if (by > ngroups) {        // further rows: entity-table gradients, per destination row (step_touch.h).
+        // (As workgroups of the weight-gradient launch they are throttled to two per CU by its 64 KB of LDS: 23.6 us
+        // for that launch instead of 16.6; here they cost 2.6 us.)
+        table_sum_block(ra.touch_M, ra.touch_row_bits, reinterpret_cast<const tkey_t *>(touch + ra.touch_keys),
+                        reinterpret_cast<const int *>(touch + ra.touch_perm), ra.DG, D, ra.tabs, table_store & 1,
+                        (long long)(by - ngroups - 1) * gx + bx);
+        return;
+    }
+    // fused tail: what follows reads what tiles / vector ops of THIS launch wrote (slabs and the post-pass' last vectors and
+    // rows of `parts`, all written through) or must come after their last read of the epochs. One lane polls the arrival
+    // counter (agent scope, bounded), then the workgroup's barrier. No acquire fence: nothing on this XCD has read those
+    // lines before in this launch. Everything that does NOT depend on them -- the group's record, its rank-1 records, the u
+    // vectors (pre-pass), the old value -- is requested before the wait.
+    auto wait_phase1 = [&]() {
+        if (ra.arrive) {
+            if (threadIdx.x == 0) {
+                // (hundreds of workgroups wait on ONE word: polled every ~1.5 us while more than a few arrivals are missing --
+                // at one poll per 0.25 us each they saturated the word's L2 channel and the post-pass next to them took
+                // 31 us instead of 15 -- and quickly only for the last few)
+                for (int spins = 0;; ++spins) {
+                    const unsigned have = uop_poll(ra.arrive);
+                    if ((int)(have - ra.phase1) >= 0) break;
+                    if (spins >= UOP_SPIN_LIMIT) {
+                        flag_error(ra.err, MPQE_FLAG_INTERNAL);
+                        break;
+                    }
+#ifndef MPQE_EMU
+                    if (ra.phase1 - have > 3u) __builtin_amdgcn_s_sleep(48);
+                    else __builtin_amdgcn_s_sleep(2);
+#endif
+                }
+            }
+            __syncthreads();
+        }
+    };
+    if (by == ngroups) {       // one extra workgroup row: the loss reduction rides along
+        if (bx == 0) {
+            wait_phase1();
+            // the step is over: the next step's granules (forward pre-pass, backward post-pass) get new tags, and the
+            // count of finished transpose workgroups a new target (step_uniform.h, step_chain.h)
+            if (epoch_b && threadIdx.x == 0) {
+                *epoch_b = *epoch_b + 1u;
+                *(epoch_b - 16) = *(epoch_b - 16) + 1u;       // epoch_f
+                if (table_store & 2) *(epoch_b + 32) = *(epoch_b + 32) + 1u;      // merged launch: its own epoch (DoneMeta)
+                *(epoch_b + 24) = 0u;       // the grid barrier of the next step's in-launch sort starts from zero (step_touch.h)
+            }
+            // a touch plan whose build could not finish (its workgroups were not all resident: step_touch.h)
+            if (touch && threadIdx.x == 0 && reinterpret_cast<const TouchHeader *>(touch)->pad[0]) flag_error(ra.err, MPQE_FLAG_INTERNAL);
+            if (ra.lm.chain) loss_block_chain(ra.lm, ra.bterms, ra.loss, reinterpret_cast<float *>(part), 4);
+            else loss_block(ra.sd, ra.terms, ra.loss, reinterpret_cast<float *>(part), 4);
+        }
+        return;
+    }
+    const RGroup g = groups[by];
+    const long long elems = g.kind <= 1 ? (long long)D * D : D;
+    if (g.kind >= 2 && vec && (256 % (D / 4)) == 0) {
+        // a vector group (bias / mode row): hundreds of partial rows of D floats (one per chain block), ONE
+        // workgroup: D/4 lanes cover a row, the 256 / (D/4) row groups each walk every RG-th row with 8 loads
+        // in flight, then the row groups' sums are added in order (fixed order: reproducible)
+        if (bx != 0) return;
+        wait_phase1();
+        const int LQ = D / 4, RG = 256 / LQ;
+        const int c4 = threadIdx.x % LQ, rg = threadIdx.x / LQ;
+        const float *pv = partial + (long long)g.start * D + 4 * c4;
+        f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+        for (int i = rg; i < g.count; i += RG * 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = i + RG * q;
+                v[q] = gload4(pv + (long long)(k < g.count ? k : i) * D);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (i + RG * q < g.count) acc4 += v[q];
+        }
+        f32x4 *flat = &part[0][0];
+        flat[threadIdx.x] = acc4;
+        __syncthreads();
+        if (rg != 0) return;
+        float *dstv = g.kind == 2 ? gp.bias[g.layer] : (gp.mode_emb ? gp.mode_emb + g.row * D : nullptr);
+        if (!dstv) return;
+        f32x4 t = flat[c4];
+        for (int q = 1; q < RG; ++q) t += flat[q * LQ + c4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dstv[4 * c4 + k] = zeroed ? t[k] : dstv[4 * c4 + k] + t[k];
+        return;
+    }
+    const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const long long idx = ((long long)bx * 64 + el) * 4;
+    if ((long long)bx * 256 >= elems) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const float *p = (g.kind <= 1 ? slabs : partial) + (long long)g.start * elems + idx;
+    float *dst;
+    if (g.kind == 0) dst = gp.basis[g.layer] ? gp.basis[g.layer] + g.row * elems : nullptr;
+    else if (g.kind == 1) dst = gp.root[g.layer];
+    else if (g.kind == 2) dst = gp.bias[g.layer];
+    else dst = gp.mode_emb ? gp.mode_emb + g.row * D : nullptr;
+    // rank-1 terms of a matrix group (sources whose input state is one vector per batch: out[i][j] += u[i] v[j], v = the
+    // column sum of the destination's gradient rows; chain form, D % 64 == 0). Wave sg takes terms sg, sg + 4, ... in
+    // order into its partial sum: their records are requested together, then their u / v pieces together -- two round
+    // trips next to the slab loads whatever the count (a loop of dependent record -> vector loads per term, and then a
+    // staged version with two workgroup barriers per eight terms, were the launch's long pole).
+    const bool r1 = g.kind <= 1 && g.r1_count > 0 && vec && idx + 3 < elems && !(STEP_DBG & 2);
+    const int ri = (int)(idx / D), rj = (int)(idx % D);
+    Rank1 rk0[R1_CHUNK];
+    float u0[R1_CHUNK];
+    if (r1) {       // first chunk of this wave's terms: records, then the u pieces (vectors of the forward pre-pass)
+#pragma unroll
+        for (int q = 0; q < R1_CHUNK; ++q) rk0[q] = rank1[g.r1_start + (sg + 4 * q < g.r1_count ? sg + 4 * q : (sg < g.r1_count ? sg : 0))];
+#pragma unroll
+        for (int q = 0; q < R1_CHUNK; ++q) u0[q] = gload1(VT + (long long)rk0[q].u * D + ri);
+    }
+    f32x4 old4 = {0.f, 0.f, 0.f, 0.f};       // accumulate mode: the old value travels with the other loads, not after them
+    if (vec && dst && !zeroed && sg == 0 && idx + 3 < elems) old4 = gload4(dst + idx);
+    wait_phase1();
+    if (r1) {
+        for (int t0 = sg; t0 < g.r1_count; t0 += 4 * R1_CHUNK) {
+            Rank1 rk[R1_CHUNK];
+            float u[R1_CHUNK];
+            f32x4 v[R1_CHUNK];
+            if (t0 == sg) {
+#pragma unroll
+                for (int q = 0; q < R1_CHUNK; ++q) {
+                    rk[q] = rk0[q];
+                    u[q] = u0[q];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < R1_CHUNK; ++q) rk[q] = rank1[g.r1_start + (t0 + 4 * q < g.r1_count ? t0 + 4 * q : t0)];
+#pragma unroll
+                for (int q = 0; q < R1_CHUNK; ++q) u[q] = gload1(VT + (long long)rk[q].u * D + ri);
+            }
+#pragma unroll
+            for (int q = 0; q < R1_CHUNK; ++q) v[q] = gload4(VT + (long long)rk[q].v * D + rj);
+#pragma unroll
+            for (int q = 0; q < R1_CHUNK; ++q)
+                if (t0 + 4 * q < g.r1_count) s += u[q] * v[q];
+        }
+    }
+    if (vec) {
+        if (idx < elems) {
+            // four slabs of this wave in flight at a time (slab i, i+4, i+8, i+12; clamped loads, masked adds)
+            for (int i = sg; i < g.count; i += 16) {
+                f32x4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = i + 4 * q;
+                    v[q] = gload4(p + (long long)(k < g.count ? k : i) * elems);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (i + 4 * q < g.count) s += v[q];
+            }
+        }
+    } else {
+        for (int i = sg; i < g.count; i += 4)
+            for (int k = 0; k < 4; ++k)
+                if (idx + k < elems) s[k] += p[(long long)i * elems + k];
+    }
+    part[sg][el] = s;
+    __syncthreads();
+    if (sg != 0 || !dst) return;
+    const bool have_old = vec && !zeroed && idx + 3 < elems;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (idx + k < elems) {
+            const float sum = (part[0][el][k] + part[1][el][k]) + (part[2][el][k] + part[3][el][k]);
+            dst[idx + k] = zeroed ? sum : (have_old ? old4[k] : dst[idx + k]) + sum;
+        }
+}
+
+__global__ __launch_bounds__(256) void step_reduce_kernel(ReduceArgs ra) {
+    __shared__ f32x4 part[4][64];
+    reduce_block(ra, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, part);
+}
+
 struct TailArgs {
     const WSource *wsrc;
     const WBlock *wblock;
@@ -1001,15 +1225,57 @@ __device__ __forceinline__ void post_block(const StepDev *__restrict__ sd, const
     }       // (else: padding)
 }
 
-template <int MODE>
+// FUSED (chain form, LD_T; diagnostics switch FUSE_TAIL, off by default): the step's reduction rides in this launch --
+// `fa.first` workgroups of tiles / vector ops / zero fill as before, then the reduction's workgroups: entity-table rows and
+// the loss (they read what the chain launch wrote) and, waiting for the arrival counter of the tiles and vector ops, the
+// reduction groups: two launches per step instead of three. Built, parity-tested (tests/test_step.py), and SLOWER on the
+// AIFB step -- 32.3 us against 19.8 + 10.2 -- for two measured reasons: (1) every workgroup of a launch has the launch's
+// register footprint, the tile's 228 VGPRs = two workgroups per CU whatever their LDS, so ~2 800 table-row and ~400
+// group workgroups queue for the ~270 slots the tiles and vector ops leave (and the waiting groups hold some); (2) the
+// post-pass outputs the reduction reads must be written through to reach another XCD inside a launch, and those
+// agent-scope stores stretch the post-pass' dependence chain from 15.7 to 20.6 us. DESIGN.md 4.2 (round 3).
+struct FuseArgs {
+    int first;              // workgroups in front of the reduction's (the un-fused launch's grid); 0: not fused
+    int gx, trows;          // the reduction's grid: gx workgroups per group, trows rows of gx table-row workgroups
+    int tx;                 // the table-row workgroups are dealt to the first tx XCDs only (8: all): not where the post-pass runs
+    int tspan;              // workgroups of the launch the table rows take (holes included)
+    unsigned *arrive;       // arrival counter (zeroed by the chain launch)
+};
+template <int MODE, bool FUSED = false>
 __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restrict__ sd, TailArgs ta,
                                                         const float *__restrict__ H, const float *__restrict__ GH,
                                                         long long level_stride, GradPtrs gp, int zeroed, LayerPtrs lp,
-                                                        UArgs ua) {
+                                                        UArgs ua, FuseArgs fa, ReduceArgs ra) {
     // weight-gradient tiles only: the DMA ring takes 64 KB of LDS per workgroup, which would throttle the
     // thousands of light partial-sum / anchor workgroups to 2 per CU if they shared this kernel
     // (LD_T, the chain form: the tiles meet in a 17 KB LDS tile at their end; the post-pass' vector ops use 8 KB)
-    __shared__ __attribute__((aligned(16))) float smem[MODE == LD_T ? GWR_SMEM_FLOATS : (MODE == LD_FAST ? GWD_SMEM_FLOATS : GT_SMEM_FLOATS)];
+    __shared__ __attribute__((aligned(16))) float smem[MODE == LD_T ? (FUSED ? GWR_SMEM_FLOATS2 : GWR_SMEM_FLOATS) : (MODE == LD_FAST ? GWD_SMEM_FLOATS : GT_SMEM_FLOATS)];
+    if constexpr (FUSED) {
+        if ((int)blockIdx.x >= fa.first) {
+            int p = (int)blockIdx.x - fa.first;
+            const int T = fa.tspan;
+            int bx, by;
+            if (p < T) {
+                if ((p & 7) >= fa.tx) return;            // (a hole: this XCD is the post-pass')
+                p = (p >> 3) * fa.tx + (p & 7);
+                if (p >= fa.trows * fa.gx) return;
+                bx = p % fa.gx, by = ra.ngroups + 1 + p / fa.gx;
+            } else if (p == T) bx = 0, by = ra.ngroups;
+            else bx = (p - T - 1) % fa.gx, by = (p - T - 1) / fa.gx;
+            reduce_block(ra, bx, by, fa.gx, reinterpret_cast<f32x4(*)[64]>(smem));
+            return;
+        }
+    }
+    // (fused: a tile / vector-op workgroup counts itself in once its stores -- written through -- are acknowledged)
+    auto arrived = [&]() {
+        if constexpr (FUSED) {
+#ifndef MPQE_EMU
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            __syncthreads();
+            if (threadIdx.x == 0) atomicAdd(fa.arrive, 1u);
+        }
+    };
 #ifndef MPQE_EMU
     long long tick0 = 0;
     if (ta.stamps && threadIdx.x == 0) {
@@ -1042,15 +1308,17 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
             ta.stamps[(long long)blockIdx.x * 8 + 6] = 1 + (long long)ua.ops[ub / ua.chunks].kind;
         }
 #endif
+        arrived();
         return;
     }
     if (tb >= ta.wblocks) {        // zero fill of a gradient matrix nobody writes (uniform branch)
         if (tb - ta.wblocks < ta.zblocks) zmat_block(ta.zmats, ta.zper, tb - ta.wblocks, sd->D, gp);
         return;
     }
-    grad_w_block<MODE>(sd, ta.wsrc, ta.nwsrc, ta.wblock, H, GH, level_stride, ta.slabs, tb, ta.wblocks,
+    grad_w_block<MODE, (FUSED ? 2 : 4)>(sd, ta.wsrc, ta.nwsrc, ta.wblock, H, GH, level_stride, ta.slabs, tb, ta.wblocks,
                        smem, gp, zeroed != 0, ta.stamps ? ta.stamps + (long long)blockIdx.x * 8 : nullptr, ta.D, nullptr, ta.tile_n,
-                       ta.ux > 0 ? 8 - ta.ux : 8);      // zeroed: this call zero-filled the gradients, a store suffices
+                       ta.ux > 0 ? 8 - ta.ux : 8, FUSED);      // zeroed: this call zero-filled the gradients, a store suffices
+    arrived();
 #ifndef MPQE_EMU
     if (ta.stamps && threadIdx.x == 0) {
         ta.stamps[(long long)blockIdx.x * 8 + 1] = (long long)wall_clock64();
@@ -1073,152 +1341,6 @@ __global__ __launch_bounds__(256) void step_tail_small_kernel(const StepDev *__r
                          bid - ta.vblocks);
 }
 
-
-// out += sum of the group's slabs / partial rows. A workgroup owns 256 consecutive elements (4 per
-// lane, 16-byte loads); its 4 waves each add every 4th slab (two loads in flight), the four sums
-// are combined as (0+1)+(2+3): a fixed order. (A one-thread-per-16-elements variant that walked all
-// slabs serially measured 2.5x slower: the 40-slab root group became the long pole.)
-__global__ __launch_bounds__(256) void step_reduce_kernel(const RGroup *__restrict__ groups, int ngroups, int D,
-                                                          GradPtrs gp, const float *__restrict__ slabs,
-                                                          const float *__restrict__ partial, int vec,
-                                                          const StepDev *__restrict__ sd,
-                                                          const float *__restrict__ terms,
-                                                          float *__restrict__ loss, int zeroed, LossMeta lm,
-                                                          const float *__restrict__ bterms,
-                                                          const Rank1 *__restrict__ rank1,
-                                                          const float *__restrict__ VT, unsigned *epoch_b,
-                                                          const char *__restrict__ touch, size_t touch_keys,
-                                                          const float *__restrict__ DG, TablePtrs tabs, int table_store,
-                                                          long long touch_M, int touch_row_bits, size_t touch_perm,
-                                                          int32_t *err) {
-    // zeroed: this call zero-filled the gradients, so `out` is known to be 0 -- a store replaces the
-    // read-modify-write (whose read would be one more dependent round trip at the end of the chain)
-    __shared__ f32x4 part[4][64];
-    if ((int)blockIdx.y > ngroups) {        // further rows: entity-table gradients, per destination row (step_touch.h).
-        // (As workgroups of the weight-gradient launch they are throttled to two per CU by its 64 KB of LDS: 23.6 us
-        // for that launch instead of 16.6; here they cost 2.6 us.)
-        table_sum_block(touch_M, touch_row_bits, reinterpret_cast<const tkey_t *>(touch + touch_keys),
-                        reinterpret_cast<const int *>(touch + touch_perm), DG, D, tabs, table_store & 1,
-                        (long long)((int)blockIdx.y - ngroups - 1) * gridDim.x + blockIdx.x);
-        return;
-    }
-    if ((int)blockIdx.y == ngroups) {       // one extra workgroup row: the loss reduction rides along
-        if (blockIdx.x == 0) {
-            // the step is over: the next step's granules (forward pre-pass, backward post-pass) get new tags, and the
-            // count of finished transpose workgroups a new target (step_uniform.h, step_chain.h)
-            if (epoch_b && threadIdx.x == 0) {
-                *epoch_b = *epoch_b + 1u;
-                *(epoch_b - 16) = *(epoch_b - 16) + 1u;       // epoch_f
-                if (table_store & 2) *(epoch_b + 32) = *(epoch_b + 32) + 1u;      // merged launch: its own epoch (DoneMeta)
-                *(epoch_b + 24) = 0u;       // the grid barrier of the next step's in-launch sort starts from zero (step_touch.h)
-            }
-            // a touch plan whose build could not finish (its workgroups were not all resident: step_touch.h)
-            if (touch && threadIdx.x == 0 && reinterpret_cast<const TouchHeader *>(touch)->pad[0]) flag_error(err, MPQE_FLAG_INTERNAL);
-            if (lm.chain) loss_block_chain(lm, bterms, loss, reinterpret_cast<float *>(part), 4);
-            else loss_block(sd, terms, loss, reinterpret_cast<float *>(part), 4);
-        }
-        return;
-    }
-    const RGroup g = groups[blockIdx.y];
-    const long long elems = g.kind <= 1 ? (long long)D * D : D;
-    if (g.kind >= 2 && vec && (256 % (D / 4)) == 0) {
-        // a vector group (bias / mode row): hundreds of partial rows of D floats (one per chain block), ONE
-        // workgroup: D/4 lanes cover a row, the 256 / (D/4) row groups each walk every RG-th row with 8 loads
-        // in flight, then the row groups' sums are added in order (fixed order: reproducible)
-        if (blockIdx.x != 0) return;
-        const int LQ = D / 4, RG = 256 / LQ;
-        const int c4 = threadIdx.x % LQ, rg = threadIdx.x / LQ;
-        const float *pv = partial + (long long)g.start * D + 4 * c4;
-        f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
-        for (int i = rg; i < g.count; i += RG * 8) {
-            f32x4 v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int k = i + RG * q;
-                v[q] = gload4(pv + (long long)(k < g.count ? k : i) * D);
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (i + RG * q < g.count) acc4 += v[q];
-        }
-        f32x4 *flat = &part[0][0];
-        flat[threadIdx.x] = acc4;
-        __syncthreads();
-        if (rg != 0) return;
-        float *dstv = g.kind == 2 ? gp.bias[g.layer] : (gp.mode_emb ? gp.mode_emb + g.row * D : nullptr);
-        if (!dstv) return;
-        f32x4 t = flat[c4];
-        for (int q = 1; q < RG; ++q) t += flat[q * LQ + c4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) dstv[4 * c4 + k] = zeroed ? t[k] : dstv[4 * c4 + k] + t[k];
-        return;
-    }
-    const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
-    const long long idx = ((long long)blockIdx.x * 64 + el) * 4;
-    if ((long long)blockIdx.x * 256 >= elems) return;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    const float *p = (g.kind <= 1 ? slabs : partial) + (long long)g.start * elems + idx;
-    float *dst;
-    if (g.kind == 0) dst = gp.basis[g.layer] ? gp.basis[g.layer] + g.row * elems : nullptr;
-    else if (g.kind == 1) dst = gp.root[g.layer];
-    else if (g.kind == 2) dst = gp.bias[g.layer];
-    else dst = gp.mode_emb ? gp.mode_emb + g.row * D : nullptr;
-    // rank-1 terms of a matrix group (sources whose input state is one vector per batch: out[i][j] += u[i] v[j], v = the
-    // column sum of the destination's gradient rows; chain form, D % 64 == 0). Wave sg takes terms sg, sg + 4, ... in
-    // order into its partial sum: their records are requested together, then their u / v pieces together -- two round
-    // trips next to the slab loads whatever the count (a loop of dependent record -> vector loads per term, and then a
-    // staged version with two workgroup barriers per eight terms, were the launch's long pole).
-    if (g.kind <= 1 && g.r1_count > 0 && vec && idx + 3 < elems && !(STEP_DBG & 2)) {
-        const int i = (int)(idx / D), j = (int)(idx % D);
-        for (int t0 = sg; t0 < g.r1_count; t0 += 4 * R1_CHUNK) {
-            Rank1 rk[R1_CHUNK];
-#pragma unroll
-            for (int q = 0; q < R1_CHUNK; ++q) rk[q] = rank1[g.r1_start + (t0 + 4 * q < g.r1_count ? t0 + 4 * q : t0)];
-            float u[R1_CHUNK];
-            f32x4 v[R1_CHUNK];
-#pragma unroll
-            for (int q = 0; q < R1_CHUNK; ++q) {
-                u[q] = gload1(VT + (long long)rk[q].u * D + i);
-                v[q] = gload4(VT + (long long)rk[q].v * D + j);
-            }
-#pragma unroll
-            for (int q = 0; q < R1_CHUNK; ++q)
-                if (t0 + 4 * q < g.r1_count) s += u[q] * v[q];
-        }
-    }
-    f32x4 old4 = {0.f, 0.f, 0.f, 0.f};       // accumulate mode: the old value travels with the slab loads, not after them
-    if (vec && dst && !zeroed && sg == 0 && idx + 3 < elems) old4 = gload4(dst + idx);
-    if (vec) {
-        if (idx < elems) {
-            // four slabs of this wave in flight at a time (slab i, i+4, i+8, i+12; clamped loads, masked adds)
-            for (int i = sg; i < g.count; i += 16) {
-                f32x4 v[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int k = i + 4 * q;
-                    v[q] = gload4(p + (long long)(k < g.count ? k : i) * elems);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (i + 4 * q < g.count) s += v[q];
-            }
-        }
-    } else {
-        for (int i = sg; i < g.count; i += 4)
-            for (int k = 0; k < 4; ++k)
-                if (idx + k < elems) s[k] += p[(long long)i * elems + k];
-    }
-    part[sg][el] = s;
-    __syncthreads();
-    if (sg != 0 || !dst) return;
-    const bool have_old = vec && !zeroed && idx + 3 < elems;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (idx + k < elems) {
-            const float sum = (part[0][el][k] + part[1][el][k]) + (part[2][el][k] + part[3][el][k]);
-            dst[idx + k] = zeroed ? sum : (have_old ? old4[k] : dst[idx + k]) + sum;
-        }
-}
 
 // ------------------------------------------------------------------------------------ host side
 namespace {
@@ -2214,6 +2336,16 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->o_cops = take(hp->cops.size() * sizeof(ChainOp));
     hp->o_wtslots = take(hp->wt_slots.size() * sizeof(WtSlot));
     hp->o_zmats = take(hp->zmats.size() * sizeof(ZMat));
+    {   // post-pass outputs the step's reduction reads (fused tail: they travel inside one launch)
+        std::vector<char> isv((size_t)std::max(hp->nvec, 1), 0);
+        for (size_t k = 0; k < hp->rank1.size(); ++k)
+            if (hp->rank1[k].v >= 0 && hp->rank1[k].v < hp->nvec) isv[hp->rank1[k].v] = 1;
+        for (size_t k = 0; k < hp->uops_b.size(); ++k) {
+            UOp &op = hp->uops_b[k];
+            op.through = (op.out_part >= 0 || (op.out_vec >= 0 && op.out_vec < hp->nvec && isv[op.out_vec])) ? 1 : 0;
+        }
+        for (size_t k = 0; k < hp->uops_f.size(); ++k) hp->uops_f[k].through = 1;
+    }
     hp->o_uopf = take(hp->uops_f.size() * sizeof(UOp));
     hp->o_uopb = take(hp->uops_b.size() * sizeof(UOp));
     hp->o_rank1 = take(hp->rank1.size() * sizeof(Rank1));
@@ -2950,6 +3082,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             pa.slots = reinterpret_cast<const WtSlot *>(db + hp.o_wtslots);
             pa.WT = WT;
             pa.wt_count = epoch_f + 32;
+            pa.tail_arrive = nullptr;      // (set below once the launch form is known)
             pa.fwd_done = merged && pa.ublocks > 0 ? epoch_f + 33 : nullptr;
             pa.ua.vt_through = merged ? 1 : 0;
         } else if (zblocks > 0) {
@@ -3001,6 +3134,45 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     ub.ops = reinterpret_cast<const UOp *>(db + hp.o_uopb);
     ub.nops = (int)hp.uops_b.size();
     ub.epoch = epoch_b;
+    // the step's reduction: a launch of its own, or (chain form, split tail, switch FUSE_TAIL) trailing workgroups of the
+    // weight-gradient launch
+    ReduceArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    const long long r_elems = (long long)D * D;
+    const unsigned r_gx = (unsigned)((r_elems + 255) / 256);
+    unsigned r_trows = 0;         // entity-table gradient rows: 256 / (D / 4) sorted positions per workgroup
+    if (use_touch && !(STEP_DBG & 1)) {
+        const long long per = 256 / (D / 4), tblk = (hp.touch_M + per - 1) / per;
+        r_trows = (unsigned)((tblk + r_gx - 1) / r_gx);
+    }
+    ra.groups = reinterpret_cast<const RGroup *>(db + hp.o_groups);
+    ra.ngroups = (int)hp.groups.size();
+    ra.D = D;
+    ra.gp = gp;
+    ra.slabs = slabs;
+    ra.partial = parts;
+    ra.vec = (int)(D % 4 == 0);
+    ra.zeroed = (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0;
+    ra.sd = sd;
+    ra.terms = terms;
+    ra.loss = loss;
+    ra.lm = lm;
+    ra.bterms = bterms;
+    ra.rank1 = reinterpret_cast<const Rank1 *>(db + hp.o_rank1);
+    ra.VT = VT;
+    ra.epoch_b = use_chain ? epoch_b : nullptr;
+    ra.touch = use_touch ? reinterpret_cast<const char *>(touch) : nullptr;
+    ra.touch_keys = touch_layout(hp.touch_M, 0).keys;
+    ra.touch_perm = touch_layout(hp.touch_M, 0).perm;
+    ra.DG = reinterpret_cast<const float *>(wb + hp.o_DG);
+    ra.tabs = tabs;
+    ra.table_store = ((sparse_tables || (P->flags & MPQE_STEP_ZERO_GRADS)) ? 1 : 0) | (merged ? 2 : 0);
+    ra.touch_M = (long long)hp.touch_M;
+    ra.touch_row_bits = touch_row_bits;
+    ra.err = err;
+    const bool fuse_tail = use_chain && backward && !merged && NL == 1 && D % 64 == 0 && dbg_on("FUSE_TAIL");
+    pa.tail_arrive = fuse_tail ? epoch_f + 41 : nullptr;
+    bool reduced = false;
     auto launch_grad_w = [&](hipStream_t on, int first, int count) {
         TailArgs tl = ta;
         tl.wblock = ta.wblock + first;
@@ -3023,18 +3195,38 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         if (nblocks <= 0) return;
         dim3 tgrid((unsigned)nblocks);
         const int zeroed = (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0;
-        if (use_chain)
+        FuseArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        if (use_chain && fuse_tail && first == 0 && count == hp.wblocks_total) {
+            // [tiles / vector ops / zero fill as before][table rows][loss][reduction groups]: the groups wait for the tiles
+            // and vector ops, which come before them in the launch
+            fa.first = (nblocks + 7) / 8 * 8;
+            fa.gx = (int)r_gx;
+            fa.trows = (int)r_trows;
+            fa.tx = 8;
+            fa.tspan = (fa.trows * fa.gx + fa.tx - 1) / fa.tx * 8;
+            fa.arrive = epoch_f + 41;
+            ReduceArgs rf = ra;
+            rf.arrive = fa.arrive;
+            rf.phase1 = (unsigned)(tl.ublocks + count);
+            UArgs uf = ub;
+            uf.vt_through = 2;      // (only the outputs the reduction reads: UOp.through)
+            dim3 fgrid((unsigned)(fa.first + fa.tspan + 1 + (int)(hp.groups.size() * r_gx)));
+            hipLaunchKernelGGL((step_tail_kernel<LD_T, true>), fgrid, dim3(256), 0, on, sd, tl, (const float *)H,
+                               (const float *)GH, hp.level_stride, gp, zeroed, lp, uf, fa, rf);
+            reduced = true;
+        } else if (use_chain)
             hipLaunchKernelGGL(step_tail_kernel<LD_T>, tgrid, dim3(256), 0, on, sd, tl, (const float *)H,
-                               (const float *)GH, hp.level_stride, gp, zeroed, lp, ub);
+                               (const float *)GH, hp.level_stride, gp, zeroed, lp, ub, fa, ra);
         else if (fast && hp.whole_ksteps)
             hipLaunchKernelGGL(step_tail_kernel<LD_FAST>, tgrid, dim3(256), 0, on, sd, tl, (const float *)H,
-                               (const float *)GH, hp.level_stride, gp, zeroed, lp, ub);
+                               (const float *)GH, hp.level_stride, gp, zeroed, lp, ub, fa, ra);
         else if (vec)
             hipLaunchKernelGGL(step_tail_kernel<LD_PRED>, tgrid, dim3(256), 0, on, sd, tl, (const float *)H,
-                               (const float *)GH, hp.level_stride, gp, zeroed, lp, ub);
+                               (const float *)GH, hp.level_stride, gp, zeroed, lp, ub, fa, ra);
         else
             hipLaunchKernelGGL(step_tail_kernel<LD_SCALAR>, tgrid, dim3(256), 0, on, sd, tl, (const float *)H,
-                               (const float *)GH, hp.level_stride, gp, zeroed, lp, ub);
+                               (const float *)GH, hp.level_stride, gp, zeroed, lp, ub, fa, ra);
     };
     if (use_chain) {
         // assemble -> levels -> scores (-> levels back -> anchor-table gradients): one launch per lane
@@ -3238,24 +3430,9 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             hipLaunchKernelGGL(step_tail_small_kernel, dim3(small_blocks), dim3(256), 0, s, sd, ta, tabs,
                                (const float *)H, (const float *)GH, hp.level_stride);
     }
-    {
-        const long long elems = (long long)D * D;
-        const unsigned gx = (unsigned)((elems + 255) / 256);
-        unsigned trows = 0;         // entity-table gradient rows: 256 / (D / 4) sorted positions per workgroup
-        if (use_touch && !(STEP_DBG & 1)) {
-            const long long per = 256 / (D / 4), tblk = (hp.touch_M + per - 1) / per;
-            trows = (unsigned)((tblk + gx - 1) / gx);
-        }
-        dim3 grid(gx, (unsigned)hp.groups.size() + 1 + trows);
-        hipLaunchKernelGGL(step_reduce_kernel, grid, dim3(256), 0, s,
-                           reinterpret_cast<const RGroup *>(db + hp.o_groups), (int)hp.groups.size(), D, gp,
-                           (const float *)slabs, (const float *)parts, (int)(D % 4 == 0), sd, (const float *)terms,
-                           loss, (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0, lm, bterms,
-                           reinterpret_cast<const Rank1 *>(db + hp.o_rank1), (const float *)VT, epoch_b,
-                           reinterpret_cast<const char *>(touch), touch_layout(hp.touch_M, 0).keys,
-                           (const float *)(wb + hp.o_DG), tabs,
-                           ((sparse_tables || (P->flags & MPQE_STEP_ZERO_GRADS)) ? 1 : 0) | (merged ? 2 : 0),
-                           (long long)hp.touch_M, touch_row_bits, touch_layout(hp.touch_M, 0).perm, err);
+    if (!reduced) {
+        dim3 grid(r_gx, (unsigned)hp.groups.size() + 1 + r_trows);
+        hipLaunchKernelGGL(step_reduce_kernel, grid, dim3(256), 0, s, ra);
     }
     return mpqe_launch_status();
 }

@@ -49,7 +49,8 @@ struct UArgs {
     const unsigned *fwd_done;   // pre-pass workgroups finished, ever (their plain VT stores are out)
     const unsigned *epoch_m;    // epoch of the merged launches (targets of both counters)
     int fwd_blocks;
-    int vt_through;             // merged launch, pre-pass: VT stores written through (uop_publish)
+    int vt_through;             // 1: merged launch, pre-pass: VT (and `parts`) stores written through (uop_publish); 2: fused
+                                // tail, post-pass: those of the ops marked UOp.through
 };
 
 // Merged launch: wait until (a) the pre-pass workgroups of this launch have all finished -- the post-pass reads their
@@ -185,9 +186,15 @@ __device__ __forceinline__ void uop_fetch_inputs(const UOp &op, const UArgs &ua,
 
 __device__ __forceinline__ void uop_publish(const UOp &op, int e, int D, float v, const UArgs &ua, unsigned tag) {
     if (op.out_gran >= 0) gran_store(ua.gran + (long long)op.out_gran * D + e, tag, v);      // (first: somebody may wait)
+#ifndef MPQE_EMU
+    const bool thr = ua.vt_through == 1 || (ua.vt_through == 2 && op.through);
+    if (op.out_part >= 0 && thr) {      // (fused tail: the reduction workgroups of the same launch read the row)
+        __hip_atomic_store(ua.parts + (long long)op.out_part * D + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else
+#endif
     if (op.out_part >= 0) ua.parts[(long long)op.out_part * D + e] = v;
 #ifndef MPQE_EMU
-    if (ua.vt_through) {
+    if (thr) {
         // merged launch, pre-pass: the post-pass workgroups of the SAME launch read these vectors with plain loads, from
         // other XCDs -- written through to memory at agent scope (the write-through store on the hand-off path of the
         // post-pass cost 3.4 us per step: there the granule goes first and VT stays a plain store)

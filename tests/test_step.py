@@ -289,6 +289,18 @@ def test_fused_step_chain_kernels(be, D, readout, adaptive, shared, L):
                              flags=_capi.STEP_SPLIT_TAIL | _capi.STEP_ZERO_GRADS, repeat=2))
         runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0,
                              flags=_capi.STEP_MERGE_TAIL | _capi.STEP_ZERO_GRADS, repeat=3))
+        # the reduction as trailing workgroups of the weight-gradient launch (two launches per step in the split form):
+        # accumulate and zero-fill modes, three runs on one descriptor buffer (the arrival counter is re-armed per step)
+        be.lib.mpqe_debug_option(b'FUSE_TAIL', 1, 1)
+        try:
+            fz = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0,
+                          flags=_capi.STEP_SPLIT_TAIL | _capi.STEP_ZERO_GRADS, repeat=3)
+            fa = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_SPLIT_TAIL)
+        finally:
+            be.lib.mpqe_debug_option(b'FUSE_TAIL', 0, 0)
+        runs += [fz, fa]
+        for k in fz[3]:          # (same tiles, same order of additions: zero fill + store == accumulate into zeros)
+            np.testing.assert_array_equal(fz[3][k], fa[3][k], err_msg=k)
     if every:
         # entity-table gradients by fp32 atomics instead of the per-row sums of the touch plan
         runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, touch=False))

@@ -32,7 +32,10 @@ def main():
     ap.add_argument('--trace', action='store_true', help='CHAIN_DBG=6 builds: per-item cycle stamps of block 0')
     ap.add_argument('--touch', default='step', choices=['step', 'pack'])
     ap.add_argument('--reps', type=int, default=1)
+    ap.add_argument('--eight-waves', action='store_true')
+    ap.add_argument('--no-ksplit', action='store_true')
     ap.add_argument('--debug-opt', action='append', default=[], metavar='NAME=VALUE')
+    ap.add_argument("--no-self-check", action="store_true")
     args = ap.parse_args()
     from mpqe_amd import ops, synthetic
     from mpqe_amd.data_utils import make_feature_modules
@@ -54,7 +57,7 @@ def main():
     model.validate = False
     data = bench.StepData(schema, model, args.batch_size, np.random.RandomState(1000), dev)
     step = FusedTrainStep(model, prune=not args.no_prune, merge_tail=True if (args.merge_tail or args.merged) else None,
-                          touch=args.touch)
+                          touch=args.touch, eight_waves=args.eight_waves, ksplit=not args.no_ksplit)
     packed = bench.pack_for_fused(step, data)
     assert step.uses_chain(packed), 'this step does not take the chain kernel'
     for _ in range(5):
