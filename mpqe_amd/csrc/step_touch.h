@@ -405,37 +405,57 @@ __device__ __forceinline__ void table_sum_block(long long M, int row_bits, const
     const long long k = block * per + threadIdx.x / lpr;
     const int c = (threadIdx.x % lpr) * 4;
     if (k >= M) return;
+    // ONE round trip for everything that depends on k alone: my key, my predecessor's, and the keys / permutation entries of
+    // the next TS_AHEAD positions (a run is ~8 rows long on the AIFB step); a second one for the rows. (Requested one after
+    // the other -- key, then permutation entry, then row, then the next keys ... -- a run cost five dependent round trips.)
     const tkey_t key = keys[k];
-    if (key == TOUCH_INVALID || (k > 0 && keys[k - 1] == key)) return;
-    f32x4 acc = gload4(DG + (perm ? (long long)perm[k] : k) * D + c);
-    for (long long j0 = k + 1; j0 < M; j0 += TS_AHEAD) {
-        tkey_t kk[TS_AHEAD];
+    const tkey_t prev = k > 0 ? keys[k - 1] : TOUCH_INVALID;
+    const long long p0 = perm ? (long long)perm[k] : k;
+    tkey_t kk[TS_AHEAD];
+    long long pj[TS_AHEAD];
+#pragma unroll
+    for (int q = 0; q < TS_AHEAD; ++q) {
+        const long long j = k + 1 + q < M ? k + 1 + q : M - 1;
+        kk[q] = keys[j];
+        pj[q] = perm ? (long long)perm[j] : j;
+    }
+    if (key == TOUCH_INVALID || (k > 0 && prev == key)) return;
+    f32x4 acc = gload4(DG + p0 * D + c);
+    {
         f32x4 v[TS_AHEAD];
-        if (perm) {
-            long long pj[TS_AHEAD];
-#pragma unroll
-            for (int q = 0; q < TS_AHEAD; ++q) {
-                const long long j = j0 + q < M ? j0 + q : M - 1;
-                kk[q] = keys[j];
-                pj[q] = perm[j];
-            }
-#pragma unroll
-            for (int q = 0; q < TS_AHEAD; ++q) v[q] = gload4(DG + pj[q] * D + c);
-        } else {
-#pragma unroll
-            for (int q = 0; q < TS_AHEAD; ++q) {
-                const long long j = j0 + q < M ? j0 + q : M - 1;
-                kk[q] = keys[j];
-                v[q] = gload4(DG + j * D + c);
-            }
-        }
+        bool on[TS_AHEAD];
         bool more = true;
 #pragma unroll
-        for (int q = 0; q < TS_AHEAD; ++q) {
-            more = more && j0 + q < M && kk[q] == key;
-            if (more) acc += v[q];
+        for (int q = 0; q < TS_AHEAD; ++q) {          // (rows beyond the run's end are not requested)
+            more = more && k + 1 + q < M && kk[q] == key;
+            on[q] = more;
+            v[q] = more ? gload4(DG + pj[q] * D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (!more) break;
+#pragma unroll
+        for (int q = 0; q < TS_AHEAD; ++q)
+            if (on[q]) acc += v[q];
+        if (more) {                                   // a longer run: the rest in chunks, as before
+            for (long long j0 = k + 1 + TS_AHEAD; j0 < M; j0 += TS_AHEAD) {
+                tkey_t k2[TS_AHEAD];
+                long long p2[TS_AHEAD];
+#pragma unroll
+                for (int q = 0; q < TS_AHEAD; ++q) {
+                    const long long j = j0 + q < M ? j0 + q : M - 1;
+                    k2[q] = keys[j];
+                    p2[q] = perm ? (long long)perm[j] : j;
+                }
+                f32x4 w[TS_AHEAD];
+#pragma unroll
+                for (int q = 0; q < TS_AHEAD; ++q) w[q] = gload4(DG + p2[q] * D + c);
+                bool go = true;
+#pragma unroll
+                for (int q = 0; q < TS_AHEAD; ++q) {
+                    go = go && j0 + q < M && k2[q] == key;
+                    if (go) acc += w[q];
+                }
+                if (!go) break;
+            }
+        }
     }
     const int tab = (int)(key >> row_bits);
     const long long row = (long long)(key & ((1ull << row_bits) - 1ull));
