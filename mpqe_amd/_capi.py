@@ -155,7 +155,7 @@ STEP_SPARSE_TABLES = 64
 STEP_MERGE_TAIL = 128
 STEP_SPLIT_TAIL = 256
 STEP_BUILD_TOUCH = 512
-TSORT_MAX_ENTRIES = 256 * 1024        # csrc/step_touch.h: the in-step touch plan covers this many looked-up ids
+TSORT_MAX_ENTRIES = 256 * 2048        # csrc/step_touch.h: the in-step touch plan covers this many looked-up ids
 
 
 def make_step_params(dim, num_relations, readout, table_ptrs, table_rows, node_map_ptr, node_map_len,

@@ -2360,7 +2360,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         const int rb = touch_bits(trows), kb = rb + 5;
         const long long M = anchors + 2 * graphs;
         if (chain && (P->flags & MPQE_STEP_BUILD_TOUCH) && M <= TSORT_MAX_ENTRIES && kb <= 31) {
-            hp->ts_blocks = (int)((M + TSORT_PER_BLOCK - 1) / TSORT_PER_BLOCK);
+            hp->ts_blocks = tsort_blocks(M);
             hp->ts_key_bits = kb;
             hp->ts_row_bits = rb;
             tmeta.nb = nb;
@@ -2429,7 +2429,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->touch_M = anchors + 2 * graphs;
     hp->o_DG = take(chain ? (size_t)hp->touch_M * D * 4 : 0);       // per-entry table-gradient rows (step_touch.h)
     // in-step sort: (key, entry) ping-pong buffers [4][blocks x 1024] + digit counts [4 passes][blocks][256]
-    hp->o_tsort = take(hp->ts_blocks ? (size_t)hp->ts_blocks * (4 * TSORT_PER_BLOCK + 4 * 256) * sizeof(unsigned) : 0);
+    hp->o_tsort = take(hp->ts_blocks ? (size_t)hp->ts_blocks * (4 * (size_t)TSORT_THREADS * tsort_rounds(hp->touch_M) + 4 * 256) * sizeof(unsigned) : 0);
     hp->total = off;
     return MPQE_OK;
 }
@@ -2645,8 +2645,8 @@ extern "C" int mpqe_step_touch_build(const mpqe_step_params_t *P, const mpqe_ste
     if (M <= TSORT_MAX_ENTRIES && kb <= 31 && !dbg_on("TOUCH_ROCPRIM")) {
         // the whole plan in one launch (step_touch.h: tsort_block) behind the clear of its barrier counter and the
         // upload of the batch table
-        const int nblk = (int)((M + TSORT_PER_BLOCK - 1) / TSORT_PER_BLOCK);
-        const size_t Mp = (size_t)nblk * TSORT_PER_BLOCK;
+        const int nblk = tsort_blocks(M);
+        const size_t Mp = (size_t)nblk * TSORT_THREADS * tsort_rounds(M);
         TSortArgs sa;
         memset(&sa, 0, sizeof(sa));
         sa.ka = reinterpret_cast<unsigned *>(wb + L.w_keys);
@@ -2672,6 +2672,7 @@ extern "C" int mpqe_step_touch_build(const mpqe_step_params_t *P, const mpqe_ste
         sa.key_bits = kb;
         sa.row_bits = rb;
         sa.nblk = nblk;
+        sa.rounds = tsort_rounds(M);
         hipLaunchKernelGGL(touch_sort_kernel, dim3((unsigned)nblk), dim3(TSORT_THREADS), 0, s, sa);
         return mpqe_launch_status();
     }
@@ -3038,7 +3039,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             if (build_touch) {
                 const TouchLayout TL = touch_layout(hp.touch_M, 0);
                 char *tb = reinterpret_cast<char *>(touch);
-                const size_t Mp = (size_t)hp.ts_blocks * TSORT_PER_BLOCK;
+                const size_t Mp = (size_t)hp.ts_blocks * TSORT_THREADS * tsort_rounds(hp.touch_M);
                 TSortArgs &ts = pa.ts;
                 ts.tm = reinterpret_cast<const TouchMeta *>(db + hp.o_tmeta);
                 ts.anchor_ids = ids;
@@ -3060,6 +3061,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                 ts.key_bits = hp.ts_key_bits;
                 ts.row_bits = hp.ts_row_bits;
                 ts.nblk = hp.ts_blocks;
+                ts.rounds = tsort_rounds(hp.touch_M);
                 ts.stamps = nullptr;
                 if (dbg_on("TSORT_TRAIL")) pa.strail = hp.ts_blocks;
                 else {

@@ -26,6 +26,19 @@
 typedef unsigned long long tkey_t;
 #define TOUCH_INVALID (~0ull)
 
+// the one-launch sort (tsort_block, below): workgroups of 256 threads, four entries per thread -- eight for plans beyond
+// 256 x 1024 entries (AIFB step: 22 workgroups, sort done at ~29 us with four, 11 workgroups and ~37 us with eight)
+#define TSORT_THREADS 256
+#define TSORT_ROUNDS 8
+#define TSORT_PER_BLOCK (TSORT_THREADS * TSORT_ROUNDS)
+#define TSORT_MAX_BLOCKS 256
+#define TSORT_MAX_ENTRIES ((long long)TSORT_MAX_BLOCKS * TSORT_PER_BLOCK)
+static inline int tsort_rounds(long long M) { return M <= (long long)TSORT_MAX_BLOCKS * TSORT_THREADS * 4 ? 4 : TSORT_ROUNDS; }
+static inline int tsort_blocks(long long M) {
+    const long long per = (long long)TSORT_THREADS * tsort_rounds(M);
+    return (int)((M + per - 1) / per);
+}
+
 struct TouchHeader {
     long long M;            // entries
     int row_bits, key_bits; // key = table << row_bits | row
@@ -58,7 +71,7 @@ static inline TouchLayout touch_layout(long long M, int key_bits /* 0: the devic
     L.total = off;
     if (key_bits <= 0) return L;
     off = 0;
-    const size_t Mp = ((size_t)M + 1023) / 1024 * 1024;      // (the one-launch sort works on whole workgroups of 1024 entries)
+    const size_t Mp = ((size_t)M + TSORT_PER_BLOCK - 1) / TSORT_PER_BLOCK * TSORT_PER_BLOCK;      // (whole workgroups of the one-launch sort)
     L.w_keys = off;
     off += align_up(Mp * sizeof(tkey_t), 256);
     L.w_vals = off;
@@ -149,8 +162,8 @@ __global__ __launch_bounds__(256) void touch_keys_kernel(TouchMeta tm, const lon
 // reproduces the plan (tools/graph_pack_probe.py): the next step for the host side of pack.)
 
 // The whole touch plan by workgroups that synchronise among themselves (the library sort is a chain of ~6 launches of
-// 3 - 8 us each, latency-bound at these sizes: ~54 us of device time). NB = ceil(M / 1024) workgroups of 256 threads,
-// FOUR entries per thread (entry = 1024 b + 256 r + t in round r: a round is a "virtual" group of four waves), all
+// 3 - 8 us each, latency-bound at these sizes: ~54 us of device time). NB = ceil(M / 2048) workgroups of 256 threads,
+// EIGHT entries per thread (entry = 2048 b + 256 r + t in round r: a round is a "virtual" group of four waves), all
 // workgroups resident at once; a stable LSD radix sort, 8 bits per pass:
 //   1  digit d of my key; my rank among the entries of MY WAVE AND ROUND with the same digit (eight ballots build the
 //      mask of equal-digit lanes), the count per (round, wave, digit) to LDS; thread d turns the 16 counts of digit d into
@@ -168,24 +181,20 @@ __global__ __launch_bounds__(256) void touch_keys_kernel(TouchMeta tm, const lon
 // is zero when the launch starts (pack-time build: a 4-byte memset in front of it; inside the step: the reduction launch
 // of the previous step leaves it zero); spins are bounded (a launch that cannot make progress leaves the header's
 // `pad[0]` = 1 instead of hanging -- e.g. when not all NB workgroups fit on the device together).
-#define TSORT_THREADS 256
-#define TSORT_ROUNDS 4
-#define TSORT_PER_BLOCK (TSORT_THREADS * TSORT_ROUNDS)
-#define TSORT_MAX_BLOCKS 256
-#define TSORT_MAX_ENTRIES ((long long)TSORT_MAX_BLOCKS * TSORT_PER_BLOCK)
 #define TSORT_META_WORDS 512      // sizeof(TouchMeta) / 4, rounded up
-#define TSORT_LDS_WORDS (TSORT_ROUNDS * 4 * 256 + 256 + 256 + 4 + TSORT_META_WORDS)
+#define TSORT_LDS_WORDS (TSORT_ROUNDS * 4 * 256 / 2 + 256 + 256 + 4 + TSORT_META_WORDS)      // (the digit counts are 16-bit)
 struct TSortArgs {
     const TouchMeta *tm;        // device copy (the packed step's descriptor table / the build's workspace)
     const long long *anchor_ids, *targets, *negs, *node_map;
     long long map_len;
-    unsigned *ka, *va, *kb, *vb;        // ping-pong (key, entry) buffers, [nblk * 1024] each
+    unsigned *ka, *va, *kb, *vb;        // ping-pong (key, entry) buffers, [nblk * TSORT_PER_BLOCK] each
     unsigned *hist;                     // [passes][nblk][256]
     unsigned *counter;                  // the grid barrier
     tkey_t *keys_out;
     int *perm, *erow;                   // erow: NULL = not wanted
     TouchHeader *th_out;
     int M, key_bits, row_bits, nblk;
+    int rounds;                         // entries per thread (tsort_rounds)
     long long *stamps;                  // diagnostics (mpqe_debug_chain_stamps): 8 words per sort workgroup, or NULL
 };
 #ifndef MPQE_EMU
@@ -215,8 +224,9 @@ __device__ __forceinline__ bool tsort_grid_barrier(unsigned *counter, unsigned t
 }
 // one workgroup of the sort; `smem`: TSORT_LDS_WORDS words. Threads >= TSORT_THREADS of a larger workgroup must not call.
 __device__ __forceinline__ void tsort_block(const TSortArgs &sa, int b, unsigned *smem) {
-    unsigned(*whist)[256] = reinterpret_cast<unsigned(*)[256]>(smem);       // [round * 4 + wave][digit]
-    unsigned *gbase = smem + TSORT_ROUNDS * 4 * 256, *scan = gbase + 256, *ok = scan + 256;
+    // [round * 4 + wave][digit]: counts of at most 64, their prefix over the workgroup's 2048 entries at most 2048: 16 bits
+    unsigned short(*whist)[256] = reinterpret_cast<unsigned short(*)[256]>(smem);
+    unsigned *gbase = smem + TSORT_ROUNDS * 4 * 256 / 2, *scan = gbase + 256, *ok = scan + 256;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nblk = sa.nblk, M = sa.M;
     // the batch table through LDS: touch_key_of walks it per entry (from memory that was five dependent round trips in
     // front of the first id load -- 9 to 16 us next to running chain workgroups)
@@ -230,13 +240,14 @@ __device__ __forceinline__ void tsort_block(const TSortArgs &sa, int b, unsigned
         if (sa.stamps && t == 0 && stamp_i < 7) sa.stamps[(long long)b * 8 + stamp_i++] = (long long)wall_clock64();
     };
     stamp();
+    const int R = sa.rounds, per_block = R * TSORT_THREADS;      // (uniform: 4 or 8 entries per thread)
     unsigned k[TSORT_ROUNDS], v[TSORT_ROUNDS];
 #pragma unroll
     for (int r = 0; r < TSORT_ROUNDS; ++r) {
-        const int i = b * TSORT_PER_BLOCK + r * TSORT_THREADS + t;
+        const int i = b * per_block + r * TSORT_THREADS + t;
         k[r] = 0xffffffffu;                                 // (slots beyond M: a key behind every real one, never stored)
         v[r] = (unsigned)i;
-        if (i < M) {
+        if (r < R && i < M) {
             int er;
             const tkey_t key = touch_key_of(tm, i, sa.anchor_ids, sa.targets, sa.negs, sa.node_map, sa.map_len, &er);
             k[r] = key == TOUCH_INVALID ? 0xffffffffu : (unsigned)key;
@@ -249,11 +260,12 @@ __device__ __forceinline__ void tsort_block(const TSortArgs &sa, int b, unsigned
     bool good = true;
     stamp();
     for (int p = 0; p < passes; ++p) {
-        for (int q = t; q < TSORT_ROUNDS * 4 * 256; q += TSORT_THREADS) smem[q] = 0;
+        for (int q = t; q < TSORT_ROUNDS * 4 * 256 / 2; q += TSORT_THREADS) smem[q] = 0;
         __syncthreads();
         unsigned below[TSORT_ROUNDS];
 #pragma unroll
         for (int r = 0; r < TSORT_ROUNDS; ++r) {
+            if (r >= R) continue;                          // (uniform)
             const unsigned d = (k[r] >> (8 * p)) & 255u;
             unsigned long long peers = ~0ull;              // lanes of my wave whose entry of this round has my digit
 #pragma unroll
@@ -262,7 +274,7 @@ __device__ __forceinline__ void tsort_block(const TSortArgs &sa, int b, unsigned
                 peers &= ((d >> bit) & 1u) ? m : ~m;
             }
             below[r] = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
-            if (below[r] == 0) whist[r * 4 + wave][d] = (unsigned)__popcll(peers);
+            if (below[r] == 0) whist[r * 4 + wave][d] = (unsigned short)__popcll(peers);
         }
         __syncthreads();
         {   // exclusive prefix over my workgroup's (round, wave) groups; its count of digit t
@@ -270,7 +282,7 @@ __device__ __forceinline__ void tsort_block(const TSortArgs &sa, int b, unsigned
 #pragma unroll
             for (int w = 0; w < TSORT_ROUNDS * 4; ++w) {
                 const unsigned c = whist[w][t];
-                whist[w][t] = run;
+                whist[w][t] = (unsigned short)run;
                 run += c;
             }
             tsort_st(sa.hist + ((size_t)p * nblk + b) * 256 + t, run);
@@ -303,7 +315,7 @@ __device__ __forceinline__ void tsort_block(const TSortArgs &sa, int b, unsigned
                 const unsigned y = __shfl_up(x, off, 64);
                 if (lane >= off) x += y;
             }
-            if (lane == 63) ok[1 + wave] = x;              // (ok[1..3]: the sums of waves 0..2; 4 words were reserved)
+            if (lane == 63 && wave < 3) ok[1 + wave] = x;  // (ok[1..3]: the sums of waves 0..2; 4 words are reserved)
             __syncthreads();
             unsigned pre = 0;
             for (int w = 0; w < wave; ++w) pre += ok[1 + w];
@@ -318,25 +330,27 @@ __device__ __forceinline__ void tsort_block(const TSortArgs &sa, int b, unsigned
         }
         if (p + 1 < passes) {
 #pragma unroll
-            for (int r = 0; r < TSORT_ROUNDS; ++r) {
-                tsort_st(dk + at[r], k[r]);                // (the padding keys travel too: they stay behind every real key)
-                tsort_st(dv + at[r], v[r]);
-            }
+            for (int r = 0; r < TSORT_ROUNDS; ++r)
+                if (r < R) {
+                    tsort_st(dk + at[r], k[r]);            // (the padding keys travel too: they stay behind every real key)
+                    tsort_st(dv + at[r], v[r]);
+                }
             bar += (unsigned)nblk;
             good = tsort_grid_barrier(sa.counter, bar, ok) && good;
             stamp();
 #pragma unroll
-            for (int r = 0; r < TSORT_ROUNDS; ++r) {
-                const int i = b * TSORT_PER_BLOCK + r * TSORT_THREADS + t;
-                k[r] = tsort_ld(dk + i);
-                v[r] = tsort_ld(dv + i);
-            }
+            for (int r = 0; r < TSORT_ROUNDS; ++r)
+                if (r < R) {
+                    const int i = b * per_block + r * TSORT_THREADS + t;
+                    k[r] = tsort_ld(dk + i);
+                    v[r] = tsort_ld(dv + i);
+                }
             dk = dk == sa.ka ? sa.kb : sa.ka;
             dv = dv == sa.va ? sa.vb : sa.va;
         } else {
 #pragma unroll
             for (int r = 0; r < TSORT_ROUNDS; ++r)
-                if (v[r] < (unsigned)M) {                  // the plan: sorted key, entry of the rank
+                if (r < R && v[r] < (unsigned)M) {         // the plan: sorted key, entry of the rank
                     sa.keys_out[at[r]] = k[r] == 0xffffffffu ? TOUCH_INVALID : (tkey_t)k[r];
                     sa.perm[at[r]] = (int)v[r];
                 }

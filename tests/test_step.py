@@ -464,15 +464,15 @@ def test_fused_step_rejects_bad_descriptors(be):
     assert be.lib.mpqe_step_workspace_bytes(ctypes.byref(P), SB, 17, None) == 0         # > MAX_BATCHES
 
 
-@pytest.mark.parametrize('sizes', [(9, 5), (700, 333), (3000, 1111), (11000, 2500), (45000, 10000)])
+@pytest.mark.parametrize('sizes', [(9, 5), (700, 333), (3000, 1111), (11000, 2500), (45000, 10000), (92000, 21000)])
 def test_touch_plan_one_launch_equals_library_sort(be, sizes):
     """The touch plan built in ONE launch (keys, a grid-synchronised stable 8-bit LSD radix sort with one entry per thread,
     inverse permutation: csrc/step_touch.h touch_sort_kernel; plans of up to 65 536 looked-up ids) is byte for byte the plan
     of the keys kernel + rocPRIM radix_sort_pairs (mpqe_debug_option TOUCH_ROCPRIM) -- a stable sort has one answer.
-    1 to 61 workgroups, bad ids included. (The host emulator runs workgroups one after the other and has no grid barrier:
+    1 to 256 workgroups of 2048 ids, bad ids included. (The host emulator runs workgroups one after the other and has no grid barrier:
     there both builds take the library-sort stand-in and the test only pins the layout.)"""
     if be.name == 'emu' and sizes[0] > 11000:
-        pytest.skip('250 workgroups: GPU only (the CPU suite\'s time budget)')
+        pytest.skip('125 / 256 workgroups: GPU only (the CPU suite\'s time budget)')
     rng = np.random.RandomState(sizes[0])
     nmodes, rows_per = 3, [70, 40000, 130]
     node_map = np.full(sum(rows_per) + 1, -1, np.int64)
