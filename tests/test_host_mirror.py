@@ -98,3 +98,26 @@ def test_hard_negatives_only_for_intersections(enc_case):
     model = build_model(c, 'cpu')
     with pytest.raises(Exception, match='Hard negative examples'):
         model.margin_loss(c.formula, c.queries, hard_negatives=True)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` starts its N ranks itself -- and must REFUSE (non-zero exit, no JSON line) when fewer
+    than N GPUs are visible, instead of running one rank and claiming more. No GPU here: --gpus 2 is already too many.
+    (Counting devices does not initialise the GPU runtime; the parent process never touches a GPU.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('two or more GPUs visible')
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0
+    assert b'n_gpus' not in p.stdout
+    assert b'GPU(s) visible' in p.stderr
+    # a launcher's world size that disagrees with --gpus is refused too
+    env2 = dict(env, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
+    q = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4', '--steps', '1', '--warmup', '0'],
+                       env=env2, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert q.returncode != 0 and b'WORLD_SIZE' in q.stderr
