@@ -78,6 +78,8 @@ def parse():
                          'touched-matrix bucket + row exchange')
     ap.add_argument('--debug-opt', action='append', default=[], metavar='NAME=VALUE',
                     help='timing experiments: a diagnostics switch of the library (mpqe_debug_option), e.g. TAIL_UX=0')
+    ap.add_argument('--host-ids', default='direct', choices=['direct', 'copy'],
+                    help='pack_ms loops: ids in host memory read in place from pinned memory (default) or copied per pack')
     ap.add_argument('--replay', action='store_true',
                     help='time the replay of 4 pre-packed steps (round 2\'s headline) instead of fresh ids per step')
     ap.add_argument('--touch', default='step', choices=['step', 'pack', 'atomics'],
@@ -593,7 +595,7 @@ def main():
         touch = {'step': 'step', 'pack': 'pack', 'atomics': False}[args.touch]
         fstep = FusedTrainStep(model, lanes=args.lanes, prune=not args.no_prune, chain=not args.no_chain,
                                ksplit=not args.no_ksplit, eight_waves=args.eight_waves, uniform=not args.no_uniform,
-                               touch=touch, sparse_tables=args.sparse_tables,
+                               touch=touch, sparse_tables=args.sparse_tables, host_ids=args.host_ids,
                                merge_tail=None if args.merge_tail < 0 else bool(args.merge_tail))
         packed = [pack_for_fused(fstep, d, 1.0 / world) for d in pool]
         captured = [fstep.capture(p) for p in packed] if args.graph else None
@@ -732,8 +734,8 @@ def main():
                             'dense_gradient_bytes': dense_bytes})
     if rank == 0 and use_fused and world == 1:
         # host side of a step whose ids arrive from the HOST (a data loader's numpy arrays): packing = descriptors (cached
-        # per formula) + ids into pinned staging + ONE host-to-device copy on the copy stream, overlapped with the step
-        # that is running; the step waits for its own copy only. Outside `value` (SURVEY.md 8d excludes collation;
+        # per formula) + ids into the packed step's pinned buffer, which the kernels read in place (--host-ids copy: one host-to-device copy per
+        # pack, in stream order). Outside `value` (SURVEY.md 8d excludes collation;
         # `value` itself runs on fresh ids that are already resident), reported so that it can be held against ms_per_step.
         host = StepData(schema, model, args.batch_size, np.random.RandomState(4242), device)
         torch.cuda.synchronize()

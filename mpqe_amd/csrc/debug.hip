@@ -33,7 +33,7 @@ extern "C" void mpqe_debug_option(const char *name, int value, int set) {
 }
 
 // host (pinned) -> device copy on `stream`: hipMemcpyAsync behind the C ABI, so that a host mirror without a HIP binding
-// of its own can put the ids of the next step on a copy stream (mpqe_amd/fused.py: pack)
+// of its own can send the ids of the next step with one asynchronous copy (mpqe_amd/fused.py: pack)
 extern "C" int mpqe_copy_to_device(void *dst, const void *src_host, size_t bytes, void *stream) {
     if (!dst || !src_host) return MPQE_ERR_INVALID_ARG;
     return hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, as_stream(stream)) == hipSuccess ? MPQE_OK : MPQE_ERR_LAUNCH;

@@ -27,17 +27,17 @@ class StepBuffers(object):
     a recurring set finds it resident, hand-off epochs carried on), the id buffer (when the ids came from the host) and
     the touch plan. Handed back to the step object's pool by PackedStep.__del__ -- explicit ownership: a buffer set is
     either in the pool's free list or referenced by exactly one live PackedStep."""
-    __slots__ = ('desc', 'desc_resident', 'ids', 'touch', 'touch_ptr', 'last_use', 'copied', 'skey')
+    __slots__ = ('desc', 'desc_resident', 'ids', 'stage', 'last_use', 'touch', 'touch_ptr', 'skey')
 
     def __init__(self):
-        self.desc = self.ids = self.touch = self.touch_ptr = self.last_use = self.copied = self.skey = None
+        self.desc = self.ids = self.stage = self.last_use = self.touch = self.touch_ptr = self.skey = None
         self.desc_resident = False
 
 
 class PackedStep(object):
     __slots__ = ('batches', 'nb', 'anchor_ids', 'targets', 'negs', 'num_graphs', 'ws_bytes', 'sizes',
                  'desc', 'desc_bytes', 'desc_ptr', 'lanes', 'order', 'lane_begin', 'touch',
-                 'touch_ptr', 'touch_entries', 'touch_sizes', 'bufs', 'owner', 'ids_ref', 'step_flags', 'touch_mode', 'copy_waited', 'captured')
+                 'touch_ptr', 'touch_entries', 'touch_sizes', 'bufs', 'owner', 'ids_ref', 'step_flags', 'touch_mode', 'captured')
 
     @property
     def desc_resident(self):
@@ -130,13 +130,16 @@ class FusedTrainStep(object):
     batches of equal depth together (longest chains first)."""
 
     def __init__(self, model, margin=1.0, lanes=1, prune=True, chain=True, ksplit=True, eight_waves=False,
-                 uniform=True, touch=True, sparse_tables=False, merge_tail=None):
+                 uniform=True, touch=True, sparse_tables=False, merge_tail=None, host_ids='direct'):
         """touch: how the entity-table gradients are accumulated (chain form; include/mpqe_amd.h) --
         True / 'step': per-entry gradient rows summed per table row in a fixed order, the plan (which looked-up ids share
         a row) built INSIDE the step by workgroups of its first launch (MPQE_STEP_BUILD_TOUCH): nothing id-dependent
         happens outside run(); steps too large for it fall back to 'pack'. 'pack': the same sums, the plan built by pack()
         (mpqe_step_touch_build) -- for callers that need the plan's keys before the step runs (StepExchange's row
-        exchange). False: fp32 atomics."""
+        exchange). False: fp32 atomics.
+        host_ids: how ids that arrive in host memory reach the kernels -- 'direct': the step reads them from the packed
+        step's PINNED host buffer in place (176 KB per AIFB step, each id read twice: no copy to launch or wait for);
+        'copy': one host-to-device copy per pack, in stream order (~20 us of the stream's time per step)."""
         enc = model.enc
         if not hasattr(enc, 'table') or getattr(enc, 'node_maps', None) is None:
             raise ValueError('FusedTrainStep needs a DirectEncoder built with node_maps')
@@ -155,6 +158,9 @@ class FusedTrainStep(object):
         self.uniform = bool(uniform and chain)
         if touch not in (True, False, 'step', 'pack'):
             raise ValueError("touch: True / 'step', 'pack' or False")
+        if host_ids not in ('direct', 'copy'):
+            raise ValueError("host_ids: 'direct' or 'copy'")
+        self.host_ids = host_ids
         self.touch = bool(touch and chain)
         self.touch_mode = ('pack' if touch == 'pack' or eight_waves or lanes > 1 else 'step') if self.touch else None
         # row-sparse entity-table gradients (include/mpqe_amd.h: MPQE_STEP_SPARSE_TABLES): only the rows a step's ids touch
@@ -181,7 +187,6 @@ class FusedTrainStep(object):
         self.err = ops.new_error_word(self.device)
         self._ws = None
         self._desc_cache, self._size_cache, self._pool = {}, {}, {}
-        self._copy_stream = torch.cuda.Stream(device=self.device)      # ids host -> device, beside the running step
         self.num_lanes = max(1, min(int(lanes), _capi.STEP_MAX_LANES))
         self._streams = [None] + [torch.cuda.Stream(device=self.device) for _ in range(self.num_lanes - 1)]
         self._fork = torch.cuda.Event()
@@ -270,7 +275,7 @@ class FusedTrainStep(object):
         their size (`batch_size`, or `targets` for its length). A CUDA tensor (a loader that stages ids itself, ids drawn
         on the device): pack() does no device work at all; the step reads the tensor when it runs, keep its contents
         until then. A numpy array / CPU tensor (a collate function that writes this layout directly): one copy into
-        pinned staging + one host-to-device copy on the copy stream."""
+        pinned staging + one host-to-device copy, in stream order."""
         m = self.model
         nb = len(batches)
         if nb == 0 or nb > _capi.STEP_MAX_BATCHES:
@@ -386,8 +391,8 @@ class FusedTrainStep(object):
             if len(self._pool) > 1024:
                 self._pool.clear()
             free = self._pool[skey] = []
-        # (FIFO, and at least three sets take turns before one is used again: the copy that refills a set's id buffer waits
-        # for the step that read it last -- three packs back that step is done, one pack back it is the step still running)
+        # (FIFO, and at least three sets take turns before one is used again: plan buffers a caller may still want to read
+        # -- the optimiser's row plan of the step before -- are not overwritten by the very next pack)
         if len(free) >= 3:
             bufs = free.pop(0)
         else:
@@ -403,16 +408,31 @@ class FusedTrainStep(object):
         ps.touch_entries = sz[4]
         ps.touch_sizes = (sz[2], sz[3])
         ps.touch, ps.touch_ptr = None, None
-        ps.copy_waited, ps.captured = True, False
+        ps.captured = False
         n_ids = na + 2 * ngr
         if ids is not None and torch.is_tensor(ids) and ids.is_cuda:
             if not (ids.dtype == torch.long and ids.is_contiguous() and ids.numel() == n_ids and ids.device == self.device):
                 raise ValueError('ids: a contiguous int64 tensor of %d ids (flatten_ids layout)' % n_ids)
             ps.ids_ref = dev = ids
         else:
-            # ids -> ONE pinned staging buffer (numpy views, no per-batch tensors) -> the device in ONE copy, on the copy
-            # stream: it overlaps with the step that is running; run() makes the step wait for it
-            stage = self._staging(n_ids)
+            # ids from the host. 'direct': into the PINNED buffer this packed step owns (pooled with its other buffers); the
+            # kernels read it in place -- pinned host memory is mapped into the device's address space --, so there is no
+            # copy to launch, to order or to wait for. The buffer is refilled only after the step that read it last has
+            # finished (an event per buffer set; three sets take turns, so the wait is over before it is asked for).
+            # 'copy': pinned staging ring -> ONE host-to-device copy in stream order (behind the step that read this id
+            # buffer last, in front of the one that will). (A separate copy stream with events both ways was measured
+            # too: the loop is host-bound either way and the copy sometimes queued behind the running step -- 0.078 or
+            # 0.185 ms per step by run.)
+            direct = self.host_ids == 'direct'
+            if direct:
+                if bufs.stage is None or bufs.stage.numel() < n_ids:
+                    bufs.stage = torch.empty(max(n_ids, 1 << 12), dtype=torch.long, pin_memory=True)
+                    bufs.last_use = None
+                if bufs.last_use is not None:
+                    bufs.last_use.synchronize()
+                stage = bufs.stage[:n_ids]
+            else:
+                stage = self._staging(n_ids)
             if ids is None:
                 self.flatten_ids(batches, out=stage.numpy())
             else:
@@ -422,24 +442,21 @@ class FusedTrainStep(object):
                 np.copyto(stage.numpy(), h)
             if prof is not None:
                 t1 = time.perf_counter(); prof['ids to staging'] = prof.get('ids to staging', 0.0) + t1 - t0; t0 = t1
-            if bufs.ids is None or bufs.ids.numel() < n_ids:
-                bufs.ids = torch.empty(n_ids, dtype=torch.long, device=self.device)
-                bufs.last_use = None
-            dev = bufs.ids[:n_ids]
-            cs = self._copy_stream
-            if bufs.last_use is not None:
-                cs.wait_event(bufs.last_use)          # (the step that read these ids last)
-            # (the library's own hipMemcpyAsync wrapper: `with torch.cuda.stream(...)` + copy_ is ~25 us of host time)
-            st = ops.lib().mpqe_copy_to_device(dev.data_ptr(), stage.data_ptr(), 8 * n_ids, cs.cuda_stream)
-            _capi.check(ops.lib(), st, 'mpqe_copy_to_device')
-            self._stage_events[self._stage_next].record(cs)      # the staging buffer is free again once this copy has run
-            if bufs.copied is None:
-                bufs.copied = torch.cuda.Event()
-            bufs.copied.record(cs)
-            ps.copy_waited = False
-            ps.ids_ref = bufs.ids
-            if prof is not None:
-                t1 = time.perf_counter(); prof['copy to device'] = prof.get('copy to device', 0.0) + t1 - t0; t0 = t1
+            if direct:
+                dev = stage
+                ps.ids_ref = bufs.stage
+            else:
+                if bufs.ids is None or bufs.ids.numel() < n_ids:
+                    bufs.ids = torch.empty(n_ids, dtype=torch.long, device=self.device)
+                dev = bufs.ids[:n_ids]
+                cs = torch.cuda.current_stream(self.device)
+                # (the library's own hipMemcpyAsync wrapper: copy_ through torch is ~3x the host time)
+                st = ops.lib().mpqe_copy_to_device(dev.data_ptr(), stage.data_ptr(), 8 * n_ids, cs.cuda_stream)
+                _capi.check(ops.lib(), st, 'mpqe_copy_to_device')
+                self._stage_events[self._stage_next].record(cs)      # the staging buffer is free again once this copy has run
+                ps.ids_ref = bufs.ids
+                if prof is not None:
+                    t1 = time.perf_counter(); prof['copy to device'] = prof.get('copy to device', 0.0) + t1 - t0; t0 = t1
         ps.anchor_ids, ps.targets, ps.negs = dev[:na], dev[na:na + ngr], dev[na + ngr:]
         if self.touch:
             if bufs.touch is None:
@@ -447,9 +464,6 @@ class FusedTrainStep(object):
                 bufs.touch_ptr = (bufs.touch.data_ptr() + 255) // 256 * 256
             ps.touch, ps.touch_ptr = bufs.touch, bufs.touch_ptr
             if mode == 'pack':
-                if not ps.copy_waited:
-                    torch.cuda.current_stream(self.device).wait_event(bufs.copied)
-                    ps.copy_waited = True
                 self.build_touch(ps)
             if prof is not None:
                 t1 = time.perf_counter(); prof['touch plan'] = prof.get('touch plan', 0.0) + t1 - t0
@@ -534,9 +548,6 @@ class FusedTrainStep(object):
         self.P.flags = self.flags | packed.step_flags | (_capi.STEP_ZERO_GRADS if (backward and zero_grad) else 0)
         bufs = packed.bufs
         stream = torch.cuda.current_stream(self.device)
-        if not packed.copy_waited:
-            stream.wait_event(bufs.copied)              # the ids' host-to-device copy (pack(), on the copy stream)
-            packed.copy_waited = True
         loss = torch.empty(1 + packed.nb, dtype=torch.float32, device=self.device)
         sp = sn = None
         if scores:
@@ -563,10 +574,10 @@ class FusedTrainStep(object):
             st = L.mpqe_step_forward_backward(*args)
         _capi.check(L, st, 'mpqe_step_forward_backward')
         bufs.desc_resident = True
-        if packed.ids_ref is bufs.ids and bufs.ids is not None and not packed.captured:
+        if packed.ids_ref is bufs.stage and bufs.stage is not None and not packed.captured:
             if bufs.last_use is None:
                 bufs.last_use = torch.cuda.Event()
-            bufs.last_use.record(stream)                # (the id buffer may be refilled once this step has run)
+            bufs.last_use.record(stream)                # (the pinned id buffer may be refilled once this step has run)
         if scores:
             return loss, sp, sn
         return loss

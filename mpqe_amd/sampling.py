@@ -9,7 +9,7 @@ Mersenne Twister.
 
     sampler = NegativeSampler(queries, device)                     # once per formula
     negs = sampler.sample(idx, seed)                               # idx: positions of the batch's queries
-    sampler.sample(idx, seed, out=packed.negs[lo:hi])              # or straight into a packed step
+    sampler.sample(idx, seed, out=ids[lo:hi])      # or straight into the device id tensor handed to FusedTrainStep.pack(ids=...)
 """
 import numpy as np
 import torch

@@ -296,7 +296,7 @@ def test_sparse_tables_training_loop():
 
 def test_fresh_ids_every_step_in_step_plan_equals_pack_time_plan():
     """The training-loop regime: fresh ids every step for a recurring descriptor set. The step that builds its touch
-    plan itself (default) from (a) host arrays -- staged and copied on the copy stream -- and (b) a flat id tensor
+    plan itself (default) from (a) host arrays -- staged and copied in stream order -- and (b) a flat id tensor
     already on the device, against a step object that builds the plan in pack() (touch='pack'): losses, scores and
     every gradient bit for bit, 15 steps, two packed steps alive at a time (their buffers come from the step object's
     pool and go back to it when the packed step dies)."""
