@@ -52,6 +52,8 @@ def parse():
     ap.add_argument('--batch-size', type=int, default=512)
     ap.add_argument('--readout', default='mp')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-pack-ms', action='store_true',
+                    help='skip the pack_ms record (host-side loops with ids in host memory): profiler runs, so that the per-kernel averages are those of the timed loop')
     ap.add_argument('--no-scatter', action='store_true', help='skip the roofline_scatter record (general-graph scatter-aggregate)')
     ap.add_argument('--no-self-check', action='store_true',
                     help='skip the pre-timing comparison with the module path (timing experiments with builds that are wrong on purpose)')
@@ -238,11 +240,19 @@ def exchange_check(fstep, exchange, xplan, packed):
         return 'exchange failed (%s: %s): dense form used' % (type(e).__name__, e)
 
 
-def pack_for_fused(step, data, scale=1.0):
+def pack_for_fused(step, data, scale=1.0, resident=False):
     """scale: 1 / world_size under data parallelism -- the mean over ranks is folded into the batch weights,
-    so the all-reduce (a sum) leaves the averaged gradient with no extra pass over the bucket."""
-    return step.pack([dict(formula=b['formula'], anchor_ids=b['anchor_np'], targets=b['targets_np'],
-                           negs=b['negs_np'], weight=b['weight'] * scale) for b in data.batches])
+    so the all-reduce (a sum) leaves the averaged gradient with no extra pass over the bucket.
+    resident: the ids go to HBM first (one tensor in the library's layout) and the packed step reads them there, as the
+    timed loop's steps do -- for the kernel timings and the replay figure; otherwise the ids stay in host memory (the
+    `pack_ms` loops: read in place from the packed step's pinned buffer)."""
+    batches = [dict(formula=b['formula'], anchor_ids=b['anchor_np'], targets=b['targets_np'],
+                    negs=b['negs_np'], weight=b['weight'] * scale) for b in data.batches]
+    if resident:
+        ids = torch.from_numpy(step.flatten_ids(batches)).to(step.device)
+        return step.pack([dict(formula=b['formula'], weight=b['weight'], batch_size=len(b['targets'])) for b in batches],
+                         ids=ids)
+    return step.pack(batches)
 
 
 def time_fused_kernels(step, packed, data, model, readout, reps=20):
@@ -597,7 +607,7 @@ def main():
                                ksplit=not args.no_ksplit, eight_waves=args.eight_waves, uniform=not args.no_uniform,
                                touch=touch, sparse_tables=args.sparse_tables, host_ids=args.host_ids,
                                merge_tail=None if args.merge_tail < 0 else bool(args.merge_tail))
-        packed = [pack_for_fused(fstep, d, 1.0 / world) for d in pool]
+        packed = [pack_for_fused(fstep, d, 1.0 / world, resident=True) for d in pool]
         captured = [fstep.capture(p) for p in packed] if args.graph else None
         if fresh:
             # the timed steps' inputs: per formula set its descriptors (formula, weight, size) and, resident in HBM before
@@ -732,7 +742,7 @@ def main():
                             'table_rows_gathered': int(np.mean([x.entries for x in xplans])),
                             'forms': sorted(set(x.form for x in xplans)),
                             'dense_gradient_bytes': dense_bytes})
-    if rank == 0 and use_fused and world == 1:
+    if rank == 0 and use_fused and world == 1 and not args.no_pack_ms:
         # host side of a step whose ids arrive from the HOST (a data loader's numpy arrays): packing = descriptors (cached
         # per formula) + ids into the packed step's pinned buffer, which the kernels read in place (--host-ids copy: one host-to-device copy per
         # pack, in stream order). Outside `value` (SURVEY.md 8d excludes collation;

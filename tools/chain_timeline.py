@@ -58,7 +58,7 @@ def main():
     data = bench.StepData(schema, model, args.batch_size, np.random.RandomState(1000), dev)
     step = FusedTrainStep(model, prune=not args.no_prune, merge_tail=True if (args.merge_tail or args.merged) else None,
                           touch=args.touch, eight_waves=args.eight_waves, ksplit=not args.no_ksplit)
-    packed = bench.pack_for_fused(step, data)
+    packed = bench.pack_for_fused(step, data, resident=True)       # (ids in HBM, as in the timed loop of bench.py)
     assert step.uses_chain(packed), 'this step does not take the chain kernel'
     for _ in range(5):
         step.run(packed)
