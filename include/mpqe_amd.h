@@ -18,7 +18,11 @@
  *     mpqe_debug_* entry points at the end of this file are DIAGNOSTICS:
  *     process-global, off by default, to be set from one thread while no
  *     call is in flight; nothing in the data path depends on them;
- *   - `stream` is a hipStream_t passed as void* (0 = the null stream);
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); the fused
+ *     step (mpqe_step_forward_backward) hands data from workgroup to workgroup
+ *     INSIDE its launches and expects the GPU to itself: one process per GPU
+ *     (several processes oversubscribing one GPU can exhaust its bounded spins
+ *     -> MPQE_FLAG_INTERNAL, never a hang);
  *   - every function returns MPQE_OK or a negative MPQE_ERR_* code and never
  *     synchronises. Data-dependent faults (an index outside its table) cannot
  *     be seen from the host without a sync: kernels then skip the access and
@@ -47,7 +51,12 @@ extern "C" {
 #define MPQE_FLAG_BAD_RELATION 4     /* edge type outside [0, num_relations)           */
 #define MPQE_FLAG_BAD_INDEX 8        /* scatter index outside [0, dim_size)            */
 #define MPQE_FLAG_INTERNAL 16        /* a hand-off between workgroups inside a launch did
-                                        not arrive within its spin bound (library fault)  */
+                                        not arrive within its spin bound (library fault);
+                                        bits 8.. say which (diagnostics: 0x100 a pre-pass
+                                        vector, 0x200 the transposed copies, 0x400 a
+                                        completion counter, 0x800 a vector op's inputs,
+                                        0x1000 the fused tail's arrivals, 0x2000 the
+                                        touch plan's sort)                                 */
 
 /* query templates, reference data_utils.py:325-362 */
 enum {

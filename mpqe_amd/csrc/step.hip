@@ -1002,7 +1002,7 @@ __device__ __forceinline__ void reduce_block(const ReduceArgs &ra, int bx, int b
                     const unsigned have = uop_poll(ra.arrive);
                     if ((int)(have - ra.phase1) >= 0) break;
                     if (spins >= UOP_SPIN_LIMIT) {
-                        flag_error(ra.err, MPQE_FLAG_INTERNAL);
+                        flag_error(ra.err, MPQE_FLAG_INTERNAL | 0x1000);
                         break;
                     }
 #ifndef MPQE_EMU
@@ -1026,7 +1026,7 @@ __device__ __forceinline__ void reduce_block(const ReduceArgs &ra, int bx, int b
                 *(epoch_b + 24) = 0u;       // the grid barrier of the next step's in-launch sort starts from zero (step_touch.h)
             }
             // a touch plan whose build could not finish (its workgroups were not all resident: step_touch.h)
-            if (touch && threadIdx.x == 0 && reinterpret_cast<const TouchHeader *>(touch)->pad[0]) flag_error(ra.err, MPQE_FLAG_INTERNAL);
+            if (touch && threadIdx.x == 0 && reinterpret_cast<const TouchHeader *>(touch)->pad[0]) flag_error(ra.err, MPQE_FLAG_INTERNAL | 0x2000);
             if (ra.lm.chain) loss_block_chain(ra.lm, ra.bterms, ra.loss, reinterpret_cast<float *>(part), 4);
             else loss_block(ra.sd, ra.terms, ra.loss, reinterpret_cast<float *>(part), 4);
         }

@@ -139,7 +139,7 @@ __device__ __forceinline__ f32x4 chain_gran_read4(const unsigned long long *g, u
         }
         if (ok) break;
         if (spins >= (1 << 18)) {           // (never, unless the launch is broken: report, do not hang)
-            flag_error(err, MPQE_FLAG_INTERNAL);
+            flag_error(err, MPQE_FLAG_INTERNAL | 0x100);
             break;
         }
     }
@@ -151,7 +151,7 @@ __device__ __forceinline__ float chain_gran_read1(const unsigned long long *g, u
         const unsigned long long x = chain_gran_load(g);
         if ((unsigned)(x >> 32) == tag) return __uint_as_float((unsigned)x);
         if (spins >= (1 << 18)) {
-            flag_error(err, MPQE_FLAG_INTERNAL);
+            flag_error(err, MPQE_FLAG_INTERNAL | 0x100);
             return 0.f;
         }
     }
@@ -985,7 +985,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
             unsigned have = wt_have0;
             for (int spins = 0; (int)(have - want) < 0; ++spins) {
                 if (spins >= (1 << 18)) {
-                    flag_error(ca.err, MPQE_FLAG_INTERNAL);
+                    flag_error(ca.err, MPQE_FLAG_INTERNAL | 0x200);
                     break;
                 }
 #ifndef MPQE_EMU

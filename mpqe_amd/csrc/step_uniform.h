@@ -67,7 +67,7 @@ __device__ __forceinline__ unsigned uop_poll(const unsigned *p) {
 __device__ __forceinline__ void uop_wait_until(const unsigned *p, unsigned want, int32_t *err) {
     for (int spins = 0; (int)(uop_poll(p) - want) < 0; ++spins) {
         if (spins >= UOP_SPIN_LIMIT) {
-            flag_error(err, MPQE_FLAG_INTERNAL);
+            flag_error(err, MPQE_FLAG_INTERNAL | 0x400);
             break;
         }
 #ifndef MPQE_EMU
@@ -171,7 +171,7 @@ __device__ __forceinline__ void uop_fetch_inputs(const UOp &op, const UArgs &ua,
             }
         if (!left) break;
         if (spins >= UOP_SPIN_LIMIT) {           // (never, unless the launch is broken: report instead of hanging)
-            flag_error(ua.err, MPQE_FLAG_INTERNAL);
+            flag_error(ua.err, MPQE_FLAG_INTERNAL | 0x800);
             break;
         }
 #ifndef MPQE_EMU

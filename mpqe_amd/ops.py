@@ -61,7 +61,11 @@ def raise_on_flags(err):
                                   (4, 'edge type outside [0, num_relations)'),
                                   (8, 'scatter index outside [0, dim_size)')) if flags & bit]
         if flags & 16:
-            raise RuntimeError('mpqe_amd: an in-launch hand-off between workgroups timed out (library fault)')
+            sites = [n for bit, n in ((0x100, 'a pre-pass vector'), (0x200, 'the transposed weight copies'),
+                                      (0x400, 'a completion counter'), (0x800, 'a vector op\'s inputs'),
+                                      (0x1000, 'the fused tail\'s arrivals'), (0x2000, 'the touch plan\'s sort')) if flags & bit]
+            raise RuntimeError('mpqe_amd: an in-launch hand-off between workgroups timed out (library fault): '
+                               + (', '.join(sites) or 'unknown site'))
         raise IndexError('mpqe_amd: ' + '; '.join(names))
 
 
