@@ -303,8 +303,9 @@ int mpqe_hinge_bwd(const float *pos, const float *neg, int64_t n, float margin, 
  *             OUTPUT buffer (mpqe_step_touch_bytes; valid once the call has run: mpqe_adam_rows_step and the row exchange
  *             read its keys), and a step with fresh ids costs no more than a replayed one -- nothing id-dependent is left
  *             for collation time (the reference resolves ids and accumulates embedding gradients inside forward /
- *             backward: encoders.py:40-43, data_utils.py:35). Steps of more than 524 288 looked-up ids, the level form
- *             and EIGHT_WAVES return MPQE_ERR_UNSUPPORTED: build the plan with mpqe_step_touch_build instead.       */
+ *             backward: encoders.py:40-43, data_utils.py:35). The level form has no use for a plan and leaves the buffer
+ *             alone. Steps of more than 524 288 looked-up ids, or split over stream lanes, return MPQE_ERR_UNSUPPORTED:
+ *             build the plan with mpqe_step_touch_build instead.                                              */
 #define MPQE_STEP_BUILD_TOUCH 512
 
 typedef struct {
