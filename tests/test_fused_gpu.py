@@ -222,8 +222,11 @@ def test_captured_steps_own_their_workspace(chain):
         torch.cuda.synchronize()
         np.testing.assert_array_equal(loss.cpu().numpy(), ref[name][0].cpu().numpy())
         for k, q in model.named_parameters():
-            if k.startswith('enc.'):          # entity tables: fp32 atomics, order-dependent last bits
-                np.testing.assert_allclose(q.grad.cpu().numpy(), ref[name][1][k].cpu().numpy(), rtol=1e-5, atol=1e-7)
+            if k.startswith('enc.') and not chain:
+                # level form: entity-table gradients by fp32 atomics -- the order of the additions into a popular entity's
+                # row differs from run to run (hundreds of terms: the usual gradient tolerance, not last-bit equality; a
+                # tighter bound failed once in ~10 runs)
+                np.testing.assert_allclose(q.grad.cpu().numpy(), ref[name][1][k].cpu().numpy(), rtol=1e-4, atol=1e-6)
             else:
                 assert torch.equal(q.grad, ref[name][1][k]), (name, k)
     step.check()
