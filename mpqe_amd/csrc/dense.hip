@@ -86,15 +86,26 @@ __global__ __launch_bounds__(256) void dense_grad_w_kernel(const float *__restri
                           slabs + (long long)blockIdx.x * din * dout, smem);
 }
 
-// grad_W[j][i] (+)= sum_c slab[c][i][j], chunks in order
+// grad_W[j][i] (+)= sum_c slab[c][i][j], chunks in order. Consecutive threads walk j: the nch slab reads (the bulk of the
+// traffic: nch x din x dout floats) are coalesced, the single transposed store is the strided one; eight loads in flight
+// per thread, added in chunk order (fixed order: reproducible).
 __global__ __launch_bounds__(256) void dense_reduce_w_kernel(const float *__restrict__ slabs, int nch, int din, int dout,
                                                              float *__restrict__ gW, int ldgw, int overwrite) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;      // over [dout][din]: consecutive threads = consecutive i
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;      // over [din][dout]
     if (idx >= (long long)din * dout) return;
-    const int j = (int)(idx / din), i = (int)(idx % din);
+    const int i = (int)(idx / dout), j = (int)(idx % dout);
     const long long elems = (long long)din * dout;
+    const float *p = slabs + idx;
     float s = 0.f;
-    for (int c = 0; c < nch; ++c) s += slabs[c * elems + (long long)i * dout + j];
+    int c = 0;
+    for (; c + 8 <= nch; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(long long)(c + u) * elems];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < nch; ++c) s += p[(long long)c * elems];
     float *o = gW + (long long)j * ldgw + i;
     *o = overwrite ? s : *o + s;
 }

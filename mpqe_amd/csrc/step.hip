@@ -1027,6 +1027,7 @@ __device__ __forceinline__ void reduce_block(const ReduceArgs &ra, int bx, int b
             }
             // a touch plan whose build could not finish (its workgroups were not all resident: step_touch.h)
             if (touch && threadIdx.x == 0 && reinterpret_cast<const TouchHeader *>(touch)->pad[0]) flag_error(ra.err, MPQE_FLAG_INTERNAL | 0x2000);
+            if (!ra.loss) return;
             if (ra.lm.chain) loss_block_chain(ra.lm, ra.bterms, ra.loss, reinterpret_cast<float *>(part), 4);
             else loss_block(ra.sd, ra.terms, ra.loss, reinterpret_cast<float *>(part), 4);
         }
@@ -2574,6 +2575,21 @@ extern "C" size_t mpqe_step_desc_bytes(const mpqe_step_params_t *P, const mpqe_s
     return cp ? cp->hp.desc_total : 0;
 }
 
+extern "C" int mpqe_step_states_layout(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb,
+                                       const mpqe_step_lanes_t *lanes, int64_t *states_offset, int64_t *grads_offset,
+                                       int64_t *level_stride, int64_t *row_offset) {
+    int st;
+    const std::shared_ptr<CachedPlan> cp = plan_for(P, B, nb, lanes, &st);
+    if (!cp) return st ? st : MPQE_ERR_INVALID_ARG;
+    const HostPlan &hp = cp->hp;
+    if (hp.chain) return MPQE_ERR_UNSUPPORTED;        // (the chain form keeps the node states in LDS)
+    if (states_offset) *states_offset = (int64_t)hp.o_H;
+    if (grads_offset) *grads_offset = (int64_t)hp.o_GH;
+    if (level_stride) *level_stride = (int64_t)hp.level_stride;
+    for (int i = 0; row_offset && i <= nb; ++i) row_offset[i] = i < nb ? (int64_t)hp.sd.b[i].row_off : (int64_t)hp.sd.rows_total;
+    return MPQE_OK;
+}
+
 // ---- touch plan (step_touch.h)
 static int touch_dims(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, long long *M, int *row_bits,
                       int *key_bits) {
@@ -2874,6 +2890,11 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     }
     const HostPlan &hp = cached->hp;
     const bool use_chain = hp.chain;
+    // backward = 2 / 3: the step in two calls around a readout the CALLER computes (include/mpqe_amd.h: MPQE_STEP_PHASE_*;
+    // level form, every node state live)
+    const bool phase_fwd = backward == MPQE_STEP_PHASE_STATES, phase_bwd = backward == MPQE_STEP_PHASE_FROM_STATES;
+    if (backward < 0 || backward > 3) return MPQE_ERR_INVALID_ARG;
+    if ((phase_fwd || phase_bwd) && (use_chain || hp.nlanes > 1 || P->readout != MPQE_READOUT_SUM)) return MPQE_ERR_UNSUPPORTED;
     // touch plan given: the chain form stores per-entry table-gradient rows and sums them per destination (no atomics)
     bool use_touch = touch != nullptr && use_chain && backward;
     // ... BUILD_TOUCH: `touch` is an OUTPUT -- the step builds the plan of the ids it is called with inside its chain launch
@@ -3000,7 +3021,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                         ((P->flags & MPQE_STEP_MERGE_TAIL) || hp.blk_off[nb] <= STEP_CUS + STEP_CUS / 8);
     {
         ZeroSegs &zs = pa.zs;
-        if (backward && (P->flags & MPQE_STEP_ZERO_GRADS)) {
+        if (backward && !phase_bwd && (P->flags & MPQE_STEP_ZERO_GRADS)) {     // (two-call step: the first call fills)
             auto seg = [&](float *ptr, long long n) {
                 if (!ptr || n <= 0) return;
                 // (merged launch: a root matrix that tiles / a rank-1 op of the SAME launch write whole is not zero-filled
@@ -3157,7 +3178,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     ra.zeroed = (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0;
     ra.sd = sd;
     ra.terms = terms;
-    ra.loss = loss;
+    ra.loss = phase_bwd ? nullptr : loss;       // (two-call step: the loss is the caller's)
     ra.lm = lm;
     ra.bterms = bterms;
     ra.rank1 = reinterpret_cast<const Rank1 *>(db + hp.o_rank1);
@@ -3346,7 +3367,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         mark(s);
     }
     // ---- forward
-    for (int l = 0; !use_chain && l < NL; ++l) {
+    for (int l = 0; !use_chain && !phase_bwd && l < NL; ++l) {
         const long long nr = row0[l + 1] - row0[l], ngr = gr0[l + 1] - gr0[l];
         const long long waves = nr + 2 * ngr;
         const int lpr_h = [&] { if (!vec_tab) return 64; int q = 1; while (q < 64 && q * 4 < D) q <<= 1; return q; }();
@@ -3355,7 +3376,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                            ls[l], sd, tabs, nm, (long long)P->node_map_len, P->mode_emb, (long long)P->num_modes, ids,
                            tg, ng, H, tpos, tneg, err, vec_tab, row0[l], nr, gr0[l], ngr);
     }
-    for (int p = 0; !use_chain && p < hp.Lmax; ++p)
+    for (int p = 0; !use_chain && !phase_bwd && p < hp.Lmax; ++p)
         for (int l = 0; l < NL; ++l) {
             if (p >= hp.lane_Lmax[l]) continue;
             const float *hin = H + (long long)p * hp.level_stride;
@@ -3388,6 +3409,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             (void)hipStreamWaitEvent(s, reinterpret_cast<hipEvent_t>(lanes->join_event[l]), 0);
         }
     };
+    if (phase_fwd) return mpqe_launch_status();     // the node states of every level are in the workspace (mpqe_step_states_layout)
     if (!backward) {      // (not reached with the chain kernel)
         for (int l = 0; l < NL; ++l) { LAUNCH_SCORE_D(false, (float *)nullptr, l); }
         join();
@@ -3398,7 +3420,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
 
     // ---- backward (the score kernel's backward instance writes scores and hinge terms too; the loss
     // itself is reduced by the last launch of the step)
-    for (int l = 0; !use_chain && l < NL; ++l) { LAUNCH_SCORE_D(true, GH, l); }
+    // (two-call step: the caller has written the rows of gH[L_b] itself)
+    for (int l = 0; !use_chain && !phase_bwd && l < NL; ++l) { LAUNCH_SCORE_D(true, GH, l); }
 #undef LAUNCH_SCORE_D
 #undef LAUNCH_SCORE
     for (int p = hp.Lmax - 1; !use_chain && p >= 0; --p)

@@ -7,7 +7,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _setup(readout, adaptive, shared, D=64, B=96, seed=0):
+def _setup(readout, adaptive, shared, D=64, B=96, seed=0, weight_decay=0, scatter_op='add'):
     from mpqe_amd import synthetic
     from mpqe_amd.data_utils import make_feature_modules
     from mpqe_amd.encoders import DirectEncoder
@@ -17,7 +17,8 @@ def _setup(readout, adaptive, shared, D=64, B=96, seed=0):
     graph = synthetic.SchemaGraph(schema, D)
     fm, node_maps = make_feature_modules(schema.ids, D, schema.num_entities)
     model = RGCNEncoderDecoder(graph, DirectEncoder(None, fm, node_maps), readout=readout, num_layers=3,
-                               shared_layers=shared, adaptive=adaptive, weight_decay=0).to('cuda:0')
+                               shared_layers=shared, adaptive=adaptive, weight_decay=weight_decay,
+                               scatter_op=scatter_op).to('cuda:0')
     with torch.no_grad():
         for p in model.layers.parameters():
             p.mul_(5.0)
@@ -74,6 +75,70 @@ def test_fused_step_equals_module_path(readout, adaptive, shared, lanes):
     for k, p in model.named_parameters():
         if k.startswith('layers'):
             assert torch.equal(p.grad, g1[k]), k
+
+
+@pytest.mark.parametrize('readout,adaptive,shared,scatter_op,D,host_ids', [
+    ('mlp', True, False, 'add', 64, 'direct'), ('mlp', False, True, 'max', 128, 'copy'),
+    ('targetmlp', True, True, 'add', 128, 'direct'), ('targetmlp', False, False, 'mean', 64, 'copy')])
+def test_fused_step_with_learned_readout_equals_module_path(readout, adaptive, shared, scatter_op, D, host_ids):
+    """MLPReadout / TargetMLPReadout (reference model.py:497-553) through the fused step: two library calls around the
+    readout of all batches at once (FusedTrainStep._run_states). Against the module path's margin_loss arithmetic,
+    regulariser included (model.py:486-490)."""
+    from mpqe_amd import ops
+    from mpqe_amd.fused import FusedTrainStep
+    wd = 1e-3
+    model, batches = _setup(readout, adaptive, shared, D=D, weight_decay=wd, scatter_op=scatter_op)
+    model.zero_grad(set_to_none=True)
+    total, sp_ref, sn_ref, per = None, [], [], []
+    for b in batches:
+        out = model.encode(b['formula'], b['queries'])
+        pos = model.score(b['formula'], out, b['targets'].tolist())
+        neg = model.score(b['formula'], out, b['negs'].tolist())
+        h = ops.hinge(pos, neg, 1.0)
+        per.append(h.item())
+        l = (h + wd * sum(torch.norm(p) for p in model.readout.parameters())) * b['weight']
+        total = l if total is None else total + l
+        sp_ref.append(pos.detach())
+        sn_ref.append(neg.detach())
+    total.backward()
+    ref = {k: (torch.zeros_like(p) if p.grad is None else p.grad.clone()) for k, p in model.named_parameters()}
+    step = FusedTrainStep(model, host_ids=host_ids)
+    assert step.external
+    packed = step.pack(batches)
+    with torch.no_grad():
+        step.flat_grad.fill_(3.0)                # zero_grad covers the readout's parameters too
+    loss, sp, sn = step.run(packed, scores=True)
+    step.check()
+    np.testing.assert_allclose(loss[0].item(), total.item(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(loss[1:].cpu().numpy(), np.array(per, np.float32), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sp.cpu().numpy(), torch.cat(sp_ref).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sn.cpu().numpy(), torch.cat(sn_ref).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    for k, p in model.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref[k].cpu().numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+    # accumulate on top (zero_grad=False): twice the gradient; forward only: the same loss, gradients untouched
+    step.run(packed, zero_grad=False)
+    for k, p in model.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), 2 * ref[k].cpu().numpy(), rtol=1e-4, atol=4e-6, err_msg=k)
+    keep = step.flat_grad.clone()
+    l2 = step.run(packed, backward=False)
+    np.testing.assert_allclose(l2[0].item(), total.item(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(step.flat_grad, keep)
+    # fresh ids through the same descriptor set (pooled buffers, cached index plan)
+    rng = np.random.RandomState(5)
+    for b in batches:
+        rng.shuffle(b['negs'])
+    p3 = step.pack(batches)
+    l3 = step.run(p3)
+    step.check()
+    assert np.isfinite(l3.cpu().numpy()).all() and abs(l3[0].item() - total.item()) > 0
+    # the whole step (both library calls and the readout's autograd between them) replayed from a hipGraph
+    g3 = step.flat_grad.clone()
+    cap = step.capture(p3)
+    step.flat_grad.fill_(-1.0)
+    l4 = cap.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(l4.cpu().numpy(), l3.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(step.flat_grad.cpu().numpy(), g3.cpu().numpy(), rtol=1e-4, atol=2e-6)
 
 
 def test_fused_step_bad_id_is_reported():
