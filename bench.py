@@ -193,9 +193,10 @@ def self_check(model, fstep, packed, data, world):
         raise SystemExit(3)
 
 
-def fresh_check(fstep, desc, ids, data):
+def fresh_check(fstep, desc, ids, data, exact=True):
     """The timed loop's form of a step -- descriptors + a flat id tensor already on the device, the touch plan built
-    inside the step -- against pack() from host arrays of the same ids: same loss and gradients, bit for bit."""
+    inside the step -- against pack() from host arrays of the same ids: same loss and gradients, bit for bit (exact;
+    the level form under the learned readouts adds table gradients with fp32 atomics: gradient tolerance there)."""
     loss_a = fstep.run(fstep.pack(desc, ids=ids)).clone()
     ga = fstep.flat_grad.clone()
     h = ids.cpu().numpy()
@@ -211,7 +212,9 @@ def fresh_check(fstep, desc, ids, data):
         og += B
     loss_b = fstep.run(fstep.pack(batches))
     fstep.check()
-    if not (torch.equal(loss_a, loss_b) and torch.equal(ga, fstep.flat_grad)):
+    same = (torch.equal(loss_a, loss_b) and torch.equal(ga, fstep.flat_grad)) if exact else \
+        (torch.allclose(loss_a, loss_b, rtol=1e-5, atol=1e-6) and torch.allclose(ga, fstep.flat_grad, rtol=1e-4, atol=2e-6))
+    if not same:
         sys.stderr.write('bench self-check FAILED: device-resident ids vs host ids differ\n')
         raise SystemExit(3)
 
@@ -596,7 +599,8 @@ def main():
     rng = np.random.RandomState(1000 + rank)
     pool = [StepData(schema, model, args.batch_size, rng, device) for _ in range(4)]      # 4 formula sets
 
-    use_fused = args.path in ('auto', 'fused') and args.readout in ('mp', 'sum', 'max')
+    use_fused = args.path in ('auto', 'fused') and args.readout in ('mp', 'sum', 'max', 'mlp', 'targetmlp')
+    learned = args.readout in ('mlp', 'targetmlp')        # (fused step = three library calls around the readout: fused.py)
     fresh = use_fused and not args.replay and not args.graph
     reducer = fstep = packed = captured = exchange = xplans = fresh_ids = descs = None
     n_total = args.warmup + args.steps * max(1, args.repeats)
@@ -655,7 +659,7 @@ def main():
     if use_fused and not args.no_self_check and not args.sparse_tables:      # (the check compares DENSE gradients)
         self_check(model, fstep, packed[0], pool[0], world)
         if fresh:
-            fresh_check(fstep, descs[0], fresh_ids[0][0], pool[0])
+            fresh_check(fstep, descs[0], fresh_ids[0][0], pool[0], exact=not learned)
     xnote = None
     if exchange is not None:
         # the exchange against the literal dense all-reduce on one step (N-rank hardware is not available to the tests):
@@ -719,11 +723,13 @@ def main():
                    'global_query_graphs_per_step': graphs_per_step,
                    'parallelism': 'dp%d (graphs sharded by rank, RCCL all-reduce of gradients)' % world
                                   if world > 1 else 'single GPU',
-                   'host_path': 'fused step: one C-ABI call per step, %d stream lane(s)%s'
-                                % (args.lanes, ', replayed from a hipGraph' if args.graph else '') if use_fused
+                   'host_path': ('fused step: %s per step, %d stream lane(s)%s'
+                                 % ('three C-ABI calls around the learned readout of all batches' if learned else 'one C-ABI call',
+                                    args.lanes, ', replayed from a hipGraph' if args.graph else '')) if use_fused
                                 else 'drop-in modules (one autograd graph per step)',
                    'ids': ('fresh every step: %d pre-drawn id sets resident in HBM, 4 formula sets; id -> row lookups and the '
-                           'touch plan (%s) inside the timed step' % (sum(int(t.shape[0]) for t in fresh_ids), args.touch))
+                           '%s inside the timed step' % (sum(int(t.shape[0]) for t in fresh_ids),
+                                                         'table gradients by fp32 atomics' if learned else 'touch plan (%s)' % args.touch))
                           if fresh else 'replay of 4 pre-packed steps'},
     }
     if replay_ms is not None:
@@ -803,7 +809,8 @@ def main():
                                   '+ step; flat_host_ids_loop_per_step: host ids already in the library layout -> copy + step'}
     if rank == 0:
         flops_fwd, flops_all, bytes_all, launches = layer_work(pool[0], model)
-        if use_fused:
+        executed = None
+        if use_fused and not learned:
             fams, executed = time_fused_kernels(fstep, packed[0], pool[0], model, args.readout)
             dom = max(fams, key=lambda f: f['total_us_per_step'])
             out['roofline'] = {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['achieved'],
@@ -833,11 +840,14 @@ def main():
                                'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
                                'avg_launch_us': dur * 1e6, 'algorithmic_flops_per_launch': per_launch_flops,
                                'launches_per_step': launches}
+            if learned and use_fused:
+                out['roofline']['note'] = ('the layer tile core timed through the module path\'s launch (one batch per launch); the '
+                                           'fused three-call step runs the same core over all batches of a level per launch')
         if world == 1 and not args.no_scatter:
             out['roofline_scatter'] = time_scatter_aggregate()
         out['step_work'] = {'layer_flops_fwd_bwd': flops_all, 'scatter_aggregate_bytes_fwd_bwd': bytes_all,
                             'layer_tflops_over_whole_step': flops_all / (elapsed / args.steps) / 1e12}
-        if use_fused:       # flops_all is SURVEY 8d's count (every node state); executed = after pruning
+        if executed is not None:       # flops_all is SURVEY 8d's count (every node state); executed = after pruning
             out['step_work']['layer_flops_executed'] = executed
             out['step_work']['executed_tflops_over_whole_step'] = executed / (elapsed / args.steps) / 1e12
         if world == 1 and not args.no_cpu_baseline:

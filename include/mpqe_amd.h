@@ -63,7 +63,8 @@ enum {
     MPQE_Q_1CHAIN = 0, MPQE_Q_2CHAIN = 1, MPQE_Q_3CHAIN = 2, MPQE_Q_2INTER = 3,
     MPQE_Q_3INTER = 4, MPQE_Q_3INTER_CHAIN = 5, MPQE_Q_3CHAIN_INTER = 6, MPQE_Q_COUNT = 7
 };
-enum { MPQE_READOUT_SUM = 0, MPQE_READOUT_MAX = 1, MPQE_READOUT_TM = 2 };
+enum { MPQE_READOUT_SUM = 0, MPQE_READOUT_MAX = 1, MPQE_READOUT_TM = 2,
+       MPQE_READOUT_CALLER = 3 /* fused step only: the readout is the caller's (MPQE_STEP_PHASE_*) */ };
 enum { MPQE_SCATTER_ADD = 0, MPQE_SCATTER_MAX = 1, MPQE_SCATTER_MEAN = 2 };
 #define MPQE_MAX_TEMPLATE_EDGES 3
 #define MPQE_MAX_TEMPLATE_NODES 4
@@ -392,26 +393,34 @@ int mpqe_step_touch_build(const mpqe_step_params_t *params_host, const mpqe_step
  * kernel runs (dim 64 / 128 / 256, MPQE_STEP_NO_CHAIN clear, every batch at most 5 passes) the order is: for each lane its chain launch (assemble, levels forward, scores,
  * levels backward), then for each lane its weight-gradient launch. Fewer are filled as far as they go.
  * For roofline accounting only.                                                                     */
-/* backward = MPQE_STEP_PHASE_STATES / MPQE_STEP_PHASE_FROM_STATES: the step in TWO calls around a readout the caller
- * computes itself -- the learned readouts of the reference (MLPReadout / TargetMLPReadout, model.py:497-553), whose
- * Linear layers are the caller's (mpqe_linear_fwd / bwd). Level form only (MPQE_STEP_NO_CHAIN), one lane, readout =
- * MPQE_READOUT_SUM in the params (every node state is then live); anything else returns MPQE_ERR_UNSUPPORTED.
+/* readout = MPQE_READOUT_CALLER: the step in THREE calls around a readout the caller computes itself -- the learned
+ * readouts of the reference (MLPReadout / TargetMLPReadout, model.py:497-553), whose Linear layers are the caller's
+ * (mpqe_linear_fwd / bwd); everything else of the step stays in the library. `backward` then names the call; the
+ * level form runs (node states in HBM, every state live), one lane. Same params / batches / ids / desc / workspace in all
+ * calls; upload_desc as usual in the first, 0 afterwards. (readout CALLER with backward 0 / 1, or a phase with another
+ * readout: MPQE_ERR_INVALID_ARG.)
  *   PHASE_STATES       zero fill (MPQE_STEP_ZERO_GRADS), gather, every level forward. Afterwards the node states of
  *                      level p are rows [rows_total, dim] at workspace + states_offset + 4 * p * level_stride
  *                      (mpqe_step_states_layout); batch b's graphs own rows row_offset[b] + g * N_b + n, and its final
- *                      states are those of level num_passes_b. loss / scores are not written.
+ *                      states are those of level num_passes_b.
+ *   PHASE_SCORES       the caller has written the query embeddings [graphs_total, dim] (batch order) at workspace +
+ *                      queries_offset: cosine scores against the targets / negatives, hinge terms, d loss / d embedding
+ *                      to workspace + query_grads_offset, the targets' / negatives' entity-table gradients into grads.
+ *                      scores_pos / scores_neg are written.
  *   PHASE_FROM_STATES  the caller has put d loss / d (final state) into the same rows of the gradient levels
- *                      (workspace + grads_offset + ...) -- every row of a batch's final level --; the call runs the
- *                      levels backward, the weight / bias / mode-vector gradients, the anchors' entity-table gradients
- *                      and the reduction, ADDING into grads (no zero fill: the first call did it, and the caller's own
- *                      target / negative table gradients are already there). loss / scores are not written.
- * Same params / batches / ids / desc / workspace in both calls; upload_desc as usual in the first, 0 in the second.  */
+ *                      (workspace + grads_offset + ...) -- every row of a batch's final level --: levels backward,
+ *                      weight / bias / mode-vector gradients, the anchors' entity-table gradients, the reduction;
+ *                      `loss` is written.
+ *   PHASE_SCORES_ONLY  PHASE_SCORES without gradients, and `loss` written: the forward-only step (grads may be NULL). */
 #define MPQE_STEP_PHASE_STATES 2
-#define MPQE_STEP_PHASE_FROM_STATES 3
+#define MPQE_STEP_PHASE_SCORES 3
+#define MPQE_STEP_PHASE_FROM_STATES 4
+#define MPQE_STEP_PHASE_SCORES_ONLY 5
 int mpqe_step_states_layout(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,
                             int num_batches, const mpqe_step_lanes_t *lanes, int64_t *states_offset /* bytes */,
                             int64_t *grads_offset /* bytes */, int64_t *level_stride /* floats */,
-                            int64_t *row_offset /* [num_batches + 1], rows */);
+                            int64_t *row_offset /* [num_batches + 1], rows */, int64_t *queries_offset /* bytes */,
+                            int64_t *query_grads_offset /* bytes */);
 int mpqe_step_forward_backward(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,
                                int num_batches, const int64_t *anchor_ids, const int64_t *targets,
                                const int64_t *negs, float margin, const mpqe_step_grads_t *grads_host,

@@ -106,6 +106,7 @@ PROTOTYPES = {
     'mpqe_step_desc_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, ctypes.POINTER(StepLanes)]),
     'mpqe_step_states_layout': (I, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, ctypes.POINTER(StepLanes),
                                     ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                                    ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                     ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     'mpqe_step_forward_backward': (I, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, P, P, P, F,
                                        ctypes.POINTER(StepGrads), I, P, P, P, P, Z, I, P, Z, P, ctypes.POINTER(StepLanes),
@@ -124,6 +125,7 @@ QUERY_TYPE_IDS = {'1-chain': 0, '2-chain': 1, '3-chain': 2, '2-inter': 3, '3-int
                   '3-inter_chain': 5, '3-chain_inter': 6}
 QUERY_NAMES = {v: k for k, v in QUERY_TYPE_IDS.items()}
 READOUT_IDS = {'sum': 0, 'max': 1, 'mp': 2}
+READOUT_CALLER = 3          # fused step only: the readout is the caller's (STEP_PHASE_*)
 SCATTER_IDS = {'add': 0, 'max': 1, 'mean': 2}
 
 FLAG_BAD_NODE_ID, FLAG_BAD_EDGE, FLAG_BAD_RELATION, FLAG_BAD_INDEX = 1, 2, 4, 8
@@ -159,7 +161,8 @@ STEP_SPARSE_TABLES = 64
 STEP_MERGE_TAIL = 128
 STEP_SPLIT_TAIL = 256
 STEP_BUILD_TOUCH = 512
-STEP_PHASE_STATES, STEP_PHASE_FROM_STATES = 2, 3      # `backward` values of the two-call step (learned readouts)
+# `backward` values of the step in three calls around the caller's readout (learned readouts; include/mpqe_amd.h)
+STEP_PHASE_STATES, STEP_PHASE_SCORES, STEP_PHASE_FROM_STATES, STEP_PHASE_SCORES_ONLY = 2, 3, 4, 5
 TSORT_MAX_ENTRIES = 256 * 2048        # csrc/step_touch.h: the in-step touch plan covers this many looked-up ids
 
 

@@ -618,7 +618,9 @@ __global__ __launch_bounds__(256) void step_score_kernel(
     const float *__restrict__ tpos, const float *__restrict__ tneg, float margin, float eps,
     float *__restrict__ s_pos, float *__restrict__ s_neg, float *__restrict__ terms,
     float *__restrict__ GH, TablePtrs tabs, const long long *__restrict__ node_map, long long map_len,
-    const long long *__restrict__ targets, const long long *__restrict__ negs, long long g0, long long ng) {
+    const long long *__restrict__ targets, const long long *__restrict__ negs, long long g0, long long ng,
+    const float *__restrict__ Q, float *__restrict__ GQ) {
+    // Q != NULL (MPQE_READOUT_CALLER): the query embedding of graph gi is row gi of Q, its gradient goes to row gi of GQ
     const long long gl = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (gl >= ng) return;
@@ -640,7 +642,7 @@ __global__ __launch_bounds__(256) void step_score_kernel(
         q[j] = 0.f;
         arg[j] = 0;
         if (c < D) {
-            q[j] = readout_value(sd->readout, h, N, A, D, c, &arg[j]);
+            q[j] = Q ? Q[gi * D + c] : readout_value(sd->readout, h, N, A, D, c, &arg[j]);
             const float a = tp_[c], bb = tn_[c];
             dp += q[j] * a;
             dn += q[j] * bb;
@@ -697,7 +699,8 @@ __global__ __launch_bounds__(256) void step_score_kernel(
             }
             const float gq = gsp * tp_[c] * inv_p + gsn * tn_[c] * inv_n - kq * q[j];
             float *gh = GH + (long long)b.L * level_stride + row0 * D + c;
-            for (int n = 0; n < N; ++n) {
+            if (Q) GQ[gi * D + c] = gq;
+            for (int n = 0; n < N && !Q; ++n) {
                 float gv;
                 if (sd->readout == MPQE_READOUT_SUM) gv = gq;
                 else if (sd->readout == MPQE_READOUT_TM) gv = n == A ? gq : 0.f;
@@ -1027,7 +1030,6 @@ __device__ __forceinline__ void reduce_block(const ReduceArgs &ra, int bx, int b
             }
             // a touch plan whose build could not finish (its workgroups were not all resident: step_touch.h)
             if (touch && threadIdx.x == 0 && reinterpret_cast<const TouchHeader *>(touch)->pad[0]) flag_error(ra.err, MPQE_FLAG_INTERNAL | 0x2000);
-            if (!ra.loss) return;
             if (ra.lm.chain) loss_block_chain(ra.lm, ra.bterms, ra.loss, reinterpret_cast<float *>(part), 4);
             else loss_block(ra.sd, ra.terms, ra.loss, reinterpret_cast<float *>(part), 4);
         }
@@ -1399,7 +1401,7 @@ struct HostPlan {
     size_t o_cref, o_cops, o_wtslots, o_WT;
     // workspace offsets (bytes)
     size_t o_sd, o_wsrc, o_wblock, o_vsrc, o_vblock, o_groups, o_anchor, desc_total;     // descriptor buffer
-    size_t o_H, o_GH, o_tpos, o_tneg, o_spos, o_sneg, o_terms, o_slabs, o_parts, total;  // workspace
+    size_t o_H, o_GH, o_tpos, o_tneg, o_spos, o_sneg, o_terms, o_slabs, o_parts, o_Q, o_GQ, total;  // workspace
     long long level_stride;
 };
 
@@ -1460,7 +1462,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     if (P->dim <= 0 || P->dim > 64 * STEP_MAX_COLS_PER_LANE) return MPQE_ERR_UNSUPPORTED;
     if (P->num_layers <= 0 || P->num_layers > MPQE_STEP_MAX_LAYERS) return MPQE_ERR_UNSUPPORTED;
     if (P->num_modes <= 0 || P->num_modes > MPQE_STEP_MAX_MODES) return MPQE_ERR_UNSUPPORTED;
-    if (P->readout < 0 || P->readout > 2) return MPQE_ERR_INVALID_ARG;
+    if (P->readout < 0 || P->readout > MPQE_READOUT_CALLER) return MPQE_ERR_INVALID_ARG;
     const int D = P->dim;
     StepDev &sd = hp->sd;
     memset(&sd, 0, sizeof(sd));
@@ -2395,6 +2397,9 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->o_spos = take((size_t)graphs * 4);
     hp->o_sneg = take((size_t)graphs * 4);
     hp->o_terms = take((size_t)graphs * 4);
+    // (the caller's readout: its query embeddings in, their gradients out)
+    hp->o_Q = take(P->readout == MPQE_READOUT_CALLER ? (size_t)graphs * D * 4 : 0);
+    hp->o_GQ = take(P->readout == MPQE_READOUT_CALLER ? (size_t)graphs * D * 4 : 0);
     hp->o_slabs = take((size_t)hp->total_slabs * D * D * 4);
     hp->o_parts = take((size_t)hp->total_parts * D * 4);
     hp->o_WT = take(hp->wt_slots.size() * (size_t)D * D * 4);
@@ -2545,7 +2550,8 @@ static std::shared_ptr<CachedPlan> plan_for(const mpqe_step_params_t *P, const m
 
 static bool want_chain(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb) {
     if (!P || !B || nb < 1 || nb > MPQE_STEP_MAX_BATCHES) return false;
-    bool use_chain = !(P->flags & MPQE_STEP_NO_CHAIN) && (P->dim == 64 || P->dim == 128 || P->dim == 256);
+    bool use_chain = !(P->flags & MPQE_STEP_NO_CHAIN) && (P->dim == 64 || P->dim == 128 || P->dim == 256) &&
+                     P->readout != MPQE_READOUT_CALLER;      // (the caller's readout needs the node states in HBM)
     if (!use_chain) return false;
     long long graphs = 0;
     for (int i = 0; i < nb; ++i) graphs += B[i].batch_size;
@@ -2577,15 +2583,18 @@ extern "C" size_t mpqe_step_desc_bytes(const mpqe_step_params_t *P, const mpqe_s
 
 extern "C" int mpqe_step_states_layout(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb,
                                        const mpqe_step_lanes_t *lanes, int64_t *states_offset, int64_t *grads_offset,
-                                       int64_t *level_stride, int64_t *row_offset) {
+                                       int64_t *level_stride, int64_t *row_offset, int64_t *queries_offset,
+                                       int64_t *query_grads_offset) {
     int st;
     const std::shared_ptr<CachedPlan> cp = plan_for(P, B, nb, lanes, &st);
     if (!cp) return st ? st : MPQE_ERR_INVALID_ARG;
     const HostPlan &hp = cp->hp;
-    if (hp.chain) return MPQE_ERR_UNSUPPORTED;        // (the chain form keeps the node states in LDS)
+    if (hp.chain || P->readout != MPQE_READOUT_CALLER) return MPQE_ERR_UNSUPPORTED;        // (the chain form keeps the node states in LDS)
     if (states_offset) *states_offset = (int64_t)hp.o_H;
     if (grads_offset) *grads_offset = (int64_t)hp.o_GH;
     if (level_stride) *level_stride = (int64_t)hp.level_stride;
+    if (queries_offset) *queries_offset = (int64_t)hp.o_Q;
+    if (query_grads_offset) *query_grads_offset = (int64_t)hp.o_GQ;
     for (int i = 0; row_offset && i <= nb; ++i) row_offset[i] = i < nb ? (int64_t)hp.sd.b[i].row_off : (int64_t)hp.sd.rows_total;
     return MPQE_OK;
 }
@@ -2890,11 +2899,15 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     }
     const HostPlan &hp = cached->hp;
     const bool use_chain = hp.chain;
-    // backward = 2 / 3: the step in two calls around a readout the CALLER computes (include/mpqe_amd.h: MPQE_STEP_PHASE_*;
-    // level form, every node state live)
-    const bool phase_fwd = backward == MPQE_STEP_PHASE_STATES, phase_bwd = backward == MPQE_STEP_PHASE_FROM_STATES;
-    if (backward < 0 || backward > 3) return MPQE_ERR_INVALID_ARG;
-    if ((phase_fwd || phase_bwd) && (use_chain || hp.nlanes > 1 || P->readout != MPQE_READOUT_SUM)) return MPQE_ERR_UNSUPPORTED;
+    // backward = 2 .. 5: the step in three calls around a readout the CALLER computes (include/mpqe_amd.h: MPQE_STEP_PHASE_*,
+    // MPQE_READOUT_CALLER; level form, every node state live)
+    const int phase = backward;
+    if (phase < 0 || phase > MPQE_STEP_PHASE_SCORES_ONLY) return MPQE_ERR_INVALID_ARG;
+    const bool phase_fwd = phase == MPQE_STEP_PHASE_STATES, phase_bwd = phase == MPQE_STEP_PHASE_FROM_STATES;
+    const bool phase_score = phase == MPQE_STEP_PHASE_SCORES || phase == MPQE_STEP_PHASE_SCORES_ONLY;
+    if ((phase >= 2) != (P->readout == MPQE_READOUT_CALLER)) return MPQE_ERR_INVALID_ARG;
+    if (phase >= 2 && (use_chain || hp.nlanes > 1)) return MPQE_ERR_UNSUPPORTED;
+    if (phase == MPQE_STEP_PHASE_SCORES_ONLY) backward = 0;        // (scores and loss from the caller's embeddings, no gradients)
     // touch plan given: the chain form stores per-entry table-gradient rows and sums them per destination (no atomics)
     bool use_touch = touch != nullptr && use_chain && backward;
     // ... BUILD_TOUCH: `touch` is an OUTPUT -- the step builds the plan of the ids it is called with inside its chain launch
@@ -3021,7 +3034,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                         ((P->flags & MPQE_STEP_MERGE_TAIL) || hp.blk_off[nb] <= STEP_CUS + STEP_CUS / 8);
     {
         ZeroSegs &zs = pa.zs;
-        if (backward && !phase_bwd && (P->flags & MPQE_STEP_ZERO_GRADS)) {     // (two-call step: the first call fills)
+        if (backward && !phase_bwd && !phase_score && (P->flags & MPQE_STEP_ZERO_GRADS)) {     // (step in several calls: the first one fills)
             auto seg = [&](float *ptr, long long n) {
                 if (!ptr || n <= 0) return;
                 // (merged launch: a root matrix that tiles / a rank-1 op of the SAME launch write whole is not zero-filled
@@ -3178,7 +3191,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     ra.zeroed = (P->flags & MPQE_STEP_ZERO_GRADS) ? 1 : 0;
     ra.sd = sd;
     ra.terms = terms;
-    ra.loss = phase_bwd ? nullptr : loss;       // (two-call step: the loss is the caller's)
+    ra.loss = loss;
     ra.lm = lm;
     ra.bterms = bterms;
     ra.rank1 = reinterpret_cast<const Rank1 *>(db + hp.o_rank1);
@@ -3367,7 +3380,9 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         mark(s);
     }
     // ---- forward
-    for (int l = 0; !use_chain && !phase_bwd && l < NL; ++l) {
+    const float *Qc = P->readout == MPQE_READOUT_CALLER ? reinterpret_cast<const float *>(wb + hp.o_Q) : nullptr;
+    float *GQc = P->readout == MPQE_READOUT_CALLER ? reinterpret_cast<float *>(wb + hp.o_GQ) : nullptr;
+    for (int l = 0; !use_chain && !phase_bwd && !phase_score && l < NL; ++l) {
         const long long nr = row0[l + 1] - row0[l], ngr = gr0[l + 1] - gr0[l];
         const long long waves = nr + 2 * ngr;
         const int lpr_h = [&] { if (!vec_tab) return 64; int q = 1; while (q < 64 && q * 4 < D) q <<= 1; return q; }();
@@ -3376,7 +3391,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                            ls[l], sd, tabs, nm, (long long)P->node_map_len, P->mode_emb, (long long)P->num_modes, ids,
                            tg, ng, H, tpos, tneg, err, vec_tab, row0[l], nr, gr0[l], ngr);
     }
-    for (int p = 0; !use_chain && !phase_bwd && p < hp.Lmax; ++p)
+    for (int p = 0; !use_chain && !phase_bwd && !phase_score && p < hp.Lmax; ++p)
         for (int l = 0; l < NL; ++l) {
             if (p >= hp.lane_Lmax[l]) continue;
             const float *hin = H + (long long)p * hp.level_stride;
@@ -3397,7 +3412,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     hipLaunchKernelGGL((step_score_kernel<BWD, NJ>), dim3((unsigned)((gr0[L + 1] - gr0[L] + 3) / 4)), dim3(256), 0, \
                        ls[L], sd, (const float *)H, hp.level_stride, (const float *)tpos, (const float *)tneg,     \
                        margin, 1e-8f, spos, sneg, terms, GHP, tabs, nm, (long long)P->node_map_len, tg, ng, gr0[L], \
-                       gr0[L + 1] - gr0[L])
+                       gr0[L + 1] - gr0[L], (const float *)Qc, GQc)
 #define LAUNCH_SCORE_D(BWD, GHP, L)                  \
     if (D <= 64) LAUNCH_SCORE(BWD, 1, GHP, L);       \
     else if (D <= 128) LAUNCH_SCORE(BWD, 2, GHP, L); \
@@ -3420,8 +3435,10 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
 
     // ---- backward (the score kernel's backward instance writes scores and hinge terms too; the loss
     // itself is reduced by the last launch of the step)
-    // (two-call step: the caller has written the rows of gH[L_b] itself)
+    // (the caller's readout: its own call for the scores -- embeddings in, their gradients out --, then the caller writes the
+    // rows of gH[L_b] and the last call takes it from there)
     for (int l = 0; !use_chain && !phase_bwd && l < NL; ++l) { LAUNCH_SCORE_D(true, GH, l); }
+    if (phase_score) return mpqe_launch_status();
 #undef LAUNCH_SCORE_D
 #undef LAUNCH_SCORE
     for (int p = hp.Lmax - 1; !use_chain && p >= 0; --p)

@@ -144,8 +144,8 @@ class FusedTrainStep(object):
         enc = model.enc
         if not hasattr(enc, 'table') or getattr(enc, 'node_maps', None) is None:
             raise ValueError('FusedTrainStep needs a DirectEncoder built with node_maps')
-        # learned readouts (reference model.py:497-553): the step runs in two library calls around the readout, whose
-        # Linear layers, scatter, scores and hinge run here on the states of ALL batches at once (_run_states)
+        # learned readouts (reference model.py:497-553): the step runs in three library calls around the readout, whose
+        # Linear layers and scatter run here on the final states of ALL batches at once (_run_states)
         self.external = model.readout_str in ('mlp', 'targetmlp')
         if not self.external and model.readout_str not in _capi.READOUT_IDS:
             raise NotImplementedError('fused step covers readouts sum / max / mp / mlp / targetmlp; %r runs through the '
@@ -153,8 +153,7 @@ class FusedTrainStep(object):
         if self.external:
             if sparse_tables:
                 raise ValueError('sparse_tables needs the chain form (readouts sum / max / mp)')
-            # (ids from the host always go to the device in one copy: the readout's target look-ups are torch ops on them)
-            chain, touch, lanes, host_ids = False, False, 1, 'copy'
+            chain, touch, lanes = False, False, 1
         self.model = model
         self.margin = float(margin)
         # speed switches of the library call (include/mpqe_amd.h): identical loss / scores / gradients
@@ -231,7 +230,8 @@ class FusedTrainStep(object):
                 raise RuntimeError('parameters must be contiguous fp32 CUDA tensors')
         layers = list(m.layers)
         self.P = _capi.make_step_params(
-            m.emb_dim, layers[0].num_relations, 'sum' if self.external else m.readout_str, [t.data_ptr() for t in tabs],
+            m.emb_dim, layers[0].num_relations, _capi.READOUT_CALLER if self.external else m.readout_str,
+            [t.data_ptr() for t in tabs],
             [t.shape[0] for t in tabs], m.enc.node_maps.data_ptr(), m.enc.node_maps.shape[0],
             m.mode_embeddings.weight.data_ptr(), [l.basis.data_ptr() for l in layers],
             [l.root.data_ptr() for l in layers], [l.bias.data_ptr() for l in layers], flags=self.flags)
@@ -555,7 +555,7 @@ class FusedTrainStep(object):
             self.bind_grads()
         if self.external:
             if events is not None:
-                raise ValueError('events: not with a learned readout (the step is two library calls)')
+                raise ValueError('events: not with a learned readout (the step is three library calls)')
             return self._run_states(packed, backward, zero_grad, scores, workspace)
         # the library zero-fills the gradient buffers itself (one launch with its other prologue work)
         self.P.flags = self.flags | packed.step_flags | (_capi.STEP_ZERO_GRADS if (backward and zero_grad) else 0)
@@ -595,71 +595,62 @@ class FusedTrainStep(object):
             return loss, sp, sn
         return loss
 
-    # ------------------------------------------------------------------ learned readouts: the step in two library calls
+    # ------------------------------------------------------------------ learned readouts: the step in three library calls
     def _states_plan(self, packed):
-        """Index tensors of a descriptor set for the readout between the two calls (cached per set: functions of the
-        formulas and batch sizes alone)."""
+        """Workspace offsets and index tensors of a descriptor set for the readout between the calls (cached per set:
+        functions of the formulas and batch sizes alone)."""
         plan = self._states_cache.get(packed.skey)
         if plan is not None:
             return plan
         nb, dev = packed.nb, self.device
         i64 = ctypes.c_int64
-        so, go, ls, ro = i64(), i64(), i64(), (i64 * (nb + 1))()
+        so, go, ls, ro, qo, gqo = i64(), i64(), i64(), (i64 * (nb + 1))(), i64(), i64()
         st = ops.lib().mpqe_step_states_layout(ctypes.byref(self.P), packed.batches, nb, packed.lanes, ctypes.byref(so),
-                                              ctypes.byref(go), ctypes.byref(ls), ro)
+                                              ctypes.byref(go), ctypes.byref(ls), ro, ctypes.byref(qo), ctypes.byref(gqo))
         _capi.check(ops.lib(), st, 'mpqe_step_states_layout')
         D = self.model.emb_dim
         rows_total = int(ro[nb])
         if int(ls.value) != rows_total * D:
             raise _capi.MpqeError('mpqe_step_states_layout: unexpected level stride')
-        final, grow, gw, gb, nt, tr, pg = [], [], [], [], [], [], []
-        by_mode = {}
-        g0, lmax = 0, 0
+        final, grow, nt, tr, pg = [], [], [], [], []
+        g0, lmax, lmin = 0, 0, 1 << 30
         for i in range(nb):
             sb = packed.batches[i]
             B, L = int(sb.batch_size), int(sb.num_passes)
             A, N, _ = _TEMPLATES[_capi.QUERY_NAMES[int(sb.query_type)]]
-            lmax = max(lmax, L)
+            lmax, lmin = max(lmax, L), min(lmin, L)
             r0 = int(ro[i])
             rows = np.arange(B * N, dtype=np.int64)
             final.append(L * rows_total + r0 + rows)
             g_of = g0 + rows // N
             grow.append(g_of)
-            gw.append(np.full(B, float(sb.weight) / B, dtype=np.float32))
-            gb.append(np.full(B, i, dtype=np.int64))
             keep = (rows % N) != A                   # the target is node A (after the anchors)
             nt.append(r0 + rows[keep])
             tr.append(r0 + (rows[keep] // N) * N + A)
             pg.append(g_of[keep])
-            by_mode.setdefault(int(sb.target_mode), []).append(g0 + np.arange(B, dtype=np.int64))
             g0 += B
-        G = g0
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        modes, sel, order = [], [], []
-        for mode in sorted(by_mode):
-            g = np.concatenate(by_mode[mode])
-            g2 = np.concatenate([g, G + g])            # targets, then negatives, of this mode's batches
-            modes.append(mode)
-            sel.append(t(g2))
-            order.append(g2)
-        inv = np.argsort(np.concatenate(order), kind='stable')
-        plan = dict(states_offset=int(so.value), grads_offset=int(go.value), rows_total=rows_total, levels=lmax + 1, G=G,
-                    final=t(np.concatenate(final)), graph_of_row=t(np.concatenate(grow)), weight=t(np.concatenate(gw)),
-                    batch_of_graph=t(np.concatenate(gb)), non_target=t(np.concatenate(nt)), target_row=t(np.concatenate(tr)),
-                    pair_graph=t(np.concatenate(pg)), modes=modes, sel=sel, inv=t(inv),
-                    weight_sum=float(sum(float(packed.batches[i].weight) for i in range(nb))),
-                    sizes=torch.tensor([float(packed.batches[i].batch_size) for i in range(nb)], device=dev))
+        # (every batch at the same depth: its final states are one contiguous block of the workspace -- no gather)
+        plan = dict(states_offset=int(so.value), grads_offset=int(go.value), queries_offset=int(qo.value),
+                    query_grads_offset=int(gqo.value), rows_total=rows_total, levels=lmax + 1, G=g0,
+                    final=None if lmin == lmax else t(np.concatenate(final)), depth=lmax,
+                    graph_of_row=t(np.concatenate(grow)), non_target=t(np.concatenate(nt)),
+                    target_row=t(np.concatenate(tr)), pair_graph=t(np.concatenate(pg)),
+                    weight_sum=float(sum(float(packed.batches[i].weight) for i in range(nb))))
         if len(self._states_cache) > 1024:
             self._states_cache.clear()
         self._states_cache[packed.skey] = plan
         return plan
 
     def _run_states(self, packed, backward, zero_grad, scores, workspace):
-        """run() for the learned readouts: library call 1 (gather + every level forward), the readout / scores / hinge of
-        all batches at once on the final node states (the readout's Linear layers through ops.linear, i.e.
-        mpqe_linear_fwd / bwd), library call 2 (levels backward, weight gradients, anchors' table gradients, reduction).
-        loss[0] carries the reference's readout regulariser (model.py:486-490: weight_decay * sum of the parameter norms,
-        once per margin_loss call, hence times the sum of the batch weights); loss[1 + i] is batch i's mean hinge."""
+        """run() for the learned readouts (include/mpqe_amd.h: MPQE_READOUT_CALLER). Library call 1: gather + every level
+        forward. Here: the readout of ALL batches at once on their final node states -- Linear-ReLU-Linear through
+        ops.linear (mpqe_linear_fwd / bwd), the scatter kernel -- into the workspace. Library call 2: scores, hinge,
+        d loss / d embedding, target-table gradients. Here: that gradient back through the readout (torch.autograd.grad: no
+        AccumulateGrad nodes, so the whole step can be captured into a hipGraph). Library call 3: levels backward, weight
+        gradients, anchors' table gradients, reduction, loss. loss[0] carries the reference's readout regulariser
+        (model.py:486-490: weight_decay * sum of the parameter norms, once per margin_loss call, hence times the sum of the
+        batch weights); loss[1 + i] is batch i's mean hinge."""
         m, dev = self.model, self.device
         plan = self._states_plan(packed)
         bufs = packed.bufs
@@ -674,97 +665,91 @@ class FusedTrainStep(object):
             wptr = (workspace.data_ptr() + 255) // 256 * 256
             arena = workspace
         base = wptr - arena.data_ptr()
-        D = m.emb_dim
-        nbytes = 4 * plan['levels'] * plan['rows_total'] * D
-        Hv = arena[base + plan['states_offset']: base + plan['states_offset'] + nbytes].view(torch.float32).view(-1, D)
-        GHv = arena[base + plan['grads_offset']: base + plan['grads_offset'] + nbytes].view(torch.float32).view(-1, D)
-        scratch = torch.empty(1 + packed.nb, dtype=torch.float32, device=dev)
+        D, G, R = m.emb_dim, plan['G'], plan['rows_total']
+
+        # (two aliases of the arena with version counters of their own: the states autograd saves are views of the first,
+        # everything written here goes through the second -- the in-place check would otherwise see the writes)
+        a_read, a_write = arena.data, arena.data
+
+        def view(a, off, rows):
+            return a[base + off: base + off + 4 * rows * D].view(torch.float32).view(rows, D)
+        Hv, GHv = view(a_read, plan['states_offset'], plan['levels'] * R), view(a_write, plan['grads_offset'], plan['levels'] * R)
+        Qv, GQv = view(a_write, plan['queries_offset'], G), view(a_write, plan['query_grads_offset'], G)
+        loss = torch.empty(1 + packed.nb, dtype=torch.float32, device=dev)
+        sp = sn = None
+        if scores:
+            sp = torch.empty(G, dtype=torch.float32, device=dev)
+            sn = torch.empty_like(sp)
         L = ops.lib()
 
         def call(phase, upload):
             args = (ctypes.byref(self.P), packed.batches, packed.nb, packed.anchor_ids.data_ptr(),
                     packed.targets.data_ptr(), packed.negs.data_ptr(), self.margin, ctypes.byref(self.G), phase,
-                    scratch.data_ptr(), None, None, packed.desc_ptr, packed.desc_bytes, upload, wptr, packed.ws_bytes,
-                    self.err.data_ptr(), packed.lanes, None, 0, None, stream.cuda_stream)
-            with torch.cuda.device(dev):
+                    loss.data_ptr(), None if sp is None else sp.data_ptr(), None if sn is None else sn.data_ptr(),
+                    packed.desc_ptr, packed.desc_bytes, upload, wptr, packed.ws_bytes, self.err.data_ptr(), packed.lanes,
+                    None, 0, None, stream.cuda_stream)
+            if torch.cuda.current_device() != dev.index:
+                with torch.cuda.device(dev):
+                    st = L.mpqe_step_forward_backward(*args)
+            else:
                 st = L.mpqe_step_forward_backward(*args)
             _capi.check(L, st, 'mpqe_step_forward_backward')
 
         call(_capi.STEP_PHASE_STATES, 0 if bufs.desc_resident else 1)
         bufs.desc_resident = True
-        rparams = [m.readout.layers[0].weight, m.readout.layers[0].bias, m.readout.layers[2].weight, m.readout.layers[2].bias]
-        if backward and zero_grad:         # (the library fills the buffers it writes; these are the readout's)
+        lay = m.readout.layers
+        rparams = [lay[0].weight, lay[0].bias, lay[2].weight, lay[2].bias]
+        if backward and zero_grad:                     # (the library fills the buffers it writes; these are the readout's)
             torch._foreach_zero_([p.grad for p in rparams])
-        G = plan['G']
-        with torch.no_grad():
+        if plan['final'] is None:
+            h = Hv[plan['depth'] * R: (plan['depth'] + 1) * R].detach()
+        else:
             h = Hv.index_select(0, plan['final'])
         h.requires_grad_(bool(backward))
         # (fresh leaves aliasing the readout's parameters: a leaf is identified by its gradient accumulator node, and one
         # kept alive by an older autograd graph of the caller's belongs to the stream it was made on -- inside a hipGraph
         # capture the engine would then sync with that stream and break the capture)
-        lay = m.readout.layers
-        w0, b0, w2, b2 = [p.detach().requires_grad_(bool(backward)) for p in (lay[0].weight, lay[0].bias, lay[2].weight, lay[2].bias)]
-        leaves = [w0, b0, w2, b2]
-
-        def _mlp(_, x):
-            return ops.linear(ops.linear(x.contiguous(), w0, b0, relu=True), w2, b2)
+        w0, b0, w2, b2 = leaves = [p.detach().requires_grad_(bool(backward)) for p in rparams]
+        # (the scatter kernels directly: the index is this step's own, so no per-call flag read -- ops._scatter syncs)
+        op = {ops.scatter_add: 'add', ops.scatter_max: 'max', ops.scatter_mean: 'mean'}[m.readout.scatter_fn]
         with torch.set_grad_enabled(bool(backward)):
-            # (the scatter kernels directly: the index is this step's own, so no per-call flag read -- ops._scatter syncs)
-            op = {ops.scatter_add: 'add', ops.scatter_max: 'max', ops.scatter_mean: 'mean'}[m.readout.scatter_fn]
             if m.readout_str == 'mlp':
-                x = _mlp(m.readout.layers, h)
-                out = ops._Scatter.apply(x, plan['graph_of_row'], op, G, self.err)
-            else:
+                x, index = h, plan['graph_of_row']
+            else:                                       # reference model.py:536-547: [target | non-target] pairs
                 x = torch.cat((h.index_select(0, plan['target_row']), h.index_select(0, plan['non_target'])), dim=-1)
-                x = _mlp(m.readout.layers, x)
-                out = ops._Scatter.apply(x, plan['pair_graph'], op, G, self.err)
-            if isinstance(out, tuple):
-                out = out[0]
-            # targets | negatives of every batch: one look-up per target mode, back into graph order. The tables stay out
-            # of the autograd graph (E is a leaf): their gradient goes from dE straight into p.grad through the library's
-            # accumulate-in-place kernel -- no dense [rows, D] temporaries, and no AccumulateGrad nodes anywhere (the
-            # gradients come back from torch.autograd.grad), which also keeps the step capturable into a hipGraph
-            # (pack() keeps the two id blocks adjacent)
-            tn = torch.cat((packed.targets, packed.negs)) if packed.negs.data_ptr() != packed.targets.data_ptr() + 8 * G \
-                else packed.targets.as_strided((2 * G,), (1,))
-            with torch.no_grad():
-                mode_ids = [tn.index_select(0, sel) for sel in plan['sel']]
-                embs = [ops.embed_l2norm(m.enc.table(self.modes[mode]), m.enc.node_maps, ids, self.err)
-                        for mode, ids in zip(plan['modes'], mode_ids)]
-                E = (embs[0] if len(embs) == 1 else torch.cat(embs, dim=0)).index_select(0, plan['inv'])
-            E.requires_grad_(bool(backward))
-            pos = ops.cosine(out, E[:G])
-            neg = ops.cosine(out, E[G:])
-            terms = torch.clamp(self.margin - (pos - neg), min=0)
-            total = (terms * plan['weight']).sum()
-            if m.weight_decay > 0:
-                reg = torch.stack(torch._foreach_norm(leaves)).sum()
-                total = total + (m.weight_decay * plan['weight_sum']) * reg
-        loss = torch.zeros(1 + packed.nb, dtype=torch.float32, device=dev)
+                index = plan['pair_graph']
+            x = ops.linear(ops.linear(x, w0, b0, relu=True), w2, b2)
+            q = ops._Scatter.apply(x, index, op, G, self.err)
+            if isinstance(q, tuple):
+                q = q[0]
+            reg = torch.stack(torch._foreach_norm(leaves)).sum() if m.weight_decay > 0 else None
         with torch.no_grad():
-            loss[1:].index_add_(0, plan['batch_of_graph'], terms.detach())
-            loss[1:] /= plan['sizes']
-            loss[0] = total.detach()
-        if backward:
-            grads = torch.autograd.grad(total, [h, E] + leaves)
-            GHv.index_copy_(0, plan['final'], grads[0])
-            torch._foreach_add_([p.grad for p in rparams], list(grads[2:]))
-            nm = m.enc.node_maps
-            with torch.cuda.device(dev):
-                for mode, sel, ids in zip(plan['modes'], plan['sel'], mode_ids):
-                    table = m.enc.table(self.modes[mode])
-                    g = grads[1].index_select(0, sel)
-                    st = L.mpqe_embed_l2norm_bwd(g.data_ptr(), D, table.data_ptr(), table.shape[0], D, nm.data_ptr(),
-                                                 nm.shape[0], ids.data_ptr(), ids.shape[0], table.grad.data_ptr(),
-                                                 self.err.data_ptr(), stream.cuda_stream)
-                    _capi.check(L, st, 'mpqe_embed_l2norm_bwd')
+            Qv.copy_(q)
+        if not backward:
+            call(_capi.STEP_PHASE_SCORES_ONLY, 0)
+        else:
+            call(_capi.STEP_PHASE_SCORES, 0)
+            if reg is None:
+                grads = torch.autograd.grad([q], [h] + leaves, grad_outputs=[GQv])
+            else:
+                c = torch.full((), m.weight_decay * plan['weight_sum'], dtype=torch.float32, device=dev)
+                grads = torch.autograd.grad([q, reg], [h] + leaves, grad_outputs=[GQv, c])
+            with torch.no_grad():
+                if plan['final'] is None:
+                    GHv[plan['depth'] * R: (plan['depth'] + 1) * R].copy_(grads[0])
+                else:
+                    GHv.index_copy_(0, plan['final'], grads[0])
+                torch._foreach_add_([p.grad for p in rparams], list(grads[1:]))
             call(_capi.STEP_PHASE_FROM_STATES, 0)
+        if reg is not None:
+            with torch.no_grad():
+                loss[0] += (m.weight_decay * plan['weight_sum']) * reg.detach()
         if packed.ids_ref is bufs.stage and bufs.stage is not None and not packed.captured:
             if bufs.last_use is None:
                 bufs.last_use = torch.cuda.Event()
             bufs.last_use.record(stream)
         if scores:
-            return loss, pos.detach(), neg.detach()
+            return loss, sp, sn
         return loss
 
     def capture(self, packed, backward=True, zero_grad=True):

@@ -78,9 +78,9 @@ def oracle_step(params, cfg, node_map, batches, margin):
 
 def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=1, lanes=None, flags=0, touch='step', repeat=1,
              plan_out=None, between=None):
-    """between: the step in two calls (MPQE_STEP_PHASE_STATES / _FROM_STATES) with between(final_states) -> (d loss / d
-    final states, {table key: gradient to add}) standing in for the caller's readout; final_states[i]: batch i's [B N, D].
-    touch: 'step' = the step builds the touch plan of its ids itself (MPQE_STEP_BUILD_TOUCH, the product's default),
+    """between: the step in three calls around the CALLER's readout (MPQE_READOUT_CALLER, MPQE_STEP_PHASE_*): a generator
+    function -- between(final_states) yields the query embeddings [graphs, D], is sent their gradients and yields d loss /
+    d final states per batch; final_states[i]: batch i's [B N, D]. touch: 'step' = the step builds the touch plan of its ids itself (MPQE_STEP_BUILD_TOUCH, the product's default),
     'pack' = mpqe_step_touch_build in front of it, False = fp32 atomics. plan_out: a list that receives the plan's bytes."""
     D = params['mode_embeddings.weight'].shape[1]
     if touch == 'step' and ((flags & _capi.STEP_EIGHT_WAVES) or lanes is not None):
@@ -108,9 +108,8 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
     dnm = be.put(node_map.numpy())
     dmode = put('mode_embeddings.weight')
     if between is not None:
-        flags |= _capi.STEP_NO_CHAIN
         touch = False
-    P = _capi.make_step_params(D, R, 'sum' if between is not None else cfg['readout'], [be.ptr(t) for t in tables],
+    P = _capi.make_step_params(D, R, _capi.READOUT_CALLER if between is not None else cfg['readout'], [be.ptr(t) for t in tables],
                                [params['enc.feat-%s.weight' % m].shape[0] for m in modes], be.ptr(dnm),
                                node_map.shape[0], be.ptr(dmode), [be.ptr(x[0]) for x in lay],
                                [be.ptr(x[1]) for x in lay], [be.ptr(x[2]) for x in lay], flags=flags)
@@ -195,13 +194,14 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
     for rep in range(repeat if between is not None else 0):
         def call(phase, upload):
             be.check(be.lib.mpqe_step_forward_backward(ctypes.byref(P), SB, nb, be.ptr(d_anchor), be.ptr(d_tg), be.ptr(d_ng),
-                                                       margin, ctypes.byref(G), phase, be.ptr(loss), None, None, dptr, dsb,
-                                                       upload, wptr, wsb, be.ptr(err), lanes, None, 0, None, be.stream), 'step')
+                                                       margin, ctypes.byref(G), phase, be.ptr(loss), be.ptr(sp), be.ptr(sn), dptr,
+                                                       dsb, upload, wptr, wsb, be.ptr(err), lanes, None, 0, None, be.stream),
+                     'step')
         i64 = ctypes.c_int64
-        so, go, lstride, ro = i64(), i64(), i64(), (i64 * (nb + 1))()
+        so, go, lstride, ro, qo, gqo = i64(), i64(), i64(), (i64 * (nb + 1))(), i64(), i64()
         be.check(be.lib.mpqe_step_states_layout(ctypes.byref(P), SB, nb, lanes, ctypes.byref(so), ctypes.byref(go),
-                                                ctypes.byref(lstride), ro), 'layout')
-        assert lstride.value == ro[nb] * D and so.value % 4 == 0 and go.value % 4 == 0
+                                                ctypes.byref(lstride), ro, ctypes.byref(qo), ctypes.byref(gqo)), 'layout')
+        assert lstride.value == ro[nb] * D and all(v.value % 4 == 0 for v in (so, go, qo, gqo))
         call(_capi.STEP_PHASE_STATES, 1 if rep == 0 else 0)
         raw = np.asarray(be.get(ws))
         base = (wptr - be.ptr(ws)) // 4
@@ -210,12 +210,19 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
             at = base + so.value // 4 + SB[i].num_passes * lstride.value + ro[i] * D
             finals.append(raw[at:at + (ro[i + 1] - ro[i]) * D].reshape(-1, D).copy())
             assert np.isfinite(finals[-1]).all()
-        gfinal, tadd = between(finals)
+        gen = between(finals)
+        q = np.ascontiguousarray(next(gen), np.float32)            # query embeddings [graphs, D], batch order
+        assert q.shape == (Gtot, D)
+        put_at(ws, base + qo.value // 4, q)
+        if backward == 0:
+            call(_capi.STEP_PHASE_SCORES_ONLY, 0)
+            continue
+        call(_capi.STEP_PHASE_SCORES, 0)
+        raw = np.asarray(be.get(ws))
+        gq = raw[base + gqo.value // 4: base + gqo.value // 4 + Gtot * D].reshape(Gtot, D).copy()
+        gfinal = gen.send(gq)                                       # d loss / d final states, per batch
         for i in range(nb):
             put_at(ws, base + go.value // 4 + SB[i].num_passes * lstride.value + ro[i] * D, np.ascontiguousarray(gfinal[i], np.float32))
-        for key, g in tadd.items():
-            t = gtabs[modes.index(key)]
-            t += g if be.name == 'emu' else be.put(g)
         call(_capi.STEP_PHASE_FROM_STATES, 0)
     for rep in range(0 if between is not None else repeat):       # (repeat > 1: the same packed step again -- its hand-off epochs / counters carry on)
         be.check(be.lib.mpqe_step_forward_backward(ctypes.byref(P), SB, nb, be.ptr(d_anchor), be.ptr(d_tg),
@@ -272,11 +279,10 @@ def test_fused_step_matches_oracle(be, readout, adaptive, shared, L, mix):
 
 
 @pytest.mark.parametrize('readout,adaptive,shared,zero', [('mlp', True, False, True), ('targetmlp', False, True, False)])
-def test_two_call_step_around_a_callers_readout(be, readout, adaptive, shared, zero):
-    """The learned readouts (reference model.py:497-553) are the CALLER's: the step runs as two calls (node states out,
-    their gradients in) and the caller's readout in between -- here the oracle's own readout / score code under autograd.
-    Loss and every gradient (encoder weights, entity tables with the anchors' part from the library and the targets' part
-    from the caller) must be the oracle's for the whole model."""
+def test_step_in_three_calls_around_a_callers_readout(be, readout, adaptive, shared, zero):
+    """The learned readouts (reference model.py:497-553) are the CALLER's: the step runs as three calls -- node states
+    out; query embeddings in, their gradients out; state gradients in -- with the caller's readout in between, here the
+    oracle's own readout code under autograd. Loss, scores and every gradient must be the oracle's for the whole model."""
     D, margin = 32, 1.0
     schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(17, D, 3, shared, MIXES['all7'], readout, adaptive)
     ref_loss, ref_per, ref_sp, ref_sn = oracle_step(params, cfg, node_map, batches, margin)
@@ -284,27 +290,25 @@ def test_two_call_step_around_a_callers_readout(be, readout, adaptive, shared, z
 
     def between(finals):
         hs = [torch.from_numpy(f).requires_grad_(True) for f in finals]
-        local = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()
-                 if k.startswith('enc.') or k.startswith('readout.')}
-        total = 0
+        local = {k: v.detach().clone().requires_grad_(True) for k, v in params.items() if k.startswith('readout.')}
+        qs = []
         for b, h in zip(batches, hs):
             col = b['col']
-            q = ref_cpu.readout(cfg['readout'], cfg['scatter_op'], local, h, torch.as_tensor(col['batch']), col['B'],
-                                col['N'], col['A'])
-            pos = ref_cpu.score(local, node_map, b['formula'], q, b['targets'])
-            neg = ref_cpu.score(local, node_map, b['formula'], q, b['negs'])
-            total = total + b['weight'] * torch.clamp(margin - (pos - neg), min=0).mean()
-        total.backward()
-        seen['loss'] = total.item()
-        seen['readout'] = {k: v.grad.numpy() for k, v in local.items() if k.startswith('readout.')}
-        tadd = {k[len('enc.feat-'):-len('.weight')]: v.grad.numpy() for k, v in local.items()
-                if k.startswith('enc.') and v.grad is not None}
-        return [h.grad.numpy() for h in hs], tadd
+            qs.append(ref_cpu.readout(cfg['readout'], cfg['scatter_op'], local, h, torch.as_tensor(col['batch']), col['B'],
+                                      col['N'], col['A']))
+        q = torch.cat(qs, dim=0)
+        gq = yield q.detach().numpy()
+        q.backward(torch.from_numpy(gq))
+        seen['readout'] = {k: v.grad.numpy() for k, v in local.items()}
+        yield [h.grad.numpy() for h in hs]
 
     loss, sp, sn, grads, err = run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin,
                                         flags=_capi.STEP_ZERO_GRADS if zero else 0, between=between, repeat=2 if zero else 1)
     assert err == 0
-    np.testing.assert_allclose(seen['loss'], ref_loss, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sp, ref_sp, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sn, ref_sn, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(loss[1:], ref_per, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(loss[0], ref_loss, rtol=1e-5, atol=1e-6)
     grads.update(seen['readout'])
     done = set()
     for k, p in params.items():
@@ -313,12 +317,27 @@ def test_two_call_step_around_a_callers_readout(be, readout, adaptive, shared, z
         done.add(id(p))
         ref = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
         np.testing.assert_allclose(grads[k], ref, rtol=1e-4, atol=2e-6, err_msg=k)
+    # forward only: scores and loss from the caller's embeddings, no gradient touched
+    def forward_only(finals):
+        with torch.no_grad():
+            yield torch.cat([ref_cpu.readout(cfg['readout'], cfg['scatter_op'], params, torch.from_numpy(f),
+                                             torch.as_tensor(b['col']['batch']), b['col']['B'], b['col']['N'], b['col']['A'])
+                             for b, f in zip(batches, finals)], dim=0).numpy()
+    loss, sp, sn, grads, err = run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=0,
+                                        between=forward_only)
+    assert err == 0
+    np.testing.assert_allclose(sp, ref_sp, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(loss[0], ref_loss, rtol=1e-5, atol=1e-6)
+    assert all(not g.any() for g in grads.values())
 
 
-def test_two_call_step_refuses_what_it_does_not_cover(be):
+def test_callers_readout_refuses_what_it_does_not_cover(be):
     schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(5, 64, 2, False, MIXES['dup'], 'sum', False)
-    with pytest.raises(_capi.MpqeError):        # the chain form keeps the node states in LDS
+    with pytest.raises(_capi.MpqeError):        # a phase of the three-call step with a readout of the library's own
         run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, backward=_capi.STEP_PHASE_STATES, touch=False)
+    cfg2 = dict(cfg, readout=_capi.READOUT_CALLER)
+    with pytest.raises(_capi.MpqeError):        # the caller's readout in the one-call step
+        run_step(be, schema, mode_ids, params, node_map, cfg2, batches, 1.0, touch=False)
 
 
 @pytest.mark.parametrize('readout,adaptive,L', [('mp', True, 3), ('mp', False, 2), ('max', False, 3)])
