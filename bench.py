@@ -599,8 +599,8 @@ def main():
     rng = np.random.RandomState(1000 + rank)
     pool = [StepData(schema, model, args.batch_size, rng, device) for _ in range(4)]      # 4 formula sets
 
-    use_fused = args.path in ('auto', 'fused') and args.readout in ('mp', 'sum', 'max', 'mlp', 'targetmlp')
-    learned = args.readout in ('mlp', 'targetmlp')        # (fused step = three library calls around the readout: fused.py)
+    use_fused = args.path in ('auto', 'fused') and args.readout in ('mp', 'sum', 'max', 'mlp', 'targetmlp', 'concat')
+    learned = args.readout in ('mlp', 'targetmlp', 'concat')        # (fused step = three library calls around the readout: fused.py)
     fresh = use_fused and not args.replay and not args.graph
     reducer = fstep = packed = captured = exchange = xplans = fresh_ids = descs = None
     n_total = args.warmup + args.steps * max(1, args.repeats)

@@ -308,6 +308,10 @@ int mpqe_hinge_bwd(const float *pos, const float *neg, int64_t n, float margin, 
  *             alone. Steps of more than 524 288 looked-up ids, or split over stream lanes, return MPQE_ERR_UNSUPPORTED:
  *             build the plan with mpqe_step_touch_build instead.                                              */
 #define MPQE_STEP_BUILD_TOUCH 512
+/* ADD_STATE_GRADS  (MPQE_READOUT_CALLER, PHASE_FROM_STATES) the caller's readout read the states of EVERY level 1 .. L_b
+ *             (the reference's `concat` readout, model.py:441-446) and has written its d loss / d state into every row of
+ *             those gradient levels, not only the final one: the backward adds the gradient it propagates to them.  */
+#define MPQE_STEP_ADD_STATE_GRADS 1024
 
 typedef struct {
     int32_t query_type;        /* MPQE_Q_*                                                     */

@@ -161,6 +161,7 @@ STEP_SPARSE_TABLES = 64
 STEP_MERGE_TAIL = 128
 STEP_SPLIT_TAIL = 256
 STEP_BUILD_TOUCH = 512
+STEP_ADD_STATE_GRADS = 1024
 # `backward` values of the step in three calls around the caller's readout (learned readouts; include/mpqe_amd.h)
 STEP_PHASE_STATES, STEP_PHASE_SCORES, STEP_PHASE_FROM_STATES, STEP_PHASE_SCORES_ONLY = 2, 3, 4, 5
 TSORT_MAX_ENTRIES = 256 * 2048        # csrc/step_touch.h: the in-step touch plan covers this many looked-up ids

@@ -204,7 +204,9 @@ __device__ __forceinline__ void tmpl_bwd_x_tile(const TmplArgs &tp, long long B,
                                                 float *__restrict__ grad_x, int m,
                                                 long long b0, int n0, float *smem,
                                                 const float *__restrict__ mask_x = nullptr,
-                                                unsigned live_out = 0xFu) {
+                                                unsigned live_out = 0xFu, bool add_in = false) {
+    // add_in (fused step, caller's readout over every level): grad_x already holds a gradient of the same rows that
+    // reaches them by another route; the propagated one is added to it (before the mask).
     // live_out (fused step): node slots whose output gradient can be non-zero; the K-blocks of the
     // others would multiply exact zeros (rows the step never writes) and are left out. The caller
     // guarantees that at least one block remains.
@@ -231,7 +233,8 @@ __device__ __forceinline__ void tmpl_bwd_x_tile(const TmplArgs &tp, long long B,
             const long long b = b0 + acc_row(r);
             if (b < B) {
                 const long long idx = (b * tp.N + m) * (long long)Din + col;
-                grad_x[idx] = (mask_x && !(mask_x[idx] > 0.f)) ? 0.f : acc[r];
+                const float v = add_in ? acc[r] + grad_x[idx] : acc[r];
+                grad_x[idx] = (mask_x && !(mask_x[idx] > 0.f)) ? 0.f : v;
             }
         }
     }

@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void step_layer_bwd_x_kernel(const StepDev *__
                                                                const TileRef *__restrict__ tiles,
                                                                const float *__restrict__ Gout,
                                                                const float *__restrict__ Hin,
-                                                               float *__restrict__ Gin) {
+                                                               float *__restrict__ Gin, int add_in) {
     __shared__ __attribute__((aligned(16))) float smem[GT_SMEM_FLOATS];
     const TileRef tr = tiles[blockIdx.x];
     const BatchDev &b = sd->b[tr.batch];
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256) void step_layer_bwd_x_kernel(const StepDev *__
     tmpl_bwd_x_tile<MODE>(tp, b.B, Gout + b.row_off * D, (const float *)nullptr, pick_layer(lp.basis, li),
                           pick_layer(lp.root, li), D, D, 0,
                          Gin + b.row_off * D, m, (long long)(rem / ct) * GT_BM, (rem % ct) * GT_BN, smem,
-                         p >= 1 ? Hin + b.row_off * D : (const float *)nullptr, b.live[p + 1]);
+                         p >= 1 ? Hin + b.row_off * D : (const float *)nullptr, b.live[p + 1], add_in && p >= 1);
 }
 
 // ------------------------------------------------------------------------------------ score / loss
@@ -2482,7 +2482,7 @@ void make_key(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
               PlanKey *k) {
     memset(k, 0, sizeof(*k));
     k->dim = P->dim; k->num_layers = P->num_layers; k->num_relations = P->num_relations;
-    k->num_modes = P->num_modes; k->readout = P->readout; k->flags = P->flags & ~(MPQE_STEP_ZERO_GRADS | MPQE_STEP_NO_KSPLIT | MPQE_STEP_EIGHT_WAVES); k->nb = nb;
+    k->num_modes = P->num_modes; k->readout = P->readout; k->flags = P->flags & ~(MPQE_STEP_ZERO_GRADS | MPQE_STEP_NO_KSPLIT | MPQE_STEP_EIGHT_WAVES | MPQE_STEP_ADD_STATE_GRADS); k->nb = nb;
     k->nlanes = lanes ? lanes->num_lanes : 1;
     for (int m = 0; m < P->num_modes && m < MPQE_STEP_MAX_MODES; ++m) k->table_rows[m] = P->table_rows[m];
     if (lanes)
@@ -2907,6 +2907,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     const bool phase_score = phase == MPQE_STEP_PHASE_SCORES || phase == MPQE_STEP_PHASE_SCORES_ONLY;
     if ((phase >= 2) != (P->readout == MPQE_READOUT_CALLER)) return MPQE_ERR_INVALID_ARG;
     if (phase >= 2 && (use_chain || hp.nlanes > 1)) return MPQE_ERR_UNSUPPORTED;
+    // (the caller's readout read every level: its gradients of the intermediate levels are in the workspace already)
+    const int add_states = (phase_bwd && (P->flags & MPQE_STEP_ADD_STATE_GRADS)) ? 1 : 0;
     if (phase == MPQE_STEP_PHASE_SCORES_ONLY) backward = 0;        // (scores and loss from the caller's embeddings, no gradients)
     // touch plan given: the chain form stores per-entry table-gradient rows and sums them per destination (no atomics)
     bool use_touch = touch != nullptr && use_chain && backward;
@@ -3452,13 +3454,13 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             mark(ls[l]);
             if (fast)
                 hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_FAST>, grid, dim3(256), 0, ls[l], sd, lp, p, gb, gout,
-                                   hin, gin);
+                                   hin, gin, add_states);
             else if (vec)
                 hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_PRED>, grid, dim3(256), 0, ls[l], sd, lp, p, gb, gout,
-                                   hin, gin);
+                                   hin, gin, add_states);
             else
                 hipLaunchKernelGGL(step_layer_bwd_x_kernel<LD_SCALAR>, grid, dim3(256), 0, ls[l], sd, lp, p, gb,
-                                   gout, hin, gin);
+                                   gout, hin, gin, add_states);
             mark(ls[l]);
         }
     join();

@@ -146,10 +146,9 @@ class FusedTrainStep(object):
             raise ValueError('FusedTrainStep needs a DirectEncoder built with node_maps')
         # learned readouts (reference model.py:497-553): the step runs in three library calls around the readout, whose
         # Linear layers and scatter run here on the final states of ALL batches at once (_run_states)
-        self.external = model.readout_str in ('mlp', 'targetmlp')
+        self.external = model.readout_str in ('mlp', 'targetmlp', 'concat')
         if not self.external and model.readout_str not in _capi.READOUT_IDS:
-            raise NotImplementedError('fused step covers readouts sum / max / mp / mlp / targetmlp; %r runs through the '
-                                      'module path' % model.readout_str)
+            raise NotImplementedError('fused step: unknown readout %r' % model.readout_str)
         if self.external:
             if sparse_tables:
                 raise ValueError('sparse_tables needs the chain form (readouts sum / max / mp)')
@@ -701,7 +700,13 @@ class FusedTrainStep(object):
         rparams = [lay[0].weight, lay[0].bias, lay[2].weight, lay[2].bias]
         if backward and zero_grad:                     # (the library fills the buffers it writes; these are the readout's)
             torch._foreach_zero_([p.grad for p in rparams])
-        if plan['final'] is None:
+        concat = m.readout_str == 'concat'
+        if concat:
+            # reference model.py:441-446: the outputs of every layer side by side (every batch runs num_layers passes)
+            if plan['final'] is not None or plan['depth'] != m.num_layers:
+                raise ValueError('concat readout: every batch must run num_layers passes (adaptive=False)')
+            h = Hv.view(plan['levels'], R, D)[1:].permute(1, 0, 2).reshape(R, plan['depth'] * D)
+        elif plan['final'] is None:
             h = Hv[plan['depth'] * R: (plan['depth'] + 1) * R].detach()
         else:
             h = Hv.index_select(0, plan['final'])
@@ -713,7 +718,7 @@ class FusedTrainStep(object):
         # (the scatter kernels directly: the index is this step's own, so no per-call flag read -- ops._scatter syncs)
         op = {ops.scatter_add: 'add', ops.scatter_max: 'max', ops.scatter_mean: 'mean'}[m.readout.scatter_fn]
         with torch.set_grad_enabled(bool(backward)):
-            if m.readout_str == 'mlp':
+            if m.readout_str in ('mlp', 'concat'):
                 x, index = h, plan['graph_of_row']
             else:                                       # reference model.py:536-547: [target | non-target] pairs
                 x = torch.cat((h.index_select(0, plan['target_row']), h.index_select(0, plan['non_target'])), dim=-1)
@@ -735,7 +740,10 @@ class FusedTrainStep(object):
                 c = torch.full((), m.weight_decay * plan['weight_sum'], dtype=torch.float32, device=dev)
                 grads = torch.autograd.grad([q, reg], [h] + leaves, grad_outputs=[GQv, c])
             with torch.no_grad():
-                if plan['final'] is None:
+                if concat:        # every level's rows get the readout's part; the backward adds what it propagates
+                    GHv.view(plan['levels'], R, D)[1:].copy_(grads[0].view(R, plan['depth'], D).permute(1, 0, 2))
+                    self.P.flags |= _capi.STEP_ADD_STATE_GRADS
+                elif plan['final'] is None:
                     GHv[plan['depth'] * R: (plan['depth'] + 1) * R].copy_(grads[0])
                 else:
                     GHv.index_copy_(0, plan['final'], grads[0])

@@ -79,7 +79,8 @@ def test_fused_step_equals_module_path(readout, adaptive, shared, lanes):
 
 @pytest.mark.parametrize('readout,adaptive,shared,scatter_op,D,host_ids', [
     ('mlp', True, False, 'add', 64, 'direct'), ('mlp', False, True, 'max', 128, 'copy'),
-    ('targetmlp', True, True, 'add', 128, 'direct'), ('targetmlp', False, False, 'mean', 64, 'copy')])
+    ('targetmlp', True, True, 'add', 128, 'direct'), ('targetmlp', False, False, 'mean', 64, 'copy'),
+    ('concat', False, False, 'add', 64, 'direct'), ('concat', False, True, 'max', 128, 'direct')])
 def test_fused_step_with_learned_readout_equals_module_path(readout, adaptive, shared, scatter_op, D, host_ids):
     """MLPReadout / TargetMLPReadout (reference model.py:497-553) through the fused step: three library calls around the
     readout of all batches at once (FusedTrainStep._run_states). Against the module path's margin_loss arithmetic,

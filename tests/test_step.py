@@ -40,8 +40,8 @@ def make_problem(seed, D, num_layers, shared, mix, readout, adaptive, scale=3.0)
         params['layers.%d.basis' % l] = (torch.rand(R, D, D) * 2 - 1) * bound
         params['layers.%d.root' % l] = (torch.rand(D, D) * 2 - 1) * bound
         params['layers.%d.bias' % l] = (torch.rand(D) * 2 - 1) * bound
-    if readout in ('mlp', 'targetmlp'):        # reference model.py:497-553: Linear - ReLU - Linear
-        din = 2 * D if readout == 'targetmlp' else D
+    if readout in ('mlp', 'targetmlp', 'concat'):        # reference model.py:497-553: Linear - ReLU - Linear
+        din = 2 * D if readout == 'targetmlp' else (num_layers * D if readout == 'concat' else D)
         params['readout.layers.0.weight'] = (torch.rand(D, din) * 2 - 1) / np.sqrt(din)
         params['readout.layers.0.bias'] = (torch.rand(D) * 2 - 1) / np.sqrt(din)
         params['readout.layers.2.weight'] = (torch.rand(D, D) * 2 - 1) / np.sqrt(D)
@@ -205,12 +205,14 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
         call(_capi.STEP_PHASE_STATES, 1 if rep == 0 else 0)
         raw = np.asarray(be.get(ws))
         base = (wptr - be.ptr(ws)) // 4
-        finals = []
+        finals, levels = [], []
         for i, b in enumerate(batches):
-            at = base + so.value // 4 + SB[i].num_passes * lstride.value + ro[i] * D
-            finals.append(raw[at:at + (ro[i + 1] - ro[i]) * D].reshape(-1, D).copy())
+            levels.append([raw[base + so.value // 4 + lv * lstride.value + ro[i] * D:
+                               base + so.value // 4 + lv * lstride.value + ro[i + 1] * D].reshape(-1, D).copy()
+                           for lv in range(SB[i].num_passes + 1)])
+            finals.append(levels[-1][-1])
             assert np.isfinite(finals[-1]).all()
-        gen = between(finals)
+        gen = between(finals, levels)
         q = np.ascontiguousarray(next(gen), np.float32)            # query embeddings [graphs, D], batch order
         assert q.shape == (Gtot, D)
         put_at(ws, base + qo.value // 4, q)
@@ -220,10 +222,17 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
         call(_capi.STEP_PHASE_SCORES, 0)
         raw = np.asarray(be.get(ws))
         gq = raw[base + gqo.value // 4: base + gqo.value // 4 + Gtot * D].reshape(Gtot, D).copy()
-        gfinal = gen.send(gq)                                       # d loss / d final states, per batch
+        # d loss / d final states per batch, or {level: d loss / d states} (a readout over every level: ADD_STATE_GRADS)
+        gfinal = gen.send(gq)
         for i in range(nb):
-            put_at(ws, base + go.value // 4 + SB[i].num_passes * lstride.value + ro[i] * D, np.ascontiguousarray(gfinal[i], np.float32))
+            per = gfinal[i] if isinstance(gfinal[i], dict) else {SB[i].num_passes: gfinal[i]}
+            if isinstance(gfinal[i], dict):
+                P.flags |= _capi.STEP_ADD_STATE_GRADS
+                assert sorted(per) == list(range(1, SB[i].num_passes + 1))
+            for lv, g in per.items():
+                put_at(ws, base + go.value // 4 + lv * lstride.value + ro[i] * D, np.ascontiguousarray(g, np.float32))
         call(_capi.STEP_PHASE_FROM_STATES, 0)
+        P.flags &= ~_capi.STEP_ADD_STATE_GRADS
     for rep in range(0 if between is not None else repeat):       # (repeat > 1: the same packed step again -- its hand-off epochs / counters carry on)
         be.check(be.lib.mpqe_step_forward_backward(ctypes.byref(P), SB, nb, be.ptr(d_anchor), be.ptr(d_tg),
                                                    be.ptr(d_ng), margin, ctypes.byref(G), backward, be.ptr(loss),
@@ -278,7 +287,8 @@ def test_fused_step_matches_oracle(be, readout, adaptive, shared, L, mix):
         np.testing.assert_allclose(grads[k], ref, rtol=1e-4, atol=2e-6, err_msg=k)
 
 
-@pytest.mark.parametrize('readout,adaptive,shared,zero', [('mlp', True, False, True), ('targetmlp', False, True, False)])
+@pytest.mark.parametrize('readout,adaptive,shared,zero', [('mlp', True, False, True), ('targetmlp', False, True, False),
+                                                          ('concat', False, False, True)])
 def test_step_in_three_calls_around_a_callers_readout(be, readout, adaptive, shared, zero):
     """The learned readouts (reference model.py:497-553) are the CALLER's: the step runs as three calls -- node states
     out; query embeddings in, their gradients out; state gradients in -- with the caller's readout in between, here the
@@ -288,19 +298,28 @@ def test_step_in_three_calls_around_a_callers_readout(be, readout, adaptive, sha
     ref_loss, ref_per, ref_sp, ref_sn = oracle_step(params, cfg, node_map, batches, margin)
     seen = {}
 
-    def between(finals):
-        hs = [torch.from_numpy(f).requires_grad_(True) for f in finals]
+    def between(finals, levels):
         local = {k: v.detach().clone().requires_grad_(True) for k, v in params.items() if k.startswith('readout.')}
-        qs = []
-        for b, h in zip(batches, hs):
+        qs, leaves = [], []
+        for b, lv in zip(batches, levels):
             col = b['col']
+            if readout == 'concat':             # reference model.py:441-446: every layer's output, side by side
+                hs = [torch.from_numpy(x).requires_grad_(True) for x in lv[1:]]
+                h = torch.cat(hs, dim=1)
+            else:
+                hs = [torch.from_numpy(lv[-1]).requires_grad_(True)]
+                h = hs[0]
+            leaves.append(hs)
             qs.append(ref_cpu.readout(cfg['readout'], cfg['scatter_op'], local, h, torch.as_tensor(col['batch']), col['B'],
                                       col['N'], col['A']))
         q = torch.cat(qs, dim=0)
         gq = yield q.detach().numpy()
         q.backward(torch.from_numpy(gq))
         seen['readout'] = {k: v.grad.numpy() for k, v in local.items()}
-        yield [h.grad.numpy() for h in hs]
+        if readout == 'concat':
+            yield [{1 + i: h.grad.numpy() for i, h in enumerate(hs)} for hs in leaves]
+        else:
+            yield [hs[0].grad.numpy() for hs in leaves]
 
     loss, sp, sn, grads, err = run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin,
                                         flags=_capi.STEP_ZERO_GRADS if zero else 0, between=between, repeat=2 if zero else 1)
@@ -318,11 +337,13 @@ def test_step_in_three_calls_around_a_callers_readout(be, readout, adaptive, sha
         ref = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
         np.testing.assert_allclose(grads[k], ref, rtol=1e-4, atol=2e-6, err_msg=k)
     # forward only: scores and loss from the caller's embeddings, no gradient touched
-    def forward_only(finals):
+    def forward_only(finals, levels):
         with torch.no_grad():
-            yield torch.cat([ref_cpu.readout(cfg['readout'], cfg['scatter_op'], params, torch.from_numpy(f),
+            hs = [torch.cat([torch.from_numpy(x) for x in lv[1:]], dim=1) if readout == 'concat' else torch.from_numpy(lv[-1])
+                  for lv in levels]
+            yield torch.cat([ref_cpu.readout(cfg['readout'], cfg['scatter_op'], params, h,
                                              torch.as_tensor(b['col']['batch']), b['col']['B'], b['col']['N'], b['col']['A'])
-                             for b, f in zip(batches, finals)], dim=0).numpy()
+                             for b, h in zip(batches, hs)], dim=0).numpy()
     loss, sp, sn, grads, err = run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=0,
                                         between=forward_only)
     assert err == 0
