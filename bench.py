@@ -600,7 +600,7 @@ def main():
     pool = [StepData(schema, model, args.batch_size, rng, device) for _ in range(4)]      # 4 formula sets
 
     use_fused = args.path in ('auto', 'fused') and args.readout in ('mp', 'sum', 'max', 'mlp', 'targetmlp', 'concat')
-    learned = args.readout in ('mlp', 'targetmlp', 'concat')        # (fused step = three library calls around the readout: fused.py)
+    learned = args.readout in ('mlp', 'targetmlp', 'concat')        # (fused step on the level form, the readout inside the call: csrc/step_readout.h)
     fresh = use_fused and not args.replay and not args.graph
     reducer = fstep = packed = captured = exchange = xplans = fresh_ids = descs = None
     n_total = args.warmup + args.steps * max(1, args.repeats)
@@ -723,8 +723,8 @@ def main():
                    'global_query_graphs_per_step': graphs_per_step,
                    'parallelism': 'dp%d (graphs sharded by rank, RCCL all-reduce of gradients)' % world
                                   if world > 1 else 'single GPU',
-                   'host_path': ('fused step: %s per step, %d stream lane(s)%s'
-                                 % ('three C-ABI calls around the learned readout of all batches' if learned else 'one C-ABI call',
+                   'host_path': ('fused step: one C-ABI call per step%s, %d stream lane(s)%s'
+                                 % (' (level form, learned readout inside)' if learned else '',
                                     args.lanes, ', replayed from a hipGraph' if args.graph else '')) if use_fused
                                 else 'drop-in modules (one autograd graph per step)',
                    'ids': ('fresh every step: %d pre-drawn id sets resident in HBM, 4 formula sets; id -> row lookups and the '
@@ -810,7 +810,7 @@ def main():
     if rank == 0:
         flops_fwd, flops_all, bytes_all, launches = layer_work(pool[0], model)
         executed = None
-        if use_fused and not learned:
+        if use_fused and not learned:      # (the learned readouts run the level form: its roofline line is the layer kernel's)
             fams, executed = time_fused_kernels(fstep, packed[0], pool[0], model, args.readout)
             dom = max(fams, key=lambda f: f['total_us_per_step'])
             out['roofline'] = {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['achieved'],
@@ -842,7 +842,7 @@ def main():
                                'launches_per_step': launches}
             if learned and use_fused:
                 out['roofline']['note'] = ('the layer tile core timed through the module path\'s launch (one batch per launch); the '
-                                           'fused three-call step runs the same core over all batches of a level per launch')
+                                           'fused step\'s level form runs the same core over all batches of a level per launch')
         if world == 1 and not args.no_scatter:
             out['roofline_scatter'] = time_scatter_aggregate()
         out['step_work'] = {'layer_flops_fwd_bwd': flops_all, 'scatter_aggregate_bytes_fwd_bwd': bytes_all,

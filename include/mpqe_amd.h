@@ -64,7 +64,12 @@ enum {
     MPQE_Q_3INTER = 4, MPQE_Q_3INTER_CHAIN = 5, MPQE_Q_3CHAIN_INTER = 6, MPQE_Q_COUNT = 7
 };
 enum { MPQE_READOUT_SUM = 0, MPQE_READOUT_MAX = 1, MPQE_READOUT_TM = 2,
-       MPQE_READOUT_CALLER = 3 /* fused step only: the readout is the caller's (MPQE_STEP_PHASE_*) */ };
+       MPQE_READOUT_CALLER = 3 /* fused step only: the readout is the caller's (MPQE_STEP_PHASE_*) */,
+       /* fused step only: the reference's learned readouts, Linear(in, dim) - ReLU - Linear(dim, dim) per row, then a
+        * reduction over each graph's rows (mpqe_step_params_t.readout_*): MLP (model.py:497-515; in = dim, a row per node),
+        * TARGETMLP (model.py:518-553; in = 2 dim, a row [target | node] per non-target node), CONCAT (model.py:441-446;
+        * in = num_layers dim, a node's states after every layer side by side -- every batch runs num_layers passes) */
+       MPQE_READOUT_MLP = 4, MPQE_READOUT_TARGETMLP = 5, MPQE_READOUT_CONCAT = 6 };
 enum { MPQE_SCATTER_ADD = 0, MPQE_SCATTER_MAX = 1, MPQE_SCATTER_MEAN = 2 };
 #define MPQE_MAX_TEMPLATE_EDGES 3
 #define MPQE_MAX_TEMPLATE_NODES 4
@@ -336,6 +341,13 @@ typedef struct {
     const float *basis[MPQE_STEP_MAX_LAYERS];    /* layers[i].basis [R, dim, dim]; shared      */
     const float *root[MPQE_STEP_MAX_LAYERS];     /* layers repeat the same pointers            */
     const float *bias[MPQE_STEP_MAX_LAYERS];
+    /* learned readouts (MPQE_READOUT_MLP / _TARGETMLP / _CONCAT): the two Linear layers as nn.Linear stores them
+     * (weight [out, in] row-major, bias [out]); readout_scatter = MPQE_SCATTER_* of the reduction (the reference's
+     * --scatter_op); readout_weight_decay: model.py:486-490, loss += weight_decay * (sum of the four parameters'
+     * 2-norms) per margin_loss call, i.e. times the sum of the batch weights (0 = off). Level form, dim % 4 == 0.  */
+    const float *readout_w0, *readout_b0, *readout_w2, *readout_b2;
+    int32_t readout_scatter;
+    float readout_weight_decay;
 } mpqe_step_params_t;
 
 typedef struct {
@@ -344,6 +356,7 @@ typedef struct {
     float *basis[MPQE_STEP_MAX_LAYERS];
     float *root[MPQE_STEP_MAX_LAYERS];
     float *bias[MPQE_STEP_MAX_LAYERS];
+    float *readout_w0, *readout_b0, *readout_w2, *readout_b2;      /* learned readouts                  */
 } mpqe_step_grads_t;
 
 /* Stream lanes (optional). At the reference's batch size every launch of the step is short enough that

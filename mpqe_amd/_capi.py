@@ -40,13 +40,16 @@ class StepParams(ctypes.Structure):
                 ('tables', c_void_p * STEP_MAX_MODES), ('table_rows', ctypes.c_int64 * STEP_MAX_MODES),
                 ('node_map', c_void_p), ('node_map_len', ctypes.c_int64), ('mode_emb', c_void_p),
                 ('basis', c_void_p * STEP_MAX_LAYERS), ('root', c_void_p * STEP_MAX_LAYERS),
-                ('bias', c_void_p * STEP_MAX_LAYERS)]
+                ('bias', c_void_p * STEP_MAX_LAYERS),
+                ('readout_w0', c_void_p), ('readout_b0', c_void_p), ('readout_w2', c_void_p), ('readout_b2', c_void_p),
+                ('readout_scatter', ctypes.c_int32), ('readout_weight_decay', ctypes.c_float)]
 
 
 class StepGrads(ctypes.Structure):
     _fields_ = [('tables', c_void_p * STEP_MAX_MODES), ('mode_emb', c_void_p),
                 ('basis', c_void_p * STEP_MAX_LAYERS), ('root', c_void_p * STEP_MAX_LAYERS),
-                ('bias', c_void_p * STEP_MAX_LAYERS)]
+                ('bias', c_void_p * STEP_MAX_LAYERS),
+                ('readout_w0', c_void_p), ('readout_b0', c_void_p), ('readout_w2', c_void_p), ('readout_b2', c_void_p)]
 
 
 STEP_MAX_LANES = 4
@@ -126,6 +129,7 @@ QUERY_TYPE_IDS = {'1-chain': 0, '2-chain': 1, '3-chain': 2, '2-inter': 3, '3-int
 QUERY_NAMES = {v: k for k, v in QUERY_TYPE_IDS.items()}
 READOUT_IDS = {'sum': 0, 'max': 1, 'mp': 2}
 READOUT_CALLER = 3          # fused step only: the readout is the caller's (STEP_PHASE_*)
+LEARNED_READOUT_IDS = {'mlp': 4, 'targetmlp': 5, 'concat': 6}      # fused step only (StepParams.readout_*)
 SCATTER_IDS = {'add': 0, 'max': 1, 'mean': 2}
 
 FLAG_BAD_NODE_ID, FLAG_BAD_EDGE, FLAG_BAD_RELATION, FLAG_BAD_INDEX = 1, 2, 4, 8

@@ -255,6 +255,7 @@ __device__ __forceinline__ float *pick_grad(float *const *arr, int li) {
 #include "step_uniform.h"
 #include "step_touch.h"
 #include "grad_w_reg.h"
+#include "step_readout.h"
 #define LD_T 3          // weight-gradient launch of the chain form: register-only K loop (grad_w_reg.h)
 
 // Prologue roles of the chain launch (they were a launch of their own, 9 us in front of the chain kernel): the forward
@@ -1402,6 +1403,11 @@ struct HostPlan {
     // workspace offsets (bytes)
     size_t o_sd, o_wsrc, o_wblock, o_vsrc, o_vblock, o_groups, o_anchor, desc_total;     // descriptor buffer
     size_t o_H, o_GH, o_tpos, o_tneg, o_spos, o_sneg, o_terms, o_slabs, o_parts, o_Q, o_GQ, total;  // workspace
+    // learned readouts (step_readout.h): input rows, hidden, output and their gradients, argmax, dense-layer workspace
+    size_t o_rx, o_rh, o_ry, o_rgy, o_rgh, o_rgx, o_rarg, o_rlin, rlin_bytes;
+    long long ro_rows;
+    int ro_kin;
+    bool ro_direct;
     long long level_stride;
 };
 
@@ -1462,7 +1468,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     if (P->dim <= 0 || P->dim > 64 * STEP_MAX_COLS_PER_LANE) return MPQE_ERR_UNSUPPORTED;
     if (P->num_layers <= 0 || P->num_layers > MPQE_STEP_MAX_LAYERS) return MPQE_ERR_UNSUPPORTED;
     if (P->num_modes <= 0 || P->num_modes > MPQE_STEP_MAX_MODES) return MPQE_ERR_UNSUPPORTED;
-    if (P->readout < 0 || P->readout > MPQE_READOUT_CALLER) return MPQE_ERR_INVALID_ARG;
+    if (P->readout < 0 || P->readout > MPQE_READOUT_CONCAT) return MPQE_ERR_INVALID_ARG;
     const int D = P->dim;
     StepDev &sd = hp->sd;
     memset(&sd, 0, sizeof(sd));
@@ -2398,8 +2404,32 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->o_sneg = take((size_t)graphs * 4);
     hp->o_terms = take((size_t)graphs * 4);
     // (the caller's readout: its query embeddings in, their gradients out)
-    hp->o_Q = take(P->readout == MPQE_READOUT_CALLER ? (size_t)graphs * D * 4 : 0);
-    hp->o_GQ = take(P->readout == MPQE_READOUT_CALLER ? (size_t)graphs * D * 4 : 0);
+    hp->o_Q = take(P->readout >= MPQE_READOUT_CALLER ? (size_t)graphs * D * 4 : 0);
+    hp->o_GQ = take(P->readout >= MPQE_READOUT_CALLER ? (size_t)graphs * D * 4 : 0);
+    hp->ro_rows = 0;
+    hp->ro_kin = 0;
+    hp->ro_direct = false;
+    hp->rlin_bytes = 0;
+    if (P->readout >= MPQE_READOUT_MLP) {
+        const bool pairs = P->readout == MPQE_READOUT_TARGETMLP;
+        hp->ro_rows = pairs ? rows - graphs : rows;
+        hp->ro_kin = pairs ? 2 * D : (P->readout == MPQE_READOUT_CONCAT ? P->num_layers * D : D);
+        // (mlp with every batch at the same depth: the input rows ARE the final level of H, their gradient the same level of GH)
+        bool same = true;
+        for (int i = 1; i < nb; ++i) same = same && hp->sd.b[i].L == hp->sd.b[0].L;
+        hp->ro_direct = P->readout == MPQE_READOUT_MLP && same;
+        const size_t xin = (size_t)hp->ro_rows * hp->ro_kin * 4, xd = (size_t)hp->ro_rows * D * 4;
+        hp->o_rx = take(hp->ro_direct ? 0 : xin);
+        hp->o_rgx = take(hp->ro_direct ? 0 : xin);
+        hp->o_rh = take(xd);
+        hp->o_ry = take(xd);
+        hp->o_rgy = take(xd);
+        hp->o_rgh = take(xd);
+        hp->o_rarg = take((size_t)graphs * D);
+        hp->rlin_bytes = std::max(mpqe_linear_bwd_workspace_bytes(hp->ro_rows, hp->ro_kin, D),
+                                  mpqe_linear_bwd_workspace_bytes(hp->ro_rows, D, D));
+        hp->o_rlin = take(hp->rlin_bytes);
+    }
     hp->o_slabs = take((size_t)hp->total_slabs * D * D * 4);
     hp->o_parts = take((size_t)hp->total_parts * D * 4);
     hp->o_WT = take(hp->wt_slots.size() * (size_t)D * D * 4);
@@ -2551,7 +2581,7 @@ static std::shared_ptr<CachedPlan> plan_for(const mpqe_step_params_t *P, const m
 static bool want_chain(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb) {
     if (!P || !B || nb < 1 || nb > MPQE_STEP_MAX_BATCHES) return false;
     bool use_chain = !(P->flags & MPQE_STEP_NO_CHAIN) && (P->dim == 64 || P->dim == 128 || P->dim == 256) &&
-                     P->readout != MPQE_READOUT_CALLER;      // (the caller's readout needs the node states in HBM)
+                     P->readout < MPQE_READOUT_CALLER;      // (the caller's / the learned readouts need the node states in HBM)
     if (!use_chain) return false;
     long long graphs = 0;
     for (int i = 0; i < nb; ++i) graphs += B[i].batch_size;
@@ -2861,6 +2891,8 @@ extern "C" int mpqe_adam_rows_step(const void *touch, int64_t num_entries, float
     return mpqe_launch_status();
 }
 
+static int D_ok_for_readout(int D) { return D % 4 == 0; }      // (16-byte rows in step_readout.h)
+
 extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb,
                                           const int64_t *anchor_ids, const int64_t *targets, const int64_t *negs,
                                           float margin, const mpqe_step_grads_t *G, int backward,
@@ -2906,9 +2938,19 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     const bool phase_fwd = phase == MPQE_STEP_PHASE_STATES, phase_bwd = phase == MPQE_STEP_PHASE_FROM_STATES;
     const bool phase_score = phase == MPQE_STEP_PHASE_SCORES || phase == MPQE_STEP_PHASE_SCORES_ONLY;
     if ((phase >= 2) != (P->readout == MPQE_READOUT_CALLER)) return MPQE_ERR_INVALID_ARG;
-    if (phase >= 2 && (use_chain || hp.nlanes > 1)) return MPQE_ERR_UNSUPPORTED;
+    const bool learned = P->readout >= MPQE_READOUT_MLP;       // (step_readout.h: the readout's two Linear layers are the library's too)
+    if ((phase >= 2 || learned) && (use_chain || hp.nlanes > 1)) return MPQE_ERR_UNSUPPORTED;
+    if (learned) {
+        if (!P->readout_w0 || !P->readout_b0 || !P->readout_w2 || !P->readout_b2) return MPQE_ERR_INVALID_ARG;
+        if (P->readout_scatter < MPQE_SCATTER_ADD || P->readout_scatter > MPQE_SCATTER_MEAN) return MPQE_ERR_INVALID_ARG;
+        if (D_ok_for_readout(P->dim) == 0) return MPQE_ERR_UNSUPPORTED;
+        if (backward && G && (!G->readout_w0 || !G->readout_b0 || !G->readout_w2 || !G->readout_b2)) return MPQE_ERR_INVALID_ARG;
+        if (P->readout == MPQE_READOUT_CONCAT)
+            for (int i = 0; i < nb; ++i)
+                if (hp.sd.b[i].L != P->num_layers) return MPQE_ERR_INVALID_ARG;     // (model.py:441-446: one input block per layer)
+    }
     // (the caller's readout read every level: its gradients of the intermediate levels are in the workspace already)
-    const int add_states = (phase_bwd && (P->flags & MPQE_STEP_ADD_STATE_GRADS)) ? 1 : 0;
+    const int add_states = ((phase_bwd && (P->flags & MPQE_STEP_ADD_STATE_GRADS)) || P->readout == MPQE_READOUT_CONCAT) ? 1 : 0;
     if (phase == MPQE_STEP_PHASE_SCORES_ONLY) backward = 0;        // (scores and loss from the caller's embeddings, no gradients)
     // touch plan given: the chain form stores per-entry table-gradient rows and sums them per destination (no atomics)
     bool use_touch = touch != nullptr && use_chain && backward;
@@ -3059,6 +3101,12 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                 seg(G->bias[l], D);
             }
             seg(G->mode_emb, (long long)P->num_modes * D);
+            if (learned) {
+                seg(G->readout_w0, (long long)D * hp.ro_kin);
+                seg(G->readout_b0, D);
+                seg(G->readout_w2, (long long)D * D);
+                seg(G->readout_b2, D);
+            }
             // (SPARSE_TABLES: only the touched rows of the table gradients are ever read; they are written, not accumulated)
             for (int m = 0; m < P->num_modes && !sparse_tables; ++m) seg(G->tables[m], (long long)P->table_rows[m] * D);
             zs.block0[zs.count] = zblocks;
@@ -3382,8 +3430,70 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         mark(s);
     }
     // ---- forward
-    const float *Qc = P->readout == MPQE_READOUT_CALLER ? reinterpret_cast<const float *>(wb + hp.o_Q) : nullptr;
-    float *GQc = P->readout == MPQE_READOUT_CALLER ? reinterpret_cast<float *>(wb + hp.o_GQ) : nullptr;
+    const float *Qc = P->readout >= MPQE_READOUT_CALLER ? reinterpret_cast<const float *>(wb + hp.o_Q) : nullptr;
+    float *GQc = P->readout >= MPQE_READOUT_CALLER ? reinterpret_cast<float *>(wb + hp.o_GQ) : nullptr;
+    // learned readouts: gather -> Linear - ReLU - Linear -> reduction over each graph's rows, and the way back
+    RoArgs roa;
+    memset(&roa, 0, sizeof(roa));
+    roa.kind = P->readout;
+    roa.op = P->readout_scatter;
+    roa.mrows = hp.ro_rows;
+    roa.kin = hp.ro_kin;
+    roa.level_stride = hp.level_stride;
+    float *ro_x = nullptr, *ro_gx = nullptr, *ro_h = nullptr, *ro_y = nullptr, *ro_gy = nullptr, *ro_gh = nullptr;
+    signed char *ro_arg = nullptr;
+    if (learned) {
+        const long long lv = (long long)hp.sd.b[0].L * hp.level_stride;
+        ro_x = hp.ro_direct ? H + lv : reinterpret_cast<float *>(wb + hp.o_rx);
+        ro_gx = hp.ro_direct ? GH + lv : reinterpret_cast<float *>(wb + hp.o_rgx);
+        ro_h = reinterpret_cast<float *>(wb + hp.o_rh);
+        ro_y = reinterpret_cast<float *>(wb + hp.o_ry);
+        ro_gy = reinterpret_cast<float *>(wb + hp.o_rgy);
+        ro_gh = reinterpret_cast<float *>(wb + hp.o_rgh);
+        ro_arg = reinterpret_cast<signed char *>(wb + hp.o_rarg);
+    }
+    auto ro_blocks = [](long long threads) { return dim3((unsigned)((threads + 255) / 256)); };
+    auto ro_forward = [&]() -> int {
+        if (!hp.ro_direct)
+            hipLaunchKernelGGL(step_ro_gather_kernel, ro_blocks(roa.mrows * (roa.kin / 4)), dim3(256), 0, s, sd, roa,
+                               (const float *)H, ro_x);
+        int st = mpqe_linear_fwd(ro_x, roa.mrows, P->readout_w0, roa.kin, P->readout_b0, roa.kin, D, 1, 0, ro_h, s);
+        if (st) return st;
+        st = mpqe_linear_fwd(ro_h, roa.mrows, P->readout_w2, D, P->readout_b2, D, D, 0, 0, ro_y, s);
+        if (st) return st;
+        hipLaunchKernelGGL(step_ro_reduce_kernel, ro_blocks(hp.sd.graphs_total * (D / 4)), dim3(256), 0, s, sd, roa,
+                           (const float *)ro_y, const_cast<float *>(Qc), ro_arg);
+        return MPQE_OK;
+    };
+    auto ro_backward = [&]() -> int {
+        hipLaunchKernelGGL(step_ro_expand_kernel, ro_blocks(roa.mrows * (D / 4)), dim3(256), 0, s, sd, roa,
+                           (const float *)GQc, (const signed char *)ro_arg, ro_gy);
+        void *lw = wb + hp.o_rlin;
+        int st = mpqe_linear_bwd(ro_h, roa.mrows, P->readout_w2, D, ro_y, ro_gy, D, D, 0, 0, ro_gh, G->readout_w2, D,
+                                 G->readout_b2, lw, hp.rlin_bytes, s);
+        if (st) return st;
+        st = mpqe_linear_bwd(ro_x, roa.mrows, P->readout_w0, roa.kin, ro_h, ro_gh, roa.kin, D, 1, 0, ro_gx,
+                             G->readout_w0, roa.kin, G->readout_b0, lw, hp.rlin_bytes, s);
+        if (st) return st;
+        if (!hp.ro_direct)
+            hipLaunchKernelGGL(step_ro_spread_kernel, ro_blocks(hp.sd.rows_total * (D / 4)), dim3(256), 0, s, sd, roa,
+                               (const float *)ro_gx, GH);
+        return MPQE_OK;
+    };
+    // the readout's regulariser (model.py:486-490), after the launch that writes loss[0]
+    auto ro_regulariser = [&](bool with_grads) {
+        float wsum = 0.f;
+        for (int i = 0; i < nb; ++i) wsum += hp.sd.b[i].weight;
+        if (!(P->readout_weight_decay > 0.f)) return;
+        RoRegArgs rr;
+        memset(&rr, 0, sizeof(rr));
+        rr.p[0] = P->readout_w0; rr.p[1] = P->readout_b0; rr.p[2] = P->readout_w2; rr.p[3] = P->readout_b2;
+        rr.n[0] = (long long)D * roa.kin; rr.n[1] = D; rr.n[2] = (long long)D * D; rr.n[3] = D;
+        if (with_grads) { rr.g[0] = G->readout_w0; rr.g[1] = G->readout_b0; rr.g[2] = G->readout_w2; rr.g[3] = G->readout_b2; }
+        rr.coef = P->readout_weight_decay * wsum;
+        rr.loss = loss;
+        hipLaunchKernelGGL(step_ro_reg_kernel, dim3(1), dim3(1024), 0, s, rr);
+    };
     for (int l = 0; !use_chain && !phase_bwd && !phase_score && l < NL; ++l) {
         const long long nr = row0[l + 1] - row0[l], ngr = gr0[l + 1] - gr0[l];
         const long long waves = nr + 2 * ngr;
@@ -3427,11 +3537,16 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         }
     };
     if (phase_fwd) return mpqe_launch_status();     // the node states of every level are in the workspace (mpqe_step_states_layout)
+    if (learned && !use_chain) {
+        const int st = ro_forward();
+        if (st) return st;
+    }
     if (!backward) {      // (not reached with the chain kernel)
         for (int l = 0; l < NL; ++l) { LAUNCH_SCORE_D(false, (float *)nullptr, l); }
         join();
         hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss, lm, bterms,
                                use_chain ? epoch_f : (unsigned *)nullptr);
+        if (learned) ro_regulariser(false);
         return mpqe_launch_status();
     }
 
@@ -3441,6 +3556,10 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     // rows of gH[L_b] and the last call takes it from there)
     for (int l = 0; !use_chain && !phase_bwd && l < NL; ++l) { LAUNCH_SCORE_D(true, GH, l); }
     if (phase_score) return mpqe_launch_status();
+    if (learned && !use_chain) {
+        const int st = ro_backward();
+        if (st) return st;
+    }
 #undef LAUNCH_SCORE_D
 #undef LAUNCH_SCORE
     for (int p = hp.Lmax - 1; !use_chain && p >= 0; --p)
@@ -3478,5 +3597,6 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         dim3 grid(r_gx, (unsigned)hp.groups.size() + 1 + r_trows);
         hipLaunchKernelGGL(step_reduce_kernel, grid, dim3(256), 0, s, ra);
     }
+    if (learned) ro_regulariser(true);
     return mpqe_launch_status();
 }

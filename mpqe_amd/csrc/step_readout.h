@@ -1,0 +1,184 @@
+// Learned readouts of the fused step (level form): reference MLPReadout / TargetMLPReadout, model.py:497-553, and the
+// `concat` input of model.py:441-446. The two Linear layers run on the dense-layer kernels (dense.hip: mpqe_linear_fwd /
+// bwd); this file holds what sits around them, all of it HBM-bound row traffic:
+//   gather   X[m] = the readout's input row m        mlp: final state of node row m; concat: the states of levels 1 .. L side
+//                                                    by side; targetmlp: [target state | non-target state] of pair m
+//   reduce   q[g] = add / mean / max over graph g's   (torch_scatter semantics: max keeps the LOWEST row on ties -- strict > --,
+//            rows of Y (its N, or N - 1 pair, rows)   mean divides by the row count)
+//   expand   gY[m] = the reduction's backward
+//   spread   gX -> rows of the state-gradient levels  (targetmlp: the target's row gets the sum of its pairs' first halves)
+// A graph's rows are consecutive in every layout (graph-major node rows: row_off + g N + n; pairs: pair_off + g (N - 1) + k
+// with pair_off = row_off - g_off), so the scatter is a reduction over <= 4 consecutive rows: no index vector, no atomics.
+#pragma once
+
+struct RoArgs {
+    int kind;                // MPQE_READOUT_MLP / _TARGETMLP / _CONCAT
+    int op;                  // MPQE_SCATTER_ADD / _MAX / _MEAN
+    long long mrows;         // rows of X / Y
+    int kin;                 // columns of X
+    long long level_stride;  // floats between the levels of H / GH
+};
+
+__device__ __forceinline__ int ro_batch_of_row(const StepDev *__restrict__ sd, long long m, bool pairs) {
+    int bi = 0;
+    for (int i = 1; i < sd->nb; ++i) {
+        const long long o = pairs ? sd->b[i].row_off - sd->b[i].g_off : sd->b[i].row_off;
+        if (o <= m) bi = i;
+    }
+    return bi;
+}
+
+// one thread per (row m of X, 4 columns)
+__global__ __launch_bounds__(256) void step_ro_gather_kernel(const StepDev *__restrict__ sd, RoArgs ra,
+                                                             const float *__restrict__ H, float *__restrict__ X) {
+    const int D = sd->D, q = ra.kin / 4;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ra.mrows * q) return;
+    const long long m = t / q;
+    const int c = (int)(t % q) * 4;
+    const bool pairs = ra.kind == MPQE_READOUT_TARGETMLP;
+    const BatchDev &b = sd->b[ro_batch_of_row(sd, m, pairs)];
+    const float *src;
+    if (ra.kind == MPQE_READOUT_MLP) src = H + (long long)b.L * ra.level_stride + m * D + c;
+    else if (ra.kind == MPQE_READOUT_CONCAT) src = H + (long long)(c / D + 1) * ra.level_stride + m * D + c % D;
+    else {
+        const int N = b.tp.N, A = b.A;
+        const long long lm = m - (b.row_off - b.g_off), g = lm / (N - 1);
+        const int k = (int)(lm % (N - 1)), n = c < D ? A : (k < A ? k : k + 1);
+        src = H + (long long)b.L * ra.level_stride + (b.row_off + g * N + n) * D + (c < D ? c : c - D);
+    }
+    *reinterpret_cast<f32x4 *>(X + m * ra.kin + c) = *reinterpret_cast<const f32x4 *>(src);
+}
+
+// one thread per (graph, 4 columns): rows [r0, r0 + cnt) of Y
+__global__ __launch_bounds__(256) void step_ro_reduce_kernel(const StepDev *__restrict__ sd, RoArgs ra,
+                                                             const float *__restrict__ Y, float *__restrict__ Q,
+                                                             signed char *__restrict__ arg) {
+    const int D = sd->D, q = D / 4;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= sd->graphs_total * q) return;
+    const long long gi = t / q;
+    const int c = (int)(t % q) * 4;
+    int bi = 0;
+    for (int i = 1; i < sd->nb; ++i)
+        if (sd->b[i].g_off <= gi) bi = i;
+    const BatchDev &b = sd->b[bi];
+    const bool pairs = ra.kind == MPQE_READOUT_TARGETMLP;
+    const int cnt = pairs ? b.tp.N - 1 : b.tp.N;
+    const long long r0 = (pairs ? b.row_off - b.g_off : b.row_off) + (gi - b.g_off) * cnt;
+    f32x4 acc = *reinterpret_cast<const f32x4 *>(Y + r0 * D + c);
+    int am[4] = {0, 0, 0, 0};
+    for (int n = 1; n < cnt; ++n) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(Y + (r0 + n) * D + c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (ra.op == MPQE_SCATTER_MAX) {
+                if (v[u] > acc[u]) {
+                    acc[u] = v[u];
+                    am[u] = n;
+                }
+            } else acc[u] += v[u];
+        }
+    }
+    if (ra.op == MPQE_SCATTER_MEAN) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] /= (float)cnt;
+    }
+    *reinterpret_cast<f32x4 *>(Q + gi * D + c) = acc;
+    if (ra.op == MPQE_SCATTER_MAX && arg) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) arg[gi * D + c + u] = (signed char)am[u];
+    }
+}
+
+// one thread per (row m of Y, 4 columns)
+__global__ __launch_bounds__(256) void step_ro_expand_kernel(const StepDev *__restrict__ sd, RoArgs ra,
+                                                             const float *__restrict__ GQ,
+                                                             const signed char *__restrict__ arg, float *__restrict__ GY) {
+    const int D = sd->D, q = D / 4;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ra.mrows * q) return;
+    const long long m = t / q;
+    const int c = (int)(t % q) * 4;
+    const bool pairs = ra.kind == MPQE_READOUT_TARGETMLP;
+    const BatchDev &b = sd->b[ro_batch_of_row(sd, m, pairs)];
+    const int cnt = pairs ? b.tp.N - 1 : b.tp.N;
+    const long long lm = m - (pairs ? b.row_off - b.g_off : b.row_off), gi = b.g_off + lm / cnt;
+    const int n = (int)(lm % cnt);
+    f32x4 g = *reinterpret_cast<const f32x4 *>(GQ + gi * D + c);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (ra.op == MPQE_SCATTER_MEAN) g[u] /= (float)cnt;
+        else if (ra.op == MPQE_SCATTER_MAX) g[u] = arg[gi * D + c + u] == n ? g[u] : 0.f;
+    }
+    *reinterpret_cast<f32x4 *>(GY + m * D + c) = g;
+}
+
+// one thread per (node row, 4 columns of D): the gradient rows of the levels the readout read
+__global__ __launch_bounds__(256) void step_ro_spread_kernel(const StepDev *__restrict__ sd, RoArgs ra,
+                                                             const float *__restrict__ GX, float *__restrict__ GH) {
+    const int D = sd->D, q = D / 4;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= sd->rows_total * q) return;
+    const long long row = t / q;
+    const int c = (int)(t % q) * 4;
+    const BatchDev &b = sd->b[ro_batch_of_row(sd, row, false)];
+    if (ra.kind == MPQE_READOUT_MLP) {
+        *reinterpret_cast<f32x4 *>(GH + (long long)b.L * ra.level_stride + row * D + c) =
+            *reinterpret_cast<const f32x4 *>(GX + row * D + c);
+    } else if (ra.kind == MPQE_READOUT_CONCAT) {
+        for (int p = 0; p < b.L; ++p)
+            *reinterpret_cast<f32x4 *>(GH + (long long)(p + 1) * ra.level_stride + row * D + c) =
+                *reinterpret_cast<const f32x4 *>(GX + row * ra.kin + p * D + c);
+    } else {
+        const int N = b.tp.N, A = b.A;
+        const long long lr = row - b.row_off, g = lr / N, p0 = (b.row_off - b.g_off) + g * (N - 1);
+        const int n = (int)(lr % N);
+        f32x4 v;
+        if (n == A) {             // the target: first half of each of its graph's pairs, in pair order
+            v = *reinterpret_cast<const f32x4 *>(GX + p0 * ra.kin + c);
+            for (int k = 1; k < N - 1; ++k) {
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(GX + (p0 + k) * ra.kin + c);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] += w[u];
+            }
+        } else v = *reinterpret_cast<const f32x4 *>(GX + (p0 + (n < A ? n : n - 1)) * ra.kin + D + c);
+        *reinterpret_cast<f32x4 *>(GH + (long long)b.L * ra.level_stride + row * D + c) = v;
+    }
+}
+
+// model.py:486-490: loss += coef * sum_i ||p_i||_2 and (backward) grad_i += coef * p_i / ||p_i||. ONE workgroup walks the
+// four parameters in order (fixed order of every sum: reproducible); they are a few hundred KB.
+struct RoRegArgs {
+    const float *p[4];
+    float *g[4];
+    long long n[4];
+    float coef;
+    float *loss;
+};
+__global__ __launch_bounds__(1024) void step_ro_reg_kernel(RoRegArgs a) {
+    __shared__ float part[16];
+    __shared__ float total;
+    float sum_norms = 0.f;
+    for (int i = 0; i < 4; ++i) {
+        float s = 0.f;
+        for (long long k = threadIdx.x; k < a.n[i]; k += 1024) s += a.p[i][k] * a.p[i][k];
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tt = 0.f;
+            for (int w = 0; w < 16; ++w) tt += part[w];
+            total = sqrtf(tt);
+        }
+        __syncthreads();
+        const float nrm = total;
+        sum_norms += nrm;
+        if (a.g[i] && nrm > 0.f) {
+            const float sc = a.coef / nrm;
+            for (long long k = threadIdx.x; k < a.n[i]; k += 1024) a.g[i][k] += sc * a.p[i][k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && a.loss) *a.loss += a.coef * sum_norms;
+}

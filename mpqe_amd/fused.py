@@ -37,8 +37,7 @@ class StepBuffers(object):
 class PackedStep(object):
     __slots__ = ('batches', 'nb', 'anchor_ids', 'targets', 'negs', 'num_graphs', 'ws_bytes', 'sizes',
                  'desc', 'desc_bytes', 'desc_ptr', 'lanes', 'order', 'lane_begin', 'touch',
-                 'touch_ptr', 'touch_entries', 'touch_sizes', 'bufs', 'owner', 'ids_ref', 'step_flags', 'touch_mode', 'captured',
-                 'skey')
+                 'touch_ptr', 'touch_entries', 'touch_sizes', 'bufs', 'owner', 'ids_ref', 'step_flags', 'touch_mode', 'captured')
 
     @property
     def desc_resident(self):
@@ -144,14 +143,17 @@ class FusedTrainStep(object):
         enc = model.enc
         if not hasattr(enc, 'table') or getattr(enc, 'node_maps', None) is None:
             raise ValueError('FusedTrainStep needs a DirectEncoder built with node_maps')
-        # learned readouts (reference model.py:497-553): the step runs in three library calls around the readout, whose
-        # Linear layers and scatter run here on the final states of ALL batches at once (_run_states)
-        self.external = model.readout_str in ('mlp', 'targetmlp', 'concat')
-        if not self.external and model.readout_str not in _capi.READOUT_IDS:
+        # learned readouts (reference model.py:441-446, 497-553): inside the same library call -- gather, the two Linear
+        # layers on the dense-layer kernels, the reduction over each graph's rows, and back (csrc/step_readout.h); the
+        # level form runs (the node states must be in HBM)
+        self.learned = model.readout_str in _capi.LEARNED_READOUT_IDS
+        if not self.learned and model.readout_str not in _capi.READOUT_IDS:
             raise NotImplementedError('fused step: unknown readout %r' % model.readout_str)
-        if self.external:
+        if self.learned:
             if sparse_tables:
                 raise ValueError('sparse_tables needs the chain form (readouts sum / max / mp)')
+            if model.emb_dim % 4:
+                raise NotImplementedError('fused step with a learned readout: embedding dimension must be a multiple of 4')
             chain, touch, lanes = False, False, 1
         self.model = model
         self.margin = float(margin)
@@ -193,7 +195,7 @@ class FusedTrainStep(object):
         self.bind_grads()
         self.err = ops.new_error_word(self.device)
         self._ws = None
-        self._desc_cache, self._size_cache, self._pool, self._states_cache = {}, {}, {}, {}
+        self._desc_cache, self._size_cache, self._pool = {}, {}, {}
         self.num_lanes = max(1, min(int(lanes), _capi.STEP_MAX_LANES))
         self._streams = [None] + [torch.cuda.Stream(device=self.device) for _ in range(self.num_lanes - 1)]
         self._fork = torch.cuda.Event()
@@ -229,8 +231,8 @@ class FusedTrainStep(object):
                 raise RuntimeError('parameters must be contiguous fp32 CUDA tensors')
         layers = list(m.layers)
         self.P = _capi.make_step_params(
-            m.emb_dim, layers[0].num_relations, _capi.READOUT_CALLER if self.external else m.readout_str,
-            [t.data_ptr() for t in tabs],
+            m.emb_dim, layers[0].num_relations,
+            _capi.LEARNED_READOUT_IDS[m.readout_str] if self.learned else m.readout_str, [t.data_ptr() for t in tabs],
             [t.shape[0] for t in tabs], m.enc.node_maps.data_ptr(), m.enc.node_maps.shape[0],
             m.mode_embeddings.weight.data_ptr(), [l.basis.data_ptr() for l in layers],
             [l.root.data_ptr() for l in layers], [l.bias.data_ptr() for l in layers], flags=self.flags)
@@ -238,6 +240,18 @@ class FusedTrainStep(object):
             [t.grad.data_ptr() for t in tabs], m.mode_embeddings.weight.grad.data_ptr(),
             [l.basis.grad.data_ptr() for l in layers], [l.root.grad.data_ptr() for l in layers],
             [l.bias.grad.data_ptr() for l in layers])
+        if self.learned:
+            lay = m.readout.layers            # nn.Sequential(Linear, ReLU, Linear): state_dict keys layers.0 / layers.2
+            ro = (lay[0].weight, lay[0].bias, lay[2].weight, lay[2].bias)
+            for t in ro:
+                if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.requires_grad):
+                    raise RuntimeError('readout parameters must be trainable contiguous fp32 CUDA tensors')
+            for field, t in zip(('readout_w0', 'readout_b0', 'readout_w2', 'readout_b2'), ro):
+                setattr(self.P, field, t.data_ptr())
+                setattr(self.G, field, t.grad.data_ptr())
+            self.P.readout_scatter = _capi.SCATTER_IDS[{ops.scatter_add: 'add', ops.scatter_max: 'max',
+                                                        ops.scatter_mean: 'mean'}[m.readout.scatter_fn]]
+            self.P.readout_weight_decay = float(m.weight_decay)
         self._keep = (tabs, layers)
 
     def flatten_ids(self, batches, out=None):
@@ -295,6 +309,8 @@ class FusedTrainStep(object):
         for b in batches:
             qt = b['formula'].query_type
             passes_of.append(RGCNQueryDataset.query_diameters[qt] if m.adaptive else m.num_layers)
+        if self.learned and m.readout_str == 'concat' and any(p != m.num_layers for p in passes_of):
+            raise ValueError('concat readout: every batch must run num_layers passes (adaptive=False)')
         nl = min(self.num_lanes, nb)
         graphs = sum(_bsize(b) for b in batches)
         chain = (not (self.flags & _capi.STEP_NO_CHAIN) and m.emb_dim in (64, 128, 256)
@@ -407,7 +423,7 @@ class FusedTrainStep(object):
             bufs = StepBuffers()
             bufs.skey = skey
             bufs.desc = torch.empty(ps.desc_bytes + 256, dtype=torch.uint8, device=self.device)
-        ps.bufs, ps.owner, ps.skey = bufs, self, skey
+        ps.bufs, ps.owner = bufs, self
         ps.desc = bufs.desc
         ps.desc_ptr = (ps.desc.data_ptr() + 255) // 256 * 256
         ps.batches, ps.nb, ps.sizes = SB, nb, sizes
@@ -552,10 +568,6 @@ class FusedTrainStep(object):
         captured graph owns its arena: see capture())."""
         if backward:
             self.bind_grads()
-        if self.external:
-            if events is not None:
-                raise ValueError('events: not with a learned readout (the step is three library calls)')
-            return self._run_states(packed, backward, zero_grad, scores, workspace)
         # the library zero-fills the gradient buffers itself (one launch with its other prologue work)
         self.P.flags = self.flags | packed.step_flags | (_capi.STEP_ZERO_GRADS if (backward and zero_grad) else 0)
         bufs = packed.bufs
@@ -590,172 +602,6 @@ class FusedTrainStep(object):
             if bufs.last_use is None:
                 bufs.last_use = torch.cuda.Event()
             bufs.last_use.record(stream)                # (the pinned id buffer may be refilled once this step has run)
-        if scores:
-            return loss, sp, sn
-        return loss
-
-    # ------------------------------------------------------------------ learned readouts: the step in three library calls
-    def _states_plan(self, packed):
-        """Workspace offsets and index tensors of a descriptor set for the readout between the calls (cached per set:
-        functions of the formulas and batch sizes alone)."""
-        plan = self._states_cache.get(packed.skey)
-        if plan is not None:
-            return plan
-        nb, dev = packed.nb, self.device
-        i64 = ctypes.c_int64
-        so, go, ls, ro, qo, gqo = i64(), i64(), i64(), (i64 * (nb + 1))(), i64(), i64()
-        st = ops.lib().mpqe_step_states_layout(ctypes.byref(self.P), packed.batches, nb, packed.lanes, ctypes.byref(so),
-                                              ctypes.byref(go), ctypes.byref(ls), ro, ctypes.byref(qo), ctypes.byref(gqo))
-        _capi.check(ops.lib(), st, 'mpqe_step_states_layout')
-        D = self.model.emb_dim
-        rows_total = int(ro[nb])
-        if int(ls.value) != rows_total * D:
-            raise _capi.MpqeError('mpqe_step_states_layout: unexpected level stride')
-        final, grow, nt, tr, pg = [], [], [], [], []
-        g0, lmax, lmin = 0, 0, 1 << 30
-        for i in range(nb):
-            sb = packed.batches[i]
-            B, L = int(sb.batch_size), int(sb.num_passes)
-            A, N, _ = _TEMPLATES[_capi.QUERY_NAMES[int(sb.query_type)]]
-            lmax, lmin = max(lmax, L), min(lmin, L)
-            r0 = int(ro[i])
-            rows = np.arange(B * N, dtype=np.int64)
-            final.append(L * rows_total + r0 + rows)
-            g_of = g0 + rows // N
-            grow.append(g_of)
-            keep = (rows % N) != A                   # the target is node A (after the anchors)
-            nt.append(r0 + rows[keep])
-            tr.append(r0 + (rows[keep] // N) * N + A)
-            pg.append(g_of[keep])
-            g0 += B
-        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        # (every batch at the same depth: its final states are one contiguous block of the workspace -- no gather)
-        plan = dict(states_offset=int(so.value), grads_offset=int(go.value), queries_offset=int(qo.value),
-                    query_grads_offset=int(gqo.value), rows_total=rows_total, levels=lmax + 1, G=g0,
-                    final=None if lmin == lmax else t(np.concatenate(final)), depth=lmax,
-                    graph_of_row=t(np.concatenate(grow)), non_target=t(np.concatenate(nt)),
-                    target_row=t(np.concatenate(tr)), pair_graph=t(np.concatenate(pg)),
-                    weight_sum=float(sum(float(packed.batches[i].weight) for i in range(nb))))
-        if len(self._states_cache) > 1024:
-            self._states_cache.clear()
-        self._states_cache[packed.skey] = plan
-        return plan
-
-    def _run_states(self, packed, backward, zero_grad, scores, workspace):
-        """run() for the learned readouts (include/mpqe_amd.h: MPQE_READOUT_CALLER). Library call 1: gather + every level
-        forward. Here: the readout of ALL batches at once on their final node states -- Linear-ReLU-Linear through
-        ops.linear (mpqe_linear_fwd / bwd), the scatter kernel -- into the workspace. Library call 2: scores, hinge,
-        d loss / d embedding, target-table gradients. Here: that gradient back through the readout (torch.autograd.grad: no
-        AccumulateGrad nodes, so the whole step can be captured into a hipGraph). Library call 3: levels backward, weight
-        gradients, anchors' table gradients, reduction, loss. loss[0] carries the reference's readout regulariser
-        (model.py:486-490: weight_decay * sum of the parameter norms, once per margin_loss call, hence times the sum of the
-        batch weights); loss[1 + i] is batch i's mean hinge."""
-        m, dev = self.model, self.device
-        plan = self._states_plan(packed)
-        bufs = packed.bufs
-        stream = torch.cuda.current_stream(dev)
-        self.P.flags = self.flags | (_capi.STEP_ZERO_GRADS if (backward and zero_grad) else 0)
-        if workspace is None:
-            wptr = self._workspace(packed.ws_bytes)
-            arena = self._ws
-        else:
-            if workspace.numel() < packed.ws_bytes + 256 or workspace.device != dev:
-                raise ValueError('workspace too small for this packed step')
-            wptr = (workspace.data_ptr() + 255) // 256 * 256
-            arena = workspace
-        base = wptr - arena.data_ptr()
-        D, G, R = m.emb_dim, plan['G'], plan['rows_total']
-
-        # (two aliases of the arena with version counters of their own: the states autograd saves are views of the first,
-        # everything written here goes through the second -- the in-place check would otherwise see the writes)
-        a_read, a_write = arena.data, arena.data
-
-        def view(a, off, rows):
-            return a[base + off: base + off + 4 * rows * D].view(torch.float32).view(rows, D)
-        Hv, GHv = view(a_read, plan['states_offset'], plan['levels'] * R), view(a_write, plan['grads_offset'], plan['levels'] * R)
-        Qv, GQv = view(a_write, plan['queries_offset'], G), view(a_write, plan['query_grads_offset'], G)
-        loss = torch.empty(1 + packed.nb, dtype=torch.float32, device=dev)
-        sp = sn = None
-        if scores:
-            sp = torch.empty(G, dtype=torch.float32, device=dev)
-            sn = torch.empty_like(sp)
-        L = ops.lib()
-
-        def call(phase, upload):
-            args = (ctypes.byref(self.P), packed.batches, packed.nb, packed.anchor_ids.data_ptr(),
-                    packed.targets.data_ptr(), packed.negs.data_ptr(), self.margin, ctypes.byref(self.G), phase,
-                    loss.data_ptr(), None if sp is None else sp.data_ptr(), None if sn is None else sn.data_ptr(),
-                    packed.desc_ptr, packed.desc_bytes, upload, wptr, packed.ws_bytes, self.err.data_ptr(), packed.lanes,
-                    None, 0, None, stream.cuda_stream)
-            if torch.cuda.current_device() != dev.index:
-                with torch.cuda.device(dev):
-                    st = L.mpqe_step_forward_backward(*args)
-            else:
-                st = L.mpqe_step_forward_backward(*args)
-            _capi.check(L, st, 'mpqe_step_forward_backward')
-
-        call(_capi.STEP_PHASE_STATES, 0 if bufs.desc_resident else 1)
-        bufs.desc_resident = True
-        lay = m.readout.layers
-        rparams = [lay[0].weight, lay[0].bias, lay[2].weight, lay[2].bias]
-        if backward and zero_grad:                     # (the library fills the buffers it writes; these are the readout's)
-            torch._foreach_zero_([p.grad for p in rparams])
-        concat = m.readout_str == 'concat'
-        if concat:
-            # reference model.py:441-446: the outputs of every layer side by side (every batch runs num_layers passes)
-            if plan['final'] is not None or plan['depth'] != m.num_layers:
-                raise ValueError('concat readout: every batch must run num_layers passes (adaptive=False)')
-            h = Hv.view(plan['levels'], R, D)[1:].permute(1, 0, 2).reshape(R, plan['depth'] * D)
-        elif plan['final'] is None:
-            h = Hv[plan['depth'] * R: (plan['depth'] + 1) * R].detach()
-        else:
-            h = Hv.index_select(0, plan['final'])
-        h.requires_grad_(bool(backward))
-        # (fresh leaves aliasing the readout's parameters: a leaf is identified by its gradient accumulator node, and one
-        # kept alive by an older autograd graph of the caller's belongs to the stream it was made on -- inside a hipGraph
-        # capture the engine would then sync with that stream and break the capture)
-        w0, b0, w2, b2 = leaves = [p.detach().requires_grad_(bool(backward)) for p in rparams]
-        # (the scatter kernels directly: the index is this step's own, so no per-call flag read -- ops._scatter syncs)
-        op = {ops.scatter_add: 'add', ops.scatter_max: 'max', ops.scatter_mean: 'mean'}[m.readout.scatter_fn]
-        with torch.set_grad_enabled(bool(backward)):
-            if m.readout_str in ('mlp', 'concat'):
-                x, index = h, plan['graph_of_row']
-            else:                                       # reference model.py:536-547: [target | non-target] pairs
-                x = torch.cat((h.index_select(0, plan['target_row']), h.index_select(0, plan['non_target'])), dim=-1)
-                index = plan['pair_graph']
-            x = ops.linear(ops.linear(x, w0, b0, relu=True), w2, b2)
-            q = ops._Scatter.apply(x, index, op, G, self.err)
-            if isinstance(q, tuple):
-                q = q[0]
-            reg = torch.stack(torch._foreach_norm(leaves)).sum() if m.weight_decay > 0 else None
-        with torch.no_grad():
-            Qv.copy_(q)
-        if not backward:
-            call(_capi.STEP_PHASE_SCORES_ONLY, 0)
-        else:
-            call(_capi.STEP_PHASE_SCORES, 0)
-            if reg is None:
-                grads = torch.autograd.grad([q], [h] + leaves, grad_outputs=[GQv])
-            else:
-                c = torch.full((), m.weight_decay * plan['weight_sum'], dtype=torch.float32, device=dev)
-                grads = torch.autograd.grad([q, reg], [h] + leaves, grad_outputs=[GQv, c])
-            with torch.no_grad():
-                if concat:        # every level's rows get the readout's part; the backward adds what it propagates
-                    GHv.view(plan['levels'], R, D)[1:].copy_(grads[0].view(R, plan['depth'], D).permute(1, 0, 2))
-                    self.P.flags |= _capi.STEP_ADD_STATE_GRADS
-                elif plan['final'] is None:
-                    GHv[plan['depth'] * R: (plan['depth'] + 1) * R].copy_(grads[0])
-                else:
-                    GHv.index_copy_(0, plan['final'], grads[0])
-                torch._foreach_add_([p.grad for p in rparams], list(grads[1:]))
-            call(_capi.STEP_PHASE_FROM_STATES, 0)
-        if reg is not None:
-            with torch.no_grad():
-                loss[0] += (m.weight_decay * plan['weight_sum']) * reg.detach()
-        if packed.ids_ref is bufs.stage and bufs.stage is not None and not packed.captured:
-            if bufs.last_use is None:
-                bufs.last_use = torch.cuda.Event()
-            bufs.last_use.record(stream)
         if scores:
             return loss, sp, sn
         return loss

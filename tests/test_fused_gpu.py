@@ -82,9 +82,8 @@ def test_fused_step_equals_module_path(readout, adaptive, shared, lanes):
     ('targetmlp', True, True, 'add', 128, 'direct'), ('targetmlp', False, False, 'mean', 64, 'copy'),
     ('concat', False, False, 'add', 64, 'direct'), ('concat', False, True, 'max', 128, 'direct')])
 def test_fused_step_with_learned_readout_equals_module_path(readout, adaptive, shared, scatter_op, D, host_ids):
-    """MLPReadout / TargetMLPReadout (reference model.py:497-553) through the fused step: three library calls around the
-    readout of all batches at once (FusedTrainStep._run_states). Against the module path's margin_loss arithmetic,
-    regulariser included (model.py:486-490)."""
+    """MLPReadout / TargetMLPReadout / concat (reference model.py:441-446, 497-553) inside the fused step's one library
+    call (csrc/step_readout.h). Against the module path's margin_loss arithmetic, regulariser included (model.py:486-490)."""
     from mpqe_amd import ops
     from mpqe_amd.fused import FusedTrainStep
     wd = 1e-3
@@ -104,7 +103,7 @@ def test_fused_step_with_learned_readout_equals_module_path(readout, adaptive, s
     total.backward()
     ref = {k: (torch.zeros_like(p) if p.grad is None else p.grad.clone()) for k, p in model.named_parameters()}
     step = FusedTrainStep(model, host_ids=host_ids)
-    assert step.external
+    assert step.learned
     packed = step.pack(batches)
     with torch.no_grad():
         step.flat_grad.fill_(3.0)                # zero_grad covers the readout's parameters too

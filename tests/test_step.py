@@ -107,9 +107,11 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
         lay.append(uniq[key])
     dnm = be.put(node_map.numpy())
     dmode = put('mode_embeddings.weight')
-    if between is not None:
+    learned = between is None and cfg['readout'] in _capi.LEARNED_READOUT_IDS
+    if between is not None or learned:
         touch = False
-    P = _capi.make_step_params(D, R, _capi.READOUT_CALLER if between is not None else cfg['readout'], [be.ptr(t) for t in tables],
+    rid = _capi.READOUT_CALLER if between is not None else (_capi.LEARNED_READOUT_IDS[cfg['readout']] if learned else cfg['readout'])
+    P = _capi.make_step_params(D, R, rid, [be.ptr(t) for t in tables],
                                [params['enc.feat-%s.weight' % m].shape[0] for m in modes], be.ptr(dnm),
                                node_map.shape[0], be.ptr(dmode), [be.ptr(x[0]) for x in lay],
                                [be.ptr(x[1]) for x in lay], [be.ptr(x[2]) for x in lay], flags=flags)
@@ -125,6 +127,17 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
                 t.fill_(7.5)
     G = _capi.make_step_grads([be.ptr(t) for t in gtabs], be.ptr(gmode), [be.ptr(x[0]) for x in glay],
                               [be.ptr(x[1]) for x in glay], [be.ptr(x[2]) for x in glay])
+    gro = {}
+    if learned:        # the readout's two Linear layers are the library's too (include/mpqe_amd.h: MPQE_READOUT_MLP ...)
+        for field, key in (('readout_w0', 'readout.layers.0.weight'), ('readout_b0', 'readout.layers.0.bias'),
+                           ('readout_w2', 'readout.layers.2.weight'), ('readout_b2', 'readout.layers.2.bias')):
+            setattr(P, field, be.ptr(put(key)))
+            gro[key] = be.zeros(tuple(params[key].shape))
+            if flags & _capi.STEP_ZERO_GRADS:
+                gro[key].fill(7.5) if be.name == 'emu' else gro[key].fill_(7.5)
+            setattr(G, field, be.ptr(gro[key]))
+        P.readout_scatter = _capi.SCATTER_IDS[cfg['scatter_op']]
+        P.readout_weight_decay = float(cfg.get('weight_decay', 0))
     nb = len(batches)
     SB = (_capi.StepBatch * nb)()
     anchors = []
@@ -243,6 +256,8 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
         off = tptr - be.ptr(tbuf)
         plan_out.append(raw[off:off + tb].copy())
     grads = {'mode_embeddings.weight': be.get(gmode)}
+    for key, g in gro.items():
+        grads[key] = be.get(g)
     for m, g in zip(modes, gtabs):
         grads['enc.feat-%s.weight' % m] = be.get(g)
     for l in range(L):
@@ -350,6 +365,50 @@ def test_step_in_three_calls_around_a_callers_readout(be, readout, adaptive, sha
     np.testing.assert_allclose(sp, ref_sp, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(loss[0], ref_loss, rtol=1e-5, atol=1e-6)
     assert all(not g.any() for g in grads.values())
+
+
+@pytest.mark.parametrize('readout,scatter_op,adaptive,shared,wd', [
+    ('mlp', 'add', True, False, 1e-3), ('mlp', 'max', False, True, 0), ('targetmlp', 'add', True, True, 0),
+    ('targetmlp', 'mean', False, False, 1e-3), ('concat', 'add', False, False, 0), ('concat', 'max', False, True, 1e-3)])
+def test_fused_step_with_learned_readout_matches_oracle(be, readout, scatter_op, adaptive, shared, wd):
+    """MLPReadout / TargetMLPReadout / the concat input (reference model.py:441-446, 497-553) INSIDE the one-call step:
+    gather, Linear - ReLU - Linear on the library's dense-layer kernels, the reduction over each graph's rows, scores,
+    and all of it backward, with the readout's regulariser (model.py:486-490). Against the oracle's whole model."""
+    D, margin = 32, 1.0
+    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(23, D, 3, shared, MIXES['all7'], readout, adaptive)
+    cfg['scatter_op'], cfg['weight_decay'] = scatter_op, wd
+    total, per, sp_ref, sn_ref = 0, [], [], []
+    for b in batches:             # margin_loss per batch (regulariser included), weighted: train_helpers.py:76-120
+        q = ref_cpu.encode_queries(params, cfg, node_map, b['formula'], b['col'])
+        pos = ref_cpu.score(params, node_map, b['formula'], q, b['targets'])
+        neg = ref_cpu.score(params, node_map, b['formula'], q, b['negs'])
+        l = torch.clamp(margin - (pos - neg), min=0).mean()
+        per.append(l.item())
+        if wd > 0:
+            l = l + wd * sum(torch.norm(v) for k, v in params.items() if k.startswith('readout.'))
+        total = total + b['weight'] * l
+        sp_ref.append(pos.detach().numpy())
+        sn_ref.append(neg.detach().numpy())
+    total.backward()
+    for zero, repeat in ((True, 2), (False, 1)):
+        loss, sp, sn, grads, err = run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin,
+                                            flags=_capi.STEP_ZERO_GRADS if zero else 0, repeat=repeat)
+        assert err == 0
+        np.testing.assert_allclose(sp, np.concatenate(sp_ref), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(sn, np.concatenate(sn_ref), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(loss[1:], per, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(loss[0], total.item(), rtol=1e-5, atol=1e-6)
+        done = set()
+        for k, p in params.items():
+            if id(p) in done:
+                continue
+            done.add(id(p))
+            ref = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
+            np.testing.assert_allclose(grads[k], ref, rtol=1e-4, atol=2e-6, err_msg=k)
+    loss, sp, sn, grads, err = run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=0)
+    np.testing.assert_allclose(loss[0], total.item(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sp, np.concatenate(sp_ref), rtol=1e-5, atol=1e-6)
+    assert err == 0 and all(not g.any() for g in grads.values())
 
 
 def test_callers_readout_refuses_what_it_does_not_cover(be):

@@ -1,6 +1,6 @@
 """Training step with a learned readout (reference model.py:497-553: mlp / targetmlp), AIFB-shaped full query mix:
-the module path (one autograd graph over the per-batch ops) against the fused step in three library calls around the
-readout of all batches at once (FusedTrainStep._run_states). Prints one JSON line per readout.
+the module path (one autograd graph over the per-batch ops) against the fused step (the readout inside the same library
+call: csrc/step_readout.h). Prints one JSON line per readout.
 
     python tools/readout_step_bench.py [--readouts mlp,targetmlp] [--steps 50] [--batch-size 512] [--embed-dim 128]
 """
@@ -80,7 +80,7 @@ def main():
         cap = step.capture(bench.pack_for_fused(step, data, resident=True))
         t_graph = timed(cap.replay, args.steps, args.warmup)
         print(json.dumps(dict(readout=readout, query_graphs=data.num_graphs, embed_dim=D,
-                              module_path_ms=round(1e3 * t_mod, 4), fused_three_call_ms=round(1e3 * t_fused, 4),
+                              module_path_ms=round(1e3 * t_mod, 4), fused_step_ms=round(1e3 * t_fused, 4),
                               fused_fresh_ids_ms=round(1e3 * t_fresh, 4), fused_graph_replay_ms=round(1e3 * t_graph, 4),
                               fused_q_graphs_per_s=round(data.num_graphs / t_fresh, 1),
                               speedup=round(t_mod / t_fresh, 2), loss_module=ref_loss, loss_fused=loss[0].item(),
