@@ -26,6 +26,7 @@ def batches_of(schema, rank, B, scale):
 
 def main():
     outdir, sparse, tables = sys.argv[1], sys.argv[2] == '1', sys.argv[3]
+    readout = sys.argv[4] if len(sys.argv) > 4 else 'mp'
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.cuda.set_device(0)
@@ -41,8 +42,8 @@ def main():
     schema = synthetic.make_schema(*synthetic.KG_SHAPES['tiny'], seed=3)
     graph = synthetic.SchemaGraph(schema, D)
     fm, node_maps = make_feature_modules(schema.ids, D, schema.num_entities)
-    model = RGCNEncoderDecoder(graph, DirectEncoder(None, fm, node_maps), readout='mp', num_layers=3, shared_layers=False,
-                               adaptive=True, weight_decay=0).to('cuda:0')
+    model = RGCNEncoderDecoder(graph, DirectEncoder(None, fm, node_maps), readout=readout, num_layers=3, shared_layers=False,
+                               adaptive=readout != 'concat', weight_decay=1e-3 if readout != 'mp' else 0).to('cuda:0')
     with torch.no_grad():
         for p in model.layers.parameters():
             p.mul_(4.0)

@@ -22,14 +22,15 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize('sparse,tables', [(0, 'rows'), (1, 'rows'), (0, 'dense')])
-def test_two_ranks_equal_single_process(tmp_path, sparse, tables):
+@pytest.mark.parametrize('sparse,tables,readout', [(0, 'rows', 'mp'), (1, 'rows', 'mp'), (0, 'dense', 'mp'),
+                                                   (0, 'dense', 'targetmlp'), (0, 'dense', 'concat')])
+def test_two_ranks_equal_single_process(tmp_path, sparse, tables, readout):
     world, port = 2, _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY='0')
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'dp_worker.py'), str(tmp_path), str(sparse), tables],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'dp_worker.py'), str(tmp_path), str(sparse), tables, readout],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
