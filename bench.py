@@ -45,8 +45,10 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--repeats', type=int, default=25,
-                    help='the timed block of --steps steps is repeated this many times; the median block is reported')
+    ap.add_argument('--repeats', type=int, default=0,
+                    help='the timed block of --steps steps is repeated this many times; the median block is reported. '
+                         '0 = as many blocks as make ~0.6 s of timed steps (a few steps are timed first), at least 25 '
+                         '(5 when a block takes more than 50 ms), at most 500')
     ap.add_argument('--kg', default='aifb')
     ap.add_argument('--embed-dim', type=int, default=128)
     ap.add_argument('--batch-size', type=int, default=512)
@@ -87,9 +89,9 @@ def parse():
     ap.add_argument('--touch', default='step', choices=['step', 'pack', 'atomics'],
                     help="entity-table gradients: per-row sums with the plan built inside the step (default), built by "
                          "pack(), or fp32 atomics")
-    ap.add_argument('--fresh-sets', type=int, default=4096,
+    ap.add_argument('--fresh-sets', type=int, default=0,
                     help='distinct pre-drawn id sets (176 KB each at the default shape); the timed steps walk through them, '
-                         'wrapping around only when steps x repeats exceeds it')
+                         'wrapping around only when warmup + steps x repeats exceeds it. 0 = one per step, at most 16 384 (2.9 GB)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='nccl = RCCL over xGMI (the real path); gloo only to exercise the multi-rank code on one GPU')
     return ap.parse_args()
@@ -603,7 +605,27 @@ def main():
     learned = args.readout in ('mlp', 'targetmlp', 'concat')        # (fused step on the level form, the readout inside the call: csrc/step_readout.h)
     fresh = use_fused and not args.replay and not args.graph
     reducer = fstep = packed = captured = exchange = xplans = fresh_ids = descs = None
-    n_total = args.warmup + args.steps * max(1, args.repeats)
+
+    def auto_sizes(run_once):
+        """--repeats 0 / --fresh-sets 0: sized from a few steps timed here (every rank takes the slowest rank's estimate)."""
+        if args.repeats <= 0:
+            for _ in range(3):
+                run_once()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                run_once()
+            torch.cuda.synchronize()
+            est = (time.perf_counter() - t0) / 5 * args.steps
+            if world > 1:
+                import torch.distributed as dist
+                t = torch.tensor([est], device=device if args.backend == 'nccl' else 'cpu', dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                est = float(t.item())
+            args.repeats = int(max(25 if est < 0.05 else 5, min(500, -(-0.6 // max(est, 1e-6)))))
+        if args.fresh_sets <= 0:
+            args.fresh_sets = min(16384, args.warmup + args.steps * args.repeats)
+        return args.warmup + args.steps * max(1, args.repeats)
     if use_fused:
         from mpqe_amd.fused import FusedTrainStep
         touch = {'step': 'step', 'pack': 'pack', 'atomics': False}[args.touch]
@@ -613,6 +635,7 @@ def main():
                                merge_tail=None if args.merge_tail < 0 else bool(args.merge_tail))
         packed = [pack_for_fused(fstep, d, 1.0 / world, resident=True) for d in pool]
         captured = [fstep.capture(p) for p in packed] if args.graph else None
+        n_total = auto_sizes(lambda: fstep.run(packed[0]))
         if fresh:
             # the timed steps' inputs: per formula set its descriptors (formula, weight, size) and, resident in HBM before
             # the timed region starts, one NEVER-SEEN id set per step
@@ -625,9 +648,11 @@ def main():
             from mpqe_amd.parallel import StepExchange
             exchange = StepExchange(fstep)
             xplans = [exchange.plan(p, key=j) for j, p in enumerate(packed)]
-    elif world > 1:
-        from mpqe_amd.parallel import GradReducer
-        reducer = GradReducer(model)
+    else:
+        n_total = auto_sizes(lambda: step_modules(model, pool[0]))
+        if world > 1:
+            from mpqe_amd.parallel import GradReducer
+            reducer = GradReducer(model)
 
     def one_step(i):
         j = i % len(pool)
