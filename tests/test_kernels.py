@@ -6,6 +6,7 @@ on the real gfx950 library (`hip`, marked gpu). Integers bit-exact; fp32 forward
 absolute floor scaled to the operand magnitude, gradients rtol 1e-4.
 """
 import ctypes
+import zlib
 
 import numpy as np
 import pytest
@@ -89,7 +90,9 @@ def test_template_info_matches_oracle_tables(be):
 @pytest.mark.parametrize('relu', [0, 1])
 def test_template_layer_fwd_bwd(be, qt, shape, relu):
     B, Din, Dout, R = shape
-    rng = np.random.RandomState(hash((qt, shape, relu)) % (2 ** 31))
+    # (a seed that is the same in every process: hash() of a str is salted per interpreter, and a draw whose pre-activation
+    # lands within rounding of 0 flips the ReLU mask between kernel and oracle -- a test-data artefact, seen once)
+    rng = np.random.RandomState(zlib.crc32(repr((qt, shape, relu)).encode()) % (2 ** 31))
     N, E, ei = template_graph(qt, B)
     x = rng.randn(B * N, Din).astype(np.float32)
     basis = (rng.randn(R, Din, Dout) * 0.3).astype(np.float32)
