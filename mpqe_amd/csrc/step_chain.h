@@ -783,8 +783,11 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     chain_stamp(ca, 0);
     chain_stamp_where(ca, ref.batch, ref.fwd_count);
 #if CHAIN_DBG == 6
-    if (threadIdx.x == 0) {      // trace block 0 only: words [2 G * 8 ...) of the stamp buffer
-        S.trace = (ca.stamps && ca.cb == 0) ? ca.stamps + (long long)ca.nchain * 16 : nullptr;
+#ifndef CHAIN_TRACE_BATCH
+#define CHAIN_TRACE_BATCH 0
+#endif
+    if (threadIdx.x == 0) {      // trace ONE block (the first of batch CHAIN_TRACE_BATCH): words [2 G * 8 ...) of the stamp buffer
+        S.trace = (ca.stamps && ref.batch == CHAIN_TRACE_BATCH && g0 == 0) ? ca.stamps + (long long)ca.nchain * 16 : nullptr;
         S.trace_n = 0;
     }
 #endif
