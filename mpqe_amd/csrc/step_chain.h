@@ -230,6 +230,9 @@ __device__ __forceinline__ void chain_mask_pop(float &v, unsigned &bits) {
 #ifndef CHAIN_DBG
 #define CHAIN_DBG 0     // experiments only: 1 = no weight loads in the K loop, 2 = no MFMAs
 #endif
+#ifndef CHAIN_NOLOAD
+#define CHAIN_NOLOAD 0  // experiments only, with CHAIN_DBG = 6 (cycle trace): 1 = no weight loads in the K loop (wrong results)
+#endif
 template <int NCB>
 __device__ __forceinline__ void chain_load_t(WHalf<NCB> &f, const float *wp, int D, int t) {
     if (CHAIN_DBG == 1) return;
@@ -440,7 +443,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
             const f32x4 a = av[t];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (CHAIN_DBG != 1 && !INPLACE) chain_gload<NCB>(fn.v[t][u], wn + (long long)(16 * t + u) * D);
+                if (CHAIN_DBG != 1 && !CHAIN_NOLOAD && !INPLACE) chain_gload<NCB>(fn.v[t][u], wn + (long long)(16 * t + u) * D);
                 __builtin_amdgcn_sched_barrier(0);
 #if CHAIN_DBG == 2
 #pragma unroll
@@ -458,7 +461,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
                 }
 #endif
                 __builtin_amdgcn_sched_barrier(0);
-                if (CHAIN_DBG != 1 && INPLACE) {
+                if (CHAIN_DBG != 1 && !CHAIN_NOLOAD && INPLACE) {
                     chain_gload<NCB>(f.v[t][u], wn + (long long)(16 * t + u) * D);
                     __builtin_amdgcn_sched_barrier(0);
                 }
