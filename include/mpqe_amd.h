@@ -75,6 +75,8 @@ enum { MPQE_SCATTER_ADD = 0, MPQE_SCATTER_MAX = 1, MPQE_SCATTER_MEAN = 2 };
 #define MPQE_MAX_TEMPLATE_NODES 4
 
 const char *mpqe_status_string(int status);
+/* 4: mpqe_step_params_t / mpqe_step_grads_t carry the learned readouts' Linear layers (readout_*); mpqe_step_states_layout,
+ * MPQE_READOUT_CALLER and the MPQE_STEP_PHASE_* values of `backward`. 3: mpqe_linear_*, mpqe_debug_option, touch = OUT. */
 int mpqe_abi_version(void);
 
 /* Static shape of one query template (host side, no GPU needed).
