@@ -151,15 +151,16 @@ def test_fused_step_bad_id_is_reported():
         step.check()
 
 
-@pytest.mark.parametrize('opt', ['adam', 'sgd'])
-def test_training_loop_fused_step_plus_flat_optimizer(opt):
+@pytest.mark.parametrize('opt,readout', [('adam', 'mp'), ('sgd', 'mp'), ('sgd', 'targetmlp'), ('adam', 'mlp')])
+def test_training_loop_fused_step_plus_flat_optimizer(opt, readout):
     """Three training steps: FusedTrainStep + FlatOptimizer (one launch over the flat parameter buffer)
     against the module path + torch.optim (the reference's loop, train_helpers.py:76-120, train.py:83-88)."""
     import copy
     from mpqe_amd import ops
     from mpqe_amd.fused import FusedTrainStep
     from mpqe_amd.optim import FlatOptimizer
-    model, batches = _setup('mp', True, False)
+    model, batches = _setup(readout, True, False, weight_decay=0 if readout == 'mp' else 1e-3)
+    wd = model.weight_decay
     ref_model = copy.deepcopy(model)
     ref_opt = (torch.optim.Adam(ref_model.parameters(), lr=0.01) if opt == 'adam'
                else torch.optim.SGD(ref_model.parameters(), lr=0.01, momentum=0))
@@ -173,7 +174,10 @@ def test_training_loop_fused_step_plus_flat_optimizer(opt):
         for b in batches:
             out = ref_model.encode(b['formula'], b['queries'])
             l = ops.hinge(ref_model.score(b['formula'], out, b['targets'].tolist()),
-                          ref_model.score(b['formula'], out, b['negs'].tolist()), 1.0) * b['weight']
+                          ref_model.score(b['formula'], out, b['negs'].tolist()), 1.0)
+            if readout != 'mp':      # margin_loss's regulariser on the readout's parameters (model.py:486-490)
+                l = l + wd * sum(torch.norm(p) for p in ref_model.readout.parameters())
+            l = l * b['weight']
             total = l if total is None else total + l
         total.backward()
         ref_opt.step()
