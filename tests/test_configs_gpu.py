@@ -179,7 +179,9 @@ def drop_near_ties(batches, cpu_params, cfg, node_maps, model, tol=1e-6):
     ('aifb', 128, 'mp', True, 'default'), ('aifb', 128, 'mp', True, 'no_prune'), ('aifb', 128, 'mp', True, 'no_uniform'),
     ('aifb', 128, 'mp', True, 'no_chain'),            # configs[1], the benchmarked one, with the speed switches on and off
     ('mutag', 256, 'sum', False, 'default'),          # configs[2]
-    ('am', 128, 'max', False, 'default')])            # configs[3]
+    ('am', 128, 'max', False, 'default'),             # configs[3]
+    # the learned readouts at the benchmarked shape (level form, the readout inside the call: csrc/step_readout.h)
+    ('aifb', 128, 'mlp', True, 'default'), ('aifb', 128, 'targetmlp', False, 'default'), ('aifb', 128, 'concat', False, 'default')])
 def test_benchmarked_workload_against_oracle(kg, D, readout, adaptive, flags):
     """BASELINE.json configs[1] exactly as bench.py times it -- AIFB-shaped KG, the 11-batch post-burn-in mix at
     B = 512, D = 128, readout mp (TM), adaptive, num_layers 3 unshared, the reference's loss weights -- through the
@@ -207,7 +209,7 @@ def test_benchmarked_workload_against_oracle(kg, D, readout, adaptive, flags):
     kw = dict(default={}, no_prune=dict(prune=False), no_uniform=dict(uniform=False), no_chain=dict(chain=False))[flags]
     step = FusedTrainStep(model, **kw)
     packed = step.pack(batches)
-    assert step.uses_chain(packed) == (flags != 'no_chain')
+    assert step.uses_chain(packed) == (flags != 'no_chain' and not step.learned)
     loss, sp, sn = step.run(packed, scores=True)
     step.check()
     sp, sn, loss = sp.cpu().numpy(), sn.cpu().numpy(), loss.cpu().numpy()
