@@ -172,9 +172,14 @@ int mpqe_rgcn_plan_build(const int64_t *edge_index /*[2, E]*/, const int64_t *ed
                          int32_t *err, void *stream);
 size_t mpqe_rgcn_general_workspace_bytes(int64_t num_nodes, int64_t num_edges, int64_t num_relations,
                                          int64_t dim_in, int64_t dim_out, int backward);
+/* relu_mask (may be NULL; needs relu, dim_out % 64 == 0): mpqe_rgcn_general_mask_bytes(num_nodes, dim_out) bytes, 8-byte
+ * aligned; the forward leaves the ReLU mask of `out` there as bit words (bit c % 64 of word [node][c / 64] = out > 0) and
+ * the backward, given the same buffer, masks with them and never reads `out` (its gathered reads of `out` rows were a
+ * third of the backward kernels' row traffic).                                                            */
+size_t mpqe_rgcn_general_mask_bytes(int64_t num_nodes, int64_t dim_out);
 int mpqe_rgcn_general_fwd(const void *plan, int64_t num_nodes, int64_t num_edges, int64_t num_relations,
                           const float *x, const float *basis, const float *root, const float *bias,
-                          int64_t dim_in, int64_t dim_out, int relu, float *out,
+                          int64_t dim_in, int64_t dim_out, int relu, float *out, uint64_t *relu_mask,
                           void *workspace, size_t workspace_bytes, void *stream);
 /* The scatter-aggregate of the forward alone (the destination-sorted segmented sum): out[i] = act(bias + msg[E + i] +
  * sum over the edges into i, in edge order, of their message rows); msg [E + Nn, dim] in the plan's slot order, as the
@@ -187,7 +192,8 @@ int mpqe_rgcn_general_aggregate(const void *plan, int64_t num_nodes, int64_t num
  * [R, dim_in, dim_out] with zeros nor pays a read-modify-write of it (33 MB each at the stress shape). grad_x is always
  * written.                                                                                              */
 int mpqe_rgcn_general_bwd(const void *plan, int64_t num_nodes, int64_t num_edges, int64_t num_relations,
-                          const float *x, const float *out, const float *grad_out,
+                          const float *x, const float *out /* may be NULL with relu_mask */,
+                          const uint64_t *relu_mask /* the forward's, or NULL */, const float *grad_out,
                           const float *basis, const float *root,
                           int64_t dim_in, int64_t dim_out, int relu, int overwrite,
                           float *grad_x, float *grad_basis, float *grad_root, float *grad_bias,

@@ -78,9 +78,10 @@ PROTOTYPES = {
     'mpqe_rgcn_plan_workspace_bytes': (Z, [L, L, L]),
     'mpqe_rgcn_plan_build': (I, [P, P, L, L, L, P, Z, P, Z, P, P]),
     'mpqe_rgcn_general_workspace_bytes': (Z, [L, L, L, L, L, I]),
-    'mpqe_rgcn_general_fwd': (I, [P, L, L, L, P, P, P, P, L, L, I, P, P, Z, P]),
+    'mpqe_rgcn_general_mask_bytes': (Z, [L, L]),
+    'mpqe_rgcn_general_fwd': (I, [P, L, L, L, P, P, P, P, L, L, I, P, P, P, Z, P]),
     'mpqe_rgcn_general_aggregate': (I, [P, L, L, L, P, P, L, I, P, P]),
-    'mpqe_rgcn_general_bwd': (I, [P, L, L, L, P, P, P, P, P, L, L, I, I, P, P, P, P, P, Z, P]),
+    'mpqe_rgcn_general_bwd': (I, [P, L, L, L, P, P, P, P, P, P, L, L, I, I, P, P, P, P, P, Z, P]),
     'mpqe_linear_fwd': (I, [P, L, P, L, P, L, L, I, I, P, P]),
     'mpqe_linear_bwd_workspace_bytes': (Z, [L, L, L]),
     'mpqe_linear_bwd': (I, [P, L, P, L, P, P, L, L, I, I, P, P, L, P, P, Z, P]),

@@ -450,8 +450,10 @@ __global__ __launch_bounds__(256) void rgcn_gen_gemm_kernel(
 template <bool TRANS, bool RELU>
 __global__ __launch_bounds__(256) void rgcn_gen_gemm_rows_kernel(
     const int *__restrict__ rows, const int *__restrict__ rel_ptr, const int *__restrict__ tile_ptr, int R,
-    const float *__restrict__ a, const float *__restrict__ mask, const float *__restrict__ basis,
+    const float *__restrict__ a, const unsigned long long *__restrict__ mask, const float *__restrict__ basis,
     const float *__restrict__ root, int Din, int Dout, float *__restrict__ msg) {
+    // RELU: `mask` = the ReLU mask of the rows of `a` as bit words (bias_grad.h: bit c % 64 of word [row][c / 64]) -- 8
+    // bytes per row and iteration instead of 16 bytes per lane of the gathered `out` row.
     // Occupancy by LDS footprint: the forward form runs ONE workgroup per CU (144 KB claimed, 8 KB used), the transposed form
     // two. Measured at the stress shape, forward: 3 / 2 / 1 workgroups per CU = 139.8 / 114.5 / 86.6 us (transposed: - /
     // 106.8 / 113.3): with more workgroups in flight the gathered half-lines and the streamed matrices evict each other
@@ -517,11 +519,12 @@ __global__ __launch_bounds__(256) void rgcn_gen_gemm_rows_kernel(
         if (more) load_ids(start2, nrows2, idn);           // (in flight under this tile's K loop)
         if (nrows > 0) {
             const float *W = r < R ? basis + (long long)r * Din * Dout : root;
-            const float *pa[4], *pm[4];
+            const float *pa[4];
+            const unsigned long long *pm[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 pa[g] = a + (long long)idc[g] * K + KW * kq;
-                pm[g] = RELU ? mask + (long long)idc[g] * K + KW * kq : nullptr;
+                pm[g] = RELU ? mask + (long long)idc[g] * (K / 64) : nullptr;
             }
             // A lane takes KW = 4 H consecutive k of its row per iteration (H 16-byte loads: with H = 2 the four kq groups
             // cover a whole 128-byte line of the row per load pair). MFMA (h, u) multiplies the k slots
@@ -535,16 +538,20 @@ __global__ __launch_bounds__(256) void rgcn_gen_gemm_rows_kernel(
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int n = 0; n < 4; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-            f32x4 A[GGM_PF][4][H], M[RELU ? GGM_PF : 1][4][H], B[GGM_PF][4 * H];
+            f32x4 A[GGM_PF][4][H], B[GGM_PF][4 * H];
+            unsigned long long M[RELU ? GGM_PF : 1][4];
+            int MO[RELU ? GGM_PF : 1];         // bit offset of the lane's first k of the stage inside its mask word
             auto load = [&](int s, int it) {
                 const int ic = it < niter ? it : niter - 1;        // (beyond the end: the last piece again, unused)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int h = 0; h < H; ++h) {
-                        A[s][g][h] = gload4(pa[g] + 4 * KW * ic + 4 * h);
-                        if (RELU) M[s][g][h] = gload4(pm[g] + 4 * KW * ic + 4 * h);
-                    }
+                    for (int h = 0; h < H; ++h) A[s][g][h] = gload4(pa[g] + 4 * KW * ic + 4 * h);
+                if (RELU) {         // (the 4 KW k of an iteration lie in ONE 64-bit word: 4 KW divides 64)
+                    MO[s] = (4 * KW * ic + KW * kq) & 63;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) M[s][g] = pm[g][(4 * KW * ic) >> 6];
+                }
 #pragma unroll
                 for (int q = 0; q < 4 * H; ++q)      // non-TRANS: q = 4 h + u, a row of W each; TRANS: q = H n + h
                     B[s][q] = TRANS ? gload4(pw + (long long)ic * wstep + (long long)(q / H) * Dout + 4 * (q % H))
@@ -557,8 +564,9 @@ __global__ __launch_bounds__(256) void rgcn_gen_gemm_rows_kernel(
                     for (int h = 0; h < H; ++h) {
                         f32x4 av = A[s][g][h];
                         if (RELU) {
+                            const unsigned nib = (unsigned)(M[s][g] >> (MO[s] + 4 * h));
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) av[u] = M[s][g][h][u] > 0.f ? av[u] : 0.f;
+                            for (int u = 0; u < 4; ++u) av[u] = ((nib >> u) & 1u) ? av[u] : 0.f;
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
@@ -610,7 +618,11 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const int *__restrict_
                                                           long long Nn, long long E, int D,
                                                           const float *__restrict__ msg,
                                                           const float *__restrict__ bias, int relu,
-                                                          float *__restrict__ out, int vec) {
+                                                          float *__restrict__ out, int vec,
+                                                          unsigned long long *__restrict__ bits = nullptr) {
+    // bits (may be NULL; needs vec, relu, D % 64 == 0): the ReLU mask of `out` as bit words -- bit c % 64 of word
+    // [row][c / 64] = out[row][c] > 0 (bias_grad.h) -- for the backward, which then never reads `out`. The 16 lanes that hold
+    // 64 consecutive columns of a row are one DPP row: their nibbles are OR-ed with four row rotations.
     const int per_row = vec ? D / 4 : D;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long i = idx / per_row;
@@ -639,6 +651,8 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const int *__restrict_
             s[2] = s[2] > 0.f ? s[2] : 0.f; s[3] = s[3] > 0.f ? s[3] : 0.f;
         }
         *reinterpret_cast<f32x4 *>(out + i * D + c) = s;
+        if (bits)
+            mask_word_store(bits, i, D, c, (s[0] > 0.f ? 1u : 0u) | (s[1] > 0.f ? 2u : 0u) | (s[2] > 0.f ? 4u : 0u) | (s[3] > 0.f ? 8u : 0u));
     } else {
         float s = msg[(E + i) * D + c] + (bias ? bias[c] : 0.f);
         for (int k = k0; k < k1; ++k) s += msg[(long long)list[k] * D + c];
@@ -704,7 +718,8 @@ template <bool RELU>
 __global__ __launch_bounds__(256) void rgcn_gen_grad_w_rows_kernel(
     const int *__restrict__ rows_fwd, const int *__restrict__ rows_bwd, const int *__restrict__ rel_ptr,
     const int *__restrict__ chunk_ptr, int R, const float *__restrict__ x, const float *__restrict__ g,
-    const float *__restrict__ out, int Din, int Dout, float *__restrict__ slabs) {
+    const unsigned long long *__restrict__ out /* RELU: mask bit words of the rows of g (bias_grad.h) */, int Din, int Dout,
+    float *__restrict__ slabs) {
     __shared__ __attribute__((aligned(16))) float smem[GGR_LDS_TILES * 64 * GGR_LDT];
     // The tiles of one K-chunk read the SAME rows (each 256-byte piece of an x row by Dout / 64 tiles, of a g row by
     // Din / 64): they are given to ONE XCD (workgroup b runs on XCD b % 8) and dispatched together, so a piece comes
@@ -747,10 +762,12 @@ __global__ __launch_bounds__(256) void rgcn_gen_grad_w_rows_kernel(
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (q1 > q0) {
-        const float *xa = x + i0 + 4 * pos, *gb = g + j0 + 4 * pos, *ob = RELU ? out + j0 + 4 * pos : nullptr;
+        const float *xa = x + i0 + 4 * pos, *gb = g + j0 + 4 * pos;
+        const unsigned long long *ob = RELU ? out + (j0 >> 6) : nullptr;      // (a tile's 64 columns: one word per row)
         int IA[GGR_PF], IB[GGR_PF];
         float live[GGR_PF], live_use[GGR_PF];     // 1 / 0 per slot: ids stage, rows stage (the ids stage runs PF ahead)
-        f32x4 A[GGR_PF], B[GGR_PF], M[RELU ? GGR_PF : 1];
+        f32x4 A[GGR_PF], B[GGR_PF];
+        unsigned long long M[RELU ? GGR_PF : 1];
         auto load_ids = [&](int s, int t) {
             const int q = q0 + 16 * t + 4 * wave + kq;
             const int qc = q < q1 ? q : q1 - 1;        // (clamped: a slot beyond the chunk contributes zero)
@@ -763,14 +780,15 @@ __global__ __launch_bounds__(256) void rgcn_gen_grad_w_rows_kernel(
             A[s] = gload4(xa + (long long)IA[s] * Din);       // (the zero of a slot beyond the chunk is applied at the USE:
                                                               // a multiply right behind the load would wait for it)
             B[s] = gload4(gb + (long long)IB[s] * Dout);
-            if (RELU) M[s] = gload4(ob + (long long)IB[s] * Dout);
+            if (RELU) M[s] = ob[(long long)IB[s] * (Dout / 64)];
         };
         auto mma = [&](int s) {
             f32x4 b = B[s];
             const f32x4 a = A[s] * live_use[s];
             if (RELU) {
+                const unsigned nib = (unsigned)(M[s] >> (4 * pos));
 #pragma unroll
-                for (int k = 0; k < 4; ++k) b[k] = M[s][k] > 0.f ? b[k] : 0.f;
+                for (int k = 0; k < 4; ++k) b[k] = ((nib >> k) & 1u) ? b[k] : 0.f;
             }
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -909,16 +927,17 @@ extern "C" size_t mpqe_rgcn_general_workspace_bytes(int64_t Nn, int64_t E, int64
     if (!backward) return align_up(slots * (size_t)Dout * 4, 256) + 256;
     return align_up(slots * (size_t)Din * 4, 256) +
            align_up((size_t)chunk_bound(Nn, E, R) * (size_t)Din * (size_t)Dout * 4, 256) +
-           bias_partial_bytes(Nn, Dout) + 256;
+           bias_partial_bytes(Nn, Dout) + align_up((size_t)Nn * (size_t)((Dout + 63) / 64) * 8, 256) + 256;
 }
 
 extern "C" int mpqe_rgcn_general_fwd(const void *plan, int64_t Nn, int64_t E, int64_t R, const float *x,
                                      const float *basis, const float *root, const float *bias, int64_t Din,
-                                     int64_t Dout, int relu, float *out, void *workspace, size_t workspace_bytes,
-                                     void *stream) {
+                                     int64_t Dout, int relu, float *out, uint64_t *relu_mask, void *workspace,
+                                     size_t workspace_bytes, void *stream) {
     if (!plan || Nn < 0 || E < 0 || R < 0 || Din <= 0 || Dout <= 0) return MPQE_ERR_INVALID_ARG;
     if (Nn == 0) return MPQE_OK;
     if (!x || !root || !out || (R > 0 && !basis)) return MPQE_ERR_INVALID_ARG;
+    if (relu_mask && (!relu || Dout % 64 != 0 || (uintptr_t)relu_mask % 8 != 0)) return MPQE_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < mpqe_rgcn_general_workspace_bytes(Nn, E, R, Din, Dout, 0))
         return MPQE_ERR_WORKSPACE;
     PlanView P = plan_view(plan, Nn, E, R);
@@ -936,7 +955,7 @@ extern "C" int mpqe_rgcn_general_fwd(const void *plan, int64_t Nn, int64_t E, in
         const long long per1 = 8 * cg1, slots1 = mpqe_dbg_value("GEN_SLOTS", 256) / per1 * per1;
         dim3 g1((unsigned)(items1 < slots1 || slots1 == 0 || dbg_on("GEN_NOT_PERSISTENT") ? items1 : slots1));
         hipLaunchKernelGGL((rgcn_gen_gemm_rows_kernel<false, false>), g1, dim3(256), 0, s, P.rows_fwd, P.rel_ptr, P.tile_ptr,
-                           (int)R, x, (const float *)nullptr, basis, root, (int)Din, (int)Dout, msg);
+                           (int)R, x, (const unsigned long long *)nullptr, basis, root, (int)Din, (int)Dout, msg);
     } else
     if (gvec)
         hipLaunchKernelGGL((rgcn_gen_gemm_kernel<false, LD_PRED>), grid, dim3(256), 0, s, P.rows_fwd, P.rel_ptr,
@@ -947,9 +966,16 @@ extern "C" int mpqe_rgcn_general_fwd(const void *plan, int64_t Nn, int64_t E, in
     const int vec = Dout % 4 == 0 && ptr_vec_ok(out, Dout) && (!bias || (uintptr_t)bias % 16 == 0) &&
                     (uintptr_t)workspace % 16 == 0;
     const long long threads = Nn * (vec ? Dout / 4 : Dout);
+    if (relu_mask && !vec) return MPQE_ERR_INVALID_ARG;       // (the mask words come from the 16-byte form)
     hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, P.dst_ptr,
-                       P.dst_list, (long long)Nn, (long long)E, (int)Dout, (const float *)msg, bias, relu, out, vec);
+                       P.dst_list, (long long)Nn, (long long)E, (int)Dout, (const float *)msg, bias, relu, out, vec,
+                       reinterpret_cast<unsigned long long *>(relu_mask));
     return mpqe_launch_status();
+}
+
+extern "C" size_t mpqe_rgcn_general_mask_bytes(int64_t Nn, int64_t Dout) {
+    if (Nn < 0 || Dout <= 0 || Dout % 64 != 0) return 0;
+    return (size_t)Nn * (size_t)(Dout / 64) * 8;
 }
 
 // The scatter-aggregate step of the forward alone: out[i] = act(bias + msg[E + i] + sum of msg[e] over the edges INTO i
@@ -970,7 +996,8 @@ extern "C" int mpqe_rgcn_general_aggregate(const void *plan, int64_t Nn, int64_t
 }
 
 extern "C" int mpqe_rgcn_general_bwd(const void *plan, int64_t Nn, int64_t E, int64_t R, const float *x,
-                                     const float *out, const float *grad_out, const float *basis, const float *root,
+                                     const float *out, const uint64_t *relu_mask, const float *grad_out,
+                                     const float *basis, const float *root,
                                      int64_t Din, int64_t Dout, int relu, int overwrite, float *grad_x, float *grad_basis,
                                      float *grad_root, float *grad_bias, void *workspace, size_t workspace_bytes,
                                      void *stream) {
@@ -983,7 +1010,8 @@ extern "C" int mpqe_rgcn_general_bwd(const void *plan, int64_t Nn, int64_t E, in
         }
         return MPQE_OK;
     }
-    if (!x || !grad_out || !root || (R > 0 && !basis) || (relu && !out)) return MPQE_ERR_INVALID_ARG;
+    if (!x || !grad_out || !root || (R > 0 && !basis) || (relu && !out && !relu_mask)) return MPQE_ERR_INVALID_ARG;
+    if (relu_mask && (!relu || Dout % 64 != 0 || (uintptr_t)relu_mask % 8 != 0)) return MPQE_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < mpqe_rgcn_general_workspace_bytes(Nn, E, R, Din, Dout, 1))
         return MPQE_ERR_WORKSPACE;
     PlanView P = plan_view(plan, Nn, E, R);
@@ -994,8 +1022,24 @@ extern "C" int mpqe_rgcn_general_bwd(const void *plan, int64_t Nn, int64_t E, in
     float *bias_part = reinterpret_cast<float *>(
         reinterpret_cast<char *>(slabs) + align_up((size_t)chunk_bound(Nn, E, R) * (size_t)Din * (size_t)Dout * 4, 256));
     const bool gvec = (!basis || ptr_vec_ok(basis, Dout)) && ptr_vec_ok(root, Dout) && (Din * Dout) % 4 == 0 &&
-                      ptr_vec_ok(grad_out, Dout) && (!relu || ptr_vec_ok(out, Dout)) && ptr_vec_ok(x, Din);
+                      ptr_vec_ok(grad_out, Dout) && (!relu || !out || ptr_vec_ok(out, Dout)) && ptr_vec_ok(x, Din);
     const float *mask = relu ? out : nullptr;
+    // the ReLU mask as bit words for the register-operand kernels (one pass over `out`, shared with the bias sums)
+    unsigned long long *mbits = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(bias_part) +
+                                                                       bias_partial_bytes(Nn, Dout));
+    const bool rows64_any = gvec && Din % 64 == 0 && Dout % 64 == 0 && !(dbg_on("GEN_LDS_GEMM") && dbg_on("GEN_LDS_GRADW"));
+    // (the caller's words, written by the forward's segmented sum -- the backward then never reads `out` --, or made here
+    // by the bias sums' pass over `out`)
+    const bool use_bits = relu && rows64_any && (grad_x || grad_basis || grad_root);
+    if (relu_mask) {
+        if (!rows64_any) {
+            if (!out) return MPQE_ERR_INVALID_ARG;         // (the LDS-staged kernels mask with `out` itself)
+        } else mbits = const_cast<unsigned long long *>(reinterpret_cast<const unsigned long long *>(relu_mask));
+    }
+    if (relu && !out && !(relu_mask && rows64_any)) return MPQE_ERR_INVALID_ARG;
+    if (grad_bias || (use_bits && !relu_mask))
+        launch_bias_grad((long long)Nn, grad_out, mask, (int)Dout, relu, bias_part, grad_bias, s, overwrite,
+                         use_bits && !relu_mask ? mbits : nullptr, relu_mask && rows64_any ? mbits : nullptr);
     if (grad_x) {
         dim3 grid((unsigned)(((tile_bound(Nn, E, R) + 7) / 8 * 8) * ((Din + GT_BN - 1) / GT_BN)));
         const bool rows64g = gvec && Din % 64 == 0 && Dout % 64 == 0 && !dbg_on("GEN_LDS_GEMM");
@@ -1005,10 +1049,10 @@ extern "C" int mpqe_rgcn_general_bwd(const void *plan, int64_t Nn, int64_t E, in
         dim3 g1((unsigned)(items1 < slots1 || slots1 == 0 || dbg_on("GEN_NOT_PERSISTENT") ? items1 : slots1));
         if (rows64g && relu)
             hipLaunchKernelGGL((rgcn_gen_gemm_rows_kernel<true, true>), g1, dim3(256), 0, s, P.rows_bwd, P.rel_ptr, P.tile_ptr,
-                               (int)R, grad_out, mask, basis, root, (int)Din, (int)Dout, gmsg);
+                               (int)R, grad_out, (const unsigned long long *)mbits, basis, root, (int)Din, (int)Dout, gmsg);
         else if (rows64g)
             hipLaunchKernelGGL((rgcn_gen_gemm_rows_kernel<true, false>), g1, dim3(256), 0, s, P.rows_bwd, P.rel_ptr, P.tile_ptr,
-                               (int)R, grad_out, mask, basis, root, (int)Din, (int)Dout, gmsg);
+                               (int)R, grad_out, (const unsigned long long *)nullptr, basis, root, (int)Din, (int)Dout, gmsg);
         else if (gvec)
             hipLaunchKernelGGL((rgcn_gen_gemm_kernel<true, LD_PRED>), grid, dim3(256), 0, s, P.rows_bwd, P.rel_ptr,
                                P.tile_ptr, (int)R, grad_out, mask, basis, root, (int)Din, (int)Dout, gmsg);
@@ -1028,10 +1072,10 @@ extern "C" int mpqe_rgcn_general_bwd(const void *plan, int64_t Nn, int64_t E, in
         const dim3 grid1((unsigned)(((chunk_bound(Nn, E, R) + 7) / 8 * 8) * tiles));      // (rows kernel: 1-D, see there)
         if (rows64 && relu && !dbg_on("GEN_NOMASK"))
             hipLaunchKernelGGL(rgcn_gen_grad_w_rows_kernel<true>, grid1, dim3(256), 0, s, P.rows_fwd, P.rows_bwd, P.rel_ptr,
-                               P.chunk_ptr, (int)R, x, grad_out, mask, (int)Din, (int)Dout, slabs);
+                               P.chunk_ptr, (int)R, x, grad_out, (const unsigned long long *)mbits, (int)Din, (int)Dout, slabs);
         else if (rows64)
             hipLaunchKernelGGL(rgcn_gen_grad_w_rows_kernel<false>, grid1, dim3(256), 0, s, P.rows_fwd, P.rows_bwd, P.rel_ptr,
-                               P.chunk_ptr, (int)R, x, grad_out, mask, (int)Din, (int)Dout, slabs);
+                               P.chunk_ptr, (int)R, x, grad_out, (const unsigned long long *)nullptr, (int)Din, (int)Dout, slabs);
         else if (gvec)
             hipLaunchKernelGGL(rgcn_gen_grad_w_kernel<LD_PRED>, grid, dim3(256), 0, s, P.rows_fwd, P.rows_bwd, P.rel_ptr,
                                P.chunk_ptr, (int)R, x, grad_out, mask, (int)Din, (int)Dout, relu, slabs);
@@ -1043,6 +1087,5 @@ extern "C" int mpqe_rgcn_general_bwd(const void *plan, int64_t Nn, int64_t E, in
         hipLaunchKernelGGL(rgcn_gen_reduce_w_kernel, rgrid, dim3(256), 0, s, P.chunk_ptr, (int)R, (int)Din,
                            (int)Dout, (const float *)slabs, grad_basis, grad_root, overwrite);
     }
-    if (grad_bias) launch_bias_grad((long long)Nn, grad_out, mask, (int)Dout, relu, bias_part, grad_bias, s, overwrite);
     return mpqe_launch_status();
 }

@@ -148,6 +148,7 @@ class _RGCNLayer(torch.autograd.Function):
                                                                         tuple(root.shape)))
         L = lib()
         out = torch.empty((x.shape[0], Dout), dtype=torch.float32, device=x.device)
+        mask_bits = None
         with torch.cuda.device(x.device):
             if isinstance(graph, Template):
                 if x.shape[0] != graph.B * graph.N:
@@ -160,16 +161,20 @@ class _RGCNLayer(torch.autograd.Function):
                     raise ValueError('plan was built for %d nodes / %d relations' % (graph.Nn, graph.R))
                 wb = L.mpqe_rgcn_general_workspace_bytes(graph.Nn, graph.E, R, Din, Dout, 0)
                 ws = _ws(wb, x.device)
+                # (the ReLU mask as bit words, 1 / 32 of `out`: the backward masks with them instead of gathering `out` rows)
+                mb = L.mpqe_rgcn_general_mask_bytes(graph.Nn, Dout) if relu else 0
+                if mb:
+                    mask_bits = torch.empty(mb // 8, dtype=torch.int64, device=x.device)
                 _ck(L.mpqe_rgcn_general_fwd(_p(graph.buf), graph.Nn, graph.E, R, _p(x), _p(basis), _p(root),
-                                            _p(bias), Din, Dout, int(relu), _p(out), _p(ws), wb, _stream()),
+                                            _p(bias), Din, Dout, int(relu), _p(out), _p(mask_bits), _p(ws), wb, _stream()),
                     'mpqe_rgcn_general_fwd')
         ctx.graph, ctx.relu, ctx.has_bias = graph, bool(relu), bias is not None
-        ctx.save_for_backward(x, basis, root, out if relu else None)
+        ctx.save_for_backward(x, basis, root, out if relu else None, mask_bits)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, basis, root, out = ctx.saved_tensors
+        x, basis, root, out, mask_bits = ctx.saved_tensors
         g = _f(g, 'grad_out')
         graph, relu = ctx.graph, ctx.relu
         R, Din, Dout = basis.shape
@@ -192,7 +197,7 @@ class _RGCNLayer(torch.autograd.Function):
             else:
                 wb = L.mpqe_rgcn_general_workspace_bytes(graph.Nn, graph.E, R, Din, Dout, 1)
                 ws = _ws(wb, x.device)
-                _ck(L.mpqe_rgcn_general_bwd(_p(graph.buf), graph.Nn, graph.E, R, _p(x), _p(out), _p(g), _p(basis),
+                _ck(L.mpqe_rgcn_general_bwd(_p(graph.buf), graph.Nn, graph.E, R, _p(x), _p(out), _p(mask_bits), _p(g), _p(basis),
                                             _p(root), Din, Dout, int(relu), 1, _p(gx), _p(gb), _p(gr), _p(gbias),
                                             _p(ws), wb, _stream()), 'mpqe_rgcn_general_bwd')
         return gx, gb, gr, gbias, None, None

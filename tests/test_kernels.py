@@ -151,8 +151,12 @@ def run_general(be, x, ei, et, basis, root, bias, relu, gout, Nn):
     out = be.empty((Nn, Dout))
     wf = be.lib.mpqe_rgcn_general_workspace_bytes(Nn, E, R, Din, Dout, 0)
     ws = be.nbytes(wf)
+    # the ReLU mask as bit words, where the library offers it (dim_out % 64 == 0): written by the forward, and the first
+    # backward call below runs on it WITHOUT `out`; the second call gets `out` alone and makes the words itself
+    mb = be.lib.mpqe_rgcn_general_mask_bytes(Nn, Dout) if relu else 0
+    mbits = be.nbytes(mb) if mb else None
     be.check(be.lib.mpqe_rgcn_general_fwd(be.ptr(plan), Nn, E, R, be.ptr(dx), be.ptr(db), be.ptr(dr), be.ptr(dbi),
-                                          Din, Dout, relu, be.ptr(out), be.ptr(ws), wf, be.stream), 'fwd')
+                                          Din, Dout, relu, be.ptr(out), be.ptr(mbits), be.ptr(ws), wf, be.stream), 'fwd')
     wb = be.lib.mpqe_rgcn_general_workspace_bytes(Nn, E, R, Din, Dout, 1)
     ws2 = be.nbytes(wb)
     gx = be.empty((Nn, Din))
@@ -161,16 +165,20 @@ def run_general(be, x, ei, et, basis, root, bias, relu, gout, Nn):
     gb, gr, gbi = be.zeros(basis.shape), be.zeros(root.shape), be.zeros(bias.shape)
     for t in (gb, gr, gbi):
         t.fill(np.nan) if be.name == 'emu' else t.fill_(float('nan'))
-    be.check(be.lib.mpqe_rgcn_general_bwd(be.ptr(plan), Nn, E, R, be.ptr(dx), be.ptr(out), be.ptr(dg), be.ptr(db),
+    # (`out` may stay away only when the register-operand kernels run: dims multiples of 64, 16-byte aligned operands)
+    no_out = mbits is not None and Din % 64 == 0
+    be.check(be.lib.mpqe_rgcn_general_bwd(be.ptr(plan), Nn, E, R, be.ptr(dx), None if no_out else be.ptr(out), be.ptr(mbits),
+                                          be.ptr(dg), be.ptr(db),
                                           be.ptr(dr), Din, Dout, relu, 1, be.ptr(gx), be.ptr(gb), be.ptr(gr),
                                           be.ptr(gbi), be.ptr(ws2), wb, be.stream), 'bwd')
     ab, ar, abi = be.zeros(basis.shape), be.zeros(root.shape), be.zeros(bias.shape)
     for t in (ab, ar, abi):
         t.fill(0.5) if be.name == 'emu' else t.fill_(0.5)
     gx2 = be.empty((Nn, Din))
-    be.check(be.lib.mpqe_rgcn_general_bwd(be.ptr(plan), Nn, E, R, be.ptr(dx), be.ptr(out), be.ptr(dg), be.ptr(db),
+    be.check(be.lib.mpqe_rgcn_general_bwd(be.ptr(plan), Nn, E, R, be.ptr(dx), be.ptr(out), None, be.ptr(dg), be.ptr(db),
                                           be.ptr(dr), Din, Dout, relu, 0, be.ptr(gx2), be.ptr(ab), be.ptr(ar),
                                           be.ptr(abi), be.ptr(ws2), wb, be.stream), 'bwd (accumulate)')
+    np.testing.assert_allclose(np.asarray(be.get(gx2)), np.asarray(be.get(gx)), rtol=1e-6, atol=1e-6)
     for acc, wr in ((ab, gb), (ar, gr), (abi, gbi)):
         np.testing.assert_allclose(np.asarray(be.get(acc)), np.asarray(be.get(wr)) + 0.5, rtol=1e-6, atol=1e-6)
     return [be.get(a) for a in (out, gx, gb, gr, gbi)], int(be.get(err)[0])
