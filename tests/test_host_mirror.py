@@ -121,3 +121,13 @@ def test_bench_refuses_more_ranks_than_gpus():
     q = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4', '--steps', '1', '--warmup', '0'],
                        env=env2, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert q.returncode != 0 and b'WORLD_SIZE' in q.stderr
+
+
+def test_graft_entry_expects_this_abi():
+    """__graft_entry__.build() asserts the library's ABI version: keep the number there in step with the library's."""
+    import os
+    import re
+    from mpqe_amd import _lib
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), '__graft_entry__.py')).read()
+    m = re.search(r'mpqe_abi_version\(\) == (\d+)', src)
+    assert m and int(m.group(1)) == _lib.load().mpqe_abi_version()
