@@ -2,9 +2,39 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <ucontext.h>
 
 #include <vector>
+
+// Context switch. glibc's swapcontext saves and restores the signal mask with a system call per switch, and a kernel with
+// MFMAs switches millions of times (a third of the CPU suite's time was spent in rt_sigprocmask): on x86-64 the fibers
+// switch with a dozen instructions instead -- callee-saved registers and the stack pointer, nothing else is live across a
+// call. -DEMU_UCONTEXT keeps the portable form (other hosts, sanitizer builds).
+#if defined(__x86_64__) && !defined(EMU_UCONTEXT)
+#define EMU_FAST_SWITCH 1
+extern "C" void emu_switch(void **save_sp, void *const *load_sp);
+asm(".text\n"
+    ".globl emu_switch\n"
+    ".type emu_switch,@function\n"
+    "emu_switch:\n"
+    "    pushq %rbp\n"
+    "    pushq %rbx\n"
+    "    pushq %r12\n"
+    "    pushq %r13\n"
+    "    pushq %r14\n"
+    "    pushq %r15\n"
+    "    movq %rsp, (%rdi)\n"
+    "    movq (%rsi), %rsp\n"
+    "    popq %r15\n"
+    "    popq %r14\n"
+    "    popq %r13\n"
+    "    popq %r12\n"
+    "    popq %rbx\n"
+    "    popq %rbp\n"
+    "    ret\n"
+    ".size emu_switch, .-emu_switch\n");
+#endif
 
 emu_uint3 threadIdx, blockIdx;
 dim3 blockDim, gridDim;
@@ -12,13 +42,21 @@ dim3 blockDim, gridDim;
 namespace emu {
 namespace {
 struct Fiber {
+#ifdef EMU_FAST_SWITCH
+    void *sp = nullptr;
+#else
     ucontext_t ctx;
+#endif
     char *stack = nullptr;
     unsigned tid = 0;
     bool done = false;
 };
 constexpr size_t kStack = 256 * 1024;
+#ifdef EMU_FAST_SWITCH
+void *g_main_sp = nullptr;
+#else
 ucontext_t g_main;
+#endif
 std::vector<Fiber> g_fibers;
 Fiber *g_cur = nullptr;
 const std::function<void()> *g_body = nullptr;
@@ -33,12 +71,30 @@ void set_tid(unsigned tid) {
     threadIdx.y = (tid / blockDim.x) % blockDim.y;
     threadIdx.z = tid / (blockDim.x * blockDim.y);
 }
+#ifdef EMU_FAST_SWITCH
+void yield() { emu_switch(&g_cur->sp, &g_main_sp); }
+#else
 void yield() { swapcontext(&g_cur->ctx, &g_main); }
+#endif
 void trampoline() {
     (*g_body)();
     g_cur->done = true;
     yield();
+    abort();          // (a finished fiber is never resumed)
 }
+#ifdef EMU_FAST_SWITCH
+// a fresh fiber: emu_switch pops six registers, then returns into trampoline with the stack as a call would leave it
+// (return-address slot 16-byte aligned, a null return address above it)
+void fiber_init(Fiber &f) {
+    char *top = f.stack + kStack;
+    top -= (uintptr_t)top % 16;
+    void **sp = reinterpret_cast<void **>(top);
+    *--sp = nullptr;                                   // trampoline's (never used) return address
+    *--sp = reinterpret_cast<void *>(&trampoline);     // emu_switch's `ret` target
+    for (int r = 0; r < 6; ++r) *--sp = nullptr;       // rbp rbx r12 r13 r14 r15
+    f.sp = sp;
+}
+#endif
 void wave_barrier() {
     const int w = g_cur->tid / 64;
     const int gen = g_wave_gen[w];
@@ -139,11 +195,15 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
                     Fiber &f = g_fibers[t];
                     f.tid = t;
                     f.done = false;
+#ifdef EMU_FAST_SWITCH
+                    fiber_init(f);
+#else
                     getcontext(&f.ctx);
                     f.ctx.uc_stack.ss_sp = f.stack;
                     f.ctx.uc_stack.ss_size = kStack;
                     f.ctx.uc_link = &g_main;
                     makecontext(&f.ctx, (void (*)())trampoline, 0);
+#endif
                 }
                 int remaining = (int)nthreads;
                 while (remaining > 0) {
@@ -154,7 +214,11 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
                         if (f.done) continue;
                         g_cur = &f;
                         set_tid(t);
+#ifdef EMU_FAST_SWITCH
+                        emu_switch(&g_main_sp, &f.sp);
+#else
                         swapcontext(&g_main, &f.ctx);
+#endif
                         if (f.done) {
                             --remaining;
                             --g_alive;

@@ -282,8 +282,6 @@ MIXES = {
 @pytest.mark.parametrize('mix', ['all7', 'dup', 'fast', 'fastragged'])
 def test_fused_step_matches_oracle(be, readout, adaptive, shared, L, mix):
     D, margin = (64 if mix.startswith('fast') else 32), 1.0
-    if mix.startswith('fast') and readout == 'max':
-        pytest.skip('one fast-path case per readout family is enough for the emulator budget')
     schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(
         11, D, L, shared, MIXES[mix], readout, adaptive)
     ref_loss, ref_per, ref_sp, ref_sn = oracle_step(params, cfg, node_map, batches, margin)
@@ -308,8 +306,6 @@ def test_step_in_three_calls_around_a_callers_readout(be, readout, adaptive, sha
     """The learned readouts (reference model.py:497-553) are the CALLER's: the step runs as three calls -- node states
     out; query embeddings in, their gradients out; state gradients in -- with the caller's readout in between, here the
     oracle's own readout code under autograd. Loss, scores and every gradient must be the oracle's for the whole model."""
-    if be.name == 'emu' and readout == 'targetmlp':
-        pytest.skip('two of the three cases on the emulator (the CPU suite\'s time budget); all on the GPU')
     D, margin = 32, 1.0
     schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(17, D, 3, shared, MIXES['all7'], readout, adaptive)
     ref_loss, ref_per, ref_sp, ref_sn = oracle_step(params, cfg, node_map, batches, margin)
@@ -376,8 +372,6 @@ def test_fused_step_with_learned_readout_matches_oracle(be, readout, scatter_op,
     """MLPReadout / TargetMLPReadout / the concat input (reference model.py:441-446, 497-553) INSIDE the one-call step:
     gather, Linear - ReLU - Linear on the library's dense-layer kernels, the reduction over each graph's rows, scores,
     and all of it backward, with the readout's regulariser (model.py:486-490). Against the oracle's whole model."""
-    if be.name == 'emu' and (readout, scatter_op) not in (('mlp', 'add'), ('targetmlp', 'mean'), ('concat', 'max')):
-        pytest.skip('one case per readout on the emulator (the CPU suite\'s time budget); all six on the GPU')
     D, margin = 32, 1.0
     schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(23, D, 3, shared, MIXES['all7'], readout, adaptive)
     cfg['scatter_op'], cfg['weight_decay'] = scatter_op, wd
@@ -426,8 +420,6 @@ def test_callers_readout_refuses_what_it_does_not_cover(be):
 
 @pytest.mark.parametrize('readout,adaptive,L', [('mp', True, 3), ('mp', False, 2), ('max', False, 3)])
 def test_fused_step_pruning_changes_nothing(be, readout, adaptive, L):
-    if be.name == 'emu' and readout == 'max':
-        pytest.skip('max readout keeps every state (pruning is a no-op): GPU only, for the CPU suite\'s time budget')
     """Node states that cannot reach the readout are skipped by default (MPQE_STEP_NO_PRUNE computes them
     all, as the reference does): same scores bit for bit, same gradients (the skipped terms are exact
     zeros; only the weight-gradient chunking differs)."""
@@ -465,8 +457,7 @@ def test_fused_step_chain_kernels(be, D, readout, adaptive, shared, L):
     runs = [got, lev]
     # every node state as per-graph rows (the default treats states no anchor has reached yet as one vector per batch)
     runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_NO_UNIFORM))
-    # (the host emulator runs the further variants at D = 64 only: the CPU suite's time budget; the GPU runs them all)
-    every = be.name == 'hip' or D == 64
+    every = True
     if every or readout == 'mp':
         # Where the weight-gradient tiles + post-pass run. A step this small takes the MERGED launch by default (workgroups
         # of the chain launch: include/mpqe_amd.h MPQE_STEP_MERGE_TAIL); the benchmarked step is larger and takes the
@@ -663,8 +654,6 @@ def test_touch_plan_one_launch_equals_library_sort(be, sizes):
     of the keys kernel + rocPRIM radix_sort_pairs (mpqe_debug_option TOUCH_ROCPRIM) -- a stable sort has one answer.
     1 to 256 workgroups of 2048 ids, bad ids included. (The host emulator runs workgroups one after the other and has no grid barrier:
     there both builds take the library-sort stand-in and the test only pins the layout.)"""
-    if be.name == 'emu' and sizes[0] > 11000:
-        pytest.skip('125 / 256 workgroups: GPU only (the CPU suite\'s time budget)')
     rng = np.random.RandomState(sizes[0])
     nmodes, rows_per = 3, [70, 40000, 130]
     node_map = np.full(sum(rows_per) + 1, -1, np.int64)
