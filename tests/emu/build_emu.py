@@ -17,7 +17,7 @@ def sources():
 
 
 def build_emu(force=False):
-    # a prebuilt variant (e.g. an AddressSanitizer build: DESIGN.md, Oracle and parity) can be injected
+    # a prebuilt variant (e.g. the AddressSanitizer build of tools/emu_asan.sh) can be injected
     if os.environ.get('MPQE_EMU_LIB'):
         return os.environ['MPQE_EMU_LIB']
     deps = sources() + glob.glob(os.path.join(ROOT, 'mpqe_amd', 'csrc', '*.h')) + \
