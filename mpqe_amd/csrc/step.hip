@@ -2103,8 +2103,10 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                 }
                 hp->uops_b.push_back(op);
             }
-            for (size_t k = 0; k < hp->uops_f.size(); ++k) hp->uops_f[k].out_gran = gran_of[hp->uops_f[k].out_vec];
-            for (size_t k = 0; k < hp->uops_b.size(); ++k) hp->uops_b[k].out_gran = gran_of[hp->uops_b[k].out_vec];
+            for (size_t k = 0; k < hp->uops_f.size(); ++k)
+                if (hp->uops_f[k].out_vec >= 0) hp->uops_f[k].out_gran = gran_of[hp->uops_f[k].out_vec];
+            for (size_t k = 0; k < hp->uops_b.size(); ++k)          // (a rank-1 op writes a matrix, not a vector: out_vec = -1)
+                if (hp->uops_b[k].out_vec >= 0) hp->uops_b[k].out_gran = gran_of[hp->uops_b[k].out_vec];
         }
     }
     hp->nvec = (int)vinfo.size();

@@ -20,4 +20,4 @@ if [ ! -f $lib ] || [ $newest -nt $lib ]; then
 fi
 cd $root
 LD_PRELOAD=$rt ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 MPQE_EMU_LIB=$lib \
-    python -m pytest -x -q -m "not gpu" -p no:cacheprovider "$@"
+    python -m pytest -x -q -s -m "not gpu" -p no:cacheprovider "$@"      # (-s: a report must not die in pytest's capture)
