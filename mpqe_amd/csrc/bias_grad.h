@@ -51,7 +51,7 @@ static __global__ __launch_bounds__(256) void bias_partial_kernel(long long rows
                 if (bits) {         // (Dout % 64 == 0: the whole wave is here)
                     const long long wi = (r + 4 * q) * (Dout / 64) + blockIdx.y;
 #ifdef MPQE_EMU
-                    int w = on ? 1 << (cl & 31) : 0;
+                    int w = on ? (int)(1u << (cl & 31)) : 0;
                     for (int m = 1; m < 32; m <<= 1) w |= __shfl_xor(w, m, 64);
                     if ((cl & 31) == 0) reinterpret_cast<unsigned *>(bits)[2 * wi + (cl >> 5)] = (unsigned)w;
 #else

@@ -1,23 +1,32 @@
 #!/bin/bash
-# Kernel logic under AddressSanitizer, on the CPU (GPU sanitizer runs are not available on this pool): the emulator build
-# of the kernel sources (tests/emu) compiled with -fsanitize=address, loaded by the tests through MPQE_EMU_LIB. The test
-# arrays are numpy buffers from the sanitizer's malloc, so a kernel that indexes outside an operand is reported with the
-# kernel's source line. Fibers switch with ucontext here (-DEMU_UCONTEXT: the sanitizer knows swapcontext), ~10x slower
-# than the default emulator build: pick tests with -k.
+# Kernel logic under a sanitizer, on the CPU (GPU sanitizer runs are not available on this pool): the emulator build of
+# the kernel sources (tests/emu) compiled with -fsanitize=address (default) or =undefined (MPQE_SAN=undefined), loaded by
+# the tests through MPQE_EMU_LIB. The test arrays are numpy buffers from the sanitizer's malloc, so a kernel -- or the host
+# planner -- that indexes outside an operand is reported with its source line. With the address sanitizer the fibers switch
+# with ucontext (-DEMU_UCONTEXT: it knows swapcontext), ~10x slower than the default emulator build: pick tests with -k.
 #   tools/emu_asan.sh tests/test_kernels.py -k "general or dense"
-#   tools/emu_asan.sh tests/test_step.py -k "learned_readout and mlp-add"
+#   MPQE_SAN=undefined tools/emu_asan.sh tests/test_step.py -k "learned_readout and mlp-add"
 set -e
 root=$(cd $(dirname $0)/.. && pwd)
 CL=/opt/rocm/lib/llvm/bin/clang++
-rt=$($CL -print-file-name=libclang_rt.asan-x86_64.so)
-out=${TMPDIR:-/tmp}/mpqe_emu_asan
+san=${MPQE_SAN:-address}
+if [ $san = address ]; then
+    flags="-fsanitize=address -DEMU_UCONTEXT"
+    rt=$($CL -print-file-name=libclang_rt.asan-x86_64.so)
+    export ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0
+else
+    flags="-fsanitize=undefined -fno-sanitize=vptr,function"
+    rt=$($CL -print-file-name=libclang_rt.ubsan_standalone-x86_64.so)
+    export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
+fi
+out=${TMPDIR:-/tmp}/mpqe_emu_$san
 mkdir -p $out
-lib=$out/libmpqe_emu_asan.so
+lib=$out/libmpqe_emu_$san.so
 newest=$(ls -t $root/mpqe_amd/csrc/*.hip $root/mpqe_amd/csrc/*.h $root/tests/emu/emu_runtime.cpp $root/include/mpqe_amd.h | head -1)
 if [ ! -f $lib ] || [ $newest -nt $lib ]; then
-    $CL -x c++ -std=c++17 -O1 -g -fPIC -shared -fsanitize=address -DEMU_UCONTEXT -I$root/tests/emu/include -I$root/include \
+    $CL -x c++ -std=c++17 -O1 -g -fPIC -shared $flags -I$root/tests/emu/include -I$root/include \
         $root/mpqe_amd/csrc/*.hip $root/tests/emu/emu_runtime.cpp -o $lib
 fi
 cd $root
-LD_PRELOAD=$rt ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 MPQE_EMU_LIB=$lib \
-    python -m pytest -x -q -s -m "not gpu" -p no:cacheprovider "$@"      # (-s: a report must not die in pytest's capture)
+# (-s: a report must not die in pytest's capture)
+LD_PRELOAD=$rt MPQE_EMU_LIB=$lib python -m pytest -x -q -s -m "not gpu" -p no:cacheprovider "$@"
