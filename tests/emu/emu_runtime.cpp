@@ -11,6 +11,13 @@
 // MFMAs switches millions of times (a third of the CPU suite's time was spent in rt_sigprocmask): on x86-64 the fibers
 // switch with a dozen instructions instead -- callee-saved registers and the stack pointer, nothing else is live across a
 // call. -DEMU_UCONTEXT keeps the portable form (other hosts, sanitizer builds).
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define EMU_ASAN 1
+#include <sanitizer/asan_interface.h>
+#include <sanitizer/common_interface_defs.h>
+#endif
+#endif
 #if defined(__x86_64__) && !defined(EMU_UCONTEXT)
 #define EMU_FAST_SWITCH 1
 extern "C" void emu_switch(void **save_sp, void *const *load_sp);
@@ -72,11 +79,29 @@ void set_tid(unsigned tid) {
     threadIdx.z = tid / (blockDim.x * blockDim.y);
 }
 #ifdef EMU_FAST_SWITCH
+#ifdef EMU_ASAN
+// AddressSanitizer is told about every stack switch (it tracks the bounds of the running stack): start_switch in front
+// of it, finish_switch as the first thing on the other side. A fiber that is done passes NULL (its fake stack is freed).
+const void *g_main_bottom = nullptr;
+size_t g_main_size = 0;
+void *g_main_fake = nullptr;
+void yield() {
+    Fiber *f = g_cur;
+    void *fake = nullptr;
+    __sanitizer_start_switch_fiber(f->done ? nullptr : &fake, g_main_bottom, g_main_size);
+    emu_switch(&f->sp, &g_main_sp);
+    __sanitizer_finish_switch_fiber(fake, &g_main_bottom, &g_main_size);
+}
+#else
 void yield() { emu_switch(&g_cur->sp, &g_main_sp); }
+#endif
 #else
 void yield() { swapcontext(&g_cur->ctx, &g_main); }
 #endif
 void trampoline() {
+#if defined(EMU_FAST_SWITCH) && defined(EMU_ASAN)
+    __sanitizer_finish_switch_fiber(nullptr, &g_main_bottom, &g_main_size);      // (first entry of this fiber)
+#endif
     (*g_body)();
     g_cur->done = true;
     yield();
@@ -86,6 +111,10 @@ void trampoline() {
 // a fresh fiber: emu_switch pops six registers, then returns into trampoline with the stack as a call would leave it
 // (return-address slot 16-byte aligned, a null return address above it)
 void fiber_init(Fiber &f) {
+#ifdef EMU_ASAN
+    // (the stack's previous run ended inside trampoline -> yield, never unwound: its frames' redzones are still poisoned)
+    __asan_unpoison_memory_region(f.stack, kStack);
+#endif
     char *top = f.stack + kStack;
     top -= (uintptr_t)top % 16;
     void **sp = reinterpret_cast<void **>(top);
@@ -215,7 +244,13 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
                         g_cur = &f;
                         set_tid(t);
 #ifdef EMU_FAST_SWITCH
+#ifdef EMU_ASAN
+                        __sanitizer_start_switch_fiber(&g_main_fake, f.stack, kStack);
                         emu_switch(&g_main_sp, &f.sp);
+                        __sanitizer_finish_switch_fiber(g_main_fake, nullptr, nullptr);
+#else
+                        emu_switch(&g_main_sp, &f.sp);
+#endif
 #else
                         swapcontext(&g_main, &f.ctx);
 #endif

@@ -2,8 +2,7 @@
 # Kernel logic under a sanitizer, on the CPU (GPU sanitizer runs are not available on this pool): the emulator build of
 # the kernel sources (tests/emu) compiled with -fsanitize=address (default) or =undefined (MPQE_SAN=undefined), loaded by
 # the tests through MPQE_EMU_LIB. The test arrays are numpy buffers from the sanitizer's malloc, so a kernel -- or the host
-# planner -- that indexes outside an operand is reported with its source line. With the address sanitizer the fibers switch
-# with ucontext (-DEMU_UCONTEXT: it knows swapcontext), ~10x slower than the default emulator build: pick tests with -k.
+# planner -- that indexes outside an operand is reported with its source line. ~3x slower than the default emulator build.
 #   tools/emu_asan.sh tests/test_kernels.py -k "general or dense"
 #   MPQE_SAN=undefined tools/emu_asan.sh tests/test_step.py -k "learned_readout and mlp-add"
 set -e
@@ -11,7 +10,7 @@ root=$(cd $(dirname $0)/.. && pwd)
 CL=/opt/rocm/lib/llvm/bin/clang++
 san=${MPQE_SAN:-address}
 if [ $san = address ]; then
-    flags="-fsanitize=address -DEMU_UCONTEXT"
+    flags="-fsanitize=address"        # (the fibers' stack switches are announced to the sanitizer: emu_runtime.cpp)
     rt=$($CL -print-file-name=libclang_rt.asan-x86_64.so)
     export ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0
 else
