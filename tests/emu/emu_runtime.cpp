@@ -72,6 +72,8 @@ long g_events = 0;
 constexpr int kMaxWaves = 16;
 int g_wave_alive[kMaxWaves], g_wave_gen[kMaxWaves], g_wave_arrived[kMaxWaves];
 float g_xa[kMaxWaves][64], g_xb[kMaxWaves][64];
+int g_wave_order = -1;                  // MPQE_EMU_WAVE_ORDER (read once)
+unsigned long long g_wave_rng = 0;
 
 void set_tid(unsigned tid) {
     threadIdx.x = tid % blockDim.x;
@@ -204,6 +206,11 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
         g_fibers.resize(nthreads);
         for (size_t i = old; i < nthreads; ++i) g_fibers[i].stack = (char *)malloc(kStack);
     }
+    if (g_wave_order < 0) {
+        const char *e = getenv("MPQE_EMU_WAVE_ORDER");
+        g_wave_order = e ? atoi(e) : 0;
+        g_wave_rng = (unsigned long long)g_wave_order * 0x9E3779B97F4A7C15ull + 1;
+    }
     blockDim = block;
     gridDim = grid;
     g_body = &body;
@@ -238,7 +245,25 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
                 while (remaining > 0) {
                     int progressed = 0;
                     const long ev0 = g_events;
-                    for (unsigned t = 0; t < nthreads; ++t) {
+                    // The order in which the WAVES of the workgroup get their turn: ascending by default; MPQE_EMU_WAVE_ORDER=1
+                    // descending, >= 2 a fresh pseudo-random order every round (the value seeds it). Waves are independent
+                    // between barriers on the GPU, so a kernel's results must not depend on this -- a hand-off between waves
+                    // without a barrier shows up as a difference (lanes keep their order inside a wave: they run in lockstep
+                    // there, which the emulator models only at the shuffle / MFMA exchanges).
+                    const unsigned nwaves = (nthreads + 63) / 64;
+                    unsigned worder[kMaxWaves];
+                    for (unsigned w = 0; w < nwaves; ++w) worder[w] = g_wave_order == 1 ? nwaves - 1 - w : w;
+                    if (g_wave_order >= 2)
+                        for (unsigned w = nwaves; w > 1; --w) {
+                            g_wave_rng = g_wave_rng * 6364136223846793005ull + 1442695040888963407ull;
+                            const unsigned j = (unsigned)((g_wave_rng >> 33) % w);
+                            const unsigned tmp = worder[w - 1];
+                            worder[w - 1] = worder[j];
+                            worder[j] = tmp;
+                        }
+                    for (unsigned k = 0; k < nwaves * 64; ++k) {
+                        const unsigned t = worder[k / 64] * 64 + k % 64;
+                        if (t >= nthreads) continue;
                         Fiber &f = g_fibers[t];
                         if (f.done) continue;
                         g_cur = &f;
