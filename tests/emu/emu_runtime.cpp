@@ -214,9 +214,15 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
     blockDim = block;
     gridDim = grid;
     g_body = &body;
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-        for (unsigned by = 0; by < grid.y; ++by)
-            for (unsigned bx = 0; bx < grid.x; ++bx) {
+    // MPQE_EMU_BLOCK_ORDER=1: the workgroups of a launch run in DESCENDING order (for kernels whose workgroups do not depend
+    // on each other: a result that depends on which workgroup came last shows up; the fused step's launches hand data from
+    // earlier to later workgroups on purpose and need the ascending order)
+    static const int block_order = getenv("MPQE_EMU_BLOCK_ORDER") ? atoi(getenv("MPQE_EMU_BLOCK_ORDER")) : 0;
+    for (unsigned bz_ = 0; bz_ < grid.z; ++bz_)
+        for (unsigned by_ = 0; by_ < grid.y; ++by_)
+            for (unsigned bx_ = 0; bx_ < grid.x; ++bx_) {
+                const unsigned bx = block_order ? grid.x - 1 - bx_ : bx_, by = block_order ? grid.y - 1 - by_ : by_,
+                               bz = block_order ? grid.z - 1 - bz_ : bz_;
                 blockIdx.x = bx;
                 blockIdx.y = by;
                 blockIdx.z = bz;
