@@ -835,7 +835,7 @@ def main():
     if rank == 0:
         flops_fwd, flops_all, bytes_all, launches = layer_work(pool[0], model)
         executed = None
-        if use_fused and not learned:      # (the learned readouts run the level form: its roofline line is the layer kernel's)
+        if use_fused:
             fams, executed = time_fused_kernels(fstep, packed[0], pool[0], model, args.readout)
             dom = max(fams, key=lambda f: f['total_us_per_step'])
             out['roofline'] = {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['achieved'],
@@ -865,9 +865,6 @@ def main():
                                'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
                                'avg_launch_us': dur * 1e6, 'algorithmic_flops_per_launch': per_launch_flops,
                                'launches_per_step': launches}
-            if learned and use_fused:
-                out['roofline']['note'] = ('the layer tile core timed through the module path\'s launch (one batch per launch); the '
-                                           'fused step\'s level form runs the same core over all batches of a level per launch')
         if world == 1 and not args.no_scatter:
             out['roofline_scatter'] = time_scatter_aggregate()
         out['step_work'] = {'layer_flops_fwd_bwd': flops_all, 'scatter_aggregate_bytes_fwd_bwd': bytes_all,
