@@ -620,8 +620,11 @@ __global__ __launch_bounds__(256) void step_score_kernel(
     float *__restrict__ s_pos, float *__restrict__ s_neg, float *__restrict__ terms,
     float *__restrict__ GH, TablePtrs tabs, const long long *__restrict__ node_map, long long map_len,
     const long long *__restrict__ targets, const long long *__restrict__ negs, long long g0, long long ng,
-    const float *__restrict__ Q, float *__restrict__ GQ) {
-    // Q != NULL (MPQE_READOUT_CALLER): the query embedding of graph gi is row gi of Q, its gradient goes to row gi of GQ
+    const float *__restrict__ Q, float *__restrict__ GQ, const float *__restrict__ RY, float *__restrict__ RGY,
+    int ro_op) {
+    // Q != NULL (MPQE_READOUT_CALLER): the query embedding of graph gi is row gi of Q, its gradient goes to row gi of GQ.
+    // RY != NULL (the learned readouts, step_readout.h): the embedding is the add / max / mean (ro_op: MPQE_SCATTER_*) over the
+    // graph's rows of RY -- its N node rows, or its N - 1 pair rows (TARGETMLP) -- and the rows' gradients go to RGY.
     const long long gl = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (gl >= ng) return;
@@ -633,6 +636,10 @@ __global__ __launch_bounds__(256) void step_score_kernel(
     const int D = sd->D, N = b.tp.N, A = b.A;
     const long long row0 = b.row_off + (gi - b.g_off) * N;
     const float *h = H + (long long)b.L * level_stride + row0 * D;
+    const bool ro_pairs = RY && sd->readout == MPQE_READOUT_TARGETMLP;
+    const int ro_cnt = ro_pairs ? N - 1 : N;
+    const long long ro_r0 = ro_pairs ? (b.row_off - b.g_off) + (gi - b.g_off) * (N - 1) : row0;
+    if (RY) h = RY + ro_r0 * D;
     const float *tp_ = tpos + gi * D, *tn_ = tneg + gi * D;
     float q[NJ];
     int arg[NJ];
@@ -643,7 +650,10 @@ __global__ __launch_bounds__(256) void step_score_kernel(
         q[j] = 0.f;
         arg[j] = 0;
         if (c < D) {
-            q[j] = Q ? Q[gi * D + c] : readout_value(sd->readout, h, N, A, D, c, &arg[j]);
+            if (RY) {
+                q[j] = readout_value(ro_op == MPQE_SCATTER_MAX ? MPQE_READOUT_MAX : MPQE_READOUT_SUM, h, ro_cnt, 0, D, c, &arg[j]);
+                if (ro_op == MPQE_SCATTER_MEAN) q[j] /= (float)ro_cnt;
+            } else q[j] = Q ? Q[gi * D + c] : readout_value(sd->readout, h, N, A, D, c, &arg[j]);
             const float a = tp_[c], bb = tn_[c];
             dp += q[j] * a;
             dn += q[j] * bb;
@@ -701,7 +711,13 @@ __global__ __launch_bounds__(256) void step_score_kernel(
             const float gq = gsp * tp_[c] * inv_p + gsn * tn_[c] * inv_n - kq * q[j];
             float *gh = GH + (long long)b.L * level_stride + row0 * D + c;
             if (Q) GQ[gi * D + c] = gq;
-            for (int n = 0; n < N && !Q; ++n) {
+            if (RY) {
+                float *gy = RGY + ro_r0 * D + c;
+                for (int n = 0; n < ro_cnt; ++n)
+                    gy[(long long)n * D] = ro_op == MPQE_SCATTER_ADD ? gq
+                                           : (ro_op == MPQE_SCATTER_MEAN ? gq / (float)ro_cnt : (arg[j] == n ? gq : 0.f));
+            }
+            for (int n = 0; n < N && !Q && !RY; ++n) {
                 float gv;
                 if (sd->readout == MPQE_READOUT_SUM) gv = gq;
                 else if (sd->readout == MPQE_READOUT_TM) gv = n == A ? gq : 0.f;
@@ -1404,7 +1420,7 @@ struct HostPlan {
     size_t o_sd, o_wsrc, o_wblock, o_vsrc, o_vblock, o_groups, o_anchor, desc_total;     // descriptor buffer
     size_t o_H, o_GH, o_tpos, o_tneg, o_spos, o_sneg, o_terms, o_slabs, o_parts, o_Q, o_GQ, total;  // workspace
     // learned readouts (step_readout.h): input rows, hidden, output and their gradients, argmax, dense-layer workspace
-    size_t o_rx, o_rh, o_ry, o_rgy, o_rgh, o_rgx, o_rarg, o_rlin, rlin_bytes;
+    size_t o_rx, o_rh, o_ry, o_rgy, o_rgh, o_rgx, o_rlin, rlin_bytes;
     long long ro_rows;
     int ro_kin;
     bool ro_direct;
@@ -2406,8 +2422,8 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->o_sneg = take((size_t)graphs * 4);
     hp->o_terms = take((size_t)graphs * 4);
     // (the caller's readout: its query embeddings in, their gradients out)
-    hp->o_Q = take(P->readout >= MPQE_READOUT_CALLER ? (size_t)graphs * D * 4 : 0);
-    hp->o_GQ = take(P->readout >= MPQE_READOUT_CALLER ? (size_t)graphs * D * 4 : 0);
+    hp->o_Q = take(P->readout == MPQE_READOUT_CALLER ? (size_t)graphs * D * 4 : 0);
+    hp->o_GQ = take(P->readout == MPQE_READOUT_CALLER ? (size_t)graphs * D * 4 : 0);
     hp->ro_rows = 0;
     hp->ro_kin = 0;
     hp->ro_direct = false;
@@ -2427,7 +2443,6 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         hp->o_ry = take(xd);
         hp->o_rgy = take(xd);
         hp->o_rgh = take(xd);
-        hp->o_rarg = take((size_t)graphs * D);
         hp->rlin_bytes = std::max(mpqe_linear_bwd_workspace_bytes(hp->ro_rows, hp->ro_kin, D),
                                   mpqe_linear_bwd_workspace_bytes(hp->ro_rows, D, D));
         hp->o_rlin = take(hp->rlin_bytes);
@@ -3432,8 +3447,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         mark(s);
     }
     // ---- forward
-    const float *Qc = P->readout >= MPQE_READOUT_CALLER ? reinterpret_cast<const float *>(wb + hp.o_Q) : nullptr;
-    float *GQc = P->readout >= MPQE_READOUT_CALLER ? reinterpret_cast<float *>(wb + hp.o_GQ) : nullptr;
+    const float *Qc = P->readout == MPQE_READOUT_CALLER ? reinterpret_cast<const float *>(wb + hp.o_Q) : nullptr;
+    float *GQc = P->readout == MPQE_READOUT_CALLER ? reinterpret_cast<float *>(wb + hp.o_GQ) : nullptr;
     // learned readouts: gather -> Linear - ReLU - Linear -> reduction over each graph's rows, and the way back
     RoArgs roa;
     memset(&roa, 0, sizeof(roa));
@@ -3443,7 +3458,6 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     roa.kin = hp.ro_kin;
     roa.level_stride = hp.level_stride;
     float *ro_x = nullptr, *ro_gx = nullptr, *ro_h = nullptr, *ro_y = nullptr, *ro_gy = nullptr, *ro_gh = nullptr;
-    signed char *ro_arg = nullptr;
     if (learned) {
         const long long lv = (long long)hp.sd.b[0].L * hp.level_stride;
         ro_x = hp.ro_direct ? H + lv : reinterpret_cast<float *>(wb + hp.o_rx);
@@ -3452,7 +3466,6 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         ro_y = reinterpret_cast<float *>(wb + hp.o_ry);
         ro_gy = reinterpret_cast<float *>(wb + hp.o_rgy);
         ro_gh = reinterpret_cast<float *>(wb + hp.o_rgh);
-        ro_arg = reinterpret_cast<signed char *>(wb + hp.o_rarg);
     }
     auto ro_blocks = [](long long threads) { return dim3((unsigned)((threads + 255) / 256)); };
     auto ro_forward = [&]() -> int {
@@ -3463,14 +3476,10 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         if (st) return st;
         st = mpqe_linear_fwd(ro_h, roa.mrows, P->readout_w2, D, P->readout_b2, D, D, 0, 0, ro_y, s);
         if (st) return st;
-        hipLaunchKernelGGL(step_ro_reduce_kernel, ro_blocks(hp.sd.graphs_total * (D / 4)), dim3(256), 0, s, sd, roa,
-                           (const float *)ro_y, const_cast<float *>(Qc), ro_arg);
-        return MPQE_OK;
+        return MPQE_OK;         // (the reduction over each graph's rows: inside the score kernel)
     };
     auto ro_backward = [&]() -> int {
-        hipLaunchKernelGGL(step_ro_expand_kernel, ro_blocks(roa.mrows * (D / 4)), dim3(256), 0, s, sd, roa,
-                           (const float *)GQc, (const signed char *)ro_arg, ro_gy);
-        void *lw = wb + hp.o_rlin;
+        void *lw = wb + hp.o_rlin;         // (the score kernel has written the rows' gradients)
         int st = mpqe_linear_bwd(ro_h, roa.mrows, P->readout_w2, D, ro_y, ro_gy, D, D, 0, 0, ro_gh, G->readout_w2, D,
                                  G->readout_b2, lw, hp.rlin_bytes, s);
         if (st) return st;
@@ -3526,7 +3535,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     hipLaunchKernelGGL((step_score_kernel<BWD, NJ>), dim3((unsigned)((gr0[L + 1] - gr0[L] + 3) / 4)), dim3(256), 0, \
                        ls[L], sd, (const float *)H, hp.level_stride, (const float *)tpos, (const float *)tneg,     \
                        margin, 1e-8f, spos, sneg, terms, GHP, tabs, nm, (long long)P->node_map_len, tg, ng, gr0[L], \
-                       gr0[L + 1] - gr0[L], (const float *)Qc, GQc)
+                       gr0[L + 1] - gr0[L], (const float *)Qc, GQc, \
+                       (const float *)(learned ? ro_y : nullptr), learned ? ro_gy : (float *)nullptr, roa.op)
 #define LAUNCH_SCORE_D(BWD, GHP, L)                  \
     if (D <= 64) LAUNCH_SCORE(BWD, 1, GHP, L);       \
     else if (D <= 128) LAUNCH_SCORE(BWD, 2, GHP, L); \

@@ -4,8 +4,9 @@
 //   gather   X[m] = the readout's input row m        mlp: final state of node row m; concat: the states of levels 1 .. L side
 //                                                    by side; targetmlp: [target state | non-target state] of pair m
 //   reduce   q[g] = add / mean / max over graph g's   (torch_scatter semantics: max keeps the LOWEST row on ties -- strict > --,
-//            rows of Y (its N, or N - 1 pair, rows)   mean divides by the row count)
-//   expand   gY[m] = the reduction's backward
+//            rows of Y (its N, or N - 1 pair, rows)   mean divides by the row count): INSIDE the score kernel (step.hip:
+//            step_score_kernel, RY / RGY), which reads the rows where it used to read the node states and writes the rows'
+//            gradients where it used to write the states' -- no launch, no buffer for the embedding
 //   spread   gX -> rows of the state-gradient levels  (targetmlp: the target's row gets the sum of its pairs' first halves)
 // A graph's rows are consecutive in every layout (graph-major node rows: row_off + g N + n; pairs: pair_off + g (N - 1) + k
 // with pair_off = row_off - g_off), so the scatter is a reduction over <= 4 consecutive rows: no index vector, no atomics.
@@ -48,70 +49,6 @@ __global__ __launch_bounds__(256) void step_ro_gather_kernel(const StepDev *__re
         src = H + (long long)b.L * ra.level_stride + (b.row_off + g * N + n) * D + (c < D ? c : c - D);
     }
     *reinterpret_cast<f32x4 *>(X + m * ra.kin + c) = *reinterpret_cast<const f32x4 *>(src);
-}
-
-// one thread per (graph, 4 columns): rows [r0, r0 + cnt) of Y
-__global__ __launch_bounds__(256) void step_ro_reduce_kernel(const StepDev *__restrict__ sd, RoArgs ra,
-                                                             const float *__restrict__ Y, float *__restrict__ Q,
-                                                             signed char *__restrict__ arg) {
-    const int D = sd->D, q = D / 4;
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= sd->graphs_total * q) return;
-    const long long gi = t / q;
-    const int c = (int)(t % q) * 4;
-    int bi = 0;
-    for (int i = 1; i < sd->nb; ++i)
-        if (sd->b[i].g_off <= gi) bi = i;
-    const BatchDev &b = sd->b[bi];
-    const bool pairs = ra.kind == MPQE_READOUT_TARGETMLP;
-    const int cnt = pairs ? b.tp.N - 1 : b.tp.N;
-    const long long r0 = (pairs ? b.row_off - b.g_off : b.row_off) + (gi - b.g_off) * cnt;
-    f32x4 acc = *reinterpret_cast<const f32x4 *>(Y + r0 * D + c);
-    int am[4] = {0, 0, 0, 0};
-    for (int n = 1; n < cnt; ++n) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(Y + (r0 + n) * D + c);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (ra.op == MPQE_SCATTER_MAX) {
-                if (v[u] > acc[u]) {
-                    acc[u] = v[u];
-                    am[u] = n;
-                }
-            } else acc[u] += v[u];
-        }
-    }
-    if (ra.op == MPQE_SCATTER_MEAN) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] /= (float)cnt;
-    }
-    *reinterpret_cast<f32x4 *>(Q + gi * D + c) = acc;
-    if (ra.op == MPQE_SCATTER_MAX && arg) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) arg[gi * D + c + u] = (signed char)am[u];
-    }
-}
-
-// one thread per (row m of Y, 4 columns)
-__global__ __launch_bounds__(256) void step_ro_expand_kernel(const StepDev *__restrict__ sd, RoArgs ra,
-                                                             const float *__restrict__ GQ,
-                                                             const signed char *__restrict__ arg, float *__restrict__ GY) {
-    const int D = sd->D, q = D / 4;
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= ra.mrows * q) return;
-    const long long m = t / q;
-    const int c = (int)(t % q) * 4;
-    const bool pairs = ra.kind == MPQE_READOUT_TARGETMLP;
-    const BatchDev &b = sd->b[ro_batch_of_row(sd, m, pairs)];
-    const int cnt = pairs ? b.tp.N - 1 : b.tp.N;
-    const long long lm = m - (pairs ? b.row_off - b.g_off : b.row_off), gi = b.g_off + lm / cnt;
-    const int n = (int)(lm % cnt);
-    f32x4 g = *reinterpret_cast<const f32x4 *>(GQ + gi * D + c);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        if (ra.op == MPQE_SCATTER_MEAN) g[u] /= (float)cnt;
-        else if (ra.op == MPQE_SCATTER_MAX) g[u] = arg[gi * D + c + u] == n ? g[u] : 0.f;
-    }
-    *reinterpret_cast<f32x4 *>(GY + m * D + c) = g;
 }
 
 // one thread per (node row, 4 columns of D): the gradient rows of the levels the readout read
