@@ -148,7 +148,8 @@ def _touch_bits(v):
 
 class ExchangePlan(object):
     __slots__ = ('form', 'grad_views', 'bucket', 'bucket_views', 'bucket_bytes', 'rows', 'n_own', 'cap', 'gidx', 'send',
-                 'recv', 'plan', 'plan_ptr', 'entries', 'wire_bytes', 'union')
+                 'recv', 'plan', 'plan_ptr', 'entries', 'wire_bytes', 'union', 'desc_hash', 'send_keys', 'all_keys', 'plan_ws',
+                 'plan_sizes', 'in_step')
 
 
 class StepExchange(object):
@@ -207,8 +208,11 @@ class StepExchange(object):
         if tables not in ('auto', 'dense', 'rows'):
             raise ValueError("tables: 'auto', 'dense' or 'rows'")
         self.table_mode = tables if tables != 'auto' else ('dense' if 4 * (hi - lo) <= self.DENSE_TABLE_BYTES else 'rows')
-        if self.table_mode == 'rows' and fused_step.touch_mode != 'pack':
-            raise ValueError("the row exchange plans with the touch plan's keys: FusedTrainStep(touch='pack')")
+        # the row exchange plans with the keys of the step's touch plan: built by pack() (touch='pack': plan() reads them
+        # before the step runs) or by the step itself (touch='step', the default: the keys are an OUTPUT of run() and
+        # reduce() plans from them, stream-ordered -- no object collective, no host read, nothing id-dependent in pack())
+        if self.table_mode == 'rows' and fused_step.touch_mode not in ('pack', 'step'):
+            raise ValueError("the row exchange plans with the touch plan's keys: FusedTrainStep(touch='step' | 'pack')")
         self._plans = {}
         import ctypes
         self._tab_g = (ctypes.c_void_p * len(self.tables))(
@@ -236,17 +240,47 @@ class StepExchange(object):
         else:
             dist.all_gather_into_tensor(out, t, group=self.group)
 
-    def plan(self, packed, key=None):
-        """Collective: every rank calls it with ITS packed step (same number of calls in the same order).
-        key: the caller's name for what recurs across steps -- the formula sets of ALL ranks at this step (e.g. the index
-        into a common schedule of formula sets). A key seen before returns its cached plan with no collective; the caller
-        vouches that the same key means the same descriptor sets on every rank. Only with dense tables (the row exchange
-        depends on the ids)."""
+    @staticmethod
+    def descriptor_hash(packed):
+        """64-bit hash of a packed step's descriptor set (formulas, relation ids, passes, sizes, weights): what a plan
+        key must stand for."""
+        import hashlib
+        return int.from_bytes(hashlib.blake2b(bytes(packed.batches), digest_size=8).digest(), 'little') & ((1 << 63) - 1)
+
+    def plan(self, packed, key=None, verify=False):
+        """Collective on a key's first use: every rank calls it with ITS packed step (same number of calls in the same
+        order). key: the caller's name for what recurs across steps -- the formula sets of ALL ranks at this step (e.g.
+        the index into a common schedule of formula sets). A key seen before returns its cached plan with no collective.
+        What the key is trusted for, and what is checked:
+          * first use: the ranks exchange (key, descriptor hash) next to their matrix lists; ranks that arrive with
+            DIFFERENT keys raise (a schedule that has drifted apart);
+          * every later use: this rank's descriptor set must hash to what the key was planned for, else ValueError
+            (a key re-used for another formula set would reduce the wrong matrices -- silently diverging replicas);
+          * verify=True (a collective: every rank must pass it in the same call): additionally all-reduces (min, max)
+            of the combined hash, so a rank whose OWN set still matches learns that another rank's does not.
+        With the row exchange and a pack-time touch plan (touch='pack') the ids take part: no caching."""
         import ctypes
         from . import _capi, ops
         rows = self.table_mode == 'rows'
-        if key is not None and not rows and key in self._plans:
-            return self._plans[key]
+        in_step = rows and self.fused.touch_mode == 'step' and getattr(packed, 'touch_mode', None) == 'step'
+        dh = self.descriptor_hash(packed)
+        if key is not None and (not rows or in_step) and key in self._plans:
+            ep = self._plans[key]
+            ok = ep.desc_hash[self.rank] == dh
+            if verify and self.world > 1:
+                import hashlib
+                mine = int.from_bytes(hashlib.blake2b(repr((ok, ep.desc_hash)).encode(), digest_size=7).digest(), 'little')
+                t = torch.tensor([mine, -mine], dtype=torch.int64)
+                if self.backend != 'gloo':
+                    t = t.to(self.dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                lo_hi = t.tolist()
+                if lo_hi[0] != -lo_hi[1]:
+                    raise ValueError('StepExchange.plan(key=%r): the ranks disagree about what this key stands for' % (key,))
+            if not ok:
+                raise ValueError('StepExchange.plan(key=%r): this packed step is not the descriptor set the key was planned '
+                                 'for (a plan key must name ONE formula set per rank)' % (key,))
+            return ep
         f = self.fused
         m = f.model
         layers = list(m.layers)
@@ -263,10 +297,13 @@ class StepExchange(object):
                     mine.add((kk, int(b.edge_type[e])))
         gathered = [None] * self.world
         if self.world > 1:
-            dist.all_gather_object(gathered, sorted(mine), group=self.group)
+            dist.all_gather_object(gathered, (repr(key), dh, sorted(mine)), group=self.group)
         else:
-            gathered = [sorted(mine)]
-        union = sorted(set().union(*[set(map(tuple, g)) for g in gathered]))
+            gathered = [(repr(key), dh, sorted(mine))]
+        if len(set(g[0] for g in gathered)) != 1:
+            raise ValueError('StepExchange.plan: the ranks arrived with different keys %r' % ([g[0] for g in gathered],))
+        desc_hash = tuple(g[1] for g in gathered)
+        union = sorted(set().union(*[set(map(tuple, g[2])) for g in gathered]))
         segs, full = [], []
         DD = self.D * self.D
         for p in f.params:
@@ -295,6 +332,9 @@ class StepExchange(object):
         ep = ExchangePlan()
         ep.union = union
         ep.rows = rows
+        ep.desc_hash = desc_hash
+        ep.in_step = in_step
+        ep.send_keys = ep.all_keys = ep.plan_ws = ep.plan_sizes = None
         nsel, nfull = sum(n for _, n in merged), sum(n for _, n in spans)
         if nsel >= self.DENSE_FRACTION * nfull:
             # most of the gradient is touched by some rank: all-reduce the parameter spans where they lie, no copies
@@ -320,10 +360,42 @@ class StepExchange(object):
                     self._plans.clear()
                 self._plans[key] = ep
             return ep
+        if in_step:
+            # ---- rows, the step builds its own touch plan: its sorted keys exist only after run(). Everything id-dependent
+            # happens in reduce(packed=...), on the device, at FIXED sizes: every rank sends cap = (its looked-up ids) key
+            # slots -- the first key of every run of equal keys, the other slots invalid --, so no count has to be exchanged
+            # or read back. Here: the buffers (a function of the descriptor set alone -> cached under the key).
+            L = ops.lib()
+            M = int(packed.touch_entries)
+            caps = [None] * self.world
+            if self.world > 1:
+                dist.all_gather_object(caps, M, group=self.group)      # (once per key)
+            else:
+                caps = [M]
+            ep.cap = max(max(caps), 1)
+            ep.n_own = M
+            ep.entries = self.world * ep.cap
+            nbytes = L.mpqe_rows_plan_bytes(ep.entries)
+            wbytes = L.mpqe_rows_plan_workspace_bytes(ep.entries, self.row_bits + 5)
+            ep.plan_sizes = (nbytes, wbytes)
+            ep.plan = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.dev)
+            ep.plan_ptr = (ep.plan.data_ptr() + 255) // 256 * 256
+            ep.plan_ws = torch.empty(wbytes + 256, dtype=torch.uint8, device=self.dev)
+            ep.send_keys = torch.full((ep.cap,), -1, dtype=torch.int64, device=self.dev)
+            ep.all_keys = torch.empty(self.world * ep.cap, dtype=torch.int64, device=self.dev)
+            ep.gidx = torch.zeros(ep.cap, dtype=torch.int64, device=self.dev)
+            ep.send = torch.zeros(ep.cap, self.D, dtype=torch.float32, device=self.dev)
+            ep.recv = torch.empty(self.world * ep.cap, self.D, dtype=torch.float32, device=self.dev)
+            ep.wire_bytes += int((w - 1) * ep.cap * (self.D * 4 + 8))
+            if key is not None:
+                if len(self._plans) > 4096:
+                    self._plans.clear()
+                self._plans[key] = ep
+            return ep
         # ---- rows: this rank's distinct keys from its touch plan, all ranks' keys, one plan over all of them
         if packed.touch is None or packed.touch_mode != 'pack':
-            raise ValueError("the row exchange needs a packed step whose touch plan was built by pack(): "
-                             "FusedTrainStep(touch='pack')")
+            raise ValueError("the row exchange needs a packed step whose touch plan was built by pack() "
+                             "(FusedTrainStep(touch='pack')) or by the step itself (touch='step')")
         f.check_touch(packed)
         base = packed.touch_ptr - packed.touch.data_ptr()
         M = packed.touch_entries
@@ -366,8 +438,46 @@ class StepExchange(object):
         only; None with dense tables)."""
         return (ep.plan_ptr, ep.entries) if ep.rows else None
 
-    def reduce(self, ep):
-        """After fused_step.run(packed): every p.grad <- sum over ranks (stream-ordered, no host read)."""
+    def _plan_rows_in_step(self, ep, packed):
+        """Row exchange of a step that built its own touch plan (touch='step'): called AFTER run(packed), stream-ordered,
+        no host read, no object collective. This rank's sorted keys are in the plan buffer the step has just written;
+        the first key of every run goes out (the other slots invalid: fixed size), the keys of all ranks are gathered and
+        every rank sorts them into the same row plan (stable: equal keys stay in rank order)."""
+        from . import _capi, ops
+        if packed is None or packed.touch is None or getattr(packed, 'touch_mode', None) != 'step':
+            raise ValueError("reduce(plan, packed=...): the packed step that has just run (touch='step')")
+        M = int(packed.touch_entries)
+        if M != ep.n_own:
+            raise ValueError('reduce: this packed step has %d looked-up ids, the plan was made for %d' % (M, ep.n_own))
+        base = packed.touch_ptr - packed.touch.data_ptr()
+        keys = packed.touch[base + 256: base + 256 + 8 * M].view(torch.int64)
+        # a failed in-step sort (flagged in the plan's header; the reduction launch also raises MPQE_FLAG_INTERNAL) leaves
+        # garbage keys: rows outside the tables are masked here, the error word says the rest
+        first = torch.ones(M, dtype=torch.bool, device=self.dev)
+        first[1:] = keys[1:] != keys[:-1]
+        tab = keys >> self.row_bits
+        row = keys & ((1 << self.row_bits) - 1)
+        ok = first & (keys != -1) & (tab >= 0) & (tab < len(self.tables))
+        lim = torch.tensor([t.shape[0] for t in self.tables], dtype=torch.int64, device=self.dev)
+        tabc = tab.clamp(0, len(self.tables) - 1)
+        ok = ok & (row < lim[tabc])
+        ep.send_keys.fill_(-1)
+        ep.send_keys[:M] = torch.where(ok, keys, torch.full_like(keys, -1))
+        base_t = torch.tensor(self.row_base, dtype=torch.int64, device=self.dev)
+        ep.gidx.zero_()
+        ep.gidx[:M] = torch.where(ok, base_t[tabc] + row, torch.zeros_like(row))
+        self._all_gather(ep.all_keys, ep.send_keys)
+        L = ops.lib()
+        nbytes, wbytes = ep.plan_sizes
+        with torch.cuda.device(self.dev):
+            st = L.mpqe_rows_plan_build(ep.all_keys.data_ptr(), ep.entries, self.row_bits, self.row_bits + 5, ep.plan_ptr,
+                                        nbytes, (ep.plan_ws.data_ptr() + 255) // 256 * 256, wbytes,
+                                        torch.cuda.current_stream().cuda_stream)
+        _capi.check(L, st, 'mpqe_rows_plan_build')
+
+    def reduce(self, ep, packed=None):
+        """After fused_step.run(packed): every p.grad <- sum over ranks (stream-ordered, no host read). packed: the step
+        that has just run -- needed (only) by the row exchange of a step that builds its own touch plan."""
         from . import _capi, ops
         if ep.form == 'dense':
             for v in ep.grad_views:
@@ -378,7 +488,10 @@ class StepExchange(object):
             torch._foreach_copy_(ep.grad_views, ep.bucket_views)
         if not ep.rows:
             return
-        if ep.n_own:
+        if ep.in_step:
+            self._plan_rows_in_step(ep, packed)
+            torch.index_select(self.tab2d, 0, ep.gidx, out=ep.send)     # (invalid slots: row 0, never summed)
+        elif ep.n_own:
             torch.index_select(self.tab2d, 0, ep.gidx, out=ep.send[:ep.n_own])
         self._all_gather(ep.recv, ep.send)
         L = ops.lib()

@@ -200,3 +200,90 @@ FULL_MIX = [('1-chain', False), ('2-chain', False), ('3-chain', False),
             ('2-inter', False), ('2-inter', True), ('3-inter', False), ('3-inter', True),
             ('3-inter_chain', False), ('3-inter_chain', True),
             ('3-chain_inter', False), ('3-chain_inter', True)]
+
+
+# ----------------------------------------------------------------------------- grounded queries on a real adjacency
+# For end-task runs (tools/train_synthetic.py): queries whose target really answers them on `adj`, negatives that do
+# not. A minimal stand-in for the reference's KG sampler (mpqe/graph.py:227-473, out of scope): one random
+# walk per query, the answer set by following the inverse relations back from the anchors.
+def _answers(adj, formula, anchors):
+    """All entities that answer the query (formula, anchors) on adj."""
+    def back(rel, nodes):          # {x : some y in nodes with y in adj[rel][x]} = union of the inverse lists
+        inv = adj[reverse_relation(rel)]
+        out = set()
+        for y in nodes:
+            out |= inv.get(y, set())
+        return out
+    qt, rels = formula.query_type, formula.rels
+    if qt.endswith('-chain'):
+        s = {anchors[0]}
+        for r in reversed(rels):
+            s = back(r, s)
+        return s, [s]
+    if qt.endswith('-inter'):
+        br = [back(rels[i], {anchors[i]}) for i in range(len(rels))]
+        return set.intersection(*br), br
+    if qt == '3-inter_chain':
+        br = [back(rels[0], {anchors[0]}), back(rels[1][0], back(rels[1][1], {anchors[1]}))]
+        return br[0] & br[1], br
+    v = back(rels[1][0], {anchors[0]}) & back(rels[1][1], {anchors[1]})         # 3-chain_inter
+    s = back(rels[0], v)
+    return s, [s]
+
+
+def sample_grounded_queries(schema, adj, formula, count, rng, n_neg=8, n_hard=4, max_tries=50):
+    """`count` Query objects of `formula` grounded on adj: the target reaches every anchor along the formula's relations;
+    neg_samples = entities of the target mode that are NOT answers; hard_neg_samples (intersection types) = entities
+    that satisfy some branch but not the query (falling back to plain negatives where there are none)."""
+    def nb(rel, x):
+        s = adj[rel].get(int(x))
+        return None if not s else sorted(s)[int(rng.randint(len(s)))]
+    qt, rels = formula.query_type, formula.rels
+    pool = schema.ids[formula.target_mode]
+    out = []
+    for _ in range(count):
+        for _try in range(max_tries):
+            t = int(_pick(schema, formula.target_mode, rng))
+            ok = True
+            if qt.endswith('-chain'):
+                x, vs = t, []
+                for r in rels:
+                    x = nb(r, x)
+                    if x is None:
+                        ok = False
+                        break
+                    vs.append(x)
+                anchors, variables = (vs[-1:] if ok else []), vs[:-1]
+            elif qt.endswith('-inter'):
+                anchors = [nb(r, t) for r in rels]
+                variables = []
+                ok = all(a is not None for a in anchors)
+            elif qt == '3-inter_chain':
+                a0, v = nb(rels[0], t), nb(rels[1][0], t)
+                a1 = nb(rels[1][1], v) if v is not None else None
+                anchors, variables = [a0, a1], [v]
+                ok = a0 is not None and a1 is not None
+            else:
+                v = nb(rels[0], t)
+                a0 = nb(rels[1][0], v) if v is not None else None
+                a1 = nb(rels[1][1], v) if v is not None else None
+                anchors, variables = [a0, a1], [v]
+                ok = a0 is not None and a1 is not None
+            if not ok:
+                continue
+            ans, branches = _answers(adj, formula, anchors)
+            assert t in ans
+            cand = [int(x) for x in pool if int(x) not in ans]
+            if not cand:
+                continue
+            neg = [cand[int(i)] for i in rng.randint(len(cand), size=n_neg)]
+            hard = None
+            if 'inter' in qt:
+                some = set().union(*branches) - ans
+                hc = sorted(some) if some else cand
+                hard = [hc[int(i)] for i in rng.randint(len(hc), size=n_hard)]
+            out.append(Query(query_graph_tuple(formula, t, anchors, variables), neg, hard, keep_graph=True))
+            break
+        else:
+            raise RuntimeError('no grounded query of %s found' % (formula,))
+    return out

@@ -121,10 +121,7 @@ def scatter_mean(src, index, dim_size):
     return scatter_add(src, index, dim_size) / cnt[:, None]
 
 
-def scatter_max(src, index, dim_size):
-    """Returns (values, argmax); argmax = lowest source row attaining the max;
-    rows with no source: value 0 / arg -1. The tie-break is this build's
-    statement -- the reference discards argmax (model.py:384-385)."""
+def _scatter_max_arg(src, index, dim_size):
     idx = index[:, None].expand_as(src)
     val = torch.zeros((dim_size, src.shape[1]), dtype=src.dtype).scatter_reduce(
         0, idx, src, reduce='amax', include_self=False)
@@ -135,6 +132,35 @@ def scatter_max(src, index, dim_size):
         0, idx, cand, reduce='amin', include_self=True)
     arg = torch.where(first < src.shape[0], first, torch.full_like(first, -1))
     return val, arg
+
+
+class _ScatterMax(torch.autograd.Function):
+    """torch_scatter's scatter_max as the reference uses it (model.py:384, 509, 547): the backward routes each output
+    element's gradient to ITS argmax row only (torch_scatter: grad_src = grad_out gathered where arg == row). torch's own
+    scatter_reduce('amax') backward would split the gradient evenly between tied rows instead -- different at exact ties
+    (two nodes with identical states), identical everywhere else."""
+
+    @staticmethod
+    def forward(ctx, src, index, dim_size):
+        val, arg = _scatter_max_arg(src.detach(), index, dim_size)
+        ctx.save_for_backward(arg)
+        ctx.n = src.shape[0]
+        ctx.mark_non_differentiable(arg)
+        return val, arg
+
+    @staticmethod
+    def backward(ctx, gval, _garg):
+        arg, = ctx.saved_tensors
+        g = torch.zeros((ctx.n + 1, gval.shape[1]), dtype=gval.dtype)
+        g.scatter_add_(0, torch.where(arg >= 0, arg, torch.full_like(arg, ctx.n)), gval)
+        return g[:ctx.n], None, None
+
+
+def scatter_max(src, index, dim_size):
+    """Returns (values, argmax); argmax = lowest source row attaining the max;
+    rows with no source: value 0 / arg -1. The tie-break is this build's
+    statement -- the reference discards argmax (model.py:384-385)."""
+    return _ScatterMax.apply(src, index, dim_size)
 
 
 _SCATTER = {'add': scatter_add, 'mean': scatter_mean,

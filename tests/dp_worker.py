@@ -27,9 +27,17 @@ def batches_of(schema, rank, B, scale):
 def main():
     outdir, sparse, tables = sys.argv[1], sys.argv[2] == '1', sys.argv[3]
     readout = sys.argv[4] if len(sys.argv) > 4 else 'mp'
+    touch = sys.argv[5] if len(sys.argv) > 5 else ('pack' if tables == 'rows' else 'step')
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    # MPQE_DP_BACKEND=nccl: one rank per GPU over RCCL (needs `world` visible devices); default: gloo through the host,
+    # every rank on cuda:0 (what a one-GPU box can run)
+    backend = os.environ.get('MPQE_DP_BACKEND', 'gloo')
+    dev = 'cuda:%d' % (rank if backend == 'nccl' else 0)
+    torch.cuda.set_device(torch.device(dev))
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     from mpqe_amd import synthetic
     from mpqe_amd.data_utils import make_feature_modules
     from mpqe_amd.encoders import DirectEncoder
@@ -43,22 +51,29 @@ def main():
     graph = synthetic.SchemaGraph(schema, D)
     fm, node_maps = make_feature_modules(schema.ids, D, schema.num_entities)
     model = RGCNEncoderDecoder(graph, DirectEncoder(None, fm, node_maps), readout=readout, num_layers=3, shared_layers=False,
-                               adaptive=readout != 'concat', weight_decay=1e-3 if readout != 'mp' else 0).to('cuda:0')
+                               adaptive=readout != 'concat', weight_decay=1e-3 if readout != 'mp' else 0).to(dev)
     with torch.no_grad():
         for p in model.layers.parameters():
             p.mul_(4.0)
     # tables = 'rows': the row exchange (plans with the keys of a touch plan built at pack time); 'dense': the tables ride in
     # the all-reduce and the step builds its touch plan itself (the default)
-    step = FusedTrainStep(model, sparse_tables=sparse, touch='pack' if tables == 'rows' else 'step')
+    step = FusedTrainStep(model, sparse_tables=sparse, touch=touch)
     packed = step.pack(batches_of(schema, rank, B, 1.0 / world))
     ex = StepExchange(step, tables=tables)
     plan = ex.plan(packed, key='set0')
-    if tables == 'dense':
-        assert ex.plan(packed, key='set0') is plan          # a recurring key: no collective, the cached plan
+    if tables == 'dense' or touch == 'step':
+        assert ex.plan(packed, key='set0', verify=True) is plan          # a recurring key: the cached plan (verified across ranks)
+        # a key re-used for ANOTHER formula set must be refused, not reduce the wrong matrices
+        other = step.pack(batches_of(schema, rank + 7, B, 1.0 / world))
+        try:
+            ex.plan(other, key='set0')
+            raise SystemExit('a plan key re-used for another descriptor set was accepted')
+        except ValueError:
+            pass
     for p in model.parameters():
         p.grad.fill_(3.0)
     step.run(packed)
-    ex.reduce(plan)
+    ex.reduce(plan, packed=packed)
     step.check()
     torch.cuda.synchronize()
     out = dict(flat=step.flat_grad.cpu().numpy(), wire=np.array([plan.wire_bytes]), dense=np.array([step.flat_grad.numel() * 4]))

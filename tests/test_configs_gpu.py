@@ -14,7 +14,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def build(kg, D, readout, adaptive, seed=0):
+def build(kg, D, readout, adaptive, seed=0, num_layers=3):
     from mpqe_amd import synthetic
     from mpqe_amd.data_utils import make_feature_modules
     from mpqe_amd.encoders import DirectEncoder
@@ -23,7 +23,7 @@ def build(kg, D, readout, adaptive, seed=0):
     schema = synthetic.make_schema(*synthetic.KG_SHAPES[kg], seed=seed)
     graph = synthetic.SchemaGraph(schema, D)
     fm, node_maps = make_feature_modules(schema.ids, D, schema.num_entities)
-    model = RGCNEncoderDecoder(graph, DirectEncoder(None, fm, node_maps), readout=readout, num_layers=3,
+    model = RGCNEncoderDecoder(graph, DirectEncoder(None, fm, node_maps), readout=readout, num_layers=num_layers,
                                shared_layers=False, adaptive=adaptive, weight_decay=0)
     with torch.no_grad():
         for p in model.layers.parameters():
@@ -178,6 +178,7 @@ def drop_near_ties(batches, cpu_params, cfg, node_maps, model, tol=1e-6):
 @pytest.mark.parametrize('kg,D,readout,adaptive,flags', [
     ('aifb', 128, 'mp', True, 'default'), ('aifb', 128, 'mp', True, 'no_prune'), ('aifb', 128, 'mp', True, 'no_uniform'),
     ('aifb', 128, 'mp', True, 'no_chain'),            # configs[1], the benchmarked one, with the speed switches on and off
+    ('aifb', 128, 'mp', True, 'device_ids'),          # ... and packed the way bench.py's timed loop packs: pack(descs, ids=<CUDA tensor>)
     ('mutag', 256, 'sum', False, 'default'),          # configs[2]
     ('am', 128, 'max', False, 'default'),             # configs[3]
     # the learned readouts at the benchmarked shape (level form, the readout inside the call: csrc/step_readout.h)
@@ -206,9 +207,18 @@ def test_benchmarked_workload_against_oracle(kg, D, readout, adaptive, flags):
     if readout == 'max':
         batches, dropped = drop_near_ties(batches, cpu_params, cfg, node_maps, model)
         assert dropped < 0.05 * 11 * 512, dropped       # (a handful of graphs, not a loophole)
-    kw = dict(default={}, no_prune=dict(prune=False), no_uniform=dict(uniform=False), no_chain=dict(chain=False))[flags]
+    kw = dict(default={}, no_prune=dict(prune=False), no_uniform=dict(uniform=False), no_chain=dict(chain=False),
+              device_ids={})[flags]
     step = FusedTrainStep(model, **kw)
-    packed = step.pack(batches)
+    if flags == 'device_ids':
+        # the form the bench times: descriptors (formula, weight, size) + ONE device-resident id tensor in the library's
+        # layout; pack() does no device work, the id -> row lookups and the touch plan happen inside the step
+        ids = torch.from_numpy(step.flatten_ids(batches)).to('cuda:0')
+        descs = [dict(formula=b['formula'], weight=b['weight'], batch_size=len(b['targets'])) for b in batches]
+        packed = step.pack(descs, ids=ids)
+        assert packed.touch_mode == 'step' and packed.ids_ref is ids
+    else:
+        packed = step.pack(batches)
     assert step.uses_chain(packed) == (flags != 'no_chain' and not step.learned)
     loss, sp, sn = step.run(packed, scores=True)
     step.check()
@@ -273,3 +283,102 @@ def test_stress_shape_against_oracle(qt):
             assert int((g.abs().sum(1) > 0).sum().item()) <= len(rows), k
         else:
             np.testing.assert_allclose(g.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+def test_config0_literal_against_oracle():
+    """BASELINE.json configs[0] literally: 1-chain queries, embed_dim 128, readout sum, batch 512, the CLI's default
+    num_layers = 2 (reference train.py:23-33), not adaptive -- fused step against the oracle in the reference's op
+    sequence: scores, loss, every gradient."""
+    from mpqe_amd.fused import FusedTrainStep
+    from oracle import ref_cpu
+    schema, node_maps, model = build('aifb', 128, 'sum', False, num_layers=2)
+    assert len(model.layers) == 2
+    cpu_params = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    model = model.to('cuda:0')
+    b = draw(schema, '1-chain', 512, np.random.RandomState(21))
+    cfg = dict(readout='sum', scatter_op='add', num_layers=2, adaptive=False, weight_decay=0)
+    step = FusedTrainStep(model)
+    packed = step.pack([b])
+    assert step.uses_chain(packed) and int(packed.batches[0].num_passes) == 2
+    loss, sp, sn = step.run(packed, scores=True)
+    step.check()
+    col = ref_cpu.collate(b['formula'], _queries(b), model.rel_ids, model.mode_ids)
+    q = ref_cpu.encode_queries(cpu_params, cfg, node_maps, b['formula'], col)
+    pos = ref_cpu.score(cpu_params, node_maps, b['formula'], q, b['targets'])
+    neg = ref_cpu.score(cpu_params, node_maps, b['formula'], q, b['negs'])
+    np.testing.assert_allclose(sp.cpu().numpy(), pos.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sn.cpu().numpy(), neg.detach().numpy(), rtol=1e-5, atol=1e-6)
+    ref_loss = torch.clamp(1.0 - (pos - neg), min=0).mean()
+    np.testing.assert_allclose(loss[0].item(), ref_loss.item(), rtol=1e-5, atol=1e-6)
+    ref_loss.backward()
+    for k, p in model.named_parameters():
+        ref = cpu_params[k].grad
+        ref = torch.zeros_like(cpu_params[k]) if ref is None else ref
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.parametrize('flags', ['default', 'no_chain'])
+def test_max_readout_exact_ties_at_full_shape(flags):
+    """max readout with CONSTRUCTED exact ties at B = 512, D = 128: both anchors of every 2-inter / 3-inter graph are the
+    SAME entity, so their node states are identical in every column at every level (an anchor's state depends on its own
+    row, root and bias only) and the readout's max is attained twice wherever an anchor wins. torch_scatter routes the
+    gradient to ONE of them (reference model.py:384: scatter_max's argmax); the build's statement is the lowest node row.
+    The oracle's scatter_max has that rule in its backward; graphs with a NEAR tie between different values (the
+    summation order decides there) are taken out of both sides as in the test above -- exact ties stay in."""
+    from mpqe_amd import synthetic
+    from mpqe_amd.fused import FusedTrainStep
+    from oracle import ref_cpu
+    schema, node_maps, model = build('aifb', 128, 'max', False)
+    cpu_params = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    model = model.to('cuda:0')
+    cfg = dict(readout='max', scatter_op='add', num_layers=3, adaptive=False, weight_decay=0)
+    rng = np.random.RandomState(77)
+    batches = []
+    for qt in ('2-inter', '3-inter'):
+        for _ in range(200):
+            f = synthetic.sample_formula(schema, qt, rng)
+            if f.anchor_modes[0] == f.anchor_modes[1]:
+                break
+        assert f.anchor_modes[0] == f.anchor_modes[1], 'no %s formula with two anchors of one mode' % qt
+        anchors = np.stack([synthetic._pick(schema, m, rng, size=512) for m in f.anchor_modes], axis=1)
+        anchors[:, 1] = anchors[:, 0]
+        batches.append(dict(formula=f, anchor_ids=anchors, targets=synthetic._pick(schema, f.target_mode, rng, size=512),
+                            negs=synthetic._pick(schema, f.target_mode, rng, size=512), weight=1.0))
+    torch.set_num_threads(min(16, max(1, len(__import__('os').sched_getaffinity(0)))))
+    kept, ties = [], 0
+    with torch.no_grad():
+        for b in batches:
+            col = ref_cpu.collate(b['formula'], _queries(b), model.rel_ids, model.mode_ids)
+            keep = {}
+            ref_cpu.encode_queries(cpu_params, cfg, node_maps, b['formula'], col, keep=keep)
+            h = keep['layers'][-1].reshape(col['B'], col['N'], -1)
+            assert torch.equal(h[:, 0], h[:, 1])                       # the constructed ties are exact in the oracle
+            top2 = torch.topk(h, 2, dim=1).values
+            gap = top2[:, 0] - top2[:, 1]
+            near = ((gap > 0) & (gap <= 1e-6)).any(dim=1).numpy()      # different values, too close: dropped
+            ties += int(((gap == 0).any(dim=1).numpy() & ~near).sum())
+            kept.append(sub(b, np.nonzero(~near)[0]))
+    assert ties > 900, ties                                            # (nearly every graph has a tied column)
+    step = FusedTrainStep(model, chain=flags != 'no_chain')
+    packed = step.pack(kept)
+    loss, sp, sn = step.run(packed, scores=True)
+    step.check()
+    sp, sn, loss = sp.cpu().numpy(), sn.cpu().numpy(), loss.cpu().numpy()
+    total, off = 0, 0
+    assert packed.order == list(range(len(kept)))
+    for i, b in enumerate(kept):
+        n = len(b['targets'])
+        col = ref_cpu.collate(b['formula'], _queries(b), model.rel_ids, model.mode_ids)
+        q = ref_cpu.encode_queries(cpu_params, cfg, node_maps, b['formula'], col)
+        pos = ref_cpu.score(cpu_params, node_maps, b['formula'], q, b['targets'])
+        neg = ref_cpu.score(cpu_params, node_maps, b['formula'], q, b['negs'])
+        np.testing.assert_allclose(sp[off:off + n], pos.detach().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(sn[off:off + n], neg.detach().numpy(), rtol=1e-5, atol=1e-6)
+        total = total + torch.clamp(1.0 - (pos - neg), min=0).mean()
+        off += n
+    np.testing.assert_allclose(loss[0], total.item(), rtol=1e-5, atol=1e-6)
+    total.backward()
+    for k, p in model.named_parameters():
+        ref = cpu_params[k].grad
+        ref = torch.zeros_like(cpu_params[k]) if ref is None else ref
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-6, err_msg=k)

@@ -22,16 +22,36 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize('sparse,tables,readout', [(0, 'rows', 'mp'), (1, 'rows', 'mp'), (0, 'dense', 'mp'),
-                                                   (0, 'dense', 'targetmlp'), (0, 'dense', 'concat')])
-def test_two_ranks_equal_single_process(tmp_path, sparse, tables, readout):
+def _gpus():
+    import torch
+    return torch.cuda.device_count()          # (counting devices does not initialise the GPU: children may still be started)
+
+
+CASES = [(0, 'rows', 'mp', 'pack'), (1, 'rows', 'mp', 'pack'), (0, 'rows', 'mp', 'step'), (1, 'rows', 'mp', 'step'),
+         (0, 'dense', 'mp', 'step'), (0, 'dense', 'targetmlp', 'step'), (0, 'dense', 'concat', 'step')]
+
+
+@pytest.mark.parametrize('sparse,tables,readout,touch', CASES)
+def test_two_ranks_equal_single_process(tmp_path, sparse, tables, readout, touch):
+    _two_ranks(tmp_path, sparse, tables, readout, touch, 'gloo')
+
+
+@pytest.mark.skipif(_gpus() < 2, reason='RCCL needs one GPU per rank: fewer than 2 GPUs visible on this box')
+@pytest.mark.parametrize('sparse,tables,readout,touch', [CASES[1], CASES[3], CASES[4]])
+def test_two_ranks_equal_single_process_rccl(tmp_path, sparse, tables, readout, touch):
+    """The same over RCCL (backend 'nccl' on ROCm), one rank per GPU: dist.all_reduce / all_gather_into_tensor on device
+    buffers (parallel.py: _all_reduce / _all_gather). Collected everywhere, runs the moment two GPUs are visible."""
+    _two_ranks(tmp_path, sparse, tables, readout, touch, 'nccl')
+
+
+def _two_ranks(tmp_path, sparse, tables, readout, touch, backend):
     world, port = 2, _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY='0')
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'dp_worker.py'), str(tmp_path), str(sparse), tables, readout],
-                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+                   HSA_ENABLE_IPC_MODE_LEGACY='0', MPQE_DP_BACKEND=backend)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'dp_worker.py'), str(tmp_path), str(sparse), tables,
+                                       readout, touch], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
@@ -58,7 +78,13 @@ def test_two_ranks_equal_single_process(tmp_path, sparse, tables, readout):
     assert str(r[0]['form'][0]) == str(r[1]['form'][0])
 
 
-def test_bench_gpus_flag_starts_its_ranks():
+@pytest.mark.skipif(_gpus() < 2, reason='RCCL needs one GPU per rank: fewer than 2 GPUs visible on this box')
+def test_bench_two_gpus_rccl():
+    """`python bench.py --gpus 2` over RCCL, one rank per GPU, exactly as the driver's scaling run starts it."""
+    test_bench_gpus_flag_starts_its_ranks(backend='nccl')
+
+
+def test_bench_gpus_flag_starts_its_ranks(backend='gloo'):
     """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (a child torch.distributed.run,
     before the parent touches the GPU) and report n_gpus = 2 with the exchange record; here over gloo, both ranks on the
     one GPU of the box (RCCL refuses two ranks on one device)."""
@@ -66,7 +92,7 @@ def test_bench_gpus_flag_starts_its_ranks():
     root = os.path.dirname(HERE)
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
-    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2',
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', backend, '--steps', '2',
                         '--warmup', '1', '--repeats', '1', '--no-cpu-baseline', '--no-scatter'], env=env, cwd=root,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
