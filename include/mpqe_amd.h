@@ -50,6 +50,11 @@ extern "C" {
 #define MPQE_FLAG_BAD_EDGE 2         /* edge endpoint outside [0, num_nodes)           */
 #define MPQE_FLAG_BAD_RELATION 4     /* edge type outside [0, num_relations)           */
 #define MPQE_FLAG_BAD_INDEX 8        /* scatter index outside [0, dim_size)            */
+#define MPQE_FLAG_TOUCH_RETRY 32     /* the step could not build its own touch plan (MPQE_STEP_BUILD_TOUCH: the sort's
+                                        workgroups were not all resident at once, e.g. on a shared GPU). Everything but
+                                        the entity-table gradients is complete; those were NOT accumulated (dense: the
+                                        step's zero fill stands; SPARSE_TABLES: the rows are untouched). Recover with
+                                        mpqe_step_touch_build (MPQE_STEP_TOUCH_LIBRARY_SORT) + mpqe_step_table_rows.  */
 #define MPQE_FLAG_INTERNAL 16        /* a hand-off between workgroups inside a launch did
                                         not arrive within its spin bound (library fault);
                                         bits 8.. say which (diagnostics: 0x100 a pre-pass
@@ -75,7 +80,8 @@ enum { MPQE_SCATTER_ADD = 0, MPQE_SCATTER_MAX = 1, MPQE_SCATTER_MEAN = 2 };
 #define MPQE_MAX_TEMPLATE_NODES 4
 
 const char *mpqe_status_string(int status);
-/* 4: mpqe_step_params_t / mpqe_step_grads_t carry the learned readouts' Linear layers (readout_*); mpqe_step_states_layout,
+/* 5: MPQE_FLAG_TOUCH_RETRY, MPQE_STEP_TOUCH_LIBRARY_SORT, mpqe_step_table_rows (a failed in-step touch plan is recovered, not
+ * fatal). 4: mpqe_step_params_t / mpqe_step_grads_t carry the learned readouts' Linear layers (readout_*); mpqe_step_states_layout,
  * MPQE_READOUT_CALLER and the MPQE_STEP_PHASE_* values of `backward`. 3: mpqe_linear_*, mpqe_debug_option, touch = OUT. */
 int mpqe_abi_version(void);
 
@@ -325,6 +331,10 @@ int mpqe_hinge_bwd(const float *pos, const float *neg, int64_t n, float margin, 
  *             (the reference's `concat` readout, model.py:441-446) and has written its d loss / d state into every row of
  *             those gradient levels, not only the final one: the backward adds the gradient it propagates to them.  */
 #define MPQE_STEP_ADD_STATE_GRADS 1024
+/* TOUCH_LIBRARY_SORT  (mpqe_step_touch_build only) build the plan with the library's multi-launch radix sort instead of
+ *             the one-launch sort whose workgroups synchronise among themselves: slower, and independent of how many
+ *             workgroups the device can hold at once -- the recovery path behind MPQE_FLAG_TOUCH_RETRY.          */
+#define MPQE_STEP_TOUCH_LIBRARY_SORT 2048
 
 typedef struct {
     int32_t query_type;        /* MPQE_Q_*                                                     */
@@ -456,6 +466,17 @@ int mpqe_step_forward_backward(const mpqe_step_params_t *params_host, const mpqe
                                void *touch /* mpqe_step_touch_build's buffer (read), the plan buffer to fill (MPQE_STEP_BUILD_TOUCH), or
                                               NULL */, void *stream);
 
+/* The entity-table part of a step's reduction again, from a plan built AFTER the step ran: sums the per-entry gradient
+ * rows the step left in `workspace` (its chain launch writes them whatever happens to the plan) per destination row in
+ * plan order into grads->tables -- written where the step would have written them (MPQE_STEP_ZERO_GRADS or
+ * MPQE_STEP_SPARSE_TABLES in params->flags), added otherwise. For a step that reported MPQE_FLAG_TOUCH_RETRY: same
+ * params / batches / desc / workspace as that call (nothing else may have run in the workspace since), `touch` from
+ * mpqe_step_touch_build on the same ids. Chain form only. The reference's embedding backward cannot fail
+ * (encoders.py:40-43 + autograd); this is what makes the in-step plan equally safe.                            */
+int mpqe_step_table_rows(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host, int num_batches,
+                         const mpqe_step_grads_t *grads_host, const void *desc, void *workspace, size_t workspace_bytes,
+                         const void *touch, void *stream);
+
 /* Ids of the next step from pinned host memory to the device on `stream` (hipMemcpyAsync; stream-ordered, returns at
  * once): the reference moves its index tensors with .to(device) per call (utils.py:17-23). For host mirrors without a
  * HIP binding of their own.                                                                          */
@@ -522,7 +543,8 @@ void mpqe_debug_chain_stamps(void *device_buffer, size_t num_blocks);
  * K-step has landed [5] and when its K loop ends [6].                                                */
 void mpqe_debug_tail_stamps(void *device_buffer, size_t num_blocks);
 /* Named diagnostics switches (timing experiments; tests that force a rarely taken path, e.g. "TOUCH_ROCPRIM" = the
- * library sort instead of the one-launch sort, "GEN_SLOTS" = grid size of the persistent gather-GEMMs). set != 0
+ * library sort instead of the one-launch sort, "TSORT_FAIL" = the in-step sort gives up as if its workgroups were not
+ * co-resident, "GEN_SLOTS" = grid size of the persistent gather-GEMMs). set != 0
  * stores `value` under `name`, set == 0 removes it. Process-global (see Conventions).                    */
 void mpqe_debug_option(const char *name, int value, int set);
 

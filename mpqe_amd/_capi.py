@@ -123,6 +123,7 @@ PROTOTYPES = {
     'mpqe_rows_plan_build': (I, [P, L, I, I, P, Z, P, Z, P]),
     'mpqe_table_rows_sum': (I, [P, L, P, L, ctypes.POINTER(c_void_p), I, I, P]),
     'mpqe_step_touch_build': (I, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, P, P, P, P, Z, P, Z, P]),
+    'mpqe_step_table_rows': (I, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, ctypes.POINTER(StepGrads), P, P, Z, P, P]),
 }
 
 QUERY_TYPE_IDS = {'1-chain': 0, '2-chain': 1, '3-chain': 2, '2-inter': 3, '3-inter': 4,
@@ -134,6 +135,7 @@ LEARNED_READOUT_IDS = {'mlp': 4, 'targetmlp': 5, 'concat': 6}      # fused step 
 SCATTER_IDS = {'add': 0, 'max': 1, 'mean': 2}
 
 FLAG_BAD_NODE_ID, FLAG_BAD_EDGE, FLAG_BAD_RELATION, FLAG_BAD_INDEX = 1, 2, 4, 8
+FLAG_INTERNAL, FLAG_TOUCH_RETRY = 16, 32
 
 
 def bind(cdll):
@@ -167,6 +169,7 @@ STEP_MERGE_TAIL = 128
 STEP_SPLIT_TAIL = 256
 STEP_BUILD_TOUCH = 512
 STEP_ADD_STATE_GRADS = 1024
+STEP_TOUCH_LIBRARY_SORT = 2048
 # `backward` values of the step in three calls around the caller's readout (learned readouts; include/mpqe_amd.h)
 STEP_PHASE_STATES, STEP_PHASE_SCORES, STEP_PHASE_FROM_STATES, STEP_PHASE_SCORES_ONLY = 2, 3, 4, 5
 TSORT_MAX_ENTRIES = 256 * 2048        # csrc/step_touch.h: the in-step touch plan covers this many looked-up ids

@@ -1004,7 +1004,7 @@ __device__ __forceinline__ void reduce_block(const ReduceArgs &ra, int bx, int b
         // for that launch instead of 16.6; here they cost 2.6 us.)
         table_sum_block(ra.touch_M, ra.touch_row_bits, reinterpret_cast<const tkey_t *>(touch + ra.touch_keys),
                         reinterpret_cast<const int *>(touch + ra.touch_perm), ra.DG, D, ra.tabs, table_store & 1,
-                        (long long)(by - ngroups - 1) * gx + bx);
+                        (long long)(by - ngroups - 1) * gx + bx, &reinterpret_cast<const TouchHeader *>(touch)->pad[0]);
         return;
     }
     // fused tail: what follows reads what tiles / vector ops of THIS launch wrote (slabs and the post-pass' last vectors and
@@ -1045,8 +1045,9 @@ __device__ __forceinline__ void reduce_block(const ReduceArgs &ra, int bx, int b
                 if (table_store & 2) *(epoch_b + 32) = *(epoch_b + 32) + 1u;      // merged launch: its own epoch (DoneMeta)
                 *(epoch_b + 24) = 0u;       // the grid barrier of the next step's in-launch sort starts from zero (step_touch.h)
             }
-            // a touch plan whose build could not finish (its workgroups were not all resident: step_touch.h)
-            if (touch && threadIdx.x == 0 && reinterpret_cast<const TouchHeader *>(touch)->pad[0]) flag_error(ra.err, MPQE_FLAG_INTERNAL | 0x2000);
+            // a touch plan whose build could not finish (its workgroups were not all resident: step_touch.h): the table rows
+            // above stored nothing; the caller rebuilds the plan and sums them again (mpqe_step_table_rows)
+            if (touch && threadIdx.x == 0 && reinterpret_cast<const TouchHeader *>(touch)->pad[0]) flag_error(ra.err, MPQE_FLAG_TOUCH_RETRY);
             if (ra.lm.chain) loss_block_chain(ra.lm, ra.bterms, ra.loss, reinterpret_cast<float *>(part), 4);
             else loss_block(ra.sd, ra.terms, ra.loss, reinterpret_cast<float *>(part), 4);
         }
@@ -2529,7 +2530,7 @@ void make_key(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
               PlanKey *k) {
     memset(k, 0, sizeof(*k));
     k->dim = P->dim; k->num_layers = P->num_layers; k->num_relations = P->num_relations;
-    k->num_modes = P->num_modes; k->readout = P->readout; k->flags = P->flags & ~(MPQE_STEP_ZERO_GRADS | MPQE_STEP_NO_KSPLIT | MPQE_STEP_EIGHT_WAVES | MPQE_STEP_ADD_STATE_GRADS); k->nb = nb;
+    k->num_modes = P->num_modes; k->readout = P->readout; k->flags = P->flags & ~(MPQE_STEP_ZERO_GRADS | MPQE_STEP_NO_KSPLIT | MPQE_STEP_EIGHT_WAVES | MPQE_STEP_ADD_STATE_GRADS | MPQE_STEP_TOUCH_LIBRARY_SORT); k->nb = nb;
     k->nlanes = lanes ? lanes->num_lanes : 1;
     for (int m = 0; m < P->num_modes && m < MPQE_STEP_MAX_MODES; ++m) k->table_rows[m] = P->table_rows[m];
     if (lanes)
@@ -2714,7 +2715,7 @@ extern "C" int mpqe_step_touch_build(const mpqe_step_params_t *P, const mpqe_ste
     th.row_bits = rb;
     th.key_bits = kb;
     static_assert(sizeof(TouchMeta) <= 2048, "touch_layout reserves 2 KB for the batch table");
-    if (M <= TSORT_MAX_ENTRIES && kb <= 31 && !dbg_on("TOUCH_ROCPRIM")) {
+    if (M <= TSORT_MAX_ENTRIES && kb <= 31 && !dbg_on("TOUCH_ROCPRIM") && !(P->flags & MPQE_STEP_TOUCH_LIBRARY_SORT)) {
         // the whole plan in one launch (step_touch.h: tsort_block) behind the clear of its barrier counter and the
         // upload of the batch table
         const int nblk = tsort_blocks(M);
@@ -2874,6 +2875,51 @@ extern "C" int mpqe_table_rows_sum(const void *plan, int64_t n, const float *row
     const long long per = 256 / (dim / 4);
     hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)((n + per - 1) / per)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const char *>(plan), L.keys, L.perm, rows, (int)dim, tabs, store);
+    return mpqe_launch_status();
+}
+
+// The entity-table rows of a step's reduction again (include/mpqe_amd.h): a step whose own touch plan could not be built
+// (MPQE_FLAG_TOUCH_RETRY) left every entry's gradient row in its workspace; `touch` is a plan built afterwards.
+__global__ __launch_bounds__(256) void step_table_rows_kernel(const char *__restrict__ touch, size_t o_keys, size_t o_perm,
+                                                              long long M, int row_bits, const float *__restrict__ DG, int D,
+                                                              TablePtrs tabs, int store) {
+    table_sum_block(M, row_bits, reinterpret_cast<const tkey_t *>(touch + o_keys), reinterpret_cast<const int *>(touch + o_perm),
+                    DG, D, tabs, store, (long long)blockIdx.x, &reinterpret_cast<const TouchHeader *>(touch)->pad[0]);
+}
+extern "C" int mpqe_step_table_rows(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, const mpqe_step_grads_t *G,
+                                    const void *desc, void *workspace, size_t workspace_bytes, const void *touch, void *stream) {
+    if (!P || !B || !G || !desc || !workspace || !touch || nb < 1 || nb > MPQE_STEP_MAX_BATCHES) return MPQE_ERR_INVALID_ARG;
+    if ((uintptr_t)touch % 256 != 0 || (uintptr_t)workspace % 256 != 0) return MPQE_ERR_INVALID_ARG;
+    std::shared_ptr<const CachedPlan> cached;
+    {
+        PlanKey key;
+        make_key(P, B, nb, nullptr, &key);
+        key.chain = want_chain(P, B, nb) ? 1 : 0;
+        std::lock_guard<std::mutex> lock(g_plan_mu);
+        auto it = g_plans.find(const_cast<void *>(desc));
+        if (it != g_plans.end() && memcmp(&it->second->key, &key, sizeof(key)) == 0) cached = it->second;
+    }
+    if (!cached) return MPQE_ERR_INVALID_ARG;           // (not the descriptor buffer of a step that has run with these descriptors)
+    const HostPlan &hp = cached->hp;
+    if (!hp.chain || hp.touch_M <= 0) return MPQE_ERR_UNSUPPORTED;
+    if (workspace_bytes < hp.total) return MPQE_ERR_WORKSPACE;
+    const int D = P->dim;
+    if (D % 4 != 0 || 256 % (D / 4) != 0) return MPQE_ERR_UNSUPPORTED;
+    long long trows = 1;
+    TablePtrs tabs;
+    memset(&tabs, 0, sizeof(tabs));
+    for (int m = 0; m < P->num_modes; ++m) {
+        trows = std::max(trows, (long long)P->table_rows[m]);
+        tabs.grad[m] = G->tables[m];
+        tabs.rows[m] = P->table_rows[m];
+        if (G->tables[m] && (uintptr_t)G->tables[m] % 16 != 0) return MPQE_ERR_INVALID_ARG;
+    }
+    const TouchLayout TL = touch_layout(hp.touch_M, 0);
+    const long long per = 256 / (D / 4);
+    const int store = ((P->flags & MPQE_STEP_SPARSE_TABLES) || (P->flags & MPQE_STEP_ZERO_GRADS)) ? 1 : 0;
+    hipLaunchKernelGGL(step_table_rows_kernel, dim3((unsigned)((hp.touch_M + per - 1) / per)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const char *>(touch), TL.keys, TL.perm, (long long)hp.touch_M, touch_bits(trows),
+                       reinterpret_cast<const float *>(reinterpret_cast<const char *>(workspace) + hp.o_DG), D, tabs, store);
     return mpqe_launch_status();
 }
 
@@ -3163,6 +3209,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                 ts.row_bits = hp.ts_row_bits;
                 ts.nblk = hp.ts_blocks;
                 ts.rounds = tsort_rounds(hp.touch_M);
+                ts.fail = dbg_on("TSORT_FAIL") ? 1 : 0;
                 ts.stamps = nullptr;
                 if (dbg_on("TSORT_TRAIL")) pa.strail = hp.ts_blocks;
                 else {

@@ -195,6 +195,7 @@ struct TSortArgs {
     TouchHeader *th_out;
     int M, key_bits, row_bits, nblk;
     int rounds;                         // entries per thread (tsort_rounds)
+    int fail;                           // diagnostics ("TSORT_FAIL"): give up at once, as a sort whose workgroups are not co-resident does
     long long *stamps;                  // diagnostics (mpqe_debug_chain_stamps): 8 words per sort workgroup, or NULL
 };
 #ifndef MPQE_EMU
@@ -228,6 +229,18 @@ __device__ __forceinline__ void tsort_block(const TSortArgs &sa, int b, unsigned
     unsigned short(*whist)[256] = reinterpret_cast<unsigned short(*)[256]>(smem);
     unsigned *gbase = smem + TSORT_ROUNDS * 4 * 256 / 2, *scan = gbase + 256, *ok = scan + 256;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nblk = sa.nblk, M = sa.M;
+    if (sa.fail) {         // (uniform; the plan's arrays stay as they are: garbage that nobody may use)
+        if (b == 0 && t == 0) {
+            TouchHeader th;
+            memset(&th, 0, sizeof(th));
+            th.M = M;
+            th.row_bits = sa.row_bits;
+            th.key_bits = sa.key_bits;
+            th.pad[0] = 1;
+            *sa.th_out = th;
+        }
+        return;
+    }
     // the batch table through LDS: touch_key_of walks it per entry (from memory that was five dependent round trips in
     // front of the first id load -- 9 to 16 us next to running chain workgroups)
     static_assert(sizeof(TouchMeta) <= TSORT_META_WORDS * 4 && sizeof(TouchMeta) % 4 == 0, "TSORT_META_WORDS");
@@ -375,6 +388,16 @@ __device__ __forceinline__ void tsort_block(const TSortArgs &sa, int b, unsigned
 __device__ __forceinline__ void tsort_block(const TSortArgs &sa, int b, unsigned *) {
     if (b != 0 || threadIdx.x != 0) return;
     const int M = sa.M;
+    if (sa.fail) {
+        TouchHeader th;
+        memset(&th, 0, sizeof(th));
+        th.M = M;
+        th.row_bits = sa.row_bits;
+        th.key_bits = sa.key_bits;
+        th.pad[0] = 1;
+        *sa.th_out = th;
+        return;
+    }
     std::vector<std::pair<tkey_t, int>> e((size_t)M);
     for (int i = 0; i < M; ++i) {
         int er;
@@ -411,29 +434,35 @@ __global__ __launch_bounds__(TSORT_THREADS) void touch_sort_kernel(TSortArgs sa)
 // data-parallel row exchange, mpqe_table_rows_sum, in gathered order); NULL: DG[k].
 // (M, row_bits: the plan header's fields, by value where the caller knows them -- the fused step does: one round trip less
 // in front of the keys)
+// failed != NULL: a word that is non-zero when the plan could not be built (the header's pad[0] of a plan the step built
+// itself: step.hip) -- nothing is stored then; the word travels with the first keys, and every permutation entry is
+// clamped into [0, M), so a garbage plan costs wrong loads at valid addresses and no store at all.
 template <class TabsT>
 __device__ __forceinline__ void table_sum_block(long long M, int row_bits, const tkey_t *__restrict__ keys,
                                                 const int *__restrict__ perm, const float *__restrict__ DG, int D,
-                                                const TabsT &tabs, int store, long long block) {
+                                                const TabsT &tabs, int store, long long block,
+                                                const int *__restrict__ failed = nullptr) {
     const int lpr = D / 4, per = 256 / lpr;          // positions per workgroup (D = 64 / 128 / 256: 16 / 8 / 4)
     const long long k = block * per + threadIdx.x / lpr;
     const int c = (threadIdx.x % lpr) * 4;
     if (k >= M) return;
+    const int bad = failed ? *failed : 0;
+    auto inside = [M](long long p) { return p < 0 ? 0ll : (p >= M ? M - 1 : p); };
     // ONE round trip for everything that depends on k alone: my key, my predecessor's, and the keys / permutation entries of
     // the next TS_AHEAD positions (a run is ~8 rows long on the AIFB step); a second one for the rows. (Requested one after
     // the other -- key, then permutation entry, then row, then the next keys ... -- a run cost five dependent round trips.)
     const tkey_t key = keys[k];
     const tkey_t prev = k > 0 ? keys[k - 1] : TOUCH_INVALID;
-    const long long p0 = perm ? (long long)perm[k] : k;
+    const long long p0 = perm ? inside((long long)perm[k]) : k;
     tkey_t kk[TS_AHEAD];
     long long pj[TS_AHEAD];
 #pragma unroll
     for (int q = 0; q < TS_AHEAD; ++q) {
         const long long j = k + 1 + q < M ? k + 1 + q : M - 1;
         kk[q] = keys[j];
-        pj[q] = perm ? (long long)perm[j] : j;
+        pj[q] = perm ? inside((long long)perm[j]) : j;
     }
-    if (key == TOUCH_INVALID || (k > 0 && prev == key)) return;
+    if (bad || key == TOUCH_INVALID || (k > 0 && prev == key)) return;
     f32x4 acc = gload4(DG + p0 * D + c);
     {
         f32x4 v[TS_AHEAD];
@@ -456,7 +485,7 @@ __device__ __forceinline__ void table_sum_block(long long M, int row_bits, const
                 for (int q = 0; q < TS_AHEAD; ++q) {
                     const long long j = j0 + q < M ? j0 + q : M - 1;
                     k2[q] = keys[j];
-                    p2[q] = perm ? (long long)perm[j] : j;
+                    p2[q] = perm ? inside((long long)perm[j]) : j;
                 }
                 f32x4 w[TS_AHEAD];
 #pragma unroll

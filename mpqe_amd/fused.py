@@ -196,6 +196,9 @@ class FusedTrainStep(object):
         self.err = ops.new_error_word(self.device)
         self._ws = None
         self._desc_cache, self._size_cache, self._pool = {}, {}, {}
+        # descriptor sets whose in-step touch plan failed once (run(checked=True)): their plans are built by pack() from then on
+        self._pack_touch_sets = set()
+        self.touch_retries = 0
         self.num_lanes = max(1, min(int(lanes), _capi.STEP_MAX_LANES))
         self._streams = [None] + [torch.cuda.Stream(device=self.device) for _ in range(self.num_lanes - 1)]
         self._fork = torch.cuda.Event()
@@ -387,6 +390,8 @@ class FusedTrainStep(object):
         mode = self.touch_mode
         if mode == 'step' and (not chain or na + 2 * ngr > _capi.TSORT_MAX_ENTRIES):
             mode = 'pack'
+        if mode == 'step' and self._pack_touch_sets and (bytes(SB), tuple(lane_begin)) in self._pack_touch_sets:
+            mode = 'pack'
         ps.touch_mode = mode
         ps.step_flags = _capi.STEP_BUILD_TOUCH if mode == 'step' else 0
         skey = (bytes(SB), tuple(lane_begin), mode)
@@ -493,12 +498,14 @@ class FusedTrainStep(object):
                 t1 = time.perf_counter(); prof['touch plan'] = prof.get('touch plan', 0.0) + t1 - t0
         return ps
 
-    def build_touch(self, ps):
+    def build_touch(self, ps, library_sort=False):
         """The touch plan of the packed step's ids (include/mpqe_amd.h: mpqe_step_touch_build): which looked-up
         entities share a table row, sorted once here, so that the step adds their gradient rows in a fixed order
         instead of with float atomics. Stream-ordered on the current stream, no synchronisation. Call it again
-        after refilling ps.anchor_ids / targets / negs in place with new ids."""
+        after refilling ps.anchor_ids / targets / negs in place with new ids. library_sort: the multi-launch library
+        sort, which does not depend on how many workgroups the device holds at once (the recovery path)."""
         L = ops.lib()
+        self.P.flags = self.flags | (_capi.STEP_TOUCH_LIBRARY_SORT if library_sort else 0)
         nbytes, wbytes = ps.touch_sizes
         if nbytes == 0:
             raise _capi.MpqeError('mpqe_step_touch_bytes rejected the step descriptors')
@@ -559,13 +566,21 @@ class FusedTrainStep(object):
             self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
         return (self._ws.data_ptr() + 255) // 256 * 256
 
-    def run(self, packed, backward=True, zero_grad=True, scores=False, events=None, workspace=None):
+    def run(self, packed, backward=True, zero_grad=True, scores=False, events=None, workspace=None, checked=False):
         """Returns loss [1 + nb] on the device: loss[0] = weighted step loss, loss[1 + i] = mean hinge
         of library batch i = the caller's batch packed.order[i] (identity with one lane); scores come
         back in the same library order. With backward=True every p.grad then holds d loss[0] / d p
         (accumulated on top of the previous content unless zero_grad). workspace: a uint8 tensor of at
         least packed.ws_bytes + 256 bytes to run in instead of the step object's shared arena (a
-        captured graph owns its arena: see capture())."""
+        captured graph owns its arena: see capture()).
+        checked: read the error word before returning (ONE 4-byte device-to-host read: the call then waits for the
+        step) -- the gradients are then known to be whole before an optimiser can consume them. A step that could not
+        build its own touch plan (MPQE_FLAG_TOUCH_RETRY: the sort's workgroups were not all resident at once, e.g. on
+        a GPU shared with another process; the reference's embedding backward, encoders.py:40-43, has no such failure
+        mode) is RECOVERED here: the plan is rebuilt with the library sort, the entity-table rows are summed again
+        from the per-entry rows the step left in its workspace (mpqe_step_table_rows), and this descriptor set takes
+        pack-time plans from then on; a bad id raises IndexError, a timed-out hand-off RuntimeError, as check() does
+        -- but now, not a step later."""
         if backward:
             self.bind_grads()
         # the library zero-fills the gradient buffers itself (one launch with its other prologue work)
@@ -598,6 +613,21 @@ class FusedTrainStep(object):
             st = L.mpqe_step_forward_backward(*args)
         _capi.check(L, st, 'mpqe_step_forward_backward')
         bufs.desc_resident = True
+        if checked:
+            flags = int(self.err.item())                  # (synchronises)
+            if flags & _capi.FLAG_TOUCH_RETRY and backward and packed.touch_ptr is not None:
+                self.err.fill_(flags & ~_capi.FLAG_TOUCH_RETRY)
+                self.touch_retries += 1
+                self._pack_touch_sets.add((bytes(packed.batches), tuple(packed.lane_begin)))
+                self.build_touch(packed, library_sort=True)
+                self.P.flags = self.flags | packed.step_flags | (_capi.STEP_ZERO_GRADS if zero_grad else 0)
+                with torch.cuda.device(self.device):
+                    st = L.mpqe_step_table_rows(ctypes.byref(self.P), packed.batches, packed.nb, ctypes.byref(self.G),
+                                                packed.desc_ptr, wptr, packed.ws_bytes, packed.touch_ptr, stream.cuda_stream)
+                _capi.check(L, st, 'mpqe_step_table_rows')
+                flags &= ~_capi.FLAG_TOUCH_RETRY
+            if flags:
+                ops.raise_on_flags(self.err)
         if packed.ids_ref is bufs.stage and bufs.stage is not None and not packed.captured:
             if bufs.last_use is None:
                 bufs.last_use = torch.cuda.Event()

@@ -66,6 +66,10 @@ def raise_on_flags(err):
                                       (0x1000, 'the fused tail\'s arrivals'), (0x2000, 'the touch plan\'s sort')) if flags & bit]
             raise RuntimeError('mpqe_amd: an in-launch hand-off between workgroups timed out (library fault): '
                                + (', '.join(sites) or 'unknown site'))
+        if flags & 32:
+            raise RuntimeError('mpqe_amd: a step could not build its own touch plan (the sort\'s workgroups were not all '
+                               'resident at once -- a shared GPU?) and its entity-table gradients were NOT accumulated; '
+                               'FusedTrainStep.run(..., checked=True) rebuilds the plan and recovers them')
         raise IndexError('mpqe_amd: ' + '; '.join(names))
 
 

@@ -151,6 +151,47 @@ def test_fused_step_bad_id_is_reported():
         step.check()
 
 
+@pytest.mark.parametrize('sparse', [False, True])
+def test_checked_run_recovers_a_failed_in_step_touch_plan(sparse):
+    """FusedTrainStep.run(checked=True): a step whose own touch plan could not be built (forced: TSORT_FAIL) is recovered
+    before the call returns -- plan rebuilt with the library sort, entity-table rows summed again -- and its descriptor set
+    takes pack-time plans from then on; without `checked` the failure is named at check(), never silently consumed."""
+    from mpqe_amd import ops
+    from mpqe_amd.fused import FusedTrainStep
+    model, batches = _setup('mp', True, False, D=64, B=96)
+    step = FusedTrainStep(model, sparse_tables=sparse)
+    packed = step.pack(batches)
+    assert packed.touch_mode == 'step'
+    step.run(packed)
+    step.check()
+    good = {k: p.grad.clone() for k, p in model.named_parameters()}
+    lib = ops.lib()
+    lib.mpqe_debug_option(b'TSORT_FAIL', 1, 1)
+    try:
+        for p in model.parameters():
+            p.grad.fill_(5.0)
+        step.run(packed)
+        with pytest.raises(RuntimeError, match='touch plan'):
+            step.check()
+        for p in model.parameters():
+            p.grad.fill_(5.0)
+        loss = step.run(packed, checked=True)
+        assert step.touch_retries == 1
+        step.check()
+    finally:
+        lib.mpqe_debug_option(b'TSORT_FAIL', 0, 0)
+    for k, p in model.named_parameters():
+        if sparse and k.startswith('enc.'):
+            touched = good[k].ne(5.0).any(dim=1) | p.grad.ne(5.0).any(dim=1)
+            assert torch.equal(p.grad[touched], good[k][touched]), k
+            assert bool((p.grad[~touched] == 5.0).all()), k
+        else:
+            assert torch.equal(p.grad, good[k]), k
+    assert step.pack(batches).touch_mode == 'pack'           # this descriptor set no longer relies on the in-step sort
+    other = step.pack(batches[:3])
+    assert other.touch_mode == 'step'
+
+
 @pytest.mark.parametrize('opt,readout', [('adam', 'mp'), ('sgd', 'mp'), ('sgd', 'targetmlp'), ('adam', 'mlp')])
 def test_training_loop_fused_step_plus_flat_optimizer(opt, readout):
     """Three training steps: FusedTrainStep + FlatOptimizer (one launch over the flat parameter buffer)

@@ -77,7 +77,7 @@ def oracle_step(params, cfg, node_map, batches, margin):
 
 
 def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=1, lanes=None, flags=0, touch='step', repeat=1,
-             plan_out=None, between=None):
+             plan_out=None, between=None, recover=False, before_recovery=None):
     """between: the step in three calls around the CALLER's readout (MPQE_READOUT_CALLER, MPQE_STEP_PHASE_*): a generator
     function -- between(final_states) yields the query embeddings [graphs, D], is sent their gradients and yields d loss /
     d final states per batch; final_states[i]: batch i's [B N, D]. touch: 'step' = the step builds the touch plan of its ids itself (MPQE_STEP_BUILD_TOUCH, the product's default),
@@ -251,6 +251,22 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
                                                    be.ptr(d_ng), margin, ctypes.byref(G), backward, be.ptr(loss),
                                                    be.ptr(sp), be.ptr(sn), dptr, dsb, 1 if rep == 0 else 0, wptr, wsb,
                                                    be.ptr(err), lanes, None, 0, tptr, be.stream), 'step')
+    if recover and (int(be.get(err)[0]) & _capi.FLAG_TOUCH_RETRY):
+        # the step could not build its own touch plan: everything but the entity-table gradients is complete. Rebuild the plan
+        # with the library sort and sum the table rows again from the per-entry rows the step left in its workspace.
+        if before_recovery is not None:
+            before_recovery({m: np.asarray(be.get(g)).copy() for m, g in zip(modes, gtabs)})
+        P.flags |= _capi.STEP_TOUCH_LIBRARY_SORT
+        be.check(be.lib.mpqe_step_touch_build(ctypes.byref(P), SB, nb, be.ptr(d_anchor), be.ptr(d_tg), be.ptr(d_ng), tptr, tb,
+                                              (be.ptr(twbuf) + 255) // 256 * 256, twb, be.stream), 'touch rebuild')
+        P.flags &= ~_capi.STEP_TOUCH_LIBRARY_SORT
+        be.check(be.lib.mpqe_step_table_rows(ctypes.byref(P), SB, nb, ctypes.byref(G), dptr, wptr, wsb, tptr, be.stream), 'table rows')
+        e = np.asarray(be.get(err)).copy()
+        e[0] &= ~_capi.FLAG_TOUCH_RETRY
+        if be.name == 'emu':
+            err[:] = e
+        else:
+            err.copy_(be.put(e))
     if plan_out is not None and touch:
         raw = np.asarray(be.get(tbuf)).view(np.uint8)
         off = tptr - be.ptr(tbuf)
@@ -298,6 +314,45 @@ def test_fused_step_matches_oracle(be, readout, adaptive, shared, L, mix):
         seen.add(id(p))
         ref = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
         np.testing.assert_allclose(grads[k], ref, rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.parametrize('zero', [True, False])
+def test_failed_in_step_touch_plan_is_recovered(be, request, zero):
+    """The step builds the touch plan of its ids by workgroups that must all be resident at once (step_touch.h); on a GPU
+    shared with other work that can fail -- a failure mode the reference does not have (its embedding backward is plain
+    autograd, encoders.py:40-43). Forced here (mpqe_debug_option TSORT_FAIL): the step must flag MPQE_FLAG_TOUCH_RETRY and
+    nothing else, leave the entity-table gradients unaccumulated (never garbage), deliver every other gradient, and after
+    mpqe_step_touch_build (library sort) + mpqe_step_table_rows every gradient must be the oracle's."""
+    D, margin = 64, 1.0
+    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(23, D, 3, False, MIXES['all7'], 'mp', True)
+    ref_loss, ref_per, ref_sp, ref_sn = oracle_step(params, cfg, node_map, batches, margin)
+    be.lib.mpqe_debug_option(b'TSORT_FAIL', 1, 1)
+    request.addfinalizer(lambda: be.lib.mpqe_debug_option(b'TSORT_FAIL', 0, 0))
+    flags = _capi.STEP_ZERO_GRADS if zero else 0
+    # without recovery: the flag, and table gradients that are exactly what the caller / the zero fill left there
+    loss, sp, sn, grads, err = run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, flags=flags)
+    assert err == _capi.FLAG_TOUCH_RETRY
+    np.testing.assert_allclose(loss[0], ref_loss, rtol=1e-5, atol=1e-6)
+    for k, p in params.items():
+        ref = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
+        if k.startswith('enc.'):
+            assert not grads[k].any(), k          # (run_step's buffers start from zero / are zero-filled by the step)
+        else:
+            np.testing.assert_allclose(grads[k], ref, rtol=1e-4, atol=2e-6, err_msg=k)
+    seen = {}
+    loss, sp, sn, grads, err = run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, flags=flags, recover=True,
+                                        before_recovery=lambda t: seen.update(t))
+    assert err == 0 and seen
+    np.testing.assert_allclose(sp, ref_sp, rtol=1e-5, atol=1e-6)
+    for k, p in params.items():
+        ref = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
+        np.testing.assert_allclose(grads[k], ref, rtol=1e-4, atol=2e-6, err_msg=k)
+    # the recovered gradients are the ones an undisturbed step delivers, bit for bit (same plan, same order of additions)
+    be.lib.mpqe_debug_option(b'TSORT_FAIL', 0, 0)
+    _, _, _, good, err = run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, flags=flags)
+    assert err == 0
+    for k in grads:
+        np.testing.assert_array_equal(grads[k], good[k], err_msg=k)
 
 
 @pytest.mark.parametrize('readout,adaptive,shared,zero', [('mlp', True, False, True), ('targetmlp', False, True, False),
