@@ -23,6 +23,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // never reads the environment.
 int mpqe_dbg_value(const char *name, int unset);
 static inline bool dbg_on(const char *name) { return mpqe_dbg_value(name, 0) != 0; }
+int mpqe_dbg_generation();       // bumped by every mpqe_debug_option call (plan caches key on it)
 
 // Host-side copy of the template tables (reference data_utils.py:325-362).
 struct TemplateDesc {

@@ -13,6 +13,7 @@
 
 namespace {
 std::atomic<int> g_any(0);
+std::atomic<int> g_gen(0);
 std::mutex g_mu;
 std::unordered_map<std::string, int> g_opts;
 }  // namespace
@@ -24,9 +25,13 @@ int mpqe_dbg_value(const char *name, int unset) {
     return it == g_opts.end() ? unset : it->second;
 }
 
+// changes with every mpqe_debug_option call: cached launch plans that a switch may have shaped are keyed by it
+int mpqe_dbg_generation() { return g_gen.load(std::memory_order_relaxed); }
+
 extern "C" void mpqe_debug_option(const char *name, int value, int set) {
     if (!name) return;
     std::lock_guard<std::mutex> lock(g_mu);
+    g_gen.fetch_add(1, std::memory_order_relaxed);
     if (set) g_opts[name] = value;
     else g_opts.erase(name);
     g_any.store(g_opts.empty() ? 0 : 1, std::memory_order_relaxed);

@@ -21,6 +21,7 @@
 // Arithmetic is identical to the per-op kernels (same tile bodies, rgcn_template_body.h);
 // margin_loss's two encoder passes are one here (the query embedding does not depend on the
 // target).
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -253,6 +254,7 @@ __device__ __forceinline__ float *pick_grad(float *const *arr, int li) {
 
 #include "step_chain.h"
 #include "step_uniform.h"
+#include "step_closure.h"
 #include "step_touch.h"
 #include "grad_w_reg.h"
 #include "step_readout.h"
@@ -1193,6 +1195,8 @@ struct TailArgs {
     int D;                   // = sd->D, by value: a tile's record is then the first and only load in front of its rows
     int tile_n;              // columns per weight-gradient tile
     int ux;                  // > 0: XCDs set aside for the post-pass' vector ops (step_tail_kernel)
+    ClosureArgs ca;          // ca.ncl > 0: the post-pass as closures (step_closure.h) -- the launch's FIRST ncl workgroups, padded
+    int clpad;               // to clpad (a multiple of 8: tile b keeps XCD b % 8); ublocks is 0 then
 
     const long long *node_map;
     long long map_len;
@@ -1310,7 +1314,24 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
     // tiles the others (workgroup b runs on XCD b % 8) -- the vector ops are a latency chain of small loads and polls, the
     // tiles stream ~40 MB through their XCDs' L2s and fabric ports
     int ub = -1, tb;
-    if (ta.ux > 0) {
+    if (ta.ca.ncl > 0) {       // the post-pass as closures: the launch's first workgroups, one per batch (step_closure.h)
+        if ((int)blockIdx.x < ta.clpad) {
+            if ((int)blockIdx.x < ta.ca.ncl) {
+#ifndef MPQE_EMU
+                __builtin_amdgcn_s_setprio(3);      // a latency chain next to throughput work
+#endif
+                closure_block((int)blockIdx.x, ta.D, ta.ca, lp, ua, smem, gp, zeroed);
+#ifndef MPQE_EMU
+                if (ta.stamps && threadIdx.x == 0) {
+                    ta.stamps[(long long)blockIdx.x * 8 + 5] = (long long)wall_clock64();       // (word 1 stays 0: not a tile)
+                    ta.stamps[(long long)blockIdx.x * 8 + 6] = 1 + 5;                           // kind 5: a closure
+                }
+#endif
+            }
+            return;
+        }
+        tb = (int)blockIdx.x - ta.clpad;
+    } else if (ta.ux > 0) {
         const int x = (int)blockIdx.x & 7, r = (int)blockIdx.x >> 3, tx = 8 - ta.ux;
         if (x >= tx) {
             ub = r * ta.ux + (x - tx);
@@ -1395,6 +1416,11 @@ struct HostPlan {
     // batch-uniform node states: vector ops of the forward pre-pass / backward post-pass, rank-1 weight-gradient terms
     bool chain, uniform;
     std::vector<UOp> uops_f, uops_b;
+    // split tail launch: the backward post-pass as one closure workgroup per batch (step_closure.h); empty: the vector-op form
+    std::vector<UOp> uops_c;
+    std::vector<Closure> closures;
+    std::vector<ClItemRec> citems;
+    size_t o_uopc, o_closures, o_citems;
     std::vector<Rank1> rank1;
     int nvec, ngran;
     size_t o_uopf, o_uopb, o_rank1, o_epoch, o_gran, o_VT, o_DG;
@@ -2124,6 +2150,162 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                 if (hp->uops_f[k].out_vec >= 0) hp->uops_f[k].out_gran = gran_of[hp->uops_f[k].out_vec];
             for (size_t k = 0; k < hp->uops_b.size(); ++k)          // (a rank-1 op writes a matrix, not a vector: out_vec = -1)
                 if (hp->uops_b[k].out_vec >= 0) hp->uops_b[k].out_gran = gran_of[hp->uops_b[k].out_vec];
+            // ---- the same post-pass as CLOSURES (step_closure.h): per batch ONE workgroup runs its ops in dependence order,
+            // vectors handed on through LDS slots. Only where the post-pass is a launch's own role -- the split tail launch
+            // (the merged launch and the fused tail keep the vector-op form: their ops wait for other workgroups anyway).
+            hp->uops_c.clear();
+            hp->closures.clear();
+            hp->citems.clear();
+            long long blk_total = 0;
+            for (int i = 0; i < nb; ++i) blk_total += (sd.b[i].B + CH_GB - 1) / CH_GB;
+            const bool will_merge = hp->nlanes == 1 && !(P->flags & MPQE_STEP_SPLIT_TAIL) &&
+                                    ((P->flags & MPQE_STEP_MERGE_TAIL) || blk_total <= STEP_CUS + STEP_CUS / 8);
+            if (!will_merge && hp->nlanes == 1 && !dbg_on("NO_CLOSURE") && !dbg_on("FUSE_TAIL")) {
+                bool ok = true;
+                std::vector<UOp> all;
+                std::vector<Closure> cls;
+                std::vector<ClItemRec> items;
+                std::vector<RGroup> moved;               // rank-1-only matrices whose terms span batches: reduction groups
+                // the R1 ops of uops_b are its last r1_only.size() entries, in r1_only's order
+                const size_t r1_first = hp->uops_b.size() - r1_only.size();
+                std::vector<char> r1_taken(r1_only.size(), 0);
+                for (int i = 0; i < nb && ok; ++i) {
+                    std::vector<UOp> pre, body;
+                    std::unordered_map<int, int> slot_of_vec, slot_of_part;
+                    int nslots = 0;
+                    auto part_slot = [&](int row0, int nrows) -> int {      // the column sum of rows [row0, row0 + nrows) of `parts`
+                        auto it = slot_of_part.find(row0);
+                        if (it != slot_of_part.end()) return it->second;
+                        UOp op;
+                        memset(&op, 0, sizeof(op));
+                        op.kind = UOP_RED;
+                        op.out_vec = op.out_part = op.mask_vec = -1;
+                        op.in_kind[0] = 3;
+                        op.row0 = row0;
+                        op.nrows = nrows;
+                        op.out_gran = nslots++;
+                        pre.push_back(op);
+                        slot_of_part[row0] = op.out_gran;
+                        return op.out_gran;
+                    };
+                    auto vt_slot = [&](int v) -> int {                      // a copy of VT row v (a pre-pass vector)
+                        auto it = slot_of_vec.find(v);
+                        if (it != slot_of_vec.end()) return it->second;
+                        UOp op;
+                        memset(&op, 0, sizeof(op));
+                        op.kind = UOP_RED;
+                        op.out_vec = op.out_part = op.mask_vec = -1;
+                        op.in_kind[0] = 2;
+                        op.in_vec[0] = v;
+                        op.nrows = 1;
+                        op.out_gran = nslots++;
+                        pre.push_back(op);
+                        slot_of_vec[v] = op.out_gran;
+                        return op.out_gran;
+                    };
+                    // the batch's column-sum vectors somebody reads (UOP_RED of the vector-op form): slot + VT row
+                    for (size_t k = 0; k < r1_first; ++k) {
+                        const UOp &o = hp->uops_b[k];
+                        if (o.kind != UOP_RED || vinfo[o.out_vec].batch != i) continue;
+                        const int sl = part_slot(o.row0, o.nrows);
+                        for (size_t q = 0; q < pre.size(); ++q)
+                            if (pre[q].out_gran == sl) pre[q].out_vec = o.out_vec;
+                        slot_of_vec[o.out_vec] = sl;
+                    }
+                    auto rewrite_in = [&](UOp &op, int t) {
+                        if (op.in_kind[t] == 3) op.in_gran[t] = part_slot(op.in_vec[t], op.in_gran[t]);
+                        else if (op.in_kind[t] == 0) {
+                            auto it = slot_of_vec.find(op.in_vec[t]);
+                            if (it == slot_of_vec.end()) { ok = false; return; }      // (its producer is not of this batch: cannot be)
+                            op.in_gran[t] = it->second;
+                        } else { ok = false; return; }
+                        op.in_kind[t] = UOP_IN_LDS;
+                    };
+                    for (size_t k = 0; k < r1_first && ok; ++k) {          // BWD ops: level L-1 down to 0 (uops_b's order)
+                        UOp op = hp->uops_b[k];
+                        if (op.kind != UOP_BWD || vinfo[op.out_vec].batch != i) continue;
+                        for (int t = 0; t < op.nterms; ++t) rewrite_in(op, t);
+                        if (op.mask_vec >= 0) op.mask_vec = vt_slot(op.mask_vec);      // (closure ops: the LDS slot of its copy)
+                        op.out_gran = nslots++;
+                        slot_of_vec[op.out_vec] = op.out_gran;
+                        op.wait_mask = 0;
+                        body.push_back(op);
+                    }
+                    for (size_t k = 0; k < r1_only.size() && ok; ++k) {   // rank-1-only matrices all of whose terms are this batch's
+                        UOp op = hp->uops_b[r1_first + k];
+                        bool mine = true, any = false;
+                        for (int t = 0; t < op.nterms; ++t) {
+                            const int bt = vinfo[hp->rank1[r1_only[k].r1_start + t].v].batch;
+                            mine = mine && bt == i;
+                            any = any || bt == i;
+                        }
+                        if (!mine) {
+                            if (any && !r1_taken[k]) {
+                                r1_taken[k] = 2;
+                                moved.push_back(r1_only[k]);
+                            }
+                            continue;
+                        }
+                        r1_taken[k] = 1;
+                        for (int t = 0; t < op.nterms && ok; ++t) {
+                            rewrite_in(op, t);
+                            op.mat[t] = vt_slot(op.u_vec[t]);                // (R1 ops have no matrix: the u vector's slot)
+                        }
+                        op.wait_mask = 0;
+                        body.push_back(op);
+                    }
+                    if (nslots > CL_MAX_SLOTS) ok = false;
+                    if (!ok || (pre.empty() && body.empty())) continue;
+                    Closure c;
+                    c.first = (int)all.size();
+                    c.npre = (int)pre.size();
+                    c.count = (int)(pre.size() + body.size());
+                    c.pad = 0;
+                    c.item_first = (int)items.size();
+                    for (size_t q = 0; q < body.size(); ++q) {             // the BWD ops' items: (op, chunk, term)
+                        const UOp &op = body[q];
+                        if (op.kind != UOP_BWD) continue;
+                        for (int ch = 0; ch < D / 64; ++ch)
+                            for (int t = 0; t < op.nterms; ++t) {
+                                ClItemRec r;
+                                memset(&r, 0, sizeof(r));
+                                r.layer = op.layer[t];
+                                r.mat = op.mat[t];
+                                r.chunk = ch;
+                                r.flags = (t == 0 ? CLI_FIRST : 0) | (t == op.nterms - 1 ? CLI_LAST : 0) |
+                                          (t == op.nterms - 1 && ch == D / 64 - 1 ? CLI_OPEND : 0);
+                                r.in_slot = op.in_gran[t];
+                                r.out_slot = op.out_gran;
+                                r.out_vec = op.out_vec;
+                                r.out_part = op.out_part;
+                                r.mask_slot = op.mask_vec;          // (rewritten to the LDS slot of its copy: below)
+                                items.push_back(r);
+                            }
+                    }
+                    c.nitems = (int)items.size() - c.item_first;
+                    if (c.nitems > CL_MAX_ITEMS) ok = false;
+                    all.insert(all.end(), pre.begin(), pre.end());
+                    all.insert(all.end(), body.begin(), body.end());
+                    cls.push_back(c);
+                }
+                for (size_t k = 0; k < r1_only.size(); ++k) ok = ok && r1_taken[k] != 0;
+                if (ok && !cls.empty()) {
+                    // heaviest closures first: they start first
+                    std::stable_sort(cls.begin(), cls.end(), [&](const Closure &a, const Closure &b) {
+                        auto terms = [&](const Closure &c) {
+                            int n = 0;
+                            for (int k = c.first + c.npre; k < c.first + c.count; ++k)
+                                if (all[k].kind == UOP_BWD) n += all[k].nterms;
+                            return n;
+                        };
+                        return terms(a) > terms(b);
+                    });
+                    hp->uops_c.swap(all);
+                    hp->closures.swap(cls);
+                    hp->citems.swap(items);
+                    hp->groups.insert(hp->groups.end(), moved.begin(), moved.end());
+                }
+            }
         }
     }
     hp->nvec = (int)vinfo.size();
@@ -2376,6 +2558,9 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     }
     hp->o_uopf = take(hp->uops_f.size() * sizeof(UOp));
     hp->o_uopb = take(hp->uops_b.size() * sizeof(UOp));
+    hp->o_uopc = take(hp->uops_c.size() * sizeof(UOp));
+    hp->o_closures = take(hp->closures.size() * sizeof(Closure));
+    hp->o_citems = take(hp->citems.size() * sizeof(ClItemRec));
     hp->o_rank1 = take(hp->rank1.size() * sizeof(Rank1));
     hp->o_done_inc = take(hp->done_inc.size() * sizeof(int));
     TouchMeta tmeta;
@@ -2475,6 +2660,9 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         put(hp->o_zmats, hp->zmats.data(), hp->zmats.size() * sizeof(ZMat));
         put(hp->o_uopf, hp->uops_f.data(), hp->uops_f.size() * sizeof(UOp));
         put(hp->o_uopb, hp->uops_b.data(), hp->uops_b.size() * sizeof(UOp));
+        put(hp->o_uopc, hp->uops_c.data(), hp->uops_c.size() * sizeof(UOp));
+        put(hp->o_closures, hp->closures.data(), hp->closures.size() * sizeof(Closure));
+        put(hp->o_citems, hp->citems.data(), hp->citems.size() * sizeof(ClItemRec));
         put(hp->o_rank1, hp->rank1.data(), hp->rank1.size() * sizeof(Rank1));
         put(hp->o_done_inc, hp->done_inc.data(), hp->done_inc.size() * sizeof(int));
         if (hp->ts_blocks) put(hp->o_tmeta, &tmeta, sizeof(tmeta));
@@ -2485,6 +2673,23 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     // in-step sort: (key, entry) ping-pong buffers [4][blocks x 1024] + digit counts [4 passes][blocks][256]
     hp->o_tsort = take(hp->ts_blocks ? (size_t)hp->ts_blocks * (4 * (size_t)TSORT_THREADS * tsort_rounds(hp->touch_M) + 4 * 256) * sizeof(unsigned) : 0);
     hp->total = off;
+    if (dbg_on("DUMP_PLAN")) {        // diagnostics: what the step's launches consist of
+        fprintf(stderr, "plan: chain %d uniform %d blocks %d | tile sources %zu tiles %d slabs %d | groups %zu | uops f %zu b %zu | closures %zu ops %zu | rank1 %zu | zmats %zu | touch M %lld\n",
+                (int)chain, (int)hp->uniform, hp->blk_off[nb], hp->wsrc.size(), hp->wblocks_total, hp->total_slabs, hp->groups.size(),
+                hp->uops_f.size(), hp->uops_b.size(), hp->closures.size(), hp->uops_c.size(), hp->rank1.size(), hp->zmats.size(), hp->touch_M);
+        for (size_t k = 0; k < hp->groups.size(); ++k)
+            fprintf(stderr, "  group %zu kind %d layer %d row %lld slabs/rows %d rank1 %d\n", k, hp->groups[k].kind, hp->groups[k].layer,
+                    hp->groups[k].row, hp->groups[k].count, hp->groups[k].r1_count);
+        for (size_t k = 0; k < hp->closures.size(); ++k) {
+            const Closure &c = hp->closures[k];
+            int terms = 0, r1 = 0, bw = 0;
+            for (int q = c.first + c.npre; q < c.first + c.count; ++q) {
+                if (hp->uops_c[q].kind == UOP_BWD) { terms += hp->uops_c[q].nterms; ++bw; }
+                else ++r1;
+            }
+            fprintf(stderr, "  closure %zu pre %d bwd ops %d terms %d r1 ops %d\n", k, c.npre, bw, terms, r1);
+        }
+    }
     return MPQE_OK;
 }
 
@@ -2512,6 +2717,7 @@ int plan_auto(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
 // Everything make_plan() reads, field by field (struct padding never takes part in the comparison).
 struct PlanKey {
     int dim, num_layers, num_relations, num_modes, readout, flags, nb, nlanes, chain;
+    int dbg_gen;                              // diagnostics switches may shape a plan (TILE_N, NO_CLOSURE, ...): their generation
     int lane_begin[MPQE_STEP_MAX_LANES + 1];
     int alias[MPQE_STEP_MAX_LAYERS];          // first layer with the same parameter buffers
     long long table_rows[MPQE_STEP_MAX_MODES];      // (the in-step touch plan's key widths and batch table)
@@ -2532,6 +2738,7 @@ void make_key(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     k->dim = P->dim; k->num_layers = P->num_layers; k->num_relations = P->num_relations;
     k->num_modes = P->num_modes; k->readout = P->readout; k->flags = P->flags & ~(MPQE_STEP_ZERO_GRADS | MPQE_STEP_NO_KSPLIT | MPQE_STEP_EIGHT_WAVES | MPQE_STEP_ADD_STATE_GRADS | MPQE_STEP_TOUCH_LIBRARY_SORT); k->nb = nb;
     k->nlanes = lanes ? lanes->num_lanes : 1;
+    k->dbg_gen = mpqe_dbg_generation();
     for (int m = 0; m < P->num_modes && m < MPQE_STEP_MAX_MODES; ++m) k->table_rows[m] = P->table_rows[m];
     if (lanes)
         for (int l = 0; l <= MPQE_STEP_MAX_LANES; ++l) k->lane_begin[l] = lanes->batch_begin[l];
@@ -2975,7 +3182,14 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         std::lock_guard<std::mutex> lock(g_plan_mu);
         auto it = g_plans.find(desc);
         if (it != g_plans.end() && memcmp(&it->second->key, &key, sizeof(key)) == 0) cached = it->second;
-        else if (it != g_plans.end() && !upload_desc) return MPQE_ERR_INVALID_ARG;   // desc holds another step's table
+        else if (it != g_plans.end() && !upload_desc) {
+            // desc holds another step's table -- unless only the diagnostics switches changed since it was planned: then the
+            // same step is planned again and its table uploaded again by this call
+            PlanKey old = it->second->key;
+            old.dbg_gen = key.dbg_gen;
+            if (memcmp(&old, &key, sizeof(key)) != 0) return MPQE_ERR_INVALID_ARG;
+            upload_desc = 1;
+        }
         if (!cached && g_recent && memcmp(&g_recent->key, &key, sizeof(key)) == 0) {
             // (the size queries of this packed step have just built it)
             if (g_plans.size() >= 1024) g_plans.clear();      // plans in use stay alive through their shared_ptr
@@ -3269,6 +3483,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     ta.D = D;
     ta.tile_n = hp.tile_n;
     ta.ux = 0;
+    memset(&ta.ca, 0, sizeof(ta.ca));
+    ta.clpad = 0;
     ta.node_map = nm;
     ta.map_len = (long long)P->node_map_len;
     ta.anchor_ids = ids;
@@ -3330,6 +3546,16 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         if (first == 0 && (P->flags & MPQE_STEP_ZERO_GRADS)) tl.zblocks = (int)hp.zmats.size() * ta.zper;
         if (first == 0) tl.ublocks = ub.nops * ub.chunks;
         int nblocks = tl.ublocks + count + tl.zblocks;
+        const bool closures = use_chain && first == 0 && !hp.closures.empty() && !fuse_tail;
+        if (closures) {
+            tl.ublocks = 0;
+            tl.ca.cl = reinterpret_cast<const Closure *>(db + hp.o_closures);
+            tl.ca.ops = reinterpret_cast<const UOp *>(db + hp.o_uopc);
+            tl.ca.items = reinterpret_cast<const ClItemRec *>(db + hp.o_citems);
+            tl.ca.ncl = (int)hp.closures.size();
+            tl.clpad = (tl.ca.ncl + 7) / 8 * 8;
+            nblocks = tl.clpad + count + tl.zblocks;
+        } else
         {
             // chain form: two of the eight XCDs for the post-pass' vector ops, six for the tiles (AIFB step, same box,
             // three runs each: 64.95 / 65.15 / 65.04 us against 65.70 / 65.60 / 65.47 with both kinds everywhere; one

@@ -162,6 +162,8 @@ def test_checked_run_recovers_a_failed_in_step_touch_plan(sparse):
     step = FusedTrainStep(model, sparse_tables=sparse)
     packed = step.pack(batches)
     assert packed.touch_mode == 'step'
+    for p in model.parameters():
+        p.grad.fill_(5.0)                    # (row-sparse tables: rows no id touches keep what they hold)
     step.run(packed)
     step.check()
     good = {k: p.grad.clone() for k, p in model.named_parameters()}

@@ -74,7 +74,9 @@ def _two_ranks(tmp_path, sparse, tables, readout, touch, backend):
         assert (tab0[~touched] == 0).all() and (tab1[~touched] == 0).all()
     if tables == 'rows':
         np.testing.assert_array_equal(r[0]['union_keys'], r[1]['union_keys'])
-    assert r[0]['wire'][0] <= r[0]['dense'][0], (r[0]['wire'], r[0]['dense'])   # (tiny KG, 8 relations: most are in the union)
+    if not (tables == 'rows' and touch == 'step'):      # (in-step plans send fixed-size key / row slots: one per looked-up id --
+        # more than this 60-entity KG's whole tables; the sizes it is for have 10^5 .. 10^6 rows)
+        assert r[0]['wire'][0] <= r[0]['dense'][0], (r[0]['wire'], r[0]['dense'])   # (tiny KG, 8 relations: most are in the union)
     assert str(r[0]['form'][0]) == str(r[1]['form'][0])
 
 

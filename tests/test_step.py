@@ -316,6 +316,31 @@ def test_fused_step_matches_oracle(be, readout, adaptive, shared, L, mix):
         np.testing.assert_allclose(grads[k], ref, rtol=1e-4, atol=2e-6, err_msg=k)
 
 
+@pytest.mark.parametrize('D,readout,adaptive', [(128, 'mp', True), (64, 'mp', True), (128, 'sum', False)])
+def test_post_pass_closures_match_oracle(be, request, D, readout, adaptive):
+    """The backward post-pass of the batch-uniform node states as one closure workgroup per batch (split tail launch,
+    csrc/step_closure.h) against the oracle and against the vector-op form it replaces (mpqe_debug_option NO_CLOSURE):
+    batches of more than 8 x 16 graphs, so that a column sum has more rows than the closure has row groups (its order
+    of additions then differs from the vector ops': same values within rounding), every chain depth, ragged sizes."""
+    mix = [('3-chain', 200, 1.0), ('2-chain', 150, 0.5), ('3-inter_chain', 40, 0.25), ('3-chain_inter', 33, 2.0),
+           ('3-chain', 17, 0.3)]
+    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(29, D, 3, False, mix, readout, adaptive)
+    ref_loss, ref_per, ref_sp, ref_sn = oracle_step(params, cfg, node_map, batches, 1.0)
+    for zero in (True, False):
+        flags = _capi.STEP_SPLIT_TAIL | (_capi.STEP_ZERO_GRADS if zero else 0)
+        got = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=flags, repeat=2 if zero else 1)
+        assert got[4] == 0
+        np.testing.assert_allclose(got[0][0], ref_loss, rtol=1e-5, atol=1e-6)
+        for k, p in params.items():
+            ref = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
+            np.testing.assert_allclose(got[3][k], ref, rtol=1e-4, atol=2e-6, err_msg=k)
+    be.lib.mpqe_debug_option(b'NO_CLOSURE', 1, 1)
+    request.addfinalizer(lambda: be.lib.mpqe_debug_option(b'NO_CLOSURE', 0, 0))
+    old = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_SPLIT_TAIL)
+    for k in got[3]:
+        np.testing.assert_allclose(got[3][k], old[3][k], rtol=1e-5, atol=1e-7, err_msg=k)
+
+
 @pytest.mark.parametrize('zero', [True, False])
 def test_failed_in_step_touch_plan_is_recovered(be, request, zero):
     """The step builds the touch plan of its ids by workgroups that must all be resident at once (step_touch.h); on a GPU
@@ -516,13 +541,14 @@ def test_fused_step_chain_kernels(be, D, readout, adaptive, shared, L):
     if every or readout == 'mp':
         # Where the weight-gradient tiles + post-pass run. A step this small takes the MERGED launch by default (workgroups
         # of the chain launch: include/mpqe_amd.h MPQE_STEP_MERGE_TAIL); the benchmarked step is larger and takes the
-        # SPLIT form (a launch of their own) -- forced here: same gradients bit for bit. Then the merged form forced, three
+        # SPLIT form (a launch of their own, the post-pass as closures: step_closure.h) -- forced here: the same gradients
+        # (other kernels for the batch-uniform part: equal within rounding, not bit for bit). Then the merged form forced, three
         # runs on one descriptor buffer -- the later runs' counters start from the earlier ones' (targets are epoch x
         # count) -- with the call's own zero fill (the whole-root rule).
         split = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_SPLIT_TAIL)
         runs.append(split)
         for k in got[3]:
-            np.testing.assert_array_equal(split[3][k], got[3][k], err_msg=k)
+            np.testing.assert_allclose(split[3][k], got[3][k], rtol=1e-5, atol=1e-7, err_msg=k)
         runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0,
                              flags=_capi.STEP_SPLIT_TAIL | _capi.STEP_ZERO_GRADS, repeat=2))
         runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0,
