@@ -1320,7 +1320,7 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
 #ifndef MPQE_EMU
                 __builtin_amdgcn_s_setprio(3);      // a latency chain next to throughput work
 #endif
-                closure_block((int)blockIdx.x, ta.D, ta.ca, lp, ua, smem, gp, zeroed);
+                closure_block((int)blockIdx.x, ta.D, ta.ca, lp, ua, smem, gp, zeroed, ta.stamps ? ta.stamps + (long long)blockIdx.x * 8 : nullptr);
 #ifndef MPQE_EMU
                 if (ta.stamps && threadIdx.x == 0) {
                     ta.stamps[(long long)blockIdx.x * 8 + 5] = (long long)wall_clock64();       // (word 1 stays 0: not a tile)
@@ -1417,10 +1417,8 @@ struct HostPlan {
     bool chain, uniform;
     std::vector<UOp> uops_f, uops_b;
     // split tail launch: the backward post-pass as one closure workgroup per batch (step_closure.h); empty: the vector-op form
-    std::vector<UOp> uops_c;
-    std::vector<Closure> closures;
-    std::vector<ClItemRec> citems;
-    size_t o_uopc, o_closures, o_citems;
+    std::vector<ClBlock> closures;
+    size_t o_closures;
     std::vector<Rank1> rank1;
     int nvec, ngran;
     size_t o_uopf, o_uopb, o_rank1, o_epoch, o_gran, o_VT, o_DG;
@@ -2153,86 +2151,145 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
             // ---- the same post-pass as CLOSURES (step_closure.h): per batch ONE workgroup runs its ops in dependence order,
             // vectors handed on through LDS slots. Only where the post-pass is a launch's own role -- the split tail launch
             // (the merged launch and the fused tail keep the vector-op form: their ops wait for other workgroups anyway).
-            hp->uops_c.clear();
             hp->closures.clear();
-            hp->citems.clear();
             long long blk_total = 0;
             for (int i = 0; i < nb; ++i) blk_total += (sd.b[i].B + CH_GB - 1) / CH_GB;
             const bool will_merge = hp->nlanes == 1 && !(P->flags & MPQE_STEP_SPLIT_TAIL) &&
                                     ((P->flags & MPQE_STEP_MERGE_TAIL) || blk_total <= STEP_CUS + STEP_CUS / 8);
-            if (!will_merge && hp->nlanes == 1 && !dbg_on("NO_CLOSURE") && !dbg_on("FUSE_TAIL")) {
+            // Measured on the AIFB step (profiles/r04_*): NOT faster yet -- a closure is one wave per SIMD working through
+            // dependent LDS / scalar reads: ~1 us per item, the 3-chain batch's closure 21 - 30 us against 15.4 for the
+            // vector-op form's last op -- so it is built only on request (mpqe_debug_option CLOSURE = 1).
+            if (!will_merge && hp->nlanes == 1 && dbg_on("CLOSURE") && !dbg_on("FUSE_TAIL")) {
                 bool ok = true;
-                std::vector<UOp> all;
-                std::vector<Closure> cls;
-                std::vector<ClItemRec> items;
+                std::vector<ClBlock> cls;
                 std::vector<RGroup> moved;               // rank-1-only matrices whose terms span batches: reduction groups
                 // the R1 ops of uops_b are its last r1_only.size() entries, in r1_only's order
                 const size_t r1_first = hp->uops_b.size() - r1_only.size();
                 std::vector<char> r1_taken(r1_only.size(), 0);
                 for (int i = 0; i < nb && ok; ++i) {
-                    std::vector<UOp> pre, body;
+                    ClBlock cb;
+                    memset(&cb, 0, sizeof(cb));
+                    cb.batch = i;
                     std::unordered_map<int, int> slot_of_vec, slot_of_part;
                     int nslots = 0;
+                    auto add_pre = [&](int kind, int row, int nrows) -> int {
+                        if (cb.npre >= CL_MAX_PRE) { ok = false; return 0; }
+                        ClPreRec &r = cb.pre[cb.npre++];
+                        r.kind = kind;
+                        r.row = row;
+                        r.nrows = nrows;
+                        r.slot = nslots++;
+                        r.out_vec = -1;
+                        return r.slot;
+                    };
                     auto part_slot = [&](int row0, int nrows) -> int {      // the column sum of rows [row0, row0 + nrows) of `parts`
                         auto it = slot_of_part.find(row0);
                         if (it != slot_of_part.end()) return it->second;
-                        UOp op;
-                        memset(&op, 0, sizeof(op));
-                        op.kind = UOP_RED;
-                        op.out_vec = op.out_part = op.mask_vec = -1;
-                        op.in_kind[0] = 3;
-                        op.row0 = row0;
-                        op.nrows = nrows;
-                        op.out_gran = nslots++;
-                        pre.push_back(op);
-                        slot_of_part[row0] = op.out_gran;
-                        return op.out_gran;
+                        const int sl = add_pre(3, row0, nrows);
+                        slot_of_part[row0] = sl;
+                        return sl;
                     };
                     auto vt_slot = [&](int v) -> int {                      // a copy of VT row v (a pre-pass vector)
                         auto it = slot_of_vec.find(v);
                         if (it != slot_of_vec.end()) return it->second;
-                        UOp op;
-                        memset(&op, 0, sizeof(op));
-                        op.kind = UOP_RED;
-                        op.out_vec = op.out_part = op.mask_vec = -1;
-                        op.in_kind[0] = 2;
-                        op.in_vec[0] = v;
-                        op.nrows = 1;
-                        op.out_gran = nslots++;
-                        pre.push_back(op);
-                        slot_of_vec[v] = op.out_gran;
-                        return op.out_gran;
+                        const int sl = add_pre(2, v, 1);
+                        slot_of_vec[v] = sl;
+                        return sl;
                     };
                     // the batch's column-sum vectors somebody reads (UOP_RED of the vector-op form): slot + VT row
-                    for (size_t k = 0; k < r1_first; ++k) {
+                    for (size_t k = 0; k < r1_first && ok; ++k) {
                         const UOp &o = hp->uops_b[k];
                         if (o.kind != UOP_RED || vinfo[o.out_vec].batch != i) continue;
                         const int sl = part_slot(o.row0, o.nrows);
-                        for (size_t q = 0; q < pre.size(); ++q)
-                            if (pre[q].out_gran == sl) pre[q].out_vec = o.out_vec;
+                        for (int q = 0; q < cb.npre; ++q)
+                            if (cb.pre[q].slot == sl) cb.pre[q].out_vec = o.out_vec;
                         slot_of_vec[o.out_vec] = sl;
                     }
-                    auto rewrite_in = [&](UOp &op, int t) {
-                        if (op.in_kind[t] == 3) op.in_gran[t] = part_slot(op.in_vec[t], op.in_gran[t]);
-                        else if (op.in_kind[t] == 0) {
+                    auto in_slot = [&](const UOp &op, int t) -> int {
+                        if (op.in_kind[t] == 3) return part_slot(op.in_vec[t], op.in_gran[t]);
+                        if (op.in_kind[t] == 0) {
                             auto it = slot_of_vec.find(op.in_vec[t]);
-                            if (it == slot_of_vec.end()) { ok = false; return; }      // (its producer is not of this batch: cannot be)
-                            op.in_gran[t] = it->second;
-                        } else { ok = false; return; }
-                        op.in_kind[t] = UOP_IN_LDS;
+                            if (it != slot_of_vec.end()) return it->second;
+                        }
+                        ok = false;                                         // (its producer is not of this batch: cannot be)
+                        return 0;
                     };
-                    for (size_t k = 0; k < r1_first && ok; ++k) {          // BWD ops: level L-1 down to 0 (uops_b's order)
-                        UOp op = hp->uops_b[k];
-                        if (op.kind != UOP_BWD || vinfo[op.out_vec].batch != i) continue;
-                        for (int t = 0; t < op.nterms; ++t) rewrite_in(op, t);
-                        if (op.mask_vec >= 0) op.mask_vec = vt_slot(op.mask_vec);      // (closure ops: the LDS slot of its copy)
-                        op.out_gran = nslots++;
-                        slot_of_vec[op.out_vec] = op.out_gran;
-                        op.wait_mask = 0;
-                        body.push_back(op);
+                    // BWD ops, level L-1 down to 0 (uops_b's order: the ops of one level are adjacent and independent of each
+                    // other). Per level and 64-row chunk ONE item per distinct matrix, with every (op, term) that multiplies by it.
+                    struct LevOp { int k, acc, out_slot, mask_slot, terms_left[4]; int ins[UOP_MAX_TERMS]; };
+                    {
+                        std::vector<size_t> mine;
+                        for (size_t k = 0; k < r1_first; ++k)
+                            if (hp->uops_b[k].kind == UOP_BWD && vinfo[hp->uops_b[k].out_vec].batch == i) mine.push_back(k);
+                        size_t q0 = 0;
+                        while (q0 < mine.size() && ok) {
+                            const int lev = vinfo[hp->uops_b[mine[q0]].out_vec].level;
+                            size_t q1 = q0;
+                            while (q1 < mine.size() && vinfo[hp->uops_b[mine[q1]].out_vec].level == lev) ++q1;
+                            if (q1 - q0 > CL_ACCS) { ok = false; break; }
+                            std::vector<LevOp> lops;
+                            for (size_t q = q0; q < q1 && ok; ++q) {
+                                const UOp &op = hp->uops_b[mine[q]];
+                                LevOp lo;
+                                memset(&lo, 0, sizeof(lo));
+                                lo.k = (int)mine[q];
+                                lo.acc = (int)(q - q0);
+                                for (int t = 0; t < op.nterms; ++t) lo.ins[t] = in_slot(op, t);
+                                lo.mask_slot = op.mask_vec >= 0 ? vt_slot(op.mask_vec) : -1;
+                                lops.push_back(lo);
+                            }
+                            // (outputs get their slots after every input of the level is resolved: a level never reads its own)
+                            for (size_t q = 0; q < lops.size(); ++q) {
+                                lops[q].out_slot = nslots++;
+                                const UOp &op = hp->uops_b[lops[q].k];
+                                if (op.out_vec >= 0 || op.out_part >= 0) {
+                                    if (cb.nout >= CL_MAX_OUT) { ok = false; break; }
+                                    ClOutRec &o = cb.out[cb.nout++];
+                                    o.slot = lops[q].out_slot;
+                                    o.out_vec = op.out_vec;
+                                    o.out_part = op.out_part;
+                                }
+                            }
+                            // distinct matrices of the level in first-use order, each with its (op, term) uses
+                            struct MatUse { int layer, mat; std::vector<std::pair<int, int>> uses; };
+                            std::vector<MatUse> mats;
+                            for (size_t q = 0; q < lops.size(); ++q) {
+                                const UOp &op = hp->uops_b[lops[q].k];
+                                for (int t = 0; t < op.nterms; ++t) {
+                                    size_t m = 0;
+                                    for (; m < mats.size(); ++m)
+                                        if (mats[m].layer == uid[op.layer[t]] && mats[m].mat == op.mat[t] && mats[m].uses.size() < CL_USES) break;
+                                    if (m == mats.size()) mats.push_back(MatUse{uid[op.layer[t]], op.mat[t], {}});
+                                    mats[m].uses.push_back(std::make_pair((int)q, t));
+                                }
+                            }
+                            for (int ch = 0; ch < D / 64 && ok; ++ch) {
+                                int seen[CL_ACCS] = {0, 0, 0};             // terms of each op already emitted in this chunk
+                                for (size_t m = 0; m < mats.size(); ++m) {
+                                    if (cb.nitems >= CL_MAX_ITEMS) { ok = false; break; }
+                                    ClItemRec &r = cb.item[cb.nitems++];
+                                    memset(&r, 0, sizeof(r));
+                                    r.layer = mats[m].layer;
+                                    r.mat = mats[m].mat;
+                                    const bool level_end = ch == D / 64 - 1 && m + 1 == mats.size();
+                                    r.meta = ch | ((int)mats[m].uses.size() << 8) | (level_end ? 1 << 16 : 0);
+                                    for (size_t u = 0; u < mats[m].uses.size(); ++u) {
+                                        const int q = mats[m].uses[u].first, t = mats[m].uses[u].second;
+                                        const UOp &op = hp->uops_b[lops[q].k];
+                                        const int fl = (seen[q] == 0 ? CLI_FIRST : 0) | (seen[q] == op.nterms - 1 ? CLI_LAST : 0);
+                                        ++seen[q];
+                                        if (lops[q].ins[t] > 31 || lops[q].out_slot > 31 || lops[q].mask_slot > 31) ok = false;
+                                        r.use[u] = lops[q].ins[t] | (lops[q].acc << 5) | (fl << 7) | (lops[q].out_slot << 9) |
+                                                   ((lops[q].mask_slot + 1) << 14);
+                                    }
+                                }
+                            }
+                            for (size_t q = 0; q < lops.size(); ++q) slot_of_vec[hp->uops_b[lops[q].k].out_vec] = lops[q].out_slot;
+                            q0 = q1;
+                        }
                     }
                     for (size_t k = 0; k < r1_only.size() && ok; ++k) {   // rank-1-only matrices all of whose terms are this batch's
-                        UOp op = hp->uops_b[r1_first + k];
+                        const UOp &op = hp->uops_b[r1_first + k];
                         bool mine = true, any = false;
                         for (int t = 0; t < op.nterms; ++t) {
                             const int bt = vinfo[hp->rank1[r1_only[k].r1_start + t].v].batch;
@@ -2247,62 +2304,31 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                             continue;
                         }
                         r1_taken[k] = 1;
+                        if (cb.nr1 >= CL_MAX_R1) { ok = false; break; }
+                        ClR1Rec &r = cb.r1[cb.nr1++];
+                        r.layer = op.r1_layer;
+                        r.rel = op.r1_rel;
+                        r.nterms = op.nterms;
                         for (int t = 0; t < op.nterms && ok; ++t) {
-                            rewrite_in(op, t);
-                            op.mat[t] = vt_slot(op.u_vec[t]);                // (R1 ops have no matrix: the u vector's slot)
+                            r.v[t] = in_slot(op, t);
+                            r.u[t] = vt_slot(op.u_vec[t]);
                         }
-                        op.wait_mask = 0;
-                        body.push_back(op);
                     }
                     if (nslots > CL_MAX_SLOTS) ok = false;
-                    if (!ok || (pre.empty() && body.empty())) continue;
-                    Closure c;
-                    c.first = (int)all.size();
-                    c.npre = (int)pre.size();
-                    c.count = (int)(pre.size() + body.size());
-                    c.pad = 0;
-                    c.item_first = (int)items.size();
-                    for (size_t q = 0; q < body.size(); ++q) {             // the BWD ops' items: (op, chunk, term)
-                        const UOp &op = body[q];
-                        if (op.kind != UOP_BWD) continue;
-                        for (int ch = 0; ch < D / 64; ++ch)
-                            for (int t = 0; t < op.nterms; ++t) {
-                                ClItemRec r;
-                                memset(&r, 0, sizeof(r));
-                                r.layer = op.layer[t];
-                                r.mat = op.mat[t];
-                                r.chunk = ch;
-                                r.flags = (t == 0 ? CLI_FIRST : 0) | (t == op.nterms - 1 ? CLI_LAST : 0) |
-                                          (t == op.nterms - 1 && ch == D / 64 - 1 ? CLI_OPEND : 0);
-                                r.in_slot = op.in_gran[t];
-                                r.out_slot = op.out_gran;
-                                r.out_vec = op.out_vec;
-                                r.out_part = op.out_part;
-                                r.mask_slot = op.mask_vec;          // (rewritten to the LDS slot of its copy: below)
-                                items.push_back(r);
-                            }
+                    while (ok && cb.nitems % 4 != 0) {                     // whole trips of the item loop: items that do nothing
+                        if (cb.nitems >= CL_MAX_ITEMS) { ok = false; break; }
+                        ClItemRec &r = cb.item[cb.nitems++];
+                        memset(&r, 0, sizeof(r));
+                        r.mat = -1;                 // (no uses, no barrier: the root matrix of layer 0 is read and dropped)
                     }
-                    c.nitems = (int)items.size() - c.item_first;
-                    if (c.nitems > CL_MAX_ITEMS) ok = false;
-                    all.insert(all.end(), pre.begin(), pre.end());
-                    all.insert(all.end(), body.begin(), body.end());
-                    cls.push_back(c);
+                    if (!ok || (cb.npre == 0 && cb.nitems == 0 && cb.nr1 == 0)) continue;
+                    cls.push_back(cb);
                 }
                 for (size_t k = 0; k < r1_only.size(); ++k) ok = ok && r1_taken[k] != 0;
                 if (ok && !cls.empty()) {
                     // heaviest closures first: they start first
-                    std::stable_sort(cls.begin(), cls.end(), [&](const Closure &a, const Closure &b) {
-                        auto terms = [&](const Closure &c) {
-                            int n = 0;
-                            for (int k = c.first + c.npre; k < c.first + c.count; ++k)
-                                if (all[k].kind == UOP_BWD) n += all[k].nterms;
-                            return n;
-                        };
-                        return terms(a) > terms(b);
-                    });
-                    hp->uops_c.swap(all);
+                    std::stable_sort(cls.begin(), cls.end(), [](const ClBlock &a, const ClBlock &b) { return a.nitems > b.nitems; });
                     hp->closures.swap(cls);
-                    hp->citems.swap(items);
                     hp->groups.insert(hp->groups.end(), moved.begin(), moved.end());
                 }
             }
@@ -2558,9 +2584,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     }
     hp->o_uopf = take(hp->uops_f.size() * sizeof(UOp));
     hp->o_uopb = take(hp->uops_b.size() * sizeof(UOp));
-    hp->o_uopc = take(hp->uops_c.size() * sizeof(UOp));
-    hp->o_closures = take(hp->closures.size() * sizeof(Closure));
-    hp->o_citems = take(hp->citems.size() * sizeof(ClItemRec));
+    hp->o_closures = take(hp->closures.size() * (size_t)CL_BLOCK_WORDS * 4);
     hp->o_rank1 = take(hp->rank1.size() * sizeof(Rank1));
     hp->o_done_inc = take(hp->done_inc.size() * sizeof(int));
     TouchMeta tmeta;
@@ -2660,9 +2684,8 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         put(hp->o_zmats, hp->zmats.data(), hp->zmats.size() * sizeof(ZMat));
         put(hp->o_uopf, hp->uops_f.data(), hp->uops_f.size() * sizeof(UOp));
         put(hp->o_uopb, hp->uops_b.data(), hp->uops_b.size() * sizeof(UOp));
-        put(hp->o_uopc, hp->uops_c.data(), hp->uops_c.size() * sizeof(UOp));
-        put(hp->o_closures, hp->closures.data(), hp->closures.size() * sizeof(Closure));
-        put(hp->o_citems, hp->citems.data(), hp->citems.size() * sizeof(ClItemRec));
+        for (size_t k = 0; k < hp->closures.size(); ++k)
+            put(hp->o_closures + k * (size_t)CL_BLOCK_WORDS * 4, &hp->closures[k], sizeof(ClBlock));
         put(hp->o_rank1, hp->rank1.data(), hp->rank1.size() * sizeof(Rank1));
         put(hp->o_done_inc, hp->done_inc.data(), hp->done_inc.size() * sizeof(int));
         if (hp->ts_blocks) put(hp->o_tmeta, &tmeta, sizeof(tmeta));
@@ -2674,21 +2697,15 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->o_tsort = take(hp->ts_blocks ? (size_t)hp->ts_blocks * (4 * (size_t)TSORT_THREADS * tsort_rounds(hp->touch_M) + 4 * 256) * sizeof(unsigned) : 0);
     hp->total = off;
     if (dbg_on("DUMP_PLAN")) {        // diagnostics: what the step's launches consist of
-        fprintf(stderr, "plan: chain %d uniform %d blocks %d | tile sources %zu tiles %d slabs %d | groups %zu | uops f %zu b %zu | closures %zu ops %zu | rank1 %zu | zmats %zu | touch M %lld\n",
+        fprintf(stderr, "plan: chain %d uniform %d blocks %d | tile sources %zu tiles %d slabs %d | groups %zu | uops f %zu b %zu | closures %zu | rank1 %zu | zmats %zu | touch M %lld\n",
                 (int)chain, (int)hp->uniform, hp->blk_off[nb], hp->wsrc.size(), hp->wblocks_total, hp->total_slabs, hp->groups.size(),
-                hp->uops_f.size(), hp->uops_b.size(), hp->closures.size(), hp->uops_c.size(), hp->rank1.size(), hp->zmats.size(), hp->touch_M);
+                hp->uops_f.size(), hp->uops_b.size(), hp->closures.size(), hp->rank1.size(), hp->zmats.size(), hp->touch_M);
         for (size_t k = 0; k < hp->groups.size(); ++k)
             fprintf(stderr, "  group %zu kind %d layer %d row %lld slabs/rows %d rank1 %d\n", k, hp->groups[k].kind, hp->groups[k].layer,
                     hp->groups[k].row, hp->groups[k].count, hp->groups[k].r1_count);
-        for (size_t k = 0; k < hp->closures.size(); ++k) {
-            const Closure &c = hp->closures[k];
-            int terms = 0, r1 = 0, bw = 0;
-            for (int q = c.first + c.npre; q < c.first + c.count; ++q) {
-                if (hp->uops_c[q].kind == UOP_BWD) { terms += hp->uops_c[q].nterms; ++bw; }
-                else ++r1;
-            }
-            fprintf(stderr, "  closure %zu pre %d bwd ops %d terms %d r1 ops %d\n", k, c.npre, bw, terms, r1);
-        }
+        for (size_t k = 0; k < hp->closures.size(); ++k)
+            fprintf(stderr, "  closure %zu batch %d pre %d items %d r1 %d\n", k, hp->closures[k].batch, hp->closures[k].npre,
+                    hp->closures[k].nitems, hp->closures[k].nr1);
     }
     return MPQE_OK;
 }
@@ -3549,9 +3566,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         const bool closures = use_chain && first == 0 && !hp.closures.empty() && !fuse_tail;
         if (closures) {
             tl.ublocks = 0;
-            tl.ca.cl = reinterpret_cast<const Closure *>(db + hp.o_closures);
-            tl.ca.ops = reinterpret_cast<const UOp *>(db + hp.o_uopc);
-            tl.ca.items = reinterpret_cast<const ClItemRec *>(db + hp.o_citems);
+            tl.ca.blocks = reinterpret_cast<const int *>(db + hp.o_closures);
             tl.ca.ncl = (int)hp.closures.size();
             tl.clpad = (tl.ca.ncl + 7) / 8 * 8;
             nblocks = tl.clpad + count + tl.zblocks;

@@ -319,13 +319,15 @@ def test_fused_step_matches_oracle(be, readout, adaptive, shared, L, mix):
 @pytest.mark.parametrize('D,readout,adaptive', [(128, 'mp', True), (64, 'mp', True), (128, 'sum', False)])
 def test_post_pass_closures_match_oracle(be, request, D, readout, adaptive):
     """The backward post-pass of the batch-uniform node states as one closure workgroup per batch (split tail launch,
-    csrc/step_closure.h) against the oracle and against the vector-op form it replaces (mpqe_debug_option NO_CLOSURE):
+    csrc/step_closure.h; mpqe_debug_option CLOSURE) against the oracle and against the vector-op form:
     batches of more than 8 x 16 graphs, so that a column sum has more rows than the closure has row groups (its order
     of additions then differs from the vector ops': same values within rounding), every chain depth, ragged sizes."""
     mix = [('3-chain', 200, 1.0), ('2-chain', 150, 0.5), ('3-inter_chain', 40, 0.25), ('3-chain_inter', 33, 2.0),
            ('3-chain', 17, 0.3)]
     schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(29, D, 3, False, mix, readout, adaptive)
     ref_loss, ref_per, ref_sp, ref_sn = oracle_step(params, cfg, node_map, batches, 1.0)
+    be.lib.mpqe_debug_option(b'CLOSURE', 1, 1)               # (built on request: not the default form)
+    request.addfinalizer(lambda: be.lib.mpqe_debug_option(b'CLOSURE', 0, 0))
     for zero in (True, False):
         flags = _capi.STEP_SPLIT_TAIL | (_capi.STEP_ZERO_GRADS if zero else 0)
         got = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=flags, repeat=2 if zero else 1)
@@ -334,8 +336,7 @@ def test_post_pass_closures_match_oracle(be, request, D, readout, adaptive):
         for k, p in params.items():
             ref = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
             np.testing.assert_allclose(got[3][k], ref, rtol=1e-4, atol=2e-6, err_msg=k)
-    be.lib.mpqe_debug_option(b'NO_CLOSURE', 1, 1)
-    request.addfinalizer(lambda: be.lib.mpqe_debug_option(b'NO_CLOSURE', 0, 0))
+    be.lib.mpqe_debug_option(b'CLOSURE', 0, 0)
     old = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_SPLIT_TAIL)
     for k in got[3]:
         np.testing.assert_allclose(got[3][k], old[3][k], rtol=1e-5, atol=1e-7, err_msg=k)

@@ -140,6 +140,11 @@ def main():
                 m = kinds == kd
                 if m.any():
                     print('      %s: %d, ends %s' % (nm, m.sum(), np.round(np.sort(uend[m])[::max(1, m.sum() // 12)], 1).tolist()))
+                if kd == 5 and m.any():      # closures: start | programme in LDS | pre phase done | item stream done | end
+                    rows = tt[uo][m]
+                    for rr in rows[np.argsort(rows[:, 5])]:
+                        print('         closure: start %.1f, block %.1f, pre %.1f, items %.1f, end %.1f' %
+                              tuple((rr[k] - t0) * 0.01 for k in (0, 2, 3, 4, 5)))
         hist = np.histogram(dur, bins=[0, 4, 6, 8, 10, 12, 14, 16, 20, 30])
         print('   duration histogram (us):', list(zip(hist[1][:-1].tolist(), hist[0].tolist())))
         return
