@@ -988,6 +988,8 @@ struct ReduceArgs {
     // wait until `arrive` has counted the launch's `phase1` tile and vector-op workgroups; NULL: a launch of its own
     const unsigned *arrive;
     unsigned phase1;
+    int early;               // 1: the loss and the entity-table rows were roles of the weight-gradient launch (TailArgs.extra0):
+                             // the loss workgroup here only closes the step (epochs, the sort's barrier word, the plan's failure flag)
 };
 // workgroup (bx, by) of the reduction: by < ngroups: 256 elements of group by (gx workgroups along x); by == ngroups: the
 // loss (bx 0); beyond: entity-table rows
@@ -1050,6 +1052,7 @@ __device__ __forceinline__ void reduce_block(const ReduceArgs &ra, int bx, int b
             // a touch plan whose build could not finish (its workgroups were not all resident: step_touch.h): the table rows
             // above stored nothing; the caller rebuilds the plan and sums them again (mpqe_step_table_rows)
             if (touch && threadIdx.x == 0 && reinterpret_cast<const TouchHeader *>(touch)->pad[0]) flag_error(ra.err, MPQE_FLAG_TOUCH_RETRY);
+            if (ra.early) return;
             if (ra.lm.chain) loss_block_chain(ra.lm, ra.bterms, ra.loss, reinterpret_cast<float *>(part), 4);
             else loss_block(ra.sd, ra.terms, ra.loss, reinterpret_cast<float *>(part), 4);
         }
@@ -1178,7 +1181,6 @@ __global__ __launch_bounds__(256) void step_reduce_kernel(ReduceArgs ra) {
     __shared__ f32x4 part[4][64];
     reduce_block(ra, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, part);
 }
-
 struct TailArgs {
     const WSource *wsrc;
     const WBlock *wblock;
@@ -1195,6 +1197,9 @@ struct TailArgs {
     int D;                   // = sd->D, by value: a tile's record is then the first and only load in front of its rows
     int tile_n;              // columns per weight-gradient tile
     int ux;                  // > 0: XCDs set aside for the post-pass' vector ops (step_tail_kernel)
+    int extra0;              // >= 0: workgroups [extra0, ...) of the launch are roles that read only what the CHAIN launch wrote --
+    int tm_blocks;           // [extra0] the loss (loss_block_chain), then tm_blocks entity-table workgroups (table_sum_multi):
+                             // they were 2 800 + 1 workgroups of the reduction launch; here they run beside the tiles
     ClosureArgs ca;          // ca.ncl > 0: the post-pass as closures (step_closure.h) -- the launch's FIRST ncl workgroups, padded
     int clpad;               // to clpad (a multiple of 8: tile b keeps XCD b % 8); ublocks is 0 then
 
@@ -1290,6 +1295,30 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
             reduce_block(ra, bx, by, fa.gx, reinterpret_cast<f32x4(*)[64]>(smem));
             return;
         }
+    }
+    if (ta.extra0 >= 0 && (int)blockIdx.x >= ta.extra0) {
+        // roles that depend on the chain launch alone: the loss of the step, the entity-table rows (step_touch.h)
+        const int e = (int)blockIdx.x - ta.extra0;
+#ifndef MPQE_EMU
+        if (ta.stamps && threadIdx.x == 0) ta.stamps[(long long)blockIdx.x * 8 + 0] = (long long)wall_clock64();
+#endif
+        if (e == 0) {
+            loss_block_chain(ra.lm, ra.bterms, ra.loss, smem, 4);
+        } else if (e - 1 < ta.tm_blocks) {
+            static_assert(sizeof(smem) >= TSM_LDS_WORDS(64) * 4, "table_sum_multi's window lives in the launch's LDS");
+            table_sum_multi(ra.touch_M, ra.touch_row_bits, reinterpret_cast<const tkey_t *>(ra.touch + ra.touch_keys),
+                            reinterpret_cast<const int *>(ra.touch + ra.touch_perm), ra.DG, ta.D, ra.tabs, ra.table_store & 1,
+                            (long long)(e - 1), &reinterpret_cast<const TouchHeader *>(ra.touch)->pad[0],
+                            reinterpret_cast<unsigned *>(smem));
+        }
+#ifndef MPQE_EMU
+        if (ta.stamps && threadIdx.x == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ta.stamps[(long long)blockIdx.x * 8 + 5] = (long long)wall_clock64();
+            ta.stamps[(long long)blockIdx.x * 8 + 6] = 1 + 6;            // kind 6: loss / entity-table rows
+        }
+#endif
+        return;
     }
     // (fused: a tile / vector-op workgroup counts itself in once its stores -- written through -- are acknowledged)
     auto arrived = [&]() {
@@ -3502,6 +3531,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     ta.ux = 0;
     memset(&ta.ca, 0, sizeof(ta.ca));
     ta.clpad = 0;
+    ta.extra0 = -1;
+    ta.tm_blocks = 0;
     ta.node_map = nm;
     ta.map_len = (long long)P->node_map_len;
     ta.anchor_ids = ids;
@@ -3554,6 +3585,18 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     ra.touch_row_bits = touch_row_bits;
     ra.err = err;
     const bool fuse_tail = use_chain && backward && !merged && NL == 1 && D % 64 == 0 && dbg_on("FUSE_TAIL");
+    // split tail launch of the chain form: the loss and the entity-table rows depend on the chain launch alone -- they run as
+    // trailing workgroups of the weight-gradient launch, beside its tiles (136 of 256 CUs busy on the AIFB step), instead of
+    // in the reduction launch behind it (mpqe_debug_option LATE_ROWS = 1: as before)
+    const bool can_early = use_chain && backward && !merged && !fuse_tail && NL == 1 && D % 4 == 0 && 256 % (D / 4) == 0;
+    // (as trailing workgroups of the weight-gradient launch itself, mpqe_debug_option EARLY_ROWS = 1: measured slower -- that
+    // launch's 230 VGPRs allow two workgroups per CU, a table workgroup took 8.6 us and the launch 6 us longer)
+    const bool early_roles = can_early && dbg_on("EARLY_ROWS");
+    // (as a light launch of their own beside the weight-gradient launch -- enqueued behind it with hipExtAnyOrderLaunch, i.e.
+    // without the queue's barrier bit -- was tried too: the flag is not honoured on gfx9 boards (hip_ext.h says so): the
+    // launch ran in order and the step took 4.4 us longer)
+    ra.early = early_roles ? 1 : 0;
+    if (early_roles) r_trows = 0;
     pa.tail_arrive = fuse_tail ? epoch_f + 41 : nullptr;
     bool reduced = false;
     auto launch_grad_w = [&](hipStream_t on, int first, int count) {
@@ -3581,6 +3624,12 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                 const int ra = (tl.ublocks + tl.ux - 1) / tl.ux, rb = (count + tl.zblocks + (8 - tl.ux) - 1) / (8 - tl.ux);
                 nblocks = 8 * (ra > rb ? ra : rb);
             }
+        }
+        if (early_roles && first == 0 && count == hp.wblocks_total) {
+            const int lpr = D / 4, pos = (256 / lpr) * TSM_OWN;
+            tl.extra0 = (nblocks + 7) / 8 * 8;
+            tl.tm_blocks = use_touch ? (int)((hp.touch_M + pos - 1) / pos) : 0;
+            nblocks = tl.extra0 + 1 + tl.tm_blocks;
         }
         tl.stamps = g_tail_stamps && (size_t)nblocks <= g_tail_stamp_blocks ? g_tail_stamps : nullptr;
         if (nblocks <= 0) return;

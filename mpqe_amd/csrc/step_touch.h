@@ -511,3 +511,91 @@ __device__ __forceinline__ void table_sum_block(long long M, int row_bits, const
     if (store) *dst = acc;
     else *dst = *dst + acc;
 }
+
+// The same sums by workgroups that take a RANGE of sorted positions each (roles of a launch whose register footprint allows
+// few workgroups per CU: thousands of one-run workgroups would queue -- step.hip: the weight-gradient launch). A workgroup
+// owns TSM_OWN positions per lane group (D / 4 lanes = one row): it stages the keys and permutation entries of its range
+// (+ look-ahead) in LDS with one round trip, then every lane group walks from the first run that STARTS in its own
+// positions to the end of the last such run, TS_AHEAD rows per round trip whatever the run lengths (a table of 10^6 rows
+// has runs of one, the AIFB step runs of eight), adding in sorted order and storing at every run's end: the same additions
+// in the same order as table_sum_block.
+#define TSM_OWN 8
+#define TSM_LOOK 64
+#define TSM_LDS_WORDS(D) (3 * ((256 / ((D) / 4)) * TSM_OWN + 1 + TSM_LOOK))
+template <class TabsT>
+__device__ __forceinline__ void table_sum_multi(long long M, int row_bits, const tkey_t *__restrict__ keys,
+                                                const int *__restrict__ perm, const float *__restrict__ DG, int D,
+                                                const TabsT &tabs, int store, long long wg, const int *__restrict__ failed,
+                                                unsigned *lds) {
+    const int lpr = D / 4, ngrp = 256 / lpr, POS = ngrp * TSM_OWN, WIN = POS + 1 + TSM_LOOK;
+    const long long base = wg * POS;
+    if (base >= M) return;
+    tkey_t *lk = reinterpret_cast<tkey_t *>(lds);            // keys of positions base - 1 + q
+    int *lp = reinterpret_cast<int *>(lds + 2 * WIN);        // entries (rows of DG) of the same positions
+    auto inside = [M](long long p) { return p < 0 ? 0ll : (p >= M ? M - 1 : p); };
+    for (int q = threadIdx.x; q < WIN; q += 256) {
+        const long long pos = base - 1 + q;
+        const bool in = pos >= 0 && pos < M;
+        lk[q] = in ? keys[pos] : TOUCH_INVALID;
+        lp[q] = (int)(in ? (perm ? inside((long long)perm[pos]) : pos) : 0);
+    }
+    const int bad = failed ? *failed : 0;
+    __syncthreads();
+    if (bad) return;
+    auto K = [&](long long pos) -> tkey_t {                  // (beyond the window: a run longer than the look-ahead)
+        if (pos < 0 || pos >= M) return TOUCH_INVALID;
+        const long long q = pos - (base - 1);
+        return q < WIN ? lk[q] : keys[pos];
+    };
+    auto E = [&](long long pos) -> long long {
+        const long long q = pos - (base - 1);
+        return q < WIN ? (long long)lp[q] : (perm ? inside((long long)perm[pos]) : pos);
+    };
+    const int g = threadIdx.x / lpr, c = (threadIdx.x % lpr) * 4;
+    const long long own0 = base + (long long)g * TSM_OWN;
+    const long long own1 = own0 + TSM_OWN < M ? own0 + TSM_OWN : M;
+    long long p = own0;
+    while (p < own1 && (K(p) == TOUCH_INVALID || K(p) == K(p - 1))) ++p;       // first run that starts in my positions
+    if (p >= own1) return;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    tkey_t cur = K(p);
+    bool have = false, done = false;
+    auto flush = [&]() {
+        const int tab = (int)(cur >> row_bits);
+        const long long row = (long long)(cur & ((1ull << row_bits) - 1ull));
+        float *gr = tabs.grad[0];      // (a runtime index into the by-value table would spill it to scratch)
+#pragma unroll
+        for (int m = 1; m < MPQE_STEP_MAX_MODES; ++m)
+            if (m == tab) gr = tabs.grad[m];
+        if (!gr) return;
+        f32x4 *dst = reinterpret_cast<f32x4 *>(gr + row * D + c);
+        if (store) *dst = acc;
+        else *dst = *dst + acc;
+    };
+    for (long long j0 = p; !done; j0 += TS_AHEAD) {
+        f32x4 v[TS_AHEAD];
+#pragma unroll
+        for (int q = 0; q < TS_AHEAD; ++q) v[q] = gload4(DG + E(j0 + q < M ? j0 + q : M - 1) * D + c);
+#pragma unroll
+        for (int q = 0; q < TS_AHEAD; ++q) {
+            if (done) continue;
+            const long long j = j0 + q;
+            const tkey_t kj = K(j);
+            if (have && kj != cur) {        // the run has ended: its row is complete
+                flush();
+                have = false;
+            }
+            if (!have) {
+                if (j >= own1 || kj == TOUCH_INVALID) {       // (position j starts a run of the next lane group / the invalid tail)
+                    done = true;
+                    continue;
+                }
+                cur = kj;
+                acc = v[q];
+                have = true;
+            } else {
+                acc += v[q];
+            }
+        }
+    }
+}

@@ -550,6 +550,18 @@ def test_fused_step_chain_kernels(be, D, readout, adaptive, shared, L):
         runs.append(split)
         for k in got[3]:
             np.testing.assert_allclose(split[3][k], got[3][k], rtol=1e-5, atol=1e-7, err_msg=k)
+        # where the loss and the entity-table rows of the split form run: in the reduction launch (default), or as trailing
+        # workgroups of the weight-gradient launch (EARLY_ROWS: table_sum_multi, a range of sorted positions per workgroup;
+        # measured slower, kept as a switch) -- the same additions in the same order, bit for bit
+        for opt in (b'EARLY_ROWS',):
+            be.lib.mpqe_debug_option(opt, 1, 1)
+            try:
+                other = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_SPLIT_TAIL)
+            finally:
+                be.lib.mpqe_debug_option(opt, 0, 0)
+            np.testing.assert_array_equal(split[0], other[0])
+            for k in got[3]:
+                np.testing.assert_array_equal(split[3][k], other[3][k], err_msg='%s %s' % (opt, k))
         runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0,
                              flags=_capi.STEP_SPLIT_TAIL | _capi.STEP_ZERO_GRADS, repeat=2))
         runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0,

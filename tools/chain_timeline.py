@@ -130,16 +130,20 @@ def main():
             i = np.nonzero(gw)[0][k]
             print('   block %4d  start %5.1f  dur %5.1f  end %5.1f  on-CU mates %d' % (i, start[i], end[i] - start[i], end[i],
                                                                                      int((place[gw] == place[i]).sum())))
-        uo = (~gw) & (tt[:, 6] >= 1) & (tt[:, 6] <= 6) & (tt[:, 5] != 0)      # vector ops of the backward post-pass
+        uo = (~gw) & (tt[:, 6] >= 1) & (tt[:, 6] <= 7) & (tt[:, 5] != 0)      # vector ops of the backward post-pass
         if uo.any():
             uend = (tt[uo, 5] - t0) * 0.01
             kinds = tt[uo, 6] - 1
             print('   post-pass vector ops: %d workgroups, start %.1f..%.1f us, end %.1f..%.1f us' %
                   (uo.sum(), start[uo].min(), start[uo].max(), uend.min(), uend.max()))
-            for kd, nm in ((2, "RED"), (1, "BWD"), (4, "R1"), (5, "CLOSURE")):
+            for kd, nm in ((2, "RED"), (1, "BWD"), (4, "R1"), (5, "CLOSURE"), (6, "ROWS")):
                 m = kinds == kd
                 if m.any():
                     print('      %s: %d, ends %s' % (nm, m.sum(), np.round(np.sort(uend[m])[::max(1, m.sum() // 12)], 1).tolist()))
+                if kd == 6 and m.any():
+                    rows = tt[uo][m]
+                    st_, en_ = (rows[:, 0] - t0) * 0.01, (rows[:, 5] - t0) * 0.01
+                    print('         table rows / loss: start %.1f .. %.1f, duration mean %.1f max %.1f' % (st_.min(), st_.max(), (en_ - st_).mean(), (en_ - st_).max()))
                 if kd == 5 and m.any():      # closures: start | programme in LDS | pre phase done | item stream done | end
                     rows = tt[uo][m]
                     for rr in rows[np.argsort(rows[:, 5])]:
