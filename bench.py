@@ -77,6 +77,10 @@ def parse():
     ap.add_argument('--sparse-tables', action='store_true',
                     help='row-sparse entity-table gradients (MPQE_STEP_SPARSE_TABLES): only the rows a step touches are '
                          'written, no zero fill of the tables (for row-sparse consumers: mpqe_adam_rows_step, the row exchange)')
+    ap.add_argument('--exchange', default='rccl', choices=['rccl', 'p2p'],
+                    help='N > 1: how the gradient bucket is summed -- rccl: torch.distributed all-reduce; p2p: the '
+                         "library's one-hop reduce-scatter + all-gather over IPC-mapped peer buffers (csrc/p2p.hip), "
+                         'self-tested against the all-reduce at start-up and falling back to it (exchange_note) on any failure')
     ap.add_argument('--dense-allreduce', action='store_true',
                     help='N > 1: all-reduce the whole flat gradient buffer (what a literal port would do) instead of the '
                          'touched-matrix bucket + row exchange')
@@ -648,7 +652,7 @@ def main():
         if world > 1 and not args.dense_allreduce:
             # gradient exchange of the steps (collective, once per formula set): which relation matrices ANY rank touches
             from mpqe_amd.parallel import StepExchange
-            exchange = StepExchange(fstep)
+            exchange = StepExchange(fstep, transport=args.exchange)
             xplans = [exchange.plan(p, key=j) for j, p in enumerate(packed)]
     else:
         n_total = auto_sizes(lambda: step_modules(model, pool[0]))
@@ -692,11 +696,14 @@ def main():
         if fresh:
             fresh_check(fstep, descs[0], fresh_ids[0][0], pool[0], exact=not learned)
     xnote = None
+    if exchange is not None and exchange.transport_note:
+        xnote = exchange.transport_note
     if exchange is not None:
         # the exchange against the literal dense all-reduce on one step (N-rank hardware is not available to the tests):
         # a mismatch falls back to the dense form, and says so
-        xnote = exchange_check(fstep, exchange, xplans[0], packed[0])
-        if xnote is not None:
+        xcheck = exchange_check(fstep, exchange, xplans[0], packed[0])
+        if xcheck is not None:
+            xnote = xcheck
             exchange = None
     step_no = 0
     for i in range(args.warmup):
@@ -777,7 +784,7 @@ def main():
                             'bytes_per_rank_per_step': int(np.mean([x.wire_bytes for x in xplans])),
                             'bucket_bytes': int(np.mean([x.bucket_bytes for x in xplans])),
                             'table_rows_gathered': int(np.mean([x.entries for x in xplans])),
-                            'forms': sorted(set(x.form for x in xplans)),
+                            'forms': sorted(set(x.form for x in xplans)), 'transport': exchange.transport,
                             'dense_gradient_bytes': dense_bytes})
     if rank == 0 and use_fused and world == 1 and not args.no_pack_ms:
         # host side of a step whose ids arrive from the HOST (a data loader's numpy arrays): packing = descriptors (cached

@@ -520,6 +520,27 @@ int mpqe_table_rows_sum(const void *plan, int64_t n, const float *rows /* [n, di
                         float *const *table_grads /* [num_modes] host array of device pointers */, int num_modes,
                         int store /* 1: rows are written, 0: added to */, void *stream);
 
+/* ---- gradient-bucket exchange over peer-mapped buffers (SURVEY.md 5 last row, 8e: "one-hop reduce-scatter + all-gather
+ * using all 7 links concurrently ... a custom P2P two-shot over IPC-mapped buffers") ------------------------------------
+ * No reference counterpart (the reference is single-process). Every rank of ONE node owns a communication buffer
+ * [bucket n floats | world staging slots of one shard | flags] (mpqe_p2p_buffer_bytes; fine-grained device memory from
+ * mpqe_p2p_alloc, which also returns its IPC handle) and maps its peers' buffers (mpqe_p2p_open on the handles, exchanged
+ * by the host side). mpqe_p2p_allreduce, stream-ordered, per rank: push my contribution to every shard into its owner's
+ * slot -> sum the slots of MY shard in rank order and write the sum into that shard of every rank's bucket -> wait until
+ * every shard of my bucket has landed. Each byte crosses one link once per direction; the sum of a shard is computed once,
+ * so all replicas hold the same bits. epoch: != 0, a new value per call (flags are epoch-stamped, never cleared). phases:
+ * 1 push | 2 reduce | 4 wait (7 = the whole exchange; separate phases are for single-process tests). Every poll is
+ * bounded: a peer that never arrives ORs MPQE_FLAG_INTERNAL into err (the caller falls back to another collective). */
+size_t mpqe_p2p_handle_bytes(void);
+size_t mpqe_p2p_buffer_bytes(int64_t n, int world, int64_t *stage_offset, int64_t *flags_offset);
+int mpqe_p2p_alloc(size_t bytes, void **ptr, void *handle_out);
+int mpqe_p2p_free(void *ptr);
+int mpqe_p2p_open(const void *handle, void **mapped);
+int mpqe_p2p_close(void *mapped);
+int mpqe_p2p_allreduce(void *const *buffers /* [world] host array: buffer of rank p as THIS process addresses it */, int rank,
+                       int world, int64_t capacity /* the n the buffers were sized for */, int64_t n /* floats to reduce, <= capacity */,
+                       uint32_t epoch, int phases, int32_t *err, void *stream);
+
 /* ---- negative sampling on the device -------------------------------------------
  * reference model.py:466-476: one negative per query, random.choice over query.neg_samples /
  * query.hard_neg_samples (ragged per query) or graph.full_lists[target_mode] (1-chain: one list for all).

@@ -123,6 +123,13 @@ PROTOTYPES = {
     'mpqe_rows_plan_build': (I, [P, L, I, I, P, Z, P, Z, P]),
     'mpqe_table_rows_sum': (I, [P, L, P, L, ctypes.POINTER(c_void_p), I, I, P]),
     'mpqe_step_touch_build': (I, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, P, P, P, P, Z, P, Z, P]),
+    'mpqe_p2p_handle_bytes': (Z, []),
+    'mpqe_p2p_buffer_bytes': (Z, [L, I, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    'mpqe_p2p_alloc': (I, [Z, ctypes.POINTER(c_void_p), P]),
+    'mpqe_p2p_free': (I, [P]),
+    'mpqe_p2p_open': (I, [P, ctypes.POINTER(c_void_p)]),
+    'mpqe_p2p_close': (I, [P]),
+    'mpqe_p2p_allreduce': (I, [ctypes.POINTER(c_void_p), I, I, L, L, ctypes.c_uint32, I, P, P]),
     'mpqe_step_table_rows': (I, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, ctypes.POINTER(StepGrads), P, P, Z, P, P]),
 }
 

@@ -63,7 +63,8 @@ def raise_on_flags(err):
         if flags & 16:
             sites = [n for bit, n in ((0x100, 'a pre-pass vector'), (0x200, 'the transposed weight copies'),
                                       (0x400, 'a completion counter'), (0x800, 'a vector op\'s inputs'),
-                                      (0x1000, 'the fused tail\'s arrivals'), (0x2000, 'the touch plan\'s sort')) if flags & bit]
+                                      (0x1000, 'the fused tail\'s arrivals'), (0x2000, 'the touch plan\'s sort'),
+                                      (0x4000, 'a peer of the p2p gradient exchange')) if flags & bit]
             raise RuntimeError('mpqe_amd: an in-launch hand-off between workgroups timed out (library fault): '
                                + (', '.join(sites) or 'unknown site'))
         if flags & 32:

@@ -1,0 +1,139 @@
+"""One-hop gradient exchange over peer-mapped buffers (csrc/p2p.hip; SURVEY.md 5 / 8e: "one-hop reduce-scatter + all-gather
+using all 7 links concurrently ... over IPC-mapped buffers"). The reference has no distributed code.
+
+    ex = PeerExchange(capacity_floats)            # collective: every rank of the node, same capacity
+    ex.bucket[:n].copy_(...)                      # the bucket lives in the communication buffer
+    ex.all_reduce(n)                              # stream-ordered: push -> reduce my shard -> wait for all shards
+    ... = ex.bucket[:n]
+
+`PeerExchange.ok` is False when the buffers could not be set up or the self-test against torch.distributed's all-reduce
+failed: callers (mpqe_amd.parallel.StepExchange(transport='p2p')) then keep to RCCL. Every device-side wait is bounded and
+reports through the error word (`check()`), never a hang.
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import _capi, ops
+
+
+class _Blob(object):
+    """A raw device allocation as a CUDA-array-interface object (torch.as_tensor wraps it without copying)."""
+
+    def __init__(self, ptr, nfloats):
+        self.__cuda_array_interface__ = {'shape': (int(nfloats),), 'typestr': '<f4', 'data': (int(ptr), False), 'version': 2}
+
+
+class PeerExchange(object):
+    def __init__(self, capacity, group=None, device=None, self_test=True):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.capacity = int(capacity)
+        self.epoch = 0
+        self.ok = False
+        self.reason = None
+        self._own = None
+        self._mapped = []
+        self.err = ops.new_error_word(self.device)
+        L = ops.lib()
+        try:
+            so, fo = ctypes.c_int64(), ctypes.c_int64()
+            nbytes = L.mpqe_p2p_buffer_bytes(self.capacity, self.world, ctypes.byref(so), ctypes.byref(fo))
+            if nbytes == 0:
+                raise RuntimeError('mpqe_p2p_buffer_bytes rejected capacity %d / world %d' % (self.capacity, self.world))
+            handle = ctypes.create_string_buffer(L.mpqe_p2p_handle_bytes())
+            ptr = ctypes.c_void_p()
+            with torch.cuda.device(self.device):
+                _capi.check(L, L.mpqe_p2p_alloc(nbytes, ctypes.byref(ptr), handle), 'mpqe_p2p_alloc')
+            self._own = ptr.value
+            handles = [None] * self.world
+            if self.world > 1:
+                dist.all_gather_object(handles, bytes(handle.raw), group=self.group)
+            else:
+                handles = [bytes(handle.raw)]
+            bufs = (ctypes.c_void_p * self.world)()
+            for p in range(self.world):
+                if p == self.rank:
+                    bufs[p] = self._own
+                    continue
+                m = ctypes.c_void_p()
+                with torch.cuda.device(self.device):
+                    _capi.check(L, L.mpqe_p2p_open(handles[p], ctypes.byref(m)), 'mpqe_p2p_open (rank %d)' % p)
+                self._mapped.append(m.value)
+                bufs[p] = m.value
+            self._bufs = bufs
+            self.bucket = torch.as_tensor(_Blob(self._own, self.capacity), device=self.device)
+            self.ok = True
+        except Exception as e:            # noqa: BLE001 -- any failure: the caller keeps to RCCL
+            self.reason = '%s: %s' % (type(e).__name__, e)
+        # every rank must agree (one rank without its buffers would leave the others waiting)
+        self.ok = self._all_agree(self.ok)
+        if self.ok and self_test and self.world > 1:
+            self.ok = self._self_test()
+
+    def _all_agree(self, flag):
+        if self.world == 1:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        if dist.get_backend(self.group) != 'gloo':
+            t = t.to(self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.item()))
+
+    def _self_test(self):
+        """One exchange of a rank-dependent pattern against torch.distributed's all-reduce (ragged size: the last shard is
+        short). Collective."""
+        n = max(1, min(self.capacity, 100003))
+        g = torch.Generator(device='cpu').manual_seed(1234 + self.rank)
+        mine = torch.randn(n, generator=g)
+        self.bucket[:n].copy_(mine.to(self.device))
+        try:
+            self.all_reduce(n)
+            torch.cuda.synchronize(self.device)
+            got = self.bucket[:n].cpu()
+            flags = int(self.err.item())
+        except Exception as e:            # noqa: BLE001
+            self.reason = 'self test: %s: %s' % (type(e).__name__, e)
+            return self._all_agree(False)
+        ref = mine.clone()
+        if dist.get_backend(self.group) == 'gloo':
+            dist.all_reduce(ref, group=self.group)
+        else:
+            r = ref.to(self.device)
+            dist.all_reduce(r, group=self.group)
+            ref = r.cpu()
+        good = flags == 0 and bool(torch.allclose(got, ref, rtol=1e-6, atol=1e-6))
+        if not good:
+            self.err.zero_()
+            self.reason = 'self test: flags %d, max abs diff %.3g' % (flags, float((got - ref).abs().max()))
+        return self._all_agree(good)
+
+    def all_reduce(self, n=None):
+        """bucket[:n] <- sum over ranks, on the current stream (no host synchronisation)."""
+        n = self.capacity if n is None else int(n)
+        self.epoch = self.epoch % 0x7fffffff + 1
+        L = ops.lib()
+        with torch.cuda.device(self.device):
+            st = L.mpqe_p2p_allreduce(self._bufs, self.rank, self.world, self.capacity, n, self.epoch, 7, self.err.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream)
+        _capi.check(L, st, 'mpqe_p2p_allreduce')
+
+    def check(self):
+        """RuntimeError if a peer did not arrive within the bound in an earlier exchange (one D2H read)."""
+        ops.raise_on_flags(self.err)
+
+    def close(self):
+        L = ops.lib()
+        torch.cuda.synchronize(self.device)
+        if self.world > 1 and dist.is_initialized():
+            dist.barrier(group=self.group)           # nobody unmaps a buffer a peer's kernel may still write
+        for m in self._mapped:
+            L.mpqe_p2p_close(m)
+        self._mapped = []
+        if self._own is not None:
+            L.mpqe_p2p_free(self._own)
+            self._own = None
+        self.ok = False

@@ -181,7 +181,12 @@ class StepExchange(object):
     DENSE_TABLE_BYTES = 32 << 20
     DENSE_FRACTION = 0.6
 
-    def __init__(self, fused_step, group=None, tables='auto'):
+    def __init__(self, fused_step, group=None, tables='auto', transport='rccl'):
+        """transport: how the bucket is summed -- 'rccl': torch.distributed's all-reduce (RCCL over xGMI; gloo in the
+        one-GPU tests); 'p2p': the library's one-hop reduce-scatter + all-gather over peer-mapped buffers
+        (mpqe_amd/p2p.py, csrc/p2p.hip: every link carries one shard each way instead of a ring's 2 (w - 1) serial hops),
+        set up and self-tested against the all-reduce here (collective), falling back to 'rccl' -- `transport_note` says
+        why -- if the buffers cannot be mapped or the self-test fails."""
         self.fused = fused_step
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -214,6 +219,18 @@ class StepExchange(object):
         if self.table_mode == 'rows' and fused_step.touch_mode not in ('pack', 'step'):
             raise ValueError("the row exchange plans with the touch plan's keys: FusedTrainStep(touch='step' | 'pack')")
         self._plans = {}
+        if transport not in ('rccl', 'p2p'):
+            raise ValueError("transport: 'rccl' or 'p2p'")
+        self.transport, self.transport_note, self.peer = 'rccl', None, None
+        if transport == 'p2p' and self.world > 1:
+            from .p2p import PeerExchange
+            cap = sum(p.numel() for p in fused_step.params
+                      if self.table_mode == 'dense' or id(p) not in self.table_ids)
+            self.peer = PeerExchange(cap, group=group, device=self.dev)
+            if self.peer.ok:
+                self.transport = 'p2p'
+            else:
+                self.transport_note = 'p2p exchange unavailable (%s): RCCL all-reduce used' % (self.peer.reason or 'a peer failed')
         import ctypes
         self._tab_g = (ctypes.c_void_p * len(self.tables))(
             *[fused_step.flat_grad.data_ptr() + 4 * self.off[id(t)] for t in self.tables])
@@ -336,7 +353,18 @@ class StepExchange(object):
         ep.in_step = in_step
         ep.send_keys = ep.all_keys = ep.plan_ws = ep.plan_sizes = None
         nsel, nfull = sum(n for _, n in merged), sum(n for _, n in spans)
-        if nsel >= self.DENSE_FRACTION * nfull:
+        if self.transport == 'p2p':
+            # the bucket IS the head of the peer-mapped communication buffer: copied in, summed in place by the one-hop
+            # exchange, copied back
+            ep.form = 'p2p'
+            ep.grad_views = [f.flat_grad[o:o + n] for o, n in merged]
+            ep.bucket = self.peer.bucket[:nsel]
+            ep.bucket_views, o = [], 0
+            for _, n in merged:
+                ep.bucket_views.append(ep.bucket[o:o + n])
+                o += n
+            ep.bucket_bytes = 4 * nsel
+        elif nsel >= self.DENSE_FRACTION * nfull:
             # most of the gradient is touched by some rank: all-reduce the parameter spans where they lie, no copies
             ep.form = 'dense'
             ep.grad_views = [f.flat_grad[o:o + n] for o, n in spans]
@@ -351,7 +379,7 @@ class StepExchange(object):
                 o += n
             ep.bucket_bytes = 4 * nsel
         w = self.world
-        ep.wire_bytes = int(2 * (w - 1) / max(w, 1) * ep.bucket_bytes)
+        ep.wire_bytes = int(2 * (w - 1) / max(w, 1) * ep.bucket_bytes)      # (ring and one-hop move the same bytes; the hops differ)
         ep.n_own = ep.cap = ep.entries = 0
         ep.gidx = ep.send = ep.recv = ep.plan = ep.plan_ptr = None
         if not rows:
@@ -482,6 +510,10 @@ class StepExchange(object):
         if ep.form == 'dense':
             for v in ep.grad_views:
                 self._all_reduce(v)
+        elif ep.form == 'p2p':
+            torch._foreach_copy_(ep.bucket_views, ep.grad_views)
+            self.peer.all_reduce(ep.bucket.numel())
+            torch._foreach_copy_(ep.grad_views, ep.bucket_views)
         elif ep.bucket.numel():
             torch._foreach_copy_(ep.bucket_views, ep.grad_views)
             self._all_reduce(ep.bucket)

@@ -28,6 +28,7 @@ def main():
     outdir, sparse, tables = sys.argv[1], sys.argv[2] == '1', sys.argv[3]
     readout = sys.argv[4] if len(sys.argv) > 4 else 'mp'
     touch = sys.argv[5] if len(sys.argv) > 5 else ('pack' if tables == 'rows' else 'step')
+    transport = sys.argv[6] if len(sys.argv) > 6 else 'rccl'
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     # MPQE_DP_BACKEND=nccl: one rank per GPU over RCCL (needs `world` visible devices); default: gloo through the host,
     # every rank on cuda:0 (what a one-GPU box can run)
@@ -59,7 +60,9 @@ def main():
     # the all-reduce and the step builds its touch plan itself (the default)
     step = FusedTrainStep(model, sparse_tables=sparse, touch=touch)
     packed = step.pack(batches_of(schema, rank, B, 1.0 / world))
-    ex = StepExchange(step, tables=tables)
+    ex = StepExchange(step, tables=tables, transport=transport)
+    if transport == 'p2p':
+        assert ex.transport == 'p2p', ex.transport_note
     plan = ex.plan(packed, key='set0')
     if tables == 'dense' or touch == 'step':
         assert ex.plan(packed, key='set0', verify=True) is plan          # a recurring key: the cached plan (verified across ranks)
@@ -75,6 +78,8 @@ def main():
     step.run(packed)
     ex.reduce(plan, packed=packed)
     step.check()
+    if ex.peer is not None:
+        ex.peer.check()
     torch.cuda.synchronize()
     out = dict(flat=step.flat_grad.cpu().numpy(), wire=np.array([plan.wire_bytes]), dense=np.array([step.flat_grad.numel() * 4]))
     out['form'] = np.array([plan.form])
@@ -100,6 +105,8 @@ def main():
         torch.cuda.synchronize()
         out['params'] = opt.flat_param.cpu().numpy()
     np.savez(os.path.join(outdir, 'rank%d.npz' % rank), **out)
+    if ex.peer is not None:
+        ex.peer.close()
     dist.destroy_process_group()
 
 

@@ -140,3 +140,37 @@ def test_row_sparse_table_exchange_equals_dense_allreduce():
         assert 0 < nbytes < 57 * 8 * 4 * world
     for t in range(2):      # replicas agree bit for bit
         np.testing.assert_array_equal(out[0][0][t].numpy(), out[1][0][t].numpy())
+
+
+def test_peer_exchange_kernels_phase_by_phase():
+    """csrc/p2p.hip on the CPU emulator, all ranks in ONE process: the buffers are plain host arrays, the phases of the
+    exchange run rank after rank (push of every rank, then reduce of every rank, then wait) -- what the kernels index and
+    sum, ragged sizes included; the cross-process part (IPC mapping, concurrent kernels) is tests/test_parallel_gpu.py's."""
+    import ctypes
+    from tests.kernel_backend import EmuBackend
+    be = EmuBackend()
+    rng = np.random.RandomState(5)
+    for world, cap, n in ((2, 1000, 1000), (3, 4099, 4097), (8, 5000, 37), (4, 64, 64)):
+        so, fo = ctypes.c_int64(), ctypes.c_int64()
+        nbytes = be.lib.mpqe_p2p_buffer_bytes(cap, world, ctypes.byref(so), ctypes.byref(fo))
+        assert nbytes > 0 and so.value % 256 == 0 and fo.value % 256 == 0
+        raw = [np.zeros(nbytes // 4 + 64, np.float32) for _ in range(world)]
+        ptrs = [(r.ctypes.data + 255) // 256 * 256 for r in raw]
+        views = [np.frombuffer((ctypes.c_char * nbytes).from_address(p), dtype=np.float32) for p in ptrs]
+        data = [rng.randn(n).astype(np.float32) for _ in range(world)]
+        for epoch in (1, 2):
+            for r in range(world):
+                views[r][:n] = data[r] * epoch
+                views[r][n:cap] = 7.0                      # beyond n: not part of the exchange
+            bufs = (ctypes.c_void_p * world)(*ptrs)
+            err = be.zeros((1,), np.int32)
+            for phase in (1, 2, 4):
+                for r in range(world):
+                    be.check(be.lib.mpqe_p2p_allreduce(bufs, r, world, cap, n, epoch, phase, be.ptr(err), be.stream), 'p2p')
+            assert int(be.get(err)[0]) == 0
+            ref = data[0] * epoch
+            for r in range(1, world):
+                ref = ref + data[r] * epoch                # rank order: the kernel's order
+            for r in range(world):
+                np.testing.assert_array_equal(views[r][:n], ref)
+                assert (views[r][n:cap] == 7.0).all()

@@ -44,14 +44,23 @@ def test_two_ranks_equal_single_process_rccl(tmp_path, sparse, tables, readout, 
     _two_ranks(tmp_path, sparse, tables, readout, touch, 'nccl')
 
 
-def _two_ranks(tmp_path, sparse, tables, readout, touch, backend):
+@pytest.mark.parametrize('sparse,tables,readout,touch', [CASES[4], CASES[3]])
+def test_two_ranks_peer_mapped_exchange(tmp_path, sparse, tables, readout, touch):
+    """The bucket summed by the library's one-hop exchange over IPC-mapped peer buffers (csrc/p2p.hip) instead of the
+    all-reduce: two processes on the ONE GPU of the box map each other's communication buffers (hipIpcGetMemHandle /
+    hipIpcOpenMemHandle work between processes of one device); same assertions as above -- the reduced gradient is the
+    single-process gradient of both ranks' batches, the replicas agree bit for bit."""
+    _two_ranks(tmp_path, sparse, tables, readout, touch, 'gloo', transport='p2p')
+
+
+def _two_ranks(tmp_path, sparse, tables, readout, touch, backend, transport='rccl'):
     world, port = 2, _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY='0', MPQE_DP_BACKEND=backend)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'dp_worker.py'), str(tmp_path), str(sparse), tables,
-                                       readout, touch], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+                                       readout, touch, transport], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
@@ -78,6 +87,8 @@ def _two_ranks(tmp_path, sparse, tables, readout, touch, backend):
         # more than this 60-entity KG's whole tables; the sizes it is for have 10^5 .. 10^6 rows)
         assert r[0]['wire'][0] <= r[0]['dense'][0], (r[0]['wire'], r[0]['dense'])   # (tiny KG, 8 relations: most are in the union)
     assert str(r[0]['form'][0]) == str(r[1]['form'][0])
+    if transport == 'p2p':
+        assert str(r[0]['form'][0]) == 'p2p'
 
 
 @pytest.mark.skipif(_gpus() < 2, reason='RCCL needs one GPU per rank: fewer than 2 GPUs visible on this box')
