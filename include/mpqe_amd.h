@@ -326,6 +326,8 @@ int mpqe_hinge_bwd(const float *pos, const float *neg, int64_t n, float margin, 
  *             backward: encoders.py:40-43, data_utils.py:35). The level form has no use for a plan and leaves the buffer
  *             alone. Steps of more than 524 288 looked-up ids, or split over stream lanes, return MPQE_ERR_UNSUPPORTED:
  *             build the plan with mpqe_step_touch_build instead.                                              */
+/*             The plan buffer must be ZERO-FILLED once, before its first use as an output: a build that gives up
+ *             (MPQE_FLAG_TOUCH_RETRY) leaves it as it was, and the step's last launch reads plan entries before it knows. */
 #define MPQE_STEP_BUILD_TOUCH 512
 /* ADD_STATE_GRADS  (MPQE_READOUT_CALLER, PHASE_FROM_STATES) the caller's readout read the states of EVERY level 1 .. L_b
  *             (the reference's `concat` readout, model.py:441-446) and has written its d loss / d state into every row of

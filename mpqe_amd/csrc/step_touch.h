@@ -435,8 +435,10 @@ __global__ __launch_bounds__(TSORT_THREADS) void touch_sort_kernel(TSortArgs sa)
 // (M, row_bits: the plan header's fields, by value where the caller knows them -- the fused step does: one round trip less
 // in front of the keys)
 // failed != NULL: a word that is non-zero when the plan could not be built (the header's pad[0] of a plan the step built
-// itself: step.hip) -- nothing is stored then; the word travels with the first keys, and every permutation entry is
-// clamped into [0, M), so a garbage plan costs wrong loads at valid addresses and no store at all.
+// itself: step.hip) -- nothing is stored then; the word travels with the first keys. The LOADS are made before it is
+// known: a plan buffer must therefore hold valid entries at all times -- the caller zero-fills it once, before its first
+// use (entry 0 / key 0 are valid), and a build that gives up leaves what an earlier build or the fill left there. (Clamping
+// every permutation entry instead cost the reduction launch ~1 us.)
 template <class TabsT>
 __device__ __forceinline__ void table_sum_block(long long M, int row_bits, const tkey_t *__restrict__ keys,
                                                 const int *__restrict__ perm, const float *__restrict__ DG, int D,
@@ -447,20 +449,19 @@ __device__ __forceinline__ void table_sum_block(long long M, int row_bits, const
     const int c = (threadIdx.x % lpr) * 4;
     if (k >= M) return;
     const int bad = failed ? *failed : 0;
-    auto inside = [M](long long p) { return p < 0 ? 0ll : (p >= M ? M - 1 : p); };
     // ONE round trip for everything that depends on k alone: my key, my predecessor's, and the keys / permutation entries of
     // the next TS_AHEAD positions (a run is ~8 rows long on the AIFB step); a second one for the rows. (Requested one after
     // the other -- key, then permutation entry, then row, then the next keys ... -- a run cost five dependent round trips.)
     const tkey_t key = keys[k];
     const tkey_t prev = k > 0 ? keys[k - 1] : TOUCH_INVALID;
-    const long long p0 = perm ? inside((long long)perm[k]) : k;
+    const long long p0 = perm ? (long long)perm[k] : k;
     tkey_t kk[TS_AHEAD];
     long long pj[TS_AHEAD];
 #pragma unroll
     for (int q = 0; q < TS_AHEAD; ++q) {
         const long long j = k + 1 + q < M ? k + 1 + q : M - 1;
         kk[q] = keys[j];
-        pj[q] = perm ? inside((long long)perm[j]) : j;
+        pj[q] = perm ? (long long)perm[j] : j;
     }
     if (bad || key == TOUCH_INVALID || (k > 0 && prev == key)) return;
     f32x4 acc = gload4(DG + p0 * D + c);
@@ -485,7 +486,7 @@ __device__ __forceinline__ void table_sum_block(long long M, int row_bits, const
                 for (int q = 0; q < TS_AHEAD; ++q) {
                     const long long j = j0 + q < M ? j0 + q : M - 1;
                     k2[q] = keys[j];
-                    p2[q] = perm ? inside((long long)perm[j]) : j;
+                    p2[q] = perm ? (long long)perm[j] : j;
                 }
                 f32x4 w[TS_AHEAD];
 #pragma unroll
@@ -532,12 +533,11 @@ __device__ __forceinline__ void table_sum_multi(long long M, int row_bits, const
     if (base >= M) return;
     tkey_t *lk = reinterpret_cast<tkey_t *>(lds);            // keys of positions base - 1 + q
     int *lp = reinterpret_cast<int *>(lds + 2 * WIN);        // entries (rows of DG) of the same positions
-    auto inside = [M](long long p) { return p < 0 ? 0ll : (p >= M ? M - 1 : p); };
     for (int q = threadIdx.x; q < WIN; q += 256) {
         const long long pos = base - 1 + q;
         const bool in = pos >= 0 && pos < M;
         lk[q] = in ? keys[pos] : TOUCH_INVALID;
-        lp[q] = (int)(in ? (perm ? inside((long long)perm[pos]) : pos) : 0);
+        lp[q] = (int)(in ? (perm ? (long long)perm[pos] : pos) : 0);
     }
     const int bad = failed ? *failed : 0;
     __syncthreads();
@@ -549,7 +549,7 @@ __device__ __forceinline__ void table_sum_multi(long long M, int row_bits, const
     };
     auto E = [&](long long pos) -> long long {
         const long long q = pos - (base - 1);
-        return q < WIN ? (long long)lp[q] : (perm ? inside((long long)perm[pos]) : pos);
+        return q < WIN ? (long long)lp[q] : (perm ? (long long)perm[pos] : pos);
     };
     const int g = threadIdx.x / lpr, c = (threadIdx.x % lpr) * 4;
     const long long own0 = base + (long long)g * TSM_OWN;

@@ -489,7 +489,8 @@ class FusedTrainStep(object):
         ps.anchor_ids, ps.targets, ps.negs = dev[:na], dev[na:na + ngr], dev[na + ngr:]
         if self.touch:
             if bufs.touch is None:
-                bufs.touch = torch.empty(sz[2] + 256, dtype=torch.uint8, device=self.device)
+                # (zero-filled once: the step reads plan entries before it knows whether its own build finished, include/mpqe_amd.h)
+                bufs.touch = torch.zeros(sz[2] + 256, dtype=torch.uint8, device=self.device)
                 bufs.touch_ptr = (bufs.touch.data_ptr() + 255) // 256 * 256
             ps.touch, ps.touch_ptr = bufs.touch, bufs.touch_ptr
             if mode == 'pack':
@@ -510,7 +511,7 @@ class FusedTrainStep(object):
         if nbytes == 0:
             raise _capi.MpqeError('mpqe_step_touch_bytes rejected the step descriptors')
         if ps.touch is None:
-            ps.touch = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            ps.touch = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.device)
             ps.touch_ptr = (ps.touch.data_ptr() + 255) // 256 * 256
         # (build workspace: ONE buffer per step object, grown on demand -- every build runs on the current stream, so the
         # next build's kernels are ordered behind this one's; pack time is host time, and an allocation + record_stream
