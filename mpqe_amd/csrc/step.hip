@@ -988,6 +988,7 @@ struct ReduceArgs {
     // wait until `arrive` has counted the launch's `phase1` tile and vector-op workgroups; NULL: a launch of its own
     const unsigned *arrive;
     unsigned phase1;
+    int rows_multi;          // 1: the entity-table workgroups take a range of sorted positions each (table_sum_multi)
     int early;               // 1: the loss and the entity-table rows were roles of the weight-gradient launch (TailArgs.extra0):
                              // the loss workgroup here only closes the step (epochs, the sort's barrier word, the plan's failure flag)
 };
@@ -1006,6 +1007,16 @@ __device__ __forceinline__ void reduce_block(const ReduceArgs &ra, int bx, int b
     if (by > ngroups) {        // further rows: entity-table gradients, per destination row (step_touch.h).
         // (As workgroups of the weight-gradient launch they are throttled to two per CU by its 64 KB of LDS: 23.6 us
         // for that launch instead of 16.6; here they cost 2.6 us.)
+        if (ra.rows_multi) {
+            // a RANGE of sorted positions per workgroup (step_touch.h: table_sum_multi): 344 workgroups for the AIFB step's
+            // 22 016 ids, all resident at once, instead of 2 752 one-run workgroups in two and a half rounds of the chip
+            static_assert(sizeof(f32x4) * 4 * 64 >= TSM_LDS_WORDS(64) * 4, "table_sum_multi's window lives in the reduction's LDS");
+            table_sum_multi(ra.touch_M, ra.touch_row_bits, reinterpret_cast<const tkey_t *>(touch + ra.touch_keys),
+                            reinterpret_cast<const int *>(touch + ra.touch_perm), ra.DG, D, ra.tabs, table_store & 1,
+                            (long long)(by - ngroups - 1) * gx + bx, &reinterpret_cast<const TouchHeader *>(touch)->pad[0],
+                            reinterpret_cast<unsigned *>(part));
+            return;
+        }
         table_sum_block(ra.touch_M, ra.touch_row_bits, reinterpret_cast<const tkey_t *>(touch + ra.touch_keys),
                         reinterpret_cast<const int *>(touch + ra.touch_perm), ra.DG, D, ra.tabs, table_store & 1,
                         (long long)(by - ngroups - 1) * gx + bx, &reinterpret_cast<const TouchHeader *>(touch)->pad[0]);
@@ -3555,8 +3566,12 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     const long long r_elems = (long long)D * D;
     const unsigned r_gx = (unsigned)((r_elems + 255) / 256);
     unsigned r_trows = 0;         // entity-table gradient rows: 256 / (D / 4) sorted positions per workgroup
+    // (mpqe_debug_option ROWS_MULTI: a range of sorted positions per table workgroup, 344 instead of 2 752 workgroups for the
+    // AIFB step -- measured 3 us SLOWER per step: a range is 3 - 4 dependent round trips per lane group where 2 752
+    // independent one-run workgroups, two rounds of the chip at 6 waves per SIMD, need two each)
+    const bool rows_multi = use_touch && D % 4 == 0 && 256 % (D / 4) == 0 && D >= 64 && dbg_on("ROWS_MULTI");
     if (use_touch && !(STEP_DBG & 1)) {
-        const long long per = 256 / (D / 4), tblk = (hp.touch_M + per - 1) / per;
+        const long long per = rows_multi ? (256 / (D / 4)) * TSM_OWN : 256 / (D / 4), tblk = (hp.touch_M + per - 1) / per;
         r_trows = (unsigned)((tblk + r_gx - 1) / r_gx);
     }
     ra.groups = reinterpret_cast<const RGroup *>(db + hp.o_groups);
@@ -3583,6 +3598,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     ra.table_store = ((sparse_tables || (P->flags & MPQE_STEP_ZERO_GRADS)) ? 1 : 0) | (merged ? 2 : 0);
     ra.touch_M = (long long)hp.touch_M;
     ra.touch_row_bits = touch_row_bits;
+    ra.rows_multi = rows_multi ? 1 : 0;
     ra.err = err;
     const bool fuse_tail = use_chain && backward && !merged && NL == 1 && D % 64 == 0 && dbg_on("FUSE_TAIL");
     // split tail launch of the chain form: the loss and the entity-table rows depend on the chain launch alone -- they run as

@@ -553,7 +553,8 @@ def test_fused_step_chain_kernels(be, D, readout, adaptive, shared, L):
         # where the loss and the entity-table rows of the split form run: in the reduction launch (default), or as trailing
         # workgroups of the weight-gradient launch (EARLY_ROWS: table_sum_multi, a range of sorted positions per workgroup;
         # measured slower, kept as a switch) -- the same additions in the same order, bit for bit
-        for opt in (b'EARLY_ROWS',):
+        # ... and the reduction's table workgroups taking a range of positions each (ROWS_MULTI; default: one run each)
+        for opt in (b'EARLY_ROWS', b'ROWS_MULTI'):
             be.lib.mpqe_debug_option(opt, 1, 1)
             try:
                 other = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_SPLIT_TAIL)
