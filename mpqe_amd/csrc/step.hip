@@ -281,6 +281,8 @@ struct PrepArgs {
     int sna;                  // launch runs on XCD b % 8): the first sblocks = 8 x rows workgroups of the launch are ROWS of
     unsigned sxrank;          // eight -- the sort's XCDs take sort workgroups, the others go on with the prologue's items
     int strail;               // != 0: the launch's LAST strail workgroups instead (diagnostics switch TSORT_TRAIL)
+    int late;                 // diagnostics ("HANDOFF_LATE"): the first transpose workgroup counts itself in ~1 s late -- a producer
+                              // that lost its CU to another process: its consumers' bounded waits run out (MPQE_FLAG_INTERNAL)
     unsigned *tail_arrive;    // fused tail: the arrival counter of the step's weight-gradient launch, zeroed here; or NULL
     int ublocks, tblocks;     // vector-op workgroups, transpose workgroups
     int lead;                 // prologue workgroups in front of the chain workgroups: sblocks + ublocks + tblocks rounded
@@ -457,6 +459,10 @@ __global__ __launch_bounds__(64 * NW) void step_chain_kernel(const StepDev *__re
                 if (threadIdx.x == 0) atomicAdd(pa.fwd_done, 1u);
             }
         } else if (bid < pa.ublocks + pa.tblocks) {
+#ifndef MPQE_EMU
+            if (pa.late && bid == pa.ublocks)
+                for (int q = 0; q < (1 << 18); ++q) __builtin_amdgcn_s_sleep(127);      // (~1 s: 2^18 x 8 128 cycles; uniform)
+#endif
             prep_transpose_block(lp, pa, D, bid - pa.ublocks, S.xs);
         }       // (else: padding)
     } else if (po.zpad == 0 || bid < po.zpad) {
@@ -3504,6 +3510,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             pa.WT = WT;
             pa.wt_count = epoch_f + 32;
             pa.tail_arrive = nullptr;      // (set below once the launch form is known)
+            pa.late = dbg_on("HANDOFF_LATE") ? 1 : 0;
             pa.fwd_done = merged && pa.ublocks > 0 ? epoch_f + 33 : nullptr;
             pa.ua.vt_through = merged ? 1 : 0;
         } else if (zblocks > 0) {

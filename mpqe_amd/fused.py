@@ -199,6 +199,7 @@ class FusedTrainStep(object):
         # descriptor sets whose in-step touch plan failed once (run(checked=True)): their plans are built by pack() from then on
         self._pack_touch_sets = set()
         self.touch_retries = 0
+        self.handoff_retries = 0           # steps run(checked=True) ran again in the level form (an in-launch hand-off timed out)
         self.num_lanes = max(1, min(int(lanes), _capi.STEP_MAX_LANES))
         self._streams = [None] + [torch.cuda.Stream(device=self.device) for _ in range(self.num_lanes - 1)]
         self._fork = torch.cuda.Event()
@@ -627,6 +628,16 @@ class FusedTrainStep(object):
                                                 packed.desc_ptr, wptr, packed.ws_bytes, packed.touch_ptr, stream.cuda_stream)
                 _capi.check(L, st, 'mpqe_step_table_rows')
                 flags &= ~_capi.FLAG_TOUCH_RETRY
+            if flags & _capi.FLAG_INTERNAL and not (flags & 0xf) and backward and zero_grad and not self.learned:
+                # An in-launch hand-off between workgroups timed out (a producer lost its CU to another process: one process
+                # per GPU is what the chain form is built for). What the launches left in the gradient buffers is not to be
+                # trusted; the LEVEL form (one launch per message-passing level, include/mpqe_amd.h MPQE_STEP_NO_CHAIN) hands
+                # nothing from workgroup to workgroup inside a launch: the step runs again there, into the same buffers --
+                # slower, never wrong. (Without the call's own zero fill the garbage cannot be taken back: that raises.)
+                self.err.fill_(flags & ~(_capi.FLAG_INTERNAL | 0xff00))
+                self.handoff_retries += 1
+                self._rerun_level_form(packed, loss, sp, sn, stream)
+                flags = int(self.err.item())
             if flags:
                 ops.raise_on_flags(self.err)
         if packed.ids_ref is bufs.stage and bufs.stage is not None and not packed.captured:
@@ -636,6 +647,30 @@ class FusedTrainStep(object):
         if scores:
             return loss, sp, sn
         return loss
+
+    def _rerun_level_form(self, packed, loss, sp, sn, stream):
+        """The packed step once more through the level form (no in-launch hand-offs), forward + backward with the call's own
+        zero fill, into the same loss / score / gradient buffers. Its plan, descriptor table and workspace are its own."""
+        L = ops.lib()
+        self.P.flags = (self.flags | _capi.STEP_NO_CHAIN | _capi.STEP_ZERO_GRADS) & ~(_capi.STEP_SPARSE_TABLES | _capi.STEP_MERGE_TAIL |
+                                                                                    _capi.STEP_SPLIT_TAIL)
+        if self.sparse_tables:
+            raise _capi.MpqeError('an in-launch hand-off timed out and row-sparse table gradients have no level form to fall back to')
+        wsb = L.mpqe_step_workspace_bytes(ctypes.byref(self.P), packed.batches, packed.nb, None)
+        dsb = L.mpqe_step_desc_bytes(ctypes.byref(self.P), packed.batches, packed.nb, None)
+        if wsb == 0 or dsb == 0:
+            raise _capi.MpqeError('the level form rejected the step descriptors')
+        ws = torch.empty(wsb + 256, dtype=torch.uint8, device=self.device)
+        desc = torch.empty(dsb + 256, dtype=torch.uint8, device=self.device)
+        args = (ctypes.byref(self.P), packed.batches, packed.nb, packed.anchor_ids.data_ptr(), packed.targets.data_ptr(),
+                packed.negs.data_ptr(), self.margin, ctypes.byref(self.G), 1, loss.data_ptr(),
+                None if sp is None else sp.data_ptr(), None if sn is None else sn.data_ptr(),
+                (desc.data_ptr() + 255) // 256 * 256, dsb, 1, (ws.data_ptr() + 255) // 256 * 256, wsb, self.err.data_ptr(), None,
+                None, 0, None, stream.cuda_stream)
+        with torch.cuda.device(self.device):
+            st = L.mpqe_step_forward_backward(*args)
+        _capi.check(L, st, 'mpqe_step_forward_backward (level form)')
+        torch.cuda.synchronize(self.device)          # (ws / desc are this call's own: they must outlive its launches)
 
     def capture(self, packed, backward=True, zero_grad=True):
         """Record one step on `packed` into a hipGraph. Returns a CapturedStep: .replay() re-runs the step on

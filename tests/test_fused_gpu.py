@@ -151,6 +151,44 @@ def test_fused_step_bad_id_is_reported():
         step.check()
 
 
+def test_checked_run_survives_a_late_producer():
+    """The chain form hands vectors and transposed weights from workgroup to workgroup inside a launch; every wait is
+    bounded. A producer that arrives ~1 s late (forced: HANDOFF_LATE -- what a co-tenant on the GPU can do) makes its
+    consumers give up: run(checked=True) must then deliver the step all the same -- through the level form, which has no
+    in-launch hand-off -- and the next, undisturbed step must run on the chain form as if nothing had happened."""
+    from mpqe_amd import ops
+    from mpqe_amd.fused import FusedTrainStep
+    model, batches = _setup('mp', True, False, D=64, B=96)
+    step = FusedTrainStep(model)
+    packed = step.pack(batches)
+    loss0 = step.run(packed, checked=True).clone()
+    good = {k: p.grad.clone() for k, p in model.named_parameters()}
+    lib = ops.lib()
+    lib.mpqe_debug_option(b'HANDOFF_LATE', 1, 1)
+    try:
+        for p in model.parameters():
+            p.grad.fill_(5.0)
+        step.run(packed)
+        with pytest.raises(RuntimeError, match='hand-off'):
+            step.check()                                   # unchecked: named a step later, never silently consumed
+        for p in model.parameters():
+            p.grad.fill_(5.0)
+        loss = step.run(packed, checked=True)
+        assert step.handoff_retries == 1
+    finally:
+        lib.mpqe_debug_option(b'HANDOFF_LATE', 0, 0)
+    np.testing.assert_allclose(loss.cpu().numpy(), loss0.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    for k, p in model.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), good[k].cpu().numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+    for p in model.parameters():
+        p.grad.fill_(5.0)
+    again = step.run(packed, checked=True)                 # the late workgroup has counted itself in meanwhile
+    assert step.handoff_retries == 1
+    assert torch.equal(again, loss0)
+    for k, p in model.named_parameters():
+        assert torch.equal(p.grad, good[k]), k
+
+
 @pytest.mark.parametrize('sparse', [False, True])
 def test_checked_run_recovers_a_failed_in_step_touch_plan(sparse):
     """FusedTrainStep.run(checked=True): a step whose own touch plan could not be built (forced: TSORT_FAIL) is recovered
