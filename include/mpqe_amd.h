@@ -565,8 +565,8 @@ void mpqe_debug_chain_stamps(void *device_buffer, size_t num_blocks);
  * ticks start -> end [2], HW_ID | XCC_ID << 32 in [3], wall clock when the tile's record is read [4], when its first
  * K-step has landed [5] and when its K loop ends [6].                                                */
 void mpqe_debug_tail_stamps(void *device_buffer, size_t num_blocks);
-/* Named diagnostics switches (timing experiments; tests that force a rarely taken path, e.g. "TOUCH_ROCPRIM" = the
- * library sort instead of the one-launch sort, "TSORT_FAIL" = the in-step sort gives up as if its workgroups were not
+/* Named diagnostics switches (timing experiments; tests that force a rarely taken path, e.g. "TOUCH_MULTI_LAUNCH" = the
+ * multi-launch sort (csrc/radix_sort.h) instead of the one-launch sort, "TSORT_FAIL" = the in-step sort gives up as if its workgroups were not
  * co-resident, "GEN_SLOTS" = grid size of the persistent gather-GEMMs). set != 0
  * stores `value` under `name`, set == 0 removes it. Process-global (see Conventions).                    */
 void mpqe_debug_option(const char *name, int value, int set);

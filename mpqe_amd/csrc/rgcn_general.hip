@@ -2,7 +2,7 @@
 // edge_type), reference mpqe/model.py:269-305): duplicate edges, self loops, isolated
 // nodes, unused relations.
 //
-//   plan     sort edges once per graph (rocPRIM LSD radix sort, stable):
+//   plan     sort edges once per graph (radix_sort.h: the library's own LSD radix sort, stable):
 //              by relation   -> message slots p in [0,E), grouped so that one MFMA tile
 //                               multiplies 64 gathered rows by ONE relation matrix;
 //                               slots [E, E+Nn) are the self/root term of every node
@@ -16,7 +16,7 @@
 //   backward gmsg[p] = gpre[drow(p)] . W[rel(p)]^T ; grad_x[i] = gmsg[E+i] + sum CSR_src(i)
 //            grad W[r] = sum_{p in rel r} x[row(p)]^T (x) gpre[drow(p)]   split over K chunks,
 //            slabs reduced in fixed order.
-#include <rocprim/device/device_radix_sort.hpp>
+#include "radix_sort.h"
 
 #include "bias_grad.h"
 #include "gemm_core.h"
@@ -148,10 +148,8 @@ struct PlanWs {
     size_t key_rel, key_dst, key_src, iota, key_out, perm, pos, sort_tmp, sort_bytes, total;
 };
 static size_t sort_tmp_bytes(int64_t E, int bits) {
-    size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const int *)nullptr, (int *)nullptr, (const int *)nullptr,
-                              (int *)nullptr, (size_t)E, 0u, (unsigned)bits, (hipStream_t) nullptr);
-    return bytes;
+    (void)bits;
+    return radix_sort_tmp_bytes<int>((long long)E);
 }
 static PlanWs plan_ws_layout(int64_t Nn, int64_t E, int64_t R) {
     PlanWs w;
@@ -217,8 +215,7 @@ extern "C" int mpqe_rgcn_plan_build(const int64_t *edge_index, const int64_t *ed
         hipLaunchKernelGGL(plan_prep_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s,
                            (const long long *)edge_index, (const long long *)edge_type, (long long)Nn, (long long)E,
                            (long long)R, key_rel, key_dst, key_src, iota, err);
-        if (rocprim::radix_sort_pairs(tmp, tmp_bytes, (const int *)key_rel, key_out, (const int *)iota, perm,
-                                      (size_t)E, 0u, (unsigned)bits_for(R), s) != hipSuccess)
+        if (radix_sort_pairs_own<int>(tmp, (const int *)key_rel, key_out, (const int *)iota, perm, (long long)E, bits_for(R), s))
             return MPQE_ERR_LAUNCH;
     }
     const long long slots = E + Nn;
@@ -233,16 +230,14 @@ extern "C" int mpqe_rgcn_plan_build(const int64_t *edge_index, const int64_t *ed
                        rel_ptr, tile_ptr, chunk_ptr);
     if (E > 0) {
         tmp_bytes = W.sort_bytes;
-        if (rocprim::radix_sort_pairs(tmp, tmp_bytes, (const int *)key_dst, key_out, (const int *)pos, dst_list,
-                                      (size_t)E, 0u, (unsigned)bits_for(Nn), s) != hipSuccess)
+        if (radix_sort_pairs_own<int>(tmp, (const int *)key_dst, key_out, (const int *)pos, dst_list, (long long)E, bits_for(Nn), s))
             return MPQE_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(plan_lower_bound_kernel, dim3((unsigned)((Nn + 1 + 255) / 256)), dim3(256), 0, s,
                        (const int *)key_out, (long long)E, (long long)Nn, dst_ptr);
     if (E > 0) {
         tmp_bytes = W.sort_bytes;
-        if (rocprim::radix_sort_pairs(tmp, tmp_bytes, (const int *)key_src, key_out, (const int *)pos, src_list,
-                                      (size_t)E, 0u, (unsigned)bits_for(Nn), s) != hipSuccess)
+        if (radix_sort_pairs_own<int>(tmp, (const int *)key_src, key_out, (const int *)pos, src_list, (long long)E, bits_for(Nn), s))
             return MPQE_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(plan_lower_bound_kernel, dim3((unsigned)((Nn + 1 + 255) / 256)), dim3(256), 0, s,

@@ -2985,7 +2985,7 @@ extern "C" int mpqe_step_touch_build(const mpqe_step_params_t *P, const mpqe_ste
     th.row_bits = rb;
     th.key_bits = kb;
     static_assert(sizeof(TouchMeta) <= 2048, "touch_layout reserves 2 KB for the batch table");
-    if (M <= TSORT_MAX_ENTRIES && kb <= 31 && !dbg_on("TOUCH_ROCPRIM") && !(P->flags & MPQE_STEP_TOUCH_LIBRARY_SORT)) {
+    if (M <= TSORT_MAX_ENTRIES && kb <= 31 && !dbg_on("TOUCH_MULTI_LAUNCH") && !(P->flags & MPQE_STEP_TOUCH_LIBRARY_SORT)) {
         // the whole plan in one launch (step_touch.h: tsort_block) behind the clear of its barrier counter and the
         // upload of the batch table
         const int nblk = tsort_blocks(M);
@@ -3027,11 +3027,10 @@ extern "C" int mpqe_step_touch_build(const mpqe_step_params_t *P, const mpqe_ste
                        reinterpret_cast<const long long *>(negs), reinterpret_cast<const long long *>(P->node_map),
                        (long long)P->node_map_len, keys, vals, reinterpret_cast<int *>(tb + L.erow), M, th,
                        reinterpret_cast<TouchHeader *>(tb));
-    size_t tmp_bytes = L.w_tmp_bytes;
-    // stable: entries of one destination row keep their entry order, so the per-row sums have ONE order
-    if (rocprim::radix_sort_pairs(wb + L.w_tmp, tmp_bytes, (const tkey_t *)keys, reinterpret_cast<tkey_t *>(tb + L.keys),
-                                  (const int *)vals, reinterpret_cast<int *>(tb + L.perm), (size_t)M, 0u, (unsigned)kb,
-                                  s) != hipSuccess)
+    // stable: entries of one destination row keep their entry order, so the per-row sums have ONE order (radix_sort.h: the
+    // library's own multi-launch sort -- nothing in it depends on how many workgroups are resident at once)
+    if (radix_sort_pairs_own<tkey_t>(wb + L.w_tmp, (const tkey_t *)keys, reinterpret_cast<tkey_t *>(tb + L.keys), (const int *)vals,
+                                     reinterpret_cast<int *>(tb + L.perm), (long long)M, kb, s))
         return MPQE_ERR_LAUNCH;
     return mpqe_launch_status();
 }
@@ -3116,10 +3115,8 @@ extern "C" int mpqe_rows_plan_build(const uint64_t *keys, int64_t n, int row_bit
     upload(s, tb, &th, sizeof(th));
     int *vals = reinterpret_cast<int *>(wb + L.w_vals);
     hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, vals, (long long)n);
-    size_t tmp_bytes = L.w_tmp_bytes;
-    if (rocprim::radix_sort_pairs(wb + L.w_tmp, tmp_bytes, reinterpret_cast<const tkey_t *>(keys),
-                                  reinterpret_cast<tkey_t *>(tb + L.keys), (const int *)vals,
-                                  reinterpret_cast<int *>(tb + L.perm), (size_t)n, 0u, (unsigned)key_bits, s) != hipSuccess)
+    if (radix_sort_pairs_own<tkey_t>(wb + L.w_tmp, reinterpret_cast<const tkey_t *>(keys), reinterpret_cast<tkey_t *>(tb + L.keys),
+                                     (const int *)vals, reinterpret_cast<int *>(tb + L.perm), (long long)n, key_bits, s))
         return MPQE_ERR_LAUNCH;
     return mpqe_launch_status();
 }

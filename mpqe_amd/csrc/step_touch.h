@@ -21,7 +21,7 @@
 //     row exchange plans with its keys) or whose steps exceed TSORT_MAX_ENTRIES.
 // Included by step.hip.
 #pragma once
-#include <rocprim/device/device_radix_sort.hpp>
+#include "radix_sort.h"
 
 typedef unsigned long long tkey_t;
 #define TOUCH_INVALID (~0ull)
@@ -80,9 +80,7 @@ static inline TouchLayout touch_layout(long long M, int key_bits /* 0: the devic
     off += align_up(Mp * sizeof(int), 256);
     L.w_hist = off;                                           // [4 passes][256 workgroups][256] digit counts, the barrier
     off += 4 * 256 * 256 * sizeof(unsigned) + 256 + 2048;     // counter (256 bytes), the batch table (TouchMeta, < 2 KB)
-    size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const tkey_t *)nullptr, (tkey_t *)nullptr, (const int *)nullptr,
-                                    (int *)nullptr, (size_t)(M > 0 ? M : 1), 0u, (unsigned)key_bits, (hipStream_t) nullptr);
+    const size_t bytes = radix_sort_tmp_bytes<tkey_t>(M > 0 ? M : 1);
     L.w_tmp = off;
     L.w_tmp_bytes = bytes;
     off += align_up(bytes, 256);

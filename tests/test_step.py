@@ -746,7 +746,7 @@ def test_fused_step_rejects_bad_descriptors(be):
 def test_touch_plan_one_launch_equals_library_sort(be, sizes):
     """The touch plan built in ONE launch (keys, a grid-synchronised stable 8-bit LSD radix sort with one entry per thread,
     inverse permutation: csrc/step_touch.h touch_sort_kernel; plans of up to 65 536 looked-up ids) is byte for byte the plan
-    of the keys kernel + rocPRIM radix_sort_pairs (mpqe_debug_option TOUCH_ROCPRIM) -- a stable sort has one answer.
+    of the keys kernel + the library's multi-launch radix sort (csrc/radix_sort.h; mpqe_debug_option TOUCH_MULTI_LAUNCH) -- a stable sort has one answer.
     1 to 256 workgroups of 2048 ids, bad ids included. (The host emulator runs workgroups one after the other and has no grid barrier:
     there both builds take the library-sort stand-in and the test only pins the layout.)"""
     rng = np.random.RandomState(sizes[0])
@@ -777,7 +777,7 @@ def test_touch_plan_one_launch_equals_library_sort(be, sizes):
     twb = be.lib.mpqe_step_touch_workspace_bytes(ctypes.byref(P), SB, 2)
     got = []
     for force_library in (False, True, False):
-        be.lib.mpqe_debug_option(b'TOUCH_ROCPRIM', 1, 1 if force_library else 0)
+        be.lib.mpqe_debug_option(b'TOUCH_MULTI_LAUNCH', 1, 1 if force_library else 0)
         try:
             tbuf, twbuf = be.nbytes(tb + 256), be.nbytes(twb + 256)
             if be.name == 'emu':
@@ -793,7 +793,7 @@ def test_touch_plan_one_launch_equals_library_sort(be, sizes):
             off = tptr - be.ptr(tbuf)
             got.append(raw[off:off + tb].copy())
         finally:
-            be.lib.mpqe_debug_option(b'TOUCH_ROCPRIM', 0, 0)
+            be.lib.mpqe_debug_option(b'TOUCH_MULTI_LAUNCH', 0, 0)
     M = int(be.lib.mpqe_step_touch_entries(SB, 2))
     assert M == 5 * B1 + 3 * B2
     # header | keys [M] u64 | perm [M] i32 | erow [M] i32, each region 256-byte aligned: compare the used bytes
