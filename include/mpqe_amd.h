@@ -543,6 +543,17 @@ int mpqe_p2p_allreduce(void *const *buffers /* [world] host array: buffer of ran
                        int world, int64_t capacity /* the n the buffers were sized for */, int64_t n /* floats to reduce, <= capacity */,
                        uint32_t epoch, int phases, int32_t *err, void *stream);
 
+/* Glue of the per-step exchange as library launches (the host mirror did it with torch._foreach_copy_ / index_select /
+ * where): mpqe_spans_copy: dst[d .. d + n) <- src[s .. s + n) for every span of a DEVICE table of {int64 dst offset, src
+ * offset, floats, first workgroup} records (4 096 floats per workgroup; total_blocks = sum of ceil(n / 4096)) -- the
+ * touched matrices into the contiguous bucket and back. mpqe_rows_prepare: from the SORTED keys of a touch plan the step
+ * built itself, the first key of every run (other slots ~0: fixed size `cap`) and the row of the flat [rows, dim]
+ * table-gradient view it names (row_base[table] + row). mpqe_rows_gather: out[i] = rows[gidx[i]].              */
+int mpqe_spans_copy(float *dst, const float *src, const void *spans_device, int nspans, int64_t total_blocks, void *stream);
+int mpqe_rows_prepare(const uint64_t *sorted_keys, int64_t M, int64_t cap, int row_bits, const int64_t *table_rows /* host */,
+                      const int64_t *row_base /* host */, int num_tables, uint64_t *send_keys, int64_t *gidx, void *stream);
+int mpqe_rows_gather(const float *rows, const int64_t *gidx, int64_t n, int64_t dim, float *out, void *stream);
+
 /* ---- negative sampling on the device -------------------------------------------
  * reference model.py:466-476: one negative per query, random.choice over query.neg_samples /
  * query.hard_neg_samples (ragged per query) or graph.full_lists[target_mode] (1-chain: one list for all).

@@ -224,3 +224,111 @@ extern "C" int mpqe_p2p_allreduce(void *const *buffers, int rank, int world, int
     if (phases & 4) hipLaunchKernelGGL(p2p_wait_kernel, dim3(1), dim3(64), 0, s, B, rank, world, epoch, err);
     return mpqe_launch_status();
 }
+
+// ---- glue of the per-step gradient exchange (mpqe_amd/parallel.py: StepExchange.reduce) as the library's own launches: what
+// was torch._foreach_copy_ / index_select / where / unique there.
+// spans: dst[do .. do + n) <- src[so .. so + n) for every span of a device table {dst offset, src offset, floats} (the
+// touched relation matrices + root / bias / mode rows into the contiguous bucket, and back). One workgroup walks 4 096
+// floats of a span; table[nspans] holds the first workgroup of every span (+ the total).
+struct SpanRec {
+    long long dst, src, n, first_block;
+};
+__global__ __launch_bounds__(256) void spans_copy_kernel(float *__restrict__ dst, const float *__restrict__ src,
+                                                         const SpanRec *__restrict__ spans, int nspans) {
+    int lo = 0, hi = nspans - 1;             // the span of this workgroup: the last one whose first_block <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (spans[mid].first_block <= (long long)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const SpanRec sp = spans[lo];
+    const long long base = ((long long)blockIdx.x - sp.first_block) * 4096;
+    float *d = dst + sp.dst;
+    const float *s = src + sp.src;
+    const bool vec = (((uintptr_t)d | (uintptr_t)s) & 15) == 0;
+    for (int k = 0; k < 4; ++k) {
+        const long long i = base + (long long)(threadIdx.x + 256 * k) * 4;
+        if (i >= sp.n) continue;
+        if (vec && i + 3 < sp.n) *reinterpret_cast<f32x4 *>(d + i) = *reinterpret_cast<const f32x4 *>(s + i);
+        else
+            for (long long q = i; q < i + 4 && q < sp.n; ++q) d[q] = s[q];
+    }
+}
+extern "C" int mpqe_spans_copy(float *dst, const float *src, const void *spans_device, int nspans, int64_t total_blocks,
+                               void *stream) {
+    if (!dst || !src || !spans_device || nspans <= 0 || total_blocks <= 0 || total_blocks >= (1ll << 31)) return MPQE_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(spans_copy_kernel, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream), dst, src,
+                       reinterpret_cast<const SpanRec *>(spans_device), nspans);
+    return mpqe_launch_status();
+}
+
+// The row exchange of a step that built its own touch plan: from the plan's SORTED keys [M] (key = table << row_bits | row,
+// ~0 = invalid) the first key of every run of equal keys goes out, every other slot invalid (fixed size: no count to
+// exchange), with the row of the flat [rows, D] table-gradient view it names (row_base[table] + row; 0 for invalid slots).
+struct RowsPrepArgs {
+    long long table_rows[MPQE_STEP_MAX_MODES], row_base[MPQE_STEP_MAX_MODES];
+    int num_tables, row_bits;
+};
+__global__ __launch_bounds__(256) void rows_prepare_kernel(const unsigned long long *__restrict__ keys, long long M, long long cap,
+                                                           RowsPrepArgs a, unsigned long long *__restrict__ send_keys,
+                                                           long long *__restrict__ gidx) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= cap) return;
+    unsigned long long out = ~0ull;
+    long long g = 0;
+    if (i < M) {
+        const unsigned long long k = keys[i];
+        const bool first = i == 0 || keys[i - 1] != k;
+        const long long tab = (long long)(k >> a.row_bits), row = (long long)(k & ((1ull << a.row_bits) - 1ull));
+        if (first && k != ~0ull && tab < a.num_tables) {
+            long long rows = a.table_rows[0], rb = a.row_base[0];
+#pragma unroll
+            for (int m = 1; m < MPQE_STEP_MAX_MODES; ++m)
+                if (m == tab) {
+                    rows = a.table_rows[m];
+                    rb = a.row_base[m];
+                }
+            if (row < rows) {
+                out = k;
+                g = rb + row;
+            }
+        }
+    }
+    send_keys[i] = out;
+    gidx[i] = g;
+}
+extern "C" int mpqe_rows_prepare(const uint64_t *sorted_keys, int64_t M, int64_t cap, int row_bits, const int64_t *table_rows,
+                                 const int64_t *row_base, int num_tables, uint64_t *send_keys, int64_t *gidx, void *stream) {
+    if (!sorted_keys || !send_keys || !gidx || !table_rows || !row_base || M < 0 || cap < M || cap <= 0 || row_bits <= 0 ||
+        row_bits > 40 || num_tables <= 0 || num_tables > MPQE_STEP_MAX_MODES)
+        return MPQE_ERR_INVALID_ARG;
+    RowsPrepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.num_tables = num_tables;
+    a.row_bits = row_bits;
+    for (int m = 0; m < num_tables; ++m) {
+        a.table_rows[m] = table_rows[m];
+        a.row_base[m] = row_base[m];
+    }
+    hipLaunchKernelGGL(rows_prepare_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const unsigned long long *>(sorted_keys), (long long)M, (long long)cap, a,
+                       reinterpret_cast<unsigned long long *>(send_keys), reinterpret_cast<long long *>(gidx));
+    return mpqe_launch_status();
+}
+// out[i][:] = rows[gidx[i]][:]   (D % 4 == 0, 16-byte aligned rows): the gradient rows a rank sends, in its key order
+__global__ __launch_bounds__(256) void rows_gather_kernel(const float *__restrict__ rows, const long long *__restrict__ gidx,
+                                                          long long n, int D, float *__restrict__ out) {
+    const int q = D / 4;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * q) return;
+    const long long i = t / q;
+    const int c = (int)(t % q) * 4;
+    *reinterpret_cast<f32x4 *>(out + i * D + c) = *reinterpret_cast<const f32x4 *>(rows + gidx[i] * D + c);
+}
+extern "C" int mpqe_rows_gather(const float *rows, const int64_t *gidx, int64_t n, int64_t dim, float *out, void *stream) {
+    if (!rows || !gidx || !out || n <= 0 || dim <= 0 || dim % 4 != 0 || (((uintptr_t)rows | (uintptr_t)out) & 15) != 0)
+        return MPQE_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(rows_gather_kernel, dim3((unsigned)((n * (dim / 4) + 255) / 256)), dim3(256), 0, as_stream(stream), rows,
+                       reinterpret_cast<const long long *>(gidx), (long long)n, (int)dim, out);
+    return mpqe_launch_status();
+}

@@ -149,7 +149,7 @@ def _touch_bits(v):
 class ExchangePlan(object):
     __slots__ = ('form', 'grad_views', 'bucket', 'bucket_views', 'bucket_bytes', 'rows', 'n_own', 'cap', 'gidx', 'send',
                  'recv', 'plan', 'plan_ptr', 'entries', 'wire_bytes', 'union', 'desc_hash', 'send_keys', 'all_keys', 'plan_ws',
-                 'plan_sizes', 'in_step')
+                 'plan_sizes', 'in_step', 'spans_in', 'spans_out', 'span_blocks', 'nspans')
 
 
 class StepExchange(object):
@@ -257,6 +257,26 @@ class StepExchange(object):
         else:
             dist.all_gather_into_tensor(out, t, group=self.group)
 
+    def _span_tables(self, ep, merged):
+        """Device tables for mpqe_spans_copy: the merged (offset, floats) spans of the flat gradient buffer <-> the bucket."""
+        recs_in, recs_out, o, blk = [], [], 0, 0
+        for off, n in merged:
+            recs_in += [o, off, n, blk]            # bucket[o ..] <- flat[off ..]
+            recs_out += [off, o, n, blk]           # flat[off ..] <- bucket[o ..]
+            o += n
+            blk += (n + 4095) // 4096
+        ep.spans_in = torch.tensor(recs_in, dtype=torch.int64, device=self.dev)
+        ep.spans_out = torch.tensor(recs_out, dtype=torch.int64, device=self.dev)
+        ep.span_blocks, ep.nspans = blk, len(merged)
+
+    def _copy_spans(self, dst, src, table, ep):
+        from . import _capi, ops
+        L = ops.lib()
+        with torch.cuda.device(self.dev):
+            st = L.mpqe_spans_copy(dst.data_ptr(), src.data_ptr(), table.data_ptr(), ep.nspans, ep.span_blocks,
+                                   torch.cuda.current_stream().cuda_stream)
+        _capi.check(L, st, 'mpqe_spans_copy')
+
     @staticmethod
     def descriptor_hash(packed):
         """64-bit hash of a packed step's descriptor set (formulas, relation ids, passes, sizes, weights): what a plan
@@ -352,6 +372,8 @@ class StepExchange(object):
         ep.desc_hash = desc_hash
         ep.in_step = in_step
         ep.send_keys = ep.all_keys = ep.plan_ws = ep.plan_sizes = None
+        ep.spans_in = ep.spans_out = None
+        ep.span_blocks = ep.nspans = 0
         nsel, nfull = sum(n for _, n in merged), sum(n for _, n in spans)
         if self.transport == 'p2p':
             # the bucket IS the head of the peer-mapped communication buffer: copied in, summed in place by the one-hop
@@ -378,6 +400,8 @@ class StepExchange(object):
                 ep.bucket_views.append(ep.bucket[o:o + n])
                 o += n
             ep.bucket_bytes = 4 * nsel
+        if ep.form != 'dense' and merged:
+            self._span_tables(ep, merged)
         w = self.world
         ep.wire_bytes = int(2 * (w - 1) / max(w, 1) * ep.bucket_bytes)      # (ring and one-hop move the same bytes; the hops differ)
         ep.n_own = ep.cap = ep.entries = 0
@@ -477,25 +501,18 @@ class StepExchange(object):
         M = int(packed.touch_entries)
         if M != ep.n_own:
             raise ValueError('reduce: this packed step has %d looked-up ids, the plan was made for %d' % (M, ep.n_own))
-        base = packed.touch_ptr - packed.touch.data_ptr()
-        keys = packed.touch[base + 256: base + 256 + 8 * M].view(torch.int64)
-        # a failed in-step sort (flagged in the plan's header; the reduction launch also raises MPQE_FLAG_INTERNAL) leaves
-        # garbage keys: rows outside the tables are masked here, the error word says the rest
-        first = torch.ones(M, dtype=torch.bool, device=self.dev)
-        first[1:] = keys[1:] != keys[:-1]
-        tab = keys >> self.row_bits
-        row = keys & ((1 << self.row_bits) - 1)
-        ok = first & (keys != -1) & (tab >= 0) & (tab < len(self.tables))
-        lim = torch.tensor([t.shape[0] for t in self.tables], dtype=torch.int64, device=self.dev)
-        tabc = tab.clamp(0, len(self.tables) - 1)
-        ok = ok & (row < lim[tabc])
-        ep.send_keys.fill_(-1)
-        ep.send_keys[:M] = torch.where(ok, keys, torch.full_like(keys, -1))
-        base_t = torch.tensor(self.row_base, dtype=torch.int64, device=self.dev)
-        ep.gidx.zero_()
-        ep.gidx[:M] = torch.where(ok, base_t[tabc] + row, torch.zeros_like(row))
-        self._all_gather(ep.all_keys, ep.send_keys)
+        import ctypes
         L = ops.lib()
+        # the first key of every run of the plan's sorted keys + the flat table row it names, one launch (a failed in-step
+        # sort -- flagged in the plan's header, MPQE_FLAG_TOUCH_RETRY in the error word -- leaves whatever keys the buffer
+        # held: keys outside the tables are masked there)
+        i64 = ctypes.c_int64 * len(self.tables)
+        with torch.cuda.device(self.dev):
+            st = L.mpqe_rows_prepare(packed.touch_ptr + 256, M, ep.cap, self.row_bits, i64(*[t.shape[0] for t in self.tables]),
+                                     i64(*self.row_base), len(self.tables), ep.send_keys.data_ptr(), ep.gidx.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
+        _capi.check(L, st, 'mpqe_rows_prepare')
+        self._all_gather(ep.all_keys, ep.send_keys)
         nbytes, wbytes = ep.plan_sizes
         with torch.cuda.device(self.dev):
             st = L.mpqe_rows_plan_build(ep.all_keys.data_ptr(), ep.entries, self.row_bits, self.row_bits + 5, ep.plan_ptr,
@@ -511,22 +528,27 @@ class StepExchange(object):
             for v in ep.grad_views:
                 self._all_reduce(v)
         elif ep.form == 'p2p':
-            torch._foreach_copy_(ep.bucket_views, ep.grad_views)
+            self._copy_spans(ep.bucket, self.fused.flat_grad, ep.spans_in, ep)       # (one launch each way: the library's own)
             self.peer.all_reduce(ep.bucket.numel())
-            torch._foreach_copy_(ep.grad_views, ep.bucket_views)
+            self._copy_spans(self.fused.flat_grad, ep.bucket, ep.spans_out, ep)
         elif ep.bucket.numel():
-            torch._foreach_copy_(ep.bucket_views, ep.grad_views)
+            self._copy_spans(ep.bucket, self.fused.flat_grad, ep.spans_in, ep)
             self._all_reduce(ep.bucket)
-            torch._foreach_copy_(ep.grad_views, ep.bucket_views)
+            self._copy_spans(self.fused.flat_grad, ep.bucket, ep.spans_out, ep)
         if not ep.rows:
             return
+        L = ops.lib()
         if ep.in_step:
             self._plan_rows_in_step(ep, packed)
-            torch.index_select(self.tab2d, 0, ep.gidx, out=ep.send)     # (invalid slots: row 0, never summed)
-        elif ep.n_own:
-            torch.index_select(self.tab2d, 0, ep.gidx, out=ep.send[:ep.n_own])
+            n_send = ep.cap                                             # (invalid slots: row 0, never summed)
+        else:
+            n_send = ep.n_own
+        if n_send:
+            with torch.cuda.device(self.dev):
+                st = L.mpqe_rows_gather(self.tab2d.data_ptr(), ep.gidx.data_ptr(), n_send, self.D, ep.send.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream)
+            _capi.check(L, st, 'mpqe_rows_gather')
         self._all_gather(ep.recv, ep.send)
-        L = ops.lib()
         with torch.cuda.device(self.dev):
             st = L.mpqe_table_rows_sum(ep.plan_ptr, ep.entries, ep.recv.data_ptr(), self.D, self._tab_g, len(self.tables), 1,
                                        torch.cuda.current_stream().cuda_stream)
