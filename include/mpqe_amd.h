@@ -479,6 +479,13 @@ int mpqe_step_table_rows(const mpqe_step_params_t *params_host, const mpqe_step_
                          const mpqe_step_grads_t *grads_host, const void *desc, void *workspace, size_t workspace_bytes,
                          const void *touch, void *stream);
 
+/* margin_loss's regulariser on the readout's parameters (reference model.py:486-490: sum_i ||p_i||_2, unsquared) for the
+ * drop-in modules: out[0] += sum_i ||params[i]||_2 (out != NULL; the caller zero-fills it) and / or grads[i] += *grad_out *
+ * params[i] / ||params[i]|| (grads != NULL; grad_out: the upstream gradient, one float on the device, NULL = 1). Up to four
+ * tensors per call, one workgroup, fixed order of every sum. The fused step computes the same inside its own call.   */
+int mpqe_l2_norms(const float *const *params /* host array of device pointers */, const int64_t *sizes /* host */, int count,
+                  const float *grad_out, float *out, float *const *grads, void *stream);
+
 /* Ids of the next step from pinned host memory to the device on `stream` (hipMemcpyAsync; stream-ordered, returns at
  * once): the reference moves its index tensors with .to(device) per call (utils.py:17-23). For host mirrors without a
  * HIP binding of their own.                                                                          */

@@ -130,6 +130,7 @@ PROTOTYPES = {
     'mpqe_p2p_open': (I, [P, ctypes.POINTER(c_void_p)]),
     'mpqe_p2p_close': (I, [P]),
     'mpqe_p2p_allreduce': (I, [ctypes.POINTER(c_void_p), I, I, L, L, ctypes.c_uint32, I, P, P]),
+    'mpqe_l2_norms': (I, [ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int64), I, P, P, ctypes.POINTER(c_void_p), P]),
     'mpqe_spans_copy': (I, [P, P, P, I, L, P]),
     'mpqe_rows_prepare': (I, [P, L, L, I, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), I, P, P, P]),
     'mpqe_rows_gather': (I, [P, P, L, L, P, P]),

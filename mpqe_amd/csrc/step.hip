@@ -3221,6 +3221,26 @@ extern "C" int mpqe_adam_rows_step(const void *touch, int64_t num_entries, float
     return mpqe_launch_status();
 }
 
+// sum_i ||p_i||_2 of up to four parameter tensors and its backward (the regulariser of margin_loss, reference
+// model.py:486-490, for the module path; the fused step calls the same kernel inside its own call)
+extern "C" int mpqe_l2_norms(const float *const *params, const int64_t *sizes, int count, const float *grad_out, float *out,
+                             float *const *grads, void *stream) {
+    if (!params || !sizes || count < 1 || count > 4 || (!out && !grads)) return MPQE_ERR_INVALID_ARG;
+    RoRegArgs rr;
+    memset(&rr, 0, sizeof(rr));
+    for (int i = 0; i < count; ++i) {
+        if (!params[i] || sizes[i] <= 0) return MPQE_ERR_INVALID_ARG;
+        rr.p[i] = params[i];
+        rr.n[i] = sizes[i];
+        rr.g[i] = grads ? grads[i] : nullptr;
+    }
+    rr.coef = 1.f;
+    rr.loss = out;                 // (+= : the caller zero-fills it)
+    rr.gscale = grad_out;
+    hipLaunchKernelGGL(step_ro_reg_kernel, dim3(1), dim3(1024), 0, as_stream(stream), rr);
+    return mpqe_launch_status();
+}
+
 static int D_ok_for_readout(int D) { return D % 4 == 0; }      // (16-byte rows in step_readout.h)
 
 extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb,

@@ -92,12 +92,14 @@ struct RoRegArgs {
     long long n[4];
     float coef;
     float *loss;
+    const float *gscale;     // != NULL: the gradients are scaled by *gscale too (an upstream gradient on the device)
 };
 __global__ __launch_bounds__(1024) void step_ro_reg_kernel(RoRegArgs a) {
     __shared__ float part[16];
     __shared__ float total;
     float sum_norms = 0.f;
     for (int i = 0; i < 4; ++i) {
+        if (!a.p[i]) continue;          // (uniform: fewer than four parameters)
         float s = 0.f;
         for (long long k = threadIdx.x; k < a.n[i]; k += 1024) s += a.p[i][k] * a.p[i][k];
         s = wave_sum(s);
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(1024) void step_ro_reg_kernel(RoRegArgs a) {
         const float nrm = total;
         sum_norms += nrm;
         if (a.g[i] && nrm > 0.f) {
-            const float sc = a.coef / nrm;
+            const float sc = (a.gscale ? a.coef * *a.gscale : a.coef) / nrm;
             for (long long k = threadIdx.x; k < a.n[i]; k += 1024) a.g[i][k] += sc * a.p[i][k];
         }
         __syncthreads();

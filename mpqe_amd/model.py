@@ -269,10 +269,8 @@ class RGCNEncoderDecoder(nn.Module):
         loss = ops.hinge(affs, neg_affs, margin)
 
         if isinstance(self.readout, nn.Module) and self.weight_decay > 0:
-            l2_reg = 0
-            for param in self.readout.parameters():
-                l2_reg += torch.norm(param)
-            loss = loss + self.weight_decay * l2_reg
+            # (reference model.py:486-490: l2_reg = sum of torch.norm(param) -- on the library's kernel, the one the fused step uses)
+            loss = loss + self.weight_decay * ops.l2_norms(list(self.readout.parameters()))
         self._check()
         return loss
 

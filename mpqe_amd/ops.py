@@ -577,6 +577,42 @@ class _Hinge(torch.autograd.Function):
         return gp, gn, None
 
 
+class _L2Norms(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *params):
+        import ctypes
+        ps = [_f(p, 'parameter') for p in params]
+        out = torch.zeros((1,), dtype=torch.float32, device=ps[0].device)
+        with torch.cuda.device(ps[0].device):
+            for i in range(0, len(ps), 4):
+                chunk = ps[i:i + 4]
+                arr = (ctypes.c_void_p * len(chunk))(*[_p(p) for p in chunk])
+                n = (ctypes.c_int64 * len(chunk))(*[p.numel() for p in chunk])
+                _ck(lib().mpqe_l2_norms(arr, n, len(chunk), None, _p(out), None, _stream()), 'mpqe_l2_norms')
+        ctx.save_for_backward(*ps)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        import ctypes
+        ps = ctx.saved_tensors
+        gl = _f(gl.reshape(1), 'grad_out')
+        grads = [torch.zeros_like(p) for p in ps]
+        with torch.cuda.device(ps[0].device):
+            for i in range(0, len(ps), 4):
+                chunk, gch = ps[i:i + 4], grads[i:i + 4]
+                arr = (ctypes.c_void_p * len(chunk))(*[_p(p) for p in chunk])
+                garr = (ctypes.c_void_p * len(chunk))(*[_p(g) for g in gch])
+                n = (ctypes.c_int64 * len(chunk))(*[p.numel() for p in chunk])
+                _ck(lib().mpqe_l2_norms(arr, n, len(chunk), _p(gl), None, garr, _stream()), 'mpqe_l2_norms')
+        return tuple(grads)
+
+
+def l2_norms(params):
+    """(a7) sum_i ||p_i||_2 over parameter tensors (unsquared: reference model.py:486-490), fixed order of every sum."""
+    return _L2Norms.apply(*[p for p in params])
+
+
 def hinge(pos, neg, margin=1.0):
     """(a7) mean(clamp(margin - (pos - neg), min=0))"""
     return _Hinge.apply(pos, neg, float(margin))

@@ -5,6 +5,7 @@ import fcntl
 import glob
 import os
 import subprocess
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
@@ -35,10 +36,12 @@ def build_emu(force=False):
         fcntl.flock(lock, fcntl.LOCK_EX)
         if force or not fresh():
             tmp = OUT + '.tmp.%d' % os.getpid()
+            started = time.time()
             cmd = [CLANG, '-x', 'c++', '-std=c++17', '-O1', '-g', '-fPIC', '-shared',
                    '-I' + os.path.join(HERE, 'include'), '-I' + os.path.join(ROOT, 'include')] + \
                 sources() + [os.path.join(HERE, 'emu_runtime.cpp'), '-o', tmp]
             subprocess.check_call(cmd)
+            os.utime(tmp, (started, started))       # a source edited while this ran is newer than the result
             os.replace(tmp, OUT)
     return OUT
 

@@ -643,3 +643,30 @@ def test_dense_layer_matches_nn_linear(be, rows, din, dout, pad, relu):
                                     None, be.ptr(gW) + 4 * off, ld, be.ptr(gb), be.ptr(ws), wb, be.stream), 'linear bwd +=')
     close(np.asarray(be.get(gW))[:, off:off + din], 2 * tW.grad.numpy()[:, off:off + din], rtol=1e-4, what='grad_W x2')
     close(np.asarray(be.get(gb)), 2 * tb.grad.numpy(), rtol=1e-4, what='grad_bias x2')
+
+
+# ------------------------------------------------------------------------------------------ regulariser (a7)
+@pytest.mark.parametrize('count', [1, 3, 4])
+def test_l2_norms_value_and_gradients(be, count):
+    """margin_loss's regulariser (reference model.py:486-490: sum of torch.norm(param), unsquared) and its backward
+    under an upstream gradient, against torch on the host."""
+    rng = np.random.default_rng(40 + count)
+    shapes = [(128, 256), (128,), (128, 128), (7,)][:count]
+    ps = [rng.standard_normal(s).astype(np.float32) for s in shapes]
+    up = np.array([0.37], dtype=np.float32)
+    tp = [torch.from_numpy(p.copy()).requires_grad_(True) for p in ps]
+    ref = sum(torch.norm(p) for p in tp)
+    (ref * float(up[0])).backward()
+    dp = [be.put(p) for p in ps]
+    dg = [be.zeros(p.shape) for p in ps]
+    out, dup = be.zeros((1,)), be.put(up)
+    arr = (ctypes.c_void_p * count)(*[be.ptr(p) for p in dp])
+    garr = (ctypes.c_void_p * count)(*[be.ptr(g) for g in dg])
+    n = (ctypes.c_int64 * count)(*[int(p.size) for p in ps])
+    be.check(be.lib.mpqe_l2_norms(arr, n, count, None, be.ptr(out), None, be.stream), 'l2_norms fwd')
+    be.check(be.lib.mpqe_l2_norms(arr, n, count, be.ptr(dup), None, garr, be.stream), 'l2_norms bwd')
+    close(be.get(out)[0], ref.item(), what='value')
+    for g, p in zip(dg, tp):
+        close(be.get(g), p.grad.numpy(), rtol=1e-5, what='grad')
+    assert be.lib.mpqe_l2_norms(arr, n, 5, None, be.ptr(out), None, be.stream) != 0
+    assert be.lib.mpqe_l2_norms(arr, n, count, None, None, None, be.stream) != 0
