@@ -100,7 +100,8 @@ struct WBlock {
     int i0, j0;                 // the output tile
     int direct;                 // >= 0: layer whose gradient matrix the tile writes itself; -1: slab
     int d0, dn;                 // merged launch: the `done` counters [d0, d0 + dn) cover the chain workgroups of the K-chunk
-    int batch, pad;
+    int batch, pad;             // pad = 1: the operands change places -- x rows from gH (at g_off), g rows from H (at x_off): the
+                                // tile is then the gradient of an nn.Linear weight [out, in] (a learned readout on the chain)
 };
 // Merged launch (chain form): the weight-gradient tiles and the backward post-pass are workgroups of the CHAIN launch,
 // behind the chain workgroups. A chain workgroup counts itself into the `done` counter of its group of DONE_GRAPHS graphs
@@ -404,7 +405,7 @@ template <int LDS_TILES>
 __device__ __forceinline__ void post_block(const StepDev *__restrict__ sd, const LayerPtrs &lp, const PostArgs &po, int pb,
                                            float *smem);
 
-template <int NCB, int KS, int NW = 4>
+template <int NCB, int KS, int NW = 4, bool RO = false>
 __global__ __launch_bounds__(64 * NW) void step_chain_kernel(const StepDev *__restrict__ sd, LayerPtrs lp,
                                                              TablePtrs tabs, ChainArgs ca, PrepArgs pa, PostArgs po) {
     __shared__ __attribute__((aligned(16))) ChainLds<NCB, KS, NW> S;
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(64 * NW) void step_chain_kernel(const StepDev *__re
 #endif
         ca.cb = bid;
         ca.nchain = pa.nchain;
-        chain_block<NCB, KS, NW>(sd, lp, tabs, ca, S);
+        chain_block<NCB, KS, NW, RO>(sd, lp, tabs, ca, S);
     } else if (role == 1) {
         constexpr int D = 16 * NCB * NW / KS;
         // The touch plan of THIS step's ids (step_touch.h): the first workgroups of the launch, so all of them are
@@ -808,10 +809,15 @@ __device__ __forceinline__ void loss_block_chain(const LossMeta &lm, const float
 __global__ __launch_bounds__(1024) void step_loss_kernel(const StepDev *__restrict__ sd,
                                                          const float *__restrict__ terms,
                                                          float *__restrict__ loss, LossMeta lm,
-                                                         const float *__restrict__ bterms, unsigned *epoch_f) {
+                                                         const float *__restrict__ bterms, unsigned *epoch_f,
+                                                         int bump_b = 0) {
     __shared__ float mean[MPQE_STEP_MAX_BATCHES];
-    // (forward-only step: this is its last launch -- the next step's forward granules get a new tag, step_uniform.h)
-    if (epoch_f && threadIdx.x == 0) *epoch_f = *epoch_f + 1u;
+    // (forward-only step: this is its last launch -- the next step's forward granules get a new tag, step_uniform.h; and
+    // when its chain launch made transposed copies -- a learned readout's forward reads them -- their count a new target)
+    if (epoch_f && threadIdx.x == 0) {
+        *epoch_f = *epoch_f + 1u;
+        if (bump_b) *(epoch_f + 16) = *(epoch_f + 16) + 1u;
+    }
     if (lm.chain) loss_block_chain(lm, bterms, loss, mean, 16);
     else loss_block(sd, terms, loss, mean, 16);
 }
@@ -852,9 +858,9 @@ __device__ __forceinline__ void grad_w_block(const StepDev *__restrict__ sd, con
     }
     const long long xs = wk.xs, xo = wk.xo, gs = wk.xs, go = wk.go;
     const long long q0 = wk.q0, q1 = wk.q1;
-    const float *x = H + wk.x_off;
+    const float *x = wk.pad ? GH + wk.g_off : H + wk.x_off;
     const float *out = nullptr;              // (masks are applied by the producers: relu = 0 everywhere)
-    const float *g = GH + wk.g_off;
+    const float *g = wk.pad ? H + wk.x_off : GH + wk.g_off;
     float *dst = slabs + wk.slab_off;
     bool direct = false;
     if (wk.direct >= 0) {
@@ -968,6 +974,9 @@ __device__ __forceinline__ void anchor_bwd_block(const StepDev *__restrict__ sd,
 // lane, 16-byte loads); its 4 waves each add every 4th slab (two loads in flight), the four sums
 // are combined as (0+1)+(2+3): a fixed order. (A one-thread-per-16-elements variant that walked all
 // slabs serially measured 2.5x slower: the 40-slab root group became the long pole.)
+#ifndef VEC_SLICES
+#define VEC_SLICES 4     // column slices (workgroups) per vector group of the reduction
+#endif
 struct ReduceArgs {
     const RGroup *groups;
     int ngroups, D;
@@ -1081,10 +1090,13 @@ __device__ __forceinline__ void reduce_block(const ReduceArgs &ra, int bx, int b
         // a vector group (bias / mode row): hundreds of partial rows of D floats (one per chain block), ONE
         // workgroup: D/4 lanes cover a row, the 256 / (D/4) row groups each walk every RG-th row with 8 loads
         // in flight, then the row groups' sums are added in order (fixed order: reproducible)
-        if (bx != 0) return;
+        // (VEC_SLICES > 1: workgroup bx takes the columns [bx D / VEC_SLICES, ...) of every row -- 128 bytes of a row at
+        // D = 128: more rows in flight per workgroup, VEC_SLICES workgroups per group; a fixed order all the same)
+        const int NS = (D % (4 * VEC_SLICES) == 0 && 256 % (D / 4 / VEC_SLICES) == 0) ? VEC_SLICES : 1;
+        if (bx >= NS) return;
         wait_phase1();
-        const int LQ = D / 4, RG = 256 / LQ;
-        const int c4 = threadIdx.x % LQ, rg = threadIdx.x / LQ;
+        const int LQ = D / 4 / NS, RG = 256 / LQ;
+        const int c4 = bx * LQ + threadIdx.x % LQ, rg = threadIdx.x / LQ;
         const float *pv = partial + (long long)g.start * D + 4 * c4;
         f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
         for (int i = rg; i < g.count; i += RG * 8) {
@@ -1101,11 +1113,18 @@ __device__ __forceinline__ void reduce_block(const ReduceArgs &ra, int bx, int b
         f32x4 *flat = &part[0][0];
         flat[threadIdx.x] = acc4;
         __syncthreads();
+        // the row groups' sums: groups rg, rg + 4, ... into four, then the four (two short chains instead of one long one)
+        const int cl = threadIdx.x % LQ;
+        f32x4 t = acc4;
+        if (rg < 4)
+            for (int q = rg + 4; q < RG; q += 4) t += flat[q * LQ + cl];
+        __syncthreads();
+        if (rg < 4) flat[threadIdx.x] = t;
+        __syncthreads();
         if (rg != 0) return;
         float *dstv = g.kind == 2 ? gp.bias[g.layer] : (gp.mode_emb ? gp.mode_emb + g.row * D : nullptr);
         if (!dstv) return;
-        f32x4 t = flat[c4];
-        for (int q = 1; q < RG; ++q) t += flat[q * LQ + c4];
+        for (int q = 1; q < 4 && q < RG; ++q) t += flat[q * LQ + cl];
 #pragma unroll
         for (int k = 0; k < 4; ++k) dstv[4 * c4 + k] = zeroed ? t[k] : dstv[4 * c4 + k] + t[k];
         return;
@@ -1495,6 +1514,11 @@ struct HostPlan {
     long long ro_rows;
     int ro_kin;
     bool ro_direct;
+    // MPQE_READOUT_MLP on the chain form: the readout's two Linear layers are levels L + 1, L + 2 of every batch, their
+    // parameters the `root` / `bias` of the virtual layers ro_layer, ro_layer + 1 (= num_layers, + 1; stored [out, in]:
+    // the transposed form of a root matrix)
+    bool ro_chain;
+    int ro_layer;
     long long level_stride;
 };
 
@@ -1557,6 +1581,12 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     if (P->num_modes <= 0 || P->num_modes > MPQE_STEP_MAX_MODES) return MPQE_ERR_UNSUPPORTED;
     if (P->readout < 0 || P->readout > MPQE_READOUT_CONCAT) return MPQE_ERR_INVALID_ARG;
     const int D = P->dim;
+    const bool ro = chain && P->readout == MPQE_READOUT_MLP;
+    const int VL0 = P->num_layers, ROL = ro ? 2 : 0;
+    if (chain && P->readout >= MPQE_READOUT_CALLER && !ro) return MPQE_ERR_UNSUPPORTED;
+    if (ro && P->num_layers + 2 > MPQE_STEP_MAX_LAYERS) return MPQE_ERR_UNSUPPORTED;
+    hp->ro_chain = ro;
+    hp->ro_layer = VL0;
     StepDev &sd = hp->sd;
     memset(&sd, 0, sizeof(sd));
     sd.nb = nb;
@@ -1613,6 +1643,10 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                 if ((d.live[p + 1] >> t.dst[e]) & 1u) m |= 1u << t.src[e];
             d.live[p] = prune ? m : all;
         }
+        if (ro) {       // the readout's hidden and output rows of every node slot (ReLU bits: level L + 1 <= CH_MASK_LEVELS)
+            if (d.L + 1 > CH_MASK_LEVELS) return MPQE_ERR_UNSUPPORTED;
+            d.live[d.L + 1] = d.live[d.L + 2] = all;
+        }
     }
     if (rows >= (1ll << 30)) return MPQE_ERR_UNSUPPORTED;
     hp->anchor_off[nb] = (int)anchors;
@@ -1661,6 +1695,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
 
     // unique layer buffers (shared layers alias one parameter set -> one gradient buffer)
     int uid[MPQE_STEP_MAX_LAYERS];
+    for (int l = 0; l < MPQE_STEP_MAX_LAYERS; ++l) uid[l] = l;       // (the readout's virtual layers: themselves)
     for (int l = 0; l < P->num_layers; ++l) {
         uid[l] = l;
         for (int m = 0; m < l; ++m)
@@ -1682,6 +1717,12 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
             for (int e = 0; e < tp.E; ++e)
                 if (!((uni[i][p] >> tp.src[e]) & 1u)) m &= ~(1u << tp.dst[e]);
             uni[i][p + 1] = m;
+        }
+        if (ro) {
+            // (a node slot no anchor has reached after the last pass has no rows in H[L], which the readout's weight
+            // gradient reads: fewer passes than the query's diameter -- such a step takes the level form)
+            if (uni[i][d.L] & d.live[d.L]) return MPQE_ERR_UNSUPPORTED;
+            uni[i][d.L + 1] = uni[i][d.L + 2] = 0u;
         }
     }
     // vector table ids: (kind, batch, level, node slot) -> row of VT; granule slots only for vectors another
@@ -1708,7 +1749,10 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         if (gran_of[v] < 0) gran_of[v] = ngran++;
         return gran_of[v];
     };
-    auto layer_of = [&](int i, int p) { return p < sd.b[i].L - 1 ? p : P->num_layers - 1; };      // reference model.py:435-441
+    // reference model.py:435-441; levels L, L + 1 (chain form with a learned readout): its two Linear layers
+    auto layer_of = [&](int i, int p) {
+        return p < sd.b[i].L - 1 ? p : (p < sd.b[i].L ? P->num_layers - 1 : VL0 + (p - sd.b[i].L));
+    };
 
     // weight-gradient sources, ordered by (unique layer, relation | root) so every reduction group
     // owns a contiguous slab range. A source whose input state is batch-uniform is a rank-1 term u (x) colsum
@@ -1752,6 +1796,9 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
             for (int n = 0; n < tp.N; ++n)          // root term: one source per live node slot
                 if ((lout >> n) & 1u) add(tp.E + n, n, n, -1);
         }
+    for (int i = 0; i < nb && ro; ++i)              // the readout's Linear layers: a root-like source per node slot and layer
+        for (int r = 0; r < ROL; ++r)
+            for (int n = 0; n < sd.b[i].tp.N; ++n) keys.push_back(Key{VL0 + r, -1, i, sd.b[i].L + r, sd.b[i].tp.E + n});
     auto key_less = [](int la, long long ra, int lb, long long rb) { return la != lb ? la < lb : ra < rb; };
     std::stable_sort(keys.begin(), keys.end(),
                      [&](const Key &a, const Key &b) { return key_less(a.layer, a.rel, b.layer, b.rel); });
@@ -1832,7 +1879,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         s.slab_start = slab;
         s.block_start = block;
         s.direct = -1;
-        s.pad = 0;
+        s.pad = (ro && key.layer >= VL0) ? 1 : 0;       // (nn.Linear's [out, in]: the tile's operands change places)
         s.rel = key.rel;
         hp->wsrc.push_back(s);
 
@@ -1934,7 +1981,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                     wkb.j0 = (tile % wct) * tile_n;
                     wkb.direct = ws.direct;
                     wkb.batch = ws.batch;
-                    wkb.pad = 0;
+                    wkb.pad = ws.pad;
                     wkb.d0 = hp->dm.base[ws.batch] + wkb.q0 / DONE_GRAPHS;
                     wkb.dn = (wkb.q1 - 1) / DONE_GRAPHS - wkb.q0 / DONE_GRAPHS + 1;
                     hp->wblock.push_back(wkb);
@@ -2019,7 +2066,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         std::vector<VKey> vk;
         for (int i = 0; i < nb; ++i) {
             const BatchDev &d = sd.b[i];
-            for (int p = 1; p <= d.L; ++p)
+            for (int p = 1; p <= d.L + ROL; ++p)
                 for (int n = 0; n < d.tp.N; ++n)
                     if ((d.live[p] >> n) & 1u) vk.push_back(VKey{0, uid[layer_of(i, p - 1)], 0, i, p, n});
             for (int k = 0; k < d.V; ++k)
@@ -2055,7 +2102,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
             for (int n = 0; n < 4; ++n) {
                 BatchDev &d = sd.b[i];
                 const bool liveL = n < d.tp.N && ((d.live[d.L] >> n) & 1u);
-                d.lpart[n] = liveL ? part_row[i][d.L][n] : -1;
+                d.lpart[n] = liveL ? part_row[i][d.L + ROL][n] : -1;      // (a learned readout: its output rows' gradients)
                 d.uvL[n] = liveL && ((uni[i][d.L] >> n) & 1u) ? gran(vec(V_UV, i, d.L, n)) : -1;     // (its granule slot)
             }
         if (uniform) {
@@ -2392,7 +2439,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->wt_slots.clear();
     {
         struct Prog {
-            int work, batch, fb, fc, bb, bc;
+            int work, batch, fb, fc, bb, bc, rof;
         };
         std::vector<Prog> progs;
         for (int i = 0; i < nb; ++i) {
@@ -2401,8 +2448,43 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
             Prog pr;
             pr.batch = i;
             int cv_slots = 0;
+            pr.rof = 0;
+            // a learned readout's Linear layers r = 0, 1 (reference model.py:497-515): per node slot one K-block, the node's own
+            // row times W_r^T (forward, a transposed copy) / its gradient row times W_r (backward: the parameter itself)
+            auto readout_ops = [&](int dir) {
+                for (int q = 0; q < ROL; ++q) {
+                    const int r = dir ? ROL - 1 - q : q;
+                    for (int n = 0; n < tp.N; ++n) {
+                        ChainOp op;
+                        op.src = op.node = (unsigned char)n;
+                        op.layer = (unsigned char)(VL0 + r);
+                        op.level = (unsigned char)(dir ? d.L + r : d.L + r + 1);
+                        op.mat = -1;
+                        op.flags = CH_FIRST | CH_LAST;
+                        op.pad = 0;
+                        if (!dir) {
+                            // H[L + 1] (the hidden rows) feeds the second layer's weight gradient; the output rows only the scores
+                            op.flags |= r == 0 ? CH_RELU : CH_NOSTORE;
+                            op.wt_slot = r;         // (its bias: constant slot r, loaded in front of the readout's K loop)
+                            op.aux = -1;
+                            size_t k = 0;
+                            for (; k < hp->wt_slots.size(); ++k)
+                                if (hp->wt_slots[k].layer == VL0 + r && hp->wt_slots[k].mat == -1) break;
+                            if (k == hp->wt_slots.size()) hp->wt_slots.push_back(WtSlot{VL0 + r, -1});
+                            op.pad = 1 + (int)k;
+                        } else {
+                            if (r == 1) op.flags |= CH_MASK;     // (gH[L + 1]: through the hidden rows' ReLU)
+                            op.wt_slot = -1;
+                            op.aux = part_row[i][d.L + r][n];
+                        }
+                        if (n == tp.N - 1) op.flags |= CH_LEVEL_END;
+                        hp->cops.push_back(op);
+                    }
+                }
+            };
             for (int dir = 0; dir < 2; ++dir) {
                 const int begin = (int)hp->cops.size();
+                if (dir && ro) readout_ops(1);
                 for (int q = 0; q < d.L; ++q) {
                     const int p = dir ? d.L - 1 - q : q;
                     const int li = p < d.L - 1 ? p : P->num_layers - 1;
@@ -2412,7 +2494,8 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                     if (dir && p >= 1) lvl_flags |= CH_MASK;
                     // the weight gradients read H[0 .. L-1] and gH[1 .. L]; H[L] feeds only the scores and gH[0]
                     // only the anchor / variable-row gradients, all inside the chain kernel
-                    if ((!dir && p == d.L - 1) || (dir && p == 0)) lvl_flags |= CH_NOSTORE;
+                    // (a learned readout on the chain: H[L] is the input of its first layer's weight gradient)
+                    if ((!dir && p == d.L - 1 && !ro) || (dir && p == 0)) lvl_flags |= CH_NOSTORE;
                     const size_t level_first = hp->cops.size();
                     // per-graph (NU) node slots only: a batch-uniform state is a vector of the pre-pass, its gradient
                     // a column sum of the post-pass. The sources of an NU node's K-blocks are its NU sources (the
@@ -2463,10 +2546,15 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                 }
                 (dir ? pr.bb : pr.fb) = begin;
                 (dir ? pr.bc : pr.fc) = (int)hp->cops.size() - begin;
+                if (!dir && ro) {
+                    const int rb = (int)hp->cops.size();
+                    readout_ops(0);
+                    pr.rof = (int)hp->cops.size() - rb;
+                }
             }
             // (the chain kernel's LDS tables: step_chain.h. Steps beyond them take the level form.)
-            if (chain && (cv_slots > CH_MAX_CV || pr.fc + pr.bc > CH_MAX_OPS)) return MPQE_ERR_UNSUPPORTED;
-            pr.work = pr.fc + pr.bc;
+            if (chain && (cv_slots > CH_MAX_CV || pr.fc + pr.rof + pr.bc > CH_MAX_OPS)) return MPQE_ERR_UNSUPPORTED;
+            pr.work = pr.fc + pr.rof + pr.bc;
             progs.push_back(pr);
         }
         // Placement (speed only, results never depend on it). Workgroups are dealt round-robin over the 8 XCDs
@@ -2497,7 +2585,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                         bins[best].push_back(ChainRef{progs[k].batch, g0, progs[k].fb, progs[k].fc, progs[k].bb,
                                                       progs[k].bc, hp->blk_off[progs[k].batch] + g0 / CH_GB,
                                                       hp->dm.base[progs[k].batch] + g0 / DONE_GRAPHS,
-                                                      (int)(bd.anchor_off + g0), (int)(bd.g_off + g0), bd.B, meta});
+                                                      (int)(bd.anchor_off + g0), (int)(bd.g_off + g0), bd.B, meta, progs[k].rof});
                         load[best] += progs[k].work;
                     }
                 }
@@ -2515,7 +2603,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                 for (int x = 0; x < STEP_XCDS; ++x) {
                     heavy[x] = false;
                     for (size_t k = 0; k < bins[x].size(); ++k)
-                        heavy[x] = heavy[x] || (bins[x][k].fwd_count + bins[x][k].bwd_count) >= wmax;
+                        heavy[x] = heavy[x] || (bins[x][k].fwd_count + bins[x][k].rof + bins[x][k].bwd_count) >= wmax;
                 }
                 // ... with room for all of them at once (two workgroups per CU): first the XCDs with a free slot on every CU
                 // that host no workgroup of the heaviest programme, then every XCD without one, then all. (AIFB mix, D = 128,
@@ -2571,7 +2659,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
             }
             for (size_t k = 0; k < longest; ++k)
                 for (int x = 0; x < STEP_XCDS; ++x)
-                    hp->crefs.push_back(k < bins[x].size() ? bins[x][k] : ChainRef{-1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0u});
+                    hp->crefs.push_back(k < bins[x].size() ? bins[x][k] : ChainRef{-1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0u, 0});
         }
         hp->cref_begin[hp->nlanes] = (int)hp->crefs.size();
         // Merged launch: the tiles queue behind the chain workgroups of their XCD and wait for the chain workgroups of
@@ -2670,8 +2758,8 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->o_done = take(2 * hp->done_inc.size() * sizeof(unsigned));      // published | arrived
     hp->desc_total = off;
     off = 0;
-    hp->o_H = take((size_t)(hp->Lmax + 1) * rows * D * 4);
-    hp->o_GH = take((size_t)(hp->Lmax + 1) * rows * D * 4);
+    hp->o_H = take((size_t)(hp->Lmax + 1 + ROL) * rows * D * 4);
+    hp->o_GH = take((size_t)(hp->Lmax + 1 + ROL) * rows * D * 4);
     hp->o_tpos = take((size_t)graphs * D * 4);
     hp->o_tneg = take((size_t)graphs * D * 4);
     hp->o_spos = take((size_t)graphs * 4);
@@ -2684,7 +2772,11 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->ro_kin = 0;
     hp->ro_direct = false;
     hp->rlin_bytes = 0;
-    if (P->readout >= MPQE_READOUT_MLP) {
+    if (ro) {           // (on the chain: no buffers of its own -- levels L + 1, L + 2 of H / GH)
+        hp->ro_rows = rows;
+        hp->ro_kin = D;
+    }
+    if (P->readout >= MPQE_READOUT_MLP && !ro) {
         const bool pairs = P->readout == MPQE_READOUT_TARGETMLP;
         hp->ro_rows = pairs ? rows - graphs : rows;
         hp->ro_kin = pairs ? 2 * D : (P->readout == MPQE_READOUT_CONCAT ? P->num_layers * D : D);
@@ -2869,8 +2961,17 @@ static std::shared_ptr<CachedPlan> plan_for(const mpqe_step_params_t *P, const m
 static bool want_chain(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb) {
     if (!P || !B || nb < 1 || nb > MPQE_STEP_MAX_BATCHES) return false;
     bool use_chain = !(P->flags & MPQE_STEP_NO_CHAIN) && (P->dim == 64 || P->dim == 128 || P->dim == 256) &&
-                     P->readout < MPQE_READOUT_CALLER;      // (the caller's / the learned readouts need the node states in HBM)
+                     (P->readout < MPQE_READOUT_CALLER || P->readout == MPQE_READOUT_MLP);
+    // (the caller's readout, targetmlp and concat need the node states in HBM: level form. MLP: two more levels of the chain,
+    // while the ReLU bits of its hidden rows have a level to live in and two layer slots are free for its parameters)
     if (!use_chain) return false;
+    if (P->readout == MPQE_READOUT_MLP) {
+        if (P->num_layers + 2 > MPQE_STEP_MAX_LAYERS || !P->readout_w0 || !P->readout_w2) return false;
+        if (!ptr_vec_ok(P->readout_w0, P->dim) || !ptr_vec_ok(P->readout_w2, P->dim)) return false;
+        if ((P->readout_b0 && (uintptr_t)P->readout_b0 % 16 != 0) || (P->readout_b2 && (uintptr_t)P->readout_b2 % 16 != 0)) return false;
+        for (int i = 0; i < nb; ++i)
+            if (B[i].num_passes + 1 > CH_MASK_LEVELS) return false;
+    }
     long long graphs = 0;
     for (int i = 0; i < nb; ++i) graphs += B[i].batch_size;
     use_chain = graphs <= CHAIN_MAX_GRAPHS && P->num_layers > 0 && P->num_layers <= MPQE_STEP_MAX_LAYERS;
@@ -3296,7 +3397,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     const bool phase_score = phase == MPQE_STEP_PHASE_SCORES || phase == MPQE_STEP_PHASE_SCORES_ONLY;
     if ((phase >= 2) != (P->readout == MPQE_READOUT_CALLER)) return MPQE_ERR_INVALID_ARG;
     const bool learned = P->readout >= MPQE_READOUT_MLP;       // (step_readout.h: the readout's two Linear layers are the library's too)
-    if ((phase >= 2 || learned) && (use_chain || hp.nlanes > 1)) return MPQE_ERR_UNSUPPORTED;
+    if ((phase >= 2 || learned) && ((use_chain && !hp.ro_chain) || hp.nlanes > 1)) return MPQE_ERR_UNSUPPORTED;
     if (learned) {
         if (!P->readout_w0 || !P->readout_b0 || !P->readout_w2 || !P->readout_b2) return MPQE_ERR_INVALID_ARG;
         if (P->readout_scatter < MPQE_SCATTER_ADD || P->readout_scatter > MPQE_SCATTER_MEAN) return MPQE_ERR_INVALID_ARG;
@@ -3372,6 +3473,18 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             gp.bias[l] = G->bias[l];
         }
     }
+    if (hp.ro_chain) {       // the readout's Linear layers: virtual layers of the chain form (HostPlan.ro_chain)
+        lp.root[hp.ro_layer] = P->readout_w0;
+        lp.bias[hp.ro_layer] = P->readout_b0;
+        lp.root[hp.ro_layer + 1] = P->readout_w2;
+        lp.bias[hp.ro_layer + 1] = P->readout_b2;
+        if (backward) {
+            gp.root[hp.ro_layer] = G->readout_w0;
+            gp.bias[hp.ro_layer] = G->readout_b0;
+            gp.root[hp.ro_layer + 1] = G->readout_w2;
+            gp.bias[hp.ro_layer + 1] = G->readout_b2;
+        }
+    }
     int vec_tab = D % 4 == 0;
     for (int m = 0; m < P->num_modes; ++m) {
         if (!P->tables[m]) return MPQE_ERR_INVALID_ARG;
@@ -3441,7 +3554,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                 // (merged launch: a root matrix that tiles / a rank-1 op of the SAME launch write whole is not zero-filled
                 // -- the fill would race with its writers, who store instead of adding)
                 for (size_t k = 0; merged && k < hp.whole_roots.size(); ++k)
-                    if (G->root[hp.whole_roots[k]] == ptr) return;
+                    if (gp.root[hp.whole_roots[k]] == ptr) return;
                 for (int k = 0; k < zs.count; ++k)
                     if (zs.p[k] == ptr) return;                  // shared layers repeat their buffers
                 if (zs.count >= PREP_MAX_SEGS) return;
@@ -3465,7 +3578,27 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                 seg(G->readout_b2, D);
             }
             // (SPARSE_TABLES: only the touched rows of the table gradients are ever read; they are written, not accumulated)
-            for (int m = 0; m < P->num_modes && !sparse_tables; ++m) seg(G->tables[m], (long long)P->table_rows[m] * D);
+            if (use_chain && !use_touch && !sparse_tables) {
+                // chain form WITHOUT a touch plan: the chain workgroups add into the tables with atomics -- a zero fill inside
+                // their own launch would race with them: a launch of its own in front
+                ZeroSegs zt;
+                memset(&zt, 0, sizeof(zt));
+                long long ztb = 0;
+                for (int m = 0; m < P->num_modes && zt.count < PREP_MAX_SEGS; ++m) {
+                    if (!G->tables[m] || P->table_rows[m] <= 0) continue;
+                    bool dup = false;
+                    for (int k = 0; k < zt.count; ++k) dup = dup || zt.p[k] == G->tables[m];
+                    if (dup) continue;
+                    zt.p[zt.count] = G->tables[m];
+                    zt.n[zt.count] = (long long)P->table_rows[m] * D;
+                    zt.block0[zt.count] = ztb;
+                    ztb += (zt.n[zt.count] + PREP_ZERO_FLOATS_PER_BLOCK - 1) / PREP_ZERO_FLOATS_PER_BLOCK;
+                    zt.count++;
+                }
+                zt.block0[zt.count] = ztb;
+                if (ztb > 0) hipLaunchKernelGGL(step_zero_kernel, dim3((unsigned)ztb), dim3(256), 0, s, zt);
+            } else
+                for (int m = 0; m < P->num_modes && !sparse_tables; ++m) seg(G->tables[m], (long long)P->table_rows[m] * D);
             zs.block0[zs.count] = zblocks;
         }
         if (use_chain) {
@@ -3475,7 +3608,9 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             pa.ua.nops = (int)hp.uops_f.size();
             pa.ua.epoch = epoch_f;
             pa.ublocks = pa.ua.nops * pa.ua.chunks;
-            pa.tblocks = backward ? (int)hp.wt_slots.size() * tpd * tpd : 0;
+            // (forward only: just the copies a learned readout's forward multiplies by -- the plan lists them last... not
+            // sorted: all of them are made, the backward levels' are then unused)
+            pa.tblocks = (backward || hp.ro_chain) ? (int)hp.wt_slots.size() * tpd * tpd : 0;
             pa.sblocks = 0;
             if (build_touch) {
                 const TouchLayout TL = touch_layout(hp.touch_M, 0);
@@ -3708,6 +3843,20 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             hipLaunchKernelGGL(step_tail_kernel<LD_SCALAR>, tgrid, dim3(256), 0, on, sd, tl, (const float *)H,
                                (const float *)GH, hp.level_stride, gp, zeroed, lp, ub, fa, ra);
     };
+    // the readout's regulariser (model.py:486-490), after the launch that writes loss[0]
+    auto ro_regulariser = [&](bool with_grads) {
+        float wsum = 0.f;
+        for (int i = 0; i < nb; ++i) wsum += hp.sd.b[i].weight;
+        if (!(P->readout_weight_decay > 0.f)) return;
+        RoRegArgs rr;
+        memset(&rr, 0, sizeof(rr));
+        rr.p[0] = P->readout_w0; rr.p[1] = P->readout_b0; rr.p[2] = P->readout_w2; rr.p[3] = P->readout_b2;
+        rr.n[0] = (long long)D * hp.ro_kin; rr.n[1] = D; rr.n[2] = (long long)D * D; rr.n[3] = D;
+        if (with_grads) { rr.g[0] = G->readout_w0; rr.g[1] = G->readout_b0; rr.g[2] = G->readout_w2; rr.g[3] = G->readout_b2; }
+        rr.coef = P->readout_weight_decay * wsum;
+        rr.loss = loss;
+        hipLaunchKernelGGL(step_ro_reg_kernel, dim3(1), dim3(1024), 0, s, rr);
+    };
     if (use_chain) {
         // assemble -> levels -> scores (-> levels back -> anchor-table gradients): one launch per lane
         ChainArgs ca;
@@ -3755,6 +3904,9 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             ca.done = merged ? reinterpret_cast<unsigned *>(db + hp.o_done) : nullptr;
             ca.arrive = ca.done ? ca.done + hp.done_inc.size() : nullptr;
             ca.done_inc = reinterpret_cast<const int *>(db + hp.o_done_inc);
+            ca.ro = hp.ro_chain ? 1 : 0;
+            ca.ro_layer = hp.ro_layer;
+            ca.ro_scatter = P->readout_scatter;
             PostArgs po;
             memset(&po, 0, sizeof(po));
             long long grid_blocks = pa.lead + pa.nchain + zblocks;
@@ -3798,7 +3950,14 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             grid_blocks += pa.strail;
             dim3 cgrid((unsigned)grid_blocks);
             mark(s);
-            if (D == 64) hipLaunchKernelGGL((step_chain_kernel<1, 1>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po);
+            if (hp.ro_chain) {
+                // (a learned readout on the chain: its own instances -- the others' code stays as it was)
+                if (D == 64) hipLaunchKernelGGL((step_chain_kernel<1, 1, 4, true>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po);
+                else if (D == 128 && (P->flags & MPQE_STEP_NO_KSPLIT))
+                    hipLaunchKernelGGL((step_chain_kernel<2, 1, 4, true>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po);
+                else if (D == 128) hipLaunchKernelGGL((step_chain_kernel<4, 2, 4, true>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po);
+                else hipLaunchKernelGGL((step_chain_kernel<4, 1, 4, true>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po);
+            } else if (D == 64) hipLaunchKernelGGL((step_chain_kernel<1, 1>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po);
             else if (D == 128 && (P->flags & MPQE_STEP_NO_KSPLIT))
                 hipLaunchKernelGGL((step_chain_kernel<2, 1>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po);
             else if (D == 128 && (P->flags & MPQE_STEP_EIGHT_WAVES))
@@ -3814,7 +3973,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                 (void)hipStreamWaitEvent(s, reinterpret_cast<hipEvent_t>(lanes->join_event[l]), 0);
             }
             hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss, lm, bterms,
-                               use_chain ? epoch_f : (unsigned *)nullptr);
+                               use_chain ? epoch_f : (unsigned *)nullptr, pa.tblocks > 0 ? 1 : 0);
+            if (learned) ro_regulariser(false);
             return mpqe_launch_status();
         }
         // (a side stream for the post-pass / table rows beside the tiles was measured: the cross-stream fork and join
@@ -3867,20 +4027,6 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             hipLaunchKernelGGL(step_ro_spread_kernel, ro_blocks(hp.sd.rows_total * (D / 4)), dim3(256), 0, s, sd, roa,
                                (const float *)ro_gx, GH);
         return MPQE_OK;
-    };
-    // the readout's regulariser (model.py:486-490), after the launch that writes loss[0]
-    auto ro_regulariser = [&](bool with_grads) {
-        float wsum = 0.f;
-        for (int i = 0; i < nb; ++i) wsum += hp.sd.b[i].weight;
-        if (!(P->readout_weight_decay > 0.f)) return;
-        RoRegArgs rr;
-        memset(&rr, 0, sizeof(rr));
-        rr.p[0] = P->readout_w0; rr.p[1] = P->readout_b0; rr.p[2] = P->readout_w2; rr.p[3] = P->readout_b2;
-        rr.n[0] = (long long)D * roa.kin; rr.n[1] = D; rr.n[2] = (long long)D * D; rr.n[3] = D;
-        if (with_grads) { rr.g[0] = G->readout_w0; rr.g[1] = G->readout_b0; rr.g[2] = G->readout_w2; rr.g[3] = G->readout_b2; }
-        rr.coef = P->readout_weight_decay * wsum;
-        rr.loss = loss;
-        hipLaunchKernelGGL(step_ro_reg_kernel, dim3(1), dim3(1024), 0, s, rr);
     };
     for (int l = 0; !use_chain && !phase_bwd && !phase_score && l < NL; ++l) {
         const long long nr = row0[l + 1] - row0[l], ngr = gr0[l + 1] - gr0[l];

@@ -42,12 +42,13 @@ __device__ __forceinline__ f32x2 gload2(const float *p) { return *(gvec2_ptr)(p)
 struct ChainOp {
     unsigned char src, node, layer, level;
     int mat, flags;
-    int wt_slot;          // backward ops: slot of the matrix's transposed copy in the step workspace;
-                          // forward, last K-block of a node update: the update's number in the forward programme (< CH_MAX_CV)
+    int wt_slot;          // backward ops: slot of the matrix's transposed copy in the step workspace (-1: the parameter itself --
+                          // a readout Linear's weight [out, in] IS the transposed form); forward, last K-block of a node
+                          // update: the update's number in the forward programme (< CH_MAX_CV; readout ops: 0 / 1)
     int aux;              // forward, last K-block of a node update: id of the node's constant vector (bias + the products
                           // of its batch-uniform sources, formed once per batch by the pre-pass), -1 = the layer's bias;
                           // backward, last K-block: first row in `parts` of the node's per-block column sums, -1 = none
-    int pad;
+    int pad;              // forward ops of a learned readout: 1 + slot of the transposed copy they multiply by (0: the parameter)
 };
 // one workgroup: graphs [g0, g0 + 16) of `batch`; its forward / backward programmes in the op table
 struct ChainRef {
@@ -59,6 +60,8 @@ struct ChainRef {
     int gi0;              // number of graph g0 among the step's graphs: g_off + g0
     int B;
     unsigned meta;        // N | A << 4 | anchor table 0 / 1 / 2 << 8 / 12 / 16 | target table << 20
+    int rof;              // learned readout on the chain (MPQE_READOUT_MLP): forward ops of its two Linear layers, between the
+                          // forward and the backward programme (whose first ops are then the readout's backward)
 };
 
 template <int NCB>
@@ -733,6 +736,8 @@ struct ChainArgs {
                                          // the weight gradients and the post-pass are a later launch
     unsigned *arrive;                    // ... and of chain workgroups whose stores have reached the L2
     const int *done_inc;                 // chain workgroups per counter and step
+    int ro;                              // != 0: a learned readout's Linear layers run on the chain (virtual layers ro_layer, + 1)
+    int ro_layer, ro_scatter;            // MPQE_SCATTER_* of the reduction over a graph's rows
 };
 
 // phase time stamps of a workgroup: the 100 MHz wall clock is one time base for the whole device, so the
@@ -765,7 +770,7 @@ __device__ __forceinline__ void chain_stamp_where(const ChainArgs &ca, int batch
 // NW = 8: the workgroup has eight waves, two per SIMD. Only the K loops use all of them (a wave of each K part on
 // every SIMD, so the node-update epilogue of one -- VALU work, which does not overlap with the MFMAs of its own
 // wave -- runs under the MFMAs of the other); the row-major phases stay with the first four waves (`four`).
-template <int NCB, int KS, int NW>
+template <int NCB, int KS, int NW, bool RO = false>
 __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, const LayerPtrs &lp, const TablePtrs &tabs,
                                             const ChainArgs &ca, ChainLds<NCB, KS, NW> &S) {
     constexpr int D = 16 * NCB * NW / KS, LDX = D + 4, BUF = 4 * CH_GB * LDX;
@@ -801,7 +806,8 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     // comes from the workgroup's own record; with a pack-time touch plan the id -> LUT -> row hops were done there (erow:
     // ONE round trip between the record and the row gather), otherwise they are done here (two); the programme's ops and
     // the batch record travel beside them.
-    const int nops = ref.fwd_count + ref.bwd_count;
+    const int rof = RO ? ref.rof : 0, nfwd = ref.fwd_count + rof;
+    const int nops = nfwd + ref.bwd_count;
     ChainOp op;
     if (tid < nops) op = ca.ops[ref.fwd_begin + tid];
     if (tid < 4 * CH_GB + 2 * CH_GB) {
@@ -859,14 +865,17 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     __syncthreads();
     {   // forward ops then backward ops of this block's programme (the host keeps them adjacent; requested above)
         if (tid < nops) {
-            if (tid < ref.fwd_count || CHAIN_DBG == 3)      // (3: timing experiment, wrong results)
+            if (tid < nfwd || CHAIN_DBG == 3) {     // (3: timing experiment, wrong results)
                 S.wp[tid] = op.mat >= 0 ? pick_layer(lp.basis, op.layer) + (long long)op.mat * D * D
                                         : pick_layer(lp.root, op.layer);
-            else
+                if (RO && op.pad > 0) S.wp[tid] = ca.WT + (long long)(op.pad - 1) * D * D;
+            } else {
                 S.wp[tid] = ca.WT + (long long)op.wt_slot * D * D;
+                if (RO && op.wt_slot < 0) S.wp[tid] = pick_layer(lp.root, op.layer);
+            }
             S.opw[tid][0] = op.src | (op.node << 8) | (op.layer << 16) | (op.level << 24);
             S.opw[tid][1] = op.flags;
-            S.opp[tid] = tid < ref.fwd_count ? op.wt_slot : op.aux;
+            S.opp[tid] = tid < nfwd ? op.wt_slot : op.aux;
             if (tid < ref.fwd_count && (op.flags & CH_LAST)) {      // one slot per forward node update
                 S.cvid[op.wt_slot] = op.aux;
                 S.cvl[op.wt_slot] = op.layer;
@@ -972,15 +981,24 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     }
     // (the count of finished transpose workgroups, for the wait in front of the backward levels: requested now)
     unsigned wt_have0 = 0;
-    if (tid == 0 && ca.backward && ca.wt_count) wt_have0 = chain_count_load(ca.wt_count);
+    if (tid == 0 && (ca.backward || RO) && ca.wt_count) wt_have0 = chain_count_load(ca.wt_count);
     // ---- forward levels
     int cur = 0;
     chain_run<NCB, KS, false, NW>(S, 0, ref.fwd_count * IPO, N, ng, ca.H + row0 * D, ca.level_stride, cur, nullptr, 0,
                                   ca.cv_gran, ca.cv_gran ? *ca.epoch_f + 1u : 0u, ca.err);
 
     chain_stamp(ca, 3);
-    if (ca.backward && ref.bwd_count > 0 && ca.wt_count) {
-        // The transposed copies the backward levels multiply by are written by workgroups of THIS launch, which
+    if constexpr (RO) {
+        // the readout's biases take the first two slots of the forward constants (dead: every forward level is done)
+        if (tid < D) {
+            const float *b0 = pick_layer(lp.bias, ca.ro_layer), *b2 = pick_layer(lp.bias, ca.ro_layer + 1);
+            S.cv[tid] = b0 ? b0[tid] : 0.f;
+            S.cv[D + tid] = b2 ? b2[tid] : 0.f;
+        }
+    }
+    if (((ca.backward && ref.bwd_count > 0) || (RO && rof > 0)) && ca.wt_count) {
+        // The transposed copies the backward levels (and a learned readout's forward) multiply by are written by
+        // workgroups of THIS launch, which
         // publish them with an agent-scope release and count themselves in (step.hip: prep_transpose_block). One lane
         // compares the count it requested before the forward levels (normally already complete) with the target and
         // polls on only if it was not; then the workgroup's barrier. No acquire fence: it would invalidate this CU's L1,
@@ -1001,8 +1019,8 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
             }
         }
         __syncthreads();
-    }
-    if (ca.backward && ref.bwd_count > 0 && four) warm(ref.fwd_count, ref.bwd_count);
+    } else if (RO) __syncthreads();
+    if (ca.backward && ref.bwd_count > 0 && four) warm(nfwd, ref.bwd_count);
     // node states that are still batch-uniform at level L (no anchor within L hops: possible when a batch runs fewer
     // passes than its diameter) never went through the K loops: the readout sees the pre-pass' vector in every row
     if (b.uvL[0] >= 0 || b.uvL[1] >= 0 || b.uvL[2] >= 0 || b.uvL[3] >= 0) {      // (uniform over the workgroup)
@@ -1020,15 +1038,24 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
         }
         __syncthreads();
     }
+    if constexpr (RO) {
+        // ---- a learned readout's Linear - ReLU - Linear on every node row (reference model.py:497-515, MLPReadout): two
+        // more levels of node updates, one K-block each (the node's own row times W^T: a transposed copy of this launch)
+        if (rof > 0)
+            chain_run<NCB, KS, false, NW>(S, ref.fwd_count, rof * IPO, N, ng, ca.H + row0 * D, ca.level_stride, cur);
+    }
     // ---- readout, cosine scores against the + and - target, hinge terms (reference model.py:447-462,
     // 483-485); backward: d hinge -> d cosine -> d readout written over H[L] in LDS (a lane group owns whole
     // graphs) and to gH[L]; target-table gradients through the normalisation. 16 lanes per graph (see above).
     if (four) {
         float *Xc = S.xs + cur * BUF;
-        float *GL = ca.GH + (long long)L * ca.level_stride + row0 * D;
+        // (a learned readout: the rows the reduction reads are its output level, L + 2)
+        float *GL = ca.GH + (long long)(RO ? L + 2 : L) * ca.level_stride + row0 * D;
         const int i = sc_i;
         const bool on = i < ng;
-        const int readout = sd->readout;
+        // (a learned readout ends in torch_scatter's add / mean / max over the graph's rows: the sum / max readouts' code)
+        const int readout = RO ? (ca.ro_scatter == MPQE_SCATTER_MAX ? MPQE_READOUT_MAX : MPQE_READOUT_SUM) : sd->readout;
+        const float rscale = RO && ca.ro_scatter == MPQE_SCATTER_MEAN ? 1.f / (float)N : 1.f;
         auto gsum = [](float v) { return chain_sum16(v); };
         const float *h = Xc + i * LDX;                    // node n at h + n * CH_GB * LDX
         float q[CC];
@@ -1058,7 +1085,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
             float tm = hn[0];
 #pragma unroll
             for (int n = 1; n < 4; ++n) tm = n == A ? hn[n] : tm;
-            q[cc] = readout == MPQE_READOUT_TM ? tm : (readout == MPQE_READOUT_SUM ? sum : best);
+            q[cc] = readout == MPQE_READOUT_TM ? tm : (readout == MPQE_READOUT_SUM ? (RO ? sum * rscale : sum) : best);
             arg[cc] = am;
         }
         float ssp = 0.f, ssn = 0.f;
@@ -1113,7 +1140,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
             const float ktp = rp > eps ? sp * chain_rcp(np_ * np_) : 0.f;
             const float ktn = rn > eps ? sn * chain_rcp(nn_ * nn_) : 0.f;
             const unsigned tmask = readout == MPQE_READOUT_SUM ? 0xFu : 1u << A;
-            const unsigned liveL = b.live[L];
+            const unsigned liveL = b.live[RO ? L + 2 : L];
             float yg_p = 0.f, yg_n = 0.f;
 #pragma unroll
             for (int cc = 0; cc < CC; ++cc) {
@@ -1122,7 +1149,8 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
                 const float gyn = gsn * (q[cc] * inv_n - ktn * tn[cc]);
                 yg_p += tp[cc] * gyp;
                 yg_n += tn[cc] * gyn;
-                const float gq = gsp * tp[cc] * inv_p + gsn * tn[cc] * inv_n - kq_ * q[cc];
+                float gq = gsp * tp[cc] * inv_p + gsn * tn[cc] * inv_n - kq_ * q[cc];
+                if (RO) gq *= rscale;
                 const unsigned takes = readout == MPQE_READOUT_MAX ? 1u << arg[cc] : tmask;   // slots that get gq
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
@@ -1174,7 +1202,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     }
 
     // ---- backward levels
-    chain_run<NCB, KS, true, NW>(S, ref.fwd_count, ref.bwd_count * IPO, N, ng, ca.GH + row0 * D, ca.level_stride, cur,
+    chain_run<NCB, KS, true, NW>(S, nfwd, ref.bwd_count * IPO, N, ng, ca.GH + row0 * D, ca.level_stride, cur,
                                  ca.parts, blk);
 
     chain_stamp(ca, 5);

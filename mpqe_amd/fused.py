@@ -143,18 +143,25 @@ class FusedTrainStep(object):
         enc = model.enc
         if not hasattr(enc, 'table') or getattr(enc, 'node_maps', None) is None:
             raise ValueError('FusedTrainStep needs a DirectEncoder built with node_maps')
-        # learned readouts (reference model.py:441-446, 497-553): inside the same library call -- gather, the two Linear
-        # layers on the dense-layer kernels, the reduction over each graph's rows, and back (csrc/step_readout.h); the
-        # level form runs (the node states must be in HBM)
+        # learned readouts (reference model.py:441-446, 497-553): inside the same library call. `mlp` on the chain form (its
+        # two Linear layers are two more levels of every graph block's programme: csrc/step_chain.h) when the dimension is
+        # one of the chain kernel's and two layer slots are free; `targetmlp`, `concat` and the rest on the level form --
+        # gather, the two Linear layers on the dense-layer kernels, the reduction over each graph's rows, and back
+        # (csrc/step_readout.h; the node states must be in HBM)
         self.learned = model.readout_str in _capi.LEARNED_READOUT_IDS
         if not self.learned and model.readout_str not in _capi.READOUT_IDS:
             raise NotImplementedError('fused step: unknown readout %r' % model.readout_str)
         if self.learned:
-            if sparse_tables:
-                raise ValueError('sparse_tables needs the chain form (readouts sum / max / mp)')
             if model.emb_dim % 4:
                 raise NotImplementedError('fused step with a learned readout: embedding dimension must be a multiple of 4')
-            chain, touch, lanes = False, False, 1
+            on_chain = (chain and model.readout_str == 'mlp' and model.emb_dim in (64, 128, 256) and
+                        model.num_layers <= 3 and not eight_waves)
+            if on_chain:
+                lanes = 1
+            else:
+                if sparse_tables:
+                    raise ValueError('sparse_tables needs the chain form (readouts sum / max / mp, mlp)')
+                chain, touch, lanes = False, False, 1
         self.model = model
         self.margin = float(margin)
         # speed switches of the library call (include/mpqe_amd.h): identical loss / scores / gradients

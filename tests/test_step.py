@@ -108,8 +108,8 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
     dnm = be.put(node_map.numpy())
     dmode = put('mode_embeddings.weight')
     learned = between is None and cfg['readout'] in _capi.LEARNED_READOUT_IDS
-    if between is not None or learned:
-        touch = False
+    if between is not None or (learned and not (cfg['readout'] == 'mlp' and D in (64, 128, 256))):
+        touch = False           # (level form: it has no use for a touch plan)
     rid = _capi.READOUT_CALLER if between is not None else (_capi.LEARNED_READOUT_IDS[cfg['readout']] if learned else cfg['readout'])
     P = _capi.make_step_params(D, R, rid, [be.ptr(t) for t in tables],
                                [params['enc.feat-%s.weight' % m].shape[0] for m in modes], be.ptr(dnm),
@@ -485,6 +485,63 @@ def test_fused_step_with_learned_readout_matches_oracle(be, readout, scatter_op,
             ref = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
             np.testing.assert_allclose(grads[k], ref, rtol=1e-4, atol=2e-6, err_msg=k)
     loss, sp, sn, grads, err = run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=0)
+    np.testing.assert_allclose(loss[0], total.item(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sp, np.concatenate(sp_ref), rtol=1e-5, atol=1e-6)
+    assert err == 0 and all(not g.any() for g in grads.values())
+
+
+@pytest.mark.parametrize('D,mix,scatter_op,adaptive,shared,wd,touch', [
+    (64, 'all7', 'add', True, False, 1e-3, 'step'), (64, 'all7', 'max', False, True, 0, False),
+    (64, 'many', 'mean', True, False, 1e-3, 'pack'), (128, 'tiny', 'add', True, False, 0, 'step'),
+    (128, 'dup', 'max', False, False, 1e-3, 'step')])
+def test_mlp_readout_on_the_chain_matches_oracle(be, capfd, D, mix, scatter_op, adaptive, shared, wd, touch):
+    """MLPReadout (reference model.py:497-515) on the CHAIN form: its Linear - ReLU - Linear are two more levels of every
+    graph block's programme (the node's own row times W^T, ReLU bits in LDS), the reduction over a graph's rows is the
+    score phase's sum / max, the weight gradients are tiles with the operands swapped (nn.Linear stores [out, in]), the
+    bias gradients column sums like the layers'. Loss, scores and every gradient against the oracle's whole model; the
+    level form (MPQE_STEP_NO_CHAIN) gives the same."""
+    margin = 1.0
+    mixes = dict(MIXES, **EDGE_MIXES)
+    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(31, D, 3, shared, mixes[mix], 'mlp', adaptive)
+    cfg['scatter_op'], cfg['weight_decay'] = scatter_op, wd
+    total, per, sp_ref, sn_ref = 0, [], [], []
+    for b in batches:
+        q = ref_cpu.encode_queries(params, cfg, node_map, b['formula'], b['col'])
+        pos = ref_cpu.score(params, node_map, b['formula'], q, b['targets'])
+        neg = ref_cpu.score(params, node_map, b['formula'], q, b['negs'])
+        l = torch.clamp(margin - (pos - neg), min=0).mean()
+        per.append(l.item())
+        if wd > 0:
+            l = l + wd * sum(torch.norm(v) for k, v in params.items() if k.startswith('readout.'))
+        total = total + b['weight'] * l
+        sp_ref.append(pos.detach().numpy())
+        sn_ref.append(neg.detach().numpy())
+    total.backward()
+    be.lib.mpqe_debug_option(b'DUMP_PLAN', 1, 1)
+    try:
+        capfd.readouterr()
+        first = run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, flags=_capi.STEP_ZERO_GRADS, touch=touch,
+                         repeat=2)
+        assert 'plan: chain 1' in capfd.readouterr().err
+    finally:
+        be.lib.mpqe_debug_option(b'DUMP_PLAN', 0, 0)
+    for what, (loss, sp, sn, grads, err) in (
+            ('zeroed', first),
+            ('accumulate', run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, touch=touch)),
+            ('level form', run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, flags=_capi.STEP_NO_CHAIN))):
+        assert err == 0, what
+        np.testing.assert_allclose(sp, np.concatenate(sp_ref), rtol=1e-5, atol=1e-6, err_msg=what)
+        np.testing.assert_allclose(sn, np.concatenate(sn_ref), rtol=1e-5, atol=1e-6, err_msg=what)
+        np.testing.assert_allclose(loss[1:], per, rtol=1e-5, atol=1e-6, err_msg=what)
+        np.testing.assert_allclose(loss[0], total.item(), rtol=1e-5, atol=1e-6, err_msg=what)
+        done = set()
+        for k, p in params.items():
+            if id(p) in done:
+                continue
+            done.add(id(p))
+            ref = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
+            np.testing.assert_allclose(grads[k], ref, rtol=1e-4, atol=2e-6, err_msg='%s %s' % (what, k))
+    loss, sp, sn, grads, err = run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=0, repeat=2)
     np.testing.assert_allclose(loss[0], total.item(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(sp, np.concatenate(sp_ref), rtol=1e-5, atol=1e-6)
     assert err == 0 and all(not g.any() for g in grads.values())
