@@ -289,6 +289,16 @@ struct PrepArgs {
     int lead;                 // prologue workgroups in front of the chain workgroups: sblocks + ublocks + tblocks rounded
                               // up to a multiple of 8 (chain workgroup b keeps XCD b % 8)
     int nchain;               // chain workgroups (holes of the placement grid included)
+    int plast;                // != 0: the prologue's items BEHIND the chain workgroups ([sort rows][chain][items]). A prologue
+                              // of more than one workgroup per CU holds slots the chain workgroups are dealt into: those wait
+                              // until prologue workgroups end, here and there, and pair up on some CUs while others stay
+                              // empty (AIFB step with the MLP readout, ~400 prologue workgroups: 203 of 256 CUs used, chain
+                              // launch 172 us; behind the chain: 256 CUs, 133 us. The default step's ~230 fit beside the chain
+                              // workgroups and are 1.2 us faster in front). Only when every chain workgroup is resident with
+                              // slots to spare: a producer must never wait for a slot held by its consumers
+    int plna;                 // ... and those items are dealt only to the plna XCDs whose CUs hold at most ONE chain workgroup
+    unsigned plxrank;         // (4 bits per XCD: rank + 1, 0 = none): an XCD whose slots are all taken by chain workgroups
+                              // would queue a producer behind its waiting consumers
     const WtSlot *slots;
     float *WT;
     unsigned *wt_count;
@@ -417,7 +427,16 @@ __global__ __launch_bounds__(64 * NW) void step_chain_kernel(const StepDev *__re
         if (NW == 4 || threadIdx.x < TSORT_THREADS) tsort_block(pa.ts, bid - ((int)gridDim.x - pa.strail), reinterpret_cast<unsigned *>(S.xs));
         return;
     }
-    if (bid < pa.lead) role = 1;
+    if (pa.plast) {
+        if (bid < pa.sblocks) role = 1;
+        else if (bid < pa.sblocks + pa.nchain) role = 0, bid -= pa.sblocks;
+        else if (bid < pa.lead + pa.nchain) {
+            const int t = bid - pa.sblocks - pa.nchain;
+            const int rk = (int)((pa.plxrank >> (4 * (t & 7))) & 15u) - 1;
+            if (rk < 0) return;
+            role = 1, bid = pa.sblocks + (t >> 3) * pa.plna + rk;      // (numbered on from the items the sort rows held)
+        } else role = 2, bid -= pa.lead + pa.nchain;
+    } else if (bid < pa.lead) role = 1;
     else if (bid < pa.lead + pa.nchain) role = 0, bid -= pa.lead;
     else role = 2, bid -= pa.lead + pa.nchain;
     if (role == 0) {
@@ -1493,6 +1512,7 @@ struct HostPlan {
     // the batch table in the descriptor image, the sort's buffers in the workspace; ts_blocks = 0: not in this plan
     int ts_blocks, ts_key_bits, ts_row_bits;
     int sort_na, sort_rank[STEP_XCDS_MAX];       // the XCDs the sort's workgroups are dealt to (rank, or -1)
+    int pl_na, pl_rank[STEP_XCDS_MAX];           // the XCDs with at most one chain workgroup per CU (PrepArgs.plast)
     size_t o_tmeta, o_tsort;
     int blk_off[MPQE_STEP_MAX_BATCHES + 1];        // chain blocks before batch i (slots of block_terms)
     std::vector<ZMat> zmats;                       // relation matrices of the gradient that no source touches
@@ -2642,6 +2662,8 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                     }
                 }
                 hp->sort_na = sna;
+                hp->pl_na = 0;
+                for (int x = 0; x < STEP_XCDS; ++x) hp->pl_rank[x] = bins[x].size() <= cus ? hp->pl_na++ : -1;
             }
             size_t longest = 0;
             for (int x = 0; x < STEP_XCDS; ++x) {
@@ -3658,6 +3680,29 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             pa.lead = (pa.sblocks / 8 * pa.sna + pa.ublocks + pa.tblocks + 7) / 8 * 8;
             if (pa.lead < pa.sblocks) pa.lead = pa.sblocks;
             pa.nchain = (int)hp.crefs.size();
+            if (NL == 1) {
+                // (two workgroups per CU by registers and LDS; D = 256: one)
+                const int slots = (D == 256 || (P->flags & MPQE_STEP_EIGHT_WAVES)) ? STEP_CUS : 2 * STEP_CUS;
+#ifdef MPQE_EMU
+                const bool fits = false && slots;       // (the host emulator runs a launch's workgroups one after the other, in order)
+#else
+                // (the placement grid's holes leave at once: only the real chain workgroups hold slots)
+                const bool fits = pa.sblocks + hp.blk_off[nb] + 32 <= slots;
+#endif
+                const int force = mpqe_dbg_value("PROLOGUE_LAST", -1);       // (timing experiments)
+                pa.plast = fits && hp.pl_na > 0 && (force >= 0 ? force != 0 : pa.lead > slots / 2) ? 1 : 0;
+                if (pa.plast) {
+                    pa.plna = hp.pl_na;
+                    pa.plxrank = 0;
+                    for (int x = 0; x < STEP_XCDS; ++x) pa.plxrank |= (unsigned)(hp.pl_rank[x] + 1) << (4 * x);
+                    const int held = pa.sblocks / 8 * (8 - pa.sna);          // items the sort rows hold
+                    const int rest = pa.ublocks + pa.tblocks > held ? pa.ublocks + pa.tblocks - held : 0;
+                    pa.lead = pa.sblocks + (rest + pa.plna - 1) / pa.plna * 8;
+                }
+            }
+            if (dbg_on("DUMP_PLAN"))
+                fprintf(stderr, "launch: sort rows %d (x8) | pre-pass %d transposes %d | lead %d | chain %d of %d | prologue behind the chain %d (XCDs %d)\n",
+                        pa.sblocks / 8, pa.ublocks, pa.tblocks, pa.lead, hp.blk_off[nb], pa.nchain, pa.plast, pa.plna);
             pa.slots = reinterpret_cast<const WtSlot *>(db + hp.o_wtslots);
             pa.WT = WT;
             pa.wt_count = epoch_f + 32;

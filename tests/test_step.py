@@ -525,6 +525,20 @@ def test_mlp_readout_on_the_chain_matches_oracle(be, capfd, D, mix, scatter_op, 
         assert 'plan: chain 1' in capfd.readouterr().err
     finally:
         be.lib.mpqe_debug_option(b'DUMP_PLAN', 0, 0)
+    # the prologue's items behind the chain workgroups, or in front (a launch order the library picks by the step's size; the
+    # host emulator runs workgroups in order and keeps the prologue in front)
+    for order in (0, 1):
+        be.lib.mpqe_debug_option(b'PROLOGUE_LAST', order, 1)
+        try:
+            other = run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, flags=_capi.STEP_ZERO_GRADS, touch=touch)
+        finally:
+            be.lib.mpqe_debug_option(b'PROLOGUE_LAST', 0, 0)
+        assert other[4] == 0
+        for a, b in zip(other[:3], first[:3]):
+            np.testing.assert_array_equal(a, b)
+        for k in first[3]:
+            if touch or not k.startswith('enc.'):      # (table gradients by atomics: their order is the hardware's)
+                np.testing.assert_array_equal(other[3][k], first[3][k], err_msg=k)
     for what, (loss, sp, sn, grads, err) in (
             ('zeroed', first),
             ('accumulate', run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, touch=touch)),
