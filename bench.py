@@ -284,6 +284,10 @@ def time_fused_kernels(step, packed, data, model, readout, reps=20):
     def flops(lo, hi, p):
         return sum(2.0 * t.B * D * D * u[p] for t, L, u in zip(tmpl[lo:hi], Ls[lo:hi], units[lo:hi]) if L > p)
     total = sum(flops(0, len(tmpl), p) for p in range(Lmax))
+    if step.learned and step.uses_chain(packed):
+        # the MLP readout on the chain form: two Linear layers on every node row -- 2 N more [B, D] x [D, D] products per
+        # batch, forward, backward-x and weight gradient alike
+        total += sum(2.0 * t.B * D * D * 2 * t.N for t in tmpl)
     plan = []                                            # (kernel, flops) per event pair, in library order
     lanes = [(packed.lane_begin[l], packed.lane_begin[l + 1]) for l in range(len(packed.lane_begin) - 1)]
     lane_total = [sum(flops(lo, hi, p) for p in range(Lmax)) for lo, hi in lanes]
@@ -691,10 +695,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # (learned readouts: mlp rides on the chain form -- csrc/step_chain.h --, targetmlp / concat on the level form)
+    level_form = bool(learned and use_fused and (fstep.flags & 2))      # (MPQE_STEP_NO_CHAIN)
     if use_fused and not args.no_self_check and not args.sparse_tables:      # (the check compares DENSE gradients)
         self_check(model, fstep, packed[0], pool[0], world)
         if fresh:
-            fresh_check(fstep, descs[0], fresh_ids[0][0], pool[0], exact=not learned)
+            fresh_check(fstep, descs[0], fresh_ids[0][0], pool[0], exact=not level_form)
     xnote = None
     if exchange is not None and exchange.transport_note:
         xnote = exchange.transport_note
@@ -762,12 +768,13 @@ def main():
                    'parallelism': 'dp%d (graphs sharded by rank, RCCL all-reduce of gradients)' % world
                                   if world > 1 else 'single GPU',
                    'host_path': ('fused step: one C-ABI call per step%s, %d stream lane(s)%s'
-                                 % (' (level form, learned readout inside)' if learned else '',
+                                 % ((' (level form, learned readout inside)' if level_form else
+                                     ' (chain form, the readout\'s Linear layers inside the chain launch)') if learned else '',
                                     args.lanes, ', replayed from a hipGraph' if args.graph else '')) if use_fused
                                 else 'drop-in modules (one autograd graph per step)',
                    'ids': ('fresh every step: %d pre-drawn id sets resident in HBM, 4 formula sets; id -> row lookups and the '
                            '%s inside the timed step' % (sum(int(t.shape[0]) for t in fresh_ids),
-                                                         'table gradients by fp32 atomics' if learned else 'touch plan (%s)' % args.touch))
+                                                         'table gradients by fp32 atomics' if level_form else 'touch plan (%s)' % args.touch))
                           if fresh else 'replay of 4 pre-packed steps'},
     }
     if replay_ms is not None:

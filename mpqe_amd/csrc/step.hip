@@ -3839,7 +3839,10 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             // three runs each: 64.95 / 65.15 / 65.04 us against 65.70 / 65.60 / 65.47 with both kinds everywhere; one
             // or three XCDs: 65.8 / 66.0). mpqe_debug_option TAIL_UX overrides (0 = everywhere).
             const int uxv = mpqe_dbg_value("TAIL_UX", 2);
-            if (use_chain && first == 0 && tl.ublocks >= 4 && uxv > 0 && uxv < 8) {
+            // (only while the tiles are all resident at once on the other XCDs -- two per CU: with more of them the vector
+            // ops' XCDs would stand idle for most of the launch. AIFB step with the MLP readout, 988 tiles: 64.3 -> 52.9 us)
+            if (use_chain && first == 0 && tl.ublocks >= 4 && uxv > 0 && uxv < 8 &&
+                (count <= (8 - uxv) * 2 * (STEP_CUS / STEP_XCDS) || mpqe_dbg_value("TAIL_UX", -1) > 0)) {
                 tl.ux = uxv;
                 const int ra = (tl.ublocks + tl.ux - 1) / tl.ux, rb = (count + tl.zblocks + (8 - tl.ux) - 1) / (8 - tl.ux);
                 nblocks = 8 * (ra > rb ? ra : rb);
@@ -3876,6 +3879,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                                (const float *)GH, hp.level_stride, gp, zeroed, lp, uf, fa, rf);
             reduced = true;
         } else if (use_chain)
+            // (ONE tile workgroup per CU -- the launch's LDS padded beyond half a CU's -- was measured on the 988-tile step of
+            // the MLP readout: 71 - 75 us against 64; two per CU stay)
             hipLaunchKernelGGL(step_tail_kernel<LD_T>, tgrid, dim3(256), 0, on, sd, tl, (const float *)H,
                                (const float *)GH, hp.level_stride, gp, zeroed, lp, ub, fa, ra);
         else if (fast && hp.whole_ksteps)

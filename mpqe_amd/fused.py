@@ -560,7 +560,7 @@ class FusedTrainStep(object):
         """True when the library runs the graph-block chain kernels for this step (csrc/step.hip)."""
         passes = max(int(packed.batches[i].num_passes) for i in range(packed.nb))
         return (not (self.flags & _capi.STEP_NO_CHAIN) and self.model.emb_dim in (64, 128, 256)
-                and packed.num_graphs <= CHAIN_MAX_GRAPHS and passes <= 5)
+                and packed.num_graphs <= CHAIN_MAX_GRAPHS and passes <= (3 if self.learned else 5))
 
     def merged(self, packed):
         """True when the weight-gradient tiles and the backward post-pass ride in the chain launch (two launches per
