@@ -128,7 +128,7 @@ struct VSource {
 // one reduction group: out[...] += sum of `count` consecutive slabs/partials starting at `start`
 // (+ matrices, chain form with uniform node states: the sum of r1_count rank-1 terms u (x) v from `r1_start` on)
 struct RGroup {
-    int kind;          // 0 basis, 1 root, 2 bias, 3 mode row
+    int kind;          // 0 basis, 1 root, 2 bias, 3 mode row; 4 / 5: column block 0 / 1 of a [D, 2 D] matrix (`root` of `layer`)
     int layer;         // layer index (kinds 0-2)
     long long row;     // relation id (kind 0) / mode id (kind 3)
     int start, count;
@@ -266,6 +266,9 @@ __device__ __forceinline__ float *pick_grad(float *const *arr, int li) {
 // chains multiply by (64 x 64 pieces through LDS), zero fill of the gradient buffers (MPQE_STEP_ZERO_GRADS).
 struct WtSlot {
     int layer, mat;       // mat < 0: root
+    // a learned readout's first Linear layer may be WIDE (targetmlp: [D, 2 D]): the copy is of its D x D column block from
+    // column col0 on, row length ld; plain: copied as it is (the backward chains multiply by the block itself), not transposed
+    int col0, ld, plain;
 };
 #define PREP_MAX_SEGS 48
 struct ZeroSegs {
@@ -312,7 +315,8 @@ __device__ __forceinline__ void prep_transpose_block(const LayerPtrs &lp, const 
     const int tpd = D / 64, per = tpd * tpd;
     const int si = tb / per, tr = (tb % per) / tpd, tc = tb % tpd;
     const WtSlot sl = pa.slots[si];
-    const float *W = sl.mat >= 0 ? pick_layer(lp.basis, sl.layer) + (long long)sl.mat * D * D : pick_layer(lp.root, sl.layer);
+    const float *W = (sl.mat >= 0 ? pick_layer(lp.basis, sl.layer) + (long long)sl.mat * D * D : pick_layer(lp.root, sl.layer)) + sl.col0;
+    const int ld = sl.ld;
     float *T = pa.WT + (long long)si * D * D;
     const int tid = threadIdx.x;
     if (tid < 256) {
@@ -320,13 +324,14 @@ __device__ __forceinline__ void prep_transpose_block(const LayerPtrs &lp, const 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = r0 + 16 * q;
-            const f32x4 v = gload4(W + (long long)(tr * 64 + r) * D + tc * 64 + 4 * c4);
+            const f32x4 v = gload4(W + (long long)(tr * 64 + r) * ld + tc * 64 + 4 * c4);
+            if (sl.plain) *reinterpret_cast<f32x4 *>(T + (long long)(tr * 64 + r) * D + tc * 64 + 4 * c4) = v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) tile[r][4 * c4 + e] = v[e];
         }
     }
     __syncthreads();
-    if (tid < 256) {
+    if (tid < 256 && !sl.plain) {
         const int c4 = tid & 15, r0 = tid >> 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1104,8 +1109,9 @@ __device__ __forceinline__ void reduce_block(const ReduceArgs &ra, int bx, int b
         return;
     }
     const RGroup g = groups[by];
-    const long long elems = g.kind <= 1 ? (long long)D * D : D;
-    if (g.kind >= 2 && vec && (256 % (D / 4)) == 0) {
+    const bool wide = g.kind >= 4;          // a column block of a [D, 2 D] matrix: rows 2 D apart
+    const long long elems = (g.kind <= 1 || wide) ? (long long)D * D : D;
+    if (g.kind >= 2 && !wide && vec && (256 % (D / 4)) == 0) {
         // a vector group (bias / mode row): hundreds of partial rows of D floats (one per chain block), ONE
         // workgroup: D/4 lanes cover a row, the 256 / (D/4) row groups each walk every RG-th row with 8 loads
         // in flight, then the row groups' sums are added in order (fixed order: reproducible)
@@ -1152,10 +1158,14 @@ __device__ __forceinline__ void reduce_block(const ReduceArgs &ra, int bx, int b
     const long long idx = ((long long)bx * 64 + el) * 4;
     if ((long long)bx * 256 >= elems) return;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    const float *p = (g.kind <= 1 ? slabs : partial) + (long long)g.start * elems + idx;
+    const float *p = ((g.kind <= 1 || wide) ? slabs : partial) + (long long)g.start * elems + idx;
     float *dst;
     if (g.kind == 0) dst = gp.basis[g.layer] ? gp.basis[g.layer] + g.row * elems : nullptr;
     else if (g.kind == 1) dst = gp.root[g.layer];
+    else if (wide) {
+        // (element idx of the block = row idx / D, column idx % D of it: `dst + idx` then IS its address)
+        dst = gp.root[g.layer] ? gp.root[g.layer] + (idx / D) * (long long)D + (g.kind == 5 ? D : 0) : nullptr;
+    }
     else if (g.kind == 2) dst = gp.bias[g.layer];
     else dst = gp.mode_emb ? gp.mode_emb + g.row * D : nullptr;
     // rank-1 terms of a matrix group (sources whose input state is one vector per batch: out[i][j] += u[i] v[j], v = the
@@ -1601,7 +1611,8 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     if (P->num_modes <= 0 || P->num_modes > MPQE_STEP_MAX_MODES) return MPQE_ERR_UNSUPPORTED;
     if (P->readout < 0 || P->readout > MPQE_READOUT_CONCAT) return MPQE_ERR_INVALID_ARG;
     const int D = P->dim;
-    const bool ro = chain && P->readout == MPQE_READOUT_MLP;
+    const bool ro = chain && (P->readout == MPQE_READOUT_MLP || P->readout == MPQE_READOUT_TARGETMLP);
+    const bool ro_pairs = ro && P->readout == MPQE_READOUT_TARGETMLP;       // rows [target | node] of the non-target nodes
     const int VL0 = P->num_layers, ROL = ro ? 2 : 0;
     if (chain && P->readout >= MPQE_READOUT_CALLER && !ro) return MPQE_ERR_UNSUPPORTED;
     if (ro && P->num_layers + 2 > MPQE_STEP_MAX_LAYERS) return MPQE_ERR_UNSUPPORTED;
@@ -1665,7 +1676,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         }
         if (ro) {       // the readout's hidden and output rows of every node slot (ReLU bits: level L + 1 <= CH_MASK_LEVELS)
             if (d.L + 1 > CH_MASK_LEVELS) return MPQE_ERR_UNSUPPORTED;
-            d.live[d.L + 1] = d.live[d.L + 2] = all;
+            d.live[d.L + 1] = d.live[d.L + 2] = ro_pairs ? all & ~(1u << t.A) : all;    // (targetmlp: the target has no row)
         }
     }
     if (rows >= (1ll << 30)) return MPQE_ERR_UNSUPPORTED;
@@ -1781,6 +1792,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         int layer;
         long long rel;     // relation id, or -1 for root
         int batch, level, slot;
+        int xo = -1, go = -1;      // >= 0: node slots of the x / g rows given (not derived from `slot`)
     };
     struct R1Key {
         int layer;
@@ -1816,9 +1828,23 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
             for (int n = 0; n < tp.N; ++n)          // root term: one source per live node slot
                 if ((lout >> n) & 1u) add(tp.E + n, n, n, -1);
         }
-    for (int i = 0; i < nb && ro; ++i)              // the readout's Linear layers: a root-like source per node slot and layer
+    // the readout's Linear layers: a root-like source per row-bearing node slot and layer (x: the layer's input rows of
+    // the slot, g: its output rows' gradients). targetmlp's first layer [D, 2 D] is two column blocks: `rel` -1 = the block
+    // that multiplies the target's row (x of slot A for every node), -2 = the node's own
+    for (int i = 0; i < nb && ro; ++i)
         for (int r = 0; r < ROL; ++r)
-            for (int n = 0; n < sd.b[i].tp.N; ++n) keys.push_back(Key{VL0 + r, -1, i, sd.b[i].L + r, sd.b[i].tp.E + n});
+            for (int n = 0; n < sd.b[i].tp.N; ++n) {
+                if (!((sd.b[i].live[sd.b[i].L + 1] >> n) & 1u)) continue;
+                Key k{VL0 + r, -1, i, sd.b[i].L + r, sd.b[i].tp.E + n};
+                if (ro_pairs && r == 0) {       // (operands as the tile takes them: x rows = gH of slot n, g rows = H of slot A)
+                    Key a = k;
+                    a.xo = n;
+                    a.go = sd.b[i].A;
+                    keys.push_back(a);
+                    k.rel = -2;
+                }
+                keys.push_back(k);
+            }
     auto key_less = [](int la, long long ra, int lb, long long rb) { return la != lb ? la < lb : ra < rb; };
     std::stable_sort(keys.begin(), keys.end(),
                      [&](const Key &a, const Key &b) { return key_less(a.layer, a.rel, b.layer, b.rel); });
@@ -1900,6 +1926,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         s.block_start = block;
         s.direct = -1;
         s.pad = (ro && key.layer >= VL0) ? 1 : 0;       // (nn.Linear's [out, in]: the tile's operands change places)
+        if (key.xo >= 0) s.pad |= 2 | (key.xo << 4) | (key.go << 8);
         s.rel = key.rel;
         hp->wsrc.push_back(s);
 
@@ -1932,6 +1959,9 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
             }
             RGroup g;
             g.kind = rel < 0 ? 1 : 0;
+            // (targetmlp's first Linear layer [D, 2 D]: its two column blocks are groups of their own, written with the row
+            // length 2 D -- kinds 4 / 5)
+            if (ro_pairs && layer == VL0) g.kind = rel == -1 ? 4 : 5;
             g.layer = layer;
             g.row = rel < 0 ? 0 : rel;
             g.start = ks < keys.size() ? hp->wsrc[ks].slab_start : 0;
@@ -1950,7 +1980,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                 ++kr;
             }
             if (rel >= 0) written[(size_t)layer * P->num_relations + rel] = 1;
-            if (nsrc == 1 && g.count == 1 && g.r1_count == 0) {
+            if (nsrc == 1 && g.count == 1 && g.r1_count == 0 && g.kind <= 1) {
                 hp->wsrc[first_src].direct = layer;
                 if (rel < 0) hp->whole_roots.push_back(layer);
             } else if (nsrc == 0 && g.r1_count <= UOP_MAX_TERMS) {
@@ -1995,13 +2025,17 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                     wkb.xs = bd.tp.N;
                     wkb.xo = is_root ? ws.slot - bd.tp.E : bd.tp.src[ws.slot];
                     wkb.go = is_root ? ws.slot - bd.tp.E : bd.tp.dst[ws.slot];
+                    if (ws.pad & 2) {           // (given, as the tile takes its operands)
+                        wkb.xo = (ws.pad >> 4) & 15;
+                        wkb.go = (ws.pad >> 8) & 15;
+                    }
                     wkb.q0 = c * ws.ch;
                     wkb.q1 = wkb.q0 + ws.ch < bd.B ? wkb.q0 + ws.ch : bd.B;
                     wkb.i0 = (tile / wct) * GT_BM;
                     wkb.j0 = (tile % wct) * tile_n;
                     wkb.direct = ws.direct;
                     wkb.batch = ws.batch;
-                    wkb.pad = ws.pad;
+                    wkb.pad = ws.pad & 1;
                     wkb.d0 = hp->dm.base[ws.batch] + wkb.q0 / DONE_GRAPHS;
                     wkb.dn = (wkb.q1 - 1) / DONE_GRAPHS - wkb.q0 / DONE_GRAPHS + 1;
                     hp->wblock.push_back(wkb);
@@ -2121,7 +2155,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         for (int i = 0; i < nb; ++i)
             for (int n = 0; n < 4; ++n) {
                 BatchDev &d = sd.b[i];
-                const bool liveL = n < d.tp.N && ((d.live[d.L] >> n) & 1u);
+                const bool liveL = n < d.tp.N && ((d.live[d.L + ROL] >> n) & 1u);
                 d.lpart[n] = liveL ? part_row[i][d.L + ROL][n] : -1;      // (a learned readout: its output rows' gradients)
                 d.uvL[n] = liveL && ((uni[i][d.L] >> n) & 1u) ? gran(vec(V_UV, i, d.L, n)) : -1;     // (its granule slot)
             }
@@ -2471,35 +2505,92 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
             pr.rof = 0;
             // a learned readout's Linear layers r = 0, 1 (reference model.py:497-515): per node slot one K-block, the node's own
             // row times W_r^T (forward, a transposed copy) / its gradient row times W_r (backward: the parameter itself)
+            auto copy_slot = [&](int layer, int col0, int ld, int plain) -> int {      // a D x D block prepared by the prologue
+                size_t k = 0;
+                for (; k < hp->wt_slots.size(); ++k) {
+                    const WtSlot &w = hp->wt_slots[k];
+                    if (w.layer == layer && w.mat == -1 && w.col0 == col0 && w.ld == ld && w.plain == plain) break;
+                }
+                if (k == hp->wt_slots.size()) hp->wt_slots.push_back(WtSlot{layer, -1, col0, ld, plain});
+                return (int)k;
+            };
             auto readout_ops = [&](int dir) {
+                const unsigned rows = d.live[d.L + 1];          // node slots with a readout row (targetmlp: not the target)
+                int last_n = 0;
+                for (int n = 0; n < tp.N; ++n)
+                    if ((rows >> n) & 1u) last_n = n;
+                auto op_of = [&](int src, int node, int r, int level) {
+                    ChainOp op;
+                    op.src = (unsigned char)src;
+                    op.node = (unsigned char)node;
+                    op.layer = (unsigned char)(VL0 + r);
+                    op.level = (unsigned char)level;
+                    op.mat = -1;
+                    op.flags = 0;
+                    op.wt_slot = 0;
+                    op.aux = -1;
+                    op.pad = 0;
+                    return op;
+                };
                 for (int q = 0; q < ROL; ++q) {
                     const int r = dir ? ROL - 1 - q : q;
-                    for (int n = 0; n < tp.N; ++n) {
-                        ChainOp op;
-                        op.src = op.node = (unsigned char)n;
-                        op.layer = (unsigned char)(VL0 + r);
-                        op.level = (unsigned char)(dir ? d.L + r : d.L + r + 1);
-                        op.mat = -1;
-                        op.flags = CH_FIRST | CH_LAST;
-                        op.pad = 0;
-                        if (!dir) {
-                            // H[L + 1] (the hidden rows) feeds the second layer's weight gradient; the output rows only the scores
-                            op.flags |= r == 0 ? CH_RELU : CH_NOSTORE;
-                            op.wt_slot = r;         // (its bias: constant slot r, loaded in front of the readout's K loop)
-                            op.aux = -1;
-                            size_t k = 0;
-                            for (; k < hp->wt_slots.size(); ++k)
-                                if (hp->wt_slots[k].layer == VL0 + r && hp->wt_slots[k].mat == -1) break;
-                            if (k == hp->wt_slots.size()) hp->wt_slots.push_back(WtSlot{VL0 + r, -1});
-                            op.pad = 1 + (int)k;
-                        } else {
-                            if (r == 1) op.flags |= CH_MASK;     // (gH[L + 1]: through the hidden rows' ReLU)
-                            op.wt_slot = -1;
-                            op.aux = part_row[i][d.L + r][n];
+                    const size_t level_first = hp->cops.size();
+                    if (!dir) {
+                        // forward: row n = ReLU([target |] node n) W_0^T + b_0), then W_2^T + b_2 -- transposed copies; the
+                        // hidden rows H[L + 1] feed the second layer's weight gradient, the output rows only the scores
+                        for (int n = 0; n < tp.N; ++n) {
+                            if (!((rows >> n) & 1u)) continue;
+                            const size_t first = hp->cops.size();
+                            if (ro_pairs && r == 0) {
+                                ChainOp ta = op_of(d.A, n, r, d.L + 1);
+                                ta.pad = 1 + copy_slot(VL0, 0, 2 * D, 0);
+                                hp->cops.push_back(ta);
+                            }
+                            ChainOp op = op_of(n, n, r, d.L + r + 1);
+                            op.pad = 1 + copy_slot(VL0 + r, (ro_pairs && r == 0) ? D : 0, (ro_pairs && r == 0) ? 2 * D : D, 0);
+                            hp->cops.push_back(op);
+                            hp->cops[first].flags |= CH_FIRST;
+                            hp->cops.back().flags |= CH_LAST | (r == 0 ? CH_RELU : CH_NOSTORE);
+                            for (size_t k = first; k < hp->cops.size(); ++k) {
+                                hp->cops[k].flags |= hp->cops.back().flags & (CH_RELU | CH_NOSTORE);
+                                hp->cops[k].wt_slot = r;      // (its bias: constant slot r, loaded in front of the readout's K loop)
+                            }
                         }
-                        if (n == tp.N - 1) op.flags |= CH_LEVEL_END;
-                        hp->cops.push_back(op);
+                    } else if (r == 1) {
+                        // backward: gH[L + 1][n] = (gH[L + 2][n] W_2) through the hidden rows' ReLU -- the parameter itself
+                        for (int n = 0; n < tp.N; ++n) {
+                            if (!((rows >> n) & 1u)) continue;
+                            ChainOp op = op_of(n, n, r, d.L + 1);
+                            op.flags = CH_FIRST | CH_LAST | CH_MASK;
+                            op.wt_slot = -1;
+                            op.aux = part_row[i][d.L + 1][n];
+                            hp->cops.push_back(op);
+                        }
+                    } else {
+                        // gH[L][n] = gH[L + 1][n] W_0 (targetmlp: its node block; the target's row: the sum over the nodes of
+                        // gH[L + 1][n] times the target block -- plain copies of the column blocks)
+                        for (int n = 0; n < tp.N; ++n) {
+                            const size_t first = hp->cops.size();
+                            if ((rows >> n) & 1u) {
+                                ChainOp op = op_of(n, n, r, d.L);
+                                op.wt_slot = ro_pairs ? copy_slot(VL0, D, 2 * D, 1) : -1;
+                                hp->cops.push_back(op);
+                            } else {
+                                for (int m = 0; m < tp.N; ++m) {
+                                    if (!((rows >> m) & 1u)) continue;
+                                    ChainOp op = op_of(m, n, r, d.L);
+                                    op.wt_slot = copy_slot(VL0, 0, 2 * D, 1);
+                                    hp->cops.push_back(op);
+                                }
+                            }
+                            if (hp->cops.size() == first) continue;
+                            hp->cops[first].flags |= CH_FIRST;
+                            hp->cops.back().flags |= CH_LAST;
+                            hp->cops.back().aux = part_row[i][d.L][n];
+                        }
                     }
+                    (void)last_n;
+                    if (hp->cops.size() > level_first) hp->cops.back().flags |= CH_LEVEL_END;
                 }
             };
             for (int dir = 0; dir < 2; ++dir) {
@@ -2540,7 +2631,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                                 size_t k = 0;
                                 for (; k < hp->wt_slots.size(); ++k)
                                     if (hp->wt_slots[k].layer == uid[li] && hp->wt_slots[k].mat == mat) break;
-                                if (k == hp->wt_slots.size()) hp->wt_slots.push_back(WtSlot{uid[li], mat});
+                                if (k == hp->wt_slots.size()) hp->wt_slots.push_back(WtSlot{uid[li], mat, 0, D, 0});
                                 op.wt_slot = (int)k;
                             }
                             hp->cops.push_back(op);
@@ -2795,8 +2886,8 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->ro_direct = false;
     hp->rlin_bytes = 0;
     if (ro) {           // (on the chain: no buffers of its own -- levels L + 1, L + 2 of H / GH)
-        hp->ro_rows = rows;
-        hp->ro_kin = D;
+        hp->ro_rows = ro_pairs ? rows - graphs : rows;
+        hp->ro_kin = ro_pairs ? 2 * D : D;
     }
     if (P->readout >= MPQE_READOUT_MLP && !ro) {
         const bool pairs = P->readout == MPQE_READOUT_TARGETMLP;
@@ -2983,11 +3074,11 @@ static std::shared_ptr<CachedPlan> plan_for(const mpqe_step_params_t *P, const m
 static bool want_chain(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb) {
     if (!P || !B || nb < 1 || nb > MPQE_STEP_MAX_BATCHES) return false;
     bool use_chain = !(P->flags & MPQE_STEP_NO_CHAIN) && (P->dim == 64 || P->dim == 128 || P->dim == 256) &&
-                     (P->readout < MPQE_READOUT_CALLER || P->readout == MPQE_READOUT_MLP);
-    // (the caller's readout, targetmlp and concat need the node states in HBM: level form. MLP: two more levels of the chain,
-    // while the ReLU bits of its hidden rows have a level to live in and two layer slots are free for its parameters)
+                     (P->readout < MPQE_READOUT_CALLER || P->readout == MPQE_READOUT_MLP || P->readout == MPQE_READOUT_TARGETMLP);
+    // (the caller's readout and concat need the node states in HBM: level form. MLP / targetmlp: two more levels of the chain,
+    // while the ReLU bits of their hidden rows have a level to live in and two layer slots are free for their parameters)
     if (!use_chain) return false;
-    if (P->readout == MPQE_READOUT_MLP) {
+    if (P->readout == MPQE_READOUT_MLP || P->readout == MPQE_READOUT_TARGETMLP) {
         if (P->num_layers + 2 > MPQE_STEP_MAX_LAYERS || !P->readout_w0 || !P->readout_w2) return false;
         if (!ptr_vec_ok(P->readout_w0, P->dim) || !ptr_vec_ok(P->readout_w2, P->dim)) return false;
         if ((P->readout_b0 && (uintptr_t)P->readout_b0 % 16 != 0) || (P->readout_b2 && (uintptr_t)P->readout_b2 % 16 != 0)) return false;

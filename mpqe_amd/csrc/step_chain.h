@@ -1055,12 +1055,32 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
         const bool on = i < ng;
         // (a learned readout ends in torch_scatter's add / mean / max over the graph's rows: the sum / max readouts' code)
         const int readout = RO ? (ca.ro_scatter == MPQE_SCATTER_MAX ? MPQE_READOUT_MAX : MPQE_READOUT_SUM) : sd->readout;
-        const float rscale = RO && ca.ro_scatter == MPQE_SCATTER_MEAN ? 1.f / (float)N : 1.f;
+        const float rscale = RO && ca.ro_scatter == MPQE_SCATTER_MEAN ? 1.f / (float)__builtin_popcount(b.live[L + 2]) : 1.f;
         auto gsum = [](float v) { return chain_sum16(v); };
         const float *h = Xc + i * LDX;                    // node n at h + n * CH_GB * LDX
         float q[CC];
         int arg[CC];
-        if (readout == MPQE_READOUT_TM) {                 // (uniform) the target slot's row is the readout
+        // (a learned readout: the reduction runs over the node slots that HAVE a row -- targetmlp: not the target's)
+        const unsigned rom = RO ? b.live[L + 2] : 0u;
+        if (RO) {
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc) {             // branch-free: N <= 4 slots, predicated by the row mask
+                const int col = sl + 16 * cc;
+                float sum = 0.f, best = 0.f;
+                int am = -1;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const bool has = (rom >> n) & 1u;
+                    const float hv_ = h[(has ? n : 0) * CH_GB * LDX + col];
+                    sum += has ? hv_ : 0.f;
+                    const bool gt = has && (am < 0 || hv_ > best);      // (lowest row wins ties: torch_scatter's max)
+                    best = gt ? hv_ : best;
+                    am = gt ? n : am;
+                }
+                q[cc] = readout == MPQE_READOUT_SUM ? sum * rscale : best;
+                arg[cc] = am < 0 ? 0 : am;
+            }
+        } else if (readout == MPQE_READOUT_TM) {          // (uniform) the target slot's row is the readout
 #pragma unroll
             for (int cc = 0; cc < CC; ++cc) {
                 q[cc] = h[A * CH_GB * LDX + sl + 16 * cc];
@@ -1085,7 +1105,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
             float tm = hn[0];
 #pragma unroll
             for (int n = 1; n < 4; ++n) tm = n == A ? hn[n] : tm;
-            q[cc] = readout == MPQE_READOUT_TM ? tm : (readout == MPQE_READOUT_SUM ? (RO ? sum * rscale : sum) : best);
+            q[cc] = readout == MPQE_READOUT_TM ? tm : (readout == MPQE_READOUT_SUM ? sum : best);
             arg[cc] = am;
         }
         float ssp = 0.f, ssn = 0.f;

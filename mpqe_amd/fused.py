@@ -154,7 +154,7 @@ class FusedTrainStep(object):
         if self.learned:
             if model.emb_dim % 4:
                 raise NotImplementedError('fused step with a learned readout: embedding dimension must be a multiple of 4')
-            on_chain = (chain and model.readout_str == 'mlp' and model.emb_dim in (64, 128, 256) and
+            on_chain = (chain and model.readout_str in ('mlp', 'targetmlp') and model.emb_dim in (64, 128, 256) and
                         model.num_layers <= 3 and not eight_waves)
             if on_chain:
                 lanes = 1

@@ -108,7 +108,7 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
     dnm = be.put(node_map.numpy())
     dmode = put('mode_embeddings.weight')
     learned = between is None and cfg['readout'] in _capi.LEARNED_READOUT_IDS
-    if between is not None or (learned and not (cfg['readout'] == 'mlp' and D in (64, 128, 256))):
+    if between is not None or (learned and not (cfg['readout'] in ('mlp', 'targetmlp') and D in (64, 128, 256))):
         touch = False           # (level form: it has no use for a touch plan)
     rid = _capi.READOUT_CALLER if between is not None else (_capi.LEARNED_READOUT_IDS[cfg['readout']] if learned else cfg['readout'])
     P = _capi.make_step_params(D, R, rid, [be.ptr(t) for t in tables],
@@ -490,19 +490,24 @@ def test_fused_step_with_learned_readout_matches_oracle(be, readout, scatter_op,
     assert err == 0 and all(not g.any() for g in grads.values())
 
 
-@pytest.mark.parametrize('D,mix,scatter_op,adaptive,shared,wd,touch', [
-    (64, 'all7', 'add', True, False, 1e-3, 'step'), (64, 'all7', 'max', False, True, 0, False),
-    (64, 'many', 'mean', True, False, 1e-3, 'pack'), (128, 'tiny', 'add', True, False, 0, 'step'),
-    (128, 'dup', 'max', False, False, 1e-3, 'step')])
-def test_mlp_readout_on_the_chain_matches_oracle(be, capfd, D, mix, scatter_op, adaptive, shared, wd, touch):
-    """MLPReadout (reference model.py:497-515) on the CHAIN form: its Linear - ReLU - Linear are two more levels of every
-    graph block's programme (the node's own row times W^T, ReLU bits in LDS), the reduction over a graph's rows is the
-    score phase's sum / max, the weight gradients are tiles with the operands swapped (nn.Linear stores [out, in]), the
-    bias gradients column sums like the layers'. Loss, scores and every gradient against the oracle's whole model; the
-    level form (MPQE_STEP_NO_CHAIN) gives the same."""
+@pytest.mark.parametrize('readout,D,mix,scatter_op,adaptive,shared,wd,touch', [
+    ('mlp', 64, 'all7', 'add', True, False, 1e-3, 'step'), ('mlp', 64, 'all7', 'max', False, True, 0, False),
+    ('mlp', 64, 'many', 'mean', True, False, 1e-3, 'pack'), ('mlp', 128, 'tiny', 'add', True, False, 0, 'step'),
+    ('mlp', 128, 'dup', 'max', False, False, 1e-3, 'step'),
+    ('targetmlp', 64, 'all7', 'add', True, False, 1e-3, 'step'), ('targetmlp', 64, 'all7', 'max', False, True, 0, False),
+    ('targetmlp', 64, 'many', 'mean', True, False, 1e-3, 'pack'), ('targetmlp', 128, 'tiny', 'mean', True, False, 0, 'step'),
+    ('targetmlp', 128, 'dup', 'max', False, False, 1e-3, 'step')])
+def test_mlp_readout_on_the_chain_matches_oracle(be, capfd, readout, D, mix, scatter_op, adaptive, shared, wd, touch):
+    """MLPReadout / TargetMLPReadout (reference model.py:497-553) on the CHAIN form: Linear - ReLU - Linear are two more
+    levels of every graph block's programme (the node's own row times W^T -- targetmlp: the target's row times the first
+    column block of W_0 plus the node's times the second --, ReLU bits in LDS), the reduction over a graph's rows is the
+    score phase's sum / max over the slots that have a row, the weight gradients are tiles with the operands swapped
+    (nn.Linear stores [out, in]; targetmlp's [D, 2 D] as two column blocks), the bias gradients column sums like the
+    layers'. Loss, scores and every gradient against the oracle's whole model; the level form (MPQE_STEP_NO_CHAIN) gives
+    the same."""
     margin = 1.0
     mixes = dict(MIXES, **EDGE_MIXES)
-    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(31, D, 3, shared, mixes[mix], 'mlp', adaptive)
+    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(31, D, 3, shared, mixes[mix], readout, adaptive)
     cfg['scatter_op'], cfg['weight_decay'] = scatter_op, wd
     total, per, sp_ref, sn_ref = 0, [], [], []
     for b in batches:
