@@ -73,7 +73,10 @@ enum { MPQE_READOUT_SUM = 0, MPQE_READOUT_MAX = 1, MPQE_READOUT_TM = 2,
        /* fused step only: the reference's learned readouts, Linear(in, dim) - ReLU - Linear(dim, dim) per row, then a
         * reduction over each graph's rows (mpqe_step_params_t.readout_*): MLP (model.py:497-515; in = dim, a row per node),
         * TARGETMLP (model.py:518-553; in = 2 dim, a row [target | node] per non-target node), CONCAT (model.py:441-446;
-        * in = num_layers dim, a node's states after every layer side by side -- every batch runs num_layers passes) */
+        * in = num_layers dim, a node's states after every layer side by side -- every batch runs num_layers passes).
+        * MLP and TARGETMLP ride on the chain form when it applies (dim 64 / 128 / 256, at most 3 passes per batch, two free
+        * layer slots, no node state still batch-uniform after the last pass): their Linear layers are two more levels of every
+        * graph block's programme; otherwise, and CONCAT always, the level form (one launch per level + dense-layer launches) */
        MPQE_READOUT_MLP = 4, MPQE_READOUT_TARGETMLP = 5, MPQE_READOUT_CONCAT = 6 };
 enum { MPQE_SCATTER_ADD = 0, MPQE_SCATTER_MAX = 1, MPQE_SCATTER_MEAN = 2 };
 #define MPQE_MAX_TEMPLATE_EDGES 3
@@ -364,7 +367,8 @@ typedef struct {
     /* learned readouts (MPQE_READOUT_MLP / _TARGETMLP / _CONCAT): the two Linear layers as nn.Linear stores them
      * (weight [out, in] row-major, bias [out]); readout_scatter = MPQE_SCATTER_* of the reduction (the reference's
      * --scatter_op); readout_weight_decay: model.py:486-490, loss += weight_decay * (sum of the four parameters'
-     * 2-norms) per margin_loss call, i.e. times the sum of the batch weights (0 = off). Level form, dim % 4 == 0.  */
+     * 2-norms) per margin_loss call, i.e. times the sum of the batch weights (0 = off). dim % 4 == 0; chain form: 16-byte
+     * aligned parameters.                                                                                             */
     const float *readout_w0, *readout_b0, *readout_w2, *readout_b2;
     int32_t readout_scatter;
     float readout_weight_decay;
@@ -585,7 +589,9 @@ void mpqe_debug_chain_stamps(void *device_buffer, size_t num_blocks);
 void mpqe_debug_tail_stamps(void *device_buffer, size_t num_blocks);
 /* Named diagnostics switches (timing experiments; tests that force a rarely taken path, e.g. "TOUCH_MULTI_LAUNCH" = the
  * multi-launch sort (csrc/radix_sort.h) instead of the one-launch sort, "TSORT_FAIL" = the in-step sort gives up as if its workgroups were not
- * co-resident, "GEN_SLOTS" = grid size of the persistent gather-GEMMs). set != 0
+ * co-resident, "GEN_SLOTS" = grid size of the persistent gather-GEMMs, "PROLOGUE_LAST" = 1 / 0: the chain launch's prologue
+ * items behind / in front of its chain workgroups whatever their number, "DUMP_PLAN" = the step's plan and launch shape on
+ * stderr). set != 0
  * stores `value` under `name`, set == 0 removes it. Process-global (see Conventions).                    */
 void mpqe_debug_option(const char *name, int value, int set);
 
