@@ -28,7 +28,9 @@ def _gpus():
 
 
 CASES = [(0, 'rows', 'mp', 'pack'), (1, 'rows', 'mp', 'pack'), (0, 'rows', 'mp', 'step'), (1, 'rows', 'mp', 'step'),
-         (0, 'dense', 'mp', 'step'), (0, 'dense', 'targetmlp', 'step'), (0, 'dense', 'concat', 'step')]
+         (0, 'dense', 'mp', 'step'), (0, 'dense', 'targetmlp', 'step'), (0, 'dense', 'concat', 'step'),
+         # the MLP readout on the chain form: its Linear layers ride in the bucket, the row-sparse tables in the row exchange
+         (0, 'dense', 'mlp', 'step'), (1, 'rows', 'mlp', 'step')]
 
 
 @pytest.mark.parametrize('sparse,tables,readout,touch', CASES)
