@@ -128,7 +128,8 @@ struct VSource {
 // one reduction group: out[...] += sum of `count` consecutive slabs/partials starting at `start`
 // (+ matrices, chain form with uniform node states: the sum of r1_count rank-1 terms u (x) v from `r1_start` on)
 struct RGroup {
-    int kind;          // 0 basis, 1 root, 2 bias, 3 mode row; 4 / 5: column block 0 / 1 of a [D, 2 D] matrix (`root` of `layer`)
+    int kind;          // 0 basis, 1 root, 2 bias, 3 mode row; 4: a D x D column block of a [D, n D] matrix (`root` of `layer`:
+                       // a learned readout's first Linear layer), row = block | n << 8
     int layer;         // layer index (kinds 0-2)
     long long row;     // relation id (kind 0) / mode id (kind 3)
     int start, count;
@@ -1164,7 +1165,8 @@ __device__ __forceinline__ void reduce_block(const ReduceArgs &ra, int bx, int b
     else if (g.kind == 1) dst = gp.root[g.layer];
     else if (wide) {
         // (element idx of the block = row idx / D, column idx % D of it: `dst + idx` then IS its address)
-        dst = gp.root[g.layer] ? gp.root[g.layer] + (idx / D) * (long long)D + (g.kind == 5 ? D : 0) : nullptr;
+        const long long cb = g.row & 255, nbk = g.row >> 8;
+        dst = gp.root[g.layer] ? gp.root[g.layer] + (idx / D) * (nbk - 1) * D + cb * D : nullptr;
     }
     else if (g.kind == 2) dst = gp.bias[g.layer];
     else dst = gp.mode_emb ? gp.mode_emb + g.row * D : nullptr;
@@ -1611,8 +1613,12 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     if (P->num_modes <= 0 || P->num_modes > MPQE_STEP_MAX_MODES) return MPQE_ERR_UNSUPPORTED;
     if (P->readout < 0 || P->readout > MPQE_READOUT_CONCAT) return MPQE_ERR_INVALID_ARG;
     const int D = P->dim;
-    const bool ro = chain && (P->readout == MPQE_READOUT_MLP || P->readout == MPQE_READOUT_TARGETMLP);
+    // (concat: the partial sums of its first layer travel through HBM in 8-byte pieces: D = 128 / 256)
+    const bool ro = chain && (P->readout == MPQE_READOUT_MLP || P->readout == MPQE_READOUT_TARGETMLP ||
+                              (P->readout == MPQE_READOUT_CONCAT && P->dim >= 128));
     const bool ro_pairs = ro && P->readout == MPQE_READOUT_TARGETMLP;       // rows [target | node] of the non-target nodes
+    const bool ro_cat = ro && P->readout == MPQE_READOUT_CONCAT;            // rows [H_1 | .. | H_L] of every node
+    const int ro_blocks = ro_pairs ? 2 : (ro_cat ? P->num_layers : 1);      // D x D column blocks of the first Linear layer
     const int VL0 = P->num_layers, ROL = ro ? 2 : 0;
     if (chain && P->readout >= MPQE_READOUT_CALLER && !ro) return MPQE_ERR_UNSUPPORTED;
     if (ro && P->num_layers + 2 > MPQE_STEP_MAX_LAYERS) return MPQE_ERR_UNSUPPORTED;
@@ -1676,6 +1682,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         }
         if (ro) {       // the readout's hidden and output rows of every node slot (ReLU bits: level L + 1 <= CH_MASK_LEVELS)
             if (d.L + 1 > CH_MASK_LEVELS) return MPQE_ERR_UNSUPPORTED;
+            if (ro_cat && d.L != P->num_layers) return MPQE_ERR_INVALID_ARG;     // (model.py:441-446: one input block per layer)
             d.live[d.L + 1] = d.live[d.L + 2] = ro_pairs ? all & ~(1u << t.A) : all;    // (targetmlp: the target has no row)
         }
     }
@@ -1736,7 +1743,8 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
             }
     }
     // ---- batch-uniform node states (see UOp): uni[i][p] = node slots of batch i that are one vector per batch at level p
-    const bool uniform = chain && !(P->flags & MPQE_STEP_NO_UNIFORM);
+    // (concat reads every node's state after EVERY layer: no state is left to the pre-pass as a vector)
+    const bool uniform = chain && !(P->flags & MPQE_STEP_NO_UNIFORM) && !ro_cat;
     hp->uniform = uniform;
     unsigned uni[MPQE_STEP_MAX_BATCHES][MPQE_STEP_MAX_LAYERS + 1];
     for (int i = 0; i < nb; ++i) {
@@ -1793,6 +1801,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         long long rel;     // relation id, or -1 for root
         int batch, level, slot;
         int xo = -1, go = -1;      // >= 0: node slots of the x / g rows given (not derived from `slot`)
+        int glev = -1;             // >= 0: level of the gH rows (else: level + 1)
     };
     struct R1Key {
         int layer;
@@ -1842,6 +1851,16 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                     a.go = sd.b[i].A;
                     keys.push_back(a);
                     k.rel = -2;
+                }
+                if (ro_cat && r == 0) {         // column block l - 1: the hidden rows' gradients (gH[L + 1]) x the states H[l]
+                    for (int l = 1; l <= sd.b[i].L; ++l) {
+                        Key c = k;
+                        c.rel = -l;
+                        c.level = l;
+                        c.glev = sd.b[i].L + 1;
+                        keys.push_back(c);
+                    }
+                    continue;
                 }
                 keys.push_back(k);
             }
@@ -1927,6 +1946,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
         s.direct = -1;
         s.pad = (ro && key.layer >= VL0) ? 1 : 0;       // (nn.Linear's [out, in]: the tile's operands change places)
         if (key.xo >= 0) s.pad |= 2 | (key.xo << 4) | (key.go << 8);
+        if (key.glev >= 0) s.pad |= 4 | (key.glev << 12);
         s.rel = key.rel;
         hp->wsrc.push_back(s);
 
@@ -1961,9 +1981,11 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
             g.kind = rel < 0 ? 1 : 0;
             // (targetmlp's first Linear layer [D, 2 D]: its two column blocks are groups of their own, written with the row
             // length 2 D -- kinds 4 / 5)
-            if (ro_pairs && layer == VL0) g.kind = rel == -1 ? 4 : 5;
+            const bool wide_g = ro && layer == VL0 && ro_blocks > 1;
+            if (wide_g) g.kind = 4;
             g.layer = layer;
             g.row = rel < 0 ? 0 : rel;
+            if (wide_g) g.row = (-1 - rel) | ((long long)ro_blocks << 8);      // column block | blocks per row
             g.start = ks < keys.size() ? hp->wsrc[ks].slab_start : 0;
             g.count = 0;
             g.r1_start = (int)kr;
@@ -2019,7 +2041,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                     const int c = q / tiles, tile = q - c * tiles;
                     WBlock wkb;
                     wkb.x_off = (long long)ws.level * hp->level_stride + bd.row_off * D;
-                    wkb.g_off = (long long)(ws.level + 1) * hp->level_stride + bd.row_off * D;
+                    wkb.g_off = (long long)((ws.pad & 4) ? (ws.pad >> 12) & 15 : ws.level + 1) * hp->level_stride + bd.row_off * D;
                     wkb.slab_off = (long long)(ws.slab_start + c) * D * D;
                     wkb.rel = ws.rel;
                     wkb.xs = bd.tp.N;
@@ -2547,7 +2569,11 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                                 hp->cops.push_back(ta);
                             }
                             ChainOp op = op_of(n, n, r, d.L + r + 1);
-                            op.pad = 1 + copy_slot(VL0 + r, (ro_pairs && r == 0) ? D : 0, (ro_pairs && r == 0) ? 2 * D : D, 0);
+                            if (ro_cat && r == 0) {      // the last level's block; the earlier levels' products come back from HBM
+                                op.pad = 1 + copy_slot(VL0, (d.L - 1) * D, ro_blocks * D, 0);
+                                if (d.L > 1) op.flags |= CH_ADDG;
+                            } else
+                                op.pad = 1 + copy_slot(VL0 + r, (ro_pairs && r == 0) ? D : 0, (ro_pairs && r == 0) ? 2 * D : D, 0);
                             hp->cops.push_back(op);
                             hp->cops[first].flags |= CH_FIRST;
                             hp->cops.back().flags |= CH_LAST | (r == 0 ? CH_RELU : CH_NOSTORE);
@@ -2569,11 +2595,23 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                     } else {
                         // gH[L][n] = gH[L + 1][n] W_0 (targetmlp: its node block; the target's row: the sum over the nodes of
                         // gH[L + 1][n] times the target block -- plain copies of the column blocks)
+                        // (concat: first the readout's share of the state gradients of levels 1 .. L - 1 -- gH[L + 1][n] times
+                        // column block l - 1 --, stored to gH[l][n] through scratch tiles; the level's own update adds it)
+                        int scratch = 0;
+                        for (int l = 1; ro_cat && l < d.L; ++l)
+                            for (int n = 0; n < tp.N; ++n) {
+                                ChainOp op = op_of(n, n, r, l);
+                                op.flags = CH_FIRST | CH_LAST;
+                                op.wt_slot = copy_slot(VL0, (l - 1) * D, ro_blocks * D, 1);
+                                op.pad = CH_TSLOT_ON | ((3 - (scratch++ & 1)) << 16);
+                                hp->cops.push_back(op);
+                            }
                         for (int n = 0; n < tp.N; ++n) {
                             const size_t first = hp->cops.size();
                             if ((rows >> n) & 1u) {
                                 ChainOp op = op_of(n, n, r, d.L);
                                 op.wt_slot = ro_pairs ? copy_slot(VL0, D, 2 * D, 1) : -1;
+                                if (ro_cat) op.wt_slot = copy_slot(VL0, (d.L - 1) * D, ro_blocks * D, 1);
                                 hp->cops.push_back(op);
                             } else {
                                 for (int m = 0; m < tp.N; ++m) {
@@ -2608,6 +2646,24 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                     // (a learned readout on the chain: H[L] is the input of its first layer's weight gradient)
                     if ((!dir && p == d.L - 1 && !ro) || (dir && p == 0)) lvl_flags |= CH_NOSTORE;
                     const size_t level_first = hp->cops.size();
+                    if (ro_cat && !dir && p >= 1) {
+                        // concat: the first readout layer's product with THIS level's input states H[p] (column block p - 1),
+                        // added to the sum so far (H[L + 1][n], through scratch tiles 3 / 2: written whole one barrier later)
+                        int scratch = 0;
+                        for (int n = 0; n < tp.N; ++n) {
+                            ChainOp op;
+                            op.src = op.node = (unsigned char)n;
+                            op.layer = (unsigned char)VL0;
+                            op.level = (unsigned char)(d.L + 1);
+                            op.mat = -1;
+                            op.flags = CH_FIRST | CH_LAST | CH_NOBIAS | (p > 1 ? CH_ADDG : 0);
+                            op.wt_slot = 0;
+                            op.aux = -1;
+                            op.pad = (1 + copy_slot(VL0, (p - 1) * D, ro_blocks * D, 0)) | CH_TSLOT_ON | ((3 - (scratch++ & 1)) << 16);
+                            hp->cops.push_back(op);
+                        }
+                    }
+                    if (ro_cat && dir && p >= 1 && p < d.L) lvl_flags |= CH_ADDG;
                     // per-graph (NU) node slots only: a batch-uniform state is a vector of the pre-pass, its gradient
                     // a column sum of the post-pass. The sources of an NU node's K-blocks are its NU sources (the
                     // uniform ones are in the node's constant vector); backward, every destination of an NU node is NU.
@@ -2887,7 +2943,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->rlin_bytes = 0;
     if (ro) {           // (on the chain: no buffers of its own -- levels L + 1, L + 2 of H / GH)
         hp->ro_rows = ro_pairs ? rows - graphs : rows;
-        hp->ro_kin = ro_pairs ? 2 * D : D;
+        hp->ro_kin = ro_blocks * D;
     }
     if (P->readout >= MPQE_READOUT_MLP && !ro) {
         const bool pairs = P->readout == MPQE_READOUT_TARGETMLP;
@@ -3074,11 +3130,16 @@ static std::shared_ptr<CachedPlan> plan_for(const mpqe_step_params_t *P, const m
 static bool want_chain(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb) {
     if (!P || !B || nb < 1 || nb > MPQE_STEP_MAX_BATCHES) return false;
     bool use_chain = !(P->flags & MPQE_STEP_NO_CHAIN) && (P->dim == 64 || P->dim == 128 || P->dim == 256) &&
-                     (P->readout < MPQE_READOUT_CALLER || P->readout == MPQE_READOUT_MLP || P->readout == MPQE_READOUT_TARGETMLP);
-    // (the caller's readout and concat need the node states in HBM: level form. MLP / targetmlp: two more levels of the chain,
+                     (P->readout < MPQE_READOUT_CALLER || P->readout >= MPQE_READOUT_MLP);
+    // (the caller's readout needs the node states in HBM: level form. The learned readouts: two more levels of the chain,
     // while the ReLU bits of their hidden rows have a level to live in and two layer slots are free for their parameters)
     if (!use_chain) return false;
-    if (P->readout == MPQE_READOUT_MLP || P->readout == MPQE_READOUT_TARGETMLP) {
+    if (P->readout >= MPQE_READOUT_MLP) {
+        if (P->readout == MPQE_READOUT_CONCAT) {        // (its partial sums travel in 8-byte pieces; one input block per layer)
+            if (P->dim < 128) return false;
+            for (int i = 0; i < nb; ++i)
+                if (B[i].num_passes != P->num_layers) return false;
+        }
         if (P->num_layers + 2 > MPQE_STEP_MAX_LAYERS || !P->readout_w0 || !P->readout_w2) return false;
         if (!ptr_vec_ok(P->readout_w0, P->dim) || !ptr_vec_ok(P->readout_w2, P->dim)) return false;
         if ((P->readout_b0 && (uintptr_t)P->readout_b0 % 16 != 0) || (P->readout_b2 && (uintptr_t)P->readout_b2 % 16 != 0)) return false;

@@ -28,8 +28,13 @@
 #define CH_RELU 8         // forward epilogue applies ReLU (and records the mask bits)
 #define CH_MASK 16        // backward epilogue masks with the bits recorded for this (level, node)
 #define CH_NOSTORE 32     // the result stays in LDS: nothing after the chain kernel reads H[L] or gH[0]
+#define CH_ADDG 64        // (learned readouts, concat) the epilogue adds what is stored at the update's own rows of H / gH: a
+                          // partial sum of the readout's first layer over the levels (forward) / the readout's share of a
+                          // level's state gradient (backward, in front of the ReLU mask)
+#define CH_NOBIAS 128      // ... forward: no constant vector is added (a partial sum)
+#define CH_TSLOT_ON (1 << 20)   // ChainOp.pad: bits 16-19 = the LDS tile slot the update writes (else: its node slot)
 #define CH_MASK_LEVELS 4  // ReLU outputs live at levels 1 .. L-1: chains up to L = 5 passes
-#define CH_MAX_OPS 72     // forward + backward K-blocks of one batch (5 passes x 7 x 2 = 70 at most)
+#define CH_MAX_OPS 80     // forward + backward K-blocks of one batch (5 passes x 7 x 2 = 70; 3 passes + the concat readout: 74)
 #define CH_MAX_CV 12      // forward node updates of one batch (3 passes x 4 node slots; the host checks)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -311,7 +316,7 @@ __device__ __forceinline__ void chain_colsum(ChainLds<NCB, KS, NW> &S, const flo
 // an op as the K loop sees it: wave-uniform, read from LDS (a vector load from HBM here would sit in vmcnt
 // behind the weight prefetch and drain it)
 struct ChainStep {
-    int src, node, layer, level, flags, part;
+    int src, node, tslot, level, flags, part;      // tslot: LDS tile slot of the output (= node, but for the concat readout's scratch)
 };
 
 // The K loop of one direction: the block's programme (T half-blocks) as ONE software pipeline across node
@@ -320,7 +325,7 @@ struct ChainStep {
 // inside a branch makes hipcc's s_waitcnt bookkeeping fall back to vmcnt(0) at the join, which would
 // serialise every half-block behind the prefetch just issued for the next one; sched_barriers keep hipcc's
 // scheduler from sinking the prefetch loads down to the MFMAs that use them.
-template <int NCB, int KS, bool BWD, int NW>
+template <int NCB, int KS, bool BWD, int NW, bool RO = false>
 __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int first_op, int T /* items */, int N, int ng,
                                           float *__restrict__ Xrows, long long level_stride, int &cur,
                                           float *parts = nullptr, int blk = 0,
@@ -342,7 +347,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
         ChainStep o;
         o.src = w & 0xff;
         o.node = (w >> 8) & 0xff;
-        o.layer = (w >> 16) & 0xff;
+        o.tslot = RO ? (w >> 16) & 0xff : o.node;
         o.level = (w >> 24) & 0xff;
         o.flags = __builtin_amdgcn_readfirstlane(S.opw[k][1]);
         o.part = __builtin_amdgcn_readfirstlane(S.opp[k]);      // (forward: the node update's cv slot)
@@ -435,6 +440,21 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
 #endif
         // all four A fragments of the item up front: one exposed LDS round trip per item
         const float *xp = S.xs + cur * BUF + (op.src * CH_GB + j) * LDX + kbase + 64 * h + 4 * kq;
+        // (CH_ADDG: the rows to add are requested here, by the waves that will finish the update, and land under the MFMAs.
+        // L1-bypassing loads: a row may have been read -- and cached -- at an earlier level, before its last writer)
+        unsigned long long ga[RO ? 4 : 1][RO ? (NCB + 1) / 2 : 1];
+        if constexpr (RO) {
+            if (finisher && h == IPO - 1 && (op.flags & CH_LAST) && (op.flags & CH_ADDG)) {
+                const float *Xadd = Xrows + (long long)op.level * level_stride + ((long long)(4 * kq) * N + op.node) * D + colb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c2 = 0; c2 < (NCB + 1) / 2; ++c2) {
+                        const bool in = 4 * kq + r < ng;
+                        ga[r][c2] = in ? chain_gran_load(reinterpret_cast<const unsigned long long *>(Xadd + (long long)r * N * D) + c2) : 0ull;
+                    }
+            }
+        }
         f32x4 av[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) av[t] = *reinterpret_cast<const f32x4 *>(xp + 16 * t);
@@ -477,7 +497,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
             // K split: the first K part's waves park their partial sums in the node's LDS output tile (nobody
             // reads it before the level ends); the last part's waves pick them up behind the barrier and finish
             float *Xn = S.xs + (cur ^ 1) * BUF;
-            float *tile = Xn + (op.node * CH_GB + 4 * kq) * LDX + colb;     // this lane's 4 rows x NCB columns
+            float *tile = Xn + (op.tslot * CH_GB + 4 * kq) * LDX + colb;    // this lane's 4 rows x NCB columns
             if (KS > 1 && !finisher) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -537,11 +557,20 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
                 }
                 CHAIN_TRACE(4)
                 const int mslot = ((op.level - 1) * 4 + op.node) * MT + (threadIdx.x & (MT - 1));   // levels 1 .. L-1
-                if (!BWD) {
+                if (!BWD && !(RO && (op.flags & CH_NOBIAS))) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int c = 0; c < NCB; ++c) v[r][c] += bv[c];
+                }
+                if constexpr (RO && NCB % 2 == 0) {
+                    if (op.flags & CH_ADDG) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int c = 0; c < NCB; ++c)
+                                v[r][c] += __uint_as_float((unsigned)(ga[r][c / 2] >> (32 * (c & 1))));
+                    }
                 }
                 if (MODE == 1) {
                     unsigned bits = 0;
@@ -868,15 +897,16 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
             if (tid < nfwd || CHAIN_DBG == 3) {     // (3: timing experiment, wrong results)
                 S.wp[tid] = op.mat >= 0 ? pick_layer(lp.basis, op.layer) + (long long)op.mat * D * D
                                         : pick_layer(lp.root, op.layer);
-                if (RO && op.pad > 0) S.wp[tid] = ca.WT + (long long)(op.pad - 1) * D * D;
+                if (RO && (op.pad & 0xffff) > 0) S.wp[tid] = ca.WT + (long long)((op.pad & 0xffff) - 1) * D * D;
             } else {
                 S.wp[tid] = ca.WT + (long long)op.wt_slot * D * D;
                 if (RO && op.wt_slot < 0) S.wp[tid] = pick_layer(lp.root, op.layer);
             }
-            S.opw[tid][0] = op.src | (op.node << 8) | (op.layer << 16) | (op.level << 24);
+            // (byte 2: the LDS tile slot the update writes)
+            S.opw[tid][0] = op.src | (op.node << 8) | (((RO && (op.pad & CH_TSLOT_ON)) ? (op.pad >> 16) & 15 : op.node) << 16) | (op.level << 24);
             S.opw[tid][1] = op.flags;
             S.opp[tid] = tid < nfwd ? op.wt_slot : op.aux;
-            if (tid < ref.fwd_count && (op.flags & CH_LAST)) {      // one slot per forward node update
+            if (tid < ref.fwd_count && (op.flags & CH_LAST) && !(op.flags & CH_NOBIAS)) {      // one slot per forward node update
                 S.cvid[op.wt_slot] = op.aux;
                 S.cvl[op.wt_slot] = op.layer;
             }
@@ -984,8 +1014,8 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     if (tid == 0 && (ca.backward || RO) && ca.wt_count) wt_have0 = chain_count_load(ca.wt_count);
     // ---- forward levels
     int cur = 0;
-    chain_run<NCB, KS, false, NW>(S, 0, ref.fwd_count * IPO, N, ng, ca.H + row0 * D, ca.level_stride, cur, nullptr, 0,
-                                  ca.cv_gran, ca.cv_gran ? *ca.epoch_f + 1u : 0u, ca.err);
+    chain_run<NCB, KS, false, NW, RO>(S, 0, ref.fwd_count * IPO, N, ng, ca.H + row0 * D, ca.level_stride, cur, nullptr, 0,
+                                      ca.cv_gran, ca.cv_gran ? *ca.epoch_f + 1u : 0u, ca.err);
 
     chain_stamp(ca, 3);
     if constexpr (RO) {
@@ -1042,7 +1072,7 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
         // ---- a learned readout's Linear - ReLU - Linear on every node row (reference model.py:497-515, MLPReadout): two
         // more levels of node updates, one K-block each (the node's own row times W^T: a transposed copy of this launch)
         if (rof > 0)
-            chain_run<NCB, KS, false, NW>(S, ref.fwd_count, rof * IPO, N, ng, ca.H + row0 * D, ca.level_stride, cur);
+            chain_run<NCB, KS, false, NW, true>(S, ref.fwd_count, rof * IPO, N, ng, ca.H + row0 * D, ca.level_stride, cur);
     }
     // ---- readout, cosine scores against the + and - target, hinge terms (reference model.py:447-462,
     // 483-485); backward: d hinge -> d cosine -> d readout written over H[L] in LDS (a lane group owns whole
@@ -1222,8 +1252,8 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     }
 
     // ---- backward levels
-    chain_run<NCB, KS, true, NW>(S, nfwd, ref.bwd_count * IPO, N, ng, ca.GH + row0 * D, ca.level_stride, cur,
-                                 ca.parts, blk);
+    chain_run<NCB, KS, true, NW, RO>(S, nfwd, ref.bwd_count * IPO, N, ng, ca.GH + row0 * D, ca.level_stride, cur,
+                                     ca.parts, blk);
 
     chain_stamp(ca, 5);
     if (ca.done) {

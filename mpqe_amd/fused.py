@@ -154,8 +154,8 @@ class FusedTrainStep(object):
         if self.learned:
             if model.emb_dim % 4:
                 raise NotImplementedError('fused step with a learned readout: embedding dimension must be a multiple of 4')
-            on_chain = (chain and model.readout_str in ('mlp', 'targetmlp') and model.emb_dim in (64, 128, 256) and
-                        model.num_layers <= 3 and not eight_waves)
+            on_chain = (chain and model.emb_dim in (64, 128, 256) and model.num_layers <= 3 and not eight_waves and
+                        (model.readout_str != 'concat' or (model.emb_dim >= 128 and not model.adaptive)))
             if on_chain:
                 lanes = 1
             else:
@@ -635,7 +635,7 @@ class FusedTrainStep(object):
                                                 packed.desc_ptr, wptr, packed.ws_bytes, packed.touch_ptr, stream.cuda_stream)
                 _capi.check(L, st, 'mpqe_step_table_rows')
                 flags &= ~_capi.FLAG_TOUCH_RETRY
-            if flags & _capi.FLAG_INTERNAL and not (flags & 0xf) and backward and zero_grad and not self.learned:
+            if flags & _capi.FLAG_INTERNAL and not (flags & 0xf) and backward and zero_grad and self.uses_chain(packed):
                 # An in-launch hand-off between workgroups timed out (a producer lost its CU to another process: one process
                 # per GPU is what the chain form is built for). What the launches left in the gradient buffers is not to be
                 # trusted; the LEVEL form (one launch per message-passing level, include/mpqe_amd.h MPQE_STEP_NO_CHAIN) hands

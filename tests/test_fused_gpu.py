@@ -151,16 +151,18 @@ def test_fused_step_bad_id_is_reported():
         step.check()
 
 
-def test_checked_run_survives_a_late_producer():
+@pytest.mark.parametrize('readout', ['mp', 'mlp'])
+def test_checked_run_survives_a_late_producer(readout):
     """The chain form hands vectors and transposed weights from workgroup to workgroup inside a launch; every wait is
     bounded. A producer that arrives ~1 s late (forced: HANDOFF_LATE -- what a co-tenant on the GPU can do) makes its
     consumers give up: run(checked=True) must then deliver the step all the same -- through the level form, which has no
     in-launch hand-off -- and the next, undisturbed step must run on the chain form as if nothing had happened."""
     from mpqe_amd import ops
     from mpqe_amd.fused import FusedTrainStep
-    model, batches = _setup('mp', True, False, D=64, B=96)
+    model, batches = _setup(readout, True, False, D=64, B=96, weight_decay=0 if readout == 'mp' else 1e-3)
     step = FusedTrainStep(model)
     packed = step.pack(batches)
+    assert step.uses_chain(packed)          # (mlp: the readout's Linear layers ride in the chain launch)
     loss0 = step.run(packed, checked=True).clone()
     good = {k: p.grad.clone() for k, p in model.named_parameters()}
     lib = ops.lib()
