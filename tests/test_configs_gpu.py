@@ -181,8 +181,10 @@ def drop_near_ties(batches, cpu_params, cfg, node_maps, model, tol=1e-6):
     ('aifb', 128, 'mp', True, 'device_ids'),          # ... and packed the way bench.py's timed loop packs: pack(descs, ids=<CUDA tensor>)
     ('mutag', 256, 'sum', False, 'default'),          # configs[2]
     ('am', 128, 'max', False, 'default'),             # configs[3]
-    # the learned readouts at the benchmarked shape (level form, the readout inside the call: csrc/step_readout.h)
-    ('aifb', 128, 'mlp', True, 'default'), ('aifb', 128, 'targetmlp', False, 'default'), ('aifb', 128, 'concat', False, 'default')])
+    # the learned readouts at the benchmarked shape, the readout inside the call: on the chain form (their Linear layers as two
+    # more levels of every block's programme: csrc/step_chain.h) and on the level form (csrc/step_readout.h)
+    ('aifb', 128, 'mlp', True, 'default'), ('aifb', 128, 'targetmlp', False, 'default'), ('aifb', 128, 'concat', False, 'default'),
+    ('aifb', 128, 'concat', False, 'no_chain')])
 def test_benchmarked_workload_against_oracle(kg, D, readout, adaptive, flags):
     """BASELINE.json configs[1] exactly as bench.py times it -- AIFB-shaped KG, the 11-batch post-burn-in mix at
     B = 512, D = 128, readout mp (TM), adaptive, num_layers 3 unshared, the reference's loss weights -- through the
@@ -219,7 +221,7 @@ def test_benchmarked_workload_against_oracle(kg, D, readout, adaptive, flags):
         assert packed.touch_mode == 'step' and packed.ids_ref is ids
     else:
         packed = step.pack(batches)
-    assert step.uses_chain(packed) == (flags != 'no_chain' and not step.learned)
+    assert step.uses_chain(packed) == (flags != 'no_chain')       # (the learned readouts ride on the chain form too)
     loss, sp, sn = step.run(packed, scores=True)
     step.check()
     sp, sn, loss = sp.cpu().numpy(), sn.cpu().numpy(), loss.cpu().numpy()
