@@ -238,6 +238,9 @@ __device__ __forceinline__ void chain_mask_pop(float &v, unsigned &bits) {
 #ifndef CHAIN_DBG
 #define CHAIN_DBG 0     // experiments only: 1 = no weight loads in the K loop, 2 = no MFMAs
 #endif
+#ifndef CHAIN_LATE_DECODE
+#define CHAIN_LATE_DECODE 1   // K split form: an op's LDS words become scalars BEHIND the item in front of which they were requested
+#endif
 #ifndef CHAIN_NOLOAD
 #define CHAIN_NOLOAD 0  // experiments only, with CHAIN_DBG = 6 (cycle trace): 1 = no weight loads in the K loop (wrong results)
 #endif
@@ -351,6 +354,27 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
         o.level = (w >> 24) & 0xff;
         o.flags = __builtin_amdgcn_readfirstlane(S.opw[k][1]);
         o.part = __builtin_amdgcn_readfirstlane(S.opp[k]);      // (forward: the node update's cv slot)
+        return o;
+    };
+    // the same in two halves: the op's words are requested from LDS in front of an item and turned into scalars behind it --
+    // a readfirstlane right behind its ds_read waits out the LDS round trip (~130 cycles per item: the ops of one wave per
+    // SIMD hide nothing), behind the item's 64 MFMAs the words have long landed
+    struct RawOp {
+        int w0, w1, w2;
+    };
+    auto get_raw = [&](int it) -> RawOp {
+        const int k = first_op + (it < T ? it : T - 1) / IPO;
+        return RawOp{S.opw[k][0], S.opw[k][1], S.opp[k]};
+    };
+    auto decode = [&](const RawOp &r) -> ChainStep {
+        const int w = __builtin_amdgcn_readfirstlane(r.w0);
+        ChainStep o;
+        o.src = w & 0xff;
+        o.node = (w >> 8) & 0xff;
+        o.tslot = RO ? (w >> 16) & 0xff : o.node;
+        o.level = (w >> 24) & 0xff;
+        o.flags = __builtin_amdgcn_readfirstlane(r.w1);
+        o.part = __builtin_amdgcn_readfirstlane(r.w2);
         return o;
     };
     // matrix pointers come from LDS (filled in phase A1): no scalar memory round trip, no branch, per item
@@ -674,6 +698,15 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
         // (the matrix pointer of the next item's prefetch is read from LDS one item early, like the ops)
         const float *wn1 = wptr(1);
         while (true) {
+#if CHAIN_LATE_DECODE
+            const RawOp r2_ = get_raw(it + 2);
+            const float *w2_ = wptr(it + 2);
+            item(oc, it, f0, f0, wn1, std::true_type());
+            if (++it >= T) break;
+            oc = on;
+            on = decode(r2_);
+            wn1 = w2_;
+#else
             const ChainStep o2_ = get_op(it + 2);
             const float *w2_ = wptr(it + 2);
             item(oc, it, f0, f0, wn1, std::true_type());
@@ -681,6 +714,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
             oc = on;
             on = o2_;
             wn1 = w2_;
+#endif
         }
     } else if constexpr (NCB <= 2) {
         WHalf<NCB> f0, f1, f2, f3;
