@@ -287,7 +287,10 @@ def time_fused_kernels(step, packed, data, model, readout, reps=20):
     if step.learned and step.uses_chain(packed):
         # the MLP readout on the chain form: two Linear layers on every node row -- 2 N more [B, D] x [D, D] products per
         # batch, forward, backward-x and weight gradient alike
-        total += sum(2.0 * t.B * D * D * 2 * t.N for t in tmpl)
+        # (targetmlp: rows [target | node] of the N - 1 other nodes, 2 + 1 products each; concat: L + 1 per node)
+        per_graph = {'mlp': lambda t, L: 2 * t.N, 'targetmlp': lambda t, L: 3 * (t.N - 1),
+                     'concat': lambda t, L: (L + 1) * t.N}[readout]
+        total += sum(2.0 * t.B * D * D * per_graph(t, L) for t, L in zip(tmpl, Ls))
     plan = []                                            # (kernel, flops) per event pair, in library order
     lanes = [(packed.lane_begin[l], packed.lane_begin[l + 1]) for l in range(len(packed.lane_begin) - 1)]
     lane_total = [sum(flops(lo, hi, p) for p in range(Lmax)) for lo, hi in lanes]

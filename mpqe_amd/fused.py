@@ -171,7 +171,8 @@ class FusedTrainStep(object):
         # chain form: weight-gradient tiles + backward post-pass as workgroups of the chain launch (True), as a launch of
         # their own (False), or the library's choice by step size (None; include/mpqe_amd.h MPQE_STEP_MERGE_TAIL)
         self.merge_tail = merge_tail
-        self.uniform = bool(uniform and chain)
+        # (concat on the chain form reads every node's state after every layer: the library leaves none to the pre-pass)
+        self.uniform = bool(uniform and chain) and not (self.learned and model.readout_str == 'concat')
         if touch not in (True, False, 'step', 'pack'):
             raise ValueError("touch: True / 'step', 'pack' or False")
         if host_ids not in ('direct', 'copy'):
