@@ -1613,9 +1613,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     if (P->num_modes <= 0 || P->num_modes > MPQE_STEP_MAX_MODES) return MPQE_ERR_UNSUPPORTED;
     if (P->readout < 0 || P->readout > MPQE_READOUT_CONCAT) return MPQE_ERR_INVALID_ARG;
     const int D = P->dim;
-    // (concat: the partial sums of its first layer travel through HBM in 8-byte pieces: D = 128 / 256)
-    const bool ro = chain && (P->readout == MPQE_READOUT_MLP || P->readout == MPQE_READOUT_TARGETMLP ||
-                              (P->readout == MPQE_READOUT_CONCAT && P->dim >= 128));
+    const bool ro = chain && P->readout >= MPQE_READOUT_MLP && P->readout <= MPQE_READOUT_CONCAT;
     const bool ro_pairs = ro && P->readout == MPQE_READOUT_TARGETMLP;       // rows [target | node] of the non-target nodes
     const bool ro_cat = ro && P->readout == MPQE_READOUT_CONCAT;            // rows [H_1 | .. | H_L] of every node
     const int ro_blocks = ro_pairs ? 2 : (ro_cat ? P->num_layers : 1);      // D x D column blocks of the first Linear layer
@@ -3135,8 +3133,7 @@ static bool want_chain(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, 
     // while the ReLU bits of their hidden rows have a level to live in and two layer slots are free for their parameters)
     if (!use_chain) return false;
     if (P->readout >= MPQE_READOUT_MLP) {
-        if (P->readout == MPQE_READOUT_CONCAT) {        // (its partial sums travel in 8-byte pieces; one input block per layer)
-            if (P->dim < 128) return false;
+        if (P->readout == MPQE_READOUT_CONCAT) {        // (one input block per layer)
             for (int i = 0; i < nb; ++i)
                 if (B[i].num_passes != P->num_layers) return false;
         }

@@ -475,7 +475,10 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
 #pragma unroll
                     for (int c2 = 0; c2 < (NCB + 1) / 2; ++c2) {
                         const bool in = 4 * kq + r < ng;
-                        ga[r][c2] = in ? chain_gran_load(reinterpret_cast<const unsigned long long *>(Xadd + (long long)r * N * D) + c2) : 0ull;
+                        if constexpr (NCB % 2 == 0)
+                            ga[r][c2] = in ? chain_gran_load(reinterpret_cast<const unsigned long long *>(Xadd + (long long)r * N * D) + c2) : 0ull;
+                        else        // (D = 64: one column per lane, a 4-byte piece)
+                            ga[r][c2] = in ? (unsigned long long)chain_count_load(reinterpret_cast<const unsigned *>(Xadd + (long long)r * N * D)) : 0ull;
                     }
             }
         }
@@ -587,7 +590,7 @@ __device__ __forceinline__ void chain_run(ChainLds<NCB, KS, NW> &S, const int fi
 #pragma unroll
                         for (int c = 0; c < NCB; ++c) v[r][c] += bv[c];
                 }
-                if constexpr (RO && NCB % 2 == 0) {
+                if constexpr (RO) {
                     if (op.flags & CH_ADDG) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)

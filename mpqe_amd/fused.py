@@ -155,7 +155,7 @@ class FusedTrainStep(object):
             if model.emb_dim % 4:
                 raise NotImplementedError('fused step with a learned readout: embedding dimension must be a multiple of 4')
             on_chain = (chain and model.emb_dim in (64, 128, 256) and model.num_layers <= 3 and not eight_waves and
-                        (model.readout_str != 'concat' or (model.emb_dim >= 128 and not model.adaptive)))
+                        (model.readout_str != 'concat' or not model.adaptive))
             if on_chain:
                 lanes = 1
             else:

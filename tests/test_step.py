@@ -108,8 +108,7 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
     dnm = be.put(node_map.numpy())
     dmode = put('mode_embeddings.weight')
     learned = between is None and cfg['readout'] in _capi.LEARNED_READOUT_IDS
-    if between is not None or (learned and not ((cfg['readout'] != 'concat' and D in (64, 128, 256)) or
-                                                (cfg['readout'] == 'concat' and D in (128, 256) and not cfg['adaptive']))):
+    if between is not None or (learned and not (D in (64, 128, 256) and (cfg['readout'] != 'concat' or not cfg['adaptive']))):
         touch = False           # (level form: it has no use for a touch plan)
     rid = _capi.READOUT_CALLER if between is not None else (_capi.LEARNED_READOUT_IDS[cfg['readout']] if learned else cfg['readout'])
     P = _capi.make_step_params(D, R, rid, [be.ptr(t) for t in tables],
@@ -499,7 +498,7 @@ def test_fused_step_with_learned_readout_matches_oracle(be, readout, scatter_op,
     ('targetmlp', 64, 'many', 'mean', True, False, 1e-3, 'pack'), ('targetmlp', 128, 'tiny', 'mean', True, False, 0, 'step'),
     ('targetmlp', 128, 'dup', 'max', False, False, 1e-3, 'step'),
     ('concat', 128, 'all7', 'add', False, False, 1e-3, 'step'), ('concat', 128, 'dup', 'max', False, True, 0, 'pack'),
-    ('concat', 128, 'tiny', 'mean', False, False, 0, False)])
+    ('concat', 128, 'tiny', 'mean', False, False, 0, False), ('concat', 64, 'many', 'add', False, False, 1e-3, 'step')])
 def test_mlp_readout_on_the_chain_matches_oracle(be, capfd, readout, D, mix, scatter_op, adaptive, shared, wd, touch):
     """MLPReadout / TargetMLPReadout (reference model.py:497-553) on the CHAIN form: Linear - ReLU - Linear are two more
     levels of every graph block's programme (the node's own row times W^T -- targetmlp: the target's row times the first
