@@ -1546,9 +1546,9 @@ struct HostPlan {
     long long ro_rows;
     int ro_kin;
     bool ro_direct;
-    // MPQE_READOUT_MLP on the chain form: the readout's two Linear layers are levels L + 1, L + 2 of every batch, their
-    // parameters the `root` / `bias` of the virtual layers ro_layer, ro_layer + 1 (= num_layers, + 1; stored [out, in]:
-    // the transposed form of a root matrix)
+    // the learned readouts (MPQE_READOUT_MLP / _TARGETMLP / _CONCAT) on the chain form: the readout's two Linear layers are
+    // levels L + 1, L + 2 of every batch, their parameters the `root` / `bias` of the virtual layers ro_layer, ro_layer + 1
+    // (= num_layers, + 1; stored [out, in]: the transposed form of a root matrix; the first may be [D, n D]: column blocks)
     bool ro_chain;
     int ro_layer;
     long long level_stride;
@@ -2536,9 +2536,6 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
             };
             auto readout_ops = [&](int dir) {
                 const unsigned rows = d.live[d.L + 1];          // node slots with a readout row (targetmlp: not the target)
-                int last_n = 0;
-                for (int n = 0; n < tp.N; ++n)
-                    if ((rows >> n) & 1u) last_n = n;
                 auto op_of = [&](int src, int node, int r, int level) {
                     ChainOp op;
                     op.src = (unsigned char)src;
@@ -2625,7 +2622,6 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
                             hp->cops.back().aux = part_row[i][d.L][n];
                         }
                     }
-                    (void)last_n;
                     if (hp->cops.size() > level_first) hp->cops.back().flags |= CH_LEVEL_END;
                 }
             };

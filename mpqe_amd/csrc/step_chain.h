@@ -65,7 +65,7 @@ struct ChainRef {
     int gi0;              // number of graph g0 among the step's graphs: g_off + g0
     int B;
     unsigned meta;        // N | A << 4 | anchor table 0 / 1 / 2 << 8 / 12 / 16 | target table << 20
-    int rof;              // learned readout on the chain (MPQE_READOUT_MLP): forward ops of its two Linear layers, between the
+    int rof;              // learned readout on the chain (MPQE_READOUT_MLP / _TARGETMLP / _CONCAT): forward ops of its two Linear layers, between the
                           // forward and the backward programme (whose first ops are then the readout's backward)
 };
 

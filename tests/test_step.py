@@ -500,6 +500,19 @@ def test_fused_step_with_learned_readout_matches_oracle(be, readout, scatter_op,
     ('concat', 128, 'all7', 'add', False, False, 1e-3, 'step'), ('concat', 128, 'dup', 'max', False, True, 0, 'pack'),
     ('concat', 128, 'tiny', 'mean', False, False, 0, False), ('concat', 64, 'many', 'add', False, False, 1e-3, 'step')])
 def test_mlp_readout_on_the_chain_matches_oracle(be, capfd, readout, D, mix, scatter_op, adaptive, shared, wd, touch):
+    """The learned readouts inside the chain launch against the oracle's whole model (see _readout_on_the_chain)."""
+    _readout_on_the_chain(be, capfd, readout, D, mix, scatter_op, adaptive, shared, wd, touch, 3)
+
+
+@pytest.mark.parametrize('readout,D,mix,L', [('concat', 128, 'd1', 1), ('concat', 64, 'dup', 2), ('targetmlp', 64, 'd1', 1),
+                                             ('mlp', 128, 'dup', 2)])
+def test_learned_readout_on_the_chain_with_fewer_layers(be, capfd, readout, D, mix, L):
+    """The same with one and two message-passing layers (concat: one and two column blocks of its first Linear layer; the
+    readout's virtual layers sit right behind the model's)."""
+    _readout_on_the_chain(be, capfd, readout, D, mix, 'add', False, False, 1e-3, 'step', L)
+
+
+def _readout_on_the_chain(be, capfd, readout, D, mix, scatter_op, adaptive, shared, wd, touch, L):
     """MLPReadout / TargetMLPReadout (reference model.py:497-553) on the CHAIN form: Linear - ReLU - Linear are two more
     levels of every graph block's programme (the node's own row times W^T -- targetmlp: the target's row times the first
     column block of W_0 plus the node's times the second --, ReLU bits in LDS), the reduction over a graph's rows is the
@@ -508,8 +521,8 @@ def test_mlp_readout_on_the_chain_matches_oracle(be, capfd, readout, D, mix, sca
     layers'. Loss, scores and every gradient against the oracle's whole model; the level form (MPQE_STEP_NO_CHAIN) gives
     the same."""
     margin = 1.0
-    mixes = dict(MIXES, **EDGE_MIXES)
-    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(31, D, 3, shared, mixes[mix], readout, adaptive)
+    mixes = dict(MIXES, d1=[('1-chain', 20, 1.0), ('2-inter', 37, 0.5)], **EDGE_MIXES)      # (d1: diameter 1)
+    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(31, D, L, shared, mixes[mix], readout, adaptive)
     cfg['scatter_op'], cfg['weight_decay'] = scatter_op, wd
     total, per, sp_ref, sn_ref = 0, [], [], []
     for b in batches:
