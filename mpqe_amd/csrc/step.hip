@@ -3713,6 +3713,12 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     // workgroups and queue behind them. Hence: merged up to 9/8 x CUs chain workgroups unless a flag says otherwise.
     const bool merged = use_chain && backward && NL == 1 && !(P->flags & MPQE_STEP_SPLIT_TAIL) &&
                         ((P->flags & MPQE_STEP_MERGE_TAIL) || hp.blk_off[nb] <= STEP_CUS + STEP_CUS / 8);
+    // ... or only the POST-PASS (its vector ops are few, light, and a three-level dependence chain: it then runs while the
+    // slower batches' chain workgroups are still at work, and the weight-gradient launch is its tiles alone). Experiment:
+    // mpqe_debug_option POST_IN_CHAIN
+    const bool post_only = use_chain && backward && NL == 1 && !merged && D % 64 == 0 && !hp.uops_b.empty() &&
+                           hp.closures.empty() && dbg_on("POST_IN_CHAIN") && !dbg_on("FUSE_TAIL");
+    const bool pic = merged || post_only;          // the post-pass rides in the chain launch
     {
         ZeroSegs &zs = pa.zs;
         if (backward && !phase_bwd && !phase_score && (P->flags & MPQE_STEP_ZERO_GRADS)) {     // (step in several calls: the first one fills)
@@ -3720,7 +3726,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                 if (!ptr || n <= 0) return;
                 // (merged launch: a root matrix that tiles / a rank-1 op of the SAME launch write whole is not zero-filled
                 // -- the fill would race with its writers, who store instead of adding)
-                for (size_t k = 0; merged && k < hp.whole_roots.size(); ++k)
+                for (size_t k = 0; pic && k < hp.whole_roots.size(); ++k)
                     if (gp.root[hp.whole_roots[k]] == ptr) return;
                 for (int k = 0; k < zs.count; ++k)
                     if (zs.p[k] == ptr) return;                  // shared layers repeat their buffers
@@ -3853,8 +3859,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             pa.wt_count = epoch_f + 32;
             pa.tail_arrive = nullptr;      // (set below once the launch form is known)
             pa.late = dbg_on("HANDOFF_LATE") ? 1 : 0;
-            pa.fwd_done = merged && pa.ublocks > 0 ? epoch_f + 33 : nullptr;
-            pa.ua.vt_through = merged ? 1 : 0;
+            pa.fwd_done = pic && pa.ublocks > 0 ? epoch_f + 33 : nullptr;
+            pa.ua.vt_through = pic ? 1 : 0;
         } else if (zblocks > 0) {
             hipLaunchKernelGGL(step_zero_kernel, dim3((unsigned)zblocks), dim3(256), 0, s, zs);
         }
@@ -3944,16 +3950,16 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     ra.touch_perm = touch_layout(hp.touch_M, 0).perm;
     ra.DG = reinterpret_cast<const float *>(wb + hp.o_DG);
     ra.tabs = tabs;
-    ra.table_store = ((sparse_tables || (P->flags & MPQE_STEP_ZERO_GRADS)) ? 1 : 0) | (merged ? 2 : 0);
+    ra.table_store = ((sparse_tables || (P->flags & MPQE_STEP_ZERO_GRADS)) ? 1 : 0) | (pic ? 2 : 0);
     ra.touch_M = (long long)hp.touch_M;
     ra.touch_row_bits = touch_row_bits;
     ra.rows_multi = rows_multi ? 1 : 0;
     ra.err = err;
-    const bool fuse_tail = use_chain && backward && !merged && NL == 1 && D % 64 == 0 && dbg_on("FUSE_TAIL");
+    const bool fuse_tail = use_chain && backward && !pic && NL == 1 && D % 64 == 0 && dbg_on("FUSE_TAIL");
     // split tail launch of the chain form: the loss and the entity-table rows depend on the chain launch alone -- they run as
     // trailing workgroups of the weight-gradient launch, beside its tiles (136 of 256 CUs busy on the AIFB step), instead of
     // in the reduction launch behind it (mpqe_debug_option LATE_ROWS = 1: as before)
-    const bool can_early = use_chain && backward && !merged && !fuse_tail && NL == 1 && D % 4 == 0 && 256 % (D / 4) == 0;
+    const bool can_early = use_chain && backward && !pic && !fuse_tail && NL == 1 && D % 4 == 0 && 256 % (D / 4) == 0;
     // (as trailing workgroups of the weight-gradient launch itself, mpqe_debug_option EARLY_ROWS = 1: measured slower -- that
     // launch's 230 VGPRs allow two workgroups per CU, a table workgroup took 8.6 us and the launch 6 us longer)
     const bool early_roles = can_early && dbg_on("EARLY_ROWS");
@@ -3969,7 +3975,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         tl.wblock = ta.wblock + first;
         tl.wblocks = count;
         if (first == 0 && (P->flags & MPQE_STEP_ZERO_GRADS)) tl.zblocks = (int)hp.zmats.size() * ta.zper;
-        if (first == 0) tl.ublocks = ub.nops * ub.chunks;
+        if (first == 0 && !post_only) tl.ublocks = ub.nops * ub.chunks;
         int nblocks = tl.ublocks + count + tl.zblocks;
         const bool closures = use_chain && first == 0 && !hp.closures.empty() && !fuse_tail;
         if (closures) {
@@ -4096,7 +4102,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             ca.wt_count = pa.tblocks > 0 ? pa.wt_count : nullptr;
             ca.wt_blocks = pa.tblocks;
             // (counters and their epoch advance on merged steps only: targets are epoch x count)
-            ca.done = merged ? reinterpret_cast<unsigned *>(db + hp.o_done) : nullptr;
+            ca.done = pic ? reinterpret_cast<unsigned *>(db + hp.o_done) : nullptr;
             ca.arrive = ca.done ? ca.done + hp.done_inc.size() : nullptr;
             ca.done_inc = reinterpret_cast<const int *>(db + hp.o_done_inc);
             ca.ro = hp.ro_chain ? 1 : 0;
@@ -4105,17 +4111,17 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             PostArgs po;
             memset(&po, 0, sizeof(po));
             long long grid_blocks = pa.lead + pa.nchain + zblocks;
-            if (merged) {
+            if (pic) {
                 unsigned *done = reinterpret_cast<unsigned *>(db + hp.o_done);
                 po.zpad = (int)((zblocks + 7) / 8 * 8);
                 if (po.zpad == 0) po.zpad = 8;              // (> 0 marks the merged launch)
-                po.zmblocks = (P->flags & MPQE_STEP_ZERO_GRADS) ? (int)hp.zmats.size() * ta.zper : 0;
+                po.zmblocks = (merged && (P->flags & MPQE_STEP_ZERO_GRADS)) ? (int)hp.zmats.size() * ta.zper : 0;
                 po.ublocks = ub.nops * ub.chunks;
                 po.na = hp.post_na;
                 po.xrank = 0;
                 for (int x = 0; x < STEP_XCDS; ++x) po.xrank |= (unsigned)(hp.post_rank[x] + 1) << (4 * x);
                 po.ppad = (po.zmblocks + po.ublocks + po.na - 1) / po.na * po.na;
-                po.wblocks = hp.wblocks_total;
+                po.wblocks = merged ? hp.wblocks_total : 0;      // (post-pass only: the tiles stay a launch of their own)
                 po.zper = ta.zper;
                 po.D = D;
                 po.tile_n = hp.tile_n;

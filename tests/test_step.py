@@ -645,7 +645,8 @@ def test_fused_step_chain_kernels(be, D, readout, adaptive, shared, L):
         # workgroups of the weight-gradient launch (EARLY_ROWS: table_sum_multi, a range of sorted positions per workgroup;
         # measured slower, kept as a switch) -- the same additions in the same order, bit for bit
         # ... and the reduction's table workgroups taking a range of positions each (ROWS_MULTI; default: one run each)
-        for opt in (b'EARLY_ROWS', b'ROWS_MULTI'):
+        # ... and the post-pass alone riding in the chain launch (POST_IN_CHAIN: the tiles stay a launch of their own)
+        for opt in (b'EARLY_ROWS', b'ROWS_MULTI', b'POST_IN_CHAIN'):
             be.lib.mpqe_debug_option(opt, 1, 1)
             try:
                 other = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_SPLIT_TAIL)
@@ -656,6 +657,12 @@ def test_fused_step_chain_kernels(be, D, readout, adaptive, shared, L):
                 np.testing.assert_array_equal(split[3][k], other[3][k], err_msg='%s %s' % (opt, k))
         runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0,
                              flags=_capi.STEP_SPLIT_TAIL | _capi.STEP_ZERO_GRADS, repeat=2))
+        be.lib.mpqe_debug_option(b'POST_IN_CHAIN', 1, 1)
+        try:        # (three runs on one descriptor buffer: the counters' targets are epoch x count; the whole-root rule)
+            runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0,
+                                 flags=_capi.STEP_SPLIT_TAIL | _capi.STEP_ZERO_GRADS, repeat=3))
+        finally:
+            be.lib.mpqe_debug_option(b'POST_IN_CHAIN', 0, 0)
         runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0,
                              flags=_capi.STEP_MERGE_TAIL | _capi.STEP_ZERO_GRADS, repeat=3))
         # the reduction as trailing workgroups of the weight-gradient launch (two launches per step in the split form):

@@ -2,7 +2,7 @@
 # A/B of a debug option on one box:  tools/r04_opt.sh <tag> <OPTION> "<readouts>"
 out=gpurun_out/$1; mkdir -p $out; opt=$2
 export TMPDIR=/tmp; VALS=(${V0:-0} ${V1:-1})
-for rep in 1 2; do
+for rep in ${REPS:-1 2}; do
 for cfg in ${3:-mp mlp}; do
 for v in 0 1; do
   timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-scatter --no-pack-ms --readout $cfg --debug-opt $opt=${VALS[$v]:-$v} > $out/b_${cfg}_$v$rep.json 2> $out/b_${cfg}_$v$rep.err
