@@ -1871,9 +1871,23 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     // MFMA time each, no K split, so no extra slab -- is built in, mpqe_debug_option TILE_N = 32, and was measured on the AIFB step:
     // the tiles end at 11.0 us instead of 14.8, but 320 of them next to the post-pass' 100 vector-op workgroups slow ITS
     // latency chain from 15 to 18.9 us, and the launch from 19.7 to 23.5.)
+    // (Round 4, with the post-pass on two XCDs of its own: 64 x 32 while all of them are resident at once on the other six --
+    // 272 for the AIFB step: 67.8 -> 67.2 us per step, three runs each on one box.)
     int tile_n = GT_BN;
     if (chain && D % 64 == 0) {
-        if (mpqe_dbg_value("TILE_N", 0) == 32) tile_n = 32;       // (timing experiments)
+        long long n32 = 0;
+        for (size_t k = 0; k < keys.size(); ++k) {
+            int nch1, ch1;
+            pick_chunks(sd.b[keys[k].batch].B, 32, &nch1, &ch1, 512);
+            n32 += (long long)nch1 * (D / 64) * (D / 32);
+        }
+        long long blk_all = 0;
+        for (int i = 0; i < nb; ++i) blk_all += (sd.b[i].B + CH_GB - 1) / CH_GB;
+        // (not where the tiles ride in the chain launch -- the merged form of small steps, measured with 64 x 64 only)
+        const bool rides = hp->nlanes == 1 && !(P->flags & MPQE_STEP_SPLIT_TAIL) &&
+                           ((P->flags & MPQE_STEP_MERGE_TAIL) || blk_all <= STEP_CUS + STEP_CUS / 8);
+        const int forced = mpqe_dbg_value("TILE_N", 0);           // (timing experiments: 32 / 64)
+        if (forced == 32 || (forced != 64 && !rides && n32 <= 6 * 2 * (STEP_CUS / STEP_XCDS))) tile_n = 32;
     }
     hp->tile_n = tile_n;
     const int wct = (D + tile_n - 1) / tile_n;            // column tiles of a weight gradient
