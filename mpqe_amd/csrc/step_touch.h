@@ -518,8 +518,15 @@ __device__ __forceinline__ void table_sum_block(long long M, int row_bits, const
 // positions to the end of the last such run, TS_AHEAD rows per round trip whatever the run lengths (a table of 10^6 rows
 // has runs of one, the AIFB step runs of eight), adding in sorted order and storing at every run's end: the same additions
 // in the same order as table_sum_block.
+// (Smaller ranges -- 2 / 3 / 4 positions per lane group, 1 376 / 918 / 688 workgroups -- measured in the reduction launch of
+// the AIFB step: 13.8 / 13.0 / 11.5 us against 10.3 with the one-run workgroups of table_sum_block: the staging round trip and
+// its barrier cost more than the second round of the chip they save.)
+#ifndef TSM_OWN
 #define TSM_OWN 8
+#endif
+#ifndef TSM_LOOK
 #define TSM_LOOK 64
+#endif
 #define TSM_LDS_WORDS(D) (3 * ((256 / ((D) / 4)) * TSM_OWN + 1 + TSM_LOOK))
 template <class TabsT>
 __device__ __forceinline__ void table_sum_multi(long long M, int row_bits, const tkey_t *__restrict__ keys,
