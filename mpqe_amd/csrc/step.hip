@@ -138,7 +138,9 @@ struct RGroup {
 struct Rank1 {
     int u, v;          // vector ids: out[i][j] += VT[u][i] * VT[v][j]
 };
+#ifndef R1_CHUNK
 #define R1_CHUNK 8
+#endif
 #ifndef STEP_DBG
 #define STEP_DBG 0      // timing experiments only (wrong results): 1 = no table-sum rows in the reduction launch,
 #endif                  // 2 = no rank-1 terms, 3 = neither
@@ -1244,7 +1246,17 @@ __device__ __forceinline__ void reduce_block(const ReduceArgs &ra, int bx, int b
         }
 }
 
+// (REDUCE_WAVES = 6 / 8: the launch's 92 VGPRs capped at 80 / 64 for six / eight instead of five workgroups per CU -- its
+// 2 752 table-row workgroups are two and a half rounds of the chip -- measured: 9.8 / 11.1 us against 10.3, the step 0.3 -
+// 1.2 us SLOWER: the spills land in the group workgroups, the launch's critical path)
+#ifndef REDUCE_WAVES
+#define REDUCE_WAVES 0
+#endif
+#if REDUCE_WAVES
+__global__ __launch_bounds__(256, REDUCE_WAVES) void step_reduce_kernel(ReduceArgs ra) {
+#else
 __global__ __launch_bounds__(256) void step_reduce_kernel(ReduceArgs ra) {
+#endif
     __shared__ f32x4 part[4][64];
     reduce_block(ra, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, part);
 }
