@@ -512,6 +512,46 @@ def test_learned_readout_on_the_chain_with_fewer_layers(be, capfd, readout, D, m
     _readout_on_the_chain(be, capfd, readout, D, mix, 'add', False, False, 1e-3, 'step', L)
 
 
+@pytest.mark.parametrize('readout', ['mlp', 'concat'])
+def test_learned_readout_falls_back_to_the_level_form(be, capfd, readout):
+    """Fewer passes than a query's diameter leave node states batch-uniform after the last pass: such a step cannot ride
+    on the chain form with a learned readout (its weight gradient reads every node's rows of H[L]) -- the planner turns it
+    away and the SAME call runs the level form: same loss, scores and gradients as the oracle's. (concat: on the chain
+    form, whose pre-pass it switches off.)"""
+    D, margin = 64, 1.0
+    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(37, D, 2, False, EDGE_MIXES['tiny'], readout, False)
+    cfg['weight_decay'] = 1e-3
+    total, sp_ref = 0, []
+    for b in batches:
+        q = ref_cpu.encode_queries(params, cfg, node_map, b['formula'], b['col'])
+        pos = ref_cpu.score(params, node_map, b['formula'], q, b['targets'])
+        neg = ref_cpu.score(params, node_map, b['formula'], q, b['negs'])
+        l = torch.clamp(margin - (pos - neg), min=0).mean()
+        l = l + 1e-3 * sum(torch.norm(v) for k, v in params.items() if k.startswith('readout.'))
+        total = total + b['weight'] * l
+        sp_ref.append(pos.detach().numpy())
+    total.backward()
+    be.lib.mpqe_debug_option(b'DUMP_PLAN', 1, 1)
+    try:
+        capfd.readouterr()
+        loss, sp, sn, grads, err = run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, touch=False)
+        # (concat leaves no state to the pre-pass at all -- every level's state of every node is an input of its --: it
+        # stays on the chain form)
+        assert ('plan: chain 1' if readout == 'concat' else 'plan: chain 0') in capfd.readouterr().err
+    finally:
+        be.lib.mpqe_debug_option(b'DUMP_PLAN', 0, 0)
+    assert err == 0
+    np.testing.assert_allclose(sp, np.concatenate(sp_ref), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(loss[0], total.item(), rtol=1e-5, atol=1e-6)
+    done = set()
+    for k, p in params.items():
+        if id(p) in done:
+            continue
+        done.add(id(p))
+        ref = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
+        np.testing.assert_allclose(grads[k], ref, rtol=1e-4, atol=2e-6, err_msg=k)
+
+
 def _readout_on_the_chain(be, capfd, readout, D, mix, scatter_op, adaptive, shared, wd, touch, L):
     """MLPReadout / TargetMLPReadout (reference model.py:497-553) on the CHAIN form: Linear - ReLU - Linear are two more
     levels of every graph block's programme (the node's own row times W^T -- targetmlp: the target's row times the first
