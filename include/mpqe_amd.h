@@ -74,9 +74,9 @@ enum { MPQE_READOUT_SUM = 0, MPQE_READOUT_MAX = 1, MPQE_READOUT_TM = 2,
         * reduction over each graph's rows (mpqe_step_params_t.readout_*): MLP (model.py:497-515; in = dim, a row per node),
         * TARGETMLP (model.py:518-553; in = 2 dim, a row [target | node] per non-target node), CONCAT (model.py:441-446;
         * in = num_layers dim, a node's states after every layer side by side -- every batch runs num_layers passes).
-        * They ride on the chain form when it applies (dim 64 / 128 / 256, at most 3 passes per batch,
-        * two free layer slots, no node state still batch-uniform after the last pass): their Linear layers are two more levels
-        * of every graph block's programme; otherwise the level form (one launch per level + dense-layer launches) */
+        * They ride on the chain form when it applies (dim 64 / 128 / 256, at most 3 passes per batch, two free layer
+        * slots): their Linear layers are two more levels of every graph block's programme; otherwise the level form (one
+        * launch per level + dense-layer launches) */
        MPQE_READOUT_MLP = 4, MPQE_READOUT_TARGETMLP = 5, MPQE_READOUT_CONCAT = 6 };
 enum { MPQE_SCATTER_ADD = 0, MPQE_SCATTER_MAX = 1, MPQE_SCATTER_MEAN = 2 };
 #define MPQE_MAX_TEMPLATE_EDGES 3

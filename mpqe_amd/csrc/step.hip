@@ -1754,26 +1754,31 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     }
     // ---- batch-uniform node states (see UOp): uni[i][p] = node slots of batch i that are one vector per batch at level p
     // (concat reads every node's state after EVERY layer: no state is left to the pre-pass as a vector)
-    const bool uniform = chain && !(P->flags & MPQE_STEP_NO_UNIFORM) && !ro_cat;
-    hp->uniform = uniform;
+    bool uniform = chain && !(P->flags & MPQE_STEP_NO_UNIFORM) && !ro_cat;
     unsigned uni[MPQE_STEP_MAX_BATCHES][MPQE_STEP_MAX_LAYERS + 1];
-    for (int i = 0; i < nb; ++i) {
-        const BatchDev &d = sd.b[i];
-        const TmplArgs &tp = d.tp;
-        uni[i][0] = uniform ? (((1u << tp.N) - 1u) & ~((1u << d.A) - 1u)) : 0u;
-        for (int p = 0; p < d.L; ++p) {
-            unsigned m = uni[i][p];
-            for (int e = 0; e < tp.E; ++e)
-                if (!((uni[i][p] >> tp.src[e]) & 1u)) m &= ~(1u << tp.dst[e]);
-            uni[i][p + 1] = m;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        bool left_over = false;
+        for (int i = 0; i < nb; ++i) {
+            const BatchDev &d = sd.b[i];
+            const TmplArgs &tp = d.tp;
+            uni[i][0] = uniform ? (((1u << tp.N) - 1u) & ~((1u << d.A) - 1u)) : 0u;
+            for (int p = 0; p < d.L; ++p) {
+                unsigned m = uni[i][p];
+                for (int e = 0; e < tp.E; ++e)
+                    if (!((uni[i][p] >> tp.src[e]) & 1u)) m &= ~(1u << tp.dst[e]);
+                uni[i][p + 1] = m;
+            }
+            if (ro) {
+                // (a node slot no anchor has reached after the last pass -- fewer passes than the query's diameter -- has no
+                // rows in H[L], which the readout's weight gradient reads: such a step keeps every state per graph)
+                left_over = left_over || (uni[i][d.L] & d.live[d.L]) != 0u;
+                uni[i][d.L + 1] = uni[i][d.L + 2] = 0u;
+            }
         }
-        if (ro) {
-            // (a node slot no anchor has reached after the last pass has no rows in H[L], which the readout's weight
-            // gradient reads: fewer passes than the query's diameter -- such a step takes the level form)
-            if (uni[i][d.L] & d.live[d.L]) return MPQE_ERR_UNSUPPORTED;
-            uni[i][d.L + 1] = uni[i][d.L + 2] = 0u;
-        }
+        if (!left_over) break;
+        uniform = false;
     }
+    hp->uniform = uniform;
     // vector table ids: (kind, batch, level, node slot) -> row of VT; granule slots only for vectors another
     // workgroup of the producing launch reads
     enum { V_UV = 0, V_CV = 1, V_SV = 2 };

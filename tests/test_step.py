@@ -513,11 +513,10 @@ def test_learned_readout_on_the_chain_with_fewer_layers(be, capfd, readout, D, m
 
 
 @pytest.mark.parametrize('readout', ['mlp', 'concat'])
-def test_learned_readout_falls_back_to_the_level_form(be, capfd, readout):
-    """Fewer passes than a query's diameter leave node states batch-uniform after the last pass: such a step cannot ride
-    on the chain form with a learned readout (its weight gradient reads every node's rows of H[L]) -- the planner turns it
-    away and the SAME call runs the level form: same loss, scores and gradients as the oracle's. (concat: on the chain
-    form, whose pre-pass it switches off.)"""
+def test_learned_readout_with_fewer_passes_than_the_diameter(be, capfd, readout):
+    """Fewer passes than a query's diameter leave node states batch-uniform after the last pass; a learned readout's weight
+    gradient reads every node's rows of H[L], so the planner keeps every state of such a step per graph (the pre-pass off,
+    as concat always has it) and the step stays on the chain form: same loss, scores and gradients as the oracle's."""
     D, margin = 64, 1.0
     schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(37, D, 2, False, EDGE_MIXES['tiny'], readout, False)
     cfg['weight_decay'] = 1e-3
@@ -534,10 +533,8 @@ def test_learned_readout_falls_back_to_the_level_form(be, capfd, readout):
     be.lib.mpqe_debug_option(b'DUMP_PLAN', 1, 1)
     try:
         capfd.readouterr()
-        loss, sp, sn, grads, err = run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, touch=False)
-        # (concat leaves no state to the pre-pass at all -- every level's state of every node is an input of its --: it
-        # stays on the chain form)
-        assert ('plan: chain 1' if readout == 'concat' else 'plan: chain 0') in capfd.readouterr().err
+        loss, sp, sn, grads, err = run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin)
+        assert 'plan: chain 1 uniform 0' in capfd.readouterr().err
     finally:
         be.lib.mpqe_debug_option(b'DUMP_PLAN', 0, 0)
     assert err == 0
