@@ -291,6 +291,7 @@ struct PrepArgs {
     int late;                 // diagnostics ("HANDOFF_LATE"): the first transpose workgroup counts itself in ~1 s late -- a producer
                               // that lost its CU to another process: its consumers' bounded waits run out (MPQE_FLAG_INTERNAL)
     unsigned *tail_arrive;    // fused tail: the arrival counter of the step's weight-gradient launch, zeroed here; or NULL
+    int *runs_count;          // the number of run starts the weight-gradient launch will compact (touch_runs_block), zeroed here; or NULL
     int ublocks, tblocks;     // vector-op workgroups, transpose workgroups
     int lead;                 // prologue workgroups in front of the chain workgroups: sblocks + ublocks + tblocks rounded
                               // up to a multiple of 8 (chain workgroup b keeps XCD b % 8)
@@ -431,6 +432,7 @@ __global__ __launch_bounds__(64 * NW) void step_chain_kernel(const StepDev *__re
     // post roles: a producer is never queued behind a consumer that waits for it
     int bid = (int)blockIdx.x, role;
     if (bid == 0 && threadIdx.x == 0 && pa.tail_arrive) *pa.tail_arrive = 0u;       // (read by the NEXT launch)
+    if (bid == 0 && threadIdx.x == 0 && pa.runs_count) *pa.runs_count = 0;
     if (pa.strail && bid >= (int)gridDim.x - pa.strail) {
         if (NW == 4 || threadIdx.x < TSORT_THREADS) tsort_block(pa.ts, bid - ((int)gridDim.x - pa.strail), reinterpret_cast<unsigned *>(S.xs));
         return;
@@ -1031,6 +1033,8 @@ struct ReduceArgs {
     const unsigned *arrive;
     unsigned phase1;
     int rows_multi;          // 1: the entity-table workgroups take a range of sorted positions each (table_sum_multi)
+    const int *runs;         // != NULL: the plan's run starts, compacted by a role of the weight-gradient launch
+                             // (touch_runs_block): runs[0 .. runs[touch_M]) -- the table workgroups take those, not every position
     int early;               // 1: the loss and the entity-table rows were roles of the weight-gradient launch (TailArgs.extra0):
                              // the loss workgroup here only closes the step (epochs, the sort's barrier word, the plan's failure flag)
 };
@@ -1061,7 +1065,8 @@ __device__ __forceinline__ void reduce_block(const ReduceArgs &ra, int bx, int b
         }
         table_sum_block(ra.touch_M, ra.touch_row_bits, reinterpret_cast<const tkey_t *>(touch + ra.touch_keys),
                         reinterpret_cast<const int *>(touch + ra.touch_perm), ra.DG, D, ra.tabs, table_store & 1,
-                        (long long)(by - ngroups - 1) * gx + bx, &reinterpret_cast<const TouchHeader *>(touch)->pad[0]);
+                        (long long)(by - ngroups - 1) * gx + bx, &reinterpret_cast<const TouchHeader *>(touch)->pad[0],
+                        ra.runs, ra.runs ? ra.runs + ra.touch_M : nullptr);
         return;
     }
     // fused tail: what follows reads what tiles / vector ops of THIS launch wrote (slabs and the post-pass' last vectors and
@@ -1276,6 +1281,9 @@ struct TailArgs {
     int D;                   // = sd->D, by value: a tile's record is then the first and only load in front of its rows
     int tile_n;              // columns per weight-gradient tile
     int ux;                  // > 0: XCDs set aside for the post-pass' vector ops (step_tail_kernel)
+    int runs_front, runs_n;  // > 0: the launch's first runs_front workgroups (runs_n of them at work) compact the touch plan's run
+    int *runs_out;           // starts (touch_runs_block) for the reduction launch's table workgroups: runs_out[0 .. M) the
+                             // positions, runs_out[M] their number
     int extra0;              // >= 0: workgroups [extra0, ...) of the launch are roles that read only what the CHAIN launch wrote --
     int tm_blocks;           // [extra0] the loss (loss_block_chain), then tm_blocks entity-table workgroups (table_sum_multi):
                              // they were 2 800 + 1 workgroups of the reduction launch; here they run beside the tiles
@@ -1359,9 +1367,23 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
     // thousands of light partial-sum / anchor workgroups to 2 per CU if they shared this kernel
     // (LD_T, the chain form: the tiles meet in a 17 KB LDS tile at their end; the post-pass' vector ops use 8 KB)
     __shared__ __attribute__((aligned(16))) float smem[MODE == LD_T ? (FUSED ? GWR_SMEM_FLOATS2 : GWR_SMEM_FLOATS) : (MODE == LD_FAST ? GWD_SMEM_FLOATS : GT_SMEM_FLOATS)];
+    // The launch's FIRST ta.runs_front workgroups (a multiple of 8: workgroup b of the rest keeps XCD b % 8) compact the run
+    // starts of the step's touch plan for the reduction launch's table workgroups (touch_runs_block): they depend on the chain
+    // launch alone and are through before the first tile has its rows
+    int bid = (int)blockIdx.x;
+    if (ta.runs_front > 0) {
+        if (bid < ta.runs_front) {
+            if (bid < ta.runs_n)
+                touch_runs_block(ra.touch_M, reinterpret_cast<const tkey_t *>(ra.touch + ra.touch_keys), ta.runs_out,
+                                 ta.runs_out + ra.touch_M, &reinterpret_cast<const TouchHeader *>(ra.touch)->pad[0],
+                                 reinterpret_cast<int *>(smem), bid);
+            return;
+        }
+        bid -= ta.runs_front;
+    }
     if constexpr (FUSED) {
-        if ((int)blockIdx.x >= fa.first) {
-            int p = (int)blockIdx.x - fa.first;
+        if (bid >= fa.first) {
+            int p = bid - fa.first;
             const int T = fa.tspan;
             int bx, by;
             if (p < T) {
@@ -1375,11 +1397,11 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
             return;
         }
     }
-    if (ta.extra0 >= 0 && (int)blockIdx.x >= ta.extra0) {
+    if (ta.extra0 >= 0 && bid >= ta.extra0) {
         // roles that depend on the chain launch alone: the loss of the step, the entity-table rows (step_touch.h)
-        const int e = (int)blockIdx.x - ta.extra0;
+        const int e = bid - ta.extra0;
 #ifndef MPQE_EMU
-        if (ta.stamps && threadIdx.x == 0) ta.stamps[(long long)blockIdx.x * 8 + 0] = (long long)wall_clock64();
+        if (ta.stamps && threadIdx.x == 0) ta.stamps[(long long)bid * 8 + 0] = (long long)wall_clock64();
 #endif
         if (e == 0) {
             loss_block_chain(ra.lm, ra.bterms, ra.loss, smem, 4);
@@ -1393,8 +1415,8 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
 #ifndef MPQE_EMU
         if (ta.stamps && threadIdx.x == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            ta.stamps[(long long)blockIdx.x * 8 + 5] = (long long)wall_clock64();
-            ta.stamps[(long long)blockIdx.x * 8 + 6] = 1 + 6;            // kind 6: loss / entity-table rows
+            ta.stamps[(long long)bid * 8 + 5] = (long long)wall_clock64();
+            ta.stamps[(long long)bid * 8 + 6] = 1 + 6;            // kind 6: loss / entity-table rows
         }
 #endif
         return;
@@ -1413,8 +1435,8 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
     long long tick0 = 0;
     if (ta.stamps && threadIdx.x == 0) {
         tick0 = (long long)__builtin_amdgcn_s_memtime();        // shader-clock ticks: word 2 = ticks start -> end
-        ta.stamps[(long long)blockIdx.x * 8 + 0] = (long long)wall_clock64();
-        ta.stamps[(long long)blockIdx.x * 8 + 3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+        ta.stamps[(long long)bid * 8 + 0] = (long long)wall_clock64();
+        ta.stamps[(long long)bid * 8 + 3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
                                                    ((long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
     }
 #endif
@@ -1423,39 +1445,39 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
     // tiles stream ~40 MB through their XCDs' L2s and fabric ports
     int ub = -1, tb;
     if (ta.ca.ncl > 0) {       // the post-pass as closures: the launch's first workgroups, one per batch (step_closure.h)
-        if ((int)blockIdx.x < ta.clpad) {
-            if ((int)blockIdx.x < ta.ca.ncl) {
+        if (bid < ta.clpad) {
+            if (bid < ta.ca.ncl) {
 #ifndef MPQE_EMU
                 __builtin_amdgcn_s_setprio(3);      // a latency chain next to throughput work
 #endif
-                closure_block((int)blockIdx.x, ta.D, ta.ca, lp, ua, smem, gp, zeroed, ta.stamps ? ta.stamps + (long long)blockIdx.x * 8 : nullptr);
+                closure_block(bid, ta.D, ta.ca, lp, ua, smem, gp, zeroed, ta.stamps ? ta.stamps + (long long)bid * 8 : nullptr);
 #ifndef MPQE_EMU
                 if (ta.stamps && threadIdx.x == 0) {
-                    ta.stamps[(long long)blockIdx.x * 8 + 5] = (long long)wall_clock64();       // (word 1 stays 0: not a tile)
-                    ta.stamps[(long long)blockIdx.x * 8 + 6] = 1 + 5;                           // kind 5: a closure
+                    ta.stamps[(long long)bid * 8 + 5] = (long long)wall_clock64();       // (word 1 stays 0: not a tile)
+                    ta.stamps[(long long)bid * 8 + 6] = 1 + 5;                           // kind 5: a closure
                 }
 #endif
             }
             return;
         }
-        tb = (int)blockIdx.x - ta.clpad;
+        tb = bid - ta.clpad;
     } else if (ta.ux > 0) {
-        const int x = (int)blockIdx.x & 7, r = (int)blockIdx.x >> 3, tx = 8 - ta.ux;
+        const int x = bid & 7, r = bid >> 3, tx = 8 - ta.ux;
         if (x >= tx) {
             ub = r * ta.ux + (x - tx);
             if (ub >= ta.ublocks) return;
         }
         tb = r * tx + x;
     } else {
-        if ((int)blockIdx.x < ta.ublocks) ub = (int)blockIdx.x;
-        tb = (int)blockIdx.x - ta.ublocks;
+        if (bid < ta.ublocks) ub = bid;
+        tb = bid - ta.ublocks;
     }
     if (ub >= 0) {         // uniform node states, backward: vector ops on column sums
         uop_block(ub, sd->D, lp, ua, smem, &gp, zeroed);
 #ifndef MPQE_EMU
         if (ta.stamps && threadIdx.x == 0) {
-            ta.stamps[(long long)blockIdx.x * 8 + 5] = (long long)wall_clock64();       // (word 1 stays 0: not a tile)
-            ta.stamps[(long long)blockIdx.x * 8 + 6] = 1 + (long long)ua.ops[ub / ua.chunks].kind;
+            ta.stamps[(long long)bid * 8 + 5] = (long long)wall_clock64();       // (word 1 stays 0: not a tile)
+            ta.stamps[(long long)bid * 8 + 6] = 1 + (long long)ua.ops[ub / ua.chunks].kind;
         }
 #endif
         arrived();
@@ -1466,13 +1488,13 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepDev *__restric
         return;
     }
     grad_w_block<MODE, (FUSED ? 2 : 4)>(sd, ta.wsrc, ta.nwsrc, ta.wblock, H, GH, level_stride, ta.slabs, tb, ta.wblocks,
-                       smem, gp, zeroed != 0, ta.stamps ? ta.stamps + (long long)blockIdx.x * 8 : nullptr, ta.D, nullptr, ta.tile_n,
+                       smem, gp, zeroed != 0, ta.stamps ? ta.stamps + (long long)bid * 8 : nullptr, ta.D, nullptr, ta.tile_n,
                        ta.ux > 0 ? 8 - ta.ux : 8, FUSED);      // zeroed: this call zero-filled the gradients, a store suffices
     arrived();
 #ifndef MPQE_EMU
     if (ta.stamps && threadIdx.x == 0) {
-        ta.stamps[(long long)blockIdx.x * 8 + 1] = (long long)wall_clock64();
-        ta.stamps[(long long)blockIdx.x * 8 + 2] = (long long)__builtin_amdgcn_s_memtime() - tick0;
+        ta.stamps[(long long)bid * 8 + 1] = (long long)wall_clock64();
+        ta.stamps[(long long)bid * 8 + 2] = (long long)__builtin_amdgcn_s_memtime() - tick0;
     }
 #endif
 }
@@ -1529,7 +1551,7 @@ struct HostPlan {
     size_t o_closures;
     std::vector<Rank1> rank1;
     int nvec, ngran;
-    size_t o_uopf, o_uopb, o_rank1, o_epoch, o_gran, o_VT, o_DG;
+    size_t o_uopf, o_uopb, o_rank1, o_epoch, o_gran, o_VT, o_DG, o_runs;
     std::vector<char> image;      // the descriptor table as uploaded ([0, o_epoch) of the desc buffer)
     long long touch_M;
     // touch plan built inside the step (MPQE_STEP_BUILD_TOUCH; step_touch.h: tsort_block): sort workgroups, key widths,
@@ -3025,6 +3047,7 @@ int make_plan(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, c
     hp->o_VT = take((size_t)hp->nvec * D * 4);
     hp->touch_M = anchors + 2 * graphs;
     hp->o_DG = take(chain ? (size_t)hp->touch_M * D * 4 : 0);       // per-entry table-gradient rows (step_touch.h)
+    hp->o_runs = take(chain ? ((size_t)hp->touch_M + 64) * sizeof(int) : 0);      // the touch plan's run starts + their number
     // in-step sort: (key, entry) ping-pong buffers [4][blocks x 1024] + digit counts [4 passes][blocks][256]
     hp->o_tsort = take(hp->ts_blocks ? (size_t)hp->ts_blocks * (4 * (size_t)TSORT_THREADS * tsort_rounds(hp->touch_M) + 4 * 256) * sizeof(unsigned) : 0);
     hp->total = off;
@@ -3929,6 +3952,8 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     memset(&ta.ca, 0, sizeof(ta.ca));
     ta.clpad = 0;
     ta.extra0 = -1;
+    ta.runs_front = ta.runs_n = 0;
+    ta.runs_out = nullptr;
     ta.tm_blocks = 0;
     ta.node_map = nm;
     ta.map_len = (long long)P->node_map_len;
@@ -3999,6 +4024,19 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     // launch ran in order and the step took 4.4 us longer)
     ra.early = early_roles ? 1 : 0;
     if (early_roles) r_trows = 0;
+    // The table workgroups of the reduction launch take the plan's RUN STARTS, compacted by one workgroup of the weight-gradient
+    // launch (touch_runs_block), instead of every sorted position: a step's distinct rows are at most the tables' rows -- the
+    // launch is sized for that bound (AIFB step: 326 workgroups instead of 2 752). mpqe_debug_option NO_RUNS = 1: as before.
+    const bool use_runs = use_touch && !pic && !fuse_tail && !early_roles && !rows_multi && NL == 1 && D % 4 == 0 &&
+                          256 % (D / 4) == 0 && !(STEP_DBG & 1) && !dbg_on("NO_RUNS");
+    if (use_runs) {
+        long long total_rows = 0;
+        for (int m = 0; m < P->num_modes; ++m) total_rows += P->table_rows[m];
+        const long long rmax = std::min<long long>(hp.touch_M, total_rows), per = 256 / (D / 4);
+        r_trows = (unsigned)(((rmax + per - 1) / per + r_gx - 1) / r_gx);
+        ra.runs = reinterpret_cast<const int *>(wb + hp.o_runs);
+        pa.runs_count = reinterpret_cast<int *>(wb + hp.o_runs) + hp.touch_M;
+    }
     pa.tail_arrive = fuse_tail ? epoch_f + 41 : nullptr;
     bool reduced = false;
     auto launch_grad_w = [&](hipStream_t on, int first, int count) {
@@ -4035,6 +4073,12 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             tl.extra0 = (nblocks + 7) / 8 * 8;
             tl.tm_blocks = use_touch ? (int)((hp.touch_M + pos - 1) / pos) : 0;
             nblocks = tl.extra0 + 1 + tl.tm_blocks;
+        }
+        if (use_runs && first == 0 && count == hp.wblocks_total) {       // a few workgroups in front: the touch plan's run starts
+            tl.runs_n = (int)((hp.touch_M + TRUNS_PER - 1) / TRUNS_PER);
+            tl.runs_front = (tl.runs_n + 7) / 8 * 8;
+            tl.runs_out = reinterpret_cast<int *>(wb + hp.o_runs);
+            nblocks += tl.runs_front;
         }
         tl.stamps = g_tail_stamps && (size_t)nblocks <= g_tail_stamp_blocks ? g_tail_stamps : nullptr;
         if (nblocks <= 0) return;

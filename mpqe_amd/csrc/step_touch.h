@@ -437,14 +437,22 @@ __global__ __launch_bounds__(TSORT_THREADS) void touch_sort_kernel(TSortArgs sa)
 // known: a plan buffer must therefore hold valid entries at all times -- the caller zero-fills it once, before its first
 // use (entry 0 / key 0 are valid), and a build that gives up leaves what an earlier build or the fill left there. (Clamping
 // every permutation entry instead cost the reduction launch ~1 us.)
+// runs != NULL: the lane groups take the run STARTS listed there (touch_runs_block: runs[0 .. *nruns), any order) instead of
+// every sorted position -- a step's distinct rows are at most the tables' rows, four to five times fewer than its entries on
+// the AIFB step, and the launch is sized for that bound.
 template <class TabsT>
 __device__ __forceinline__ void table_sum_block(long long M, int row_bits, const tkey_t *__restrict__ keys,
                                                 const int *__restrict__ perm, const float *__restrict__ DG, int D,
                                                 const TabsT &tabs, int store, long long block,
-                                                const int *__restrict__ failed = nullptr) {
+                                                const int *__restrict__ failed = nullptr,
+                                                const int *__restrict__ runs = nullptr, const int *__restrict__ nruns = nullptr) {
     const int lpr = D / 4, per = 256 / lpr;          // positions per workgroup (D = 64 / 128 / 256: 16 / 8 / 4)
-    const long long k = block * per + threadIdx.x / lpr;
+    long long k = block * per + threadIdx.x / lpr;
     const int c = (threadIdx.x % lpr) * 4;
+    if (runs) {
+        if (k >= (long long)*nruns) return;
+        k = runs[k];
+    }
     if (k >= M) return;
     const int bad = failed ? *failed : 0;
     // ONE round trip for everything that depends on k alone: my key, my predecessor's, and the keys / permutation entries of
@@ -509,6 +517,46 @@ __device__ __forceinline__ void table_sum_block(long long M, int row_bits, const
     f32x4 *dst = reinterpret_cast<f32x4 *>(g + row * D + c);
     if (store) *dst = acc;
     else *dst = *dst + acc;
+}
+
+// The run starts of a plan's sorted keys, compacted (a few workgroups of 256 threads, TRUNS_PER positions each; roles of the
+// weight-gradient launch, which has the time: step.hip): runs[0 .. *count) = the sorted positions k whose key is valid and
+// differs from its predecessor's, in NO particular order (every run is summed on its own: the order of the list changes no
+// result) -- a thread's positions are requested together, a workgroup's starts are numbered through LDS and take their
+// place in the list with ONE atomic add on *count (zeroed by the chain launch). A plan that could not be built adds nothing.
+// lds: 2 ints.
+#define TRUNS_EACH 8
+#define TRUNS_PER (256 * TRUNS_EACH)
+__device__ __forceinline__ void touch_runs_block(long long M, const tkey_t *__restrict__ keys, int *__restrict__ runs,
+                                                 int *__restrict__ count, const int *__restrict__ failed, int *lds, int block) {
+    const int tid = threadIdx.x;
+    const int bad = failed ? *failed : 0;
+    const long long base = (long long)block * TRUNS_PER;
+    tkey_t key[TRUNS_EACH], prev[TRUNS_EACH];
+#pragma unroll
+    for (int q = 0; q < TRUNS_EACH; ++q) {              // (coalesced: position base + 256 q + tid)
+        const long long k = base + 256 * q + tid;
+        key[q] = k < M ? keys[k] : TOUCH_INVALID;
+        prev[q] = (k > 0 && k < M) ? keys[k - 1] : TOUCH_INVALID;
+    }
+    if (tid == 0) lds[0] = 0;
+    __syncthreads();
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < TRUNS_EACH; ++q) {
+        const long long k = base + 256 * q + tid;
+        c += (!bad && key[q] != TOUCH_INVALID && (k == 0 || prev[q] != key[q])) ? 1 : 0;
+    }
+    const int mine = c > 0 ? (int)atomicAdd(reinterpret_cast<unsigned *>(&lds[0]), (unsigned)c) : 0;
+    __syncthreads();
+    if (tid == 0) lds[1] = lds[0] > 0 ? (int)atomicAdd(reinterpret_cast<unsigned *>(count), (unsigned)lds[0]) : 0;
+    __syncthreads();
+    int at = lds[1] + mine;
+#pragma unroll
+    for (int q = 0; q < TRUNS_EACH; ++q) {
+        const long long k = base + 256 * q + tid;
+        if (!bad && key[q] != TOUCH_INVALID && (k == 0 || prev[q] != key[q])) runs[at++] = (int)k;
+    }
 }
 
 // The same sums by workgroups that take a RANGE of sorted positions each (roles of a launch whose register footprint allows

@@ -683,7 +683,8 @@ def test_fused_step_chain_kernels(be, D, readout, adaptive, shared, L):
         # measured slower, kept as a switch) -- the same additions in the same order, bit for bit
         # ... and the reduction's table workgroups taking a range of positions each (ROWS_MULTI; default: one run each)
         # ... and the post-pass alone riding in the chain launch (POST_IN_CHAIN: the tiles stay a launch of their own)
-        for opt in (b'EARLY_ROWS', b'ROWS_MULTI', b'POST_IN_CHAIN'):
+        # ... and the table workgroups taking every sorted position (NO_RUNS) instead of the compacted run starts (default)
+        for opt in (b'EARLY_ROWS', b'ROWS_MULTI', b'POST_IN_CHAIN', b'NO_RUNS'):
             be.lib.mpqe_debug_option(opt, 1, 1)
             try:
                 other = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_SPLIT_TAIL)
