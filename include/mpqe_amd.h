@@ -591,7 +591,8 @@ void mpqe_debug_tail_stamps(void *device_buffer, size_t num_blocks);
  * multi-launch sort (csrc/radix_sort.h) instead of the one-launch sort, "TSORT_FAIL" = the in-step sort gives up as if its workgroups were not
  * co-resident, "GEN_SLOTS" = grid size of the persistent gather-GEMMs, "PROLOGUE_LAST" = 1 / 0: the chain launch's prologue
  * items behind / in front of its chain workgroups whatever their number, "POST_IN_CHAIN" = the backward post-pass as roles of
- * the chain launch with the tiles a launch of their own, "DUMP_PLAN" = the step's plan and launch shape on stderr). set != 0
+ * the chain launch with the tiles a launch of their own, "NO_RUNS" = the reduction's table workgroups take every sorted
+ * position of the touch plan instead of its compacted run starts, "DUMP_PLAN" = the step's plan and launch shape on stderr). set != 0
  * stores `value` under `name`, set == 0 removes it. Process-global (see Conventions).                    */
 void mpqe_debug_option(const char *name, int value, int set);
 
