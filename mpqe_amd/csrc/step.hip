@@ -423,6 +423,7 @@ struct PostArgs {
 template <int LDS_TILES>
 __device__ __forceinline__ void post_block(const StepDev *__restrict__ sd, const LayerPtrs &lp, const PostArgs &po, int pb,
                                            float *smem);
+__device__ __forceinline__ void zmat_block(const ZMat *__restrict__ zmats, int zper, int zb, int D, const GradPtrs &gp);
 
 template <int NCB, int KS, int NW = 4, bool RO = false>
 __global__ __launch_bounds__(64 * NW) void step_chain_kernel(const StepDev *__restrict__ sd, LayerPtrs lp,
@@ -497,6 +498,11 @@ __global__ __launch_bounds__(64 * NW) void step_chain_kernel(const StepDev *__re
         }       // (else: padding)
     } else if (po.zpad == 0 || bid < po.zpad) {
         if ((long long)bid < pa.zs.block0[pa.zs.count]) prep_zero_block(pa.zs, bid);
+        // (split tail: the relation matrices nothing writes this step are zero-filled HERE, behind the chain workgroups -- the
+        // launch has idle CUs from the moment its light batches are through -- not by workgroups of the weight-gradient launch)
+        else if (po.zpad == 0 && po.zmblocks > 0 && (long long)bid < pa.zs.block0[pa.zs.count] + po.zmblocks) {
+            if (NW == 4 || threadIdx.x < 256) zmat_block(po.zmats, po.zper, bid - (int)pa.zs.block0[pa.zs.count], po.D, po.gp);
+        }
     } else {
         // (post roles only on the XCDs picked for them: workgroup b runs on XCD b % 8; the others leave at once)
         const int pb = bid - po.zpad;
@@ -4039,11 +4045,12 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     }
     pa.tail_arrive = fuse_tail ? epoch_f + 41 : nullptr;
     bool reduced = false;
+    bool zmats_done_in_chain = false;
     auto launch_grad_w = [&](hipStream_t on, int first, int count) {
         TailArgs tl = ta;
         tl.wblock = ta.wblock + first;
         tl.wblocks = count;
-        if (first == 0 && (P->flags & MPQE_STEP_ZERO_GRADS)) tl.zblocks = (int)hp.zmats.size() * ta.zper;
+        if (first == 0 && (P->flags & MPQE_STEP_ZERO_GRADS) && !zmats_done_in_chain) tl.zblocks = (int)hp.zmats.size() * ta.zper;
         if (first == 0 && !post_only) tl.ublocks = ub.nops * ub.chunks;
         int nblocks = tl.ublocks + count + tl.zblocks;
         const bool closures = use_chain && first == 0 && !hp.closures.empty() && !fuse_tail;
@@ -4186,6 +4193,19 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
             PostArgs po;
             memset(&po, 0, sizeof(po));
             long long grid_blocks = pa.lead + pa.nchain + zblocks;
+            // (split tail: the untouched relation matrices' zero fill rides behind the chain workgroups; mpqe_debug_option
+            // ZMATS_IN_TAIL = 1: by workgroups of the weight-gradient launch, as before)
+            const bool zm_here = !pic && backward && (P->flags & MPQE_STEP_ZERO_GRADS) && !hp.zmats.empty() && !dbg_on("ZMATS_IN_TAIL") &&
+                                 !phase_bwd && !phase_score;
+            if (zm_here) {
+                po.zmblocks = (int)hp.zmats.size() * ta.zper;
+                po.zmats = ta.zmats;
+                po.zper = ta.zper;
+                po.D = D;
+                po.gp = gp;
+                grid_blocks += po.zmblocks;
+                zmats_done_in_chain = true;
+            }
             if (pic) {
                 unsigned *done = reinterpret_cast<unsigned *>(db + hp.o_done);
                 po.zpad = (int)((zblocks + 7) / 8 * 8);
