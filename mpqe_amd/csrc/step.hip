@@ -1039,6 +1039,7 @@ struct ReduceArgs {
     const unsigned *arrive;
     unsigned phase1;
     int rows_multi;          // 1: the entity-table workgroups take a range of sorted positions each (table_sum_multi)
+    int nmat;                // >= 0: the launch's rows are packed (step_reduce_kernel): the first nmat groups are the matrix groups
     const int *runs;         // != NULL: the plan's run starts, compacted by a role of the weight-gradient launch
                              // (touch_runs_block): runs[0 .. runs[touch_M]) -- the table workgroups take those, not every position
     int early;               // 1: the loss and the entity-table rows were roles of the weight-gradient launch (TailArgs.extra0):
@@ -1269,7 +1270,23 @@ __global__ __launch_bounds__(256, REDUCE_WAVES) void step_reduce_kernel(ReduceAr
 __global__ __launch_bounds__(256) void step_reduce_kernel(ReduceArgs ra) {
 #endif
     __shared__ f32x4 part[4][64];
-    reduce_block(ra, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, part);
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+    if (ra.nmat >= 0) {
+        // packed rows: [0, nmat) the matrix groups (gx workgroups each); row nmat: every vector group's column slices side
+        // by side, then the loss; beyond: the entity-table rows -- a row of gx workgroups per VECTOR group left all but its
+        // first few without work (9 x 60 of them on the AIFB step, dispatched in front of the table workgroups)
+        if (by == ra.nmat) {
+            const int g = ra.nmat + bx / VEC_SLICES;
+            if (g < ra.ngroups) {
+                by = g;
+                bx = bx % VEC_SLICES;
+            } else if (bx == (ra.ngroups - ra.nmat) * VEC_SLICES) {
+                by = ra.ngroups;
+                bx = 0;
+            } else return;
+        } else if (by > ra.nmat) by += ra.ngroups - ra.nmat;
+    }
+    reduce_block(ra, bx, by, (int)gridDim.x, part);
 }
 struct TailArgs {
     const WSource *wsrc;
@@ -3980,6 +3997,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
     // weight-gradient launch
     ReduceArgs ra;
     memset(&ra, 0, sizeof(ra));
+    ra.nmat = -1;
     const long long r_elems = (long long)D * D;
     const unsigned r_gx = (unsigned)((r_elems + 255) / 256);
     unsigned r_trows = 0;         // entity-table gradient rows: 256 / (D / 4) sorted positions per workgroup
@@ -4425,7 +4443,14 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                                (const float *)H, (const float *)GH, hp.level_stride);
     }
     if (!reduced) {
-        dim3 grid(r_gx, (unsigned)hp.groups.size() + 1 + r_trows);
+        // (matrix groups first in the table, vector groups behind them: then the vector groups share ONE row of the launch)
+        int nmat = 0;
+        const int ng = (int)hp.groups.size();
+        while (nmat < ng && (hp.groups[nmat].kind <= 1 || hp.groups[nmat].kind >= 4)) ++nmat;
+        bool packed = ra.vec && D % 4 == 0 && 256 % (D / 4) == 0 && !dbg_on("REDUCE_ROWS") && (ng - nmat) * VEC_SLICES + 1 <= (int)r_gx;
+        for (int k = nmat; k < ng; ++k) packed = packed && (hp.groups[k].kind == 2 || hp.groups[k].kind == 3);
+        ra.nmat = packed ? nmat : -1;
+        dim3 grid(r_gx, (unsigned)(packed ? nmat + 1 : ng + 1) + r_trows);
         hipLaunchKernelGGL(step_reduce_kernel, grid, dim3(256), 0, s, ra);
     }
     if (learned) ro_regulariser(true);
