@@ -472,6 +472,30 @@ int mpqe_step_forward_backward(const mpqe_step_params_t *params_host, const mpqe
                                void *touch /* mpqe_step_touch_build's buffer (read), the plan buffer to fill (MPQE_STEP_BUILD_TOUCH), or
                                               NULL */, void *stream);
 
+/* The same call with per-call extras (extra = NULL: exactly mpqe_step_forward_backward). For the host mirror's drop-in
+ * entry points -- RGCNEncoderDecoder.margin_loss / .forward (reference model.py:400-494) routed through the fused step:
+ *   batch_weight[i]  a DEVICE scalar (or NULL = 1): batch i's loss weight is batches_host[i].weight * *batch_weight[i],
+ *                    read when the step runs. `loss = l_0 + w_1 * l_1 + ...; loss.backward()` (reference
+ *                    train_helpers.py:81-119) hands every margin_loss node its upstream gradient as a 0-dim device tensor:
+ *                    the backward of ALL nodes is then ONE step whose weights are those tensors, with no device-to-host read.
+ *                    The weights scale the gradients (and the readout regulariser's, model.py:486-490); loss[0] is formed
+ *                    with the host weights alone. A launch of one workgroup writes them into the resident descriptor table
+ *                    in front of the step's launches (a later call without extras writes the host weights back).
+ *   query_out        [sum_b B_b, dim] or NULL: the query embeddings (the readout's output rows, model.py:447-449) in batch
+ *                    order -- what the evaluation form scores against ragged negative lists (model.py:454-460,
+ *                    mpqe_cosine_fwd with q_row). Chain form only (MPQE_ERR_UNSUPPORTED otherwise).                    */
+typedef struct {
+    const float *batch_weight[MPQE_STEP_MAX_BATCHES];
+    float *query_out;
+} mpqe_step_extra_t;
+int mpqe_step_forward_backward_ex(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,
+                                  int num_batches, const int64_t *anchor_ids, const int64_t *targets,
+                                  const int64_t *negs, float margin, const mpqe_step_grads_t *grads_host,
+                                  int backward, float *loss, float *scores_pos, float *scores_neg, void *desc,
+                                  size_t desc_bytes, int upload_desc, void *workspace, size_t workspace_bytes,
+                                  int32_t *err, const mpqe_step_lanes_t *lanes, void *const *events, int num_events,
+                                  void *touch, void *stream, const mpqe_step_extra_t *extra_host);
+
 /* The entity-table part of a step's reduction again, from a plan built AFTER the step ran: sums the per-entry gradient
  * rows the step left in `workspace` (its chain launch writes them whatever happens to the plan) per destination row in
  * plan order into grads->tables -- written where the step would have written them (MPQE_STEP_ZERO_GRADS or
@@ -564,6 +588,22 @@ int mpqe_spans_copy(float *dst, const float *src, const void *spans_device, int 
 int mpqe_rows_prepare(const uint64_t *sorted_keys, int64_t M, int64_t cap, int row_bits, const int64_t *table_rows /* host */,
                       const int64_t *row_base /* host */, int num_tables, uint64_t *send_keys, int64_t *gidx, void *stream);
 int mpqe_rows_gather(const float *rows, const int64_t *gidx, int64_t n, int64_t dim, float *out, void *stream);
+
+/* ---- negative sampling with python's own stream (reference model.py:466-476) -- HOST function, no device work ----------
+ * margin_loss draws one negative per query with random.choice(list): CPython's Random.choice is
+ * list[_randbelow(len)], _randbelow(n): k = n.bit_length(); r = getrandbits(k); while r >= n: r = getrandbits(k), and
+ * getrandbits(k <= 32) is ONE 32-bit Mersenne-Twister output shifted right by 32 - k. The drop-in keeps that stream: the
+ * host mirror takes raw outputs from the interpreter's generator (random.getrandbits(32 * n) = n consecutive outputs, the
+ * first in the low bits) and this routine replays the rejection loop over them for queries cursor[0] .. nq - 1 in order:
+ *   words [nwords] raw outputs; lens_host [nq] list length per query (or NULL: every list has `len_all` entries);
+ *   base_host [nq] (or NULL = 0): offset of query i's list in `cand_host`; out_host[i] = cand_host[base + r] (cand_host
+ *   NULL: out_host[i] = r, the drawn position).
+ * cursor_host[0] (in/out) = next query to serve, cursor_host[1] (out) = words consumed by this call (all of them unless the
+ * last query was served first). Returns MPQE_OK, or MPQE_ERR_INVALID_ARG for an empty list (random.choice raises
+ * IndexError) or one of 2^32 or more entries. Every pointer is a HOST pointer.                                        */
+int mpqe_host_random_choice(const uint32_t *words_host, int64_t nwords, const int64_t *lens_host, int64_t len_all,
+                            const int64_t *base_host, const int64_t *cand_host, int64_t nq, int64_t *cursor_host,
+                            int64_t *out_host);
 
 /* ---- negative sampling on the device -------------------------------------------
  * reference model.py:466-476: one negative per query, random.choice over query.neg_samples /

@@ -55,6 +55,11 @@ class StepGrads(ctypes.Structure):
 STEP_MAX_LANES = 4
 
 
+class StepExtra(ctypes.Structure):
+    # include/mpqe_amd.h: mpqe_step_extra_t
+    _fields_ = [('batch_weight', c_void_p * STEP_MAX_BATCHES), ('query_out', c_void_p)]
+
+
 class StepLanes(ctypes.Structure):
     _fields_ = [('num_lanes', ctypes.c_int32), ('batch_begin', ctypes.c_int32 * (STEP_MAX_LANES + 1)),
                 ('aux_stream', c_void_p * STEP_MAX_LANES), ('fork_event', c_void_p),
@@ -115,6 +120,10 @@ PROTOTYPES = {
     'mpqe_step_forward_backward': (I, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, P, P, P, F,
                                        ctypes.POINTER(StepGrads), I, P, P, P, P, Z, I, P, Z, P, ctypes.POINTER(StepLanes),
                                        P, I, P, P]),
+    'mpqe_step_forward_backward_ex': (I, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, P, P, P, F,
+                                          ctypes.POINTER(StepGrads), I, P, P, P, P, Z, I, P, Z, P, ctypes.POINTER(StepLanes),
+                                          P, I, P, P, ctypes.POINTER(StepExtra)]),
+    'mpqe_host_random_choice': (I, [P, L, P, L, P, P, L, P, P]),
     'mpqe_step_touch_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I]),
     'mpqe_step_touch_workspace_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I]),
     'mpqe_step_touch_entries': (L, [ctypes.POINTER(StepBatch), I]),

@@ -43,3 +43,35 @@ extern "C" int mpqe_copy_to_device(void *dst, const void *src_host, size_t bytes
     if (!dst || !src_host) return MPQE_ERR_INVALID_ARG;
     return hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, as_stream(stream)) == hipSuccess ? MPQE_OK : MPQE_ERR_LAUNCH;
 }
+
+// random.choice's draws replayed over raw Mersenne-Twister outputs (include/mpqe_amd.h: mpqe_host_random_choice; reference
+// model.py:470-476). CPython: choice(seq) = seq[_randbelow(len(seq))]; _randbelow(n): k = n.bit_length();
+// r = getrandbits(k) until r < n; getrandbits(k <= 32) = one 32-bit output >> (32 - k). Host only.
+extern "C" int mpqe_host_random_choice(const uint32_t *words, int64_t nwords, const int64_t *lens, int64_t len_all,
+                                       const int64_t *base, const int64_t *cand, int64_t nq, int64_t *cursor, int64_t *out) {
+    if (!words || nwords < 0 || nq < 0 || !cursor || !out || cursor[0] < 0) return MPQE_ERR_INVALID_ARG;
+    int64_t q = cursor[0], w = 0;
+    int64_t n = 0;
+    int shift = 0;
+    bool fresh = true;
+    while (q < nq && w < nwords) {
+        if (fresh) {
+            n = lens ? lens[q] : len_all;
+            if (n <= 0 || n > 0xffffffffLL) {
+                cursor[1] = w;
+                return MPQE_ERR_INVALID_ARG;
+            }
+            shift = 32 - (64 - __builtin_clzll((unsigned long long)n));     // 32 - n.bit_length()
+            fresh = false;
+        }
+        const int64_t r = (int64_t)(words[w++] >> shift);
+        if (r < n) {
+            out[q] = cand ? cand[(base ? base[q] : 0) + r] : r;
+            ++q;
+            fresh = true;
+        }
+    }
+    cursor[0] = q;
+    cursor[1] = w;
+    return MPQE_OK;
+}

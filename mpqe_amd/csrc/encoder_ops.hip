@@ -676,4 +676,4 @@ extern "C" const char *mpqe_status_string(int status) {
         default: return "unknown status";
     }
 }
-extern "C" int mpqe_abi_version(void) { return 5; }
+extern "C" int mpqe_abi_version(void) { return 6; }

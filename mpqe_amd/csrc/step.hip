@@ -1132,7 +1132,9 @@ __device__ __forceinline__ void reduce_block(const ReduceArgs &ra, int bx, int b
         // in flight, then the row groups' sums are added in order (fixed order: reproducible)
         // (VEC_SLICES > 1: workgroup bx takes the columns [bx D / VEC_SLICES, ...) of every row -- 128 bytes of a row at
         // D = 128: more rows in flight per workgroup, VEC_SLICES workgroups per group; a fixed order all the same)
-        const int NS = (D % (4 * VEC_SLICES) == 0 && 256 % (D / 4 / VEC_SLICES) == 0) ? VEC_SLICES : 1;
+        // (a row of the unpacked grid has gx = ceil(D D / 256) workgroups: D = 16 has ONE -- no slices there, or the columns
+        // beyond the first slice were never summed)
+        const int NS = (D % (4 * VEC_SLICES) == 0 && 256 % (D / 4 / VEC_SLICES) == 0 && (ra.nmat >= 0 || gx >= VEC_SLICES)) ? VEC_SLICES : 1;
         if (bx >= NS) return;
         wait_phase1();
         const int LQ = D / 4 / NS, RG = 256 / LQ;
@@ -3121,6 +3123,9 @@ struct PlanKey {
 struct CachedPlan {
     PlanKey key;
     HostPlan hp;
+    // the batch weights in the resident descriptor table are not the plan's (a call with mpqe_step_extra_t.batch_weight wrote
+    // host x device products there): the next call without extras writes the host weights back first
+    mutable bool weights_patched = false;
 };
 std::mutex g_plan_mu;
 std::unordered_map<void *, std::shared_ptr<CachedPlan>> g_plans;
@@ -3588,6 +3593,18 @@ extern "C" int mpqe_l2_norms(const float *const *params, const int64_t *sizes, i
 
 static int D_ok_for_readout(int D) { return D % 4 == 0; }      // (16-byte rows in step_readout.h)
 
+// batch weights of a call with extras: sd->b[i].weight = host weight x *device scalar (one workgroup, in front of the step's
+// launches on its stream; wdev[i] NULL: the host weight alone -- which is also how a later call without extras restores them)
+struct WeightPatch {
+    const float *wdev[MPQE_STEP_MAX_BATCHES];
+    float whost[MPQE_STEP_MAX_BATCHES];
+    int nb;
+};
+__global__ __launch_bounds__(64) void step_weights_kernel(StepDev *sd, WeightPatch wp) {
+    const int i = threadIdx.x;
+    if (i < wp.nb) sd->b[i].weight = wp.wdev[i] ? wp.whost[i] * *wp.wdev[i] : wp.whost[i];
+}
+
 extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb,
                                           const int64_t *anchor_ids, const int64_t *targets, const int64_t *negs,
                                           float margin, const mpqe_step_grads_t *G, int backward,
@@ -3595,6 +3612,19 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                                           size_t desc_bytes, int upload_desc, void *workspace,
                                           size_t workspace_bytes, int32_t *err, const mpqe_step_lanes_t *lanes,
                                           void *const *events, int num_events, void *touch, void *stream) {
+    return mpqe_step_forward_backward_ex(P, B, nb, anchor_ids, targets, negs, margin, G, backward, loss, scores_pos, scores_neg,
+                                         desc, desc_bytes, upload_desc, workspace, workspace_bytes, err, lanes, events, num_events,
+                                         touch, stream, nullptr);
+}
+
+extern "C" int mpqe_step_forward_backward_ex(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb,
+                                             const int64_t *anchor_ids, const int64_t *targets, const int64_t *negs,
+                                             float margin, const mpqe_step_grads_t *G, int backward,
+                                             float *loss, float *scores_pos, float *scores_neg, void *desc,
+                                             size_t desc_bytes, int upload_desc, void *workspace,
+                                             size_t workspace_bytes, int32_t *err, const mpqe_step_lanes_t *lanes,
+                                             void *const *events, int num_events, void *touch, void *stream,
+                                             const mpqe_step_extra_t *extra) {
     if (!P || !B || nb < 1 || nb > MPQE_STEP_MAX_BATCHES || !desc) return MPQE_ERR_INVALID_ARG;
     const bool ask_chain = want_chain(P, B, nb);
     // The launch plan is a pure function of the descriptors; it is kept on the host next to the device
@@ -3747,6 +3777,20 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         (void)hipMemcpyAsync(db, hp.image.data(), hp.image.size(), hipMemcpyHostToDevice, s);
         (void)hipMemsetAsync(db + hp.o_epoch, 0, hp.desc_total - hp.o_epoch, s);
     }
+    bool dev_weights = false;
+    for (int i = 0; extra && i < nb; ++i) dev_weights = dev_weights || extra->batch_weight[i] != nullptr;
+    if (extra && extra->query_out && !use_chain) return MPQE_ERR_UNSUPPORTED;       // (the chain workgroups' score phase writes it)
+    if (dev_weights || (cached->weights_patched && !upload_desc)) {
+        WeightPatch wp;
+        memset(&wp, 0, sizeof(wp));
+        wp.nb = nb;
+        for (int i = 0; i < nb; ++i) {
+            wp.whost[i] = hp.sd.b[i].weight;
+            wp.wdev[i] = dev_weights ? extra->batch_weight[i] : nullptr;
+        }
+        hipLaunchKernelGGL(step_weights_kernel, dim3(1), dim3(64), 0, s, const_cast<StepDev *>(sd), wp);
+    }
+    cached->weights_patched = dev_weights;
     unsigned *epoch_f = reinterpret_cast<unsigned *>(db + hp.o_epoch), *epoch_b = epoch_f + 16;
     float *VT = reinterpret_cast<float *>(wb + hp.o_VT);
     UArgs ua;
@@ -4156,6 +4200,14 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         if (with_grads) { rr.g[0] = G->readout_w0; rr.g[1] = G->readout_b0; rr.g[2] = G->readout_w2; rr.g[3] = G->readout_b2; }
         rr.coef = P->readout_weight_decay * wsum;
         rr.loss = loss;
+        if (dev_weights && with_grads) {        // (the gradients' coefficient: weight_decay x sum_i host_i x *device_i, formed on the device)
+            rr.nw = nb;
+            rr.wd = P->readout_weight_decay;
+            for (int i = 0; i < nb; ++i) {
+                rr.whost[i] = hp.sd.b[i].weight;
+                rr.wdev[i] = extra->batch_weight[i];
+            }
+        }
         hipLaunchKernelGGL(step_ro_reg_kernel, dim3(1), dim3(1024), 0, s, rr);
     };
     if (use_chain) {
@@ -4190,6 +4242,7 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
         ca.s_pos = spos;
         ca.s_neg = sneg;
         ca.terms = terms;
+        ca.q_out = extra ? extra->query_out : nullptr;
         ca.err = err;
         ca.backward = backward ? 1 : 0;
         ca.stamps = g_chain_stamps && 2 * hp.crefs.size() + (size_t)hp.ts_blocks <= g_chain_stamp_blocks ? g_chain_stamps : nullptr;

@@ -788,6 +788,7 @@ struct ChainArgs {
     long long level_stride;
     float margin, eps;
     float *s_pos, *s_neg, *terms;
+    float *q_out;           // != NULL: the query embeddings [graphs of the step, D] (mpqe_step_extra_t.query_out)
     int32_t *err;
     int backward;
     long long *stamps;      // diagnostics (mpqe_debug_chain_stamps): 8 words per workgroup, or NULL
@@ -1174,6 +1175,11 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
             for (int n = 1; n < 4; ++n) tm = n == A ? hn[n] : tm;
             q[cc] = readout == MPQE_READOUT_TM ? tm : (readout == MPQE_READOUT_SUM ? sum : best);
             arg[cc] = am;
+        }
+        if (ca.q_out && on) {         // (uniform per launch: the evaluation form's ragged scoring reads these rows)
+            float *qo = ca.q_out + (gi0 + i) * D;
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc) qo[sl + 16 * cc] = q[cc];
         }
         float ssp = 0.f, ssn = 0.f;
 #pragma unroll

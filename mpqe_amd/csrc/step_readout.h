@@ -93,11 +93,23 @@ struct RoRegArgs {
     float coef;
     float *loss;
     const float *gscale;     // != NULL: the gradients are scaled by *gscale too (an upstream gradient on the device)
+    // nw > 0: the GRADIENTS' coefficient is wd * sum_i whost[i] * *wdev[i] (wdev[i] NULL: 1) instead of coef -- per-batch upstream
+    // gradients on the device (mpqe_step_extra_t.batch_weight); the loss term keeps coef
+    int nw;
+    float wd;
+    float whost[MPQE_STEP_MAX_BATCHES];
+    const float *wdev[MPQE_STEP_MAX_BATCHES];
 };
 __global__ __launch_bounds__(1024) void step_ro_reg_kernel(RoRegArgs a) {
     __shared__ float part[16];
     __shared__ float total;
     float sum_norms = 0.f;
+    float gcoef = a.coef;
+    if (a.nw > 0) {                 // (every thread forms the same sum in the same order)
+        float ws = 0.f;
+        for (int i = 0; i < a.nw; ++i) ws += a.wdev[i] ? a.whost[i] * *a.wdev[i] : a.whost[i];
+        gcoef = a.wd * ws;
+    }
     for (int i = 0; i < 4; ++i) {
         if (!a.p[i]) continue;          // (uniform: fewer than four parameters)
         float s = 0.f;
@@ -114,7 +126,7 @@ __global__ __launch_bounds__(1024) void step_ro_reg_kernel(RoRegArgs a) {
         const float nrm = total;
         sum_norms += nrm;
         if (a.g[i] && nrm > 0.f) {
-            const float sc = (a.gscale ? a.coef * *a.gscale : a.coef) / nrm;
+            const float sc = (a.gscale ? gcoef * *a.gscale : gcoef) / nrm;
             for (long long k = threadIdx.x; k < a.n[i]; k += 1024) a.g[i][k] += sc * a.p[i][k];
         }
         __syncthreads();

@@ -94,6 +94,7 @@ class QueryGraphBatch(object):
     def __init__(self, template):
         self.template = template
         self.num_nodes = template.B * template.N
+        self.ids = None            # BatchIds of a collated batch (RGCNQueryDataset.collate_fn)
         self.x = None
         self.device = None
         self._tensors = None
@@ -121,6 +122,44 @@ class QueryGraphBatch(object):
     batch = property(lambda self: self._get(2))
 
 
+class FormulaIds(object):
+    """Every id the queries of ONE formula carry, as arrays built once (the reference re-reads the Query objects with
+    python list comprehensions per batch: data_utils.py:382-383, model.py:470-477): targets [Nq], anchors [Nq, A], and the
+    candidate lists of the negative draws as CSR (flat ids + offsets). A batch is a window [start, end) of them."""
+
+    def __init__(self, queries):
+        n = len(queries)
+        A = len(queries[0].anchor_nodes) if n else 0
+        self.n, self.A = n, A
+        self.targets = np.fromiter((q.target_node for q in queries), dtype=np.int64, count=n)
+        self.anchors = np.empty((n, A), dtype=np.int64)
+        for i in range(A):
+            self.anchors[:, i] = [q.anchor_nodes[i] for q in queries]
+        self.anchors_sm = np.ascontiguousarray(self.anchors.T)          # slot-major [A, Nq]: the fused step's id layout
+        self.neg = self._csr([q.neg_samples for q in queries])
+        self.hard = self._csr([getattr(q, 'hard_neg_samples', None) for q in queries])
+
+    @staticmethod
+    def _csr(lists):
+        """(flat ids, offsets [n + 1], lengths [n]); None when any query has no list (the python path then raises what the
+        reference raises)."""
+        if any(l is None for l in lists):
+            return None
+        lens = np.fromiter((len(l) for l in lists), dtype=np.int64, count=len(lists))
+        off = np.zeros(len(lists) + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        flat = np.fromiter((v for l in lists for v in l), dtype=np.int64, count=int(off[-1]))
+        return flat, off, lens
+
+
+class BatchIds(object):
+    """The window of a FormulaIds one collated batch covers; rides on the batch's query-graph object (`q_graphs.ids`)."""
+    __slots__ = ('fi', 'start', 'end', 'anchor_ref')
+
+    def __init__(self, fi, start, end, anchor_ref=None):
+        self.fi, self.start, self.end, self.anchor_ref = fi, start, end, anchor_ref
+
+
 class QueryDataset(Dataset):
     """reference: data_utils.py:268-311. One formula per batch, drawn with probability
     proportional to its number of queries; the index window wraps around the formula's list."""
@@ -137,7 +176,7 @@ class QueryDataset(Dataset):
     def __getitem__(self, index):
         return index
 
-    def collate_fn(self, idx_list):
+    def _window(self, idx_list):
         counts = np.array(list(self.num_formula_queries.values()))
         pick = np.argmax(np.random.multinomial(1, counts / float(self.num_queries)))
         formula = list(self.num_formula_queries.keys())[pick]
@@ -147,6 +186,10 @@ class QueryDataset(Dataset):
         end = min((hi + 1) % n, n)
         if end <= start:
             end = n
+        return formula, start, end
+
+    def collate_fn(self, idx_list):
+        formula, start, end = self._window(idx_list)
         return formula, self.queries[formula][start:end]
 
 
@@ -161,11 +204,43 @@ class RGCNQueryDataset(QueryDataset):
         self.mode_ids = enc_dec.mode_ids
         self.rel_ids = enc_dec.rel_ids
 
+        self._formula_ids = {}
+
+    def formula_ids(self, formula):
+        fi = self._formula_ids.get(formula)
+        if fi is None:
+            fi = self._formula_ids[formula] = FormulaIds(self.queries[formula])
+        return fi
+
     def collate_fn(self, idx_list):
-        formula, queries = super(RGCNQueryDataset, self).collate_fn(idx_list)
-        anchor_ids, var_ids, graph = RGCNQueryDataset.get_query_graph(formula, queries, self.rel_ids,
-                                                                      self.mode_ids)
-        return formula, queries, anchor_ids, var_ids, graph
+        """reference: data_utils.py:369-375. Same draws (one np.random.multinomial per batch), same window, same return
+        values; the ids of the window come from the formula's arrays (FormulaIds, built on the formula's first batch)
+        instead of per-query python loops, and ride along on the graph object so that margin_loss need not walk the
+        Query objects again (mpqe_amd/dropin.py)."""
+        formula, start, end = self._window(idx_list)
+        queries = self.queries[formula][start:end]
+        fi = self.formula_ids(formula)
+        info = ops.template_info(formula.query_type)
+        if fi.A != info.num_anchors or info.num_anchors != len(formula.anchor_modes):
+            raise ValueError('formula %s has %d anchor modes, template expects %d'
+                             % (formula, len(formula.anchor_modes), info.num_anchors))
+        var_ids, edge_type = self._formula_consts(formula, info)
+        graph = QueryGraphBatch(ops.Template(formula.query_type, end - start, edge_type))
+        anchor_ids = torch.from_numpy(fi.anchors[start:end])
+        graph.ids = BatchIds(fi, start, end, anchor_ids)
+        return formula, queries, anchor_ids, torch.from_numpy(var_ids.copy()), graph
+
+    def _formula_consts(self, formula, info):
+        c = getattr(self, '_consts', None)
+        if c is None:
+            c = self._consts = {}
+        v = c.get(formula)
+        if v is None:
+            nodes, rels = formula.get_nodes(), formula.get_rels()
+            var_ids = np.array([self.mode_ids[nodes[info.var_node[k]]] for k in range(info.num_vars)], dtype=np.int64)
+            edge_type = [self.rel_ids[reverse_relation(rels[info.rel_label[e]])] for e in range(info.num_edges)]
+            v = c[formula] = (var_ids, edge_type)
+        return v
 
     @staticmethod
     def get_query_graph(formula, queries, rel_ids, mode_ids):

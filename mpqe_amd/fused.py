@@ -397,8 +397,10 @@ class FusedTrainStep(object):
         # step's first run takes that plan over)
         # where the touch plan is built: inside the step (nothing id-dependent left for pack), or here
         mode = self.touch_mode
+        external = isinstance(ids, str)
         if mode == 'step' and (not chain or na + 2 * ngr > _capi.TSORT_MAX_ENTRIES):
-            mode = 'pack'
+            # (the level form has no use for a plan: a step whose ids are named per run carries none)
+            mode = None if (external and not chain) else 'pack'
         if mode == 'step' and self._pack_touch_sets and (bytes(SB), tuple(lane_begin)) in self._pack_touch_sets:
             mode = 'pack'
         ps.touch_mode = mode
@@ -448,7 +450,13 @@ class FusedTrainStep(object):
         ps.touch, ps.touch_ptr = None, None
         ps.captured = False
         n_ids = na + 2 * ngr
-        if ids is not None and torch.is_tensor(ids) and ids.is_cuda:
+        if isinstance(ids, str):
+            if ids != 'external':
+                raise ValueError("ids: an id array, or 'external' (the ids' addresses are handed to run(id_ptrs=...))")
+            # descriptors and buffers only: every run names the three id arrays itself (mpqe_amd/dropin.py: the calls of one
+            # training step append their ids to pinned arenas the kernels read in place)
+            ps.ids_ref = dev = None
+        elif ids is not None and torch.is_tensor(ids) and ids.is_cuda:
             if not (ids.dtype == torch.long and ids.is_contiguous() and ids.numel() == n_ids and ids.device == self.device):
                 raise ValueError('ids: a contiguous int64 tensor of %d ids (flatten_ids layout)' % n_ids)
             ps.ids_ref = dev = ids
@@ -495,20 +503,25 @@ class FusedTrainStep(object):
                 ps.ids_ref = bufs.ids
                 if prof is not None:
                     t1 = time.perf_counter(); prof['copy to device'] = prof.get('copy to device', 0.0) + t1 - t0; t0 = t1
-        ps.anchor_ids, ps.targets, ps.negs = dev[:na], dev[na:na + ngr], dev[na + ngr:]
-        if self.touch:
+        if dev is None:
+            ps.anchor_ids = ps.targets = ps.negs = None
+        else:
+            ps.anchor_ids, ps.targets, ps.negs = dev[:na], dev[na:na + ngr], dev[na + ngr:]
+        if self.touch and mode is not None:
             if bufs.touch is None:
                 # (zero-filled once: the step reads plan entries before it knows whether its own build finished, include/mpqe_amd.h)
                 bufs.touch = torch.zeros(sz[2] + 256, dtype=torch.uint8, device=self.device)
                 bufs.touch_ptr = (bufs.touch.data_ptr() + 255) // 256 * 256
             ps.touch, ps.touch_ptr = bufs.touch, bufs.touch_ptr
             if mode == 'pack':
+                if dev is None:
+                    raise ValueError("ids='external' needs the in-step touch plan (touch='step')")
                 self.build_touch(ps)
             if prof is not None:
                 t1 = time.perf_counter(); prof['touch plan'] = prof.get('touch plan', 0.0) + t1 - t0
         return ps
 
-    def build_touch(self, ps, library_sort=False):
+    def build_touch(self, ps, library_sort=False, id_ptrs=None):
         """The touch plan of the packed step's ids (include/mpqe_amd.h: mpqe_step_touch_build): which looked-up
         entities share a table row, sorted once here, so that the step adds their gradient rows in a fixed order
         instead of with float atomics. Stream-ordered on the current stream, no synchronisation. Call it again
@@ -532,15 +545,11 @@ class FusedTrainStep(object):
         if getattr(self, '_touch_ws_stream', None) not in (None, stream.cuda_stream):
             stream.wait_stream(self._touch_ws_stream_obj)      # (a caller that switched streams: order the re-use)
         self._touch_ws_stream, self._touch_ws_stream_obj = stream.cuda_stream, stream
-        if torch.cuda.current_device() != self.device.index:
-            with torch.cuda.device(self.device):
-                st = L.mpqe_step_touch_build(ctypes.byref(self.P), ps.batches, ps.nb, ps.anchor_ids.data_ptr(),
-                                             ps.targets.data_ptr(), ps.negs.data_ptr(), ps.touch_ptr, nbytes,
-                                             (ws.data_ptr() + 255) // 256 * 256, wbytes, stream.cuda_stream)
-        else:
-            st = L.mpqe_step_touch_build(ctypes.byref(self.P), ps.batches, ps.nb, ps.anchor_ids.data_ptr(),
-                                         ps.targets.data_ptr(), ps.negs.data_ptr(), ps.touch_ptr, nbytes,
-                                         (ws.data_ptr() + 255) // 256 * 256, wbytes, stream.cuda_stream)
+        if id_ptrs is None:
+            id_ptrs = (ps.anchor_ids.data_ptr(), ps.targets.data_ptr(), ps.negs.data_ptr())
+        with torch.cuda.device(self.device):
+            st = L.mpqe_step_touch_build(ctypes.byref(self.P), ps.batches, ps.nb, id_ptrs[0], id_ptrs[1], id_ptrs[2],
+                                         ps.touch_ptr, nbytes, (ws.data_ptr() + 255) // 256 * 256, wbytes, stream.cuda_stream)
         _capi.check(L, st, 'mpqe_step_touch_build')
 
     def _staging(self, n):
@@ -556,6 +565,10 @@ class FusedTrainStep(object):
         if self._stage_ring[k] is None or self._stage_ring[k].numel() < n:
             self._stage_ring[k] = torch.empty(max(n, 1 << 15), dtype=torch.long, pin_memory=True)
         return self._stage_ring[k][:n]
+
+    def uses_chain_dims(self):
+        """True when steps of this model run the chain kernels (whatever the batches: at most 5 passes assumed)."""
+        return not (self.flags & _capi.STEP_NO_CHAIN) and self.model.emb_dim in (64, 128, 256)
 
     def uses_chain(self, packed):
         """True when the library runs the graph-block chain kernels for this step (csrc/step.hip)."""
@@ -576,7 +589,8 @@ class FusedTrainStep(object):
             self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
         return (self._ws.data_ptr() + 255) // 256 * 256
 
-    def run(self, packed, backward=True, zero_grad=True, scores=False, events=None, workspace=None, checked=False):
+    def run(self, packed, backward=True, zero_grad=True, scores=False, events=None, workspace=None, checked=False,
+            id_ptrs=None, extra=None, out=None):
         """Returns loss [1 + nb] on the device: loss[0] = weighted step loss, loss[1 + i] = mean hinge
         of library batch i = the caller's batch packed.order[i] (identity with one lane); scores come
         back in the same library order. With backward=True every p.grad then holds d loss[0] / d p
@@ -590,18 +604,32 @@ class FusedTrainStep(object):
         mode) is RECOVERED here: the plan is rebuilt with the library sort, the entity-table rows are summed again
         from the per-entry rows the step left in its workspace (mpqe_step_table_rows), and this descriptor set takes
         pack-time plans from then on; a bad id raises IndexError, a timed-out hand-off RuntimeError, as check() does
-        -- but now, not a step later."""
+        -- but now, not a step later.
+        id_ptrs: (anchor ids, targets, negatives) as three addresses the DEVICE can read (a step packed with ids='external').
+        extra: a _capi.StepExtra (include/mpqe_amd.h: mpqe_step_extra_t -- per-batch loss weights as device scalars, the query
+        embeddings out). out: (loss [1 + nb], scores_pos, scores_neg) tensors to write instead of new ones (scores: None = not
+        wanted)."""
         if backward:
             self.bind_grads()
         # the library zero-fills the gradient buffers itself (one launch with its other prologue work)
         self.P.flags = self.flags | packed.step_flags | (_capi.STEP_ZERO_GRADS if (backward and zero_grad) else 0)
         bufs = packed.bufs
         stream = torch.cuda.current_stream(self.device)
-        loss = torch.empty(1 + packed.nb, dtype=torch.float32, device=self.device)
         sp = sn = None
-        if scores:
-            sp = torch.empty(packed.num_graphs, dtype=torch.float32, device=self.device)
-            sn = torch.empty_like(sp)
+        if out is not None:
+            loss, sp, sn = out
+            scores = sp is not None
+        else:
+            loss = torch.empty(1 + packed.nb, dtype=torch.float32, device=self.device)
+            if scores:
+                sp = torch.empty(packed.num_graphs, dtype=torch.float32, device=self.device)
+                sn = torch.empty_like(sp)
+        if id_ptrs is None:
+            if packed.anchor_ids is None:
+                raise ValueError("a step packed with ids='external' runs with id_ptrs=(anchors, targets, negatives)")
+            id_ptrs = (packed.anchor_ids.data_ptr(), packed.targets.data_ptr(), packed.negs.data_ptr())
+        elif packed.touch_mode == 'pack':
+            raise ValueError('id_ptrs: steps with the in-step touch plan only')
         if workspace is None:
             wptr = self._workspace(packed.ws_bytes)
         else:
@@ -609,18 +637,21 @@ class FusedTrainStep(object):
                 raise ValueError('workspace too small for this packed step')
             wptr = (workspace.data_ptr() + 255) // 256 * 256
         L = ops.lib()
-        args = (ctypes.byref(self.P), packed.batches, packed.nb, packed.anchor_ids.data_ptr(),
-                packed.targets.data_ptr(), packed.negs.data_ptr(), self.margin, ctypes.byref(self.G),
+        args = (ctypes.byref(self.P), packed.batches, packed.nb, id_ptrs[0], id_ptrs[1], id_ptrs[2], self.margin,
+                ctypes.byref(self.G),
                 1 if backward else 0, loss.data_ptr(), None if sp is None else sp.data_ptr(),
                 None if sn is None else sn.data_ptr(), packed.desc_ptr, packed.desc_bytes,
                 0 if bufs.desc_resident else 1, wptr, packed.ws_bytes, self.err.data_ptr(), packed.lanes,
                 events, 0 if events is None else len(events), packed.touch_ptr,
                 stream.cuda_stream)
+        fn = L.mpqe_step_forward_backward
+        if extra is not None:
+            fn, args = L.mpqe_step_forward_backward_ex, args + (ctypes.byref(extra),)
         if torch.cuda.current_device() != self.device.index:        # (the context manager costs ~10 us of host time)
             with torch.cuda.device(self.device):
-                st = L.mpqe_step_forward_backward(*args)
+                st = fn(*args)
         else:
-            st = L.mpqe_step_forward_backward(*args)
+            st = fn(*args)
         _capi.check(L, st, 'mpqe_step_forward_backward')
         bufs.desc_resident = True
         if checked:
@@ -629,7 +660,7 @@ class FusedTrainStep(object):
                 self.err.fill_(flags & ~_capi.FLAG_TOUCH_RETRY)
                 self.touch_retries += 1
                 self._pack_touch_sets.add((bytes(packed.batches), tuple(packed.lane_begin)))
-                self.build_touch(packed, library_sort=True)
+                self.build_touch(packed, library_sort=True, id_ptrs=id_ptrs)
                 self.P.flags = self.flags | packed.step_flags | (_capi.STEP_ZERO_GRADS if zero_grad else 0)
                 with torch.cuda.device(self.device):
                     st = L.mpqe_step_table_rows(ctypes.byref(self.P), packed.batches, packed.nb, ctypes.byref(self.G),
@@ -644,11 +675,11 @@ class FusedTrainStep(object):
                 # slower, never wrong. (Without the call's own zero fill the garbage cannot be taken back: that raises.)
                 self.err.fill_(flags & ~(_capi.FLAG_INTERNAL | 0xff00))
                 self.handoff_retries += 1
-                self._rerun_level_form(packed, loss, sp, sn, stream)
+                self._rerun_level_form(packed, loss, sp, sn, stream, id_ptrs, extra)
                 flags = int(self.err.item())
             if flags:
                 ops.raise_on_flags(self.err)
-        if packed.ids_ref is bufs.stage and bufs.stage is not None and not packed.captured:
+        if packed.ids_ref is not None and packed.ids_ref is bufs.stage and bufs.stage is not None and not packed.captured:
             if bufs.last_use is None:
                 bufs.last_use = torch.cuda.Event()
             bufs.last_use.record(stream)                # (the pinned id buffer may be refilled once this step has run)
@@ -656,7 +687,7 @@ class FusedTrainStep(object):
             return loss, sp, sn
         return loss
 
-    def _rerun_level_form(self, packed, loss, sp, sn, stream):
+    def _rerun_level_form(self, packed, loss, sp, sn, stream, id_ptrs, extra=None):
         """The packed step once more through the level form (no in-launch hand-offs), forward + backward with the call's own
         zero fill, into the same loss / score / gradient buffers. Its plan, descriptor table and workspace are its own."""
         L = ops.lib()
@@ -670,13 +701,13 @@ class FusedTrainStep(object):
             raise _capi.MpqeError('the level form rejected the step descriptors')
         ws = torch.empty(wsb + 256, dtype=torch.uint8, device=self.device)
         desc = torch.empty(dsb + 256, dtype=torch.uint8, device=self.device)
-        args = (ctypes.byref(self.P), packed.batches, packed.nb, packed.anchor_ids.data_ptr(), packed.targets.data_ptr(),
-                packed.negs.data_ptr(), self.margin, ctypes.byref(self.G), 1, loss.data_ptr(),
+        args = (ctypes.byref(self.P), packed.batches, packed.nb, id_ptrs[0], id_ptrs[1], id_ptrs[2], self.margin,
+                ctypes.byref(self.G), 1, loss.data_ptr(),
                 None if sp is None else sp.data_ptr(), None if sn is None else sn.data_ptr(),
                 (desc.data_ptr() + 255) // 256 * 256, dsb, 1, (ws.data_ptr() + 255) // 256 * 256, wsb, self.err.data_ptr(), None,
-                None, 0, None, stream.cuda_stream)
+                None, 0, None, stream.cuda_stream, None if extra is None else ctypes.byref(extra))
         with torch.cuda.device(self.device):
-            st = L.mpqe_step_forward_backward(*args)
+            st = L.mpqe_step_forward_backward_ex(*args)
         _capi.check(L, st, 'mpqe_step_forward_backward (level form)')
         torch.cuda.synchronize(self.device)          # (ws / desc are this call's own: they must outlive its launches)
 

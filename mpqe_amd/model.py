@@ -128,6 +128,11 @@ class RGCNEncoderDecoder(nn.Module):
         # one 4-byte D2H read per call to turn a bad id into IndexError (see ops.raise_on_flags)
         self.validate = True
         self._err = None
+        # margin_loss / forward-without-autograd on the fused step (mpqe_amd/dropin.py): one library call per margin_loss for
+        # the loss value, ONE fused step per backward pass for all of them. False: the per-op module path below (also taken
+        # by foreign encoders, by encode_twice and by configurations the fused step does not cover).
+        self.fused = True
+        self._dropin_state = None
 
     # ------------------------------------------------------------------ readouts (model.py:380-398)
     def sum_readout(self, embs, batch_idx, batch_size=None, num_nodes=None, **kwargs):
@@ -236,9 +241,46 @@ class RGCNEncoderDecoder(nn.Module):
                 if err is not None:
                     ops.raise_on_flags(err)
 
+    # ------------------------------------------------------------------ the fused step behind the entry points
+    def dropin(self):
+        """The model's DropIn (mpqe_amd/dropin.py), or None when this model takes the module path."""
+        if not self.fused or self.encode_twice:
+            return None
+        d = self._dropin_state
+        if d is False:
+            return None
+        if d is not None and d.stale() and d.refresh():
+            return d
+        if d is None or d.stale():
+            from .dropin import DropIn
+            enc = self.enc
+            try:
+                if not (hasattr(enc, 'table') and getattr(enc, 'node_maps', None) is not None):
+                    raise ValueError('foreign encoder')
+                if self._device().type != 'cuda':
+                    raise ValueError('not on the GPU')          # (the module path raises the package's usual error)
+                d = DropIn(self)
+            except (ValueError, NotImplementedError):
+                d = False
+            self.__dict__['_dropin_state'] = d
+        return d or None
+
+    def _fused_covers(self, d, formula, n_queries):
+        # (concat reads one block per layer: the reference's own Linear fails on fewer passes; huge batches: the in-step
+        # touch plan's limit -- both stay on the module path)
+        if d.step.learned and self.readout_str == 'concat' and d._passes(formula) != self.num_layers:
+            return False
+        from .dropin import MAX_IDS
+        return 0 < n_queries and 5 * n_queries <= MAX_IDS
+
     # ------------------------------------------------------------------ reference entry points
     def forward(self, formula, queries, target_nodes, anchor_ids=None, var_ids=None, q_graphs=None,
                 neg_nodes=None, neg_lengths=None):
+        if not torch.is_grad_enabled():
+            d = self.dropin()
+            if d is not None and self._fused_covers(d, formula, len(queries)) and (
+                    neg_nodes is None or d.step.uses_chain_dims()):
+                return d.forward(formula, queries, target_nodes, anchor_ids, var_ids, q_graphs, neg_nodes, neg_lengths)
         out = self.encode(formula, queries, anchor_ids, var_ids, q_graphs)
         scores = self.score(formula, out, target_nodes, neg_nodes, neg_lengths)
         self._check()
@@ -257,6 +299,9 @@ class RGCNEncoderDecoder(nn.Module):
 
     def margin_loss(self, formula, queries, anchor_ids=None, var_ids=None, q_graphs=None,
                     hard_negatives=False, margin=1):
+        d = self.dropin()
+        if d is not None and self._fused_covers(d, formula, len(queries)):
+            return d.margin_loss(formula, queries, anchor_ids, var_ids, q_graphs, hard_negatives, margin)
         neg_nodes = self.sample_negatives(formula, queries, hard_negatives)
         targets = [query.target_node for query in queries]
         if self.encode_twice:

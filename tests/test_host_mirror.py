@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()                      # raises ImportError when the .so is missing/stale
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.mpqe_abi_version() == 5
+    assert lib.mpqe_abi_version() == 6
     assert lib.mpqe_status_string(-3) == b'workspace too small'
 
 

@@ -77,7 +77,8 @@ def oracle_step(params, cfg, node_map, batches, margin):
 
 
 def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=1, lanes=None, flags=0, touch='step', repeat=1,
-             plan_out=None, between=None, recover=False, before_recovery=None):
+             plan_out=None, between=None, recover=False, before_recovery=None, dev_weights=False, query_out=None,
+             then_plain=False):
     """between: the step in three calls around the CALLER's readout (MPQE_READOUT_CALLER, MPQE_STEP_PHASE_*): a generator
     function -- between(final_states) yields the query embeddings [graphs, D], is sent their gradients and yields d loss /
     d final states per batch; final_states[i]: batch i's [B N, D]. touch: 'step' = the step builds the touch plan of its ids itself (MPQE_STEP_BUILD_TOUCH, the product's default),
@@ -147,7 +148,7 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
         E = col['E']
         SB[i] = _capi.make_step_batch(b['qt'], passes, b['B'], col['edge_type'][:E], col['var_ids'],
                                       [modes.index(m) for m in f.anchor_modes], modes.index(f.target_mode),
-                                      b['weight'])
+                                      2.0 if dev_weights else b['weight'])
         anchors.append(np.ascontiguousarray(col['anchor_ids'].T).reshape(-1))
     d_anchor = be.put(np.concatenate(anchors))
     d_tg = be.put(np.concatenate([b['targets'] for b in batches]))
@@ -246,11 +247,29 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
                 put_at(ws, base + go.value // 4 + lv * lstride.value + ro[i] * D, np.ascontiguousarray(g, np.float32))
         call(_capi.STEP_PHASE_FROM_STATES, 0)
         P.flags &= ~_capi.STEP_ADD_STATE_GRADS
+    extra = None
+    if dev_weights or query_out is not None:
+        # include/mpqe_amd.h: mpqe_step_extra_t -- batch weights as DEVICE scalars (host weight 2 x device weight w / 2 = w:
+        # the same step), the query embeddings out
+        extra = _capi.StepExtra()
+        if dev_weights:
+            dw = be.put(np.array([0.5 * b['weight'] for b in batches], np.float32))
+            keep.append(dw)
+            for i in range(nb):
+                extra.batch_weight[i] = be.ptr(dw) + 4 * i
+        if query_out is not None:
+            dq = be.empty((Gtot, D))
+            extra.query_out = be.ptr(dq)
     for rep in range(0 if between is not None else repeat):       # (repeat > 1: the same packed step again -- its hand-off epochs / counters carry on)
-        be.check(be.lib.mpqe_step_forward_backward(ctypes.byref(P), SB, nb, be.ptr(d_anchor), be.ptr(d_tg),
-                                                   be.ptr(d_ng), margin, ctypes.byref(G), backward, be.ptr(loss),
-                                                   be.ptr(sp), be.ptr(sn), dptr, dsb, 1 if rep == 0 else 0, wptr, wsb,
-                                                   be.ptr(err), lanes, None, 0, tptr, be.stream), 'step')
+        args = (ctypes.byref(P), SB, nb, be.ptr(d_anchor), be.ptr(d_tg), be.ptr(d_ng), margin, ctypes.byref(G), backward,
+                be.ptr(loss), be.ptr(sp), be.ptr(sn), dptr, dsb, 1 if rep == 0 else 0, wptr, wsb, be.ptr(err), lanes, None, 0, tptr,
+                be.stream)
+        if extra is None or (then_plain and rep == repeat - 1):
+            be.check(be.lib.mpqe_step_forward_backward(*args), 'step')
+        else:
+            be.check(be.lib.mpqe_step_forward_backward_ex(*(args + (ctypes.byref(extra),))), 'step')
+    if query_out is not None:
+        query_out.append(be.get(dq))
     if recover and (int(be.get(err)[0]) & _capi.FLAG_TOUCH_RETRY):
         # the step could not build its own touch plan: everything but the entity-table gradients is complete. Rebuild the plan
         # with the library sort and sum the table rows again from the per-entry rows the step left in its workspace.
@@ -312,6 +331,76 @@ def test_fused_step_matches_oracle(be, readout, adaptive, shared, L, mix):
         if id(p) in seen:
             continue                      # shared layers: one buffer, one accumulated gradient
         seen.add(id(p))
+        ref = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
+        np.testing.assert_allclose(grads[k], ref, rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.parametrize('D,readout,adaptive,L', [(64, 'mp', True, 3), (128, 'sum', False, 2), (32, 'max', False, 2),
+                                                  (64, 'mlp', False, 2)])
+def test_step_with_device_batch_weights_and_query_out(be, D, readout, adaptive, L):
+    """mpqe_step_forward_backward_ex (the drop-in margin_loss / forward, mpqe_amd/dropin.py): per-batch loss weights read
+    from DEVICE scalars give the gradients of the same step with host weights (reference train_helpers.py:81-119:
+    loss = l_0 + w_1 l_1 + ...; backward); the query embeddings it writes are the oracle's readout rows (model.py:447-449);
+    and a later call WITHOUT extras on the same resident descriptor table sees the host weights again."""
+    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(
+        31, D, L, False, MIXES['all7'] if D != 128 else MIXES['dup'], readout, adaptive)
+    if readout == 'mlp':
+        cfg['weight_decay'] = 0.01
+    ref_loss, ref_per, ref_sp, ref_sn = oracle_step(params, cfg, node_map, batches, 1.0)
+    chain = D in (64, 128, 256)
+    qs = [] if chain else None
+    loss, sp, sn, grads, err = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, dev_weights=True,
+                                        query_out=qs, flags=_capi.STEP_ZERO_GRADS)
+    assert err == 0
+    np.testing.assert_allclose(sp, ref_sp, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(loss[1:], ref_per, rtol=1e-5, atol=1e-6)
+    seen = set()
+    for k, p in params.items():
+        if id(p) in seen:
+            continue
+        seen.add(id(p))
+        ref = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
+        if readout == 'mlp' and k.startswith('readout.'):
+            continue            # (oracle_step leaves the regulariser out: compared below against the host-weight run)
+        np.testing.assert_allclose(grads[k], ref, rtol=1e-4, atol=2e-6, err_msg=k)
+    if chain:
+        q_ref = np.concatenate([ref_cpu.encode_queries(params, cfg, node_map, b['formula'], b['col']).detach().numpy()
+                                for b in batches])
+        np.testing.assert_allclose(qs[0], q_ref, rtol=1e-5, atol=1e-6)
+    # the same step with HOST weights: identical gradients (regulariser included), and once more with extras first and a
+    # plain call last on the same resident table (the library writes the host weights back)
+    for p in params.values():
+        p.grad = None
+    for b in batches:
+        b['weight'] = float(np.float32(b['weight']))
+    l_h, _, _, g_h, _ = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_ZERO_GRADS)
+    for k in grads:
+        np.testing.assert_allclose(grads[k], g_h[k], rtol=1e-5, atol=1e-7, err_msg=k)
+    saved = [b['weight'] for b in batches]
+    l2, _, _, g2, _ = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_ZERO_GRADS,
+                               dev_weights=True, repeat=2, then_plain=True)
+    # (then_plain's last call ran with the HOST weights of that run: 2.0 per batch)
+    for b in batches:
+        b['weight'] = 2.0
+    l3, _, _, g3, _ = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_ZERO_GRADS)
+    for b, w in zip(batches, saved):
+        b['weight'] = w
+    for k in g2:
+        np.testing.assert_allclose(g2[k], g3[k], rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+@pytest.mark.parametrize('D', [8, 16, 20])
+@pytest.mark.parametrize('readout,adaptive', [('mp', True), ('sum', False)])
+def test_fused_step_small_dimensions(be, D, readout, adaptive):
+    """The level form at the goldens' dimensions (tests/golden/enc_*: D = 16 / 32). D = 16 is the one dimension whose
+    reduction grid row is a single workgroup: the vector groups' column slices must not be used there (round 5: bias and
+    mode-vector gradients beyond the first four columns were never summed)."""
+    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(5, D, 3, False, MIXES['all7'], readout, adaptive)
+    ref_loss, ref_per, ref_sp, ref_sn = oracle_step(params, cfg, node_map, batches, 1.0)
+    loss, sp, sn, grads, err = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0)
+    assert err == 0
+    np.testing.assert_allclose(loss[0], ref_loss, rtol=1e-5, atol=1e-6)
+    for k, p in params.items():
         ref = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
         np.testing.assert_allclose(grads[k], ref, rtol=1e-4, atol=2e-6, err_msg=k)
 
