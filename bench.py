@@ -54,6 +54,8 @@ def parse():
     ap.add_argument('--batch-size', type=int, default=512)
     ap.add_argument('--readout', default='mp')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-dropin-loop', action='store_true',
+                    help='skip the secondary key dropin_loop (the reference loop body through model.margin_loss)')
     ap.add_argument('--no-pack-ms', action='store_true',
                     help='skip the pack_ms record (host-side loops with ids in host memory): profiler runs, so that the per-kernel averages are those of the timed loop')
     ap.add_argument('--no-scatter', action='store_true', help='skip the roofline_scatter record (general-graph scatter-aggregate)')
@@ -906,6 +908,15 @@ def main():
         if executed is not None:       # flops_all is SURVEY 8d's count (every node state); executed = after pruning
             out['step_work']['layer_flops_executed'] = executed
             out['step_work']['executed_tflops_over_whole_step'] = executed / (elapsed / args.steps) / 1e12
+        if world == 1 and default_workload and not args.no_dropin_loop:
+            # secondary: the reference's OWN loop body (train_helpers.py:76-120: 11 x model.margin_loss with python's
+            # negatives, `loss += w * ...`, loss.item(), loss.backward(), optimizer step) over pre-collated batches --
+            # what a maintainer who changed only the imports gets (mpqe_amd/dropin.py), next to the per-op module path
+            # the same calls took before round 5. Not `value`: that is the step alone, ids resident.
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
+            import dropin_loop_bench
+            out['dropin_loop'] = dropin_loop_bench.run(readout=args.readout, D=D, B=args.batch_size, iters=300,
+                                                       module_iters=8)
         if world == 1 and not args.no_cpu_baseline:
             cfg = dict(readout=args.readout, scatter_op='add', num_layers=3, adaptive=adaptive, weight_decay=0)
             out['cpu_baseline'] = cpu_baseline(args, schema, cpu_state, node_maps, model.rel_ids, model.mode_ids,

@@ -483,10 +483,18 @@ int mpqe_step_forward_backward(const mpqe_step_params_t *params_host, const mpqe
  *                    in front of the step's launches (a later call without extras writes the host weights back).
  *   query_out        [sum_b B_b, dim] or NULL: the query embeddings (the readout's output rows, model.py:447-449) in batch
  *                    order -- what the evaluation form scores against ragged negative lists (model.py:454-460,
- *                    mpqe_cosine_fwd with q_row). Chain form only (MPQE_ERR_UNSUPPORTED otherwise).                    */
+ *                    mpqe_cosine_fwd with q_row). Chain form only (MPQE_ERR_UNSUPPORTED otherwise).
+ *   notify           two 32-bit words the DEVICE can write and the host can read without a call (pinned host memory), or
+ *                    NULL: the workgroup that forms the loss in the call's LAST launch stores notify[1] = the error word as it
+ *                    stands, then notify[0] = notify_value. Once the host reads notify_value there, every launch of the call
+ *                    that reads anchor_ids / targets / negs has run (the id arrays may be refilled), and notify[1] tells
+ *                    whether a bad id was met -- the reference raises IndexError inside forward (encoders.py:40-43); a host
+ *                    mirror that must not synchronise per call polls this word instead.                                  */
 typedef struct {
     const float *batch_weight[MPQE_STEP_MAX_BATCHES];
     float *query_out;
+    uint32_t *notify;
+    uint32_t notify_value;
 } mpqe_step_extra_t;
 int mpqe_step_forward_backward_ex(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,
                                   int num_batches, const int64_t *anchor_ids, const int64_t *targets,

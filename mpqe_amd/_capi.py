@@ -57,7 +57,8 @@ STEP_MAX_LANES = 4
 
 class StepExtra(ctypes.Structure):
     # include/mpqe_amd.h: mpqe_step_extra_t
-    _fields_ = [('batch_weight', c_void_p * STEP_MAX_BATCHES), ('query_out', c_void_p)]
+    _fields_ = [('batch_weight', c_void_p * STEP_MAX_BATCHES), ('query_out', c_void_p), ('notify', c_void_p),
+                ('notify_value', ctypes.c_uint32)]
 
 
 class StepLanes(ctypes.Structure):

@@ -29,3 +29,26 @@ def load():
         import torch  # noqa: F401
         _lib = _capi.bind(ctypes.CDLL(LIB_PATH))
     return _lib
+
+
+_pyhost = None
+
+
+def load_pyhost():
+    """The CPython extension of the drop-in entry points' host path (csrc/host/pyhost.c, built by mpqe_amd.build next to
+    the library), bound to this library's mpqe_host_random_choice. Missing = ImportError, like the library itself."""
+    global _pyhost
+    if _pyhost is None:
+        import importlib.util
+        from .build import pyhost_path
+        path = pyhost_path()
+        if not os.path.exists(path):
+            raise ImportError('mpqe_amd: %s not found. Build it with `python -m mpqe_amd.build`.' % path)
+        spec = importlib.util.spec_from_file_location('mpqe_amd._pyhost', path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        lib = load()
+        mod.bind(ctypes.cast(lib.mpqe_host_random_choice, ctypes.c_void_p).value)
+        mod.step_fn = ctypes.cast(lib.mpqe_step_forward_backward_ex, ctypes.c_void_p).value
+        _pyhost = mod
+    return _pyhost

@@ -56,7 +56,29 @@ def build(force=False, verbose=False):
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC'] + objs + ['-o', LIB])
+    build_pyhost(force, verbose)
     return LIB
+
+
+def pyhost_path():
+    import sysconfig
+    return os.path.join(LIB_DIR, '_pyhost' + (sysconfig.get_config_var('EXT_SUFFIX') or '.so'))
+
+
+def build_pyhost(force=False, verbose=False):
+    """The CPython extension of the drop-in entry points' host path (csrc/host/pyhost.c): plain C against Python.h, no
+    device code. Returns its path."""
+    import sysconfig
+    src = os.path.join(SRC, 'host', 'pyhost.c')
+    out = pyhost_path()
+    os.makedirs(LIB_DIR, exist_ok=True)
+    if force or _stale(out, [src, os.path.join(ROOT, 'include', 'mpqe_amd.h'), os.path.abspath(__file__)]):
+        cmd = [os.environ.get('CC', 'gcc'), '-O2', '-shared', '-fPIC', '-Wall', '-I' + sysconfig.get_paths()['include'],
+               '-I' + os.path.join(ROOT, 'include'), src, '-o', out]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+    return out
 
 
 if __name__ == '__main__':

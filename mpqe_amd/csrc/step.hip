@@ -845,8 +845,17 @@ __global__ __launch_bounds__(1024) void step_loss_kernel(const StepDev *__restri
                                                          const float *__restrict__ terms,
                                                          float *__restrict__ loss, LossMeta lm,
                                                          const float *__restrict__ bterms, unsigned *epoch_f,
-                                                         int bump_b = 0) {
+                                                         int bump_b = 0, unsigned *notify = nullptr, unsigned notify_value = 0,
+                                                         const int32_t *err = nullptr) {
     __shared__ float mean[MPQE_STEP_MAX_BATCHES];
+    // (mpqe_step_extra_t.notify: this is the forward-only call's last launch -- the launches that read the ids have run)
+    if (notify && threadIdx.x == 0) {
+        notify[1] = err ? (unsigned)*err : 0u;
+#ifndef MPQE_EMU
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // (system scope: the flags word is out before the number)
+#endif
+        notify[0] = notify_value;
+    }
     // (forward-only step: this is its last launch -- the next step's forward granules get a new tag, step_uniform.h; and
     // when its chain launch made transposed copies -- a learned readout's forward reads them -- their count a new target)
     if (epoch_f && threadIdx.x == 0) {
@@ -1044,6 +1053,8 @@ struct ReduceArgs {
                              // (touch_runs_block): runs[0 .. runs[touch_M]) -- the table workgroups take those, not every position
     int early;               // 1: the loss and the entity-table rows were roles of the weight-gradient launch (TailArgs.extra0):
                              // the loss workgroup here only closes the step (epochs, the sort's barrier word, the plan's failure flag)
+    unsigned *notify;        // mpqe_step_extra_t.notify (pinned host words) or NULL; written by the loss workgroup
+    unsigned notify_value;
 };
 // workgroup (bx, by) of the reduction: by < ngroups: 256 elements of group by (gx workgroups along x); by == ngroups: the
 // loss (bx 0); beyond: entity-table rows
@@ -1117,6 +1128,14 @@ __device__ __forceinline__ void reduce_block(const ReduceArgs &ra, int bx, int b
             // a touch plan whose build could not finish (its workgroups were not all resident: step_touch.h): the table rows
             // above stored nothing; the caller rebuilds the plan and sums them again (mpqe_step_table_rows)
             if (touch && threadIdx.x == 0 && reinterpret_cast<const TouchHeader *>(touch)->pad[0]) flag_error(ra.err, MPQE_FLAG_TOUCH_RETRY);
+            // (every launch that reads the ids is over: the chain / tail launches come before this one in stream order)
+            if (ra.notify && threadIdx.x == 0) {
+                ra.notify[1] = ra.err ? (unsigned)*ra.err : 0u;
+#ifndef MPQE_EMU
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+#endif
+                ra.notify[0] = ra.notify_value;
+            }
             if (ra.early) return;
             if (ra.lm.chain) loss_block_chain(ra.lm, ra.bterms, ra.loss, reinterpret_cast<float *>(part), 4);
             else loss_block(ra.sd, ra.terms, ra.loss, reinterpret_cast<float *>(part), 4);
@@ -3779,6 +3798,8 @@ extern "C" int mpqe_step_forward_backward_ex(const mpqe_step_params_t *P, const 
     }
     bool dev_weights = false;
     for (int i = 0; extra && i < nb; ++i) dev_weights = dev_weights || extra->batch_weight[i] != nullptr;
+    unsigned *notify = extra ? reinterpret_cast<unsigned *>(extra->notify) : nullptr;
+    const unsigned notify_value = extra ? extra->notify_value : 0u;
     if (extra && extra->query_out && !use_chain) return MPQE_ERR_UNSUPPORTED;       // (the chain workgroups' score phase writes it)
     if (dev_weights || (cached->weights_patched && !upload_desc)) {
         WeightPatch wp;
@@ -4079,6 +4100,8 @@ extern "C" int mpqe_step_forward_backward_ex(const mpqe_step_params_t *P, const 
     ra.touch_row_bits = touch_row_bits;
     ra.rows_multi = rows_multi ? 1 : 0;
     ra.err = err;
+    ra.notify = notify;
+    ra.notify_value = notify_value;
     const bool fuse_tail = use_chain && backward && !pic && NL == 1 && D % 64 == 0 && dbg_on("FUSE_TAIL");
     // split tail launch of the chain form: the loss and the entity-table rows depend on the chain launch alone -- they run as
     // trailing workgroups of the weight-gradient launch, beside its tiles (136 of 256 CUs busy on the AIFB step), instead of
@@ -4340,7 +4363,8 @@ extern "C" int mpqe_step_forward_backward_ex(const mpqe_step_params_t *P, const 
                 (void)hipStreamWaitEvent(s, reinterpret_cast<hipEvent_t>(lanes->join_event[l]), 0);
             }
             hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss, lm, bterms,
-                               use_chain ? epoch_f : (unsigned *)nullptr, pa.tblocks > 0 ? 1 : 0);
+                               use_chain ? epoch_f : (unsigned *)nullptr, pa.tblocks > 0 ? 1 : 0, notify, notify_value,
+                               (const int32_t *)err);
             if (learned) ro_regulariser(false);
             return mpqe_launch_status();
         }
@@ -4447,7 +4471,7 @@ extern "C" int mpqe_step_forward_backward_ex(const mpqe_step_params_t *P, const 
         for (int l = 0; l < NL; ++l) { LAUNCH_SCORE_D(false, (float *)nullptr, l); }
         join();
         hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss, lm, bterms,
-                               use_chain ? epoch_f : (unsigned *)nullptr);
+                           use_chain ? epoch_f : (unsigned *)nullptr, 0, notify, notify_value, (const int32_t *)err);
         if (learned) ro_regulariser(false);
         return mpqe_launch_status();
     }

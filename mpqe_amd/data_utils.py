@@ -141,7 +141,7 @@ class FormulaIds(object):
 
     @staticmethod
     def _csr(lists):
-        """(flat ids, offsets [n + 1], lengths [n]); None when any query has no list (the python path then raises what the
+        """(flat ids, offsets [n + 1], lengths [n], their three addresses); None when any query has no list (the python path then raises what the
         reference raises)."""
         if any(l is None for l in lists):
             return None
@@ -149,7 +149,8 @@ class FormulaIds(object):
         off = np.zeros(len(lists) + 1, dtype=np.int64)
         np.cumsum(lens, out=off[1:])
         flat = np.fromiter((v for l in lists for v in l), dtype=np.int64, count=int(off[-1]))
-        return flat, off, lens
+        # (+ the arrays' addresses: a window's slices are then plain pointer arithmetic for the host routines)
+        return flat, off, lens, flat.ctypes.data, off.ctypes.data, lens.ctypes.data
 
 
 class BatchIds(object):

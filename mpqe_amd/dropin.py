@@ -2,7 +2,7 @@
 
 `RGCNEncoderDecoder.margin_loss(formula, queries, anchor_ids, var_ids, q_graphs, hard_negatives, margin)`
 (reference model.py:464-494) and `.forward(...)` under no_grad (model.py:400-462) keep their signatures, their python
-`random` stream and their return values, and run on `mpqe_step_forward_backward` instead of one launch per op:
+`random` stream and their return values, and run on `mpqe_step_forward_backward_ex` instead of one launch per op:
 
   margin_loss   the ids of the call (anchors, targets, the negatives drawn with python's own Mersenne-Twister stream) are
                 appended to a pinned arena the kernels read in place; ONE forward-only library call (chain launch + loss)
@@ -17,28 +17,44 @@
                 query (eval_auc_queries) comes back from the same call, ragged negative lists (eval_perc_queries) score
                 against the query embeddings the call also writes (mpqe_step_extra_t.query_out) with mpqe_cosine_fwd.
 
+Host side: per margin_loss call one numpy copy per id array, one call into the CPython extension for the negatives
+(csrc/host/pyhost.c: python's generator, the library's replay of random.choice) and one for the library call (its 24
+arguments live in a block that is rewritten in the few fields that change), then torch's Function bookkeeping.
+
 Gradients reach the parameters through `p.grad` only (torch.autograd.grad over a drop-in loss sees no inputs);
 `model.fused = False` restores the per-op module path, which is also what foreign encoders and forward() with autograd
 take.
 """
+import ctypes
 import random
 
 import numpy as np
 import torch
 
-from . import _capi, ops
+from . import _capi, _lib, ops
 from .data_utils import RGCNQueryDataset
 from .fused import FusedTrainStep, _TEMPLATES
 
 MAX_CALLS = _capi.STEP_MAX_BATCHES
 MAX_IDS = _capi.TSORT_MAX_ENTRIES          # looked-up ids of one fused step whose touch plan the step builds itself
+_P, _L, _U = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64
+
+
+class StepCall(ctypes.Structure):
+    """csrc/host/pyhost.c: StepCall -- the arguments of mpqe_step_forward_backward_ex, in order, as one block."""
+    _fields_ = [('params', _P), ('batches', _P), ('num_batches', _L), ('anchor_ids', _P), ('targets', _P), ('negs', _P),
+                ('margin', ctypes.c_double), ('grads', _P), ('backward', _L), ('loss', _P), ('scores_pos', _P),
+                ('scores_neg', _P), ('desc', _P), ('desc_bytes', _U), ('upload_desc', _L), ('workspace', _P),
+                ('workspace_bytes', _U), ('err', _P), ('lanes', _P), ('events', _P), ('num_events', _L), ('touch', _P),
+                ('stream', _P), ('extra', _P)]
 
 
 class _Arena(object):
     """Pinned host memory for the ids of the margin_loss calls between two backward passes, in the layout the step reads:
     anchors [per call: A x B, slot-major], targets [per call: B], negatives [per call: B]. The kernels read it in place
     (pinned memory is mapped into the device's address space). Re-used once no autograd node refers to it and the last
-    launch that read it has run."""
+    library call that read it has run -- which the call itself reports in a pinned word (mpqe_step_extra_t.notify): no
+    events, no synchronisation."""
 
     def __init__(self, cap_g):
         self.cap_g, self.cap_a = cap_g, 3 * cap_g
@@ -47,13 +63,12 @@ class _Arena(object):
         self.n = torch.empty(self.cap_g, dtype=torch.long, pin_memory=True)
         self.a_np, self.t_np, self.n_np = self.a.numpy(), self.t.numpy(), self.n.numpy()
         self.a_ptr, self.t_ptr, self.n_ptr = self.a.data_ptr(), self.t.data_ptr(), self.n.data_ptr()
-        self.event = torch.cuda.Event()
+        self.last_seq = None       # number of the last library call that reads it (None: none yet)
         self.reset()
 
     def reset(self):
         self.na = self.ng = self.calls = 0
         self.live = 0              # autograd nodes that may still run their backward over these ids
-        self.dirty = False         # a launch has read it since the event was recorded
 
     def fits(self, a, g):
         return self.calls < MAX_CALLS and self.na + a <= self.cap_a and self.ng + g <= self.cap_g
@@ -61,12 +76,18 @@ class _Arena(object):
 
 class _Call(object):
     """One margin_loss call as its autograd node remembers it."""
-    __slots__ = ('arena', 'oa', 'og', 'idx', 'key', 'B', 'A', 'margin', 'seq', 'g', '__weakref__')
+    __slots__ = ('arena', 'oa', 'og', 'idx', 'key', 'B', 'A', 'margin', 'seq', 'g')
 
     def __del__(self):
         arena = getattr(self, 'arena', None)
         if arena is not None:
             arena.live -= 1
+
+
+class _Rec(object):
+    """A packed step (descriptors, descriptor table, plan buffer; ids named per run) and the argument block of its library
+    call. One per (formula, batch size) for the forward-only calls, one per sequence of those for a backward pass."""
+    __slots__ = ('ps', 'call', 'addr', 'extra', 'key', 'A', 'B', 'nb')
 
 
 class _MarginLossNode(torch.autograd.Function):
@@ -97,19 +118,25 @@ class DropIn(object):
         for p, g in held:                                       # gradients the module path left there stay
             p.grad.copy_(g)
         self.device = self.step.device
+        self.dev_index = self.device.index
         self._sig = self._signature()
         self.lib = ops.lib()
+        self.host = _lib.load_pyhost()
+        self._step_fn = self.host.step_fn
         self._hook = torch.zeros((), dtype=torch.float32, device=self.device, requires_grad=True)
-        self._one = {}             # (formula, passes, B) -> packed one-batch step (forward-only calls)
-        self._multi = {}           # tuple of those keys -> packed step of a whole backward pass
+        self._one = {}             # (formula, B) -> _Rec of the one-batch step (forward-only calls)
+        self._multi = {}           # tuple of one-batch keys -> _Rec of a whole backward pass
         self._arena = None
         self._free = []
         self._pending = []         # calls whose nodes ran in the current backward pass
         self._seq = 0
         self._full_lists = {}
-        self._cursor = np.zeros(2, dtype=np.int64)
-        self._err_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
-        self._err_np = self._err_host.numpy()
+        # [0] the number of the last library call whose id reads are over, [1] the error word as that call left it: written
+        # by the device (mpqe_step_extra_t.notify), read here without a call
+        self._note = torch.zeros(2, dtype=torch.int32, pin_memory=True)
+        self._note_np = self._note.numpy().view(np.uint32)
+        self._note_ptr = self._note.data_ptr()
+        self._calls = 0            # library calls issued (their notify values, modulo 2^32)
         self.checked = False       # True: every backward pass reads the error word before it returns (one sync) and recovers
         self.steps = 0             # fused backward steps run
         self.fast_sampled = 0      # calls whose negatives were drawn by the library replay of python's stream
@@ -141,16 +168,70 @@ class DropIn(object):
             return passes
         return m.num_layers
 
-    def _packed(self, keys):
-        """The packed step (descriptors, descriptor table, plan buffer; ids external) of the batches `keys`."""
-        cache = self._one if len(keys) == 1 else self._multi
-        ps = cache.get(keys)
-        if ps is None:
-            if len(cache) > 4096:
-                cache.clear()
-            ps = cache[keys] = self.step.pack([dict(formula=f, batch_size=B, weight=1.0) for (f, _p, B) in keys],
-                                              ids='external')
-        return ps
+    def _record(self, cache, key, batches):
+        if len(cache) > 4096:
+            cache.clear()
+        step = self.step
+        r = _Rec()
+        r.ps = ps = step.pack([dict(formula=f, batch_size=B, weight=1.0) for (f, B) in batches], ids='external')
+        r.key, r.nb = key, len(batches)
+        r.extra = _capi.StepExtra()
+        c = r.call = StepCall()
+        c.params, c.grads = ctypes.addressof(step.P), ctypes.addressof(step.G)
+        c.batches, c.num_batches = ctypes.addressof(ps.batches), ps.nb
+        c.desc, c.desc_bytes = ps.desc_ptr, ps.desc_bytes
+        c.workspace_bytes = ps.ws_bytes
+        c.err = step.err.data_ptr()
+        c.touch = ps.touch_ptr
+        r.addr = ctypes.addressof(c)
+        cache[key] = r
+        return r
+
+    def _one_rec(self, formula, B):
+        r = self._one.get((formula, B))
+        if r is None:
+            A = _TEMPLATES[formula.query_type][0]
+            if A != len(formula.anchor_modes):
+                raise ValueError('formula %s has %d anchor modes, template expects %d'
+                                 % (formula, len(formula.anchor_modes), A))
+            self._passes(formula)                  # (the reference's ValueError for a diameter beyond the layers)
+            r = self._record(self._one, (formula, B), [(formula, B)])
+            r.A, r.B = A, B
+        return r
+
+    def _launch(self, r, backward, zero_grad, a_ptr, t_ptr, n_ptr, loss, sp=None, sn=None, extra=None):
+        """One library call on the current stream: the argument block's changing fields, then csrc/host/pyhost.c: step_call."""
+        step, ps, c = self.step, r.ps, r.call
+        step.P.flags = step.flags | ps.step_flags | (_capi.STEP_ZERO_GRADS if (backward and zero_grad) else 0)
+        c.params, c.grads = ctypes.addressof(step.P), ctypes.addressof(step.G)      # (refresh() makes new structs)
+        c.anchor_ids, c.targets, c.negs = a_ptr, t_ptr, n_ptr
+        c.margin = step.margin
+        c.backward = 1 if backward else 0
+        c.loss = loss.data_ptr()
+        c.scores_pos = None if sp is None else sp.data_ptr()
+        c.scores_neg = None if sn is None else sn.data_ptr()
+        bufs = ps.bufs
+        c.upload_desc = 0 if bufs.desc_resident else 1
+        c.workspace = step._workspace(ps.ws_bytes)
+        c.stream = torch._C._cuda_getCurrentRawStream(self.dev_index)
+        if extra is None:
+            extra = r.extra
+        self._calls = seq = (self._calls + 1) & 0xffffffff
+        extra.notify, extra.notify_value = self._note_ptr, seq
+        c.extra = ctypes.addressof(extra)
+        if torch._C._cuda_getDevice() != self.dev_index:
+            with torch.cuda.device(self.device):
+                st = self.host.step_call(self._step_fn, r.addr)
+        else:
+            st = self.host.step_call(self._step_fn, r.addr)
+        if st != 0:
+            _capi.check(self.lib, st, 'mpqe_step_forward_backward_ex')
+        bufs.desc_resident = True
+        return seq
+
+    def _done(self, seq):
+        """True once library call number `seq` (or a later one) has reported that its id reads are over."""
+        return seq is None or ((int(self._note_np[0]) - seq) & 0xffffffff) < 0x80000000
 
     # ------------------------------------------------------------------------------------------- arenas
     def _arena_for(self, a, g):
@@ -161,7 +242,7 @@ class DropIn(object):
             self._retire(ar)
         need = max(g * 4, 1 << 14)
         for i, cand in enumerate(self._free):
-            if cand.live == 0 and cand.cap_g >= need and cand.event.query():
+            if cand.live == 0 and cand.cap_g >= need and self._done(cand.last_seq):
                 ar = self._free.pop(i)
                 ar.reset()
                 break
@@ -173,62 +254,39 @@ class DropIn(object):
         return ar
 
     def _retire(self, ar):
-        if ar.dirty:
-            ar.event.record(torch.cuda.current_stream(self.device))
-            ar.dirty = False
         self._free.append(ar)
         if self._arena is ar:
             self._arena = None
 
     # ------------------------------------------------------------------------------------------- negatives
-    def _choice(self, lens, len_all, base, cand, B, out_ptr):
-        """random.choice per query over the candidate lists, python's own stream (include/mpqe_amd.h:
-        mpqe_host_random_choice): raw Mersenne-Twister outputs are taken from the interpreter's generator in rounds of
-        exactly as many as the queries still open need at least, so the generator ends where the reference's loop
-        leaves it."""
-        cur = self._cursor
-        cur[0] = 0
-        fn = self.lib.mpqe_host_random_choice
-        lens_p = None if lens is None else lens.ctypes.data
-        base_p = None if base is None else base.ctypes.data
-        cand_p = cand.ctypes.data
-        cur_p = cur.ctypes.data
-        done = 0
-        while done < B:
-            n = B - done
-            words = random.getrandbits(32 * n).to_bytes(4 * n, 'little')
-            st = fn(words, n, lens_p, len_all, base_p, cand_p, B, cur_p, out_ptr)
-            if st != 0:
-                raise IndexError('Cannot choose from an empty sequence')
-            done = int(cur[0])
-
     def _full_list(self, mode):
         lst = self.model.graph.full_lists[mode]
         c = self._full_lists.get(mode)
         if c is None or c[0] is not lst or c[1].shape[0] != len(lst):
-            c = self._full_lists[mode] = (lst, np.asarray(lst, dtype=np.int64))
-        return c[1]
+            arr = np.asarray(lst, dtype=np.int64)
+            c = self._full_lists[mode] = (lst, arr, arr.ctypes.data)
+        return c
 
     def _fill_ids(self, ar, formula, queries, anchor_ids, ids, hard_negatives, B, A):
         """Anchors, targets and freshly drawn negatives of one call into the arena (reference model.py:466-477,
-        data_utils.py:382-383)."""
+        data_utils.py:382-383). The negatives are random.choice's own draws: csrc/host/pyhost.c: choice takes raw outputs
+        from the interpreter's generator and the library replays CPython's rejection loop over them
+        (mpqe_host_random_choice), so the generator ends where the reference's list comprehension leaves it."""
         oa, og = ar.na, ar.ng
-        m = self.model
         fast = ids is not None and ids.end - ids.start == B and ids.fi.A == A
         # anchors, slot-major
         if fast and (anchor_ids is None or anchor_ids is ids.anchor_ref):
-            sm = ids.fi.anchors_sm
+            sm, lo, hi = ids.fi.anchors_sm, ids.start, ids.end
             for i in range(A):
-                ar.a_np[oa + i * B: oa + (i + 1) * B] = sm[i, ids.start:ids.end]
+                ar.a_np[oa + i * B: oa + (i + 1) * B] = sm[i, lo:hi]
+        elif anchor_ids is None:
+            for i in range(A):
+                ar.a_np[oa + i * B: oa + (i + 1) * B] = [q.anchor_nodes[i] for q in queries]
         else:
-            if anchor_ids is None:
-                for i in range(A):
-                    ar.a_np[oa + i * B: oa + (i + 1) * B] = [q.anchor_nodes[i] for q in queries]
-            else:
-                a = anchor_ids.detach().cpu().numpy() if torch.is_tensor(anchor_ids) else np.asarray(anchor_ids)
-                if a.shape != (B, A):
-                    raise ValueError('anchor_ids must be [%d, %d] for %s' % (B, A, formula.query_type))
-                np.copyto(ar.a_np[oa: oa + A * B].reshape(A, B), a.T, casting='same_kind')
+            a = anchor_ids.detach().cpu().numpy() if torch.is_tensor(anchor_ids) else np.asarray(anchor_ids)
+            if a.shape != (B, A):
+                raise ValueError('anchor_ids must be [%d, %d] for %s' % (B, A, formula.query_type))
+            np.copyto(ar.a_np[oa: oa + A * B].reshape(A, B), a.T, casting='same_kind')
         # targets
         if fast:
             ar.t_np[og: og + B] = ids.fi.targets[ids.start:ids.end]
@@ -242,52 +300,50 @@ class DropIn(object):
         if hard_negatives:
             csr = ids.fi.hard if fast else None
         elif formula.query_type == "1-chain":
-            full = self._full_list(formula.target_mode)
-            self._choice(None, full.shape[0], None, full, B, out_ptr)
+            _lst, full, full_ptr = self._full_list(formula.target_mode)
+            self.host.choice(random.getrandbits, 0, full.shape[0], 0, full_ptr, B, out_ptr)
             self.fast_sampled += 1
             return oa, og
         else:
             csr = ids.fi.neg if fast else None
         if csr is not None:
-            flat, off, lens = csr
-            self._choice(lens[ids.start:ids.end], 0, off[ids.start:ids.end], flat, B, out_ptr)
+            lo = 8 * ids.start
+            self.host.choice(random.getrandbits, csr[5] + lo, 0, csr[4] + lo, csr[3], B, out_ptr)
             self.fast_sampled += 1
         else:
-            ar.n_np[og: og + B] = m.sample_negatives(formula, queries, hard_negatives)
+            ar.n_np[og: og + B] = self.model.sample_negatives(formula, queries, hard_negatives)
         return oa, og
 
     # ------------------------------------------------------------------------------------------- margin_loss
     def _check_mirror(self):
-        if self._err_np[0]:
+        """Raise what a finished call's error word says (IndexError for a bad entity id, as the reference's lookup would)."""
+        if self._note_np[1]:
             torch.cuda.current_stream(self.device).synchronize()
-            self._err_np[0] = 0
+            self._note_np[1] = 0
             ops.raise_on_flags(self.step.err)
 
     def margin_loss(self, formula, queries, anchor_ids=None, var_ids=None, q_graphs=None, hard_negatives=False, margin=1):
-        m = self.model
-        if m.validate:
+        if self._note_np[1] and self.model.validate:
             self._check_mirror()
         B = len(queries)
-        A = _TEMPLATES[formula.query_type][0]
-        if A != len(formula.anchor_modes):
-            raise ValueError('formula %s has %d anchor modes, template expects %d' % (formula, len(formula.anchor_modes), A))
-        key = (formula, self._passes(formula), B)
-        ps = self._packed((key,))
-        ar = self._arena_for(A * B, B)
-        oa, og = self._fill_ids(ar, formula, queries, anchor_ids, getattr(q_graphs, 'ids', None), hard_negatives, B, A)
+        r = self._one.get((formula, B)) or self._one_rec(formula, B)
+        A = r.A
+        ar = self._arena
+        if ar is None or not ar.fits(A * B, B):
+            ar = self._arena_for(A * B, B)
+        oa, og = self._fill_ids(ar, formula, queries, anchor_ids, None if q_graphs is None else q_graphs.ids, hard_negatives,
+                                B, A)
         step = self.step
         step.margin = float(margin)
         loss = torch.empty(2, dtype=torch.float32, device=self.device)
-        step.run(ps, backward=False, id_ptrs=(ar.a_ptr + 8 * oa, ar.t_ptr + 8 * og, ar.n_ptr + 8 * og),
-                 out=(loss, None, None))
-        ar.dirty = True
+        ar.last_seq = self._launch(r, False, False, ar.a_ptr + 8 * oa, ar.t_ptr + 8 * og, ar.n_ptr + 8 * og, loss)
         idx = ar.calls
         ar.na, ar.ng, ar.calls = oa + A * B, og + B, idx + 1
         if not torch.is_grad_enabled() or not step.params:
             return loss[0]
         call = _Call()
-        call.arena, call.oa, call.og, call.idx, call.key, call.B, call.A = ar, oa, og, idx, key, B, A
-        call.margin, call.g = float(margin), None
+        call.arena, call.oa, call.og, call.idx, call.key, call.B, call.A = ar, oa, og, idx, r.key, B, A
+        call.margin, call.g = step.margin, None
         self._seq += 1
         call.seq = self._seq
         ar.live += 1
@@ -295,15 +351,16 @@ class DropIn(object):
 
     # ------------------------------------------------------------------------------------------- backward
     def _on_backward(self, call, g):
-        if not self._pending:
+        pending = self._pending
+        if not pending:
             torch.autograd.Variable._execution_engine.queue_callback(self._flush)
         if g.dtype != torch.float32 or g.device != self.device:
             g = g.to(device=self.device, dtype=torch.float32)
-        if call.g is not None:                 # (the node ran twice in one pass: retain_graph inside a pass cannot happen, but be exact)
-            g = call.g + g
-        call.g = g.detach()
-        if call not in self._pending:
-            self._pending.append(call)
+        if call.g is None:
+            pending.append(call)
+            call.g = g
+        else:                                  # (the node was reached twice in one pass)
+            call.g = call.g + g
 
     def _flush(self):
         calls, self._pending = self._pending, []
@@ -313,13 +370,18 @@ class DropIn(object):
         step = self.step
         # p.grad: None everywhere (optimizer.zero_grad()) -> the step's own zero fill; otherwise added to what is there
         params, views = step.params, step._views
-        zero = all(p.grad is None for p in params)
+        zero = True
+        for p in params:
+            if p.grad is not None:
+                zero = False
+                break
         if not zero:
             for p, v in zip(params, views):
                 if p.grad is None:
                     v.zero_()
                 elif p.grad is not v:
                     v.copy_(p.grad)
+        step.bind_grads()
         # groups the library can run as one step: consecutive calls of one arena with one margin, at most MAX_CALLS
         groups, cur, nids = [], [], 0
         for c in calls:
@@ -330,32 +392,32 @@ class DropIn(object):
             cur.append(c)
             nids += (c.A + 2) * c.B
         groups.append(cur)
-        stream = torch.cuda.current_stream(self.device)
         for grp in groups:
-            ps = self._packed(tuple(c.key for c in grp))
-            extra = _capi.StepExtra()
+            key = tuple(c.key for c in grp)
+            r = self._multi.get(key) or self._record(self._multi, key, key)
+            extra = r.extra
             for i, c in enumerate(grp):
                 extra.batch_weight[i] = c.g.data_ptr()
             ar, c0 = grp[0].arena, grp[0]
             step.margin = c0.margin
             loss = torch.empty(1 + len(grp), dtype=torch.float32, device=self.device)
-            step.run(ps, backward=True, zero_grad=zero, checked=self.checked,
-                     id_ptrs=(ar.a_ptr + 8 * c0.oa, ar.t_ptr + 8 * c0.og, ar.n_ptr + 8 * c0.og), extra=extra,
-                     out=(loss, None, None))
-            ar.dirty = True
+            ptrs = (ar.a_ptr + 8 * c0.oa, ar.t_ptr + 8 * c0.og, ar.n_ptr + 8 * c0.og)
+            if self.checked:
+                self._calls = seq = (self._calls + 1) & 0xffffffff
+                extra.notify, extra.notify_value = self._note_ptr, seq
+                step.run(r.ps, backward=True, zero_grad=zero, checked=True, id_ptrs=ptrs, extra=extra, out=(loss, None, None))
+                ar.last_seq = seq
+            else:
+                ar.last_seq = self._launch(r, True, zero, ptrs[0], ptrs[1], ptrs[2], loss, extra=extra)
             zero = False
             self.steps += 1
         for c in calls:
             c.g = None
         # the pass is over: its arena is closed (a node kept alive by retain_graph still finds its ids there)
-        if self._arena is not None and self._arena.calls:
-            self._retire(self._arena)
-        for ar in set(c.arena for c in calls):
-            if ar is not self._arena and ar.dirty:
-                ar.event.record(stream)
-                ar.dirty = False
-        if self.model.validate and not self.checked:
-            self._err_host.copy_(step.err, non_blocking=True)      # read at the next call: a bad id raises one step late
+        ar = self._arena
+        if ar is not None and ar.calls:
+            self._free.append(ar)
+            self._arena = None
 
     # ------------------------------------------------------------------------------------------- forward (evaluation)
     def forward(self, formula, queries, target_nodes, anchor_ids=None, var_ids=None, q_graphs=None, neg_nodes=None,
@@ -363,11 +425,8 @@ class DropIn(object):
         """reference model.py:400-462 without autograd: scores [B] or [B + sum(neg_lengths)]."""
         m = self.model
         B = len(queries)
-        A = _TEMPLATES[formula.query_type][0]
-        if A != len(formula.anchor_modes):
-            raise ValueError('formula %s has %d anchor modes, template expects %d' % (formula, len(formula.anchor_modes), A))
-        key = (formula, self._passes(formula), B)
-        ps = self._packed((key,))
+        r = self._one.get((formula, B)) or self._one_rec(formula, B)
+        A = r.A
         ar = self._arena_for(A * B, B)
         oa, og = ar.na, ar.ng
         if anchor_ids is None:
@@ -397,15 +456,14 @@ class DropIn(object):
         loss = torch.empty(2, dtype=torch.float32, device=self.device)
         extra = q = None
         if ragged:
-            if not self.step.uses_chain(ps):
+            if not self.step.uses_chain(r.ps):
                 raise NotImplementedError('ragged negatives on the fused forward need the chain form')
             q = torch.empty(B, m.emb_dim, dtype=torch.float32, device=self.device)
             extra = _capi.StepExtra()
             extra.query_out = q.data_ptr()
         self.step.margin = 1.0
-        self.step.run(ps, backward=False, id_ptrs=(ar.a_ptr + 8 * oa, ar.t_ptr + 8 * og, ar.n_ptr + 8 * og),
-                      extra=extra, out=(loss, scores[:B], scores[B:]))
-        ar.dirty = True
+        ar.last_seq = self._launch(r, False, False, ar.a_ptr + 8 * oa, ar.t_ptr + 8 * og, ar.n_ptr + 8 * og, loss, scores[:B],
+                                   scores[B:], extra=extra)
         ar.na, ar.ng, ar.calls = oa + A * B, og + B, ar.calls + 1
         if neg_nodes is None:
             out = scores[:B]

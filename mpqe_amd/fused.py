@@ -242,6 +242,10 @@ class FusedTrainStep(object):
             if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
                 raise RuntimeError('parameters must be contiguous fp32 CUDA tensors')
         layers = list(m.layers)
+        gv = {id(p): v for p, v in zip(self.params, self._views)}       # (the gradient views, whatever p.grad is bound to now)
+
+        def gptr(t):
+            return gv[id(t)].data_ptr()
         self.P = _capi.make_step_params(
             m.emb_dim, layers[0].num_relations,
             _capi.LEARNED_READOUT_IDS[m.readout_str] if self.learned else m.readout_str, [t.data_ptr() for t in tabs],
@@ -249,9 +253,9 @@ class FusedTrainStep(object):
             m.mode_embeddings.weight.data_ptr(), [l.basis.data_ptr() for l in layers],
             [l.root.data_ptr() for l in layers], [l.bias.data_ptr() for l in layers], flags=self.flags)
         self.G = _capi.make_step_grads(
-            [t.grad.data_ptr() for t in tabs], m.mode_embeddings.weight.grad.data_ptr(),
-            [l.basis.grad.data_ptr() for l in layers], [l.root.grad.data_ptr() for l in layers],
-            [l.bias.grad.data_ptr() for l in layers])
+            [gptr(t) for t in tabs], gptr(m.mode_embeddings.weight),
+            [gptr(l.basis) for l in layers], [gptr(l.root) for l in layers],
+            [gptr(l.bias) for l in layers])
         if self.learned:
             lay = m.readout.layers            # nn.Sequential(Linear, ReLU, Linear): state_dict keys layers.0 / layers.2
             ro = (lay[0].weight, lay[0].bias, lay[2].weight, lay[2].bias)
@@ -260,7 +264,7 @@ class FusedTrainStep(object):
                     raise RuntimeError('readout parameters must be trainable contiguous fp32 CUDA tensors')
             for field, t in zip(('readout_w0', 'readout_b0', 'readout_w2', 'readout_b2'), ro):
                 setattr(self.P, field, t.data_ptr())
-                setattr(self.G, field, t.grad.data_ptr())
+                setattr(self.G, field, gptr(t))
             self.P.readout_scatter = _capi.SCATTER_IDS[{ops.scatter_add: 'add', ops.scatter_max: 'max',
                                                         ops.scatter_mean: 'mean'}[m.readout.scatter_fn]]
             self.P.readout_weight_decay = float(m.weight_decay)

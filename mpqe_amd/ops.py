@@ -559,12 +559,14 @@ class _Hinge(torch.autograd.Function):
         pos, neg = _f(pos, 'pos scores'), _f(neg, 'neg scores')
         if pos.shape != neg.shape or pos.dim() != 1 or pos.shape[0] == 0:
             raise ValueError('hinge: pos/neg must be equal non-empty vectors')
-        loss = torch.empty((1,), dtype=torch.float32, device=pos.device)
+        # (0-dim from the start: a reshape here would make the result a VIEW created inside a Function, and the reference's
+        # `loss += w * margin_loss(...)`, train_helpers.py:103-110, writes the first loss in place -- autograd refuses that)
+        loss = torch.empty((), dtype=torch.float32, device=pos.device)
         with torch.cuda.device(pos.device):
             _ck(lib().mpqe_hinge_fwd(_p(pos), _p(neg), pos.shape[0], margin, _p(loss), _stream()), 'mpqe_hinge_fwd')
         ctx.margin = margin
         ctx.save_for_backward(pos, neg)
-        return loss.reshape(())
+        return loss
 
     @staticmethod
     def backward(ctx, gl):
@@ -582,7 +584,7 @@ class _L2Norms(torch.autograd.Function):
     def forward(ctx, *params):
         import ctypes
         ps = [_f(p, 'parameter') for p in params]
-        out = torch.zeros((1,), dtype=torch.float32, device=ps[0].device)
+        out = torch.zeros((), dtype=torch.float32, device=ps[0].device)
         with torch.cuda.device(ps[0].device):
             for i in range(0, len(ps), 4):
                 chunk = ps[i:i + 4]
@@ -590,7 +592,7 @@ class _L2Norms(torch.autograd.Function):
                 n = (ctypes.c_int64 * len(chunk))(*[p.numel() for p in chunk])
                 _ck(lib().mpqe_l2_norms(arr, n, len(chunk), None, _p(out), None, _stream()), 'mpqe_l2_norms')
         ctx.save_for_backward(*ps)
-        return out.reshape(())
+        return out
 
     @staticmethod
     def backward(ctx, gl):

@@ -192,7 +192,8 @@ def test_fused_and_module_paths_agree_and_options():
         for p in model.parameters():
             p.grad = None
         random.seed(77)
-        loss = 0.3 * model.margin_loss(*batch, hard_negatives=True, margin=0.7)
+        loss = model.margin_loss(*batch, hard_negatives=True, margin=0.7)
+        loss *= 0.3             # (in place on the call's result, as the reference's `loss += ...` does on the first loss)
         loss.backward()
         out[fused] = (loss.item(), {k: (np.zeros(tuple(p.shape), np.float32) if p.grad is None else _np(p.grad).copy())
                                     for k, p in model.named_parameters()})

@@ -260,6 +260,8 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
         if query_out is not None:
             dq = be.empty((Gtot, D))
             extra.query_out = be.ptr(dq)
+        note = be.zeros((2,), np.int32)        # (mpqe_step_extra_t.notify: the call's number + the error word, by its last launch)
+        extra.notify, extra.notify_value = be.ptr(note), 4711
     for rep in range(0 if between is not None else repeat):       # (repeat > 1: the same packed step again -- its hand-off epochs / counters carry on)
         args = (ctypes.byref(P), SB, nb, be.ptr(d_anchor), be.ptr(d_tg), be.ptr(d_ng), margin, ctypes.byref(G), backward,
                 be.ptr(loss), be.ptr(sp), be.ptr(sn), dptr, dsb, 1 if rep == 0 else 0, wptr, wsb, be.ptr(err), lanes, None, 0, tptr,
@@ -270,6 +272,9 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
             be.check(be.lib.mpqe_step_forward_backward_ex(*(args + (ctypes.byref(extra),))), 'step')
     if query_out is not None:
         query_out.append(be.get(dq))
+    if extra is not None and not then_plain:
+        got = np.asarray(be.get(note))
+        assert int(got[0]) == 4711 and int(got[1]) == int(be.get(err)[0]), got
     if recover and (int(be.get(err)[0]) & _capi.FLAG_TOUCH_RETRY):
         # the step could not build its own touch plan: everything but the entity-table gradients is complete. Rebuild the plan
         # with the library sort and sum the table rows again from the per-entry rows the step left in its workspace.
