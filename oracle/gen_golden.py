@@ -74,7 +74,10 @@ def build_reference_model(rmodel, rgraph, renc, schema, adj, D, cfg, seed):
     return model, graph, node_map
 
 
-def run_case(name, query_type, cfg, D=16, B=8, kg=('tiny',), seed=0):
+def run_case(name, query_type, cfg, D=16, B=8, kg=('tiny',), seed=0, tie_anchors=False):
+    """tie_anchors: every query's first two anchors are the SAME entity (a formula whose first two anchor modes agree is
+    drawn): their node states are then identical at every level, so a max over a graph's rows (readout `max`, scatter op
+    `max`) is attained twice wherever an anchor wins -- an exact tie, whose gradient torch_scatter gives to ONE row."""
     rmodel, rdata, rgraph, renc = _load_reference()
     from mpqe_amd import synthetic
     n_ent, n_modes, n_rel = synthetic.KG_SHAPES[kg[0]] if isinstance(kg[0], str) else kg
@@ -84,7 +87,18 @@ def run_case(name, query_type, cfg, D=16, B=8, kg=('tiny',), seed=0):
 
     rng = np.random.RandomState(1000 + seed)
     my_formula = synthetic.sample_formula(schema, query_type, rng)
+    while tie_anchors and my_formula.anchor_modes[0] != my_formula.anchor_modes[1]:
+        my_formula = synthetic.sample_formula(schema, query_type, rng)
     my_queries = synthetic.sample_queries(schema, my_formula, B, rng, n_neg=3, n_hard=2)
+    if tie_anchors:
+        from mpqe_amd.graph import Query as MyQuery
+        tied = []
+        for q in my_queries:
+            anchors = list(q.anchor_nodes)
+            anchors[1] = anchors[0]
+            tied.append(MyQuery(synthetic.query_graph_tuple(my_formula, q.target_node, anchors, []), q.neg_samples,
+                                q.hard_neg_samples, keep_graph=True))
+        my_queries = tied
     # the reference's own Query/Formula objects, built from the same tuples
     queries = [rgraph.Query(q.query_graph, q.neg_samples, q.hard_neg_samples, 100, True)
                for q in my_queries]
@@ -385,6 +399,14 @@ def main():
     for name, qt, cfg, D, k in case_matrix():
         loss = run_case(name, qt, cfg, D=D, B=8, seed=k)
         print('%-36s D=%d loss=%.6f' % (name, D, loss))
+    # exact ties under the max readout / the max scatter op (round 5): torch_scatter's backward routes a tied gradient to the
+    # lowest arg row -- pinned here by the reference's own modules running on the stand-in's scatter_max
+    for name, qt, ro, op, k in (('enc_3inter_max_ties', '3-inter', 'max', 'add', 101),
+                                ('enc_2inter_mlp_max_ties', '2-inter', 'mlp', 'max', 102)):
+        cfg = dict(adaptive=False, num_layers=2, shared_layers=False, readout=ro, scatter_op=op, weight_decay=0.0,
+                   hard_negatives=False, scale=4.0)
+        loss = run_case(name, qt, cfg, D=16, B=8, seed=k, tie_anchors=True)
+        print('%-36s D=16 loss=%.6f (tied anchors)' % (name, loss))
     run_conv_case('conv_random_a', n_nodes=40, n_edges=150, R=7, D_in=16, D_out=16, seed=1)
     run_conv_case('conv_random_b', n_nodes=9, n_edges=3, R=5, D_in=32, D_out=32, seed=2)
     run_conv_case('conv_random_c', n_nodes=300, n_edges=2000, R=12, D_in=64, D_out=64, seed=3)

@@ -57,9 +57,34 @@ def scatter_mean(src, index, dim=0, out=None, dim_size=None, fill_value=0):
     return total / count.view((-1,) + (1,) * (src.dim() - 1))
 
 
+class _ScatterArg(torch.autograd.Function):
+    """torch_scatter's scatter_max / scatter_min: values + arg index, and the BACKWARD torch_scatter has -- each output
+    element's gradient goes to its arg row only (grad_src = grad_out gathered where arg == row). torch's own
+    scatter_reduce('amax') backward, which this stand-in relied on until round 5, splits the gradient evenly between rows that
+    tie exactly; torch_scatter does not. Identical wherever no two rows of a segment hold the same value."""
+
+    @staticmethod
+    def forward(ctx, src, index, n, reduce):
+        res, arg = _scatter_arg_values(src.detach(), index, n, reduce)
+        ctx.save_for_backward(arg)
+        ctx.rows = src.shape[0]
+        ctx.mark_non_differentiable(arg)
+        return res, arg
+
+    @staticmethod
+    def backward(ctx, gres, _garg):
+        arg, = ctx.saved_tensors
+        g = torch.zeros((ctx.rows + 1,) + tuple(gres.shape[1:]), dtype=gres.dtype, device=gres.device)
+        g.scatter_add_(0, torch.where(arg >= 0, arg, torch.full_like(arg, ctx.rows)), gres)
+        return g[:ctx.rows], None, None, None
+
+
 def _scatter_arg(src, index, dim, dim_size, reduce):
     assert dim == 0
-    n = _dim_size(index, dim_size)
+    return _ScatterArg.apply(src, index, _dim_size(index, dim_size), reduce)
+
+
+def _scatter_arg_values(src, index, n, reduce):
     idx = index.view((-1,) + (1,) * (src.dim() - 1)).expand_as(src)
     init = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
     res = init.scatter_reduce(0, idx, src, reduce=reduce, include_self=False)
