@@ -734,7 +734,41 @@ def main():
         blocks.append(time.perf_counter() - t0)
         step_no += args.steps
     if use_fused:
-        fstep.check()                                     # an invalid id / a failed hand-off inside any timed step
+        # an invalid id / a failed hand-off / a p2p peer that never arrived inside any timed step -- agreed between the ranks
+        if exchange is not None:
+            exchange.check()
+        else:
+            fstep.check()
+    split_us = None
+    if world > 1 and use_fused:
+        # where an N-rank step's time goes (outside the timed region): events around the step's own launches and around the
+        # gradient exchange, on the stream both run on, over the same fresh-id steps
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(min(20, max(4, args.steps)))]
+        barrier()
+        for k, (e0, e1, e2) in enumerate(evs):
+            j = (step_no + k) % len(pool)
+            e0.record()
+            if fresh:
+                pk = fstep.pack(descs[j], ids=fresh_ids[j][((step_no + k) // len(pool)) % fresh_ids[j].shape[0]])
+            else:
+                pk = packed[j]
+            fstep.run(pk)
+            e1.record()
+            if exchange is not None:
+                exchange.reduce(xplans[j], packed=pk)
+            else:
+                import torch.distributed as dist
+                dist.all_reduce(fstep.flat_grad)
+            e2.record()
+        barrier()
+        comp = float(np.median([a.elapsed_time(b) for a, b, _ in evs])) * 1e3
+        exch = float(np.median([b.elapsed_time(c) for _, b, c in evs])) * 1e3
+        t = torch.tensor([comp, exch], device=device if args.backend == 'nccl' else 'cpu', dtype=torch.float64)
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        split_us = [float(v) for v in t.tolist()]
+        if exchange is not None:
+            exchange.check()
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor(blocks, device=device if args.backend == 'nccl' else 'cpu', dtype=torch.float64)
@@ -785,8 +819,12 @@ def main():
     if replay_ms is not None:
         out['replay'] = {'ms_per_step': replay_ms, 'value': graphs_per_step / (replay_ms * 1e-3),
                          'note': '4 pre-packed steps replayed (no fresh ids): secondary figure'}
+    if xnote is None and exchange is not None and exchange.transport_note:
+        xnote = exchange.transport_note          # (a fall-back decided during the run: StepExchange.check)
     if xnote is not None:
         out['exchange_note'] = xnote
+    if split_us is not None:
+        out['compute'] = {'us_per_step': split_us[0], 'note': 'events around the step\'s own launches (max over ranks, median step)'}
     if world > 1 and use_fused:
         dense_bytes = fstep.flat_grad.numel() * 4
         out['exchange'] = ({'form': 'dense all-reduce of the flat gradient buffer', 'bytes_per_rank_per_step': int(2 * (world - 1) / world * dense_bytes)}
@@ -798,6 +836,13 @@ def main():
                             'table_rows_gathered': int(np.mean([x.entries for x in xplans])),
                             'forms': sorted(set(x.form for x in xplans)), 'transport': exchange.transport,
                             'dense_gradient_bytes': dense_bytes})
+        out['exchange']['transport_requested'] = args.exchange
+        if args.exchange == 'p2p':
+            out['exchange']['p2p_self_test'] = ('passed (one exchange against torch.distributed\'s all-reduce at start-up)'
+                                                if exchange is not None and exchange.transport == 'p2p' else
+                                                'not in use: %s' % (xnote or 'fell back'))
+        if split_us is not None:
+            out['exchange']['us_per_step'] = split_us[1]
     if rank == 0 and use_fused and world == 1 and not args.no_pack_ms:
         # host side of a step whose ids arrive from the HOST (a data loader's numpy arrays): packing = descriptors (cached
         # per formula) + ids into the packed step's pinned buffer, which the kernels read in place (--host-ids copy: one host-to-device copy per

@@ -13,10 +13,13 @@
 // = 2 (n / w) floats over each link, one hop each way. Buffers are fine-grained device allocations (coherent between
 // agents while kernels run; hipExtMallocWithFlags) that every rank exports with hipIpcGetMemHandle and maps from its
 // peers; hand-offs are epoch-stamped flag words written after a system-scope release and polled with system-scope loads,
-// every poll BOUNDED: a peer that never arrives sets MPQE_FLAG_INTERNAL in the caller's error word instead of hanging,
-// and the host side (mpqe_amd/parallel.py) falls back to the RCCL all-reduce for good. Functionally testable with two
-// processes on ONE GPU (IPC handles work between processes of one device); what it is FOR -- eight ranks, seven links --
-// has not run here (no multi-GPU box in this build's reach).
+// every poll BOUNDED (~25 s): a peer that never arrives sets MPQE_FLAG_INTERNAL | 0x4000 in the caller's error word
+// instead of hanging -- the exchange of THAT step is then incomplete (this rank skipped its reduce, its peers will time out
+// on its shard too) and the gradients must not be used: the host side (mpqe_amd/parallel.py: StepExchange.check, a
+// collective every rank calls before its optimiser step) reads the word, agrees with the other ranks, switches to the RCCL
+// all-reduce for good and raises. EXPERIMENTAL: functionally tested with two processes on ONE GPU (IPC handles work
+// between processes of one device); what it is FOR -- eight ranks, seven xGMI links, remote writes against the local L2 --
+// has not run on hardware (no multi-GPU box in this build's reach).
 #include <string.h>
 
 #include <algorithm>
@@ -72,7 +75,11 @@ __device__ __forceinline__ bool p2p_wait(const unsigned *flag, unsigned epoch, i
             return false;
         }
 #ifndef MPQE_EMU
-        __builtin_amdgcn_s_sleep(16);
+        // (the flag is a word of this rank's OWN buffer; quick polls while the peer is about to arrive, then ~4 us naps:
+        // the bound is ~25 s of real time -- ranks that drift apart by a module load, a checkpoint or an evaluation pass
+        // on rank 0 still meet; a peer that never comes is reported, not waited for forever)
+        if (spins < 4096) __builtin_amdgcn_s_sleep(16);
+        else __builtin_amdgcn_s_sleep(127);
 #endif
     }
     return true;

@@ -7,8 +7,10 @@ using all 7 links concurrently ... over IPC-mapped buffers"). The reference has 
     ... = ex.bucket[:n]
 
 `PeerExchange.ok` is False when the buffers could not be set up or the self-test against torch.distributed's all-reduce
-failed: callers (mpqe_amd.parallel.StepExchange(transport='p2p')) then keep to RCCL. Every device-side wait is bounded and
-reports through the error word (`check()`), never a hang.
+failed: callers (mpqe_amd.parallel.StepExchange(transport='p2p')) then keep to RCCL. Every device-side wait is bounded
+(~25 s) and reports through the error word, never a hang -- but an exchange in which a wait ran out is INCOMPLETE: its
+result must not be used. StepExchange.check() (collective, before the optimiser step) is what notices, agrees between the
+ranks, falls back to RCCL for good and raises. EXPERIMENTAL until it has run across two or more GPUs.
 """
 import ctypes
 
@@ -26,7 +28,12 @@ class _Blob(object):
 
 
 class PeerExchange(object):
-    def __init__(self, capacity, group=None, device=None, self_test=True):
+    def __init__(self, capacity, group=None, device=None, self_test=True, err=None):
+        """Collective. err: the error word the exchange's bounded waits report into (default: one of its own) -- hand in the
+        fused step's, and FusedTrainStep.check() / StepExchange.check() see a peer that never arrived.
+        Set-up is three stages with an agreement after each (every rank reaches every collective whatever failed on it
+        locally): allocate + export my buffer | exchange handles, map the peers' | self test. A rank that fails a stage
+        releases what it holds; `ok` is False everywhere and the caller keeps to RCCL."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -37,8 +44,12 @@ class PeerExchange(object):
         self.reason = None
         self._own = None
         self._mapped = []
-        self.err = ops.new_error_word(self.device)
+        self._bufs = None
+        self.bucket = None
+        self.err = ops.new_error_word(self.device) if err is None else err
         L = ops.lib()
+        # ---- stage 1 (local): my buffer and its IPC handle; every peer pair must be able to map each other
+        handle = None
         try:
             so, fo = ctypes.c_int64(), ctypes.c_int64()
             nbytes = L.mpqe_p2p_buffer_bytes(self.capacity, self.world, ctypes.byref(so), ctypes.byref(fo))
@@ -49,30 +60,69 @@ class PeerExchange(object):
             with torch.cuda.device(self.device):
                 _capi.check(L, L.mpqe_p2p_alloc(nbytes, ctypes.byref(ptr), handle), 'mpqe_p2p_alloc')
             self._own = ptr.value
-            handles = [None] * self.world
+            stage = True
+        except Exception as e:            # noqa: BLE001 -- any failure: the caller keeps to RCCL
+            self.reason = '%s: %s' % (type(e).__name__, e)
+            stage = False
+        if not self._all_agree(stage):
+            self.reason = self.reason or 'a peer could not allocate / export its buffer'
+            self._release()
+            return
+        # ---- stage 2: handles (+ each rank's device) to everyone; peer access between every pair of devices; mappings
+        try:
+            mine = (bytes(handle.raw), self.device.index)
+            everyone = [None] * self.world
             if self.world > 1:
-                dist.all_gather_object(handles, bytes(handle.raw), group=self.group)
+                dist.all_gather_object(everyone, mine, group=self.group)
             else:
-                handles = [bytes(handle.raw)]
+                everyone = [mine]
             bufs = (ctypes.c_void_p * self.world)()
             for p in range(self.world):
                 if p == self.rank:
                     bufs[p] = self._own
                     continue
+                pdev = everyone[p][1]
+                if pdev != self.device.index and not torch.cuda.can_device_access_peer(self.device.index, pdev):
+                    raise RuntimeError('device %d cannot access its peer device %d (hipDeviceCanAccessPeer)'
+                                       % (self.device.index, pdev))
                 m = ctypes.c_void_p()
                 with torch.cuda.device(self.device):
-                    _capi.check(L, L.mpqe_p2p_open(handles[p], ctypes.byref(m)), 'mpqe_p2p_open (rank %d)' % p)
+                    _capi.check(L, L.mpqe_p2p_open(everyone[p][0], ctypes.byref(m)), 'mpqe_p2p_open (rank %d)' % p)
                 self._mapped.append(m.value)
                 bufs[p] = m.value
             self._bufs = bufs
             self.bucket = torch.as_tensor(_Blob(self._own, self.capacity), device=self.device)
-            self.ok = True
-        except Exception as e:            # noqa: BLE001 -- any failure: the caller keeps to RCCL
+            stage = True
+        except Exception as e:            # noqa: BLE001
             self.reason = '%s: %s' % (type(e).__name__, e)
-        # every rank must agree (one rank without its buffers would leave the others waiting)
-        self.ok = self._all_agree(self.ok)
-        if self.ok and self_test and self.world > 1:
+            stage = False
+        if not self._all_agree(stage):
+            self.reason = self.reason or 'a peer could not map the buffers'
+            self._release()
+            return
+        self.ok = True
+        # ---- stage 3: one exchange against torch.distributed's all-reduce
+        if self_test and self.world > 1:
             self.ok = self._self_test()
+            if not self.ok:
+                self._release(barrier=True)
+
+    def _release(self, barrier=False):
+        """Unmap the peers' buffers and free my own (no kernel of the exchange is in flight: set-up failed, or the self test
+        has been synchronised and -- barrier -- every rank is past it)."""
+        L = ops.lib()
+        if barrier:
+            torch.cuda.synchronize(self.device)
+            if self.world > 1 and dist.is_initialized():
+                dist.barrier(group=self.group)
+        for m in self._mapped:
+            L.mpqe_p2p_close(m)
+        self._mapped = []
+        self.bucket = None
+        if self._own is not None:
+            L.mpqe_p2p_free(self._own)
+            self._own = None
+        self.ok = False
 
     def _all_agree(self, flag):
         if self.world == 1:
@@ -126,14 +176,5 @@ class PeerExchange(object):
         ops.raise_on_flags(self.err)
 
     def close(self):
-        L = ops.lib()
-        torch.cuda.synchronize(self.device)
-        if self.world > 1 and dist.is_initialized():
-            dist.barrier(group=self.group)           # nobody unmaps a buffer a peer's kernel may still write
-        for m in self._mapped:
-            L.mpqe_p2p_close(m)
-        self._mapped = []
-        if self._own is not None:
-            L.mpqe_p2p_free(self._own)
-            self._own = None
-        self.ok = False
+        """Collective: nobody unmaps a buffer a peer's kernel may still write."""
+        self._release(barrier=True)

@@ -226,11 +226,13 @@ class StepExchange(object):
             from .p2p import PeerExchange
             cap = sum(p.numel() for p in fused_step.params
                       if self.table_mode == 'dense' or id(p) not in self.table_ids)
-            self.peer = PeerExchange(cap, group=group, device=self.dev)
+            # (its bounded waits report into the STEP's error word: check() below and FusedTrainStep.check() see them)
+            self.peer = PeerExchange(cap, group=group, device=self.dev, err=fused_step.err)
             if self.peer.ok:
                 self.transport = 'p2p'
             else:
                 self.transport_note = 'p2p exchange unavailable (%s): RCCL all-reduce used' % (self.peer.reason or 'a peer failed')
+                self.peer = None
         import ctypes
         self._tab_g = (ctypes.c_void_p * len(self.tables))(
             *[fused_step.flat_grad.data_ptr() + 4 * self.off[id(t)] for t in self.tables])
@@ -299,7 +301,10 @@ class StepExchange(object):
         import ctypes
         from . import _capi, ops
         rows = self.table_mode == 'rows'
-        in_step = rows and self.fused.touch_mode == 'step' and getattr(packed, 'touch_mode', None) == 'step'
+        # (the STEP OBJECT's configuration decides -- the same on every rank. A rank whose descriptor set fell back to
+        # pack-time plans after a recovered in-step sort, FusedTrainStep.run(checked=True), still holds sorted keys in the same
+        # plan buffer: it keeps to the cached in-step exchange plan like its peers, or the ranks' collectives would differ)
+        in_step = rows and self.fused.touch_mode == 'step' and getattr(packed, 'touch_mode', None) in ('step', 'pack')
         dh = self.descriptor_hash(packed)
         if key is not None and (not rows or in_step) and key in self._plans:
             ep = self._plans[key]
@@ -485,6 +490,52 @@ class StepExchange(object):
         ep.wire_bytes += int((w - 1) * ep.cap * self.D * 4)
         return ep
 
+    def check(self):
+        """COLLECTIVE (every rank, same point of every step -- after reduce(), before the optimiser consumes the gradients).
+        Reads this rank's error word (one 4-byte device-to-host read: waits for the step and its exchange) and all-reduces
+        what it says, so that EVERY rank learns what ANY rank met and all act alike:
+          * a peer of the p2p exchange did not arrive within its bound (MPQE_FLAG_INTERNAL | 0x4000) on any rank: that
+            exchange is incomplete everywhere -- every rank switches to the RCCL all-reduce for good (the peer buffers are
+            released, cached plans dropped: the next plan() of a key is a first use again) and raises RuntimeError; the
+            step's gradients must not be used (run the step again);
+          * anything else (a bad entity id, a failed in-launch hand-off, an unrecovered touch plan) on any rank: every rank
+            raises -- the rank that met it what FusedTrainStep.check() raises, the others RuntimeError naming the rank.
+        Returns None when every rank is clean. The reference is single-process: none of this has a counterpart there."""
+        from . import _capi, ops
+        flags = int(self.fused.err.item())
+        p2p_bad = 1 if (flags & _capi.FLAG_INTERNAL and flags & 0x4000) else 0
+        other = flags & ~0x4000 if p2p_bad else flags
+        if p2p_bad and not (other & 0xff00):
+            other &= ~_capi.FLAG_INTERNAL
+        t = torch.tensor([p2p_bad, 1 if other else 0, self.rank if (p2p_bad or other) else -1], dtype=torch.int64)
+        if self.world > 1:
+            if self.backend != 'gloo':
+                t = t.to(self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        any_p2p, any_other, who = [int(v) for v in t.tolist()]
+        if any_p2p:
+            self.fused.err.fill_(other)
+            self._fall_back('a peer did not arrive within the bound of the p2p exchange (seen by rank %d)' % who)
+            if not other:
+                raise RuntimeError('mpqe_amd: the p2p gradient exchange of this step is incomplete (%s); RCCL is used from now '
+                                   'on -- run the step again' % self.transport_note)
+        if other:
+            ops.raise_on_flags(self.fused.err)
+        if any_other:
+            raise RuntimeError('mpqe_amd: rank %d reported a fault in this step (see its exception); the gradients of this '
+                               'step must not be used' % who)
+
+    def _fall_back(self, why):
+        """p2p -> RCCL, for good, on every rank (called collectively)."""
+        if self.transport != 'p2p':
+            return
+        self.transport = 'rccl'
+        self.transport_note = 'p2p exchange abandoned (%s): RCCL all-reduce used' % why
+        self._plans.clear()
+        peer, self.peer = self.peer, None
+        if peer is not None:
+            peer.close()
+
     def rows_plan(self, ep):
         """(plan pointer, entries) for FlatOptimizer.step(packed, rows_plan=...): the rows ANY rank touched (row exchange
         only; None with dense tables)."""
@@ -496,8 +547,8 @@ class StepExchange(object):
         the first key of every run goes out (the other slots invalid: fixed size), the keys of all ranks are gathered and
         every rank sorts them into the same row plan (stable: equal keys stay in rank order)."""
         from . import _capi, ops
-        if packed is None or packed.touch is None or getattr(packed, 'touch_mode', None) != 'step':
-            raise ValueError("reduce(plan, packed=...): the packed step that has just run (touch='step')")
+        if packed is None or packed.touch is None or getattr(packed, 'touch_mode', None) not in ('step', 'pack'):
+            raise ValueError("reduce(plan, packed=...): the packed step that has just run (its touch plan holds the keys)")
         M = int(packed.touch_entries)
         if M != ep.n_own:
             raise ValueError('reduce: this packed step has %d looked-up ids, the plan was made for %d' % (M, ep.n_own))
@@ -528,9 +579,10 @@ class StepExchange(object):
             for v in ep.grad_views:
                 self._all_reduce(v)
         elif ep.form == 'p2p':
-            self._copy_spans(ep.bucket, self.fused.flat_grad, ep.spans_in, ep)       # (one launch each way: the library's own)
-            self.peer.all_reduce(ep.bucket.numel())
-            self._copy_spans(self.fused.flat_grad, ep.bucket, ep.spans_out, ep)
+            if ep.bucket.numel():
+                self._copy_spans(ep.bucket, self.fused.flat_grad, ep.spans_in, ep)       # (one launch each way: the library's own)
+                self.peer.all_reduce(ep.bucket.numel())
+                self._copy_spans(self.fused.flat_grad, ep.bucket, ep.spans_out, ep)
         elif ep.bucket.numel():
             self._copy_spans(ep.bucket, self.fused.flat_grad, ep.spans_in, ep)
             self._all_reduce(ep.bucket)

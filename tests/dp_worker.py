@@ -75,11 +75,18 @@ def main():
             pass
     for p in model.parameters():
         p.grad.fill_(3.0)
-    step.run(packed)
+    fail_rank = int(os.environ.get('MPQE_DP_FAIL_SORT_RANK', '-1'))
+    if rank == fail_rank:
+        # this rank's in-step sort gives up (as if its workgroups were not co-resident): run(checked=True) rebuilds the plan
+        # with the library sort and sums the table rows again BEFORE the exchange -- the peers never see a short bucket
+        from mpqe_amd import ops
+        ops.lib().mpqe_debug_option(b'TSORT_FAIL', 1, 1)
+    step.run(packed, checked=True)
+    if rank == fail_rank:
+        ops.lib().mpqe_debug_option(b'TSORT_FAIL', 0, 0)
+        assert step.touch_retries == 1, step.touch_retries
     ex.reduce(plan, packed=packed)
-    step.check()
-    if ex.peer is not None:
-        ex.peer.check()
+    ex.check()                    # (collective: every rank learns what any rank met -- a peer that never arrived included)
     torch.cuda.synchronize()
     out = dict(flat=step.flat_grad.cpu().numpy(), wire=np.array([plan.wire_bytes]), dense=np.array([step.flat_grad.numel() * 4]))
     out['form'] = np.array([plan.form])

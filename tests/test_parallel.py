@@ -174,3 +174,40 @@ def test_peer_exchange_kernels_phase_by_phase():
             for r in range(world):
                 np.testing.assert_array_equal(views[r][:n], ref)
                 assert (views[r][n:cap] == 7.0).all()
+
+
+def test_peer_exchange_late_rank_is_flagged_not_waited_for_forever():
+    """World 8, one rank never arrives (its push is missing): every wait on it runs out of its bound, ORs
+    MPQE_FLAG_INTERNAL | 0x4000 into the error word and returns -- never a hang --; the waiting rank does NOT publish a sum
+    over a missing slot (its shard stays as it was everywhere, its 'shard landed' flag is never raised), and the ranks that
+    wait for that shard are flagged too. What the host does with the word -- StepExchange.check(): agree between the ranks,
+    fall back to RCCL for good, raise -- is in mpqe_amd/parallel.py; this pins the device half on the CPU emulator."""
+    import ctypes
+    from mpqe_amd import _capi
+    from tests.kernel_backend import EmuBackend
+    be = EmuBackend()
+    world, cap, n, late = 8, 4096, 4001, 5
+    so, fo = ctypes.c_int64(), ctypes.c_int64()
+    nbytes = be.lib.mpqe_p2p_buffer_bytes(cap, world, ctypes.byref(so), ctypes.byref(fo))
+    raw = [np.zeros(nbytes // 4 + 64, np.float32) for _ in range(world)]
+    ptrs = [(r.ctypes.data + 255) // 256 * 256 for r in raw]
+    views = [np.frombuffer((ctypes.c_char * nbytes).from_address(p), dtype=np.float32) for p in ptrs]
+    rng = np.random.RandomState(9)
+    data = [rng.randn(n).astype(np.float32) for _ in range(world)]
+    for r in range(world):
+        views[r][:n] = data[r]
+    bufs = (ctypes.c_void_p * world)(*ptrs)
+    errs = [be.zeros((1,), np.int32) for _ in range(world)]
+    for r in range(world):
+        if r != late:
+            be.check(be.lib.mpqe_p2p_allreduce(bufs, r, world, cap, n, 1, 1, be.ptr(errs[r]), be.stream), 'push')
+    for r in range(world):
+        if r != late:
+            be.check(be.lib.mpqe_p2p_allreduce(bufs, r, world, cap, n, 1, 2, be.ptr(errs[r]), be.stream), 'reduce')
+    want = _capi.FLAG_INTERNAL | 0x4000
+    for r in range(world):
+        if r != late:       # every rank waited for the late rank's slot of its own shard: flagged, nothing published
+            assert int(be.get(errs[r])[0]) & want == want, (r, int(be.get(errs[r])[0]))
+            np.testing.assert_array_equal(views[r][:n], data[r])
+    be.check(be.lib.mpqe_p2p_allreduce(bufs, 0, world, cap, n, 1, 4, be.ptr(errs[0]), be.stream), 'wait')      # returns
+    assert int(be.get(errs[0])[0]) & want == want

@@ -55,12 +55,21 @@ def test_two_ranks_peer_mapped_exchange(tmp_path, sparse, tables, readout, touch
     _two_ranks(tmp_path, sparse, tables, readout, touch, 'gloo', transport='p2p')
 
 
-def _two_ranks(tmp_path, sparse, tables, readout, touch, backend, transport='rccl'):
+@pytest.mark.parametrize('sparse,tables,readout,touch', [CASES[4], CASES[3]])
+def test_two_ranks_one_failed_in_step_sort_is_recovered(tmp_path, sparse, tables, readout, touch):
+    """Rank 1's in-step touch-plan sort is forced to give up (mpqe_debug_option TSORT_FAIL): its step leaves the entity-table
+    rows unsummed. The data-parallel loop runs its steps checked -- run(checked=True) rebuilds the plan with the library sort
+    and sums the rows again before the exchange --, so the reduced gradient is still the single-process one and the replicas
+    agree bit for bit; with the row exchange, the recovered rank keeps to the cached in-step exchange plan like its peer."""
+    _two_ranks(tmp_path, sparse, tables, readout, touch, 'gloo', fail_sort_rank=1)
+
+
+def _two_ranks(tmp_path, sparse, tables, readout, touch, backend, transport='rccl', fail_sort_rank=-1):
     world, port = 2, _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY='0', MPQE_DP_BACKEND=backend)
+                   HSA_ENABLE_IPC_MODE_LEGACY='0', MPQE_DP_BACKEND=backend, MPQE_DP_FAIL_SORT_RANK=str(fail_sort_rank))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'dp_worker.py'), str(tmp_path), str(sparse), tables,
                                        readout, touch, transport], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
