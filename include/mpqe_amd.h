@@ -643,6 +643,11 @@ void mpqe_debug_tail_stamps(void *device_buffer, size_t num_blocks);
  * position of the touch plan instead of its compacted run starts, "DUMP_PLAN" = the step's plan and launch shape on stderr). set != 0
  * stores `value` under `name`, set == 0 removes it. Process-global (see Conventions).                    */
 void mpqe_debug_option(const char *name, int value, int set);
+/* The launch forms of the fused step that were built, proven bit-equal and measured SLOWER (the post-pass as closures
+ * "CLOSURE", the loss + table rows as roles of the weight-gradient launch "EARLY_ROWS", the reduction fused into it
+ * "FUSE_TAIL", range-per-workgroup table sums "ROWS_MULTI", the post-pass alone in the chain launch "POST_IN_CHAIN") are NOT
+ * in the shipped library: they compile with -DMPQE_EXPERIMENTS only (tools/build_variant.sh). 1 = this build has them. */
+int mpqe_debug_has_experiments(void);
 
 #ifdef __cplusplus
 }

@@ -106,6 +106,7 @@ PROTOTYPES = {
     'mpqe_debug_chain_stamps': (None, [P, Z]),
     'mpqe_debug_tail_stamps': (None, [P, Z]),
     'mpqe_debug_option': (None, [c_char_p, I, I]),
+    'mpqe_debug_has_experiments': (I, []),
     'mpqe_copy_to_device': (I, [P, P, Z, P]),
     'mpqe_sample_negatives': (I, [P, L, P, L, P, L, ctypes.c_uint64, P, P, P]),
     'mpqe_adam_step': (I, [P, P, P, P, L, DBL, DBL, DBL, DBL, DBL, L, P]),

@@ -23,6 +23,18 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // never reads the environment.
 int mpqe_dbg_value(const char *name, int unset);
 static inline bool dbg_on(const char *name) { return mpqe_dbg_value(name, 0) != 0; }
+// Launch forms that were built, proven bit-equal and measured SLOWER (the post-pass as closures, the loss
+// and table rows as roles of the weight-gradient launch, the reduction fused into it, range-per-workgroup table sums, the
+// post-pass alone in the chain launch) are not part of the shipped library: they compile only with -DMPQE_EXPERIMENTS
+// (tools/build_variant.sh <name> -DMPQE_EXPERIMENTS; tests: MPQE_EMU_EXPERIMENTS=1), where mpqe_debug_option switches them
+// on as before. In the default build exp_on() is the constant false and their host branches and kernel roles fold away.
+#ifdef MPQE_EXPERIMENTS
+#define MPQE_HAS_EXPERIMENTS 1
+static inline bool exp_on(const char *name) { return dbg_on(name); }
+#else
+#define MPQE_HAS_EXPERIMENTS 0
+#define exp_on(name) false
+#endif
 int mpqe_dbg_generation();       // bumped by every mpqe_debug_option call (plan caches key on it)
 
 // Host-side copy of the template tables (reference data_utils.py:325-362).

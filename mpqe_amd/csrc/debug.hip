@@ -37,6 +37,10 @@ extern "C" void mpqe_debug_option(const char *name, int value, int set) {
     g_any.store(g_opts.empty() ? 0 : 1, std::memory_order_relaxed);
 }
 
+// 1: this build holds the launch forms that were measured slower and taken out of the shipped library (common.h:
+// MPQE_EXPERIMENTS) -- their mpqe_debug_option switches work; 0: the switches are accepted and do nothing
+extern "C" int mpqe_debug_has_experiments(void) { return MPQE_HAS_EXPERIMENTS; }
+
 // host (pinned) -> device copy on `stream`: hipMemcpyAsync behind the C ABI, so that a host mirror without a HIP binding
 // of its own can send the ids of the next step with one asynchronous copy (mpqe_amd/fused.py: pack)
 extern "C" int mpqe_copy_to_device(void *dst, const void *src_host, size_t bytes, void *stream) {

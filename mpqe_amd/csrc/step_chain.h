@@ -803,6 +803,7 @@ struct ChainArgs {
                                          // the weight gradients and the post-pass are a later launch
     unsigned *arrive;                    // ... and of chain workgroups whose stores have reached the L2
     const int *done_inc;                 // chain workgroups per counter and step
+    int wt_early;                        // != 0: ops of the FORWARD levels read transposed copies too (concat readout): wait for them first
     int ro;                              // != 0: a learned readout's Linear layers run on the chain (virtual layers ro_layer, + 1)
     int ro_layer, ro_scatter;            // MPQE_SCATTER_* of the reduction over a graph's rows
 };
@@ -1050,28 +1051,13 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     // (the count of finished transpose workgroups, for the wait in front of the backward levels: requested now)
     unsigned wt_have0 = 0;
     if (tid == 0 && (ca.backward || RO) && ca.wt_count) wt_have0 = chain_count_load(ca.wt_count);
-    // ---- forward levels
-    int cur = 0;
-    chain_run<NCB, KS, false, NW, RO>(S, 0, ref.fwd_count * IPO, N, ng, ca.H + row0 * D, ca.level_stride, cur, nullptr, 0,
-                                      ca.cv_gran, ca.cv_gran ? *ca.epoch_f + 1u : 0u, ca.err);
-
-    chain_stamp(ca, 3);
-    if constexpr (RO) {
-        // the readout's biases take the first two slots of the forward constants (dead: every forward level is done)
-        if (tid < D) {
-            const float *b0 = pick_layer(lp.bias, ca.ro_layer), *b2 = pick_layer(lp.bias, ca.ro_layer + 1);
-            S.cv[tid] = b0 ? b0[tid] : 0.f;
-            S.cv[D + tid] = b2 ? b2[tid] : 0.f;
-        }
-    }
-    if (((ca.backward && ref.bwd_count > 0) || (RO && rof > 0)) && ca.wt_count) {
-        // The transposed copies the backward levels (and a learned readout's forward) multiply by are written by
-        // workgroups of THIS launch, which
-        // publish them with an agent-scope release and count themselves in (step.hip: prep_transpose_block). One lane
-        // compares the count it requested before the forward levels (normally already complete) with the target and
-        // polls on only if it was not; then the workgroup's barrier. No acquire fence: it would invalidate this CU's L1,
-        // and no line of the copies can be in it (or in this XCD's L2) -- nothing reads them before this point in the
-        // launch, the warm-up requests below come after the barrier, and caches do not survive a launch boundary.
+    // The transposed copies the backward levels (and a learned readout's forward) multiply by are written by workgroups of
+    // THIS launch, which publish them with an agent-scope release and count themselves in (step.hip: prep_transpose_block).
+    // One lane compares the count it requested above (normally already complete) with the target and polls on only if it
+    // was not; then the workgroup's barrier. No acquire fence: it would invalidate this CU's L1, and no line of the copies
+    // can be in it (or in this XCD's L2) -- nothing reads them before this point in the launch, the warm-up requests come
+    // after the barrier, and caches do not survive a launch boundary.
+    auto wait_for_copies = [&]() {
         if (tid == 0) {
             const unsigned want = (*ca.epoch_b + 1u) * (unsigned)ca.wt_blocks;
             unsigned have = wt_have0;
@@ -1087,7 +1073,30 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
             }
         }
         __syncthreads();
-    } else if (RO) __syncthreads();
+    };
+    // concat (reference model.py:441-446): the first readout layer's products with the states of levels 1 .. L-1 are ops of
+    // the FORWARD levels' programme (step_plan.h: ro_cat) and multiply by transposed column blocks of its weight -- copies
+    // of this launch: they must be complete before the first forward level, not only before the readout's own ops. (Until
+    // round 5 the wait stood behind the forward levels only: those ops then read whatever the copies' slots held -- the
+    // previous step's blocks, i.e. weights one optimiser step old; a first step read unwritten memory.)
+    const bool early_copies = RO && ca.wt_early && ca.wt_count && (ref.fwd_count > 0 || rof > 0);
+    if (early_copies) wait_for_copies();
+    // ---- forward levels
+    int cur = 0;
+    chain_run<NCB, KS, false, NW, RO>(S, 0, ref.fwd_count * IPO, N, ng, ca.H + row0 * D, ca.level_stride, cur, nullptr, 0,
+                                      ca.cv_gran, ca.cv_gran ? *ca.epoch_f + 1u : 0u, ca.err);
+
+    chain_stamp(ca, 3);
+    if constexpr (RO) {
+        // the readout's biases take the first two slots of the forward constants (dead: every forward level is done)
+        if (tid < D) {
+            const float *b0 = pick_layer(lp.bias, ca.ro_layer), *b2 = pick_layer(lp.bias, ca.ro_layer + 1);
+            S.cv[tid] = b0 ? b0[tid] : 0.f;
+            S.cv[D + tid] = b2 ? b2[tid] : 0.f;
+        }
+    }
+    if (!early_copies && ((ca.backward && ref.bwd_count > 0) || (RO && rof > 0)) && ca.wt_count) wait_for_copies();
+    else if (RO) __syncthreads();
     if (ca.backward && ref.bwd_count > 0 && four) warm(nfwd, ref.bwd_count);
     // node states that are still batch-uniform at level L (no anchor within L hops: possible when a batch runs fewer
     // passes than its diameter) never went through the K loops: the readout sees the pre-pass' vector in every row

@@ -9,7 +9,10 @@ import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-OUT = os.path.join(HERE, '_build', 'libmpqe_emu.so')
+# MPQE_EMU_EXPERIMENTS=1: the variant with the launch forms that were taken out of the shipped library (csrc/common.h:
+# MPQE_EXPERIMENTS) -- their tests in tests/test_step.py run against it and skip otherwise
+EXPERIMENTS = os.environ.get('MPQE_EMU_EXPERIMENTS', '') not in ('', '0')
+OUT = os.path.join(HERE, '_build', 'libmpqe_emu_exp.so' if EXPERIMENTS else 'libmpqe_emu.so')
 CLANG = '/opt/rocm/lib/llvm/bin/clang++'
 
 
@@ -37,8 +40,9 @@ def build_emu(force=False):
         if force or not fresh():
             tmp = OUT + '.tmp.%d' % os.getpid()
             started = time.time()
-            cmd = [CLANG, '-x', 'c++', '-std=c++17', '-O1', '-g', '-fPIC', '-shared',
-                   '-I' + os.path.join(HERE, 'include'), '-I' + os.path.join(ROOT, 'include')] + \
+            cmd = [CLANG, '-x', 'c++', '-std=c++17', '-O1', '-g', '-fPIC', '-shared'] + \
+                (['-DMPQE_EXPERIMENTS'] if EXPERIMENTS else []) + \
+                ['-I' + os.path.join(HERE, 'include'), '-I' + os.path.join(ROOT, 'include')] + \
                 sources() + [os.path.join(HERE, 'emu_runtime.cpp'), '-o', tmp]
             subprocess.check_call(cmd)
             os.utime(tmp, (started, started))       # a source edited while this ran is newer than the result

@@ -522,3 +522,46 @@ def test_packed_steps_own_their_buffers():
     assert id(again.bufs) in ids[2:] and again.desc_resident      # ... table still resident: nothing to upload
     assert torch.equal(step.run(again), ref) and torch.equal(step.flat_grad, g0)
     step.check()
+
+
+@pytest.mark.parametrize('readout,D', [('concat', 64), ('concat', 128), ('mlp', 64), ('targetmlp', 128)])
+def test_learned_readout_on_the_chain_uses_this_steps_weights(readout, D):
+    """A learned readout on the chain form multiplies by TRANSPOSED copies of its Linear weights that workgroups of the same
+    launch make (csrc/step.hip: prep_transpose_block). Every op that reads a copy must wait for it: the concat readout's
+    partial products sit in the FORWARD levels' programme (reference model.py:441-446: one input block per layer) and until
+    round 5 ran ahead of that wait -- a step then used the copies the PREVIOUS step had left (weights one optimiser step
+    old; harmless in a test that never changes the weights, which is why every test until then passed). Here the readout's
+    weights change between two runs of one packed step, and each run is held against the module path with the weights of
+    that run: loss and every gradient."""
+    from mpqe_amd import ops
+    from mpqe_amd.fused import FusedTrainStep
+    model, batches = _setup(readout, False, False, D=D, B=48, weight_decay=1e-3)
+    batches = batches[:7]
+    step = FusedTrainStep(model)
+    packed = step.pack(batches)
+    assert step.uses_chain(packed) and step.learned
+    gen = torch.Generator(device='cpu').manual_seed(5)
+    for trial in range(4):
+        if trial:           # new readout weights, in place: what an optimiser step does
+            with torch.no_grad():
+                for p in model.readout.parameters():
+                    p.copy_((torch.rand(p.shape, generator=gen) * 2 - 1).to(p.device) * (0.5 / np.sqrt(p.shape[-1])))
+        loss = step.run(packed)
+        step.check()
+        got = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        got_loss = loss[0].item()
+        for p in model.parameters():
+            p.grad = None
+        total = None
+        for b in batches:
+            out = model.encode(b['formula'], b['queries'])
+            pos = model.score(b['formula'], out, b['targets'].tolist())
+            neg = model.score(b['formula'], out, b['negs'].tolist())
+            l = (ops.hinge(pos, neg, 1.0) + model.weight_decay * ops.l2_norms(list(model.readout.parameters()))) * b['weight']
+            total = l if total is None else total + l
+        total.backward()
+        np.testing.assert_allclose(got_loss, total.item(), rtol=1e-5, atol=1e-6, err_msg='trial %d' % trial)
+        for k, p in model.named_parameters():
+            ref = torch.zeros_like(p) if p.grad is None else p.grad
+            np.testing.assert_allclose(got[k].cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-6, err_msg='%s (trial %d)' % (k, trial))
+        step.bind_grads()

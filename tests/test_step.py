@@ -60,6 +60,14 @@ def make_problem(seed, D, num_layers, shared, mix, readout, adaptive, scale=3.0)
     return schema, mode_ids, rel_ids, params, node_map, cfg, batches
 
 
+def _gpu_only_when_heavy(be, heavy):
+    """The fiber emulator runs a D = 128 chain launch of hundreds of node updates for tens of seconds: the heaviest
+    parametrisations run on the GPU backend only (same test, same assertions); their lighter siblings cover the same code on
+    the CPU (D = 64 of the same form, D = 128 with fewer ops)."""
+    if heavy and be.name == 'emu':
+        pytest.skip('tens of seconds on the CPU emulator: runs on the GPU backend (-m gpu)')
+
+
 def oracle_step(params, cfg, node_map, batches, margin):
     total, per, sp, sn = 0, [], [], []
     for b in batches:
@@ -416,6 +424,9 @@ def test_post_pass_closures_match_oracle(be, request, D, readout, adaptive):
     csrc/step_closure.h; mpqe_debug_option CLOSURE) against the oracle and against the vector-op form:
     batches of more than 8 x 16 graphs, so that a column sum has more rows than the closure has row groups (its order
     of additions then differs from the vector ops': same values within rounding), every chain depth, ragged sizes."""
+    if not be.lib.mpqe_debug_has_experiments():
+        pytest.skip('measured slower and taken out of the shipped library: builds with -DMPQE_EXPERIMENTS only '
+                    '(MPQE_EMU_EXPERIMENTS=1 / tools/build_variant.sh)')
     mix = [('3-chain', 200, 1.0), ('2-chain', 150, 0.5), ('3-inter_chain', 40, 0.25), ('3-chain_inter', 33, 2.0),
            ('3-chain', 17, 0.3)]
     schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(29, D, 3, False, mix, readout, adaptive)
@@ -594,6 +605,8 @@ def test_fused_step_with_learned_readout_matches_oracle(be, readout, scatter_op,
     ('concat', 128, 'all7', 'add', False, False, 1e-3, 'step'), ('concat', 128, 'dup', 'max', False, True, 0, 'pack'),
     ('concat', 128, 'tiny', 'mean', False, False, 0, False), ('concat', 64, 'many', 'add', False, False, 1e-3, 'step')])
 def test_mlp_readout_on_the_chain_matches_oracle(be, capfd, readout, D, mix, scatter_op, adaptive, shared, wd, touch):
+    _gpu_only_when_heavy(be, (readout == 'concat' and (mix, D) in (('all7', 128), ('many', 64), ('dup', 128))) or
+                         (D == 128 and mix == 'dup' and readout == 'targetmlp'))
     """The learned readouts inside the chain launch against the oracle's whole model (see _readout_on_the_chain)."""
     _readout_on_the_chain(be, capfd, readout, D, mix, scatter_op, adaptive, shared, wd, touch, 3)
 
@@ -749,6 +762,7 @@ CHAIN_MIX = [('3-chain', 21, 1.0), ('3-inter_chain', 16, 0.5), ('1-chain', 35, 0
                                                          (128, 'mp', True, False, 3), (128, 'max', False, False, 3),
                                                          (256, 'mp', True, True, 3)])
 def test_fused_step_chain_kernels(be, D, readout, adaptive, shared, L):
+    _gpu_only_when_heavy(be, (D, readout) in ((128, 'max'), (256, 'mp')))
     """The graph-block chain kernels (all levels of 16 graphs in one workgroup; D = 64 / 128 / 256) against
     the oracle and against the one-launch-per-level form (MPQE_STEP_NO_CHAIN): ragged batch sizes, every
     readout family, pruned and unpruned."""
@@ -778,7 +792,8 @@ def test_fused_step_chain_kernels(be, D, readout, adaptive, shared, L):
         # ... and the reduction's table workgroups taking a range of positions each (ROWS_MULTI; default: one run each)
         # ... and the post-pass alone riding in the chain launch (POST_IN_CHAIN: the tiles stay a launch of their own)
         # ... and the table workgroups taking every sorted position (NO_RUNS) instead of the compacted run starts (default)
-        for opt in (b'EARLY_ROWS', b'ROWS_MULTI', b'POST_IN_CHAIN', b'NO_RUNS'):
+        exps = bool(be.lib.mpqe_debug_has_experiments())      # (the forms taken out of the shipped library: -DMPQE_EXPERIMENTS)
+        for opt in ((b'EARLY_ROWS', b'ROWS_MULTI', b'POST_IN_CHAIN', b'NO_RUNS') if exps else (b'NO_RUNS',)):
             be.lib.mpqe_debug_option(opt, 1, 1)
             try:
                 other = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_SPLIT_TAIL)
@@ -789,26 +804,28 @@ def test_fused_step_chain_kernels(be, D, readout, adaptive, shared, L):
                 np.testing.assert_array_equal(split[3][k], other[3][k], err_msg='%s %s' % (opt, k))
         runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0,
                              flags=_capi.STEP_SPLIT_TAIL | _capi.STEP_ZERO_GRADS, repeat=2))
-        be.lib.mpqe_debug_option(b'POST_IN_CHAIN', 1, 1)
-        try:        # (three runs on one descriptor buffer: the counters' targets are epoch x count; the whole-root rule)
-            runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0,
-                                 flags=_capi.STEP_SPLIT_TAIL | _capi.STEP_ZERO_GRADS, repeat=3))
-        finally:
-            be.lib.mpqe_debug_option(b'POST_IN_CHAIN', 0, 0)
+        if exps:
+            be.lib.mpqe_debug_option(b'POST_IN_CHAIN', 1, 1)
+            try:        # (three runs on one descriptor buffer: the counters' targets are epoch x count; the whole-root rule)
+                runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0,
+                                     flags=_capi.STEP_SPLIT_TAIL | _capi.STEP_ZERO_GRADS, repeat=3))
+            finally:
+                be.lib.mpqe_debug_option(b'POST_IN_CHAIN', 0, 0)
         runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0,
                              flags=_capi.STEP_MERGE_TAIL | _capi.STEP_ZERO_GRADS, repeat=3))
         # the reduction as trailing workgroups of the weight-gradient launch (two launches per step in the split form):
         # accumulate and zero-fill modes, three runs on one descriptor buffer (the arrival counter is re-armed per step)
-        be.lib.mpqe_debug_option(b'FUSE_TAIL', 1, 1)
-        try:
-            fz = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0,
-                          flags=_capi.STEP_SPLIT_TAIL | _capi.STEP_ZERO_GRADS, repeat=3)
-            fa = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_SPLIT_TAIL)
-        finally:
-            be.lib.mpqe_debug_option(b'FUSE_TAIL', 0, 0)
-        runs += [fz, fa]
-        for k in fz[3]:          # (same tiles, same order of additions: zero fill + store == accumulate into zeros)
-            np.testing.assert_array_equal(fz[3][k], fa[3][k], err_msg=k)
+        if exps:
+            be.lib.mpqe_debug_option(b'FUSE_TAIL', 1, 1)
+            try:
+                fz = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0,
+                              flags=_capi.STEP_SPLIT_TAIL | _capi.STEP_ZERO_GRADS, repeat=3)
+                fa = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_SPLIT_TAIL)
+            finally:
+                be.lib.mpqe_debug_option(b'FUSE_TAIL', 0, 0)
+            runs += [fz, fa]
+            for k in fz[3]:          # (same tiles, same order of additions: zero fill + store == accumulate into zeros)
+                np.testing.assert_array_equal(fz[3][k], fa[3][k], err_msg=k)
     if every:
         # entity-table gradients by fp32 atomics instead of the per-row sums of the touch plan
         runs.append(run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, touch=False))
