@@ -52,3 +52,26 @@ def load_pyhost():
         mod.step_fn = ctypes.cast(lib.mpqe_step_forward_backward_ex, ctypes.c_void_p).value
         _pyhost = mod
     return _pyhost
+
+
+_autograd_node = None
+
+
+def load_autograd_node():
+    """The C++ autograd node of the drop-in margin_loss call (csrc/host/autograd_node.cpp, built by mpqe_amd.build), or None
+    when it has not been built: mpqe_amd/dropin.py then uses its torch.autograd.Function form (same semantics, ~20 us more
+    interpreter time per call and step)."""
+    global _autograd_node
+    if _autograd_node is None:
+        import importlib.util
+        from .build import autograd_node_path
+        path = autograd_node_path()
+        if not os.path.exists(path):
+            _autograd_node = False
+            return None
+        import torch  # noqa: F401
+        spec = importlib.util.spec_from_file_location('_autograd_node', path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        _autograd_node = mod
+    return _autograd_node or None

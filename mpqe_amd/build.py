@@ -57,7 +57,35 @@ def build(force=False, verbose=False):
     if force or jobs or _stale(LIB, objs):
         run([HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC'] + objs + ['-o', LIB])
     build_pyhost(force, verbose)
+    build_autograd_node(force, verbose)
     return LIB
+
+
+def autograd_node_path():
+    import sysconfig
+    return os.path.join(LIB_DIR, '_autograd_node' + (sysconfig.get_config_var('EXT_SUFFIX') or '.so'))
+
+
+def build_autograd_node(force=False, verbose=False):
+    """The drop-in margin_loss call's autograd node as a C++ torch::autograd::Node (csrc/host/autograd_node.cpp): g++ against
+    the installed torch's headers and libraries, no device code. Returns its path."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension
+    src = os.path.join(SRC, 'host', 'autograd_node.cpp')
+    out = autograd_node_path()
+    os.makedirs(LIB_DIR, exist_ok=True)
+    if force or _stale(out, [src, os.path.abspath(__file__)]):
+        libdir = os.path.join(os.path.dirname(torch.__file__), 'lib')
+        cmd = [os.environ.get('CXX', 'g++'), '-O2', '-shared', '-fPIC', '-std=c++17', '-DTORCH_EXTENSION_NAME=_autograd_node',
+               '-DTORCH_API_INCLUDE_EXTENSION_H', '-D_GLIBCXX_USE_CXX11_ABI=%d' % int(torch.compiled_with_cxx11_abi())] + \
+            ['-I' + i for i in cpp_extension.include_paths()] + ['-I' + sysconfig.get_paths()['include'], src, '-o', out,
+                                                                 '-L' + libdir, '-ltorch', '-ltorch_cpu', '-lc10', '-ltorch_python',
+                                                                 '-Wl,-rpath,' + libdir]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+    return out
 
 
 def pyhost_path():

@@ -124,6 +124,12 @@ class DropIn(object):
         self.host = _lib.load_pyhost()
         self._step_fn = self.host.step_fn
         self._hook = torch.zeros((), dtype=torch.float32, device=self.device, requires_grad=True)
+        # the calls' autograd nodes: C++ (csrc/host/autograd_node.cpp: the engine stays out of the interpreter until the
+        # pass' one callback) when built, else the torch.autograd.Function above
+        self._node_ext = _lib.load_autograd_node()
+        self._pass = self._node_ext.Pass(self._flush_ext) if self._node_ext is not None else None
+        self._calls_by_id = {}
+        self.node_impl = 'c++' if self._pass is not None else 'python'
         self._one = {}             # (formula, B) -> _Rec of the one-batch step (forward-only calls)
         self._multi = {}           # tuple of one-batch keys -> _Rec of a whole backward pass
         self._arena = None
@@ -240,6 +246,7 @@ class DropIn(object):
             return ar
         if ar is not None:
             self._retire(ar)
+        self._drain_dead()
         need = max(g * 4, 1 << 14)
         for i, cand in enumerate(self._free):
             if cand.live == 0 and cand.cap_g >= need and self._done(cand.last_seq):
@@ -344,9 +351,12 @@ class DropIn(object):
         call = _Call()
         call.arena, call.oa, call.og, call.idx, call.key, call.B, call.A = ar, oa, og, idx, r.key, B, A
         call.margin, call.g = step.margin, None
-        self._seq += 1
-        call.seq = self._seq
+        self._seq = seq = self._seq + 1
+        call.seq = seq
         ar.live += 1
+        if self._pass is not None:
+            self._calls_by_id[seq] = call
+            return self._node_ext.make_loss(self._pass, seq, loss)
         return _MarginLossNode.apply(self._hook, self, call, loss)
 
     # ------------------------------------------------------------------------------------------- backward
@@ -361,6 +371,31 @@ class DropIn(object):
             call.g = g
         else:                                  # (the node was reached twice in one pass)
             call.g = call.g + g
+
+    def _drain_dead(self):
+        """Calls whose C++ nodes are gone (their graphs were freed): drop the records -- their arenas' `live` counts fall."""
+        if self._pass is not None:
+            by_id = self._calls_by_id
+            for i in self._pass.take_dead():
+                by_id.pop(i, None)
+
+    def _flush_ext(self, ids, grads):
+        """The C++ nodes' one callback per backward pass (on the engine's thread, the GIL taken once)."""
+        by_id, calls = self._calls_by_id, []
+        for i, g in zip(ids, grads):
+            c = by_id.get(i)
+            if c is None:
+                continue
+            if g.dtype != torch.float32 or g.device != self.device:
+                g = g.to(device=self.device, dtype=torch.float32)
+            if c.g is None:
+                calls.append(c)
+                c.g = g
+            else:
+                c.g = c.g + g
+        self._pending = calls
+        self._flush()
+        self._drain_dead()
 
     def _flush(self):
         calls, self._pending = self._pending, []

@@ -6,7 +6,7 @@
 out=$(realpath -m $1); mkdir -p $out
 root=$(pwd)
 export TMPDIR=/tmp
-B="python3 $root/bench.py --steps 20 --warmup 3 --repeats 10 --no-cpu-baseline --no-scatter --no-pack-ms"
+B="python3 $root/bench.py --steps 20 --warmup 3 --repeats 10 --no-cpu-baseline --no-scatter --no-pack-ms --no-dropin-loop"
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- $B > $out/stats.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $out/pmc_sq -- $B > $out/pmc_sq.log 2>&1
