@@ -131,3 +131,132 @@ def test_graft_entry_expects_this_abi():
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), '__graft_entry__.py')).read()
     m = re.search(r'mpqe_abi_version\(\) == (\d+)', src)
     assert m and int(m.group(1)) == _lib.load().mpqe_abi_version()
+
+
+def _choice_lists(rng, B):
+    return [[int(v) for v in rng.randint(0, 10 ** 6, size=int(rng.choice([1, 2, 3, 5, 8, 17, 32, 64, 100, 1000, 1025])))]
+            for _ in range(B)]
+
+
+def test_host_random_choice_replays_pythons_stream():
+    """mpqe_host_random_choice (include/mpqe_amd.h) over raw outputs of the interpreter's generator = the reference's
+    `[random.choice(q.neg_samples) for q in queries]` (model.py:470-476): the same draws AND the same generator state
+    afterwards, for ragged lists (powers of two: the rejection loop's worst case), one shared list (1-chain:
+    graph.full_lists) and an empty list (random.choice raises IndexError)."""
+    import random
+    lib = _lib.load()
+    host = _lib.load_pyhost()
+    rng = np.random.RandomState(0)
+    for trial in range(30):
+        B = int(rng.randint(1, 700))
+        lists = _choice_lists(rng, B)
+        lens = np.array([len(l) for l in lists], dtype=np.int64)
+        off = np.zeros(B + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        flat = np.array([v for l in lists for v in l], dtype=np.int64)
+        random.seed(trial)
+        ref = [random.choice(l) for l in lists]
+        state = random.getstate()
+        # (a) the CPython extension: rounds of getrandbits + the library's replay inside one call
+        out = np.full(B, -1, dtype=np.int64)
+        random.seed(trial)
+        words = host.choice(random.getrandbits, lens.ctypes.data, 0, off.ctypes.data, flat.ctypes.data, B, out.ctypes.data)
+        assert out.tolist() == ref and random.getstate() == state and words >= B
+        # (b) the library routine alone, driven round by round through ctypes
+        out2 = np.full(B, -1, dtype=np.int64)
+        cur = np.zeros(2, dtype=np.int64)
+        random.seed(trial)
+        while cur[0] < B:
+            n = B - int(cur[0])
+            w = random.getrandbits(32 * n).to_bytes(4 * n, 'little')
+            assert lib.mpqe_host_random_choice(w, n, lens.ctypes.data, 0, off.ctypes.data, flat.ctypes.data, B, cur.ctypes.data,
+                                               out2.ctypes.data) == 0
+        assert out2.tolist() == ref and random.getstate() == state
+    # one list for every query (reference model.py:473-474)
+    full = [int(v) for v in rng.randint(0, 10 ** 6, size=433)]
+    arr = np.array(full, dtype=np.int64)
+    random.seed(99)
+    ref = [random.choice(full) for _ in range(512)]
+    state = random.getstate()
+    out = np.empty(512, dtype=np.int64)
+    random.seed(99)
+    host.choice(random.getrandbits, 0, len(full), 0, arr.ctypes.data, 512, out.ctypes.data)
+    assert out.tolist() == ref and random.getstate() == state
+    # an empty list: IndexError, as random.choice([]) raises
+    lens = np.array([3, 0, 2], dtype=np.int64)
+    off = np.array([0, 3, 3, 5], dtype=np.int64)
+    with pytest.raises(IndexError):
+        host.choice(random.getrandbits, lens.ctypes.data, 0, off.ctypes.data, arr.ctypes.data, 3, out.ctypes.data)
+
+
+def test_cpp_autograd_node_defers_to_one_callback_per_pass():
+    """csrc/host/autograd_node.cpp on CPU tensors: the loss tensors are tensors of their own (the reference's in-place
+    `loss += w * margin_loss(...)` works on the first one), a backward pass calls flush ONCE with every reached call and its
+    upstream gradient, and destroyed nodes are reported."""
+    import gc
+    ext = _lib.load_autograd_node()
+    assert ext is not None, 'python -m mpqe_amd.build builds mpqe_amd/lib/_autograd_node*.so'
+    got = []
+    ps = ext.Pass(lambda ids, grads: got.append(sorted(zip(ids, [float(g) for g in grads]))))
+    bufs = [torch.tensor([float(i + 1), 0.0]) for i in range(3)]
+    losses = [ext.make_loss(ps, 10 + i, bufs[i]) for i in range(3)]
+    assert all(l.requires_grad and l.dim() == 0 and not l._is_view() for l in losses)
+    loss = losses[0]
+    loss += 0.5 * losses[1]
+    loss += 0.25 * losses[2]
+    assert abs(loss.item() - 2.75) < 1e-6
+    loss.backward()
+    assert got == [[(10, 1.0), (11, 0.5), (12, 0.25)]]
+    del loss, losses
+    gc.collect()
+    assert sorted(ps.take_dead()) == [10, 11, 12] and ps.take_dead() == []
+    with torch.no_grad():
+        l = ext.make_loss(ps, 7, bufs[0])           # (a node is made all the same; nothing reaches it)
+    del l
+    gc.collect()
+    assert ps.take_dead() == [7]
+
+
+def test_collate_fn_ids_are_the_query_objects_ids():
+    """RGCNQueryDataset.collate_fn (reference data_utils.py:293-311, 369-375) takes a window of the formula's id arrays
+    (FormulaIds) instead of walking the Query objects: same anchors / targets / candidate lists as the objects hold, same
+    np.random draws and windows as the reference's arithmetic."""
+    from mpqe_amd import synthetic
+    from mpqe_amd.data_utils import RGCNQueryDataset, get_queries_iterator
+    schema = synthetic.make_schema(*synthetic.KG_SHAPES['tiny'], seed=1)
+    rng = np.random.RandomState(2)
+    queries = {}
+    for qt in ('3-inter_chain', '2-chain'):
+        f = synthetic.sample_formula(schema, qt, rng)
+        queries[f] = synthetic.sample_queries(schema, f, 37 if qt == '2-chain' else 23, rng, n_neg=5, n_hard=2)
+
+    class M(object):
+        mode_ids = {m: i for i, m in enumerate(schema.modes)}
+        rel_ids = {}
+    for m in schema.relations:
+        for (to, name) in schema.relations[m]:
+            M.rel_ids[(m, name, to)] = len(M.rel_ids)
+            M.rel_ids.setdefault((to, name, m), len(M.rel_ids))
+    np.random.seed(5)
+    it = get_queries_iterator(queries, 8, M)
+    seen = 0
+    for _ in range(12):
+        formula, qs, anchor_ids, var_ids, g = next(it)
+        ids = g.ids
+        assert ids.end - ids.start == len(qs) == anchor_ids.shape[0] and ids.anchor_ref is anchor_ids
+        ref_a, ref_v, ref_g = RGCNQueryDataset.get_query_graph(formula, qs, M.rel_ids, M.mode_ids)
+        np.testing.assert_array_equal(anchor_ids.numpy(), ref_a.numpy())
+        np.testing.assert_array_equal(var_ids.numpy(), ref_v.numpy())
+        assert g.template.edge_type == ref_g.template.edge_type and g.template.B == len(qs)
+        fi = ids.fi
+        assert fi.targets[ids.start:ids.end].tolist() == [q.target_node for q in qs]
+        np.testing.assert_array_equal(fi.anchors_sm[:, ids.start:ids.end], ref_a.numpy().T)
+        flat, off, lens = fi.neg[:3]
+        for k, q in enumerate(qs):
+            j = ids.start + k
+            assert flat[off[j]:off[j + 1]].tolist() == list(q.neg_samples) and lens[j] == len(q.neg_samples)
+            if q.hard_neg_samples is not None:
+                hf, ho = fi.hard[0], fi.hard[1]
+                assert hf[ho[j]:ho[j + 1]].tolist() == list(q.hard_neg_samples)
+        seen += len(qs)
+    assert seen > 0
