@@ -432,7 +432,8 @@ int mpqe_step_touch_build(const mpqe_step_params_t *params_host, const mpqe_step
  * launch, in this order: for level 0..Lmax-1, for each lane that has the level: layer forward; for level
  * Lmax-1..0, for each such lane: backward-x; then the weight-gradient launch. When the graph-block chain
  * kernel runs (dim 64 / 128 / 256, MPQE_STEP_NO_CHAIN clear, every batch at most 5 passes) the order is: for each lane its chain launch (assemble, levels forward, scores,
- * levels backward), then for each lane its weight-gradient launch. Fewer are filled as far as they go.
+ * levels backward), then for each lane its weight-gradient launch; in both forms last the step's reduction launch. Fewer
+ * are filled as far as they go.
  * For roofline accounting only.                                                                     */
 /* readout = MPQE_READOUT_CALLER: the step in THREE calls around a readout the caller computes itself -- the learned
  * readouts of the reference (MLPReadout / TargetMLPReadout, model.py:497-553), whose Linear layers are the caller's

@@ -2232,7 +2232,9 @@ extern "C" int mpqe_step_forward_backward_ex(const mpqe_step_params_t *P, const 
         for (int k = nmat; k < ng; ++k) packed = packed && (hp.groups[k].kind == 2 || hp.groups[k].kind == 3);
         ra.nmat = packed ? nmat : -1;
         dim3 grid(r_gx, (unsigned)(packed ? nmat + 1 : ng + 1) + r_trows);
+        mark(s);
         hipLaunchKernelGGL(step_reduce_kernel, grid, dim3(256), 0, s, ra);
+        mark(s);
     }
     if (learned) ro_regulariser(true);
     return mpqe_launch_status();
