@@ -405,17 +405,20 @@ class DropIn(object):
         step = self.step
         # p.grad: None everywhere (optimizer.zero_grad()) -> the step's own zero fill; otherwise added to what is there
         params, views = step.params, step._views
-        zero = True
-        for p in params:
-            if p.grad is not None:
-                zero = False
-                break
-        if not zero:
-            for p, v in zip(params, views):
-                if p.grad is None:
-                    v.zero_()
-                elif p.grad is not v:
-                    v.copy_(p.grad)
+        if step.zero_next:                     # (FlatOptimizer.zero_grad(): every p.grad is still its view)
+            zero, step.zero_next = True, False
+        else:
+            zero = True
+            for p in params:
+                if p.grad is not None:
+                    zero = False
+                    break
+            if not zero:
+                for p, v in zip(params, views):
+                    if p.grad is None:
+                        v.zero_()
+                    elif p.grad is not v:
+                        v.copy_(p.grad)
         step.bind_grads()
         # groups the library can run as one step: consecutive calls of one arena with one margin, at most MAX_CALLS
         groups, cur, nids = [], [], 0

@@ -111,6 +111,12 @@ class FlatOptimizer(object):
                                              self.weight_decay, stream)
         _capi.check(ops.lib(), st, 'optimiser step')
 
+    def zero_grad(self, set_to_none=True):
+        """torch.optim's call (reference train_helpers.py:78) for the drop-in entry points (mpqe_amd/dropin.py): the next
+        backward pass's fused step zero-fills the flat gradient buffer itself -- nothing is written here, and no p.grad is
+        touched (re-binding ~30 parameters' .grad costs more interpreter time than the step's call)."""
+        self.fused.zero_next = True
+
     def state_dict(self):
         return {'t': self.t, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq}
 

@@ -111,8 +111,7 @@ class _FlatAdapter(object):
         self.opt = FlatOptimizer(model.dropin().step, lr=lr, opt='adam')
 
     def zero_grad(self):
-        for p in self.model.parameters():
-            p.grad = None
+        self.opt.zero_grad()
 
     def step(self):
         self.opt.step()
