@@ -192,6 +192,9 @@ class FusedTrainStep(object):
         if self.device.type != 'cuda':
             raise RuntimeError('mpqe_amd: the model must be on the GPU -- there is no CPU path')
         self.modes = list(model.mode_ids.keys())          # table index = mode id order
+        if any(not p.requires_grad for p in model.parameters()):
+            # (the step writes every gradient buffer; a frozen table or layer has none: the module path handles that model)
+            raise ValueError('FusedTrainStep: every parameter of the model must require grad')
         self.params = [p for p in model.parameters() if p.requires_grad]
         total = sum(p.numel() for p in self.params)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
