@@ -178,9 +178,12 @@ class QueryDataset(Dataset):
         return index
 
     def _window(self, idx_list):
-        counts = np.array(list(self.num_formula_queries.values()))
-        pick = np.argmax(np.random.multinomial(1, counts / float(self.num_queries)))
-        formula = list(self.num_formula_queries.keys())[pick]
+        w = self.__dict__.get('_pick_tables')
+        if w is None:       # (the same probability vector the reference builds per batch, built once)
+            counts = np.array(list(self.num_formula_queries.values()))
+            w = self.__dict__['_pick_tables'] = (counts / float(self.num_queries), list(self.num_formula_queries.keys()))
+        pick = np.argmax(np.random.multinomial(1, w[0]))
+        formula = w[1][pick]
         n = self.num_formula_queries[formula]
         lo, hi = idx_list[0], idx_list[-1]
         start = lo % n
@@ -206,6 +209,7 @@ class RGCNQueryDataset(QueryDataset):
         self.rel_ids = enc_dec.rel_ids
 
         self._formula_ids = {}
+        self._templates = {}
 
     def formula_ids(self, formula):
         fi = self._formula_ids.get(formula)
@@ -226,7 +230,11 @@ class RGCNQueryDataset(QueryDataset):
             raise ValueError('formula %s has %d anchor modes, template expects %d'
                              % (formula, len(formula.anchor_modes), info.num_anchors))
         var_ids, edge_type = self._formula_consts(formula, info)
-        graph = QueryGraphBatch(ops.Template(formula.query_type, end - start, edge_type))
+        tk = (formula, end - start)
+        tmpl = self._templates.get(tk)
+        if tmpl is None:        # (immutable: one per formula and batch size)
+            tmpl = self._templates[tk] = ops.Template(formula.query_type, end - start, edge_type)
+        graph = QueryGraphBatch(tmpl)
         anchor_ids = torch.from_numpy(fi.anchors[start:end])
         graph.ids = BatchIds(fi, start, end, anchor_ids)
         return formula, queries, anchor_ids, torch.from_numpy(var_ids.copy()), graph
@@ -267,11 +275,28 @@ def make_data_iterator(data_loader):
             yield item
 
 
+def _sequential_batches(dataset, batch_size):
+    """What `make_data_iterator(DataLoader(dataset, batch_size, shuffle=False, collate_fn=dataset.collate_fn))` yields
+    (reference data_utils.py:412-426), without the loader: a sequential sampler's index windows [lo, lo + batch_size) over
+    range(len(dataset)), the last one short, epoch after epoch; collate_fn reads only the window's first and last index
+    (data_utils.py:293-311), so it gets a range. The loader fetched `dataset[i]` for every index of a window first (512
+    interpreter calls that return i) and wrapped every batch in profiler scopes: ~100 us per batch of the ~120.
+    The ONE thing the loader does besides: each epoch's iterator draws a base seed from torch's global generator
+    (`torch.empty((), dtype=torch.int64).random_()`, torch/utils/data/dataloader.py) -- repeated here so that torch's random
+    stream stays where the reference's run would leave it."""
+    n = len(dataset)
+    if batch_size is None or batch_size <= 0:
+        raise ValueError('batch_size should be a positive integer value, but got batch_size=%r' % (batch_size,))
+    while True:
+        torch.empty((), dtype=torch.int64).random_()
+        for lo in range(0, n, batch_size):
+            yield dataset.collate_fn(range(lo, min(lo + batch_size, n)))
+
+
 def get_queries_iterator(queries, batch_size, enc_dec=None):
     """reference: data_utils.py:422-426."""
     dataset = RGCNQueryDataset(queries, enc_dec)
-    loader = DataLoader(dataset, batch_size, shuffle=False, collate_fn=dataset.collate_fn)
-    return make_data_iterator(loader)
+    return _sequential_batches(dataset, batch_size)
 
 
 def make_feature_modules(node_ids_by_mode, embed_dim, num_entities=None):

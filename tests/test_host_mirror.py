@@ -260,3 +260,48 @@ def test_collate_fn_ids_are_the_query_objects_ids():
                 assert hf[ho[j]:ho[j + 1]].tolist() == list(q.hard_neg_samples)
         seen += len(qs)
     assert seen > 0
+
+
+def test_queries_iterator_equals_the_dataloader_form():
+    """get_queries_iterator (reference data_utils.py:412-426) without torch's DataLoader: the same batches (formula draws,
+    windows across epoch ends, Query objects, id tensors) and the same numpy AND torch random streams as
+    make_data_iterator(DataLoader(dataset, batch_size, shuffle=False, collate_fn=dataset.collate_fn))."""
+    from torch.utils.data import DataLoader
+    from mpqe_amd import synthetic
+    from mpqe_amd.data_utils import RGCNQueryDataset, get_queries_iterator, make_data_iterator
+    schema = synthetic.make_schema(*synthetic.KG_SHAPES['tiny'], seed=4)
+    rng = np.random.RandomState(6)
+    queries = {}
+    for n in (37, 90, 64):
+        f = synthetic.sample_formula(schema, '3-chain_inter', rng)
+        while f in queries:
+            f = synthetic.sample_formula(schema, '3-chain_inter', rng)
+        queries[f] = synthetic.sample_queries(schema, f, n, rng, n_neg=4, n_hard=2)
+
+    class M(object):
+        mode_ids = {m: i for i, m in enumerate(schema.modes)}
+        rel_ids = {}
+    for m in schema.relations:
+        for (to, name) in schema.relations[m]:
+            M.rel_ids.setdefault((m, name, to), len(M.rel_ids))
+            M.rel_ids.setdefault((to, name, m), len(M.rel_ids))
+
+    def run(lean):
+        np.random.seed(3)
+        torch.manual_seed(5)
+        if lean:
+            it = get_queries_iterator(queries, 32, M)
+        else:
+            ds = RGCNQueryDataset(queries, M)
+            it = make_data_iterator(DataLoader(ds, 32, shuffle=False, collate_fn=ds.collate_fn))
+        out = []
+        for _ in range(11):                 # (three epochs of the longest formula's 90 queries: 3 batches each + wrap-around)
+            f, qs, a, v, g = next(it)
+            out.append((f, [id(q) for q in qs], a.numpy().copy(), v.numpy().copy(), g.template.edge_type, g.template.B))
+        return out, np.random.get_state()[1].tolist(), torch.get_rng_state().tolist()
+    (a, na, ta), (b, nb, tb) = run(False), run(True)
+    assert na == nb and ta == tb
+    for x, y in zip(a, b):
+        assert x[0] == y[0] and x[1] == y[1] and x[4:] == y[4:]
+        np.testing.assert_array_equal(x[2], y[2])
+        np.testing.assert_array_equal(x[3], y[3])

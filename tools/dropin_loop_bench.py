@@ -71,6 +71,30 @@ def precollate(model, train_queries, B, steps):
     return out
 
 
+class _Live(object):
+    """The 11 draws of an iteration taken from the live iterators inside the timed loop (run_batch_v2 as it is,
+    train_helpers.py:157-162: collation included)."""
+
+    def __init__(self, model, train_queries, B):
+        from mpqe_amd.data_utils import get_queries_iterator
+        self.its = {qt: get_queries_iterator(train_queries[qt], B, model) for qt in train_queries}
+        self.order = [('1-chain', False, None)]
+        for qt in train_queries:
+            if qt == '1-chain':
+                continue
+            if 'inter' in qt:
+                self.order += [(qt, False, 0.005), (qt, True, 0.005)]
+            else:
+                self.order.append((qt, False, 0.01))
+
+    def __len__(self):
+        return 1
+
+    def __getitem__(self, i):
+        its = self.its
+        return ((next(its[qt]), hard, w) for qt, hard, w in self.order)
+
+
 def loop(model, optimizer, steps, iters, warmup):
     """-> seconds per iteration (wall, host + device: the loop synchronises at loss.item() as the reference's does)."""
     def body(step):
@@ -142,6 +166,11 @@ def run(readout='mp', D=128, B=512, iters=200, warmup=20, optimizer='flat', modu
         t = loop(model, opt, steps, iters if fused else module_iters, warmup if fused else 3)
         key = 'fused' if fused else 'module_path'
         out[key] = {'ms_per_step': t * 1e3, 'query_graphs_per_s': graphs / t}
+        if fused:
+            # the same iteration with its collation: every batch drawn from the live iterators inside the timed loop
+            # (get_queries_iterator -> collate_fn: windows of per-formula id arrays, no DataLoader machinery)
+            tl = loop(model, opt, _Live(model, train_queries, B), iters, warmup)
+            out[key]['ms_per_step_with_collation'] = tl * 1e3
         if fused:
             d = model.dropin()
             out[key]['fused_backward_steps'] = d.steps
