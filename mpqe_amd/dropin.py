@@ -76,7 +76,7 @@ class _Arena(object):
 
 class _Call(object):
     """One margin_loss call as its autograd node remembers it."""
-    __slots__ = ('arena', 'oa', 'og', 'idx', 'key', 'B', 'A', 'margin', 'seq', 'g')
+    __slots__ = ('arena', 'oa', 'og', 'idx', 'key', 'rid', 'B', 'A', 'margin', 'seq', 'g')
 
     def __del__(self):
         arena = getattr(self, 'arena', None)
@@ -87,7 +87,7 @@ class _Call(object):
 class _Rec(object):
     """A packed step (descriptors, descriptor table, plan buffer; ids named per run) and the argument block of its library
     call. One per (formula, batch size) for the forward-only calls, one per sequence of those for a backward pass."""
-    __slots__ = ('ps', 'call', 'addr', 'extra', 'key', 'A', 'B', 'nb')
+    __slots__ = ('ps', 'call', 'addr', 'extra', 'key', 'rid', 'A', 'B', 'nb')
 
 
 class _MarginLossNode(torch.autograd.Function):
@@ -181,6 +181,7 @@ class DropIn(object):
         r = _Rec()
         r.ps = ps = step.pack([dict(formula=f, batch_size=B, weight=1.0) for (f, B) in batches], ids='external')
         r.key, r.nb = key, len(batches)
+        self._nrec = r.rid = getattr(self, '_nrec', 0) + 1
         r.extra = _capi.StepExtra()
         c = r.call = StepCall()
         c.params, c.grads = ctypes.addressof(step.P), ctypes.addressof(step.G)
@@ -342,14 +343,15 @@ class DropIn(object):
                                 B, A)
         step = self.step
         step.margin = float(margin)
+        idx = ar.calls
+        # (a buffer of its own per call: a caller may keep the value -- `loss.detach()` for a log -- beyond its graph)
         loss = torch.empty(2, dtype=torch.float32, device=self.device)
         ar.last_seq = self._launch(r, False, False, ar.a_ptr + 8 * oa, ar.t_ptr + 8 * og, ar.n_ptr + 8 * og, loss)
-        idx = ar.calls
         ar.na, ar.ng, ar.calls = oa + A * B, og + B, idx + 1
         if not torch.is_grad_enabled() or not step.params:
             return loss[0]
         call = _Call()
-        call.arena, call.oa, call.og, call.idx, call.key, call.B, call.A = ar, oa, og, idx, r.key, B, A
+        call.arena, call.oa, call.og, call.idx, call.key, call.rid, call.B, call.A = ar, oa, og, idx, r.key, r.rid, B, A
         call.margin, call.g = step.margin, None
         self._seq = seq = self._seq + 1
         call.seq = seq
@@ -431,8 +433,8 @@ class DropIn(object):
             nids += (c.A + 2) * c.B
         groups.append(cur)
         for grp in groups:
-            key = tuple(c.key for c in grp)
-            r = self._multi.get(key) or self._record(self._multi, key, key)
+            key = tuple(c.rid for c in grp)            # (ints: the one-batch records' numbers)
+            r = self._multi.get(key) or self._record(self._multi, key, [c.key for c in grp])
             extra = r.extra
             for i, c in enumerate(grp):
                 extra.batch_weight[i] = c.g.data_ptr()

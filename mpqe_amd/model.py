@@ -242,6 +242,12 @@ class RGCNEncoderDecoder(nn.Module):
                     ops.raise_on_flags(err)
 
     # ------------------------------------------------------------------ the fused step behind the entry points
+    def _apply(self, fn, *args, **kwargs):
+        # (.to() / .cuda() / .float(): the parameters move -- the fused step's addresses are taken again at the next call)
+        out = super(RGCNEncoderDecoder, self)._apply(fn, *args, **kwargs)
+        self.__dict__['_dropin_checked'] = False
+        return out
+
     def dropin(self):
         """The model's DropIn (mpqe_amd/dropin.py), or None when this model takes the module path."""
         if not self.fused or self.encode_twice:
@@ -249,6 +255,10 @@ class RGCNEncoderDecoder(nn.Module):
         d = self._dropin_state
         if d is False:
             return None
+        if d is not None and self.__dict__.get('_dropin_checked'):
+            return d                # (nothing moved the parameters since the addresses were taken: _apply resets the flag;
+                                    # FlatOptimizer, which re-homes them, refreshes the step's pointers itself)
+        self.__dict__['_dropin_checked'] = True
         if d is not None and d.stale() and d.refresh():
             return d
         if d is None or d.stale():
