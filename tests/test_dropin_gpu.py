@@ -68,13 +68,13 @@ def test_goldens_through_forward_without_autograd(enc_case):
     np.testing.assert_allclose(_np(s_eval), c.arrays['eval_scores'], **FWD)
 
 
-def _aifb(readout='mp', adaptive=True, D=128, n_formulas=2, per_formula=700, seed=0, weight_decay=0.0):
+def _aifb(readout='mp', adaptive=True, D=128, n_formulas=2, per_formula=700, seed=0, weight_decay=0.0, kg='aifb'):
     from mpqe_amd import synthetic
     from mpqe_amd.data_utils import make_feature_modules
     from mpqe_amd.encoders import DirectEncoder
     from mpqe_amd.model import RGCNEncoderDecoder
     torch.manual_seed(seed)
-    schema = synthetic.make_schema(*synthetic.KG_SHAPES['aifb'], seed=seed)
+    schema = synthetic.make_schema(*synthetic.KG_SHAPES[kg], seed=seed)
     graph = synthetic.SchemaGraph(schema, D)
     graph.full_lists = {m: [int(v) for v in ids] for m, ids in graph.full_lists.items()}
     fm, node_maps = make_feature_modules(schema.ids, D, schema.num_entities)
@@ -137,14 +137,16 @@ def _oracle_loop_body(cpu_params, cfg, node_maps, model, record, inter_weight=0.
     return total
 
 
-@pytest.mark.parametrize('readout,adaptive,wd', [('mp', True, 0.0), ('sum', False, 0.0), ('mlp', True, 1e-3)])
-def test_reference_training_loop_body_against_oracle(readout, adaptive, wd):
+@pytest.mark.parametrize('kg,D,readout,adaptive,wd', [('aifb', 128, 'mp', True, 0.0), ('aifb', 128, 'sum', False, 0.0),
+                                                      ('aifb', 128, 'mlp', True, 1e-3),
+                                                      ('mutag', 256, 'sum', False, 0.0)])      # configs[1] (+ variants), configs[2]
+def test_reference_training_loop_body_against_oracle(kg, D, readout, adaptive, wd):
     """BASELINE configs[1] through the loop body of reference train_helpers.py:76-120: batches from
     get_queries_iterator (data_utils.py:422-426), 11 margin_loss calls, `loss += w * ...`, loss.backward() -- loss and
     every parameter gradient against the oracle; two iterations (fresh windows, p.grad = None in between as
     optimizer.zero_grad leaves it), and the python `random` stream ends where the reference's draws leave it."""
     from mpqe_amd.data_utils import get_queries_iterator
-    schema, node_maps, model, train_queries = _aifb(readout, adaptive, weight_decay=wd)
+    schema, node_maps, model, train_queries = _aifb(readout, adaptive, D=D, weight_decay=wd, kg=kg)
     cpu_params = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
     model = model.to('cuda:0')
     cfg = dict(readout=readout, scatter_op='add', num_layers=3, adaptive=adaptive, weight_decay=wd)
@@ -153,7 +155,7 @@ def test_reference_training_loop_body_against_oracle(readout, adaptive, wd):
     torch.set_num_threads(min(16, max(1, len(__import__('os').sched_getaffinity(0)))))
     d = model.dropin()
     assert d is not None
-    for it in range(2):
+    for it in range(2 if D <= 128 else 1):          # (the D = 256 oracle step takes ~20 s of CPU)
         for p in model.parameters():
             p.grad = None
         record = []
