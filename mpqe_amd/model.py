@@ -242,6 +242,15 @@ class RGCNEncoderDecoder(nn.Module):
                     ops.raise_on_flags(err)
 
     # ------------------------------------------------------------------ the fused step behind the entry points
+    def __getstate__(self):
+        # (copy.deepcopy / torch.save of the whole module: the fused step's bookkeeping -- device buffers, argument blocks,
+        # the C++ pass object -- belongs to THIS object and is rebuilt by the copy at its first call)
+        state = self.__dict__.copy()
+        state['_dropin_state'] = None
+        state['_dropin_checked'] = False
+        state['_err'] = None
+        return state
+
     def _apply(self, fn, *args, **kwargs):
         # (.to() / .cuda() / .float(): the parameters move -- the fused step's addresses are taken again at the next call)
         out = super(RGCNEncoderDecoder, self)._apply(fn, *args, **kwargs)

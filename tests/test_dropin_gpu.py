@@ -241,3 +241,40 @@ def test_evaluation_loops_on_the_fused_forward():
     # one such flip moves the mean percentile by ~3e-5 of its value; exact ties, a negative that is the target, do not flip)
     np.testing.assert_allclose(res[True][0], res[False][0], rtol=1e-5)
     np.testing.assert_allclose(res[True][1], res[False][1], rtol=2e-4)
+
+
+def test_retained_graphs_copies_and_two_models_in_one_pass():
+    """Less common uses of the same calls: backward twice over a retained graph (the ids of the calls are still in their
+    arena: every gradient doubles), a deep copy of a model that has already stepped (its fused-step state is rebuilt, the
+    two train independently), and the losses of two models summed into one backward pass (each model's calls become its own
+    fused step)."""
+    import copy
+    from mpqe_amd.data_utils import get_queries_iterator
+    schema, node_maps, model, train_queries = _aifb('mp', True, D=64, per_formula=200)
+    model = model.to('cuda:0')
+    np.random.seed(1)
+    it = get_queries_iterator(train_queries['3-chain_inter'], 128, model)
+    batch = next(it)
+    random.seed(5)
+    loss = 2.0 * model.margin_loss(*batch)
+    loss.backward(retain_graph=True)
+    g1 = {k: _np(p.grad).copy() for k, p in model.named_parameters()}
+    loss.backward()
+    for k, p in model.named_parameters():
+        np.testing.assert_allclose(_np(p.grad), 2.0 * g1[k], err_msg=k, **BWD)
+    assert model.dropin().steps == 2
+    twin = copy.deepcopy(model)
+    assert twin.dropin() is not model.dropin() and twin.dropin().steps == 0
+    for m in (model, twin):
+        for p in m.parameters():
+            p.grad = None
+    random.seed(5)
+    la = model.margin_loss(*batch)
+    random.seed(5)
+    lb = twin.margin_loss(*batch)
+    np.testing.assert_allclose(la.item(), lb.item(), rtol=1e-6)
+    (la + 3.0 * lb).backward()                       # one pass, two models
+    assert model.dropin().steps == 3 and twin.dropin().steps == 1
+    for (k, p), (_, q) in zip(model.named_parameters(), twin.named_parameters()):
+        np.testing.assert_allclose(_np(p.grad), 0.5 * g1[k], err_msg=k, **BWD)
+        np.testing.assert_allclose(_np(q.grad), 1.5 * g1[k], err_msg=k, **BWD)
