@@ -41,3 +41,31 @@ def test_trained_model_matches_oracle_training():
     assert abs(out['auc_before'] - out['oracle_auc_before']) < 1e-3
     assert abs(out['auc_after'] - out['oracle_auc_after']) < 0.01
     assert out['auc_after'] > out['auc_before'] + 0.05 and out['loss_last20'] < 0.8 * out['loss_first']
+
+
+def test_model_trained_through_the_reference_loop_matches_oracle_training():
+    """The same claim through the reference's OWN calls (mpqe_amd/dropin.py): 150 iterations of the run_train loop body
+    (train_helpers.py:76-120) -- get_queries_iterator batches, model.margin_loss with python's random negatives, `loss += w *
+    ...`, loss.item(), loss.backward(), optimiser -- beside the identical loop through the CPU oracle + torch.optim.Adam.
+    Nothing is recorded and replayed: both runs seed numpy and python's `random` alike, and because the drop-in replays
+    python's stream exactly they meet the same batches and draw the same negatives."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import train_synthetic
+    import torch
+    torch.set_num_threads(min(16, max(1, len(os.sched_getaffinity(0)))))
+    args = argparse.Namespace(kg='small', embed_dim=64, batch_size=64, steps=150, lr=0.01, readout='mp', degree=2,
+                              formulas=2, train_queries=256, test_queries=96, weight_scale=1.0, seed=0, oracle=True,
+                              eval_every=0)
+    out = train_synthetic.run_dropin(args)
+    # one fused step per backward pass (the very first pass outgrows its id arena mid-iteration and is split in two)
+    assert 150 <= out['fused_backward_steps'] <= 152, out['fused_backward_steps']
+    a, b = np.array(out['loss_curve']), np.array(out['oracle_loss_curve'])
+    rel = np.abs(a - b) / np.maximum(np.abs(b), 1e-3)
+    print('loss first %.6f / %.6f, last20 %.6f / %.6f, AUC %.4f -> %.4f (oracle %.4f -> %.4f), max / mean rel dev %.3g / %.3g, %s nodes'
+          % (a[0], b[0], out['loss_last20'], out['oracle_loss_last20'], out['auc_before'], out['auc_after'],
+             out['oracle_auc_before'], out['oracle_auc_after'], float(rel.max()), float(rel.mean()), out['node_impl']))
+    np.testing.assert_allclose(a[:10], b[:10], rtol=1e-4, atol=1e-6)        # same batches, same negatives, same arithmetic
+    assert float(rel.max()) < 0.04 and float(rel.mean()) < 0.003, (float(rel.max()), float(rel.mean()))
+    assert abs(out['auc_before'] - out['oracle_auc_before']) < 1e-3
+    assert abs(out['auc_after'] - out['oracle_auc_after']) < 0.015
+    assert out['auc_after'] > out['auc_before'] + 0.03 and out['loss_last20'] < 0.9 * out['loss_first']

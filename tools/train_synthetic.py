@@ -94,8 +94,11 @@ def main(argv=None):
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--oracle', action='store_true', help='also train through the CPU oracle + torch.optim.Adam and compare')
     ap.add_argument('--eval-every', type=int, default=0)
+    ap.add_argument('--dropin', action='store_true',
+                    help="train through the reference's own loop body and entry points (model.margin_loss, loss.backward(): "
+                         'mpqe_amd/dropin.py) instead of FusedTrainStep.pack / run')
     args = ap.parse_args(argv)
-    out = run(args)
+    out = run_dropin(args) if args.dropin else run(args)
     print(json.dumps(out))
     return out
 
@@ -201,6 +204,113 @@ def run_oracle(args, graph, node_maps, model, cpu_state, train, tq, steps, negs_
     return dict(oracle_seconds=time.perf_counter() - t0, oracle_loss_first=losses[0],
                 oracle_loss_last20=float(np.mean(losses[-20:])), oracle_auc_before=float(auc0), oracle_auc_after=float(auc1),
                 oracle_loss_curve=losses)
+
+
+def _reference_loop(model_like, iterators, query_types, optimizer, steps, margin_loss):
+    """The body of the reference's run_train (train_helpers.py:76-120, post-burn-in phase), verbatim in structure:
+    margin_loss(batch) per query type, `loss += w * ...`, loss.item(), backward, optimizer step. -> the losses."""
+    losses = []
+    for _ in range(steps):
+        optimizer.zero_grad()
+        loss = margin_loss(next(iterators['1-chain']), False)
+        for qt in query_types:
+            if qt == '1-chain':
+                continue
+            if 'inter' in qt:
+                loss += INTER_WEIGHT * margin_loss(next(iterators[qt]), False)
+                loss += INTER_WEIGHT * margin_loss(next(iterators[qt]), True)
+            else:
+                loss += PATH_WEIGHT * margin_loss(next(iterators[qt]), False)
+        losses.append(loss.item())
+        loss.backward()
+        optimizer.step()
+    return losses
+
+
+def run_dropin(args):
+    """End-task run through the reference's OWN entry points (mpqe_amd/dropin.py): the run_train loop body over
+    get_queries_iterator batches, model.margin_loss with python's random negatives, loss.backward(), FlatOptimizer --
+    beside the same loop through the CPU oracle + torch.optim.Adam. Both sides seed numpy (formula draws) and python's
+    `random` (negative draws) alike, and the drop-in replays python's stream exactly, so the two runs see the SAME batches
+    and the SAME negatives without any of them being recorded."""
+    import random
+    from mpqe_amd import evaluation
+    from mpqe_amd.data_utils import get_queries_iterator
+    from mpqe_amd.optim import FlatOptimizer
+    from oracle import ref_cpu            # the checker
+    device = torch.device('cuda:0')
+    schema, graph, node_maps, model, train, test = build(args, device)
+    graph.full_lists = {m: [int(v) for v in ids] for m, ids in graph.full_lists.items()}
+    cpu_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(device)
+    tq = test_dict(test)
+    by_type = {qt: {f: qs for f, qs in train[qt]} for qt in train}
+    order = [qt for qt, _ in __import__('mpqe_amd.synthetic', fromlist=['FULL_MIX']).FULL_MIX]
+    query_types = list(dict.fromkeys(order))
+
+    def iterators(m):
+        np.random.seed(args.seed + 11)
+        return {qt: get_queries_iterator(by_type[qt], args.batch_size, m) for qt in by_type}
+    # ---- the product path
+    with torch.no_grad():
+        auc0, _ = evaluation.eval_auc_queries(tq, model, batch_size=128, seed=0)
+    assert model.dropin() is not None, 'the model did not take the fused step'
+    opt = FlatOptimizer(model.dropin().step, lr=args.lr, opt='adam')
+    random.seed(args.seed + 12)
+    t0 = time.perf_counter()
+    losses = _reference_loop(model, iterators(model), query_types, opt, args.steps,
+                             lambda batch, hard: model.margin_loss(*batch, hard_negatives=hard))
+    torch.cuda.synchronize()
+    train_s = time.perf_counter() - t0
+    model.dropin()._check_mirror()
+    with torch.no_grad():
+        auc1, _ = evaluation.eval_auc_queries(tq, model, batch_size=128, seed=0)
+    out = dict(kg=args.kg, embed_dim=args.embed_dim, batch_size=args.batch_size, steps=args.steps, readout=args.readout,
+               train_seconds=train_s, fused_backward_steps=model.dropin().steps, node_impl=model.dropin().node_impl,
+               loss_first=losses[0], loss_last20=float(np.mean(losses[-20:])), auc_before=float(auc0), auc_after=float(auc1),
+               loss_curve=losses)
+    if not args.oracle:
+        return out
+    # ---- the same loop through the oracle
+    params = {k: v.clone().requires_grad_(True) for k, v in cpu_state.items()}
+    cfg = dict(readout=args.readout, scatter_op='add', num_layers=3, adaptive=args.readout == 'mp', weight_decay=0)
+    node_map = node_maps.cpu() if torch.is_tensor(node_maps) else node_maps
+    oopt = torch.optim.Adam(list(params.values()), lr=args.lr)
+    for p in params.values():               # (dense Adam over every parameter from step 1: see run_oracle)
+        p.grad = torch.zeros_like(p)
+
+    class ZeroInPlace(object):
+        def zero_grad(self):
+            oopt.zero_grad(set_to_none=False)
+
+        def step(self):
+            oopt.step()
+
+    def oracle_margin_loss(batch, hard):
+        formula, queries = batch[0], batch[1]
+        if hard:                                                        # reference model.py:470-476, literally
+            negs = [random.choice(q.hard_neg_samples) for q in queries]
+        elif formula.query_type == '1-chain':
+            negs = [random.choice(graph.full_lists[formula.target_mode]) for _ in queries]
+        else:
+            negs = [random.choice(q.neg_samples) for q in queries]
+        col = ref_cpu.collate(formula, queries, model.rel_ids, model.mode_ids)
+        return ref_cpu.margin_loss(params, cfg, node_map, formula, col, np.array([q.target_node for q in queries]), np.array(negs))
+
+    class Oracle(object):
+        def forward(self, formula, queries, tg, neg_nodes=None, neg_lengths=None):
+            col = ref_cpu.collate(formula, queries, model.rel_ids, model.mode_ids)
+            return ref_cpu.forward(params, cfg, node_map, formula, col, tg, neg_nodes, neg_lengths)
+    with torch.no_grad():
+        oauc0, _ = evaluation.eval_auc_queries(tq, Oracle(), batch_size=128, seed=0)
+    random.seed(args.seed + 12)
+    t0 = time.perf_counter()
+    olosses = _reference_loop(None, iterators(model), query_types, ZeroInPlace(), args.steps, oracle_margin_loss)
+    with torch.no_grad():
+        oauc1, _ = evaluation.eval_auc_queries(tq, Oracle(), batch_size=128, seed=0)
+    out.update(oracle_seconds=time.perf_counter() - t0, oracle_loss_first=olosses[0], oracle_loss_last20=float(np.mean(olosses[-20:])),
+               oracle_auc_before=float(oauc0), oracle_auc_after=float(oauc1), oracle_loss_curve=olosses)
+    return out
 
 
 if __name__ == '__main__':
