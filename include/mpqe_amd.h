@@ -486,7 +486,8 @@ int mpqe_step_forward_backward(const mpqe_step_params_t *params_host, const mpqe
  *                    order -- what the evaluation form scores against ragged negative lists (model.py:454-460,
  *                    mpqe_cosine_fwd with q_row). Chain form only (MPQE_ERR_UNSUPPORTED otherwise).
  *   notify           two 32-bit words the DEVICE can write and the host can read without a call (pinned host memory), or
- *                    NULL: the workgroup that forms the loss in the call's LAST launch stores notify[1] = the error word as it
+ *                    NULL: the workgroup that forms the loss (behind every launch and workgroup of the call that reads the
+ *                    ids) stores notify[1] = the error word as it
  *                    stands, then notify[0] = notify_value. Once the host reads notify_value there, every launch of the call
  *                    that reads anchor_ids / targets / negs has run (the id arrays may be refilled), and notify[1] tells
  *                    whether a bad id was met -- the reference raises IndexError inside forward (encoders.py:40-43); a host

@@ -50,8 +50,32 @@ def load_pyhost():
         lib = load()
         mod.bind(ctypes.cast(lib.mpqe_host_random_choice, ctypes.c_void_p).value)
         mod.step_fn = ctypes.cast(lib.mpqe_step_forward_backward_ex, ctypes.c_void_p).value
+        mod.mt_ok = _mt_selftest(mod)
         _pyhost = mod
     return _pyhost
+
+
+def _mt_selftest(mod):
+    """May _pyhost.choice_mt read this interpreter's Mersenne-Twister state in place? Only if its outputs AND the state it
+    leaves behind equal getrandbits' on a copy of the same generator, across regeneration boundaries; otherwise the drop-in
+    keeps to _pyhost.choice (raw outputs through getrandbits, a few us more per call)."""
+    import random
+    import sys
+    try:
+        import _random
+        if sys.implementation.name != 'cpython' or not issubclass(random.Random, _random.Random):
+            return False
+        mod.mt_bind(_random.Random, 0)
+        a = random.Random(20240229)
+        b = random.Random()
+        b.setstate(a.getstate())
+        for n in (1, 7, 616, 1, 700, 1300):
+            if a.getrandbits(32 * n).to_bytes(4 * n, 'little') != mod.mt_words(b, n) or a.getstate() != b.getstate():
+                return False
+        mod.mt_bind(_random.Random, 1)
+        return True
+    except Exception:          # noqa: BLE001 -- any surprise: the slower path
+        return False
 
 
 _autograd_node = None

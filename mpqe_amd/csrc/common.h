@@ -57,6 +57,25 @@ __device__ __forceinline__ void flag_error(int32_t *err, int32_t bit) {
     if (err) atomicOr(err, bit);
 }
 
+// A word handed between workgroups of ONE launch (they may sit on different XCDs, each with an L2 of its own): written
+// through / read at agent scope, no L2 write-back. (The host emulator runs a launch's workgroups one after the other.)
+template <typename T>
+__device__ __forceinline__ void agent_store(T *p, T v) {
+#ifdef MPQE_EMU
+    *p = v;
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+template <typename T>
+__device__ __forceinline__ T agent_load(const T *p) {
+#ifdef MPQE_EMU
+    return *p;
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -290,6 +290,92 @@ struct ZeroSegs {
     int count;
 };
 #define PREP_ZERO_FLOATS_PER_BLOCK 8192      // 256 threads x 8 x float4
+// Chain form: every chain block left the sum of its (<= 16) hinge terms in block_terms, and everything the
+// reduction needs to know about the batches comes by value -- no dependent loads in front of the sums.
+struct LossMeta {
+    int nb, chain;
+    int B[MPQE_STEP_MAX_BATCHES], blk_off[MPQE_STEP_MAX_BATCHES + 1];
+    float weight[MPQE_STEP_MAX_BATCHES];
+};
+__device__ __forceinline__ void loss_block_chain(const LossMeta &lm, const float *__restrict__ bterms,
+                                                 float *__restrict__ loss, float *mean, int nwaves) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int bi = w; bi < lm.nb; bi += nwaves) {
+        float s = 0.f;
+        for (int i = lm.blk_off[bi] + lane; i < lm.blk_off[bi + 1]; i += 64) s += bterms[i];
+        s = wave_sum(s);
+        if (lane == 0) {
+            mean[bi] = s / (float)lm.B[bi];
+            loss[1 + bi] = mean[bi];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float total = 0.f;
+        for (int bi = 0; bi < lm.nb; ++bi) total += lm.weight[bi] * mean[bi];
+        loss[0] = total;
+    }
+}
+
+// Forward-only step in the chain form: the loss reduction, the epoch advance and the caller's notification ride in the chain
+// launch itself -- every workgroup of the launch counts itself out as it ends, and the LAST one to end does what
+// step_loss_kernel does as a launch of its own (one launch per margin_loss call of the drop-in entry points instead of two:
+// ~2.5 us of host time and ~6 us of device time per call). The chain workgroups' block_terms are written through
+// (agent-scope stores, acknowledged before the count) and read back the same way: no L2 write-back.
+struct FinArgs {
+    unsigned *count;          // workgroups of this launch that have ended (the last one leaves 0 behind); NULL: not this form
+    float *loss;
+    const float *bterms;
+    unsigned *epoch_f;
+    int bump_b;
+    unsigned *notify;
+    unsigned notify_value;
+    const int32_t *err;
+    LossMeta lm;
+};
+__device__ __forceinline__ void chain_finish(const FinArgs &fin, float *smem) {
+    __syncthreads();          // (every wave is through its role: the state buffers are free)
+    unsigned *flag = reinterpret_cast<unsigned *>(smem);
+    float *mean = smem + 16;
+    if (threadIdx.x == 0) {
+#ifndef MPQE_EMU
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (this thread's block_terms store has been acknowledged)
+#endif
+        *flag = atomicAdd(fin.count, 1u) + 1u == gridDim.x ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*flag == 0u) return;
+    const LossMeta &lm = fin.lm;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = (int)(blockDim.x >> 6);
+    for (int bi = w; bi < lm.nb; bi += nwaves) {              // (step_loss_kernel's sums, term for term)
+        float s = 0.f;
+        for (int i = lm.blk_off[bi] + lane; i < lm.blk_off[bi + 1]; i += 64)
+            s += agent_load(fin.bterms + i);
+        s = wave_sum(s);
+        if (lane == 0) {
+            mean[bi] = s / (float)lm.B[bi];
+            fin.loss[1 + bi] = mean[bi];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float total = 0.f;
+        for (int bi = 0; bi < lm.nb; ++bi) total += lm.weight[bi] * mean[bi];
+        fin.loss[0] = total;
+        agent_store(fin.count, 0u);
+        // (the next step's forward granules get a new tag, step_uniform.h; the transposed copies' count a new target)
+        *fin.epoch_f = *fin.epoch_f + 1u;
+        if (fin.bump_b) *(fin.epoch_f + 16) = *(fin.epoch_f + 16) + 1u;
+        if (fin.notify) {
+            fin.notify[1] = fin.err ? (unsigned)agent_load(fin.err) : 0u;
+#ifndef MPQE_EMU
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");        // (system scope: the flags word is out before the number)
+#endif
+            fin.notify[0] = fin.notify_value;
+        }
+    }
+}
+
 struct PrepArgs {
     UArgs ua;
     TSortArgs ts;             // the touch plan's sort (MPQE_STEP_BUILD_TOUCH): workgroups [0, sblocks) of the launch --
@@ -434,10 +520,9 @@ __device__ __forceinline__ void post_block(const StepDev *__restrict__ sd, const
                                            float *smem);
 __device__ __forceinline__ void zmat_block(const ZMat *__restrict__ zmats, int zper, int zb, int D, const GradPtrs &gp);
 
-template <int NCB, int KS, int NW = 4, bool RO = false>
-__global__ __launch_bounds__(64 * NW) void step_chain_kernel(const StepDev *__restrict__ sd, LayerPtrs lp,
-                                                             TablePtrs tabs, ChainArgs ca, PrepArgs pa, PostArgs po) {
-    __shared__ __attribute__((aligned(16))) ChainLds<NCB, KS, NW> S;
+template <int NCB, int KS, int NW, bool RO>
+__device__ __forceinline__ void chain_roles(const StepDev *__restrict__ sd, const LayerPtrs &lp, const TablePtrs &tabs,
+                                            ChainArgs &ca, const PrepArgs &pa, const PostArgs &po, ChainLds<NCB, KS, NW> &S) {
     // role of this workgroup (uniform): chain workgroup, prologue work in front of / behind them, zero fill, then the
     // post roles: a producer is never queued behind a consumer that waits for it
     int bid = (int)blockIdx.x, role;
@@ -520,6 +605,14 @@ __global__ __launch_bounds__(64 * NW) void step_chain_kernel(const StepDev *__re
             post_block<(sizeof(S) >= 4 * 64 * GWR_LDT * sizeof(float)) ? 4 : 1>(sd, lp, po, (pb >> 3) * po.na + rk,
                                                                                 reinterpret_cast<float *>(&S));
     }
+}
+
+template <int NCB, int KS, int NW = 4, bool RO = false>
+__global__ __launch_bounds__(64 * NW) void step_chain_kernel(const StepDev *__restrict__ sd, LayerPtrs lp,
+                                                             TablePtrs tabs, ChainArgs ca, PrepArgs pa, PostArgs po, FinArgs fin) {
+    __shared__ __attribute__((aligned(16))) ChainLds<NCB, KS, NW> S;
+    chain_roles<NCB, KS, NW, RO>(sd, lp, tabs, ca, pa, po, S);
+    if (fin.count) chain_finish(fin, reinterpret_cast<float *>(&S));
 }
 
 // level form: zero fill of the gradient buffers (MPQE_STEP_ZERO_GRADS) as a launch of its own
@@ -819,33 +912,6 @@ __device__ __forceinline__ void loss_block(const StepDev *__restrict__ sd, const
     if (threadIdx.x == 0) {
         float total = 0.f;
         for (int bi = 0; bi < sd->nb; ++bi) total += sd->b[bi].weight * mean[bi];
-        loss[0] = total;
-    }
-}
-
-// Chain form: every chain block left the sum of its (<= 16) hinge terms in block_terms, and everything the
-// reduction needs to know about the batches comes by value -- no dependent loads in front of the sums.
-struct LossMeta {
-    int nb, chain;
-    int B[MPQE_STEP_MAX_BATCHES], blk_off[MPQE_STEP_MAX_BATCHES + 1];
-    float weight[MPQE_STEP_MAX_BATCHES];
-};
-__device__ __forceinline__ void loss_block_chain(const LossMeta &lm, const float *__restrict__ bterms,
-                                                 float *__restrict__ loss, float *mean, int nwaves) {
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int bi = w; bi < lm.nb; bi += nwaves) {
-        float s = 0.f;
-        for (int i = lm.blk_off[bi] + lane; i < lm.blk_off[bi + 1]; i += 64) s += bterms[i];
-        s = wave_sum(s);
-        if (lane == 0) {
-            mean[bi] = s / (float)lm.B[bi];
-            loss[1 + bi] = mean[bi];
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float total = 0.f;
-        for (int bi = 0; bi < lm.nb; ++bi) total += lm.weight[bi] * mean[bi];
         loss[0] = total;
     }
 }
@@ -1936,6 +2002,7 @@ extern "C" int mpqe_step_forward_backward_ex(const mpqe_step_params_t *P, const 
         }
         hipLaunchKernelGGL(step_ro_reg_kernel, dim3(1), dim3(1024), 0, s, rr);
     };
+    bool loss_in_chain = false;
     if (use_chain) {
         // assemble -> levels -> scores (-> levels back -> anchor-table gradients): one launch per lane
         ChainArgs ca;
@@ -2043,22 +2110,38 @@ extern "C" int mpqe_step_forward_backward_ex(const mpqe_step_params_t *P, const 
             }
             grid_blocks += pa.strail;
             dim3 cgrid((unsigned)grid_blocks);
+            // forward-only: loss, epoch advance and notification by the launch's last workgroup (chain_finish) instead of a
+            // launch behind it. mpqe_debug_option LOSS_LAUNCH = 1: step_loss_kernel as before
+            FinArgs fin;
+            memset(&fin, 0, sizeof(fin));
+            if (!backward && NL == 1 && !dbg_on("LOSS_LAUNCH")) {
+                fin.count = epoch_f + 42;
+                fin.loss = loss;
+                fin.bterms = bterms;
+                fin.epoch_f = epoch_f;
+                fin.bump_b = pa.tblocks > 0 ? 1 : 0;
+                fin.notify = notify;
+                fin.notify_value = notify_value;
+                fin.err = err;
+                fin.lm = lm;
+                loss_in_chain = true;
+            }
             mark(s);
             if (hp.ro_chain) {
                 // (a learned readout on the chain: its own instances -- the others' code stays as it was)
-                if (D == 64) hipLaunchKernelGGL((step_chain_kernel<1, 1, 4, true>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po);
+                if (D == 64) hipLaunchKernelGGL((step_chain_kernel<1, 1, 4, true>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po, fin);
                 else if (D == 128 && (P->flags & MPQE_STEP_NO_KSPLIT))
-                    hipLaunchKernelGGL((step_chain_kernel<2, 1, 4, true>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po);
-                else if (D == 128) hipLaunchKernelGGL((step_chain_kernel<4, 2, 4, true>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po);
-                else hipLaunchKernelGGL((step_chain_kernel<4, 1, 4, true>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po);
-            } else if (D == 64) hipLaunchKernelGGL((step_chain_kernel<1, 1>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po);
+                    hipLaunchKernelGGL((step_chain_kernel<2, 1, 4, true>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po, fin);
+                else if (D == 128) hipLaunchKernelGGL((step_chain_kernel<4, 2, 4, true>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po, fin);
+                else hipLaunchKernelGGL((step_chain_kernel<4, 1, 4, true>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po, fin);
+            } else if (D == 64) hipLaunchKernelGGL((step_chain_kernel<1, 1>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po, fin);
             else if (D == 128 && (P->flags & MPQE_STEP_NO_KSPLIT))
-                hipLaunchKernelGGL((step_chain_kernel<2, 1>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po);
+                hipLaunchKernelGGL((step_chain_kernel<2, 1>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po, fin);
             else if (D == 128 && (P->flags & MPQE_STEP_EIGHT_WAVES))
-                hipLaunchKernelGGL((step_chain_kernel<2, 2, 8>), cgrid, dim3(512), 0, s, sd, lp, tabs, ca, pa, po);
+                hipLaunchKernelGGL((step_chain_kernel<2, 2, 8>), cgrid, dim3(512), 0, s, sd, lp, tabs, ca, pa, po, fin);
             else if (D == 128)
-                hipLaunchKernelGGL((step_chain_kernel<4, 2>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po);
-            else hipLaunchKernelGGL((step_chain_kernel<4, 1>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po);
+                hipLaunchKernelGGL((step_chain_kernel<4, 2>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po, fin);
+            else hipLaunchKernelGGL((step_chain_kernel<4, 1>), cgrid, dim3(256), 0, s, sd, lp, tabs, ca, pa, po, fin);
             mark(s);
         }
         if (!backward) {
@@ -2066,9 +2149,10 @@ extern "C" int mpqe_step_forward_backward_ex(const mpqe_step_params_t *P, const 
                 (void)hipEventRecord(reinterpret_cast<hipEvent_t>(lanes->join_event[l]), ls[l]);
                 (void)hipStreamWaitEvent(s, reinterpret_cast<hipEvent_t>(lanes->join_event[l]), 0);
             }
-            hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss, lm, bterms,
-                               use_chain ? epoch_f : (unsigned *)nullptr, pa.tblocks > 0 ? 1 : 0, notify, notify_value,
-                               (const int32_t *)err);
+            if (!loss_in_chain)
+                hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss, lm, bterms,
+                                   use_chain ? epoch_f : (unsigned *)nullptr, pa.tblocks > 0 ? 1 : 0, notify, notify_value,
+                                   (const int32_t *)err);
             if (learned) ro_regulariser(false);
             return mpqe_launch_status();
         }

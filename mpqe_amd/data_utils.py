@@ -136,6 +136,9 @@ class FormulaIds(object):
         for i in range(A):
             self.anchors[:, i] = [q.anchor_nodes[i] for q in queries]
         self.anchors_sm = np.ascontiguousarray(self.anchors.T)          # slot-major [A, Nq]: the fused step's id layout
+        # (+ addresses: a window of these arrays is plain pointer arithmetic for the host routines, csrc/host/pyhost.c)
+        self.targets_ptr = self.targets.ctypes.data
+        self.anchors_sm_ptr, self.anchors_sm_stride = self.anchors_sm.ctypes.data, 8 * n
         self.neg = self._csr([q.neg_samples for q in queries])
         self.hard = self._csr([getattr(q, 'hard_neg_samples', None) for q in queries])
 

@@ -87,7 +87,7 @@ class _Call(object):
 class _Rec(object):
     """A packed step (descriptors, descriptor table, plan buffer; ids named per run) and the argument block of its library
     call. One per (formula, batch size) for the forward-only calls, one per sequence of those for a backward pass."""
-    __slots__ = ('ps', 'call', 'addr', 'extra', 'key', 'rid', 'A', 'B', 'nb')
+    __slots__ = ('ps', 'call', 'addr', 'extra', 'key', 'rid', 'A', 'B', 'nb', 'P_seen', 'ws_seen')
 
 
 class _MarginLossNode(torch.autograd.Function):
@@ -137,6 +137,7 @@ class DropIn(object):
         self._pending = []         # calls whose nodes ran in the current backward pass
         self._seq = 0
         self._full_lists = {}
+        self._grb = self._rng = None
         # [0] the number of the last library call whose id reads are over, [1] the error word as that call left it: written
         # by the device (mpqe_step_extra_t.notify), read here without a call
         self._note = torch.zeros(2, dtype=torch.int32, pin_memory=True)
@@ -191,6 +192,9 @@ class DropIn(object):
         c.err = step.err.data_ptr()
         c.touch = ps.touch_ptr
         r.addr = ctypes.addressof(c)
+        # (margin_loss' one-call host path, csrc/host/pyhost.c: margin_call, takes the block as _launch last left it: valid
+        # while the step's parameter struct and workspace are the ones seen then)
+        r.P_seen = r.ws_seen = None
         cache[key] = r
         return r
 
@@ -234,6 +238,9 @@ class DropIn(object):
         if st != 0:
             _capi.check(self.lib, st, 'mpqe_step_forward_backward_ex')
         bufs.desc_resident = True
+        if not backward and sp is None and extra is r.extra:
+            c.upload_desc = 0
+            r.P_seen, r.ws_seen = step.P, step._ws
         return seq
 
     def _done(self, seq):
@@ -275,6 +282,25 @@ class DropIn(object):
             c = self._full_lists[mode] = (lst, arr, arr.ctypes.data)
         return c
 
+    def _choice(self, lens, len_all, base, cand, B, out_ptr):
+        """random.choice per query over python's own generator (csrc/host/pyhost.c): its state read in place when the
+        interpreter passed the self test (mpqe_amd/_lib.py: _mt_selftest), else raw outputs through getrandbits."""
+        rng = self._mt()
+        if rng is not None:
+            self.host.choice_mt(rng, lens, len_all, base, cand, B, out_ptr)
+        else:
+            self.host.choice(random.getrandbits, lens, len_all, base, cand, B, out_ptr)
+
+    def _mt(self):
+        """python's generator when its state may be read in place (else None: raw outputs through getrandbits)."""
+        grb = random.getrandbits
+        if grb is not self._grb:               # (first call, or somebody re-bound random.getrandbits)
+            rng = getattr(grb, '__self__', None)
+            ok = (self.host.mt_ok and isinstance(rng, random.Random)
+                  and type(rng).getrandbits is random.Random.getrandbits)         # (not SystemRandom or another override)
+            self._grb, self._rng = grb, rng if ok else None
+        return self._rng
+
     def _fill_ids(self, ar, formula, queries, anchor_ids, ids, hard_negatives, B, A):
         """Anchors, targets and freshly drawn negatives of one call into the arena (reference model.py:466-477,
         data_utils.py:382-383). The negatives are random.choice's own draws: csrc/host/pyhost.c: choice takes raw outputs
@@ -309,14 +335,14 @@ class DropIn(object):
             csr = ids.fi.hard if fast else None
         elif formula.query_type == "1-chain":
             _lst, full, full_ptr = self._full_list(formula.target_mode)
-            self.host.choice(random.getrandbits, 0, full.shape[0], 0, full_ptr, B, out_ptr)
+            self._choice(0, full.shape[0], 0, full_ptr, B, out_ptr)
             self.fast_sampled += 1
             return oa, og
         else:
             csr = ids.fi.neg if fast else None
         if csr is not None:
             lo = 8 * ids.start
-            self.host.choice(random.getrandbits, csr[5] + lo, 0, csr[4] + lo, csr[3], B, out_ptr)
+            self._choice(csr[5] + lo, 0, csr[4] + lo, csr[3], B, out_ptr)
             self.fast_sampled += 1
         else:
             ar.n_np[og: og + B] = self.model.sample_negatives(formula, queries, hard_negatives)
@@ -339,14 +365,50 @@ class DropIn(object):
         ar = self._arena
         if ar is None or not ar.fits(A * B, B):
             ar = self._arena_for(A * B, B)
-        oa, og = self._fill_ids(ar, formula, queries, anchor_ids, None if q_graphs is None else q_graphs.ids, hard_negatives,
-                                B, A)
         step = self.step
-        step.margin = float(margin)
+        step.margin = margin = float(margin)
         idx = ar.calls
         # (a buffer of its own per call: a caller may keep the value -- `loss.detach()` for a log -- beyond its graph)
         loss = torch.empty(2, dtype=torch.float32, device=self.device)
-        ar.last_seq = self._launch(r, False, False, ar.a_ptr + 8 * oa, ar.t_ptr + 8 * og, ar.n_ptr + 8 * og, loss)
+        ids = None if q_graphs is None else q_graphs.ids
+        rng = self._mt()
+        if (ids is not None and rng is not None and r.P_seen is step.P and r.ws_seen is step._ws and ids.end - ids.start == B
+                and ids.fi.A == A and (anchor_ids is None or anchor_ids is ids.anchor_ref)
+                and torch._C._cuda_getDevice() == self.dev_index):
+            # the batch is a window of its formula's id arrays and this record has run before: ONE host call copies the
+            # window into the arena, draws the negatives and launches (csrc/host/pyhost.c: margin_call)
+            fi, lo = ids.fi, 8 * ids.start
+            if hard_negatives:
+                if "inter" not in formula.query_type:
+                    raise Exception("Hard negative examples can only be used with "
+                                    "intersection queries")
+                csr = fi.hard
+            elif formula.query_type == "1-chain":
+                _lst, full, full_ptr = self._full_list(formula.target_mode)
+                csr = (None, None, None, full_ptr, 0, 0, full.shape[0])
+            else:
+                csr = fi.neg
+        else:
+            csr = None
+        oa, og = ar.na, ar.ng
+        if csr is not None:
+            step.P.flags = step.flags | r.ps.step_flags
+            self._calls = seq = (self._calls + 1) & 0xffffffff
+            if len(csr) == 7:          # (one list for every query)
+                lens_p, len_all, base_p = 0, csr[6], 0
+            else:
+                lens_p, len_all, base_p = csr[5] + lo, 0, csr[4] + lo
+            st = self.host.margin_call(rng, self._step_fn, r.addr, A, B, fi.anchors_sm_ptr + lo, fi.anchors_sm_stride,
+                                       fi.targets_ptr + lo, ar.a_ptr + 8 * oa, ar.t_ptr + 8 * og, ar.n_ptr + 8 * og,
+                                       lens_p, len_all, base_p, csr[3], loss.data_ptr(),
+                                       torch._C._cuda_getCurrentRawStream(self.dev_index), margin, seq)
+            if st != 0:
+                _capi.check(self.lib, st, 'mpqe_step_forward_backward_ex')
+            ar.last_seq = seq
+            self.fast_sampled += 1
+        else:
+            self._fill_ids(ar, formula, queries, anchor_ids, ids, hard_negatives, B, A)
+            ar.last_seq = self._launch(r, False, False, ar.a_ptr + 8 * oa, ar.t_ptr + 8 * og, ar.n_ptr + 8 * og, loss)
         ar.na, ar.ng, ar.calls = oa + A * B, og + B, idx + 1
         if not torch.is_grad_enabled() or not step.params:
             return loss[0]

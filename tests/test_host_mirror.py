@@ -162,6 +162,14 @@ def test_host_random_choice_replays_pythons_stream():
         random.seed(trial)
         words = host.choice(random.getrandbits, lens.ctypes.data, 0, off.ctypes.data, flat.ctypes.data, B, out.ctypes.data)
         assert out.tolist() == ref and random.getstate() == state and words >= B
+        # (a') the same with the generator's state read in place (csrc/host/pyhost.c: choice_mt), where the interpreter passed
+        # the self test
+        if host.mt_ok:
+            out1 = np.full(B, -1, dtype=np.int64)
+            random.seed(trial)
+            w1 = host.choice_mt(random.getrandbits.__self__, lens.ctypes.data, 0, off.ctypes.data, flat.ctypes.data, B,
+                                out1.ctypes.data)
+            assert out1.tolist() == ref and random.getstate() == state and w1 == words
         # (b) the library routine alone, driven round by round through ctypes
         out2 = np.full(B, -1, dtype=np.int64)
         cur = np.zeros(2, dtype=np.int64)
@@ -182,6 +190,13 @@ def test_host_random_choice_replays_pythons_stream():
     random.seed(99)
     host.choice(random.getrandbits, 0, len(full), 0, arr.ctypes.data, 512, out.ctypes.data)
     assert out.tolist() == ref and random.getstate() == state
+    if host.mt_ok:
+        out[:] = -1
+        random.seed(99)
+        host.choice_mt(random.getrandbits.__self__, 0, len(full), 0, arr.ctypes.data, 512, out.ctypes.data)
+        assert out.tolist() == ref and random.getstate() == state
+        with pytest.raises(RuntimeError):          # (not a random.Random: refused, nothing read)
+            host.choice_mt(object(), 0, len(full), 0, arr.ctypes.data, 512, out.ctypes.data)
     # an empty list: IndexError, as random.choice([]) raises
     lens = np.array([3, 0, 2], dtype=np.int64)
     off = np.array([0, 3, 3, 5], dtype=np.int64)
