@@ -491,12 +491,24 @@ int mpqe_step_forward_backward(const mpqe_step_params_t *params_host, const mpqe
  *                    stands, then notify[0] = notify_value. Once the host reads notify_value there, every launch of the call
  *                    that reads anchor_ids / targets / negs has run (the id arrays may be refilled), and notify[1] tells
  *                    whether a bad id was met -- the reference raises IndexError inside forward (encoders.py:40-43); a host
- *                    mirror that must not synchronise per call polls this word instead.                                  */
+ *                    mirror that must not synchronise per call polls this word instead.
+ *   xcd_shift        0 .. 7: a FORWARD-ONLY step in the chain form places its workgroups `xcd_shift` XCDs further round the
+ *                    chip (a batch's graph blocks are dealt to one XCD per 32, so that its matrices stay in one L2; workgroup
+ *                    b of a launch runs on XCD b % 8). Forward-only steps of SEVERAL packed steps issued on different streams
+ *                    at once (each with a workspace of its own) then run side by side instead of sharing the CUs of XCD 0.
+ *                    Results do not depend on it.
+ *   join_event,      join_event != NULL (a hipEvent_t; join_stream a hipStream_t, NULL = the null stream): behind the call's
+ *   join_stream      last launch the library records join_event on `stream` and makes join_stream wait for it -- the call ran
+ *                    on a side stream, its consumer is enqueued on join_stream. (The other direction -- `stream` waiting for
+ *                    the parameters' last writer -- is the caller's.)                                                    */
 typedef struct {
     const float *batch_weight[MPQE_STEP_MAX_BATCHES];
     float *query_out;
     uint32_t *notify;
     uint32_t notify_value;
+    int32_t xcd_shift;
+    void *join_event;
+    void *join_stream;
 } mpqe_step_extra_t;
 int mpqe_step_forward_backward_ex(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,
                                   int num_batches, const int64_t *anchor_ids, const int64_t *targets,

@@ -58,7 +58,7 @@ STEP_MAX_LANES = 4
 class StepExtra(ctypes.Structure):
     # include/mpqe_amd.h: mpqe_step_extra_t
     _fields_ = [('batch_weight', c_void_p * STEP_MAX_BATCHES), ('query_out', c_void_p), ('notify', c_void_p),
-                ('notify_value', ctypes.c_uint32)]
+                ('notify_value', ctypes.c_uint32), ('xcd_shift', ctypes.c_int32), ('join_event', c_void_p), ('join_stream', c_void_p)]
 
 
 class StepLanes(ctypes.Structure):

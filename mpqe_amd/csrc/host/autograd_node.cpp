@@ -11,6 +11,7 @@
 //   out = make_loss(p, call_id, buf)       0-dim tensor over buf's first element (its own tensor, not an autograd view: the
 //                                          reference adds into the first loss in place), grad_fn = the node
 //   p.take_dead() -> list[int]             call ids whose nodes have been destroyed (their graphs freed) since the last call
+//   storage_use_count(t) -> int            holders of t's storage
 //
 // No arithmetic of the data path lives here.
 #include <torch/extension.h>
@@ -94,11 +95,15 @@ at::Tensor make_loss(const std::shared_ptr<Pass> &pass, int64_t id, const at::Te
     return out;
 }
 
+// holders of a tensor's storage (the drop-in's per-lane pool of loss words re-uses one only while it holds the last reference)
+int64_t storage_use_count(const at::Tensor &t) { return static_cast<int64_t>(t.storage().use_count()); }
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     py::class_<Pass, std::shared_ptr<Pass>>(m, "Pass")
         .def(py::init<py::object>())
         .def("take_dead", &Pass::take_dead);
+    m.def("storage_use_count", &storage_use_count, "number of holders of the tensor's storage");
     m.def("make_loss", &make_loss, "0-dim loss tensor over buf[0] whose grad_fn defers to the pass' flush");
 }

@@ -231,14 +231,15 @@ static PyObject *py_step_call(PyObject *self, PyObject *args) {
 }
 
 /* margin_call(rng, fn, block, A, B, anchors, anchors_stride, targets, a_dst, t_dst, n_dst, lens, len_all, base, cand, loss,
- *             stream, margin, notify_value) -> status
+ *             stream, margin, notify_value, join_stream) -> status
  * One forward-only margin_loss call of the drop-in (mpqe_amd/dropin.py) from a batch that is a window of its formula's id
  * arrays: the window's anchors (slot-major rows `anchors + i * anchors_stride`, B ids each) and targets copied into the
  * pinned arena the step reads, the negatives drawn (choice_mt), the changing fields of the call's StepCall block written,
- * the library called. Everything else in the block -- and block->extra->notify -- is as the caller left it. */
+ * the library called (block->extra->join_event set: the call runs on a side stream and the consumer's stream `join_stream`
+ * -- 0: the null stream -- waits for it). Everything else in the block -- and block->extra->notify -- is as the caller left it. */
 static PyObject *py_margin_call(PyObject *self, PyObject *const *args, Py_ssize_t nargs) {
-    if (nargs != 19) {
-        PyErr_SetString(PyExc_TypeError, "margin_call takes 19 arguments");
+    if (nargs != 20) {
+        PyErr_SetString(PyExc_TypeError, "margin_call takes 20 arguments");
         return NULL;
     }
     PyObject *rng = args[0];
@@ -251,6 +252,8 @@ static PyObject *py_margin_call(PyObject *self, PyObject *const *args, Py_ssize_
     if (margin == -1.0 && PyErr_Occurred()) return NULL;
     const unsigned long long nv = PyLong_AsUnsignedLongLongMask(args[18]);
     if (nv == (unsigned long long)-1 && PyErr_Occurred()) return NULL;
+    const unsigned long long js = PyLong_AsUnsignedLongLongMask(args[19]);
+    if (js == (unsigned long long)-1 && PyErr_Occurred()) return NULL;
     const step_fn fn = (step_fn)(uintptr_t)v[0];
     StepCall *c = (StepCall *)(uintptr_t)v[1];
     const long long A = (long long)v[2], B = (long long)v[3];
@@ -288,6 +291,7 @@ static PyObject *py_margin_call(PyObject *self, PyObject *const *args, Py_ssize_
     c->scores_pos = c->scores_neg = NULL;
     c->stream = (void *)(uintptr_t)v[15];
     ((mpqe_step_extra_t *)(uintptr_t)c->extra)->notify_value = (uint32_t)nv;
+    ((mpqe_step_extra_t *)(uintptr_t)c->extra)->join_stream = (void *)(uintptr_t)js;
     const int st = fn(c->params, c->batches, (int)c->num_batches, c->anchor_ids, c->targets, c->negs, (float)c->margin,
                       c->grads, 0, c->loss, NULL, NULL, c->desc, (size_t)c->desc_bytes, (int)c->upload_desc, c->workspace,
                       (size_t)c->workspace_bytes, c->err, c->lanes, c->events, (int)c->num_events, c->touch, c->stream, c->extra);
@@ -297,7 +301,7 @@ static PyObject *py_margin_call(PyObject *self, PyObject *const *args, Py_ssize_
 static PyMethodDef methods[] = {
     {"margin_call", (PyCFunction)(void (*)(void))py_margin_call, METH_FASTCALL,
      "margin_call(rng, fn, block, A, B, anchors, anchors_stride, targets, a_dst, t_dst, n_dst, lens, len_all, base, cand, loss, "
-     "stream, margin, notify_value) -> status"},
+     "stream, margin, notify_value, join_stream) -> status"},
     {"bind", py_bind, METH_VARARGS, "bind(address of mpqe_host_random_choice)"},
     {"choice", py_choice, METH_VARARGS, "choice(getrandbits, lens, len_all, base, cand, nq, out) -> words consumed"},
     {"choice_mt", py_choice_mt, METH_VARARGS, "choice_mt(rng, lens, len_all, base, cand, nq, out) -> words consumed"},

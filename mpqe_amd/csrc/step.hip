@@ -404,6 +404,11 @@ struct PrepArgs {
     const WtSlot *slots;
     float *WT;
     unsigned *wt_count;
+    // forward-only step with a learned readout: only the copies its forward multiplies by (tsel_n of them, slots tsel[]) are
+    // made; the first transpose workgroup counts the tskip workgroups of the others in as well, so that the count advances
+    // by the same number in every launch of the packed step (the chain workgroups' target: epoch x all)
+    int tsel_n, tsel[8];
+    unsigned tskip;
     unsigned *fwd_done;       // vector-op workgroups finished, ever (uop_wait_prepass); NULL: none
     ZeroSegs zs;
 };
@@ -412,7 +417,7 @@ struct PrepArgs {
 __device__ __forceinline__ void prep_transpose_block(const LayerPtrs &lp, const PrepArgs &pa, int D, int tb, float *smem) {
     float(*tile)[65] = reinterpret_cast<float(*)[65]>(smem);
     const int tpd = D / 64, per = tpd * tpd;
-    const int si = tb / per, tr = (tb % per) / tpd, tc = tb % tpd;
+    const int si = pa.tsel_n ? pa.tsel[tb / per] : tb / per, tr = (tb % per) / tpd, tc = tb % tpd;
     const WtSlot sl = pa.slots[si];
     const float *W = (sl.mat >= 0 ? pick_layer(lp.basis, sl.layer) + (long long)sl.mat * D * D : pick_layer(lp.root, sl.layer)) + sl.col0;
     const int ld = sl.ld;
@@ -452,7 +457,7 @@ __device__ __forceinline__ void prep_transpose_block(const LayerPtrs &lp, const 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-        atomicAdd(pa.wt_count, 1u);
+        atomicAdd(pa.wt_count, tb == 0 ? 1u + pa.tskip : 1u);
     }
 }
 
@@ -1400,6 +1405,12 @@ extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpq
                                          touch, stream, nullptr);
 }
 
+static int step_ex(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, const int64_t *anchor_ids,
+                   const int64_t *targets, const int64_t *negs, float margin, const mpqe_step_grads_t *G, int backward,
+                   float *loss, float *scores_pos, float *scores_neg, void *desc, size_t desc_bytes, int upload_desc,
+                   void *workspace, size_t workspace_bytes, int32_t *err, const mpqe_step_lanes_t *lanes, void *const *events,
+                   int num_events, void *touch, void *stream, const mpqe_step_extra_t *extra);
+
 extern "C" int mpqe_step_forward_backward_ex(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb,
                                              const int64_t *anchor_ids, const int64_t *targets, const int64_t *negs,
                                              float margin, const mpqe_step_grads_t *G, int backward,
@@ -1408,6 +1419,22 @@ extern "C" int mpqe_step_forward_backward_ex(const mpqe_step_params_t *P, const 
                                              size_t workspace_bytes, int32_t *err, const mpqe_step_lanes_t *lanes,
                                              void *const *events, int num_events, void *touch, void *stream,
                                              const mpqe_step_extra_t *extra) {
+    const int st = step_ex(P, B, nb, anchor_ids, targets, negs, margin, G, backward, loss, scores_pos, scores_neg, desc, desc_bytes,
+                           upload_desc, workspace, workspace_bytes, err, lanes, events, num_events, touch, stream, extra);
+    // (mpqe_step_extra_t.join_event / join_stream: the consumer's stream waits for this call's launches)
+    if (st == MPQE_OK && extra && extra->join_event && extra->join_stream != stream) {
+        if (hipEventRecord(reinterpret_cast<hipEvent_t>(extra->join_event), as_stream(stream)) != hipSuccess ||
+            hipStreamWaitEvent(as_stream(extra->join_stream), reinterpret_cast<hipEvent_t>(extra->join_event), 0) != hipSuccess)
+            return MPQE_ERR_LAUNCH;
+    }
+    return st;
+}
+
+static int step_ex(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb, const int64_t *anchor_ids,
+                   const int64_t *targets, const int64_t *negs, float margin, const mpqe_step_grads_t *G, int backward,
+                   float *loss, float *scores_pos, float *scores_neg, void *desc, size_t desc_bytes, int upload_desc,
+                   void *workspace, size_t workspace_bytes, int32_t *err, const mpqe_step_lanes_t *lanes, void *const *events,
+                   int num_events, void *touch, void *stream, const mpqe_step_extra_t *extra) {
     if (!P || !B || nb < 1 || nb > MPQE_STEP_MAX_BATCHES || !desc) return MPQE_ERR_INVALID_ARG;
     const bool ask_chain = want_chain(P, B, nb);
     // The launch plan is a pure function of the descriptors; it is kept on the host next to the device
@@ -1612,6 +1639,7 @@ extern "C" int mpqe_step_forward_backward_ex(const mpqe_step_params_t *P, const 
     PrepArgs pa;
     memset(&pa, 0, sizeof(pa));
     long long zblocks = 0;
+    int wt_all = 0;            // transposed-copy workgroups of a full launch of this packed step
     // merged launch: tiles + post-pass ride in the chain launch (include/mpqe_amd.h: MPQE_STEP_MERGE_TAIL)
     // Measured (AIFB mix, D = 128, B per batch 32 / 64 / 128 / 256 / 384 / 512 / 8192): merged 48.9 / 50.3 / 52.6 / 56.8 /
     // 61.3 / 68.4 / 569 us per step against 59.8 / 59.4 / 62.0 / 62.9 / 64.8 / 65.2 / 550 -- it wins while the chain
@@ -1690,6 +1718,24 @@ extern "C" int mpqe_step_forward_backward_ex(const mpqe_step_params_t *P, const 
             // (forward only: just the copies a learned readout's forward multiplies by -- the plan lists them last... not
             // sorted: all of them are made, the backward levels' are then unused)
             pa.tblocks = (backward || hp.ro_chain) ? (int)hp.wt_slots.size() * tpd * tpd : 0;
+            wt_all = pa.tblocks;
+            if (!backward && hp.ro_chain && !dbg_on("FWD_ALL_COPIES")) {
+                // (the readout's forward multiplies by the TRANSPOSED blocks of its own two layers; the relation matrices'
+                // copies and the plain column blocks belong to the backward programmes)
+                int n = 0;
+                bool fits = true;
+                for (size_t k = 0; k < hp.wt_slots.size(); ++k)
+                    if (hp.wt_slots[k].mat < 0 && !hp.wt_slots[k].plain && hp.wt_slots[k].layer >= hp.ro_layer) {
+                        if (n < 8) pa.tsel[n] = (int)k;
+                        else fits = false;
+                        ++n;
+                    }
+                if (fits && n > 0 && n < (int)hp.wt_slots.size()) {
+                    pa.tsel_n = n;
+                    pa.tblocks = n * tpd * tpd;
+                    pa.tskip = (unsigned)(wt_all - pa.tblocks);
+                }
+            }
             pa.sblocks = 0;
             if (build_touch) {
                 const TouchLayout TL = touch_layout(hp.touch_M, 0);
@@ -1757,6 +1803,10 @@ extern "C" int mpqe_step_forward_backward_ex(const mpqe_step_params_t *P, const 
                     pa.lead = pa.sblocks + (rest + pa.plna - 1) / pa.plna * 8;
                 }
             }
+            // (mpqe_step_extra_t.xcd_shift: idle workgroups in front of the chain workgroups move every one of them that many
+            // XCDs on -- forward-only steps on several streams at once)
+            if (!backward && extra && extra->xcd_shift > 0 && extra->xcd_shift < STEP_XCDS && !pa.plast && pa.sblocks == 0)
+                pa.lead += extra->xcd_shift;
             if (dbg_on("DUMP_PLAN"))
                 fprintf(stderr, "launch: sort rows %d (x8) | pre-pass %d transposes %d | lead %d | chain %d of %d | prologue behind the chain %d (XCDs %d)\n",
                         pa.sblocks / 8, pa.ublocks, pa.tblocks, pa.lead, hp.blk_off[nb], pa.nchain, pa.plast, pa.plna);
@@ -2046,7 +2096,7 @@ extern "C" int mpqe_step_forward_backward_ex(const mpqe_step_params_t *P, const 
             ca.cv_gran = pa.ublocks > 0 ? reinterpret_cast<const unsigned long long *>(db + hp.o_gran) : nullptr;
             ca.epoch_b = epoch_b;
             ca.wt_count = pa.tblocks > 0 ? pa.wt_count : nullptr;
-            ca.wt_blocks = pa.tblocks;
+            ca.wt_blocks = wt_all;
             // (counters and their epoch advance on merged steps only: targets are epoch x count)
             ca.done = pic ? reinterpret_cast<unsigned *>(db + hp.o_done) : nullptr;
             ca.arrive = ca.done ? ca.done + hp.done_inc.size() : nullptr;

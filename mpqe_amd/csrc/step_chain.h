@@ -1294,7 +1294,10 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
     // (written through: a forward-only step's last workgroup sums the terms inside this launch, step.hip: chain_finish)
     if (tid == 0)
         agent_store(ca.block_terms + ref.tb, (S.red()[0] + S.red()[1]) + (S.red()[2] + S.red()[3]));
-    if (!ca.backward) return;
+    if (!ca.backward) {
+        chain_stamp(ca, 6);
+        return;
+    }
     chain_stamp(ca, 4);
     const int blk = g0 / CH_GB;
     // column sums of gH[L] per node slot (the readout's gradient rows): the last pass' bias gradient, and what

@@ -110,11 +110,32 @@ __global__ __launch_bounds__(1024) void step_ro_reg_kernel(RoRegArgs a) {
         for (int i = 0; i < a.nw; ++i) ws += a.wdev[i] ? a.whost[i] * *a.wdev[i] : a.whost[i];
         gcoef = a.wd * ws;
     }
+    // every thread's partial sums of all four parameters first -- 16 independent loads at a time, squared and added in index
+    // order (a slot beyond the end adds + 0: the sums are what the plain loop gives, bit for bit) --, then the four
+    // reductions: one memory round trip in front of them instead of one per element and parameter
+    float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (!a.p[i]) continue;
+        const float *__restrict__ p = a.p[i];
+        const long long n = a.n[i];
+        float s = 0.f;
+        for (long long k0 = threadIdx.x; k0 < n; k0 += 16 * 1024) {
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const long long k = k0 + 1024LL * j;
+                v[j] = k < n ? p[k] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s += v[j] * v[j];
+        }
+        ps[i] = s;
+    }
+#pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (!a.p[i]) continue;          // (uniform: fewer than four parameters)
-        float s = 0.f;
-        for (long long k = threadIdx.x; k < a.n[i]; k += 1024) s += a.p[i][k] * a.p[i][k];
-        s = wave_sum(s);
+        float s = wave_sum(ps[i]);
         if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
         __syncthreads();
         if (threadIdx.x == 0) {

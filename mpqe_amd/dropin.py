@@ -36,6 +36,7 @@ from .data_utils import RGCNQueryDataset
 from .fused import FusedTrainStep, _TEMPLATES
 
 MAX_CALLS = _capi.STEP_MAX_BATCHES
+MAX_LANES = 7                              # side streams of the forward-only calls (channel 0 is the caller's stream)
 MAX_IDS = _capi.TSORT_MAX_ENTRIES          # looked-up ids of one fused step whose touch plan the step builds itself
 _P, _L, _U = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64
 
@@ -63,7 +64,8 @@ class _Arena(object):
         self.n = torch.empty(self.cap_g, dtype=torch.long, pin_memory=True)
         self.a_np, self.t_np, self.n_np = self.a.numpy(), self.t.numpy(), self.n.numpy()
         self.a_ptr, self.t_ptr, self.n_ptr = self.a.data_ptr(), self.t.data_ptr(), self.n.data_ptr()
-        self.last_seq = None       # number of the last library call that reads it (None: none yet)
+        # per channel (0: the caller's stream, 1 ..: the lanes) the number of the last library call that reads it (None: none)
+        self.last = [None] * (1 + MAX_LANES)
         self.reset()
 
     def reset(self):
@@ -87,7 +89,38 @@ class _Call(object):
 class _Rec(object):
     """A packed step (descriptors, descriptor table, plan buffer; ids named per run) and the argument block of its library
     call. One per (formula, batch size) for the forward-only calls, one per sequence of those for a backward pass."""
-    __slots__ = ('ps', 'call', 'addr', 'extra', 'key', 'rid', 'A', 'B', 'nb', 'P_seen', 'ws_seen')
+    __slots__ = ('ps', 'call', 'addr', 'extra', 'key', 'rid', 'A', 'B', 'nb', 'P_seen', 'ws_seen', 'fb')
+
+
+class _Lane(object):
+    """A side stream for forward-only margin_loss calls. A call is 32 workgroups per 512 graphs and mostly latency: with a
+    learned readout it takes 45 - 60 us on the device, three times the host's pace. Consecutive calls of a pass are
+    independent, so call k runs on lane k mod K -- its own stream, workspace, packed steps (descriptor tables: their hand-off
+    epochs must not be shared by two launches in flight), notification words and XCD (mpqe_step_extra_t.xcd_shift) -- and the
+    caller's stream waits for it before the value is used (mpqe_step_extra_t.join_event). The lane waits for the caller's
+    stream once per pass and whenever a parameter's version has changed (the optimiser's writes)."""
+    __slots__ = ('ch', 'stream', 'raw', 'event', 'event_raw', 'fork', 'ws', 'note_ptr', 'shift', 'pass_id', 'ver', 'epoch',
+                 'slots', 'next')
+
+    def __init__(self, ch, device, note_ptr):
+        self.ch = ch
+        self.stream = torch.cuda.Stream(device=device)
+        self.raw = self.stream.cuda_stream
+        self.event = torch.cuda.Event()
+        self.event.record(self.stream)              # (creates the handle)
+        self.event_raw = self.event.cuda_event
+        self.fork = torch.cuda.Event()
+        self.ws = None
+        self.note_ptr = note_ptr
+        self.shift = (2 * ch - 1) % 8               # lanes 1, 2, 3, 4 -> XCDs 1, 3, 5, 7 on from the plan's
+        self.pass_id = self.ver = -1
+        # the calls' loss words: a pool of the lane's own. torch's allocator orders a block's re-use within ONE stream; these
+        # are written on the lane's stream and read on the caller's, so a word is taken again only when (a) nobody else holds
+        # its storage any more and (b) the lane has waited for the caller's stream since it was last handed out (`epoch`
+        # counts those waits) -- its readers are then in front of the lane's next kernel
+        self.epoch = 0
+        self.slots = []            # [tensor, epoch when handed out]
+        self.next = 0
 
 
 class _MarginLossNode(torch.autograd.Function):
@@ -140,13 +173,18 @@ class DropIn(object):
         self._grb = self._rng = None
         # [0] the number of the last library call whose id reads are over, [1] the error word as that call left it: written
         # by the device (mpqe_step_extra_t.notify), read here without a call
-        self._note = torch.zeros(2, dtype=torch.int32, pin_memory=True)
+        self._note = torch.zeros(2 * (1 + MAX_LANES), dtype=torch.int32, pin_memory=True)     # (a pair per channel)
         self._note_np = self._note.numpy().view(np.uint32)
         self._note_ptr = self._note.data_ptr()
         self._calls = 0            # library calls issued (their notify values, modulo 2^32)
         self.checked = False       # True: every backward pass reads the error word before it returns (one sync) and recovers
         self.steps = 0             # fused backward steps run
         self.fast_sampled = 0      # calls whose negatives were drawn by the library replay of python's stream
+        # forward-only calls on side streams (_Lane): where a call's device time exceeds the host's pace -- the learned
+        # readouts (every node of every graph through two more layers, no liveness pruning); set_lanes(n) overrides
+        self.lanes = []
+        self._want_lanes = 3 if self.step.learned else 0       # (the runtime gives a process four hardware queues: the null stream's and three more)
+        self._pass_id = 0
 
     def _signature(self):
         ps = self.step.params
@@ -182,6 +220,7 @@ class DropIn(object):
         r = _Rec()
         r.ps = ps = step.pack([dict(formula=f, batch_size=B, weight=1.0) for (f, B) in batches], ids='external')
         r.key, r.nb = key, len(batches)
+        r.fb = batches[0]                       # (a one-batch record's (formula, batch size))
         self._nrec = r.rid = getattr(self, '_nrec', 0) + 1
         r.extra = _capi.StepExtra()
         c = r.call = StepCall()
@@ -198,20 +237,73 @@ class DropIn(object):
         cache[key] = r
         return r
 
-    def _one_rec(self, formula, B):
-        r = self._one.get((formula, B))
+    def set_lanes(self, n):
+        """Forward-only margin_loss calls on n side streams (0: on the caller's stream), from the next call on."""
+        self._want_lanes = max(0, min(int(n), MAX_LANES))
+
+    def _make_lanes(self):
+        n = self._want_lanes if self._pass is not None else 0        # (the loss words' pool asks the C++ extension who holds them)
+        self._want_lanes = n
+        while len(self.lanes) < n:
+            ch = len(self.lanes) + 1
+            self.lanes.append(_Lane(ch, self.device, self._note_ptr + 8 * ch))
+        return self.lanes[:n]
+
+    def _lane_ws(self, lane, nbytes):
+        if lane.ws is None or lane.ws.numel() < nbytes + 256:
+            if lane.ws is not None:
+                lane.stream.synchronize()          # (nothing in flight in the buffer that goes)
+            lane.ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        return (lane.ws.data_ptr() + 255) // 256 * 256
+
+    def _fork(self, lane, cur):
+        """The lane's next kernel runs behind everything the caller's stream holds now."""
+        lane.fork.record(cur)
+        lane.stream.wait_event(lane.fork)
+        lane.epoch += 1
+
+    def _lane_loss(self, lane, cur):
+        """A loss word of the lane's pool that is free (see _Lane), else a new one."""
+        slots, n, count = lane.slots, len(lane.slots), self._node_ext.storage_use_count
+        for attempt in (0, 1):
+            i = lane.next
+            for _ in range(n):
+                s = slots[i]
+                i = i + 1 if i + 1 < n else 0
+                if s[1] < lane.epoch and count(s[0]) == 1:
+                    s[1] = lane.epoch
+                    lane.next = i
+                    return s[0]
+            if attempt or n < 32:
+                break
+            self._fork(lane, cur)             # (a long run of calls without a backward pass: one wait frees the pool)
+        t = torch.empty(2, dtype=torch.float32, device=self.device)
+        self._fork(lane, cur)                 # (the block's earlier life on the caller's stream is in front of the lane now)
+        slots.append([t, lane.epoch])
+        return t
+
+    def _param_version(self):
+        """Changes whenever a parameter is written in place (torch's optimisers, load_state_dict) or by FlatOptimizer."""
+        v = self.step.param_epoch
+        for p in self.step.params:
+            v += p._version
+        return v
+
+    def _one_rec(self, formula, B, ch=0):
+        r = self._one.get((ch, formula, B))
         if r is None:
             A = _TEMPLATES[formula.query_type][0]
             if A != len(formula.anchor_modes):
                 raise ValueError('formula %s has %d anchor modes, template expects %d'
                                  % (formula, len(formula.anchor_modes), A))
             self._passes(formula)                  # (the reference's ValueError for a diameter beyond the layers)
-            r = self._record(self._one, (formula, B), [(formula, B)])
+            r = self._record(self._one, (ch, formula, B), [(formula, B)])
             r.A, r.B = A, B
         return r
 
-    def _launch(self, r, backward, zero_grad, a_ptr, t_ptr, n_ptr, loss, sp=None, sn=None, extra=None):
-        """One library call on the current stream: the argument block's changing fields, then csrc/host/pyhost.c: step_call."""
+    def _launch(self, r, backward, zero_grad, a_ptr, t_ptr, n_ptr, loss, sp=None, sn=None, extra=None, lane=None):
+        """One library call on the current stream (lane: on the lane's, the current stream waiting for it): the argument
+        block's changing fields, then csrc/host/pyhost.c: step_call."""
         step, ps, c = self.step, r.ps, r.call
         step.P.flags = step.flags | ps.step_flags | (_capi.STEP_ZERO_GRADS if (backward and zero_grad) else 0)
         c.params, c.grads = ctypes.addressof(step.P), ctypes.addressof(step.G)      # (refresh() makes new structs)
@@ -223,12 +315,20 @@ class DropIn(object):
         c.scores_neg = None if sn is None else sn.data_ptr()
         bufs = ps.bufs
         c.upload_desc = 0 if bufs.desc_resident else 1
-        c.workspace = step._workspace(ps.ws_bytes)
-        c.stream = torch._C._cuda_getCurrentRawStream(self.dev_index)
         if extra is None:
             extra = r.extra
         self._calls = seq = (self._calls + 1) & 0xffffffff
-        extra.notify, extra.notify_value = self._note_ptr, seq
+        if lane is None:
+            c.workspace = step._workspace(ps.ws_bytes)
+            c.stream = torch._C._cuda_getCurrentRawStream(self.dev_index)
+            extra.notify, extra.notify_value = self._note_ptr, seq
+            extra.join_event = extra.join_stream = None
+        else:
+            c.workspace = self._lane_ws(lane, ps.ws_bytes)
+            c.stream = lane.raw
+            extra.notify, extra.notify_value = lane.note_ptr, seq
+            extra.xcd_shift = lane.shift
+            extra.join_event, extra.join_stream = lane.event_raw, torch._C._cuda_getCurrentRawStream(self.dev_index)
         c.extra = ctypes.addressof(extra)
         if torch._C._cuda_getDevice() != self.dev_index:
             with torch.cuda.device(self.device):
@@ -240,12 +340,17 @@ class DropIn(object):
         bufs.desc_resident = True
         if not backward and sp is None and extra is r.extra:
             c.upload_desc = 0
-            r.P_seen, r.ws_seen = step.P, step._ws
+            r.P_seen, r.ws_seen = step.P, (step._ws if lane is None else lane.ws)
         return seq
 
-    def _done(self, seq):
-        """True once library call number `seq` (or a later one) has reported that its id reads are over."""
-        return seq is None or ((int(self._note_np[0]) - seq) & 0xffffffff) < 0x80000000
+    def _done(self, ar):
+        """True once the last library call of every channel that reads arena `ar` (or a later call of that channel) has
+        reported that its id reads are over."""
+        note = self._note_np
+        for ch, seq in enumerate(ar.last):
+            if seq is not None and ((int(note[2 * ch]) - seq) & 0xffffffff) >= 0x80000000:
+                return False
+        return True
 
     # ------------------------------------------------------------------------------------------- arenas
     def _arena_for(self, a, g):
@@ -257,7 +362,7 @@ class DropIn(object):
         self._drain_dead()
         need = max(g * 4, 1 << 14)
         for i, cand in enumerate(self._free):
-            if cand.live == 0 and cand.cap_g >= need and self._done(cand.last_seq):
+            if cand.live == 0 and cand.cap_g >= need and self._done(cand):
                 ar = self._free.pop(i)
                 ar.reset()
                 break
@@ -351,28 +456,56 @@ class DropIn(object):
     # ------------------------------------------------------------------------------------------- margin_loss
     def _check_mirror(self):
         """Raise what a finished call's error word says (IndexError for a bad entity id, as the reference's lookup would)."""
-        if self._note_np[1]:
+        if self._note_np[1::2].any():
             torch.cuda.current_stream(self.device).synchronize()
-            self._note_np[1] = 0
+            for lane in self.lanes:
+                lane.stream.synchronize()
+            self._note_np[1::2] = 0
             ops.raise_on_flags(self.step.err)
 
     def margin_loss(self, formula, queries, anchor_ids=None, var_ids=None, q_graphs=None, hard_negatives=False, margin=1):
-        if self._note_np[1] and self.model.validate:
+        lanes = self.lanes
+        if len(lanes) != self._want_lanes:
+            lanes = self._make_lanes()
+        if self.model.validate and (self._note_np[1::2].any() if lanes else self._note_np[1]):
             self._check_mirror()
         B = len(queries)
-        r = self._one.get((formula, B)) or self._one_rec(formula, B)
-        A = r.A
         ar = self._arena
+        if ar is not None and lanes:
+            lane = lanes[ar.calls % len(lanes)]
+            ch = lane.ch
+        else:
+            lane, ch = (lanes[0], 1) if lanes else (None, 0)
+        r = self._one.get((ch, formula, B)) or self._one_rec(formula, B, ch)
+        A = r.A
         if ar is None or not ar.fits(A * B, B):
             ar = self._arena_for(A * B, B)
         step = self.step
         step.margin = margin = float(margin)
         idx = ar.calls
         # (a buffer of its own per call: a caller may keep the value -- `loss.detach()` for a log -- beyond its graph)
-        loss = torch.empty(2, dtype=torch.float32, device=self.device)
+        if lane is None:
+            cur_raw = torch._C._cuda_getCurrentRawStream(self.dev_index)
+            loss = torch.empty(2, dtype=torch.float32, device=self.device)
+        else:
+            cur = torch.cuda.current_stream(self.device)
+            cur_raw = cur.cuda_stream
+            # the lane waits for the caller's stream where the parameters may have been written since it last did: once per
+            # backward pass, and whenever a parameter's version has moved
+            ver = self._param_version()
+            if lane.pass_id != self._pass_id or lane.ver != ver:
+                # (EVERY lane at once: a lane that waited only at its own first call of the pass would find the caller's
+                # stream already waiting for the calls before it, and the pass' first calls would run one after the other)
+                lane.fork.record(cur)
+                for ln in lanes:
+                    ln.stream.wait_event(lane.fork)
+                    ln.epoch += 1
+                    ln.pass_id, ln.ver = self._pass_id, ver
+            loss = self._lane_loss(lane, cur)
         ids = None if q_graphs is None else q_graphs.ids
         rng = self._mt()
-        if (ids is not None and rng is not None and r.P_seen is step.P and r.ws_seen is step._ws and ids.end - ids.start == B
+        if (ids is not None and rng is not None and r.P_seen is step.P and r.ws_seen is (step._ws if lane is None else lane.ws)
+                and ids.end - ids.start == B
                 and ids.fi.A == A and (anchor_ids is None or anchor_ids is ids.anchor_ref)
                 and torch._C._cuda_getDevice() == self.dev_index):
             # the batch is a window of its formula's id arrays and this record has run before: ONE host call copies the
@@ -401,19 +534,19 @@ class DropIn(object):
             st = self.host.margin_call(rng, self._step_fn, r.addr, A, B, fi.anchors_sm_ptr + lo, fi.anchors_sm_stride,
                                        fi.targets_ptr + lo, ar.a_ptr + 8 * oa, ar.t_ptr + 8 * og, ar.n_ptr + 8 * og,
                                        lens_p, len_all, base_p, csr[3], loss.data_ptr(),
-                                       torch._C._cuda_getCurrentRawStream(self.dev_index), margin, seq)
+                                       cur_raw if lane is None else lane.raw, margin, seq, 0 if lane is None else cur_raw)
             if st != 0:
                 _capi.check(self.lib, st, 'mpqe_step_forward_backward_ex')
-            ar.last_seq = seq
+            ar.last[ch] = seq
             self.fast_sampled += 1
         else:
             self._fill_ids(ar, formula, queries, anchor_ids, ids, hard_negatives, B, A)
-            ar.last_seq = self._launch(r, False, False, ar.a_ptr + 8 * oa, ar.t_ptr + 8 * og, ar.n_ptr + 8 * og, loss)
+            ar.last[ch] = self._launch(r, False, False, ar.a_ptr + 8 * oa, ar.t_ptr + 8 * og, ar.n_ptr + 8 * og, loss, lane=lane)
         ar.na, ar.ng, ar.calls = oa + A * B, og + B, idx + 1
         if not torch.is_grad_enabled() or not step.params:
             return loss[0]
         call = _Call()
-        call.arena, call.oa, call.og, call.idx, call.key, call.rid, call.B, call.A = ar, oa, og, idx, r.key, r.rid, B, A
+        call.arena, call.oa, call.og, call.idx, call.key, call.rid, call.B, call.A = ar, oa, og, idx, r.fb, r.rid, B, A
         call.margin, call.g = step.margin, None
         self._seq = seq = self._seq + 1
         call.seq = seq
@@ -508,13 +641,14 @@ class DropIn(object):
                 self._calls = seq = (self._calls + 1) & 0xffffffff
                 extra.notify, extra.notify_value = self._note_ptr, seq
                 step.run(r.ps, backward=True, zero_grad=zero, checked=True, id_ptrs=ptrs, extra=extra, out=(loss, None, None))
-                ar.last_seq = seq
+                ar.last[0] = seq
             else:
-                ar.last_seq = self._launch(r, True, zero, ptrs[0], ptrs[1], ptrs[2], loss, extra=extra)
+                ar.last[0] = self._launch(r, True, zero, ptrs[0], ptrs[1], ptrs[2], loss, extra=extra)
             zero = False
             self.steps += 1
         for c in calls:
             c.g = None
+        self._pass_id += 1
         # the pass is over: its arena is closed (a node kept alive by retain_graph still finds its ids there)
         ar = self._arena
         if ar is not None and ar.calls:
@@ -527,7 +661,7 @@ class DropIn(object):
         """reference model.py:400-462 without autograd: scores [B] or [B + sum(neg_lengths)]."""
         m = self.model
         B = len(queries)
-        r = self._one.get((formula, B)) or self._one_rec(formula, B)
+        r = self._one.get((0, formula, B)) or self._one_rec(formula, B)
         A = r.A
         ar = self._arena_for(A * B, B)
         oa, og = ar.na, ar.ng
@@ -564,7 +698,7 @@ class DropIn(object):
             extra = _capi.StepExtra()
             extra.query_out = q.data_ptr()
         self.step.margin = 1.0
-        ar.last_seq = self._launch(r, False, False, ar.a_ptr + 8 * oa, ar.t_ptr + 8 * og, ar.n_ptr + 8 * og, loss, scores[:B],
+        ar.last[0] = self._launch(r, False, False, ar.a_ptr + 8 * oa, ar.t_ptr + 8 * og, ar.n_ptr + 8 * og, loss, scores[:B],
                                    scores[B:], extra=extra)
         ar.na, ar.ng, ar.calls = oa + A * B, og + B, ar.calls + 1
         if neg_nodes is None:

@@ -209,6 +209,7 @@ class FusedTrainStep(object):
         self._desc_cache, self._size_cache, self._pool = {}, {}, {}
         # descriptor sets whose in-step touch plan failed once (run(checked=True)): their plans are built by pack() from then on
         self._pack_touch_sets = set()
+        self.param_epoch = 0               # bumped by writers of the parameters that bypass autograd's version counters (FlatOptimizer.step)
         self.zero_next = False             # FlatOptimizer.zero_grad(): the drop-in's next backward pass zero-fills (mpqe_amd/dropin.py)
         self.touch_retries = 0
         self.handoff_retries = 0           # steps run(checked=True) ran again in the level form (an in-launch hand-off timed out)

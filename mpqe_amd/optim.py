@@ -85,6 +85,7 @@ class FlatOptimizer(object):
         table rows to update). rows_plan: under data parallelism the (plan pointer, entries) of the row exchange
         (mpqe_amd.parallel.StepExchange): the rows ANY rank touched -- every replica updates the same rows."""
         self.t += 1
+        self.fused.param_epoch += 1            # (the parameters are written behind autograd's version counters: dropin.py's lanes)
         g = self.fused.flat_grad
         with torch.cuda.device(self.fused.device):
             stream = torch.cuda.current_stream().cuda_stream

@@ -278,3 +278,47 @@ def test_retained_graphs_copies_and_two_models_in_one_pass():
     for (k, p), (_, q) in zip(model.named_parameters(), twin.named_parameters()):
         np.testing.assert_allclose(_np(p.grad), 0.5 * g1[k], err_msg=k, **BWD)
         np.testing.assert_allclose(_np(q.grad), 1.5 * g1[k], err_msg=k, **BWD)
+
+
+@pytest.mark.parametrize('readout,adaptive,wd', [('mp', True, 0.0), ('mlp', False, 1e-3)])
+def test_forward_only_calls_on_side_streams_change_nothing(readout, adaptive, wd):
+    """DropIn.set_lanes(n): the forward-only margin_loss calls of a pass on n side streams (their own workspaces, packed
+    steps, notification words and XCDs; the caller's stream waits for each before its value is used; the lanes wait for
+    the caller's stream once per pass and when a parameter's version moves). Three iterations of the reference loop body
+    with an optimiser step in between -- torch.optim.Adam (version counters) and FlatOptimizer (its own epoch) --: every
+    loss value and every parameter after the last step equal the one-stream run's bit for bit; so does a no_grad loop that
+    drops every value after adding it (the allocator must not hand a value's block to another lane too early)."""
+    from mpqe_amd.data_utils import get_queries_iterator
+    from mpqe_amd.optim import FlatOptimizer
+    out = {}
+    for opt_kind in ('torch', 'flat'):
+        for lanes in (0, 3):
+            schema, node_maps, model, train_queries = _aifb(readout, adaptive, D=64, per_formula=600, weight_decay=wd)
+            model = model.to('cuda:0')
+            d = model.dropin()
+            d.set_lanes(lanes)
+            np.random.seed(5)
+            iterators = {qt: get_queries_iterator(train_queries[qt], 256, model) for qt in train_queries}
+            opt = (torch.optim.Adam(model.parameters(), lr=0.01) if opt_kind == 'torch'
+                   else FlatOptimizer(d.step, lr=0.01, opt='adam'))
+            random.seed(123)
+            values = []
+            for it in range(3):
+                opt.zero_grad()
+                loss = _reference_loop_body(model, iterators, train_queries, [])
+                values.append(loss.item())
+                loss.backward()
+                opt.step()
+            with torch.no_grad():
+                tot = torch.zeros((), device='cuda:0')
+                for k in range(40):
+                    qt = ('3-inter', '2-chain', '3-chain_inter', '1-chain')[k % 4]
+                    tot = tot + model.margin_loss(*next(iterators[qt]))
+            torch.cuda.synchronize()
+            d._check_mirror()
+            assert len(d.lanes) >= lanes and (lanes == 0 or all(l.pass_id >= 0 for l in d.lanes[:lanes]))
+            out[opt_kind, lanes] = (values, tot.item(), {k: _np(p).copy() for k, p in model.named_parameters()})
+        a, b = out[opt_kind, 0], out[opt_kind, 3]
+        assert a[0] == b[0] and a[1] == b[1], (a[0], b[0], a[1], b[1])
+        for k in a[2]:
+            np.testing.assert_array_equal(a[2][k], b[2][k], err_msg='%s (%s)' % (k, opt_kind))

@@ -86,7 +86,7 @@ def oracle_step(params, cfg, node_map, batches, margin):
 
 def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=1, lanes=None, flags=0, touch='step', repeat=1,
              plan_out=None, between=None, recover=False, before_recovery=None, dev_weights=False, query_out=None,
-             then_plain=False):
+             then_plain=False, xcd_shift=0):
     """between: the step in three calls around the CALLER's readout (MPQE_READOUT_CALLER, MPQE_STEP_PHASE_*): a generator
     function -- between(final_states) yields the query embeddings [graphs, D], is sent their gradients and yields d loss /
     d final states per batch; final_states[i]: batch i's [B N, D]. touch: 'step' = the step builds the touch plan of its ids itself (MPQE_STEP_BUILD_TOUCH, the product's default),
@@ -256,7 +256,7 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
         call(_capi.STEP_PHASE_FROM_STATES, 0)
         P.flags &= ~_capi.STEP_ADD_STATE_GRADS
     extra = None
-    if dev_weights or query_out is not None:
+    if dev_weights or query_out is not None or xcd_shift:
         # include/mpqe_amd.h: mpqe_step_extra_t -- batch weights as DEVICE scalars (host weight 2 x device weight w / 2 = w:
         # the same step), the query embeddings out
         extra = _capi.StepExtra()
@@ -270,8 +270,11 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
             extra.query_out = be.ptr(dq)
         note = be.zeros((2,), np.int32)        # (mpqe_step_extra_t.notify: the call's number + the error word, by its last launch)
         extra.notify, extra.notify_value = be.ptr(note), 4711
+        extra.xcd_shift = xcd_shift
+    kinds = list(backward) if isinstance(backward, (list, tuple)) else [backward] * repeat      # (a list: one call of each kind, in order)
+    repeat = len(kinds)
     for rep in range(0 if between is not None else repeat):       # (repeat > 1: the same packed step again -- its hand-off epochs / counters carry on)
-        args = (ctypes.byref(P), SB, nb, be.ptr(d_anchor), be.ptr(d_tg), be.ptr(d_ng), margin, ctypes.byref(G), backward,
+        args = (ctypes.byref(P), SB, nb, be.ptr(d_anchor), be.ptr(d_tg), be.ptr(d_ng), margin, ctypes.byref(G), kinds[rep],
                 be.ptr(loss), be.ptr(sp), be.ptr(sn), dptr, dsb, 1 if rep == 0 else 0, wptr, wsb, be.ptr(err), lanes, None, 0, tptr,
                 be.stream)
         if extra is None or (then_plain and rep == repeat - 1):
@@ -400,6 +403,27 @@ def test_step_with_device_batch_weights_and_query_out(be, D, readout, adaptive, 
         b['weight'] = w
     for k in g2:
         np.testing.assert_allclose(g2[k], g3[k], rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+@pytest.mark.parametrize('readout,adaptive,D', [('mp', True, 64), ('mlp', False, 64), ('sum', False, 128)])
+def test_forward_only_step_moved_round_the_chip(be, readout, adaptive, D):
+    """mpqe_step_extra_t.xcd_shift: a forward-only step whose workgroups sit 1 .. 7 XCDs further round the chip (idle
+    workgroups in front of them; forward-only steps on several streams then run side by side) returns what it returns at
+    home, bit for bit -- loss, scores, error word, and the notification by the launch's last workgroup."""
+    _gpu_only_when_heavy(be, D >= 128)
+    schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(5, D, 3, False, MIXES['dup'], readout, adaptive)
+    home = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, backward=0, repeat=2)
+    for shift in (1, 3, 7):
+        moved = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, backward=0, repeat=2, xcd_shift=shift)
+        assert moved[4] == home[4] == 0
+        for a, b in zip(moved[:3], home[:3]):
+            np.testing.assert_array_equal(a, b)
+    # ... and a whole step ignores it
+    full = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_ZERO_GRADS)
+    moved = run_step(be, schema, mode_ids, params, node_map, cfg, batches, 1.0, flags=_capi.STEP_ZERO_GRADS, xcd_shift=5)
+    np.testing.assert_array_equal(moved[0], full[0])
+    for k in full[3]:
+        np.testing.assert_array_equal(moved[3][k], full[3][k], err_msg=k)
 
 
 @pytest.mark.parametrize('D', [8, 16, 20])
@@ -723,6 +747,22 @@ def _readout_on_the_chain(be, capfd, readout, D, mix, scatter_op, adaptive, shar
     np.testing.assert_allclose(loss[0], total.item(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(sp, np.concatenate(sp_ref), rtol=1e-5, atol=1e-6)
     assert err == 0 and all(not g.any() for g in grads.values())
+    # forward-only and whole steps on ONE packed step, in turn: a forward-only call makes only the transposed copies its
+    # readout's forward multiplies by, and counts the others' workgroups in (the chain workgroups' wait target advances alike
+    # in every launch); mpqe_debug_option FWD_ALL_COPIES = 1: every copy, as until round 5
+    for every in (0, 1):
+        be.lib.mpqe_debug_option(b'FWD_ALL_COPIES', every, 1)
+        try:
+            mixed = run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=[0, 1, 0, 0, 1, 0],
+                             flags=_capi.STEP_ZERO_GRADS, touch=touch)
+        finally:
+            be.lib.mpqe_debug_option(b'FWD_ALL_COPIES', 0, 0)
+        assert mixed[4] == 0
+        np.testing.assert_array_equal(mixed[0], loss)
+        np.testing.assert_array_equal(mixed[1], sp)
+        for k in first[3]:
+            if touch or not k.startswith('enc.'):
+                np.testing.assert_array_equal(mixed[3][k], first[3][k], err_msg=k)
 
 
 def test_callers_readout_refuses_what_it_does_not_cover(be):

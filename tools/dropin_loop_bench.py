@@ -146,7 +146,7 @@ def run(readout='mp', D=128, B=512, iters=200, warmup=20, optimizer='flat', modu
     out = {'workload': 'reference train_helpers.py:76-120 loop body over pre-collated batches: 11 margin_loss calls (B=%d, D=%d, '
                        'readout %s), loss.item(), backward, optimizer step' % (B, D, readout), 'optimizer': optimizer}
     graphs = 11 * B
-    for fused in (True, False):
+    for fused in ((True, False) if module_iters > 0 else (True,)):          # (--module-iters 0: the drop-in alone)
         model, train_queries = build(readout, D, B, seed=seed)
         model = model.to(dev)
         model.fused = fused
@@ -175,7 +175,8 @@ def run(readout='mp', D=128, B=512, iters=200, warmup=20, optimizer='flat', modu
             d = model.dropin()
             out[key]['fused_backward_steps'] = d.steps
             out[key]['negatives_by_library_replay'] = d.fast_sampled
-    out['speedup'] = out['module_path']['ms_per_step'] / out['fused']['ms_per_step']
+    if 'module_path' in out:
+        out['speedup'] = out['module_path']['ms_per_step'] / out['fused']['ms_per_step']
     return out
 
 
