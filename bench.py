@@ -345,13 +345,15 @@ def time_fused_kernels(step, packed, data, model, readout, reps=20):
 
 def pmc_traffic(kernel):
     """(bytes, source): HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
-    that has it (profiles/r*_pmc.json, made by tools/pmc_summary.py: separate FETCH_SIZE and WRITE_SIZE passes,
+    that has it (profiles/r*_chain_pmc.json, made by tools/pmc_summary.py: separate FETCH_SIZE and WRITE_SIZE passes,
     FETCH_SIZE doubled as the MI355X guide prescribes for gfx950), and the file it came from. PMC counters need
     the rocprofv3 wrapper, so they are NOT collected by the process that prints the line: the value is the one
     measured when that profile was taken (same command, same code when the file's round tag is current);
     (None, None) when no summary is committed for the kernel."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json')), reverse=True):
+    # (r*_chain_pmc.json: the default workload's summaries; the other configurations' -- r*_mutag_pmc.json ... -- list the same
+    # kernel names at other shapes)
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_chain_pmc.json')), reverse=True):
         try:
             table = json.load(open(path))
         except (OSError, ValueError):
