@@ -1291,9 +1291,13 @@ __device__ __forceinline__ void chain_block(const StepDev *__restrict__ sd, cons
         }
     }
     __syncthreads();
-    // (written through: a forward-only step's last workgroup sums the terms inside this launch, step.hip: chain_finish)
-    if (tid == 0)
-        agent_store(ca.block_terms + ref.tb, (S.red()[0] + S.red()[1]) + (S.red()[2] + S.red()[3]));
+    // (forward-only step: written through -- the launch's last workgroup sums the terms inside this launch, step.hip:
+    // chain_finish; a whole step's reduction launch reads them from the L2 they stay in)
+    if (tid == 0) {
+        const float term = (S.red()[0] + S.red()[1]) + (S.red()[2] + S.red()[3]);
+        if (ca.backward) ca.block_terms[ref.tb] = term;
+        else agent_store(ca.block_terms + ref.tb, term);
+    }
     if (!ca.backward) {
         chain_stamp(ca, 6);
         return;
