@@ -750,10 +750,14 @@ def _readout_on_the_chain(be, capfd, readout, D, mix, scatter_op, adaptive, shar
     # forward-only and whole steps on ONE packed step, in turn: a forward-only call makes only the transposed copies its
     # readout's forward multiplies by, and counts the others' workgroups in (the chain workgroups' wait target advances alike
     # in every launch); mpqe_debug_option FWD_ALL_COPIES = 1: every copy, as until round 5
-    for every in (0, 1):
+    # (the CPU emulator: the short sequence at D = 64 only -- the same code, a fifth of the time)
+    if be.name == 'emu' and D > 64:
+        return
+    for every in ((0,) if be.name == 'emu' else (0, 1)):
         be.lib.mpqe_debug_option(b'FWD_ALL_COPIES', every, 1)
         try:
-            mixed = run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=[0, 1, 0, 0, 1, 0],
+            mixed = run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin,
+                             backward=[0, 1, 0] if be.name == 'emu' else [0, 1, 0, 0, 1, 0],
                              flags=_capi.STEP_ZERO_GRADS, touch=touch)
         finally:
             be.lib.mpqe_debug_option(b'FWD_ALL_COPIES', 0, 0)
