@@ -322,3 +322,33 @@ def test_forward_only_calls_on_side_streams_change_nothing(readout, adaptive, wd
         assert a[0] == b[0] and a[1] == b[1], (a[0], b[0], a[1], b[1])
         for k in a[2]:
             np.testing.assert_array_equal(a[2][k], b[2][k], err_msg='%s (%s)' % (k, opt_kind))
+
+
+@pytest.mark.parametrize('lanes', [0, 2])
+def test_bad_entity_id_on_the_training_path_raises_at_the_next_call(lanes):
+    """The reference raises IndexError inside forward (encoders.py:40-43: the embedding lookup). The drop-in's margin_loss does
+    not wait for its launch: the call's last workgroup leaves the error word in pinned host memory
+    (mpqe_step_extra_t.notify; a pair of words per side stream), and the NEXT margin_loss call -- or _check_mirror() -- raises.
+    The model keeps working afterwards."""
+    from mpqe_amd.data_utils import get_queries_iterator
+    schema, node_maps, model, train_queries = _aifb('mp', True, D=64, per_formula=300)
+    model = model.to('cuda:0')
+    d = model.dropin()
+    d.set_lanes(lanes)
+    np.random.seed(1)
+    it = get_queries_iterator(train_queries['2-inter'], 128, model)
+    good = next(it)
+    random.seed(5)
+    v0 = model.margin_loss(*good).item()
+    formula, queries = good[0], list(good[1])
+    bad_anchors = good[2].clone()
+    bad_anchors[7, 1] = schema.num_entities + 11                  # (beyond the id -> row table)
+    with torch.no_grad():
+        model.margin_loss(formula, queries, bad_anchors)        # queued, not waited for
+        torch.cuda.synchronize()
+        with pytest.raises(IndexError):
+            model.margin_loss(*good)
+        random.seed(5)
+        v1 = model.margin_loss(*good).item()
+    d._check_mirror()
+    assert v1 == v0
