@@ -112,7 +112,10 @@ __global__ __launch_bounds__(256) void p2p_reduce_kernel(P2PBufs B, int rank, in
     __shared__ unsigned last, ok;
     if (threadIdx.x == 0) ok = 1u;
     __syncthreads();
-    if (threadIdx.x < world && !p2p_wait(B.flags[rank] + (long long)threadIdx.x * P2P_FLAG_STRIDE, epoch, err)) ok = 0u;
+    // (one look, no waiting: the one-workgroup launch in front of this one -- p2p_wait_kernel on the slot flags -- has waited
+    // for the peers and reported the one that never came; up to 256 workgroups napping on a flag would hold CU slots for as
+    // long as a peer is late, and on a GPU shared with that peer's process they are the slots its step needs)
+    if (threadIdx.x < world && p2p_flag_load(B.flags[rank] + (long long)threadIdx.x * P2P_FLAG_STRIDE) != epoch) ok = 0u;
     __syncthreads();
 #ifndef MPQE_EMU
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
@@ -139,9 +142,10 @@ __global__ __launch_bounds__(256) void p2p_reduce_kernel(P2PBufs B, int rank, in
         p2p_flag_store(B.flags[threadIdx.x] + (long long)(world + rank) * P2P_FLAG_STRIDE, epoch);
 }
 
-// wait: every shard of my bucket has landed
-__global__ __launch_bounds__(64) void p2p_wait_kernel(P2PBufs B, int rank, int world, unsigned epoch, int32_t *err) {
-    if ((int)threadIdx.x < world) p2p_wait(B.flags[rank] + (long long)(world + threadIdx.x) * P2P_FLAG_STRIDE, epoch, err);
+// wait (one workgroup): flags [base, base + world) of my buffer carry this exchange's number -- base 0: every peer's slot of
+// my shard is filled (in front of the reduce launch); base world: every shard of my bucket has landed
+__global__ __launch_bounds__(64) void p2p_wait_kernel(P2PBufs B, int rank, int world, unsigned epoch, int32_t *err, int base) {
+    if ((int)threadIdx.x < world) p2p_wait(B.flags[rank] + (long long)(base + threadIdx.x) * P2P_FLAG_STRIDE, epoch, err);
 #ifndef MPQE_EMU
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 #endif
@@ -227,8 +231,11 @@ extern "C" int mpqe_p2p_allreduce(void *const *buffers, int rank, int world, int
     const unsigned g1 = (unsigned)std::min<long long>(256, (n / 4 + 255) / 256 + 1);
     const unsigned g2 = (unsigned)std::min<long long>(256, (shard / 4 + 255) / 256 + 1);
     if (phases & 1) hipLaunchKernelGGL(p2p_push_kernel, dim3(g1), dim3(256), 0, s, B, rank, world, (long long)n, shard, epoch);
-    if (phases & 2) hipLaunchKernelGGL(p2p_reduce_kernel, dim3(g2), dim3(256), 0, s, B, rank, world, (long long)n, shard, epoch, err);
-    if (phases & 4) hipLaunchKernelGGL(p2p_wait_kernel, dim3(1), dim3(64), 0, s, B, rank, world, epoch, err);
+    if (phases & 2) {
+        hipLaunchKernelGGL(p2p_wait_kernel, dim3(1), dim3(64), 0, s, B, rank, world, epoch, err, 0);
+        hipLaunchKernelGGL(p2p_reduce_kernel, dim3(g2), dim3(256), 0, s, B, rank, world, (long long)n, shard, epoch, err);
+    }
+    if (phases & 4) hipLaunchKernelGGL(p2p_wait_kernel, dim3(1), dim3(64), 0, s, B, rank, world, epoch, err, world);
     return mpqe_launch_status();
 }
 

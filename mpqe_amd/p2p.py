@@ -3,7 +3,7 @@ using all 7 links concurrently ... over IPC-mapped buffers"). The reference has 
 
     ex = PeerExchange(capacity_floats)            # collective: every rank of the node, same capacity
     ex.bucket[:n].copy_(...)                      # the bucket lives in the communication buffer
-    ex.all_reduce(n)                              # stream-ordered: push -> reduce my shard -> wait for all shards
+    ex.all_reduce(n)                              # stream-ordered: push -> wait for my slots -> reduce my shard -> wait for all shards
     ... = ex.bucket[:n]
 
 `PeerExchange.ok` is False when the buffers could not be set up or the self-test against torch.distributed's all-reduce
