@@ -37,6 +37,12 @@ from .fused import FusedTrainStep, _TEMPLATES
 
 MAX_CALLS = _capi.STEP_MAX_BATCHES
 MAX_LANES = 7                              # side streams of the forward-only calls (channel 0 is the caller's stream)
+# A chain launch's workgroups wait (bounded) for prologue workgroups of the SAME launch, which are dispatched ahead of them --
+# per XCD. That is safe while every launch in flight finds its workgroups resident at once: launches of one stream follow
+# each other, but launches on the lanes run side by side, and together they must stay well inside the chip's 256 - 512
+# workgroup slots or they could hold each other's prologue out (seen between two PROCESSES on one GPU).
+# 1 024 graphs = 64 graph blocks per call: at most 7 x ~100 workgroups in flight.
+LANE_MAX_GRAPHS = 1024
 MAX_IDS = _capi.TSORT_MAX_ENTRIES          # looked-up ids of one fused step whose touch plan the step builds itself
 _P, _L, _U = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64
 
@@ -471,6 +477,8 @@ class DropIn(object):
             self._check_mirror()
         B = len(queries)
         ar = self._arena
+        if lanes and B > LANE_MAX_GRAPHS:
+            lanes = ()              # (see LANE_MAX_GRAPHS: this call runs on the caller's stream)
         if ar is not None and lanes:
             lane = lanes[ar.calls % len(lanes)]
             ch = lane.ch

@@ -281,17 +281,20 @@ def test_retained_graphs_copies_and_two_models_in_one_pass():
 
 
 @pytest.mark.parametrize('readout,adaptive,wd', [('mp', True, 0.0), ('mlp', False, 1e-3)])
-def test_forward_only_calls_on_side_streams_change_nothing(readout, adaptive, wd):
+def test_forward_only_calls_on_side_streams_change_nothing(readout, adaptive, wd, monkeypatch):
     """DropIn.set_lanes(n): the forward-only margin_loss calls of a pass on n side streams (their own workspaces, packed
     steps, notification words and XCDs; the caller's stream waits for each before its value is used; the lanes wait for
     the caller's stream once per pass and when a parameter's version moves). Three iterations of the reference loop body
     with an optimiser step in between -- torch.optim.Adam (version counters) and FlatOptimizer (its own epoch) --: every
     loss value and every parameter after the last step equal the one-stream run's bit for bit; so does a no_grad loop that
     drops every value after adding it (the allocator must not hand a value's block to another lane too early)."""
+    from mpqe_amd import dropin as dropin_mod
     from mpqe_amd.data_utils import get_queries_iterator
     from mpqe_amd.optim import FlatOptimizer
     out = {}
     for opt_kind in ('torch', 'flat'):
+        # (second round: calls of more than LANE_MAX_GRAPHS graphs -- here every other batch size -- stay on the caller's stream)
+        monkeypatch.setattr(dropin_mod, 'LANE_MAX_GRAPHS', 1024 if opt_kind == 'torch' else 200)
         for lanes in (0, 3):
             schema, node_maps, model, train_queries = _aifb(readout, adaptive, D=64, per_formula=600, weight_decay=wd)
             model = model.to('cuda:0')
@@ -313,7 +316,10 @@ def test_forward_only_calls_on_side_streams_change_nothing(readout, adaptive, wd
                 tot = torch.zeros((), device='cuda:0')
                 for k in range(40):
                     qt = ('3-inter', '2-chain', '3-chain_inter', '1-chain')[k % 4]
-                    tot = tot + model.margin_loss(*next(iterators[qt]))
+                    batch = next(iterators[qt])
+                    if k % 2:           # (a shorter batch: the same queries without their collated ids)
+                        batch = (batch[0], batch[1][:150])
+                    tot = tot + model.margin_loss(*batch)
             torch.cuda.synchronize()
             d._check_mirror()
             assert len(d.lanes) >= lanes and (lanes == 0 or all(l.pass_id >= 0 for l in d.lanes[:lanes]))
