@@ -358,3 +358,29 @@ def test_bad_entity_id_on_the_training_path_raises_at_the_next_call(lanes):
         v1 = model.margin_loss(*good).item()
     d._check_mirror()
     assert v1 == v0
+
+
+def test_python_autograd_node_fallback_gives_the_same(monkeypatch):
+    """Without csrc/host/autograd_node.cpp built (mpqe_amd/_lib.py: load_autograd_node() -> None) the calls carry a
+    torch.autograd.Function instead of the C++ node: same loss, same gradients (and no side streams: their loss-word pool asks
+    the extension who holds a word)."""
+    from mpqe_amd import _lib
+    from mpqe_amd.data_utils import get_queries_iterator
+    out = {}
+    for impl in ('c++', 'python'):
+        if impl == 'python':
+            monkeypatch.setattr(_lib, 'load_autograd_node', lambda: None)
+        schema, node_maps, model, train_queries = _aifb('mlp', False, D=64, per_formula=400, weight_decay=1e-3)
+        model = model.to('cuda:0')
+        d = model.dropin()
+        assert d.node_impl == impl
+        np.random.seed(2)
+        iterators = {qt: get_queries_iterator(train_queries[qt], 200, model) for qt in train_queries}
+        random.seed(31)
+        loss = _reference_loop_body(model, iterators, train_queries, [])
+        loss.backward()
+        assert (len(d.lanes) > 0) == (impl == 'c++')
+        out[impl] = (loss.item(), {k: _np(p.grad).copy() for k, p in model.named_parameters()})
+    assert out['c++'][0] == out['python'][0]
+    for k in out['c++'][1]:
+        np.testing.assert_array_equal(out['c++'][1][k], out['python'][1][k], err_msg=k)
