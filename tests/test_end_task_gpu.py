@@ -69,3 +69,42 @@ def test_model_trained_through_the_reference_loop_matches_oracle_training():
     assert abs(out['auc_before'] - out['oracle_auc_before']) < 1e-3
     assert abs(out['auc_after'] - out['oracle_auc_after']) < 0.015
     assert out['auc_after'] > out['auc_before'] + 0.03 and out['loss_last20'] < 0.9 * out['loss_first']
+
+
+def test_training_through_the_dropin_is_bit_reproducible():
+    """Two runs of 300 iterations of the reference's loop (collation included, flat Adam) from the same seeds give the same
+    loss values to the last bit -- for the default readout and for one on three side streams --, and no call leaves an
+    error flag behind."""
+    import random
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import dropin_loop_bench as b
+    import torch
+    for readout in ('mp', 'mlp'):
+        runs = []
+        for rep in range(2):
+            model, tq = b.build(readout, per_formula=1024)
+            model = model.to('cuda:0')
+            np.random.seed(0)
+            random.seed(0)
+            live = b._Live(model, tq, 512)
+            opt = b._FlatAdapter(model, 0.001)
+            d = model.dropin()
+            vals = []
+            for i in range(300):
+                opt.zero_grad()
+                loss = None
+                for batch, hard, w in live[0]:
+                    l = model.margin_loss(*batch, hard_negatives=hard)
+                    if loss is None:
+                        loss = l
+                    else:
+                        loss += w * l
+                if i % 10 == 0:
+                    vals.append(loss.item())
+                loss.backward()
+                opt.step()
+            torch.cuda.synchronize()
+            d._check_mirror()
+            assert d.steps == 300 and len(d.lanes) == (3 if readout == 'mlp' else 0)
+            runs.append(vals)
+        assert runs[0] == runs[1] and np.isfinite(runs[0]).all() and runs[0][-1] < 0.8 * runs[0][0], (readout, runs[0][:3], runs[1][:3])
