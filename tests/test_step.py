@@ -688,6 +688,7 @@ def _readout_on_the_chain(be, capfd, readout, D, mix, scatter_op, adaptive, shar
     (nn.Linear stores [out, in]; targetmlp's [D, 2 D] as two column blocks), the bias gradients column sums like the
     layers'. Loss, scores and every gradient against the oracle's whole model; the level form (MPQE_STEP_NO_CHAIN) gives
     the same."""
+    _gpu_only_when_heavy(be, D >= 128 and mix == 'dup')          # (D = 128 on the emulator: the 'tiny' / 'd1' mixes)
     margin = 1.0
     mixes = dict(MIXES, d1=[('1-chain', 20, 1.0), ('2-inter', 37, 0.5)], **EDGE_MIXES)      # (d1: diameter 1)
     schema, mode_ids, rel_ids, params, node_map, cfg, batches = make_problem(31, D, L, shared, mixes[mix], readout, adaptive)
