@@ -133,6 +133,8 @@ class RGCNEncoderDecoder(nn.Module):
         # by foreign encoders, by encode_twice and by configurations the fused step does not cover).
         self.fused = True
         self._dropin_state = None
+        from .optim import register_model
+        register_model(self)            # (mpqe_amd.optim.Adam / SGD find the model of the parameters they are handed)
 
     # ------------------------------------------------------------------ readouts (model.py:380-398)
     def sum_readout(self, embs, batch_idx, batch_size=None, num_nodes=None, **kwargs):
@@ -250,6 +252,11 @@ class RGCNEncoderDecoder(nn.Module):
         state['_dropin_checked'] = False
         state['_err'] = None
         return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        from .optim import register_model
+        register_model(self)
 
     def _apply(self, fn, *args, **kwargs):
         # (.to() / .cuda() / .float(): the parameters move -- the fused step's addresses are taken again at the next call)

@@ -126,3 +126,80 @@ class FlatOptimizer(object):
         if self.opt == 'adam':
             self.exp_avg.copy_(sd['exp_avg'])
             self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# torch.optim's constructors, as the reference's training script calls them (train.py:83-88):
+#     optimizer = optim.SGD([p for p in enc_dec.parameters() if p.requires_grad], lr=args.lr, momentum=0)
+#     optimizer = optim.Adam([p for p in enc_dec.parameters() if p.requires_grad], lr=args.lr)
+# `from mpqe_amd import optim` in place of `from torch import optim` keeps those lines as they are: when the parameters are
+# exactly those of ONE model on the fused step (mpqe_amd/dropin.py) the update is FlatOptimizer's one launch over the flat
+# buffers (and zero_grad() a flag), otherwise the torch optimiser itself.
+import weakref
+
+_OWNERS = weakref.WeakValueDictionary()           # id(parameter) -> its model (mpqe_amd/model.py registers them)
+
+
+def register_model(model):
+    for p in model.parameters():
+        _OWNERS[id(p)] = model
+
+
+class _Switch(object):
+    def __init__(self, kind, params, torch_cls, lr, kwargs):
+        params = list(params)
+        if params and isinstance(params[0], dict):
+            raise ValueError('mpqe_amd.optim.%s takes a flat list of parameters (the reference builds no parameter groups); '
+                             'use torch.optim.%s for groups' % (torch_cls.__name__, torch_cls.__name__))
+        self._impl, self._flat = None, False
+        owners = {id(_OWNERS.get(id(p))) for p in params}
+        model = _OWNERS.get(id(params[0])) if params and len(owners) == 1 else None
+        d = model.dropin() if model is not None and hasattr(model, 'dropin') else None
+        plain = ((kind == 'adam' and not kwargs.get('amsgrad') and not kwargs.get('maximize'))
+                 or (kind == 'sgd' and not kwargs.get('momentum') and not kwargs.get('nesterov') and not kwargs.get('dampening')
+                     and not kwargs.get('maximize')))
+        known = {'betas', 'eps', 'weight_decay', 'momentum', 'nesterov', 'dampening', 'amsgrad', 'maximize'}
+        if (d is not None and plain and set(kwargs) <= known and len(params) == len(d.step.params)
+                and {id(p) for p in params} == {id(p) for p in d.step.params}):
+            self._impl = FlatOptimizer(d.step, lr=lr, opt=kind, betas=kwargs.get('betas', (0.9, 0.999)),
+                                       eps=kwargs.get('eps', 1e-8), weight_decay=kwargs.get('weight_decay', 0.0))
+            self._flat = True
+            self.param_groups = [dict(params=params, lr=lr)]
+        else:
+            self._impl = torch_cls(params, lr=lr, **kwargs)
+            self.param_groups = self._impl.param_groups
+
+    @property
+    def flat(self):
+        """True: one launch over the model's flat buffers; False: the torch optimiser."""
+        return self._flat
+
+    def zero_grad(self, set_to_none=True):
+        self._impl.zero_grad(set_to_none=set_to_none) if not self._flat else self._impl.zero_grad()
+
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError('closures are not supported')
+        if self._flat:
+            self._impl.lr = float(self.param_groups[0]['lr'])        # (a scheduler writes param_groups[0]['lr'])
+        self._impl.step()
+
+    def state_dict(self):
+        return self._impl.state_dict()
+
+    def load_state_dict(self, sd):
+        self._impl.load_state_dict(sd)
+
+
+class Adam(_Switch):
+    """torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0) at the reference's call."""
+
+    def __init__(self, params, lr=1e-3, **kwargs):
+        super(Adam, self).__init__('adam', params, torch.optim.Adam, lr, kwargs)
+
+
+class SGD(_Switch):
+    """torch.optim.SGD(params, lr, momentum=0, weight_decay=0) at the reference's call."""
+
+    def __init__(self, params, lr=1e-3, **kwargs):
+        super(SGD, self).__init__('sgd', params, torch.optim.SGD, lr, kwargs)

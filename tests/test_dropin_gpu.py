@@ -384,3 +384,40 @@ def test_python_autograd_node_fallback_gives_the_same(monkeypatch):
     assert out['c++'][0] == out['python'][0]
     for k in out['c++'][1]:
         np.testing.assert_array_equal(out['c++'][1][k], out['python'][1][k], err_msg=k)
+
+
+def test_torch_optim_shaped_constructors_switch_to_the_flat_update():
+    """`from mpqe_amd import optim` in place of `from torch import optim` (reference train.py:83-88): optim.Adam / optim.SGD
+    over exactly one fused model's parameters are FlatOptimizer's one launch (zero_grad a flag); anything else is the torch
+    optimiser. Three iterations of the reference loop give the parameters torch.optim.Adam gives on the same model."""
+    from mpqe_amd import optim
+    from mpqe_amd.data_utils import get_queries_iterator
+    out = {}
+    for kind in ('ours', 'torch'):
+        schema, node_maps, model, train_queries = _aifb('mp', True, D=64, per_formula=400)
+        model = model.to('cuda:0')
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = optim.Adam(params, lr=0.01) if kind == 'ours' else torch.optim.Adam(params, lr=0.01)
+        if kind == 'ours':
+            assert opt.flat and opt.param_groups[0]['lr'] == 0.01
+        np.random.seed(4)
+        iterators = {qt: get_queries_iterator(train_queries[qt], 128, model) for qt in train_queries}
+        random.seed(8)
+        for it in range(3):
+            opt.zero_grad()
+            loss = _reference_loop_body(model, iterators, train_queries, [])
+            loss.backward()
+            opt.step()
+        out[kind] = {k: _np(p).copy() for k, p in model.named_parameters()}
+    for k in out['ours']:
+        np.testing.assert_allclose(out['ours'][k], out['torch'][k], rtol=2e-5, atol=2e-7, err_msg=k)
+    # not one model's parameters / a model on the module path / options the flat update has not: the torch optimiser
+    schema, node_maps, model, train_queries = _aifb('mp', True, D=64, per_formula=50)
+    model = model.to('cuda:0')
+    params = [p for p in model.parameters() if p.requires_grad]
+    assert not optim.Adam(params[:-1], lr=0.01).flat
+    assert not optim.Adam(params, lr=0.01, amsgrad=True).flat
+    assert not optim.SGD(params, lr=0.1, momentum=0.9).flat
+    assert optim.SGD(params, lr=0.1, momentum=0).flat
+    model.fused = False
+    assert not optim.Adam(params, lr=0.01).flat
