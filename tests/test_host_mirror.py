@@ -320,3 +320,28 @@ def test_queries_iterator_equals_the_dataloader_form():
         assert x[0] == y[0] and x[1] == y[1] and x[4:] == y[4:]
         np.testing.assert_array_equal(x[2], y[2])
         np.testing.assert_array_equal(x[3], y[3])
+
+
+def test_optim_constructors_fall_back_to_torch_off_the_fused_step(enc_case):
+    """mpqe_amd.optim.Adam / SGD (torch.optim's constructors as reference train.py:83-88 calls them): a model that is not on
+    the fused step -- here: on the CPU -- gets the torch optimiser itself, with torch.optim's calls; a deep copy of the model
+    is found as its own parameters' owner."""
+    import copy
+    from mpqe_amd import optim
+    model = build_model(enc_case, 'cpu')
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = optim.Adam(params, lr=0.01)
+    assert not opt.flat and isinstance(opt._impl, torch.optim.Adam) and opt.param_groups[0]['lr'] == 0.01
+    before = params[0].detach().clone()
+    params[0].grad = torch.ones_like(params[0])
+    opt.step()
+    assert not torch.equal(before, params[0].detach())
+    opt.zero_grad()
+    assert params[0].grad is None
+    sd = opt.state_dict()
+    opt.load_state_dict(sd)
+    assert optim._OWNERS.get(id(params[0])) is model
+    twin = copy.deepcopy(model)
+    assert optim._OWNERS.get(id(next(twin.parameters()))) is twin
+    with pytest.raises(ValueError):
+        optim.SGD([dict(params=params)], lr=0.1)
