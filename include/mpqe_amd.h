@@ -497,6 +497,12 @@ int mpqe_step_forward_backward(const mpqe_step_params_t *params_host, const mpqe
  *                    b of a launch runs on XCD b % 8). Forward-only steps of SEVERAL packed steps issued on different streams
  *                    at once (each with a workspace of its own) then run side by side instead of sharing the CUs of XCD 0.
  *                    Results do not depend on it.
+ *   readout_norms    a DEVICE scalar holding sum_i ||readout parameter i||_2 as mpqe_step_readout_norms wrote it, or NULL. A
+ *                    FORWARD-ONLY step in the chain form with a learned readout and readout_weight_decay > 0 then adds the
+ *                    regulariser (model.py:486-490) to loss[0] from it instead of re-forming the four norms in a launch of
+ *                    its own per call: a caller that issues many forward-only calls between two parameter updates (the
+ *                    reference's loop: eleven margin_loss calls per optimiser step) computes them once. The caller answers
+ *                    for the scalar being current. Same arithmetic, same value.
  *   join_event,      join_event != NULL (a hipEvent_t; join_stream a hipStream_t, NULL = the null stream): behind the call's
  *   join_stream      last launch the library records join_event on `stream` and makes join_stream wait for it -- the call ran
  *                    on a side stream, its consumer is enqueued on join_stream. (The other direction -- `stream` waiting for
@@ -509,7 +515,11 @@ typedef struct {
     int32_t xcd_shift;
     void *join_event;
     void *join_stream;
+    const float *readout_norms;
 } mpqe_step_extra_t;
+/* out[0] = sum_i ||p_i||_2 over the learned readout's four parameters (readout_w0, readout_b0, readout_w2, readout_b2 of
+ * params_host; reference model.py:486-490), in the order and arithmetic of the step's own regulariser launch. One launch. */
+int mpqe_step_readout_norms(const mpqe_step_params_t *params_host, float *out, void *stream);
 int mpqe_step_forward_backward_ex(const mpqe_step_params_t *params_host, const mpqe_step_batch_t *batches_host,
                                   int num_batches, const int64_t *anchor_ids, const int64_t *targets,
                                   const int64_t *negs, float margin, const mpqe_step_grads_t *grads_host,

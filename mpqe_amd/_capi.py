@@ -58,7 +58,8 @@ STEP_MAX_LANES = 4
 class StepExtra(ctypes.Structure):
     # include/mpqe_amd.h: mpqe_step_extra_t
     _fields_ = [('batch_weight', c_void_p * STEP_MAX_BATCHES), ('query_out', c_void_p), ('notify', c_void_p),
-                ('notify_value', ctypes.c_uint32), ('xcd_shift', ctypes.c_int32), ('join_event', c_void_p), ('join_stream', c_void_p)]
+                ('notify_value', ctypes.c_uint32), ('xcd_shift', ctypes.c_int32), ('join_event', c_void_p), ('join_stream', c_void_p),
+                ('readout_norms', c_void_p)]
 
 
 class StepLanes(ctypes.Structure):
@@ -125,6 +126,7 @@ PROTOTYPES = {
     'mpqe_step_forward_backward_ex': (I, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I, P, P, P, F,
                                           ctypes.POINTER(StepGrads), I, P, P, P, P, Z, I, P, Z, P, ctypes.POINTER(StepLanes),
                                           P, I, P, P, ctypes.POINTER(StepExtra)]),
+    'mpqe_step_readout_norms': (I, [ctypes.POINTER(StepParams), P, P]),
     'mpqe_host_random_choice': (I, [P, L, P, L, P, P, L, P, P]),
     'mpqe_step_touch_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I]),
     'mpqe_step_touch_workspace_bytes': (Z, [ctypes.POINTER(StepParams), ctypes.POINTER(StepBatch), I]),

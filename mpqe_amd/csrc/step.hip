@@ -331,6 +331,8 @@ struct FinArgs {
     unsigned *notify;
     unsigned notify_value;
     const int32_t *err;
+    const float *reg_norms;   // != NULL: loss[0] += reg_coef * *reg_norms (mpqe_step_extra_t.readout_norms: the readout's regulariser)
+    float reg_coef;
     LossMeta lm;
 };
 __device__ __forceinline__ void chain_finish(const FinArgs &fin, float *smem) {
@@ -361,6 +363,8 @@ __device__ __forceinline__ void chain_finish(const FinArgs &fin, float *smem) {
     if (threadIdx.x == 0) {
         float total = 0.f;
         for (int bi = 0; bi < lm.nb; ++bi) total += lm.weight[bi] * mean[bi];
+        // (step_ro_reg_kernel's `loss[0] = fma(coef, sum of the norms, loss[0])`, with the norms of mpqe_step_readout_norms)
+        if (fin.reg_norms) total = __builtin_fmaf(fin.reg_coef, *fin.reg_norms, total);
         fin.loss[0] = total;
         agent_store(fin.count, 0u);
         // (the next step's forward granules get a new tag, step_uniform.h; the transposed copies' count a new target)
@@ -1307,6 +1311,11 @@ extern "C" int mpqe_l2_norms(const float *const *params, const int64_t *sizes, i
 }
 
 static int D_ok_for_readout(int D) { return D % 4 == 0; }      // (16-byte rows in step_readout.h)
+// input width of the learned readout's first Linear layer (reference model.py:497-553: targetmlp [target | node], concat one
+// block per layer)
+static int readout_kin(const mpqe_step_params_t *P) {
+    return P->readout == MPQE_READOUT_TARGETMLP ? 2 * P->dim : (P->readout == MPQE_READOUT_CONCAT ? P->num_layers * P->dim : P->dim);
+}
 
 // batch weights of a call with extras: sd->b[i].weight = host weight x *device scalar (one workgroup, in front of the step's
 // launches on its stream; wdev[i] NULL: the host weight alone -- which is also how a later call without extras restores them)
@@ -1318,6 +1327,23 @@ struct WeightPatch {
 __global__ __launch_bounds__(64) void step_weights_kernel(StepDev *sd, WeightPatch wp) {
     const int i = threadIdx.x;
     if (i < wp.nb) sd->b[i].weight = wp.wdev[i] ? wp.whost[i] * *wp.wdev[i] : wp.whost[i];
+}
+
+extern "C" int mpqe_step_readout_norms(const mpqe_step_params_t *P, float *out, void *stream) {
+    if (!P || !out || P->readout < MPQE_READOUT_MLP) return MPQE_ERR_INVALID_ARG;
+    if (!P->readout_w0 || !P->readout_b0 || !P->readout_w2 || !P->readout_b2 || P->dim <= 0) return MPQE_ERR_INVALID_ARG;
+    const int D = P->dim, kin = D_ok_for_readout(D) ? readout_kin(P) : 0;
+    if (kin <= 0) return MPQE_ERR_UNSUPPORTED;
+    RoRegArgs rr;
+    memset(&rr, 0, sizeof(rr));
+    rr.p[0] = P->readout_w0; rr.p[1] = P->readout_b0; rr.p[2] = P->readout_w2; rr.p[3] = P->readout_b2;
+    rr.n[0] = (long long)D * kin; rr.n[1] = D; rr.n[2] = (long long)D * D; rr.n[3] = D;
+    rr.coef = 1.f;                       // (out = fma(1, sum of the norms, 0): the sum itself)
+    rr.loss = out;
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(out, 0, sizeof(float), s) != hipSuccess) return MPQE_ERR_LAUNCH;
+    hipLaunchKernelGGL(step_ro_reg_kernel, dim3(1), dim3(1024), 0, s, rr);
+    return mpqe_launch_status();
 }
 
 extern "C" int mpqe_step_forward_backward(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int nb,
@@ -1979,7 +2005,7 @@ static int step_ex(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int 
         }
         hipLaunchKernelGGL(step_ro_reg_kernel, dim3(1), dim3(1024), 0, s, rr);
     };
-    bool loss_in_chain = false;
+    bool loss_in_chain = false, reg_in_chain = false;
     if (use_chain) {
         // assemble -> levels -> scores (-> levels back -> anchor-table gradients): one launch per lane
         ChainArgs ca;
@@ -2102,6 +2128,13 @@ static int step_ex(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int 
                 fin.err = err;
                 fin.lm = lm;
                 loss_in_chain = true;
+                if (learned && extra && extra->readout_norms && P->readout_weight_decay > 0.f) {
+                    float wsum = 0.f;
+                    for (int i = 0; i < nb; ++i) wsum += hp.sd.b[i].weight;
+                    fin.reg_norms = extra->readout_norms;
+                    fin.reg_coef = P->readout_weight_decay * wsum;
+                    reg_in_chain = true;
+                }
             }
             mark(s);
 #define LAUNCH_CHAIN(THREADS, ...)                                                                                       \
@@ -2134,7 +2167,7 @@ static int step_ex(const mpqe_step_params_t *P, const mpqe_step_batch_t *B, int 
                 hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, s, sd, (const float *)terms, loss, lm, bterms,
                                    use_chain ? epoch_f : (unsigned *)nullptr, pa.tblocks > 0 ? 1 : 0, notify, notify_value,
                                    (const int32_t *)err);
-            if (learned) ro_regulariser(false);
+            if (learned && !reg_in_chain) ro_regulariser(false);
             return mpqe_launch_status();
         }
         // (a side stream for the post-pass / table rows beside the tiles was measured: the cross-stream fork and join

@@ -152,5 +152,5 @@ __global__ __launch_bounds__(1024) void step_ro_reg_kernel(RoRegArgs a) {
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0 && a.loss) *a.loss += a.coef * sum_norms;
+    if (threadIdx.x == 0 && a.loss) *a.loss = __builtin_fmaf(a.coef, sum_norms, *a.loss);
 }

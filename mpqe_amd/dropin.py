@@ -188,6 +188,11 @@ class DropIn(object):
         self.fast_sampled = 0      # calls whose negatives were drawn by the library replay of python's stream
         # forward-only calls on side streams (_Lane): where a call's device time exceeds the host's pace -- the learned
         # readouts (every node of every graph through two more layers, no liveness pruning); set_lanes(n) overrides
+        # a learned readout's regulariser (model.py:486-490): the four norms once per parameter version, not once per call
+        # (mpqe_step_extra_t.readout_norms / mpqe_step_readout_norms; a forward-only call then has no launch for it)
+        self._reg = (torch.zeros(1, dtype=torch.float32, device=self.device)
+                     if self.step.learned and self.step.P.readout_weight_decay > 0 else None)
+        self._reg_ver = None
         self.lanes = []
         self._want_lanes = 3 if self.step.learned else 0       # (the runtime gives a process four hardware queues: the null stream's and three more)
         self._pass_id = 0
@@ -229,6 +234,8 @@ class DropIn(object):
         r.fb = batches[0]                       # (a one-batch record's (formula, batch size))
         self._nrec = r.rid = getattr(self, '_nrec', 0) + 1
         r.extra = _capi.StepExtra()
+        if self._reg is not None:
+            r.extra.readout_norms = self._reg.data_ptr()
         c = r.call = StepCall()
         c.params, c.grads = ctypes.addressof(step.P), ctypes.addressof(step.G)
         c.batches, c.num_batches = ctypes.addressof(ps.batches), ps.nb
@@ -491,6 +498,15 @@ class DropIn(object):
         step = self.step
         step.margin = margin = float(margin)
         idx = ar.calls
+        ver = self._param_version() if (lane is not None or self._reg is not None) else 0
+        if self._reg is not None and ver != self._reg_ver:
+            # (on the caller's stream, in front of the lanes' wait for it below)
+            with torch.cuda.device(self.device):
+                st = self.lib.mpqe_step_readout_norms(ctypes.byref(step.P), self._reg.data_ptr(),
+                                                      torch._C._cuda_getCurrentRawStream(self.dev_index))
+            if st != 0:
+                _capi.check(self.lib, st, 'mpqe_step_readout_norms')
+            self._reg_ver = ver
         # (a buffer of its own per call: a caller may keep the value -- `loss.detach()` for a log -- beyond its graph)
         if lane is None:
             cur_raw = torch._C._cuda_getCurrentRawStream(self.dev_index)
@@ -500,7 +516,6 @@ class DropIn(object):
             cur_raw = cur.cuda_stream
             # the lane waits for the caller's stream where the parameters may have been written since it last did: once per
             # backward pass, and whenever a parameter's version has moved
-            ver = self._param_version()
             if lane.pass_id != self._pass_id or lane.ver != ver:
                 # (EVERY lane at once: a lane that waited only at its own first call of the pass would find the caller's
                 # stream already waiting for the calls before it, and the pass' first calls would run one after the other)

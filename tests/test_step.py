@@ -86,7 +86,7 @@ def oracle_step(params, cfg, node_map, batches, margin):
 
 def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=1, lanes=None, flags=0, touch='step', repeat=1,
              plan_out=None, between=None, recover=False, before_recovery=None, dev_weights=False, query_out=None,
-             then_plain=False, xcd_shift=0):
+             then_plain=False, xcd_shift=0, readout_norms=False):
     """between: the step in three calls around the CALLER's readout (MPQE_READOUT_CALLER, MPQE_STEP_PHASE_*): a generator
     function -- between(final_states) yields the query embeddings [graphs, D], is sent their gradients and yields d loss /
     d final states per batch; final_states[i]: batch i's [B N, D]. touch: 'step' = the step builds the touch plan of its ids itself (MPQE_STEP_BUILD_TOUCH, the product's default),
@@ -256,7 +256,7 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
         call(_capi.STEP_PHASE_FROM_STATES, 0)
         P.flags &= ~_capi.STEP_ADD_STATE_GRADS
     extra = None
-    if dev_weights or query_out is not None or xcd_shift:
+    if dev_weights or query_out is not None or xcd_shift or readout_norms:
         # include/mpqe_amd.h: mpqe_step_extra_t -- batch weights as DEVICE scalars (host weight 2 x device weight w / 2 = w:
         # the same step), the query embeddings out
         extra = _capi.StepExtra()
@@ -271,6 +271,11 @@ def run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backw
         note = be.zeros((2,), np.int32)        # (mpqe_step_extra_t.notify: the call's number + the error word, by its last launch)
         extra.notify, extra.notify_value = be.ptr(note), 4711
         extra.xcd_shift = xcd_shift
+        if readout_norms:       # (mpqe_step_extra_t.readout_norms: the regulariser's four norms formed once, ahead of the calls)
+            dnorm = be.zeros((1,), np.float32)
+            keep.append(dnorm)
+            be.check(be.lib.mpqe_step_readout_norms(ctypes.byref(P), be.ptr(dnorm), be.stream), 'readout norms')
+            extra.readout_norms = be.ptr(dnorm)
     kinds = list(backward) if isinstance(backward, (list, tuple)) else [backward] * repeat      # (a list: one call of each kind, in order)
     repeat = len(kinds)
     for rep in range(0 if between is not None else repeat):       # (repeat > 1: the same packed step again -- its hand-off epochs / counters carry on)
@@ -748,6 +753,12 @@ def _readout_on_the_chain(be, capfd, readout, D, mix, scatter_op, adaptive, shar
     np.testing.assert_allclose(loss[0], total.item(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(sp, np.concatenate(sp_ref), rtol=1e-5, atol=1e-6)
     assert err == 0 and all(not g.any() for g in grads.values())
+    # the regulariser from norms formed once (mpqe_step_readout_norms) instead of a launch per forward-only call: the same bits
+    lossn, spn, snn, _g, errn = run_step(be, schema, mode_ids, params, node_map, cfg, batches, margin, backward=0, repeat=2,
+                                         readout_norms=True)
+    assert errn == 0
+    np.testing.assert_array_equal(lossn, loss)
+    np.testing.assert_array_equal(spn, sp)
     # forward-only and whole steps on ONE packed step, in turn: a forward-only call makes only the transposed copies its
     # readout's forward multiplies by, and counts the others' workgroups in (the chain workgroups' wait target advances alike
     # in every launch); mpqe_debug_option FWD_ALL_COPIES = 1: every copy, as until round 5
