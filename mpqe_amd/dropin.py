@@ -108,9 +108,14 @@ class _Lane(object):
     __slots__ = ('ch', 'stream', 'raw', 'event', 'event_raw', 'fork', 'ws', 'note_ptr', 'shift', 'pass_id', 'ver', 'epoch',
                  'slots', 'next')
 
+    _streams = {}          # (device index, channel) -> stream: one set per process, whatever the number of models
+
     def __init__(self, ch, device, note_ptr):
         self.ch = ch
-        self.stream = torch.cuda.Stream(device=device)
+        key = (device.index, ch)
+        if key not in _Lane._streams:
+            _Lane._streams[key] = torch.cuda.Stream(device=device)
+        self.stream = _Lane._streams[key]
         self.raw = self.stream.cuda_stream
         self.event = torch.cuda.Event()
         self.event.record(self.stream)              # (creates the handle)
