@@ -21,6 +21,11 @@ Host side: per margin_loss call one numpy copy per id array, one call into the C
 (csrc/host/pyhost.c: python's generator, the library's replay of random.choice) and one for the library call (its 24
 arguments live in a block that is rewritten in the few fields that change), then torch's Function bookkeeping.
 
+Between two calls the drop-in notices that parameters were written by their autograd version counters (torch's optimisers,
+load_state_dict, any in-place op on the Parameter) and by FlatOptimizer's own epoch; that is when the side streams wait for
+the caller's stream again and a learned readout's regulariser norms are formed again. Writes THROUGH `p.data` bypass the
+counters: call `model.dropin().params_changed()` after them.
+
 Gradients reach the parameters through `p.grad` only (torch.autograd.grad over a drop-in loss sees no inputs);
 `model.fused = False` restores the per-op module path, which is also what foreign encoders and forward() with autograd
 take.
@@ -299,6 +304,10 @@ class DropIn(object):
         self._fork(lane, cur)                 # (the block's earlier life on the caller's stream is in front of the lane now)
         slots.append([t, lane.epoch])
         return t
+
+    def params_changed(self):
+        """Tell the drop-in that parameters were written behind the version counters (through `p.data`)."""
+        self.step.param_epoch += 1
 
     def _param_version(self):
         """Changes whenever a parameter is written in place (torch's optimisers, load_state_dict) or by FlatOptimizer."""
