@@ -421,3 +421,36 @@ def test_torch_optim_shaped_constructors_switch_to_the_flat_update():
     assert optim.SGD(params, lr=0.1, momentum=0).flat
     model.fused = False
     assert not optim.Adam(params, lr=0.01).flat
+
+
+@pytest.mark.parametrize('readout,adaptive,wd', [('mp', True, 0.0), ('mlp', False, 1e-3), ('max', False, 0.0)])
+def test_ragged_batch_sizes_fused_against_module_path(readout, adaptive, wd):
+    """Every query type at batch sizes around the 16-graph block (1, 15, 16, 17, 33, 129), with and without hard negatives,
+    margins 1 and 0.3: the drop-in's loss and every parameter gradient against the per-op module path on the same draws."""
+    schema, node_maps, model, train_queries = _aifb(readout, adaptive, D=64, n_formulas=1, per_formula=140, weight_decay=wd)
+    model = model.to('cuda:0')
+    cases = []
+    for qt, by_formula in train_queries.items():
+        formula, queries = next(iter(by_formula.items()))
+        for B in (1, 15, 16, 17, 33, 129):
+            cases.append((formula, queries[:B], 'inter' in qt and B % 2 == 1, 1 if B != 17 else 0.3))
+    out = {}
+    for fused in (True, False):
+        model.fused = fused
+        res = []
+        random.seed(11)
+        for formula, queries, hard, margin in cases:
+            for p in model.parameters():
+                p.grad = None
+            loss = model.margin_loss(formula, queries, hard_negatives=hard, margin=margin)
+            loss.backward()
+            res.append((loss.item(), {k: (np.zeros(tuple(p.shape), np.float32) if p.grad is None else _np(p.grad).copy())
+                                      for k, p in model.named_parameters()}))
+        out[fused] = res
+    if model.dropin() is not None:
+        model.dropin()._check_mirror()
+    for i, ((lf, gf), (lm, gm)) in enumerate(zip(out[True], out[False])):
+        np.testing.assert_allclose(lf, lm, rtol=1e-5, atol=1e-6, err_msg='case %d' % i)
+        for k in gf:
+            np.testing.assert_allclose(gf[k], gm[k], err_msg='case %d (%s, B=%d) %s' % (i, cases[i][0].query_type, len(cases[i][1]), k),
+                                       **BWD)
