@@ -454,3 +454,36 @@ def test_ragged_batch_sizes_fused_against_module_path(readout, adaptive, wd):
         for k in gf:
             np.testing.assert_allclose(gf[k], gm[k], err_msg='case %d (%s, B=%d) %s' % (i, cases[i][0].query_type, len(cases[i][1]), k),
                                        **BWD)
+
+
+@pytest.mark.parametrize('readout,adaptive,wd', [('mp', True, 0.0), ('mlp', False, 1e-3)])
+def test_training_inside_a_callers_stream(readout, adaptive, wd):
+    """The caller's CURRENT stream is where the calls, the pass' fused step and the lanes' joins go: two iterations of the loop
+    inside `with torch.cuda.stream(s)` give the default stream's losses and parameters bit for bit."""
+    from mpqe_amd.data_utils import get_queries_iterator
+    from mpqe_amd.optim import FlatOptimizer
+    out = {}
+    for where in ('default', 'side'):
+        schema, node_maps, model, train_queries = _aifb(readout, adaptive, D=64, per_formula=300, weight_decay=wd)
+        model = model.to('cuda:0')
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream() if where == 'side' else torch.cuda.current_stream()
+        with torch.cuda.stream(s):
+            opt = FlatOptimizer(model.dropin().step, lr=0.01, opt='adam')
+            np.random.seed(6)
+            iterators = {qt: get_queries_iterator(train_queries[qt], 128, model) for qt in train_queries}
+            random.seed(21)
+            values = []
+            for it in range(2):
+                opt.zero_grad()
+                loss = _reference_loop_body(model, iterators, train_queries, [])
+                values.append(loss.item())
+                loss.backward()
+                opt.step()
+            s.synchronize()
+        torch.cuda.synchronize()
+        model.dropin()._check_mirror()
+        out[where] = (values, {k: _np(p).copy() for k, p in model.named_parameters()})
+    assert out['default'][0] == out['side'][0]
+    for k in out['default'][1]:
+        np.testing.assert_array_equal(out['default'][1][k], out['side'][1][k], err_msg=k)
