@@ -81,6 +81,8 @@ class _Arena(object):
 
     def reset(self):
         self.na = self.ng = self.calls = 0
+        for ch in range(len(self.last)):       # (taken again only once every channel's last reader has reported)
+            self.last[ch] = None
         self.live = 0              # autograd nodes that may still run their backward over these ids
 
     def fits(self, a, g):
