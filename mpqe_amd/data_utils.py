@@ -184,7 +184,8 @@ class QueryDataset(Dataset):
         w = self.__dict__.get('_pick_tables')
         if w is None:       # (the same probability vector the reference builds per batch, built once)
             counts = np.array(list(self.num_formula_queries.values()))
-            w = self.__dict__['_pick_tables'] = (counts / float(self.num_queries), list(self.num_formula_queries.keys()))
+            formulas = list(self.num_formula_queries.keys())
+            w = self.__dict__['_pick_tables'] = (counts / float(self.num_queries), formulas, [None] * len(formulas))
         pick = np.argmax(np.random.multinomial(1, w[0]))
         formula = w[1][pick]
         n = self.num_formula_queries[formula]
@@ -212,7 +213,6 @@ class RGCNQueryDataset(QueryDataset):
         self.rel_ids = enc_dec.rel_ids
 
         self._formula_ids = {}
-        self._templates = {}
 
     def formula_ids(self, formula):
         fi = self._formula_ids.get(formula)
@@ -224,23 +224,43 @@ class RGCNQueryDataset(QueryDataset):
         """reference: data_utils.py:369-375. Same draws (one np.random.multinomial per batch), same window, same return
         values; the ids of the window come from the formula's arrays (FormulaIds, built on the formula's first batch)
         instead of per-query python loops, and ride along on the graph object so that margin_loss need not walk the
-        Query objects again (mpqe_amd/dropin.py)."""
-        formula, start, end = self._window(idx_list)
-        queries = self.queries[formula][start:end]
+        Query objects again (mpqe_amd/dropin.py). Everything that depends on the formula alone sits in one record per
+        formula, found by the multinomial draw's index (no hashing of Formula objects on the way)."""
+        tabs = self.__dict__.get('_pick_tables')
+        if tabs is None:
+            tabs = self._tables()
+        pick = int(np.random.multinomial(1, tabs[0]).argmax())
+        rec = tabs[2][pick]
+        if rec is None:
+            rec = tabs[2][pick] = self._formula_record(tabs[1][pick])
+        formula, n, all_queries, fi, var_ids, edge_type, templates = rec
+        lo, hi = idx_list[0], idx_list[-1]
+        start = lo % n
+        end = min((hi + 1) % n, n)
+        if end <= start:
+            end = n
+        tmpl = templates.get(end - start)
+        if tmpl is None:        # (immutable: one per formula and batch size)
+            tmpl = templates[end - start] = ops.Template(formula.query_type, end - start, edge_type)
+        graph = QueryGraphBatch(tmpl)
+        anchor_ids = torch.from_numpy(fi.anchors[start:end])
+        graph.ids = BatchIds(fi, start, end, anchor_ids)
+        return formula, all_queries[start:end], anchor_ids, torch.from_numpy(var_ids.copy()), graph
+
+    def _tables(self):
+        counts = np.array(list(self.num_formula_queries.values()))
+        formulas = list(self.num_formula_queries.keys())
+        tabs = self.__dict__['_pick_tables'] = (counts / float(self.num_queries), formulas, [None] * len(formulas))
+        return tabs
+
+    def _formula_record(self, formula):
         fi = self.formula_ids(formula)
         info = ops.template_info(formula.query_type)
         if fi.A != info.num_anchors or info.num_anchors != len(formula.anchor_modes):
             raise ValueError('formula %s has %d anchor modes, template expects %d'
                              % (formula, len(formula.anchor_modes), info.num_anchors))
         var_ids, edge_type = self._formula_consts(formula, info)
-        tk = (formula, end - start)
-        tmpl = self._templates.get(tk)
-        if tmpl is None:        # (immutable: one per formula and batch size)
-            tmpl = self._templates[tk] = ops.Template(formula.query_type, end - start, edge_type)
-        graph = QueryGraphBatch(tmpl)
-        anchor_ids = torch.from_numpy(fi.anchors[start:end])
-        graph.ids = BatchIds(fi, start, end, anchor_ids)
-        return formula, queries, anchor_ids, torch.from_numpy(var_ids.copy()), graph
+        return (formula, self.num_formula_queries[formula], self.queries[formula], fi, var_ids, edge_type, {})
 
     def _formula_consts(self, formula, info):
         c = getattr(self, '_consts', None)
